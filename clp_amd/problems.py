@@ -1,0 +1,256 @@
+"""LP instance generators for the parity tests and the bench.
+
+* ``dense_lp`` / ``sparse_lp`` / ``netlib_shaped_lp``: the synthetic north-star workloads
+  (BASELINE.json configs 3-5).  Feasible and bounded by construction, and the all-slack basis with
+  every structural at its lower bound is dual feasible (costs >= 0), so the dual simplex iterates
+  from iteration 0 with no fake bounds.
+* ``nqueens`` / ``tsp_mtz`` / ``ufl`` / ``infeasible``: restatements of the programmatic generators
+  in the reference's test/test_racing_lp.cpp (:123 N-Queens, :199 TSP-MTZ, :277 infeasible,
+  :326 UFL), whose optimal LP bounds are tabulated in test/test_racing_reference.txt:9-39.  They use
+  glibc ``srand/rand`` exactly like the reference, through ctypes.
+"""
+from __future__ import annotations
+
+import ctypes
+import ctypes.util
+
+import numpy as np
+
+from .mps import INF, LpData
+
+
+def _from_coo(m, n, rows, cols, vals, col_lower, col_upper, obj, row_lower, row_upper, name=""):
+    rows = np.asarray(rows, dtype=np.int64)
+    cols = np.asarray(cols, dtype=np.int64)
+    vals = np.asarray(vals, dtype=np.float64)
+    order = np.lexsort((rows, cols))
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    col_start = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(col_start, cols + 1, 1)
+    col_start = np.cumsum(col_start)
+    return LpData(name=name, m=int(m), n=int(n), col_start=col_start.astype(np.int32), row=rows.astype(np.int32),
+                  elem=vals, col_lower=np.asarray(col_lower, dtype=np.float64),
+                  col_upper=np.asarray(col_upper, dtype=np.float64), obj=np.asarray(obj, dtype=np.float64),
+                  row_lower=np.asarray(row_lower, dtype=np.float64), row_upper=np.asarray(row_upper, dtype=np.float64),
+                  obj_offset=0.0)
+
+
+def _from_rows(n, row_list, col_lower, col_upper, obj, row_lower, row_upper, name=""):
+    rows, cols, vals = [], [], []
+    for i, r in enumerate(row_list):
+        for j, v in r:
+            rows.append(i)
+            cols.append(j)
+            vals.append(v)
+    return _from_coo(len(row_list), n, rows, cols, vals, col_lower, col_upper, obj, row_lower, row_upper, name)
+
+
+# ------------------------------------------------------------------------------------------------
+# north-star synthetic workloads
+# ------------------------------------------------------------------------------------------------
+def _finish_feasible(rng, A_csc_parts, m, n, xmax, name):
+    col_start, row, elem = A_csc_parts
+    xstar = rng.uniform(0.0, xmax, n)
+    r = np.zeros(m)
+    counts = np.diff(col_start)
+    np.add.at(r, row, elem * np.repeat(xstar, counts))
+    row_lower = r - rng.uniform(0.0, 1.0, m)
+    row_upper = r + rng.uniform(0.0, 1.0, m)
+    obj = rng.uniform(0.1, 1.0, n)
+    return LpData(name=name, m=int(m), n=int(n), col_start=col_start.astype(np.int32), row=row.astype(np.int32),
+                  elem=elem.astype(np.float64), col_lower=np.zeros(n), col_upper=np.full(n, float(xmax)), obj=obj,
+                  row_lower=row_lower, row_upper=row_upper, obj_offset=0.0)
+
+
+def dense_lp(m=5000, n=5000, seed=20260925):
+    """BASELINE config 3: every entry of A nonzero, A_ij ~ U(-1,1), 0 <= x <= 10."""
+    rng = np.random.default_rng(seed)
+    elem = rng.uniform(-1.0, 1.0, size=m * n)
+    col_start = np.arange(n + 1, dtype=np.int64) * m
+    row = np.tile(np.arange(m, dtype=np.int32), n)
+    return _finish_feasible(rng, (col_start, row, elem), m, n, 10.0, f"dense{m}x{n}")
+
+
+def sparse_lp(m=50000, n=200000, mean_nnz_per_col=50, seed=20260926):
+    """BASELINE config 4: each column draws k = 1 + Poisson(mean-1) distinct rows, values U(-1,1)
+    pushed away from zero to |v| >= 0.05, 0 <= x <= 100."""
+    rng = np.random.default_rng(seed)
+    k = 1 + rng.poisson(max(mean_nnz_per_col - 1, 0), size=n)
+    k = np.minimum(k, m)
+    col_start = np.zeros(n + 1, dtype=np.int64)
+    col_start[1:] = np.cumsum(k)
+    nnz = int(col_start[-1])
+    # distinct rows per column: sample with replacement then repair duplicates column by column
+    row = rng.integers(0, m, size=nnz, dtype=np.int64)
+    col_of = np.repeat(np.arange(n, dtype=np.int64), k)
+    key = col_of * m + row
+    while True:
+        order = np.argsort(key, kind="stable")
+        sk = key[order]
+        dup = np.zeros(nnz, dtype=bool)
+        dup[order[1:]] = sk[1:] == sk[:-1]
+        nd = int(dup.sum())
+        if nd == 0:
+            break
+        row[dup] = rng.integers(0, m, size=nd, dtype=np.int64)
+        key = col_of * m + row
+    order = np.argsort(key, kind="stable")
+    row = row[order]
+    elem = rng.uniform(-1.0, 1.0, size=nnz)
+    small = np.abs(elem) < 0.05
+    elem[small] = np.where(elem[small] < 0, -0.05, 0.05)
+    return _finish_feasible(rng, (col_start, row, elem), m, n, 100.0, f"sparse{m}x{n}")
+
+
+def netlib_shaped_lp(m=50000, n=200000, target_nnz=10_000_000, seed=20260927):
+    """Netlib-shaped variant of config 4: power-law column counts, 20% equality rows,
+    10% columns with infinite upper bound, values spanning 1e-3..1e3."""
+    rng = np.random.default_rng(seed)
+    raw = rng.pareto(1.3, size=n) + 1.0
+    k = np.maximum(1, np.minimum((raw * (target_nnz / n) / raw.mean()).astype(np.int64), m // 4))
+    col_start = np.zeros(n + 1, dtype=np.int64)
+    col_start[1:] = np.cumsum(k)
+    nnz = int(col_start[-1])
+    row = rng.integers(0, m, size=nnz, dtype=np.int64)
+    col_of = np.repeat(np.arange(n, dtype=np.int64), k)
+    key = col_of * m + row
+    while True:
+        order = np.argsort(key, kind="stable")
+        sk = key[order]
+        dup = np.zeros(nnz, dtype=bool)
+        dup[order[1:]] = sk[1:] == sk[:-1]
+        nd = int(dup.sum())
+        if nd == 0:
+            break
+        row[dup] = rng.integers(0, m, size=nd, dtype=np.int64)
+        key = col_of * m + row
+    order = np.argsort(key, kind="stable")
+    row = row[order]
+    mag = 10.0 ** rng.uniform(-3.0, 3.0, size=nnz)
+    elem = mag * rng.choice([-1.0, 1.0], size=nnz)
+    lp = _finish_feasible(rng, (col_start, row, elem), m, n, 100.0, f"netlibshaped{m}x{n}")
+    eq = rng.random(m) < 0.2
+    mid = 0.5 * (lp.row_lower + lp.row_upper)
+    lp.row_lower = np.where(eq, mid, lp.row_lower)
+    lp.row_upper = np.where(eq, mid, lp.row_upper)
+    inf_up = rng.random(n) < 0.1
+    lp.col_upper = np.where(inf_up, INF, lp.col_upper)
+    return lp
+
+
+# ------------------------------------------------------------------------------------------------
+# restated generators of test/test_racing_lp.cpp
+# ------------------------------------------------------------------------------------------------
+class _GlibcRand:
+    def __init__(self, seed):
+        self.libc = ctypes.CDLL(ctypes.util.find_library("c") or "libc.so.6")
+        self.libc.srand(ctypes.c_uint(seed))
+
+    def __call__(self):
+        return int(self.libc.rand())
+
+
+def nqueens(n):
+    """test/test_racing_lp.cpp:123-197; optimal objective -n."""
+    ncols = n * n
+    rows, lo, up = [], [], []
+    for i in range(n):
+        rows.append([(i * n + j, 1.0) for j in range(n)])
+        lo.append(1.0)
+        up.append(1.0)
+    for j in range(n):
+        rows.append([(i * n + j, 1.0) for i in range(n)])
+        lo.append(-INF)
+        up.append(1.0)
+    for k in range(-(n - 2), n - 1):
+        r = [(i * n + (i - k), 1.0) for i in range(n) if 0 <= i - k < n]
+        if len(r) > 1:
+            rows.append(r)
+            lo.append(-INF)
+            up.append(1.0)
+    for k in range(1, 2 * n - 2):
+        r = [(i * n + (k - i), 1.0) for i in range(n) if 0 <= k - i < n]
+        if len(r) > 1:
+            rows.append(r)
+            lo.append(-INF)
+            up.append(1.0)
+    return _from_rows(ncols, rows, np.zeros(ncols), np.ones(ncols), -np.ones(ncols), lo, up, f"nqueens{n}")
+
+
+def tsp_mtz(n, seed):
+    """test/test_racing_lp.cpp:199-272; bounds in test/test_racing_reference.txt:9-11."""
+    rnd = _GlibcRand(seed)
+    nX, nU = n * (n - 1), n - 1
+    ncols = nX + nU
+
+    def x(i, j):
+        return i * (n - 1) + (j - 1 if j > i else j)
+
+    obj = np.zeros(ncols)
+    for i in range(n):
+        for j in range(n):
+            if i != j:
+                obj[x(i, j)] = 1.0 + (rnd() % 100)
+    cl = np.zeros(ncols)
+    cu = np.ones(ncols)
+    cl[nX:] = 1.0
+    cu[nX:] = n - 1
+    rows, lo, up = [], [], []
+    for i in range(n):
+        rows.append([(x(i, j), 1.0) for j in range(n) if i != j])
+        lo.append(1.0)
+        up.append(1.0)
+    for j in range(n):
+        rows.append([(x(i, j), 1.0) for i in range(n) if i != j])
+        lo.append(1.0)
+        up.append(1.0)
+    for i in range(1, n):
+        for j in range(1, n):
+            if i != j:
+                rows.append([(nX + i - 1, 1.0), (nX + j - 1, -1.0), (x(i, j), float(n))])
+                lo.append(-INF)
+                up.append(float(n - 1))
+    return _from_rows(ncols, rows, cl, cu, obj, lo, up, f"tspmtz{n}")
+
+
+def ufl(nfac, ncli, seed):
+    """test/test_racing_lp.cpp:326-372; bounds in test/test_racing_reference.txt:26-29."""
+    rnd = _GlibcRand(seed)
+    ncols = nfac + nfac * ncli
+    obj = np.zeros(ncols)
+    for i in range(nfac):
+        obj[i] = 50.0 + (rnd() % 101)
+    for i in range(nfac):
+        for j in range(ncli):
+            obj[nfac + i * ncli + j] = 1.0 + (rnd() % 50)
+    rows, lo, up = [], [], []
+    for j in range(ncli):
+        rows.append([(nfac + i * ncli + j, 1.0) for i in range(nfac)])
+        lo.append(1.0)
+        up.append(1.0)
+    for i in range(nfac):
+        for j in range(ncli):
+            rows.append([(nfac + i * ncli + j, 1.0), (i, -1.0)])
+            lo.append(-INF)
+            up.append(0.0)
+    return _from_rows(ncols, rows, np.zeros(ncols), np.ones(ncols), obj, lo, up, f"ufl{nfac}x{ncli}")
+
+
+def infeasible(n):
+    """test/test_racing_lp.cpp:277-320: sum x = 1 and sum x = 2."""
+    rows = [[(i, 1.0) for i in range(n)], [(i, 1.0) for i in range(n)]]
+    lo, up = [1.0, 2.0], [1.0, 2.0]
+    for i in range(n - 1):
+        rows.append([(i, 1.0), (i + 1, 1.0)])
+        lo.append(-INF)
+        up.append(5.0)
+    return _from_rows(n, rows, np.zeros(n), np.full(n, 10.0), np.ones(n), lo, up, f"infeasible{n}")
+
+
+def unit_test_3x5():
+    """The 3x5 LP of src/unitTest.cpp:1413-1430 (basis {x0,x1,x4} -> x = {20/7, 3, 0, 0, 23/7})."""
+    rows = [0, 2, 0, 1, 2, 0, 1, 2]
+    cols = [0, 0, 1, 1, 1, 2, 3, 4]
+    vals = [7.0, 2.0, -2.0, 1.0, -2.0, 1.0, 1.0, 1.0]
+    return _from_coo(3, 5, rows, cols, vals, np.zeros(5), np.full(5, 100.0), [-4.0, 1.0, 0.0, 0.0, 0.0],
+                     [14.0, 3.0, 3.0], [14.0, 3.0, 3.0], "unittest3x5")

@@ -1,0 +1,2476 @@
+/*
+ * clp_dual_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY; see clp_dual_oracle.h).
+ *
+ * Restates the revised dual simplex of coin-or/Clp for the fast branch "no free / superbasic
+ * nonbasic variables" (moreSpecialOptions_&8, src/ClpSimplexDual.cpp:3685), scaling off,
+ * perturbation off (perturbation_ 102).  Each function cites the reference lines it follows.
+ * Variable order is Clp's: sequences [0,n) structurals, [n,n+m) row slacks, slack column = -e_i
+ * (src/ClpSimplex.cpp:3442-3474).
+ *
+ * Deliberate restrictions (documented in DESIGN.md):
+ *  - factorization = slack singletons (src/CoinAbcBaseFactorization1.cpp:2589 pivotColumnSingleton)
+ *    followed by the dense LU with partial pivoting of CoinAbcDenseFactorization::factor on the
+ *    remaining nucleus, product-form eta updates (replaceColumnPart3).  Because a slack column -e_i
+ *    has a single entry, doing the slacks first leaves the other columns untouched, so this is
+ *    arithmetically the dense factorization of the whole basis with the zero work skipped.
+ *  - cycle detection (ClpSimplexProgress::cycle) and the "objective going backwards" restore logic
+ *    of statusOfProblemInDual (:5331-5480) are not restated.
+ *  - nonbasic free columns are given "bothFake" bounds at start (the reference keeps them isFree and
+ *    uses the general branch of dualColumn0).
+ *  - CoinThreadRandom lives in CoinUtils (absent); the 32-bit LCG form is used [unverifiable here].
+ *
+ * Build: gcc -O2 -ffp-contract=off (no FMA contraction, so the arithmetic order is the source order).
+ */
+#include "clp_dual_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+/* ClpSimplex::Status, src/ClpSimplex.hpp:119-126 */
+enum { ST_FREE = 0, ST_BASIC = 1, ST_UPPER = 2, ST_LOWER = 3, ST_SUPER = 4, ST_FIXED = 5 };
+/* ClpSimplexDual::FakeBound, src/ClpSimplexDual.hpp (bits 3-4 of status_) */
+enum { FAKE_NONE = 0, FAKE_LOWER = 1, FAKE_UPPER = 2, FAKE_BOTH = 3 };
+#define FLAGGED_BIT 64
+#define REALLY_TINY 1.0e-100 /* COIN_INDEXED_REALLY_TINY_ELEMENT [CoinUtils; from memory] */
+#define DEVEX_TRY_NORM 1.0e-4 /* src/ClpSimplex.hpp:2056 */
+
+typedef struct {
+  int k;        /* nucleus size = number of basic structurals */
+  int *kcol;    /* [k] structural sequence of nucleus column c */
+  int *krow;    /* [k] original row pivoted at elimination step c (== basis position of kcol[c]) */
+  int *rowToK;  /* [m] -1 when the row's slack is basic, else elimination step of that row */
+  double *lu;   /* k*k column-major in pivoted row order: multipliers below the diagonal,
+                   U on/above it, diagonal stored inverted (CoinAbcDenseFactorization.cpp:281) */
+  int luCap;
+  double *t;    /* [m] scratch */
+  /* product-form eta file (replaceColumnPart3 :480); stored sparse, arithmetic as dense */
+  int nEta, maxEta;
+  int *etaPivot;
+  double *etaPivotValue; /* 1/alpha */
+  int *etaStart;         /* [maxEta+1] */
+  int *etaIndex;
+  double *etaValue;
+  long etaCap;
+} Factor;
+
+struct OrcModel {
+  int m, n;
+  int *colStart, *row;
+  double *elem;
+  double *colLower, *colUpper, *obj, *rowLower, *rowUpper;
+  /* rim arrays [columns | rows], src/ClpSimplex.hpp:1864-1922 */
+  double *lower, *upper, *cost, *dj, *sol;
+  unsigned char *status;
+  int *pivotVariable;
+  int haveStatus;
+  /* parameters (defaults src/ClpSimplex.cpp:49-80) */
+  double primalTolerance, dualTolerance, dualToleranceBase, dualBound, zeroTolerance, acceptablePivot_,
+      largeValue;
+  int maximumIterations, pivotRule, maximumPivots, logLevel;
+  /* state */
+  int problemStatus, numberIterations, numberRefactorizations;
+  int pivotRow, sequenceIn, sequenceOut, directionIn, directionOut;
+  double alpha, theta, dualOut, dualIn, valueIn, valueOut, lowerIn, upperIn, lowerOut, upperOut;
+  double objectiveValue;
+  double largestPrimalError, largestDualError;
+  double sumPrimalInfeasibilities, sumDualInfeasibilities, sumOfRelaxedPrimalInfeasibilities,
+      sumOfRelaxedDualInfeasibilities;
+  int numberPrimalInfeasibilities, numberDualInfeasibilities;
+  int numberFake, numberChanged, numberTimesOptimal, forceFactorization, lastBadIteration;
+  unsigned int seed;
+  Factor fac;
+  /* dual row pivot */
+  double *weights;      /* [m] by basis position */
+  double *infeas;       /* [m] dense squared infeasibility */
+  int *infIndex;        /* insertion-ordered list, as CoinIndexedVector infeasible_ */
+  int numberInfeasible;
+  double *savedWeights; /* saveWeights(1)/(2): weights keyed by sequence */
+  int *savedWhich;
+  int haveSavedWeights;
+  double *altWeightValue; /* alternateWeights_ for unrollWeights */
+  int *altWeightIndex;
+  int numberAlt;
+  /* work vectors */
+  double *rowWork0, *rowWork1, *rowWork2, *rowWork3; /* dense length m */
+  int *piIndex;
+  double *piValue;
+  int numberPi; /* packed BTRAN result / row part of tableau row */
+  int *colIndex;
+  double *colValue;
+  int numberColNz; /* packed column part of tableau row */
+  int *wIndex;
+  double *wValue;
+  int numberW; /* packed updated column */
+  int *spareIndex[2];
+  double *spareValue[2]; /* the two flip-flop candidate lists of dualColumn */
+  int numberCandidates;
+  double upperThetaFirst;
+  int *rowFlip, numberRowFlip, *colFlip, numberColFlip;
+  /* log */
+  OrcPivotRecord *log;
+  int logCount, logCap;
+  double seconds;
+};
+
+/* ------------------------------------------------------------------------------------------ */
+static inline int getStatus(const OrcModel *M, int i) { return M->status[i] & 7; }
+static inline void setStatus(OrcModel *M, int i, int s) { M->status[i] = (unsigned char)((M->status[i] & ~7) | s); }
+static inline int getFake(const OrcModel *M, int i) { return (M->status[i] >> 3) & 3; }
+static inline void setFake(OrcModel *M, int i, int f) { M->status[i] = (unsigned char)((M->status[i] & ~24) | (f << 3)); }
+static inline int flagged(const OrcModel *M, int i) { return (M->status[i] & FLAGGED_BIT) != 0; }
+static inline void setFlagged(OrcModel *M, int i) { M->status[i] |= FLAGGED_BIT; }
+static inline void clearFlagged(OrcModel *M, int i) { M->status[i] &= (unsigned char)~FLAGGED_BIT; }
+static inline double dmin(double a, double b) { return a < b ? a : b; }
+static inline double dmax(double a, double b) { return a > b ? a : b; }
+
+/* CoinThreadRandom::randomDouble, COIN_OWN_RANDOM_32 form [CoinUtils, from memory] */
+static double randomDouble(OrcModel *M)
+{
+  M->seed = 1664525u * M->seed + 1013904223u;
+  return ((double)M->seed) / 4294967296.0;
+}
+
+static double originalLower(const OrcModel *M, int i) { return i < M->n ? M->colLower[i] : M->rowLower[i - M->n]; }
+static double originalUpper(const OrcModel *M, int i) { return i < M->n ? M->colUpper[i] : M->rowUpper[i - M->n]; }
+
+/* ------------------------------------------------------------------------------------------ */
+OrcModel *orc_create(int m, int n, const int *colStart, const int *row, const double *elem,
+                     const double *colLower, const double *colUpper, const double *obj,
+                     const double *rowLower, const double *rowUpper)
+{
+  OrcModel *M = (OrcModel *)calloc(1, sizeof(OrcModel));
+  int nz = colStart[n], N = m + n;
+  M->m = m;
+  M->n = n;
+  M->colStart = (int *)malloc(sizeof(int) * (size_t)(n + 1));
+  memcpy(M->colStart, colStart, sizeof(int) * (size_t)(n + 1));
+  M->row = (int *)malloc(sizeof(int) * (size_t)(nz > 0 ? nz : 1));
+  memcpy(M->row, row, sizeof(int) * (size_t)nz);
+  M->elem = (double *)malloc(sizeof(double) * (size_t)(nz > 0 ? nz : 1));
+  memcpy(M->elem, elem, sizeof(double) * (size_t)nz);
+#define DUP(dst, src, cnt)                                    \
+  dst = (double *)malloc(sizeof(double) * (size_t)((cnt) + 1)); \
+  memcpy(dst, src, sizeof(double) * (size_t)(cnt))
+  DUP(M->colLower, colLower, n);
+  DUP(M->colUpper, colUpper, n);
+  DUP(M->obj, obj, n);
+  DUP(M->rowLower, rowLower, m);
+  DUP(M->rowUpper, rowUpper, m);
+#undef DUP
+#define DALLOC(cnt) (double *)calloc((size_t)(cnt) + 1, sizeof(double))
+#define IALLOC(cnt) (int *)calloc((size_t)(cnt) + 1, sizeof(int))
+  M->lower = DALLOC(N);
+  M->upper = DALLOC(N);
+  M->cost = DALLOC(N);
+  M->dj = DALLOC(N);
+  M->sol = DALLOC(N);
+  M->status = (unsigned char *)calloc((size_t)N + 1, 1);
+  M->pivotVariable = IALLOC(m);
+  /* ClpSimplex constructor defaults, src/ClpSimplex.cpp:44-163 */
+  M->primalTolerance = 1.0e-7;
+  M->dualTolerance = M->dualToleranceBase = 1.0e-7;
+  M->dualBound = 1.0e10;
+  M->zeroTolerance = 1.0e-13;
+  M->acceptablePivot_ = 1.0e-8;
+  M->largeValue = 1.0e15;
+  M->maximumIterations = 2147483647;
+  M->pivotRule = 1;
+  M->maximumPivots = 200; /* CoinAbcBaseFactorization1.cpp:142 default */
+  M->seed = 1234567u;     /* src/ClpModel.cpp:149 */
+  M->forceFactorization = -1;
+  M->lastBadIteration = -999999;
+  M->fac.rowToK = IALLOC(m);
+  M->fac.kcol = IALLOC(m);
+  M->fac.krow = IALLOC(m);
+  M->fac.t = DALLOC(m);
+  M->weights = DALLOC(m);
+  M->infeas = DALLOC(m);
+  M->infIndex = IALLOC(m);
+  M->savedWeights = DALLOC(m);
+  M->savedWhich = IALLOC(m);
+  M->altWeightValue = DALLOC(m);
+  M->altWeightIndex = IALLOC(m);
+  M->rowWork0 = DALLOC(m);
+  M->rowWork1 = DALLOC(m);
+  M->rowWork2 = DALLOC(m);
+  M->rowWork3 = DALLOC(m);
+  M->piIndex = IALLOC(m);
+  M->piValue = DALLOC(m);
+  M->colIndex = IALLOC(n);
+  M->colValue = DALLOC(n);
+  M->wIndex = IALLOC(m);
+  M->wValue = DALLOC(m);
+  for (int i = 0; i < 2; i++) {
+    M->spareIndex[i] = IALLOC(N);
+    M->spareValue[i] = DALLOC(N);
+  }
+  M->rowFlip = IALLOC(m);
+  M->colFlip = IALLOC(n);
+  return M;
+}
+
+static void freeFactor(Factor *F)
+{
+  free(F->kcol);
+  free(F->krow);
+  free(F->rowToK);
+  free(F->lu);
+  free(F->t);
+  free(F->etaPivot);
+  free(F->etaPivotValue);
+  free(F->etaStart);
+  free(F->etaIndex);
+  free(F->etaValue);
+}
+
+void orc_destroy(OrcModel *M)
+{
+  if (!M)
+    return;
+  free(M->colStart); free(M->row); free(M->elem);
+  free(M->colLower); free(M->colUpper); free(M->obj); free(M->rowLower); free(M->rowUpper);
+  free(M->lower); free(M->upper); free(M->cost); free(M->dj); free(M->sol); free(M->status);
+  free(M->pivotVariable);
+  freeFactor(&M->fac);
+  free(M->weights); free(M->infeas); free(M->infIndex); free(M->savedWeights); free(M->savedWhich);
+  free(M->altWeightValue); free(M->altWeightIndex);
+  free(M->rowWork0); free(M->rowWork1); free(M->rowWork2); free(M->rowWork3);
+  free(M->piIndex); free(M->piValue); free(M->colIndex); free(M->colValue); free(M->wIndex); free(M->wValue);
+  for (int i = 0; i < 2; i++) { free(M->spareIndex[i]); free(M->spareValue[i]); }
+  free(M->rowFlip); free(M->colFlip); free(M->log);
+  free(M);
+}
+
+int orc_set_option(OrcModel *M, const char *name, double v)
+{
+  if (!strcmp(name, "pivot_rule")) M->pivotRule = (int)v;
+  else if (!strcmp(name, "max_iterations")) M->maximumIterations = (int)v;
+  else if (!strcmp(name, "max_pivots")) M->maximumPivots = (int)v;
+  else if (!strcmp(name, "dual_bound")) M->dualBound = v;
+  else if (!strcmp(name, "primal_tolerance")) M->primalTolerance = v;
+  else if (!strcmp(name, "dual_tolerance")) M->dualTolerance = M->dualToleranceBase = v;
+  else if (!strcmp(name, "log_level")) M->logLevel = (int)v;
+  else if (!strcmp(name, "random_seed")) M->seed = (unsigned int)v;
+  else return -1;
+  return 0;
+}
+
+void orc_set_status(OrcModel *M, const unsigned char *status)
+{
+  memcpy(M->status, status, (size_t)(M->m + M->n));
+  M->haveStatus = 1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* matrix kernels                                                                              */
+/* ------------------------------------------------------------------------------------------ */
+
+/* ClpPackedMatrix::times :296 -- y += scalar*A*x, column loop, skips x_j == 0 */
+void orc_times(const OrcModel *M, double scalar, const double *x, double *y)
+{
+  for (int j = 0; j < M->n; j++) {
+    double value = x[j];
+    if (value) {
+      value *= scalar;
+      for (int p = M->colStart[j]; p < M->colStart[j + 1]; p++)
+        y[M->row[p]] += value * M->elem[p];
+    }
+  }
+}
+
+/* ClpPackedMatrix::transposeTimes :362 -- y_j += scalar * sum_i x_i a_ij */
+void orc_transpose_times(const OrcModel *M, double scalar, const double *x, double *y)
+{
+  for (int j = 0; j < M->n; j++) {
+    double value = 0.0;
+    for (int p = M->colStart[j]; p < M->colStart[j + 1]; p++)
+      value += x[M->row[p]] * M->elem[p];
+    y[j] += value * scalar;
+  }
+}
+
+/* Fused row pricing + first ratio pass.  Row part: ClpPackedMatrix.cpp:1039-1072, column part:
+ * gutsOfTransposeTimesUnscaled :1856-1988.  `pi` is negated while being expanded (:1009-1014)
+ * because the caller passes scalar = -1 (ClpSimplexDual.cpp:1300). */
+static int priceRowFused(const OrcModel *M, int numberPi, const int *piIndex, const double *piValue,
+                         double *piDense /* zeroed length m, returned zeroed */,
+                         const unsigned char *status, const double *dj, double zeroTolerance,
+                         double dualTolerance, double acceptablePivot, int *outIndex, double *outValue,
+                         int *numberCandidatesOut, int *candIndex, double *candValue, double *upperThetaOut)
+{
+  const int n = M->n;
+  const double multiplier[2] = { -1.0, 1.0 };
+  const double dualT = -dualTolerance;
+  const double tentativeTheta = 1.0e15; /* :1857 (pass 0 proper uses 1e25, ClpSimplexDual.cpp:3679) */
+  double upperTheta = 1.0e31;
+  int numberRemaining = 0;
+  for (int i = 0; i < numberPi; i++)
+    piDense[piIndex[i]] = -piValue[i];
+  /* row (slack) part of the tableau row is pi itself */
+  const unsigned char *statusRow = status + n;
+  const double *djRow = dj + n;
+  for (int i = 0; i < numberPi; i++) {
+    int iSequence = piIndex[i];
+    int iStatus = (statusRow[iSequence] & 3) - 1;
+    if (iStatus > 0) {
+      double mult = multiplier[iStatus - 1];
+      double alpha = piValue[i] * mult;
+      if (alpha > 0.0) {
+        double oldValue = djRow[iSequence] * mult;
+        double value = oldValue - tentativeTheta * alpha;
+        if (value < dualT) {
+          value = oldValue - upperTheta * alpha;
+          if (value < dualT && alpha >= acceptablePivot)
+            upperTheta = (oldValue - dualT) / alpha;
+          candValue[numberRemaining] = alpha * mult;
+          candIndex[numberRemaining++] = iSequence + n;
+        }
+      }
+    }
+  }
+  int numberNonZero = 0;
+  for (int iColumn = 0; iColumn < n; iColumn++) {
+    int wanted = (status[iColumn] & 3) - 1;
+    if (wanted) {
+      double value = 0.0;
+      for (int p = M->colStart[iColumn]; p < M->colStart[iColumn + 1]; p++)
+        value += piDense[M->row[p]] * M->elem[p]; /* sequential, ascending p (:1872-1886) */
+      if (fabs(value) > zeroTolerance) {
+        outValue[numberNonZero] = value;
+        outIndex[numberNonZero++] = iColumn;
+        if (wanted > 0) {
+          double mult = multiplier[wanted - 1];
+          double alpha = value * mult;
+          if (alpha > 0.0) {
+            double oldValue = dj[iColumn] * mult;
+            double value2 = oldValue - tentativeTheta * alpha;
+            if (value2 < dualT) {
+              value2 = oldValue - upperTheta * alpha;
+              if (value2 < dualT && alpha >= acceptablePivot)
+                upperTheta = (oldValue - dualT) / alpha;
+              candValue[numberRemaining] = alpha * mult;
+              candIndex[numberRemaining++] = iColumn;
+            }
+          }
+        }
+      }
+    }
+  }
+  for (int i = 0; i < numberPi; i++)
+    piDense[piIndex[i]] = 0.0;
+  *numberCandidatesOut = numberRemaining;
+  *upperThetaOut = upperTheta;
+  return numberNonZero;
+}
+
+int orc_price_row_fused(const OrcModel *M, int numberPi, const int *piIndex, const double *piValue,
+                        const unsigned char *status, const double *dj, double zeroTolerance,
+                        double dualTolerance, double acceptablePivot, int *outIndex, double *outValue,
+                        int *numberCandidates, int *candIndex, double *candValue, double *upperTheta)
+{
+  double *dense = (double *)calloc((size_t)M->m + 1, sizeof(double));
+  int r = priceRowFused(M, numberPi, piIndex, piValue, dense, status, dj, zeroTolerance, dualTolerance,
+                        acceptablePivot, outIndex, outValue, numberCandidates, candIndex, candValue, upperTheta);
+  free(dense);
+  return r;
+}
+
+/* ClpPackedMatrix::add :4874 / ClpSimplex::add for slacks: array += multiplier * column(iSequence) */
+static void addColumn(const OrcModel *M, double *array, int iSequence, double multiplier)
+{
+  if (iSequence < M->n) {
+    for (int p = M->colStart[iSequence]; p < M->colStart[iSequence + 1]; p++)
+      array[M->row[p]] += multiplier * M->elem[p];
+  } else {
+    array[iSequence - M->n] -= multiplier; /* slack column is -e_i */
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* factorization                                                                               */
+/* ------------------------------------------------------------------------------------------ */
+static void facReserveEta(Factor *F, int maxEta, long nnz)
+{
+  if (maxEta > F->maxEta || !F->etaPivot) {
+    F->maxEta = maxEta;
+    F->etaPivot = (int *)realloc(F->etaPivot, sizeof(int) * (size_t)(maxEta + 1));
+    F->etaPivotValue = (double *)realloc(F->etaPivotValue, sizeof(double) * (size_t)(maxEta + 1));
+    F->etaStart = (int *)realloc(F->etaStart, sizeof(int) * (size_t)(maxEta + 2));
+    if (!F->nEta)
+      F->etaStart[0] = 0;
+  }
+  if (nnz > F->etaCap) {
+    F->etaCap = nnz + nnz / 2 + 1024;
+    F->etaIndex = (int *)realloc(F->etaIndex, sizeof(int) * (size_t)F->etaCap);
+    F->etaValue = (double *)realloc(F->etaValue, sizeof(double) * (size_t)F->etaCap);
+  }
+}
+
+/* ClpFactorization::factorize :1649 (collect basic rows then columns, slack value -1) +
+ * CoinAbcDenseFactorization::factor :216-331 on the nucleus.  Returns 0, or -1 if singular. */
+static int factorize(OrcModel *M)
+{
+  Factor *F = &M->fac;
+  const int m = M->m, n = M->n;
+  int k = 0, numberBasic = 0;
+  for (int i = 0; i < m; i++) {
+    if (getStatus(M, n + i) == ST_BASIC) {
+      F->rowToK[i] = -1;
+      numberBasic++;
+    } else {
+      F->rowToK[i] = -2; /* nucleus row, step not yet known */
+    }
+  }
+  for (int j = 0; j < n; j++)
+    if (getStatus(M, j) == ST_BASIC) {
+      if (k < m)
+        F->kcol[k] = j;
+      k++;
+      numberBasic++;
+    }
+  if (numberBasic != m)
+    return -2;
+  F->k = k;
+  F->nEta = 0;
+  facReserveEta(F, M->maximumPivots, 0);
+  F->etaStart[0] = 0;
+  M->numberRefactorizations++;
+  /* list of nucleus rows, ascending */
+  int *rrows = (int *)malloc(sizeof(int) * (size_t)(k + 1));
+  int nr = 0;
+  for (int i = 0; i < m; i++)
+    if (F->rowToK[i] == -2)
+      rrows[nr++] = i;
+  if ((long)k * k > F->luCap) {
+    F->luCap = k * k + 16;
+    free(F->lu);
+    F->lu = (double *)malloc(sizeof(double) * (size_t)F->luCap);
+  }
+  double *lu = F->lu;
+  memset(lu, 0, sizeof(double) * (size_t)k * (size_t)k);
+  int *where = F->krow; /* reuse as temp: row -> local index */
+  int *local = (int *)malloc(sizeof(int) * (size_t)(m + 1));
+  for (int i = 0; i < m; i++)
+    local[i] = -1;
+  for (int r = 0; r < k; r++)
+    local[rrows[r]] = r;
+  for (int c = 0; c < k; c++) {
+    int j = F->kcol[c];
+    for (int p = M->colStart[j]; p < M->colStart[j + 1]; p++) {
+      int r = local[M->row[p]];
+      if (r >= 0)
+        lu[r + (size_t)c * k] = M->elem[p];
+    }
+  }
+  (void)where;
+  int *perm = (int *)malloc(sizeof(int) * (size_t)(k + 1));
+  for (int i = 0; i < k; i++)
+    perm[i] = i;
+  int status = 0;
+  double *elements = lu;
+  for (int i = 0; i < k; i++) {
+    int iRow = -1;
+    double largest = M->zeroTolerance;
+    for (int j = i; j < k; j++) {
+      double value = fabs(elements[j]);
+      if (value > largest) {
+        largest = value;
+        iRow = j;
+      }
+    }
+    if (iRow < 0) {
+      status = -1;
+      break;
+    }
+    if (iRow != i) {
+      /* full row swap (the reference swaps columns <= i now and later columns lazily, :271-300) */
+      for (int c = 0; c < k; c++) {
+        double value = lu[i + (size_t)c * k];
+        lu[i + (size_t)c * k] = lu[iRow + (size_t)c * k];
+        lu[iRow + (size_t)c * k] = value;
+      }
+      int ip = perm[i];
+      perm[i] = perm[iRow];
+      perm[iRow] = ip;
+    }
+    double pivotValue = 1.0 / elements[i];
+    elements[i] = pivotValue;
+    for (int j = i + 1; j < k; j++)
+      elements[j] *= pivotValue;
+    double *elementsA = elements;
+    for (int c = i + 1; c < k; c++) {
+      elementsA += k;
+      double value = elementsA[i];
+      for (int j = i + 1; j < k; j++)
+        elementsA[j] -= value * elements[j];
+    }
+    elements += k;
+  }
+  if (!status) {
+    for (int c = 0; c < k; c++) {
+      F->krow[c] = rrows[perm[c]];
+      F->rowToK[F->krow[c]] = c;
+    }
+    /* postProcess: pivotVariable (basis position == row) */
+    for (int i = 0; i < m; i++)
+      if (F->rowToK[i] == -1)
+        M->pivotVariable[i] = n + i;
+    for (int c = 0; c < k; c++)
+      M->pivotVariable[F->krow[c]] = F->kcol[c];
+  }
+  free(perm);
+  free(local);
+  free(rrows);
+  return status;
+}
+
+/* CoinAbcDenseFactorization::updateColumn :571-610: L, U, then the eta file.  `x` is indexed by
+ * row on input and by basis position (== row) on output. */
+static void ftran(const OrcModel *M, double *x)
+{
+  const Factor *F = &M->fac;
+  const int k = F->k, m = M->m;
+  double *t = F->t;
+  const double *lu = F->lu;
+  for (int c = 0; c < k; c++)
+    t[c] = x[F->krow[c]];
+  for (int i = 0; i < k; i++) {
+    double value = t[i];
+    if (value) {
+      const double *col = lu + (size_t)i * k;
+      for (int j = i + 1; j < k; j++)
+        t[j] -= value * col[j];
+    }
+  }
+  for (int i = k - 1; i >= 0; i--) {
+    const double *col = lu + (size_t)i * k;
+    double value = t[i] * col[i];
+    t[i] = value;
+    if (value) {
+      for (int j = 0; j < i; j++)
+        t[j] -= value * col[j];
+      int jcol = F->kcol[i];
+      for (int p = M->colStart[jcol]; p < M->colStart[jcol + 1]; p++) {
+        int r = M->row[p];
+        if (F->rowToK[r] < 0)
+          x[r] -= value * M->elem[p];
+      }
+    }
+  }
+  for (int r = 0; r < m; r++)
+    if (F->rowToK[r] < 0)
+      x[r] = x[r] * -1.0; /* inverse pivot of the slack column -e_r */
+  for (int c = 0; c < k; c++)
+    x[F->krow[c]] = t[c];
+  for (int e = 0; e < F->nEta; e++) {
+    int iPivot = F->etaPivot[e];
+    double value = x[iPivot] * F->etaPivotValue[e];
+    if (value) {
+      for (int p = F->etaStart[e]; p < F->etaStart[e + 1]; p++)
+        x[F->etaIndex[p]] -= value * F->etaValue[p];
+    }
+    x[iPivot] = value;
+  }
+}
+
+/* CoinAbcDenseFactorization::updateColumnTranspose :634-683: etas reversed, U^T, L^T. */
+static void btran(const OrcModel *M, double *y)
+{
+  const Factor *F = &M->fac;
+  const int k = F->k, m = M->m;
+  double *t = F->t;
+  const double *lu = F->lu;
+  for (int e = F->nEta - 1; e >= 0; e--) {
+    int iPivot = F->etaPivot[e];
+    double value = y[iPivot];
+    for (int p = F->etaStart[e]; p < F->etaStart[e + 1]; p++)
+      value -= y[F->etaIndex[p]] * F->etaValue[p];
+    y[iPivot] = value * F->etaPivotValue[e];
+  }
+  for (int r = 0; r < m; r++)
+    if (F->rowToK[r] < 0)
+      y[r] = y[r] * -1.0;
+  for (int c = 0; c < k; c++) {
+    double value = y[F->krow[c]];
+    int jcol = F->kcol[c];
+    for (int p = M->colStart[jcol]; p < M->colStart[jcol + 1]; p++) {
+      int r = M->row[p];
+      if (F->rowToK[r] < 0)
+        value -= y[r] * M->elem[p];
+    }
+    const double *col = lu + (size_t)c * k;
+    for (int j = 0; j < c; j++)
+      value -= t[j] * col[j];
+    t[c] = value * col[c];
+  }
+  for (int i = k - 1; i >= 0; i--) {
+    const double *col = lu + (size_t)i * k;
+    double value = t[i];
+    for (int j = i + 1; j < k; j++)
+      value -= t[j] * col[j];
+    t[i] = value;
+  }
+  for (int c = 0; c < k; c++)
+    y[F->krow[c]] = t[c];
+}
+
+/* CoinAbcDenseFactorization::checkReplacePart2 :470-478 + replaceColumnPart3 :480-544 */
+static int replaceColumn(OrcModel *M, const int *wIndex, const double *wValue, int numberW, int pivotRow, double alpha)
+{
+  Factor *F = &M->fac;
+  if (F->nEta >= M->maximumPivots)
+    return 3;
+  if (fabs(alpha) < M->zeroTolerance)
+    return 2;
+  int e = F->nEta;
+  long need = F->etaStart[e] + numberW + 1;
+  facReserveEta(F, M->maximumPivots, need);
+  int put = F->etaStart[e];
+  for (int i = 0; i < numberW; i++) {
+    if (wIndex[i] != pivotRow) {
+      F->etaIndex[put] = wIndex[i];
+      F->etaValue[put++] = wValue[i];
+    }
+  }
+  F->etaStart[e + 1] = put;
+  F->etaPivot[e] = pivotRow;
+  F->etaPivotValue[e] = 1.0 / alpha;
+  F->nEta++;
+  return 0;
+}
+
+static long factorNumberElements(const OrcModel *M)
+{
+  const Factor *F = &M->fac;
+  return (long)F->k * F->k + F->etaStart[F->nEta] + M->m;
+}
+
+int orc_factorize(OrcModel *M, const unsigned char *status, int *pivotVariable)
+{
+  memcpy(M->status, status, (size_t)(M->m + M->n));
+  int rc = factorize(M);
+  if (!rc && pivotVariable)
+    memcpy(pivotVariable, M->pivotVariable, sizeof(int) * (size_t)M->m);
+  return rc;
+}
+void orc_ftran(OrcModel *M, double *region) { ftran(M, region); }
+void orc_btran(OrcModel *M, double *region) { btran(M, region); }
+int orc_replace_column(OrcModel *M, const double *w, int pivotRow, double alpha)
+{
+  int nw = 0;
+  for (int i = 0; i < M->m; i++)
+    if (w[i]) {
+      M->wIndex[nw] = i;
+      M->wValue[nw++] = w[i];
+    }
+  int rc = replaceColumn(M, M->wIndex, M->wValue, nw, pivotRow, alpha);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* primal / dual solutions  (ClpSimplex::gutsOfSolution :574)                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* ClpSimplex::computePrimals :914-1162 (numberRefinements_ = 0) */
+static void computePrimals(OrcModel *M)
+{
+  const int m = M->m, n = M->n;
+  double *array = M->rowWork1;
+  for (int i = 0; i < m; i++)
+    M->sol[M->pivotVariable[i]] = 0.0;
+  memset(array, 0, sizeof(double) * (size_t)m);
+  orc_times(M, -1.0, M->sol, array);
+  for (int i = 0; i < m; i++)
+    array[i] = array[i] + M->sol[n + i];
+  double *rhs = M->rowWork2;
+  memcpy(rhs, array, sizeof(double) * (size_t)m);
+  ftran(M, array);
+  /* error check: B*x_B - rhs */
+  double *work = M->rowWork3;
+  memset(work, 0, sizeof(double) * (size_t)m);
+  for (int i = 0; i < m; i++) {
+    double value = array[i];
+    if (value)
+      addColumn(M, work, M->pivotVariable[i], value);
+  }
+  double largest = 0.0;
+  for (int i = 0; i < m; i++) {
+    double d = fabs(work[i] - rhs[i]);
+    if (d > largest)
+      largest = d;
+  }
+  M->largestPrimalError = largest;
+  for (int i = 0; i < m; i++)
+    M->sol[M->pivotVariable[i]] = array[i];
+  memset(array, 0, sizeof(double) * (size_t)m);
+  memset(rhs, 0, sizeof(double) * (size_t)m);
+  memset(work, 0, sizeof(double) * (size_t)m);
+}
+
+/* ClpSimplex::computeDuals :1164-1400 */
+static void computeDuals(OrcModel *M)
+{
+  const int m = M->m, n = M->n;
+  double *array = M->rowWork1;
+  for (int i = 0; i < m; i++)
+    array[i] = M->cost[M->pivotVariable[i]];
+  btran(M, array);
+  double largest = 0.0;
+  for (int i = 0; i < m; i++) {
+    int iPivot = M->pivotVariable[i];
+    double value;
+    if (iPivot >= n) {
+      value = M->cost[iPivot] + array[iPivot - n];
+    } else {
+      double v = 0.0;
+      for (int p = M->colStart[iPivot]; p < M->colStart[iPivot + 1]; p++)
+        v += array[M->row[p]] * M->elem[p];
+      value = M->cost[iPivot] - v;
+    }
+    if (fabs(value) > largest)
+      largest = fabs(value);
+  }
+  M->largestDualError = largest;
+  for (int i = 0; i < m; i++)
+    M->dj[n + i] = array[i] + M->cost[n + i];
+  for (int j = 0; j < n; j++)
+    M->dj[j] = M->cost[j];
+  orc_transpose_times(M, -1.0, array, M->dj);
+  memset(array, 0, sizeof(double) * (size_t)m);
+}
+
+/* ClpSimplex::checkPrimalSolution :2989-3069 */
+static void checkPrimalSolution(OrcModel *M)
+{
+  const int N = M->m + M->n, n = M->n;
+  double primalTolerance = M->primalTolerance;
+  double relaxedTolerance = primalTolerance + dmin(1.0e-2, M->largestPrimalError);
+  M->objectiveValue = 0.0;
+  M->sumPrimalInfeasibilities = 0.0;
+  M->numberPrimalInfeasibilities = 0;
+  M->sumOfRelaxedPrimalInfeasibilities = 0.0;
+  for (int pass = 0; pass < 2; pass++) {
+    int lo = pass ? 0 : n, hi = pass ? n : N; /* rows first, then columns */
+    for (int i = lo; i < hi; i++) {
+      double infeasibility = 0.0;
+      M->objectiveValue += M->sol[i] * M->cost[i];
+      if (M->sol[i] > M->upper[i])
+        infeasibility = M->sol[i] - M->upper[i];
+      else if (M->sol[i] < M->lower[i])
+        infeasibility = M->lower[i] - M->sol[i];
+      if (infeasibility > primalTolerance) {
+        M->sumPrimalInfeasibilities += infeasibility - primalTolerance;
+        if (infeasibility > relaxedTolerance)
+          M->sumOfRelaxedPrimalInfeasibilities += infeasibility - relaxedTolerance;
+        M->numberPrimalInfeasibilities++;
+      }
+    }
+  }
+}
+
+/* ClpSimplex::checkDualSolution :3070-3250 (no free variables) */
+static void checkDualSolution(OrcModel *M)
+{
+  const int N = M->m + M->n, n = M->n;
+  double relaxedTolerance = M->dualTolerance + dmin(1.0e-2, M->largestDualError);
+  M->sumDualInfeasibilities = 0.0;
+  M->numberDualInfeasibilities = 0;
+  M->sumOfRelaxedDualInfeasibilities = 0.0;
+  for (int pass = 0; pass < 2; pass++) {
+    int lo = pass ? n : 0, hi = pass ? N : n; /* columns first, then rows */
+    for (int i = lo; i < hi; i++) {
+      if (getStatus(M, i) != ST_BASIC && !flagged(M, i)) {
+        double distanceUp = M->upper[i] - M->sol[i];
+        double distanceDown = M->sol[i] - M->lower[i];
+        double value = M->dj[i];
+        if (distanceUp > M->primalTolerance) {
+          if (value < 0.0) {
+            double v = -value;
+            if (v > M->dualTolerance) {
+              M->sumDualInfeasibilities += v - M->dualTolerance;
+              if (v > relaxedTolerance)
+                M->sumOfRelaxedDualInfeasibilities += v - relaxedTolerance;
+              M->numberDualInfeasibilities++;
+            }
+          }
+        }
+        if (distanceDown > M->primalTolerance) {
+          if (value > 0.0) {
+            if (value > M->dualTolerance) {
+              M->sumDualInfeasibilities += value - M->dualTolerance;
+              if (value > relaxedTolerance)
+                M->sumOfRelaxedDualInfeasibilities += value - relaxedTolerance;
+              M->numberDualInfeasibilities++;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+static void gutsOfSolution(OrcModel *M)
+{
+  computePrimals(M);
+  computeDuals(M);
+  checkPrimalSolution(M);
+  checkDualSolution(M);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* fake bounds (ClpSimplexDual::changeBounds :3148, originalBound :6403, changeBound :6445)    */
+/* ------------------------------------------------------------------------------------------ */
+static void originalBound(OrcModel *M, int i)
+{
+  if (getFake(M, i) != FAKE_NONE) {
+    M->numberFake--;
+    setFake(M, i, FAKE_NONE);
+    M->lower[i] = originalLower(M, i);
+    M->upper[i] = originalUpper(M, i);
+  }
+}
+
+static int changeBound(OrcModel *M, int i)
+{
+  double oldLower = M->lower[i], oldUpper = M->upper[i], value = M->sol[i];
+  int modified = 0;
+  originalBound(M, i);
+  double lowerValue = M->lower[i], upperValue = M->upper[i];
+  M->lower[i] = oldLower;
+  M->upper[i] = oldUpper;
+  if (value == oldLower) {
+    if (upperValue > oldLower + M->dualBound) {
+      M->upper[i] = oldLower + M->dualBound;
+      setFake(M, i, FAKE_UPPER);
+      modified = 1;
+      M->numberFake++;
+    }
+  } else if (value == oldUpper) {
+    if (lowerValue < oldUpper - M->dualBound) {
+      M->lower[i] = oldUpper - M->dualBound;
+      setFake(M, i, FAKE_LOWER);
+      modified = 1;
+      M->numberFake++;
+    }
+  }
+  return modified;
+}
+
+/* initialize == 1 or 3 (:3267-3440), 0 (:3153-3266) */
+static int changeBounds(OrcModel *M, int initialize, double *outputArray, double *changeCost)
+{
+  const int N = M->m + M->n, n = M->n;
+  M->numberFake = 0;
+  if (!initialize) {
+    int numberInfeasibilities = 0;
+    double newBound = 5.0 * M->dualBound;
+    *changeCost = 0.0;
+    /* createRim1(false): put back original bounds */
+    for (int i = 0; i < N; i++) {
+      M->lower[i] = originalLower(M, i);
+      M->upper[i] = originalUpper(M, i);
+    }
+    for (int i = 0; i < N; i++) {
+      double lowerValue = M->lower[i], upperValue = M->upper[i], value = M->sol[i];
+      setFake(M, i, FAKE_NONE);
+      int st = getStatus(M, i);
+      if (st == ST_UPPER) {
+        if (fabs(value - upperValue) > M->primalTolerance) {
+          if (fabs(M->dj[i]) > 1.0e-9)
+            numberInfeasibilities++;
+          else
+            setStatus(M, i, ST_SUPER);
+        }
+      } else if (st == ST_LOWER) {
+        if (fabs(value - lowerValue) > M->primalTolerance) {
+          if (fabs(M->dj[i]) > 1.0e-9)
+            numberInfeasibilities++;
+          else
+            setStatus(M, i, ST_SUPER);
+        }
+      }
+    }
+    if (numberInfeasibilities) {
+      for (int i = 0; i < N; i++) {
+        double lowerValue = M->lower[i], upperValue = M->upper[i];
+        double newLowerValue, newUpperValue;
+        int st = getStatus(M, i);
+        if (st == ST_UPPER || st == ST_LOWER) {
+          double value = M->sol[i];
+          if (value - lowerValue <= upperValue - value) {
+            newLowerValue = dmax(lowerValue, value - 0.666667 * newBound);
+            newUpperValue = dmin(upperValue, newLowerValue + newBound);
+          } else {
+            newUpperValue = dmin(upperValue, value + 0.666667 * newBound);
+            newLowerValue = dmax(lowerValue, newUpperValue - newBound);
+          }
+          if (newLowerValue > lowerValue) {
+            if (newUpperValue < upperValue) {
+              setFake(M, i, FAKE_BOTH);
+              if (st == ST_LOWER) {
+                newLowerValue = value;
+                newUpperValue = dmin(upperValue, newLowerValue + newBound);
+              } else {
+                newUpperValue = value;
+                newLowerValue = dmax(lowerValue, newUpperValue - newBound);
+              }
+              M->numberFake++;
+            } else {
+              setFake(M, i, FAKE_LOWER);
+              M->numberFake++;
+            }
+          } else if (newUpperValue < upperValue) {
+            setFake(M, i, FAKE_UPPER);
+            M->numberFake++;
+          }
+          M->lower[i] = newLowerValue;
+          M->upper[i] = newUpperValue;
+          M->sol[i] = (st == ST_UPPER) ? newUpperValue : newLowerValue;
+          double movement = M->sol[i] - value;
+          if (movement && outputArray) {
+            if (i >= n)
+              outputArray[i - n] -= movement;
+            else
+              addColumn(M, outputArray, i, movement);
+            *changeCost += movement * M->cost[i];
+          }
+        }
+      }
+      M->dualBound = newBound;
+    } else {
+      numberInfeasibilities = -1;
+    }
+    return numberInfeasibilities;
+  } else {
+    if (initialize == 3) {
+      for (int i = 0; i < N; i++) {
+        if (getFake(M, i) != FAKE_NONE) {
+          M->lower[i] = originalLower(M, i);
+          M->upper[i] = originalUpper(M, i);
+          setFake(M, i, FAKE_NONE);
+        }
+      }
+    }
+    double testBound = 0.999999 * M->dualBound;
+    for (int i = 0; i < N; i++) {
+      int st = getStatus(M, i);
+      if (st == ST_UPPER || st == ST_LOWER) {
+        double lowerValue = M->lower[i], upperValue = M->upper[i], value = M->sol[i];
+        if (lowerValue > -M->largeValue || upperValue < M->largeValue) {
+          if (fabs(lowerValue - value) <= fabs(upperValue - value)) {
+            if (upperValue > lowerValue + testBound) {
+              if (getFake(M, i) == FAKE_NONE)
+                M->numberFake++;
+              M->upper[i] = lowerValue + M->dualBound;
+              setFake(M, i, FAKE_UPPER);
+            }
+          } else {
+            if (lowerValue < upperValue - testBound) {
+              if (getFake(M, i) == FAKE_NONE)
+                M->numberFake++;
+              M->lower[i] = upperValue - M->dualBound;
+              setFake(M, i, FAKE_LOWER);
+            }
+          }
+          M->sol[i] = (st == ST_UPPER) ? M->upper[i] : M->lower[i];
+        } else {
+          M->lower[i] = -0.5 * M->dualBound;
+          M->upper[i] = 0.5 * M->dualBound;
+          setFake(M, i, FAKE_BOTH);
+          M->numberFake++;
+          setStatus(M, i, ST_UPPER);
+          M->sol[i] = 0.5 * M->dualBound;
+        }
+      } else if (st == ST_BASIC) {
+        setFake(M, i, FAKE_NONE);
+        double gap = M->upper[i] - M->lower[i];
+        if (gap > 0.5 * M->dualBound && gap < 2.0 * M->dualBound) {
+          M->lower[i] = originalLower(M, i);
+          M->upper[i] = originalUpper(M, i);
+        }
+      }
+    }
+    return 1;
+  }
+}
+
+static int numberAtFakeBound(const OrcModel *M)
+{
+  int count = 0;
+  for (int i = 0; i < M->m + M->n; i++) {
+    int f = getFake(M, i), st = getStatus(M, i);
+    if (st == ST_UPPER && (f == FAKE_UPPER || f == FAKE_BOTH))
+      count++;
+    else if (st == ST_LOWER && (f == FAKE_LOWER || f == FAKE_BOTH))
+      count++;
+  }
+  return count;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* dual row pivot                                                                              */
+/* ------------------------------------------------------------------------------------------ */
+static void infeasibleAdd(OrcModel *M, int iRow, double value)
+{
+  if (M->infeas[iRow]) {
+    M->infeas[iRow] = value;
+  } else {
+    M->infeas[iRow] = value;
+    M->infIndex[M->numberInfeasible++] = iRow;
+  }
+}
+
+/* ClpDualRowSteepest::saveWeights :773-1014, modes 1,2,3,4 */
+static void saveWeights(OrcModel *M, int mode)
+{
+  const int m = M->m;
+  if (M->pivotRule == 0) {
+    return; /* Dantzig keeps nothing */
+  }
+  if (mode == 1) {
+    if (M->haveSavedWeights) {
+      /* change from row numbers to sequence numbers (:786-793) */
+      for (int i = 0; i < m; i++)
+        M->altWeightIndex[i] = M->pivotVariable[i];
+      M->numberAlt = 0;
+    }
+    return;
+  }
+  if (mode == 2 || mode == 4) {
+    if (!M->haveSavedWeights) {
+      /* initialize weights to 1.0 (:820-870, mode_ != 1) */
+      for (int i = 0; i < m; i++)
+        M->weights[i] = 1.0;
+      for (int i = 0; i < m; i++) {
+        M->savedWeights[i] = M->weights[i];
+        M->savedWhich[i] = M->pivotVariable[i];
+      }
+      M->haveSavedWeights = 1;
+    } else {
+      const int *which;
+      int *back = (int *)malloc(sizeof(int) * (size_t)(m + M->n + 1));
+      for (int i = 0; i < m + M->n; i++)
+        back[i] = -1;
+      if (mode != 4) {
+        memcpy(M->savedWhich, M->altWeightIndex, sizeof(int) * (size_t)m);
+        memcpy(M->savedWeights, M->weights, sizeof(double) * (size_t)m);
+        which = M->altWeightIndex;
+      } else {
+        which = M->savedWhich;
+      }
+      for (int i = 0; i < m; i++)
+        back[which[i]] = i;
+      for (int i = 0; i < m; i++) {
+        int iPivot = back[M->pivotVariable[i]];
+        if (iPivot >= 0) {
+          M->weights[i] = M->savedWeights[iPivot];
+          if (M->weights[i] < DEVEX_TRY_NORM)
+            M->weights[i] = DEVEX_TRY_NORM;
+        } else {
+          M->weights[i] = 1.0;
+        }
+      }
+      free(back);
+    }
+  }
+  if (mode >= 2) {
+    for (int i = 0; i < M->numberInfeasible; i++)
+      M->infeas[M->infIndex[i]] = 0.0;
+    M->numberInfeasible = 0;
+    double tolerance = M->primalTolerance;
+    for (int iRow = 0; iRow < m; iRow++) {
+      int iPivot = M->pivotVariable[iRow];
+      double value = M->sol[iPivot], lower = M->lower[iPivot], upper = M->upper[iPivot];
+      if (value < lower - tolerance) {
+        value -= lower;
+        value *= value;
+        infeasibleAdd(M, iRow, value);
+      } else if (value > upper + tolerance) {
+        value -= upper;
+        value *= value;
+        infeasibleAdd(M, iRow, value);
+      }
+    }
+  }
+}
+
+/* ClpDualRowSteepest::unrollWeights :1022 */
+static void unrollWeights(OrcModel *M)
+{
+  if (M->pivotRule == 0)
+    return;
+  for (int i = 0; i < M->numberAlt; i++)
+    M->weights[M->altWeightIndex[i]] = M->altWeightValue[i];
+  M->numberAlt = 0;
+}
+
+/* ClpDualRowDantzig::pivotRow :56-92 */
+static int dantzigPivotRow(OrcModel *M)
+{
+  double tolerance = M->primalTolerance;
+  if (M->largestPrimalError > 1.0e-8)
+    tolerance *= M->largestPrimalError / 1.0e-8;
+  double largest = 0.0;
+  int chosenRow = -1;
+  for (int iRow = 0; iRow < M->m; iRow++) {
+    int iSequence = M->pivotVariable[iRow];
+    double value = M->sol[iSequence];
+    double infeas = dmax(value - M->upper[iSequence], M->lower[iSequence] - value);
+    if (infeas > tolerance) {
+      if (infeas > largest) {
+        if (!flagged(M, iSequence)) {
+          chosenRow = iRow;
+          largest = infeas;
+        }
+      }
+    }
+  }
+  return chosenRow;
+}
+
+/* ClpDualRowSteepest::pivotRow :179-364 (full scan: numberWanted = number+1, mode_ < 2) */
+static int steepestPivotRow(OrcModel *M)
+{
+  double largest = 0.0;
+  int chosenRow = -1;
+  int lastPivotRow = M->pivotRow;
+  double tolerance = M->primalTolerance;
+  double error = dmin(1.0e-2, M->largestPrimalError);
+  tolerance = tolerance + error;
+  tolerance = dmin(1000.0, tolerance);
+  tolerance *= tolerance;
+  if (lastPivotRow >= 0 && lastPivotRow < M->m) {
+    int iPivot = M->pivotVariable[lastPivotRow];
+    double value = M->sol[iPivot], lower = M->lower[iPivot], upper = M->upper[iPivot];
+    if (value > upper + tolerance) {
+      value -= upper;
+      value *= value;
+      infeasibleAdd(M, lastPivotRow, value);
+    } else if (value < lower - tolerance) {
+      value -= lower;
+      value *= value;
+      infeasibleAdd(M, lastPivotRow, value);
+    } else {
+      if (M->infeas[lastPivotRow])
+        M->infeas[lastPivotRow] = REALLY_TINY;
+    }
+  }
+  int number = M->numberInfeasible;
+  /* the "can't trust infeasibilities" tolerance change (:267-273) needs lastBadIteration */
+  if (M->numberIterations < M->lastBadIteration + 200) {
+    if (M->largestDualError > M->largestPrimalError) {
+      tolerance *= dmin(M->largestDualError / M->largestPrimalError, 1000.0);
+    }
+  }
+  int start[4];
+  start[1] = number;
+  start[2] = 0;
+  double dstart = ((double)number) * randomDouble(M);
+  start[0] = (int)dstart;
+  start[3] = start[0];
+  for (int iPass = 0; iPass < 2; iPass++) {
+    int end = start[2 * iPass + 1];
+    for (int i = start[2 * iPass]; i < end; i++) {
+      int iRow = M->infIndex[i];
+      double value = M->infeas[iRow];
+      if (value > tolerance) {
+        double weight = dmin(M->weights[iRow], 1.0e50);
+        if (value > largest * weight) {
+          if (iRow == lastPivotRow) {
+            if (value * 1.0e-10 < largest * weight)
+              continue;
+            else
+              value *= 1.0e-10;
+          }
+          int iSequence = M->pivotVariable[iRow];
+          if (!flagged(M, iSequence)) {
+            if (M->sol[iSequence] > M->upper[iSequence] + tolerance || M->sol[iSequence] < M->lower[iSequence] - tolerance) {
+              chosenRow = iRow;
+              largest = value / weight;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (chosenRow < 0 && lastPivotRow < 0) {
+    int nLeft = 0;
+    for (int i = 0; i < number; i++) {
+      int iRow = M->infIndex[i];
+      if (fabs(M->infeas[iRow]) > 1.0e-50)
+        M->infIndex[nLeft++] = iRow;
+      else
+        M->infeas[iRow] = 0.0;
+    }
+    M->numberInfeasible = nLeft;
+    M->numberPrimalInfeasibilities = nLeft;
+  }
+  return chosenRow;
+}
+
+/* ClpDualRowSteepest::updatePrimalSolution :630-763 / ClpDualRowDantzig :131-170 */
+static void updatePrimalSolution(OrcModel *M, const int *which, const double *work, int number, double primalRatio,
+                                 double *objectiveChange)
+{
+  double changeObj = 0.0;
+  double tolerance = M->primalTolerance;
+  for (int i = 0; i < number; i++) {
+    int iRow = which[i];
+    int iPivot = M->pivotVariable[iRow];
+    double value = M->sol[iPivot];
+    double cost = M->cost[iPivot];
+    double change = primalRatio * work[i];
+    value -= change;
+    changeObj -= change * cost;
+    M->sol[iPivot] = value;
+    if (M->pivotRule) {
+      double lower = M->lower[iPivot], upper = M->upper[iPivot];
+      if (value < lower - tolerance) {
+        value -= lower;
+        value *= value;
+        infeasibleAdd(M, iRow, value);
+      } else if (value > upper + tolerance) {
+        value -= upper;
+        value *= value;
+        infeasibleAdd(M, iRow, value);
+      } else {
+        if (M->infeas[iRow])
+          M->infeas[iRow] = REALLY_TINY;
+      }
+    }
+  }
+  if (M->pivotRule) {
+    int iRow = M->pivotRow;
+    if (M->infeas[iRow])
+      M->infeas[iRow] = REALLY_TINY;
+  }
+  *objectiveChange += changeObj;
+}
+
+/* pack a dense position-space vector, ascending (CoinIndexedVector::scan) */
+static int packDense(double *dense, int m, int *index, double *value)
+{
+  int number = 0;
+  for (int i = 0; i < m; i++) {
+    if (dense[i]) {
+      index[number] = i;
+      value[number++] = dense[i];
+      dense[i] = 0.0;
+    }
+  }
+  return number;
+}
+
+/* ClpDualRowSteepest::updateWeights :375-540 (includes the FTRAN of the entering column, which
+ * ClpFactorization::updateTwoColumnsFT :2889 fuses with the FTRAN of the BTRAN result) */
+static double updateWeights(OrcModel *M)
+{
+  const int m = M->m;
+  double alpha = 0.0;
+  /* FTRAN entering column: rowWork1 holds the unpacked column on entry */
+  ftran(M, M->rowWork1);
+  M->numberW = packDense(M->rowWork1, m, M->wIndex, M->wValue);
+  if (M->pivotRule == 0) {
+    for (int i = 0; i < M->numberW; i++)
+      if (M->wIndex[i] == M->pivotRow) {
+        alpha = M->wValue[i];
+        break;
+      }
+    return alpha;
+  }
+  double norm = 0.0;
+  double *work2 = M->rowWork2;
+  for (int i = 0; i < M->numberPi; i++) {
+    double value = M->piValue[i];
+    norm += value * value;
+    work2[M->piIndex[i]] = value;
+  }
+  ftran(M, work2); /* tau = B^-1 rho */
+  int pivotRow = M->pivotRow;
+  norm /= M->alpha * M->alpha;
+  double multiplier = 2.0 / M->alpha;
+  int nSave = 0;
+  for (int i = 0; i < M->numberW; i++) {
+    int iRow = M->wIndex[i];
+    double theta = M->wValue[i];
+    if (iRow == pivotRow)
+      alpha = theta;
+    double devex = M->weights[iRow];
+    M->altWeightValue[nSave] = devex;
+    M->altWeightIndex[nSave++] = iRow;
+    double value = work2[iRow];
+    devex += theta * (theta * norm + value * multiplier);
+    if (devex < DEVEX_TRY_NORM)
+      devex = DEVEX_TRY_NORM;
+    M->weights[iRow] = devex;
+  }
+  M->numberAlt = nSave;
+  if (norm < DEVEX_TRY_NORM)
+    norm = DEVEX_TRY_NORM;
+  M->weights[pivotRow] = norm;
+  memset(work2, 0, sizeof(double) * (size_t)m);
+  return alpha;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* the dual simplex proper                                                                     */
+/* ------------------------------------------------------------------------------------------ */
+
+/* ClpSimplexDual::dualRow :2962-3140 (no free variables, no values pass) */
+static void dualRow(OrcModel *M)
+{
+  M->pivotRow = M->pivotRule ? steepestPivotRow(M) : dantzigPivotRow(M);
+  if (M->pivotRow >= 0) {
+    M->sequenceOut = M->pivotVariable[M->pivotRow];
+    M->valueOut = M->sol[M->sequenceOut];
+    M->lowerOut = M->lower[M->sequenceOut];
+    M->upperOut = M->upper[M->sequenceOut];
+    if (M->valueOut > M->upperOut) {
+      M->directionOut = -1;
+      M->dualOut = M->valueOut - M->upperOut;
+    } else if (M->valueOut < M->lowerOut) {
+      M->directionOut = 1;
+      M->dualOut = M->lowerOut - M->valueOut;
+    } else {
+      if (M->valueOut - M->lowerOut < M->upperOut - M->valueOut) {
+        M->directionOut = 1;
+        M->dualOut = M->lowerOut - M->valueOut;
+      } else {
+        M->directionOut = -1;
+        M->dualOut = M->valueOut - M->upperOut;
+      }
+    }
+  }
+}
+
+/* ClpSimplexDual::dualColumn :4192-4927; the first pass was fused into pricing (spareIntArray_[0]
+ * == -2 path, :4273-4281).  Candidate list is in spare list 0.  Returns bestPossible. */
+static double dualColumn(OrcModel *M, double acceptablePivot)
+{
+  const int top = M->m + M->n; /* the reference uses numberColumns_ as the top of the two lists */
+  int numberPossiblySwapped = 0;
+  int numberRemaining = M->numberCandidates;
+  double totalThru = 0.0;
+  double bestEverPivot = acceptablePivot;
+  int lastSequence = -1;
+  double lastPivot = 0.0;
+  double upperTheta = M->upperThetaFirst;
+  double newTolerance = M->dualTolerance;
+  int modifyCosts = 0;
+  double increaseInObjective = 0.0;
+  int iFlip = 0;
+  int interesting[2], swapped[2];
+  double *array[2], *spare, *spare2;
+  int *indices[2], *index, *index2;
+  array[0] = M->spareValue[0];
+  indices[0] = M->spareIndex[0];
+  array[1] = M->spareValue[1];
+  indices[1] = M->spareIndex[1];
+  spare = array[0];
+  index = indices[0];
+  for (int i = 0; i < 2; i++) {
+    interesting[i] = 0;
+    swapped[i] = top;
+  }
+  double bestPossible = 1.0;
+  M->alpha = 0.0;
+  M->sequenceIn = -1;
+  double tentativeTheta = 1.0e25;
+  interesting[0] = numberRemaining;
+  if (!numberRemaining)
+    return 0.0; /* looks infeasible */
+  int badSumPivots = 0;
+  M->theta = 1.0e50;
+  tentativeTheta = dmax(10.0 * upperTheta, 1.0e-7);
+  while (tentativeTheta < 1.0e22) {
+    double thruThis = 0.0;
+    double bestPivot = acceptablePivot;
+    int bestSequence = -1;
+    numberPossiblySwapped = top;
+    numberRemaining = 0;
+    upperTheta = 1.0e50;
+    spare = array[iFlip];
+    index = indices[iFlip];
+    spare2 = array[1 - iFlip];
+    index2 = indices[1 - iFlip];
+    double increaseInThis = 0.0;
+    for (int i = 0; i < interesting[iFlip]; i++) {
+      int iSequence = index[i];
+      double alpha = spare[i];
+      double oldValue = M->dj[iSequence];
+      double value = oldValue - tentativeTheta * alpha;
+      if (alpha < 0.0) {
+        if (value > newTolerance) {
+          double range = M->upper[iSequence] - M->lower[iSequence];
+          thruThis -= range * alpha;
+          increaseInThis -= (oldValue + M->dualTolerance) * range;
+          spare2[--numberPossiblySwapped] = alpha;
+          index2[numberPossiblySwapped] = iSequence;
+          if (fabs(alpha) > bestPivot) {
+            bestPivot = fabs(alpha);
+            bestSequence = numberPossiblySwapped;
+          }
+        } else {
+          value = oldValue - upperTheta * alpha;
+          if (value > newTolerance && -alpha >= acceptablePivot)
+            upperTheta = (oldValue - newTolerance) / alpha;
+          spare2[numberRemaining] = alpha;
+          index2[numberRemaining++] = iSequence;
+        }
+      } else {
+        if (value < -newTolerance) {
+          double range = M->upper[iSequence] - M->lower[iSequence];
+          thruThis += range * alpha;
+          increaseInThis += (oldValue - M->dualTolerance) * range;
+          spare2[--numberPossiblySwapped] = alpha;
+          index2[numberPossiblySwapped] = iSequence;
+          if (fabs(alpha) > bestPivot) {
+            bestPivot = fabs(alpha);
+            bestSequence = numberPossiblySwapped;
+          }
+        } else {
+          value = oldValue - upperTheta * alpha;
+          if (value < -newTolerance && alpha >= acceptablePivot)
+            upperTheta = (oldValue + newTolerance) / alpha;
+          spare2[numberRemaining] = alpha;
+          index2[numberRemaining++] = iSequence;
+        }
+      }
+    }
+    swapped[1 - iFlip] = numberPossiblySwapped;
+    interesting[1 - iFlip] = numberRemaining;
+    double check = fabs(totalThru + thruThis);
+    check += 1.0e-8 + 1.0e-10 * check;
+    if (check >= fabs(M->dualOut) || increaseInObjective + increaseInThis < 0.0) {
+      /* we should be pivoting in this batch: compress down to this lot */
+      numberRemaining = 0;
+      for (int i = top - 1; i >= swapped[1 - iFlip]; i--) {
+        spare[numberRemaining] = spare2[i];
+        index[numberRemaining++] = index2[i];
+      }
+      interesting[iFlip] = numberRemaining;
+      int iTry;
+      const int MAXTRY = 100;
+      for (iTry = 0; iTry < MAXTRY; iTry++) {
+        upperTheta = 1.0e50;
+        numberPossiblySwapped = top;
+        numberRemaining = 0;
+        increaseInThis = 0.0;
+        thruThis = 0.0;
+        spare = array[iFlip];
+        index = indices[iFlip];
+        spare2 = array[1 - iFlip];
+        index2 = indices[1 - iFlip];
+        for (int i = 0; i < interesting[iFlip]; i++) {
+          int iSequence = index[i];
+          double alpha = spare[i];
+          double oldValue = M->dj[iSequence];
+          double value = oldValue - upperTheta * alpha;
+          if (alpha < 0.0) {
+            if (value > newTolerance) {
+              if (-alpha >= acceptablePivot)
+                upperTheta = (oldValue - newTolerance) / alpha;
+            }
+          } else {
+            if (value < -newTolerance) {
+              if (alpha >= acceptablePivot)
+                upperTheta = (oldValue + newTolerance) / alpha;
+            }
+          }
+        }
+        bestPivot = acceptablePivot;
+        M->sequenceIn = -1;
+        double largestPivot = acceptablePivot;
+        double sumBadPivots = 0.0;
+        badSumPivots = 0;
+        upperTheta *= 1.0000000001;
+        for (int i = 0; i < interesting[iFlip]; i++) {
+          int iSequence = index[i];
+          double alpha = spare[i];
+          double value = M->dj[iSequence] - upperTheta * alpha;
+          double badDj = 0.0;
+          int addToSwapped = 0;
+          if (alpha < 0.0) {
+            if (value >= 0.0) {
+              addToSwapped = 1;
+              badDj = -M->dj[iSequence] - M->dualTolerance;
+            }
+          } else {
+            if (value <= 0.0) {
+              addToSwapped = 1;
+              badDj = M->dj[iSequence] - M->dualTolerance;
+            }
+          }
+          if (!addToSwapped) {
+            spare2[numberRemaining] = alpha;
+            index2[numberRemaining++] = iSequence;
+          } else {
+            spare2[--numberPossiblySwapped] = alpha;
+            index2[numberPossiblySwapped] = iSequence;
+            int take = 0;
+            double absAlpha = fabs(alpha);
+            if (absAlpha > bestPivot)
+              take = 1;
+            if (absAlpha < acceptablePivot && upperTheta < 1.0e20) {
+              if (alpha < 0.0) {
+                if (value > M->dualTolerance) {
+                  double gap = M->upper[iSequence] - M->lower[iSequence];
+                  if (gap < 1.0e20)
+                    sumBadPivots += value * gap;
+                  else
+                    sumBadPivots += 1.0e20;
+                }
+              } else {
+                if (value < -M->dualTolerance) {
+                  double gap = M->upper[iSequence] - M->lower[iSequence];
+                  if (gap < 1.0e20)
+                    sumBadPivots -= value * gap;
+                  else
+                    sumBadPivots += 1.0e20;
+                }
+              }
+            }
+            if (take) {
+              M->sequenceIn = numberPossiblySwapped;
+              bestPivot = absAlpha;
+              M->theta = M->dj[iSequence] / alpha;
+              largestPivot = dmax(largestPivot, 0.5 * bestPivot);
+            }
+            double range = M->upper[iSequence] - M->lower[iSequence];
+            thruThis += range * fabs(alpha);
+            increaseInThis += badDj * range;
+          }
+        }
+        if (sumBadPivots > 1.0e4) {
+          if (M->fac.nEta > 3) {
+            badSumPivots = 1;
+            break;
+          }
+        }
+        swapped[1 - iFlip] = numberPossiblySwapped;
+        interesting[1 - iFlip] = numberRemaining;
+        double increase = (fabs(M->dualOut) - totalThru) * M->theta;
+        increase += increaseInObjective;
+        if (M->theta < 0.0)
+          thruThis += fabs(M->dualOut);
+        if (increaseInObjective < 0.0 && increase < 0.0 && lastSequence >= 0) {
+          bestPivot = 0.0;
+        } else {
+          totalThru += thruThis;
+          increaseInObjective += increaseInThis;
+        }
+        if (bestPivot < 0.1 * bestEverPivot && bestEverPivot > 1.0e-6 && (bestPivot < 1.0e-3 || totalThru * 2.0 > fabs(M->dualOut))) {
+          M->sequenceIn = lastSequence;
+          iFlip = 1 - iFlip;
+          break;
+        } else if (M->sequenceIn == -1 && upperTheta > M->largeValue) {
+          if (lastPivot > acceptablePivot) {
+            M->sequenceIn = lastSequence;
+            iFlip = 1 - iFlip;
+          }
+          break;
+        } else if (totalThru >= fabs(M->dualOut)) {
+          modifyCosts = 1;
+          break;
+        } else {
+          lastSequence = M->sequenceIn;
+          if (bestPivot > bestEverPivot)
+            bestEverPivot = bestPivot;
+          iFlip = 1 - iFlip;
+          modifyCosts = 1;
+        }
+      }
+      if (iTry == MAXTRY)
+        iFlip = 1 - iFlip;
+      break;
+    } else {
+      /* skip this lot */
+      if (bestPivot > 1.0e-3 || bestPivot > bestEverPivot) {
+        bestEverPivot = bestPivot;
+        lastSequence = bestSequence;
+      } else {
+        /* keep old swapped */
+        memcpy(array[1 - iFlip] + swapped[iFlip], array[iFlip] + swapped[iFlip], sizeof(double) * (size_t)(top - swapped[iFlip]));
+        memcpy(indices[1 - iFlip] + swapped[iFlip], indices[iFlip] + swapped[iFlip], sizeof(int) * (size_t)(top - swapped[iFlip]));
+        swapped[1 - iFlip] = swapped[iFlip];
+      }
+      increaseInObjective += increaseInThis;
+      iFlip = 1 - iFlip;
+      tentativeTheta = 2.0 * upperTheta;
+      totalThru += thruThis;
+    }
+  }
+  if (M->sequenceIn < 0 && lastSequence >= 0) {
+    M->sequenceIn = lastSequence;
+    iFlip = 1 - iFlip;
+  }
+  double minimumTheta = (M->upperOut > M->lowerOut) ? 1.0e-18 : 0.0;
+  if (M->sequenceIn >= 0) {
+    iFlip = 1 - iFlip;
+    spare = array[iFlip];
+    index = indices[iFlip];
+    M->alpha = spare[M->sequenceIn];
+    M->sequenceIn = index[M->sequenceIn];
+    double oldValue = M->dj[M->sequenceIn];
+    M->theta = dmax(oldValue / M->alpha, 0.0);
+    if (M->theta < minimumTheta && fabs(M->alpha) < 1.0e5)
+      M->theta = minimumTheta;
+    if (modifyCosts && !badSumPivots) {
+      for (int i = top - 1; i >= swapped[iFlip]; i--) {
+        int iSequence = index[i];
+        double alpha = spare[i];
+        double value = M->dj[iSequence] - M->theta * alpha;
+        if (alpha < 0.0) {
+          if (value > M->dualTolerance) {
+            double modification = alpha * M->theta - M->dj[iSequence] + newTolerance;
+            M->dj[iSequence] += modification;
+            M->cost[iSequence] += modification;
+            if (modification)
+              M->numberChanged++;
+          }
+        } else {
+          if (-value > M->dualTolerance) {
+            double modification = alpha * M->theta - M->dj[iSequence] - newTolerance;
+            M->dj[iSequence] += modification;
+            M->cost[iSequence] += modification;
+            if (modification)
+              M->numberChanged++;
+          }
+        }
+      }
+    }
+  }
+  if (badSumPivots && M->fac.nEta) {
+    M->sequenceIn = -1;
+    M->acceptablePivot_ = -M->acceptablePivot_;
+  }
+  if (M->sequenceIn >= 0) {
+    M->lowerIn = M->lower[M->sequenceIn];
+    M->upperIn = M->upper[M->sequenceIn];
+    M->valueIn = M->sol[M->sequenceIn];
+    M->dualIn = M->dj[M->sequenceIn];
+    /* MODIFYCOST > 1: modify cost to hit zero exactly (:4796-4834) */
+    double modification = M->theta * M->alpha - M->dualIn;
+    double moveObjective = fabs(modification * M->sol[M->sequenceIn]);
+    double smallMove = dmax(fabs(M->objectiveValue), 1.0e-3);
+    if (moveObjective > smallMove)
+      modification *= smallMove / moveObjective;
+    if (badSumPivots)
+      modification = 0.0;
+    M->dualIn += modification;
+    M->dj[M->sequenceIn] = M->dualIn;
+    M->cost[M->sequenceIn] += modification;
+    if (modification)
+      M->numberChanged++;
+    if (M->alpha < 0.0) {
+      M->directionIn = -1;
+      M->upperIn = M->valueIn;
+    } else {
+      M->directionIn = 1;
+      M->lowerIn = M->valueIn;
+    }
+    if (fabs(M->alpha) < 1.0e-6) {
+      /* need bestPossible (:4851-4908) */
+      bestPossible = 0.0;
+      const double tent = 1.0e25, dualT = -M->dualTolerance;
+      for (int iSection = 0; iSection < 2; iSection++) {
+        int number = iSection ? M->numberColNz : M->numberPi;
+        const int *which = iSection ? M->colIndex : M->piIndex;
+        const double *work = iSection ? M->colValue : M->piValue;
+        int addSequence = iSection ? 0 : M->n;
+        for (int i = 0; i < number; i++) {
+          int iSequence = which[i] + addSequence;
+          int st = getStatus(M, iSequence);
+          double mult = 1.0;
+          if (st == ST_UPPER)
+            mult = -1.0;
+          if (st == ST_UPPER || st == ST_LOWER) {
+            double alpha = work[i] * mult;
+            if (alpha > 0.0) {
+              double oldValue = M->dj[iSequence] * mult;
+              double value = oldValue - tent * alpha;
+              if (value < dualT)
+                bestPossible = dmax(bestPossible, alpha);
+            }
+          }
+        }
+      }
+    } else {
+      bestPossible = fabs(M->alpha);
+    }
+  } else {
+    bestPossible = 0.0;
+    M->alpha = 0.0;
+  }
+  return bestPossible;
+}
+
+/* ClpSimplexDual::flipBounds :6345-6401 */
+static void flipBounds(OrcModel *M)
+{
+  for (int iSection = 0; iSection < 2; iSection++) {
+    int number = iSection ? M->numberColFlip : M->numberRowFlip;
+    const int *which = iSection ? M->colFlip : M->rowFlip;
+    int addSequence = iSection ? 0 : M->n;
+    for (int i = 0; i < number; i++) {
+      int iSequence = which[i] + addSequence;
+      int st = getStatus(M, iSequence);
+      if (st == ST_UPPER) {
+        setStatus(M, iSequence, ST_LOWER);
+        M->sol[iSequence] = M->lower[iSequence];
+      } else if (st == ST_LOWER) {
+        setStatus(M, iSequence, ST_UPPER);
+        M->sol[iSequence] = M->upper[iSequence];
+      }
+    }
+  }
+  M->numberRowFlip = 0;
+  M->numberColFlip = 0;
+}
+
+/* ClpSimplexDual::updateDualsInDual :2430-2883.  outputArray (dense, length m) gets the rhs
+ * movement of the flips.  Returns number of flips. */
+static int updateDualsInDual(OrcModel *M, double *outputArray, double theta, double *objectiveChange, int fullRecompute)
+{
+  const int n = M->n, m = M->m;
+  int numberInfeasibilities = 0;
+  double tolerance = M->dualTolerance + dmin(1.0e-2, M->largestDualError);
+  double changeObj = 0.0;
+  M->numberRowFlip = 0;
+  M->numberColFlip = 0;
+  if (!fullRecompute) {
+    {
+      double *reducedCost = M->dj + n;
+      const double *lower = M->lower + n, *upper = M->upper + n, *cost = M->cost + n;
+      const unsigned char *statusArray = M->status + n;
+      const double multiplier[] = { 0.0, 0.0, -1.0, 1.0 };
+      for (int i = 0; i < M->numberPi; i++) {
+        int iSequence = M->piIndex[i];
+        double alphaI = M->piValue[i];
+        int iStatus = (statusArray[iSequence] & 3) - 1;
+        if (iStatus) {
+          double value = reducedCost[iSequence] - theta * alphaI;
+          reducedCost[iSequence] = value;
+          double mult = multiplier[iStatus + 1];
+          value *= mult;
+          if (value < -tolerance) {
+            double movement = mult * (lower[iSequence] - upper[iSequence]);
+            M->rowFlip[M->numberRowFlip++] = iSequence;
+            changeObj -= movement * cost[iSequence];
+            outputArray[iSequence] += movement;
+          }
+        }
+      }
+    }
+    {
+      double *reducedCost = M->dj;
+      const double *lower = M->lower, *upper = M->upper, *cost = M->cost;
+      const unsigned char *statusArray = M->status;
+      const double multiplier[] = { -1.0, 1.0, -1.0, 1.0 }; /* [0],[1] overwritten as in :2500 */
+      for (int i = 0; i < M->numberColNz; i++) {
+        int iSequence = M->colIndex[i];
+        double alphaI = M->colValue[i];
+        int iStatus = (statusArray[iSequence] & 3) - 1;
+        if (iStatus) {
+          double value = reducedCost[iSequence] - theta * alphaI;
+          reducedCost[iSequence] = value;
+          double mult = multiplier[iStatus + 1];
+          value *= mult;
+          if (value < -tolerance && iStatus > 0) {
+            double movement = mult * (upper[iSequence] - lower[iSequence]);
+            M->colFlip[M->numberColFlip++] = iSequence;
+            changeObj += movement * cost[iSequence];
+            addColumn(M, outputArray, iSequence, movement);
+          }
+        }
+      }
+    }
+    numberInfeasibilities = M->numberRowFlip + M->numberColFlip;
+    M->numberPi = 0;
+    M->numberColNz = 0;
+  } else {
+    /* :2648-2868, with TRY_SET_FAKE */
+    for (int iSection = 0; iSection < 2; iSection++) {
+      int lo = iSection ? 0 : n, hi = iSection ? n : n + m;
+      for (int iSequence = lo; iSequence < hi; iSequence++) {
+        double value = M->dj[iSequence];
+        int st = getStatus(M, iSequence);
+        double movement = 0.0;
+        int flip = 0;
+        if (st == ST_UPPER) {
+          if (value > tolerance) {
+            flip = 1;
+            movement = M->lower[iSequence] - M->upper[iSequence];
+            if (fabs(movement) > M->dualBound) {
+              if (getFake(M, iSequence) == FAKE_NONE) {
+                setFake(M, iSequence, FAKE_LOWER);
+                M->lower[iSequence] = M->upper[iSequence] - M->dualBound;
+                movement = M->lower[iSequence] - M->upper[iSequence];
+                M->numberFake++;
+              }
+            }
+          } else if (value > -tolerance) {
+            if (getFake(M, iSequence) == FAKE_UPPER) {
+              movement = M->lower[iSequence] - M->upper[iSequence];
+              setStatus(M, iSequence, ST_LOWER);
+              M->sol[iSequence] = M->lower[iSequence];
+              changeObj += movement * M->cost[iSequence];
+            }
+          }
+        } else if (st == ST_LOWER) {
+          if (value < -tolerance) {
+            flip = 1;
+            movement = M->upper[iSequence] - M->lower[iSequence];
+            if (fabs(movement) > M->dualBound) {
+              if (getFake(M, iSequence) == FAKE_NONE) {
+                setFake(M, iSequence, FAKE_UPPER);
+                M->upper[iSequence] = M->lower[iSequence] + M->dualBound;
+                movement = M->upper[iSequence] - M->lower[iSequence];
+                M->numberFake++;
+              }
+            }
+          } else if (value < tolerance) {
+            if (getFake(M, iSequence) == FAKE_LOWER) {
+              movement = M->upper[iSequence] - M->lower[iSequence];
+              setStatus(M, iSequence, ST_UPPER);
+              M->sol[iSequence] = M->upper[iSequence];
+              changeObj += movement * M->cost[iSequence];
+            }
+          }
+        }
+        if (flip) {
+          changeObj += movement * M->cost[iSequence];
+          if (iSection) {
+            M->colFlip[M->numberColFlip++] = iSequence;
+            addColumn(M, outputArray, iSequence, movement);
+          } else {
+            M->rowFlip[M->numberRowFlip++] = iSequence - n;
+            outputArray[iSequence - n] += -movement;
+          }
+        }
+      }
+    }
+    numberInfeasibilities = M->numberRowFlip + M->numberColFlip;
+    flipBounds(M);
+  }
+  *objectiveChange += changeObj;
+  return numberInfeasibilities;
+}
+
+static void logPivot(OrcModel *M, int numberFlipped)
+{
+  if (M->logCount == M->logCap) {
+    M->logCap = M->logCap ? 2 * M->logCap : 1024;
+    M->log = (OrcPivotRecord *)realloc(M->log, sizeof(OrcPivotRecord) * (size_t)M->logCap);
+  }
+  OrcPivotRecord *r = &M->log[M->logCount++];
+  r->iteration = M->numberIterations;
+  r->sequenceIn = M->sequenceIn;
+  r->sequenceOut = M->sequenceOut;
+  r->pivotRow = M->pivotRow;
+  r->numberFlipped = numberFlipped;
+  r->reserved = 0;
+  r->theta = M->theta;
+  r->alpha = M->alpha;
+  r->dualOut = M->dualOut;
+  r->objective = M->objectiveValue;
+  if (M->logLevel > 7) {
+    printf("%d %.10g In: %c%d Out: %c%d theta %g alpha %g\n", M->numberIterations, M->objectiveValue,
+           M->sequenceIn < M->n ? 'C' : 'R', M->sequenceIn < M->n ? M->sequenceIn : M->sequenceIn - M->n,
+           M->sequenceOut < M->n ? 'C' : 'R', M->sequenceOut < M->n ? M->sequenceOut : M->sequenceOut - M->n, M->theta,
+           M->alpha);
+  }
+}
+
+/* ClpSimplex::housekeeping :2065-2489 (no cycle check).  Returns 0 carry on, 1 refactorize,
+ * 2 iteration limit. */
+static int housekeeping(OrcModel *M, double objectiveChange, int numberFlipped)
+{
+  M->numberIterations++;
+  if (M->pivotRow >= 0)
+    M->pivotVariable[M->pivotRow] = M->sequenceIn;
+  M->sol[M->sequenceIn] = M->valueIn;
+  if (M->sequenceIn != M->sequenceOut) {
+    setStatus(M, M->sequenceIn, ST_BASIC);
+    if (M->upper[M->sequenceOut] - M->lower[M->sequenceOut] > 0) {
+      if (fabs(M->valueOut - M->lower[M->sequenceOut]) < fabs(M->valueOut - M->upper[M->sequenceOut]))
+        setStatus(M, M->sequenceOut, ST_LOWER);
+      else
+        setStatus(M, M->sequenceOut, ST_UPPER);
+    } else {
+      setStatus(M, M->sequenceOut, ST_FIXED);
+    }
+    M->sol[M->sequenceOut] = M->valueOut;
+  } else {
+    if (fabs(M->valueIn - M->lower[M->sequenceIn]) < fabs(M->valueIn - M->upper[M->sequenceIn]))
+      setStatus(M, M->sequenceIn, ST_LOWER);
+    else
+      setStatus(M, M->sequenceIn, ST_UPPER);
+  }
+  M->objectiveValue += objectiveChange;
+  logPivot(M, numberFlipped);
+  if (M->numberIterations >= M->maximumIterations)
+    return 2;
+  int numberPivots = M->fac.nEta;
+  if (numberPivots == M->maximumPivots || M->maximumPivots < 2) {
+    return 1;
+  } else if (M->forceFactorization > 0 && numberPivots == M->forceFactorization) {
+    M->forceFactorization = (3 + 5 * M->forceFactorization) / 4;
+    if (M->forceFactorization > M->maximumPivots)
+      M->forceFactorization = -1;
+    return 1;
+  }
+  /* the randomised early refactorization after 1000+10*(m+n/4) iterations (:2469-2484) */
+  if (M->numberIterations > 1000 + 10 * (M->m + (M->n >> 2))) {
+    double random = randomDouble(M);
+    while (random < 0.45)
+      random *= 2.0;
+    int maxNumber = (M->forceFactorization < 0) ? M->maximumPivots : (M->forceFactorization < M->maximumPivots ? M->forceFactorization : M->maximumPivots);
+    if (numberPivots >= random * maxNumber)
+      return 1;
+  }
+  return 0;
+}
+
+/* unpackPacked: entering column into dense rowWork1 (ClpSimplex::unpackPacked :3439-3495) */
+static void unpackColumn(OrcModel *M, double *dense, int iSequence)
+{
+  if (iSequence >= M->n) {
+    dense[iSequence - M->n] = -1.0;
+  } else {
+    for (int p = M->colStart[iSequence]; p < M->colStart[iSequence + 1]; p++)
+      dense[M->row[p]] = M->elem[p];
+  }
+}
+
+/* ClpSimplexDual::whileIterating :973-2384.  Returns returnCode. */
+static int whileIterating(OrcModel *M)
+{
+  const int m = M->m;
+  int returnCode = -1;
+  double saveSumDual = M->sumDualInfeasibilities;
+  while (M->problemStatus == -1) {
+    dualRow(M);
+    if (M->pivotRow >= 0) {
+      double acceptablePivot = 1.0e-1 * M->acceptablePivot_;
+      if (M->numberIterations > 100)
+        acceptablePivot = M->acceptablePivot_;
+      int pivots = M->fac.nEta;
+      if (pivots > 10 || (pivots && saveSumDual))
+        acceptablePivot = 1.0e+3 * M->acceptablePivot_;
+      else if (pivots > 5)
+        acceptablePivot = 1.0e+2 * M->acceptablePivot_;
+      else if (pivots)
+        acceptablePivot = M->acceptablePivot_;
+      double bestPossiblePivot = 1.0;
+      /* BTRAN: rho = B^-T (directionOut * e_r) (:1286-1288) */
+      double *work = M->rowWork0;
+      work[M->pivotRow] = (double)M->directionOut;
+      btran(M, work);
+      M->numberPi = 0;
+      for (int i = 0; i < m; i++) {
+        double value = work[i];
+        work[i] = 0.0;
+        if (fabs(value) > M->zeroTolerance) { /* packed output drops tiny (CoinFactorization BTRAN) */
+          M->piIndex[M->numberPi] = i;
+          M->piValue[M->numberPi++] = value;
+        }
+      }
+      M->sequenceIn = -1;
+      /* row of tableau + first ratio pass (:1300) */
+      M->numberColNz = priceRowFused(M, M->numberPi, M->piIndex, M->piValue, M->rowWork1, M->status, M->dj, M->zeroTolerance,
+                                     M->dualTolerance, acceptablePivot, M->colIndex, M->colValue, &M->numberCandidates,
+                                     M->spareIndex[0], M->spareValue[0], &M->upperThetaFirst);
+      bestPossiblePivot = dualColumn(M, acceptablePivot);
+      if (M->sequenceIn < 0 && acceptablePivot <= M->acceptablePivot_) {
+        if (!M->fac.nEta)
+          M->problemStatus = 1;
+      }
+      if (M->sequenceIn >= 0) {
+        double btranAlpha = -M->alpha * M->directionOut;
+        unpackColumn(M, M->rowWork1, M->sequenceIn);
+        M->alpha = updateWeights(M);
+        double checkValue = 1.0e-7;
+        if (M->largestPrimalError > 10.0)
+          checkValue = dmin(1.0e-4, 1.0e-8 * M->largestPrimalError);
+        if (fabs(btranAlpha) < 1.0e-12 || fabs(M->alpha) < 1.0e-12 || fabs(btranAlpha - M->alpha) > checkValue * (1.0 + fabs(M->alpha))) {
+          if (M->fac.nEta) {
+            unrollWeights(M);
+            M->problemStatus = -2;
+            M->numberPi = M->numberColNz = M->numberW = 0;
+            returnCode = -2;
+            break;
+          } else {
+            double test;
+            if (fabs(btranAlpha) < 1.0e-8 || fabs(M->alpha) < 1.0e-8)
+              test = 1.0e-1 * fabs(M->alpha);
+            else
+              test = 1.0e-4 * (1.0 + fabs(M->alpha));
+            if (fabs(btranAlpha) < 1.0e-12 || fabs(M->alpha) < 1.0e-12 || fabs(btranAlpha - M->alpha) > test) {
+              unrollWeights(M);
+              setFlagged(M, M->sequenceOut);
+              M->lastBadIteration = M->numberIterations;
+              M->numberPi = M->numberColNz = M->numberW = 0;
+              if (fabs(M->alpha) < 1.0e-10 && fabs(btranAlpha) < 1.0e-8 && M->numberIterations > 100) {
+                M->problemStatus = 1;
+                returnCode = 1;
+                break;
+              }
+              continue;
+            }
+          }
+        }
+        double objectiveChange = 0.0;
+        int saveStatus = getStatus(M, M->sequenceIn);
+        setStatus(M, M->sequenceIn, ST_BASIC);
+        double *flipRhs = M->rowWork2;
+        int nswapped = updateDualsInDual(M, flipRhs, M->theta, &objectiveChange, 0);
+        setStatus(M, M->sequenceIn, saveStatus);
+        double oldDualOut = M->dualOut;
+        if (nswapped) {
+          ftran(M, flipRhs);
+          int nf = packDense(flipRhs, m, M->piIndex, M->piValue);
+          updatePrimalSolution(M, M->piIndex, M->piValue, nf, 1.0, &objectiveChange);
+          M->valueOut = M->sol[M->sequenceOut];
+          if (M->directionOut < 0)
+            M->dualOut = M->valueOut - M->upperOut;
+          else
+            M->dualOut = M->lowerOut - M->valueOut;
+        }
+        double movement = -M->dualOut * M->directionOut / M->alpha;
+        double movementOld = oldDualOut * M->directionOut / M->alpha;
+        if (objectiveChange + fabs(movementOld * M->dualIn) < -dmax(1.0e-5, 1.0e-12 * fabs(M->objectiveValue))) {
+          if (M->fac.nEta) {
+            unrollWeights(M);
+            M->problemStatus = -2;
+            M->numberW = 0;
+            M->numberRowFlip = M->numberColFlip = 0;
+            returnCode = -2;
+            break;
+          }
+        }
+        int updateStatus = replaceColumn(M, M->wIndex, M->wValue, M->numberW, M->pivotRow, M->alpha);
+        if (fabs(M->dualOut) > 1.0e50)
+          updateStatus = 2;
+        if (updateStatus == 2 && !M->fac.nEta && fabs(M->alpha) > 1.0e-5)
+          updateStatus = 4;
+        if (updateStatus == 1 || updateStatus == 4) {
+          if (M->fac.nEta > 5 || updateStatus == 4) {
+            M->problemStatus = -2;
+            returnCode = -3;
+          }
+        } else if (updateStatus == 2) {
+          unrollWeights(M);
+          if (M->fac.nEta) {
+            M->problemStatus = -2;
+            returnCode = -2;
+            M->numberW = 0;
+            M->numberRowFlip = M->numberColFlip = 0;
+            break;
+          } else {
+            setFlagged(M, M->sequenceOut);
+            M->lastBadIteration = M->numberIterations;
+            M->numberW = 0;
+            double oc = 0.0;
+            memset(M->rowWork2, 0, sizeof(double) * (size_t)m);
+            updateDualsInDual(M, M->rowWork2, 0.0, &oc, 1);
+            memset(M->rowWork2, 0, sizeof(double) * (size_t)m);
+            continue;
+          }
+        } else if (updateStatus == 3 || updateStatus == 5) {
+          M->problemStatus = -2;
+        }
+        if (M->theta < 0.0)
+          M->theta = 0.0;
+        int numberFlipped = M->numberRowFlip + M->numberColFlip;
+        flipBounds(M);
+        updatePrimalSolution(M, M->wIndex, M->wValue, M->numberW, movement, &objectiveChange);
+        M->numberW = 0;
+        M->dualOut /= M->alpha;
+        M->dualOut *= -M->directionOut;
+        M->dj[M->sequenceIn] = 0.0;
+        double oldValue = M->valueIn;
+        if (M->directionIn == -1)
+          M->valueIn = M->upperIn + M->dualOut;
+        else
+          M->valueIn = M->lowerIn + M->dualOut;
+        objectiveChange += M->cost[M->sequenceIn] * (M->valueIn - oldValue);
+        if (M->directionOut > 0) {
+          M->valueOut = M->lowerOut;
+          M->dj[M->sequenceOut] = M->theta;
+        } else {
+          M->valueOut = M->upperOut;
+          M->dj[M->sequenceOut] = -M->theta;
+        }
+        M->sol[M->sequenceOut] = M->valueOut;
+        int whatNext = housekeeping(M, objectiveChange, numberFlipped);
+        originalBound(M, M->sequenceIn);
+        changeBound(M, M->sequenceOut);
+        if (whatNext == 1) {
+          M->problemStatus = -2;
+        } else if (whatNext == 2) {
+          M->problemStatus = 3;
+          returnCode = 3;
+          break;
+        }
+      } else {
+        /* no incoming column is valid (:1869-2079) */
+        M->pivotRow = -1;
+        M->numberPi = M->numberColNz = 0;
+        if (M->fac.nEta < 2 && M->acceptablePivot_ <= 1.0e-8 && M->acceptablePivot_ > 0.0) {
+          double dualTest = 1.0e13;
+          if (!numberAtFakeBound(M))
+            dualTest = 0.0;
+          if (bestPossiblePivot < 1.0e-11 && M->dualBound > dualTest) {
+            M->problemStatus = 1;
+            returnCode = 1;
+            break;
+          }
+          if (M->fac.nEta == 0)
+            M->problemStatus = -4;
+        }
+        M->acceptablePivot_ = fabs(M->acceptablePivot_);
+        if (M->fac.nEta < 5 && M->acceptablePivot_ > 1.0e-8)
+          M->acceptablePivot_ = 1.0e-8;
+        returnCode = 1;
+        break;
+      }
+    } else {
+      /* no pivot row (:2080-2331) */
+      int numberPivots = M->fac.nEta;
+      returnCode = 0;
+      if (!numberPivots) {
+        if (M->numberPrimalInfeasibilities && M->problemStatus == -1)
+          M->problemStatus = -4;
+        int iRow;
+        for (iRow = 0; iRow < m; iRow++)
+          if (flagged(M, M->pivotVariable[iRow]))
+            break;
+        if (M->numberFake || M->numberDualInfeasibilities) {
+          M->problemStatus = -5;
+        } else {
+          if (iRow < m) {
+            M->problemStatus = -5;
+          } else {
+            M->problemStatus = 0;
+            M->numberPrimalInfeasibilities = 0;
+            M->sumPrimalInfeasibilities = 0.0;
+            M->numberDualInfeasibilities = 0;
+            M->sumDualInfeasibilities = 0.0;
+            if (M->numberChanged) {
+              /* costs were modified: restore (createRim4) and recheck (:2222-2236) */
+              M->numberChanged = 0;
+              for (int j = 0; j < M->n; j++)
+                M->cost[j] = M->obj[j];
+              for (int i = 0; i < m; i++)
+                M->cost[M->n + i] = 0.0;
+              computeDuals(M);
+              checkDualSolution(M);
+              if (M->numberDualInfeasibilities)
+                M->problemStatus = 10;
+              else
+                checkPrimalSolution(M); /* computeObjectiveValue */
+            }
+          }
+        }
+      } else {
+        M->problemStatus = -3;
+        returnCode = -2;
+        int half = (numberPivots + 1) >> 1;
+        if (M->forceFactorization < 0 || half < M->forceFactorization)
+          M->forceFactorization = half;
+      }
+      break;
+    }
+  }
+  return returnCode;
+}
+
+/* ClpSimplexDual::statusOfProblemInDual :4996-6343, the parts that matter without perturbation,
+ * values pass, Cbc options or primal fallback. */
+static void statusOfProblemInDual(OrcModel *M, int *lastCleaned, int type)
+{
+  const int m = M->m, n = M->n;
+  int numberPivots = M->fac.nEta;
+  int tentativeStatus = M->problemStatus;
+  int weightsSaved = 0;
+  double changeCost = 0.0;
+  if (M->problemStatus > -3 || numberPivots > 0) {
+    saveWeights(M, 1);
+    weightsSaved = 1;
+    if (type) {
+      int rc = factorize(M);
+      if (rc) {
+        M->problemStatus = 4; /* singular basis: the reference restores the previous basis and flags */
+        return;
+      }
+    }
+    if (M->problemStatus != -4 || numberPivots > 10)
+      M->problemStatus = -3;
+  }
+  if (type)
+    gutsOfSolution(M);
+  int situationChanged = 0;
+  int needCleanFake = 0;
+  double saveDualBound = M->dualBound;
+  while (M->problemStatus <= -3 && saveDualBound == M->dualBound) {
+    int cleanDuals = 0;
+    if (situationChanged != 0)
+      cleanDuals = 1;
+    int numberChangedBounds = 0;
+    int doOriginalTolerance = 0;
+    if (*lastCleaned == M->numberIterations)
+      doOriginalTolerance = 1;
+    if (M->sumOfRelaxedDualInfeasibilities == 0.0 && M->sumOfRelaxedPrimalInfeasibilities == 0.0) {
+      M->numberDualInfeasibilities = 0;
+      M->sumDualInfeasibilities = 0.0;
+      M->numberPrimalInfeasibilities = 0;
+      M->sumPrimalInfeasibilities = 0.0;
+    }
+    if (M->numberDualInfeasibilities == 0 || M->problemStatus == -4) {
+      if (M->numberPrimalInfeasibilities == 0) {
+        /* may be optimal - or may be bounds are wrong (:5689-5764) */
+        memset(M->rowWork3, 0, sizeof(double) * (size_t)m);
+        numberChangedBounds = (M->dualBound < 1.0e20) ? changeBounds(M, 0, M->rowWork3, &changeCost) : 0;
+        memset(M->rowWork3, 0, sizeof(double) * (size_t)m);
+        if (numberChangedBounds <= 0 && !M->numberDualInfeasibilities) {
+          if (*lastCleaned < M->numberIterations && M->numberTimesOptimal < 4) {
+            doOriginalTolerance = 2;
+            M->numberTimesOptimal++;
+            if (M->numberTimesOptimal == 1) {
+              M->dualTolerance = M->dualToleranceBase;
+            } else {
+              M->dualTolerance = M->dualToleranceBase * pow(2.0, M->numberTimesOptimal - 1);
+            }
+            cleanDuals = 2; /* if nothing changed optimal else primal */
+          } else {
+            M->problemStatus = 0; /* optimal */
+          }
+        } else {
+          cleanDuals = 1;
+          if (doOriginalTolerance == 1) {
+            /* checkUnbounded path (:5766-5826): without free variables we only get here with
+               genuinely active fake bounds -> dual infeasible if the bound is already huge */
+            if (M->dualBound > 1.0e17)
+              M->problemStatus = 2;
+            else
+              M->problemStatus = -3;
+          } else {
+            doOriginalTolerance = 2;
+          }
+        }
+      }
+      if (M->problemStatus == -4 || M->problemStatus == -5) {
+        numberChangedBounds = changeBounds(M, 0, NULL, &changeCost);
+        needCleanFake = 1;
+        if ((numberChangedBounds <= 0 || M->dualBound > 1.0e20 || (M->largestPrimalError > 1.0 && M->dualBound > 1.0e17))
+            && (numberPivots < 4 || M->sumPrimalInfeasibilities > 1.0e-6)) {
+          M->problemStatus = 1; /* infeasible */
+          if (!M->numberPrimalInfeasibilities) {
+            M->problemStatus = -1;
+            doOriginalTolerance = 2;
+          }
+        } else {
+          M->problemStatus = -1;
+          cleanDuals = 1;
+          if (numberChangedBounds <= 0)
+            doOriginalTolerance = 2;
+        }
+      }
+    } else {
+      cleanDuals = 1;
+    }
+    if (M->problemStatus < 0) {
+      if (doOriginalTolerance == 2) {
+        *lastCleaned = M->numberIterations;
+        M->numberChanged = 0;
+        /* createRim4(false): original costs back */
+        for (int j = 0; j < n; j++)
+          M->cost[j] = M->obj[j];
+        for (int i = 0; i < m; i++)
+          M->cost[n + i] = 0.0;
+        computeDuals(M);
+        checkDualSolution(M);
+        if (cleanDuals != 2) {
+          changeBounds(M, 3, NULL, &changeCost);
+          needCleanFake = 1;
+          cleanDuals = 2;
+        }
+      }
+      if (cleanDuals == 1 || (cleanDuals == 2 && !M->numberDualInfeasibilities)) {
+        double objectiveChange = 0.0;
+        memset(M->rowWork2, 0, sizeof(double) * (size_t)m);
+        updateDualsInDual(M, M->rowWork2, 0.0, &objectiveChange, 1);
+        memset(M->rowWork2, 0, sizeof(double) * (size_t)m);
+        gutsOfSolution(M);
+        updateDualsInDual(M, M->rowWork2, 0.0, &objectiveChange, 1);
+        memset(M->rowWork2, 0, sizeof(double) * (size_t)m);
+        if (M->numberDualInfeasibilities) {
+          if ((M->numberPrimalInfeasibilities || numberPivots) && M->problemStatus != 10)
+            M->problemStatus = -1;
+          else
+            M->problemStatus = 10;
+        } else if (situationChanged == 2) {
+          M->problemStatus = -1;
+          changeBounds(M, 3, NULL, &changeCost);
+        }
+        situationChanged = 0;
+      } else {
+        if (cleanDuals != 2)
+          M->problemStatus = -1;
+        else
+          M->problemStatus = 10; /* try primal */
+      }
+    }
+  }
+  if (tentativeStatus != -2 && tentativeStatus != -1) {
+    /* unflag (:6079-6120) */
+    int numberFlagged = 0;
+    for (int iRow = 0; iRow < m; iRow++) {
+      int iPivot = M->pivotVariable[iRow];
+      if (flagged(M, iPivot)) {
+        numberFlagged++;
+        clearFlagged(M, iPivot);
+      }
+    }
+    if (numberFlagged && !numberPivots) {
+      if (M->numberTimesOptimal < 3) {
+        M->numberTimesOptimal++;
+        M->problemStatus = -1;
+      } else {
+        M->problemStatus = 10;
+      }
+    }
+  }
+  if (M->problemStatus < 0) {
+    if (needCleanFake) {
+      double dummy = 0.0;
+      changeBounds(M, 3, NULL, &dummy);
+    }
+    if (weightsSaved) {
+      if (tentativeStatus > -3)
+        saveWeights(M, (type < 2) ? 2 : 4);
+      else
+        saveWeights(M, 3);
+    }
+  }
+}
+
+/* ClpSimplexDual::dual :637 -> startupSolve :230 -> gutsOfDual :432 */
+int orc_dual(OrcModel *M)
+{
+  const int m = M->m, n = M->n, N = m + n;
+  struct timespec t0, t1;
+  /* createRim: bounds, costs, solution; slack basis when no status given (allSlackBasis :7831) */
+  for (int j = 0; j < n; j++) {
+    M->lower[j] = M->colLower[j];
+    M->upper[j] = M->colUpper[j];
+    M->cost[j] = M->obj[j];
+  }
+  for (int i = 0; i < m; i++) {
+    M->lower[n + i] = M->rowLower[i];
+    M->upper[n + i] = M->rowUpper[i];
+    M->cost[n + i] = 0.0;
+  }
+  if (!M->haveStatus) {
+    for (int i = 0; i < m; i++)
+      M->status[n + i] = ST_BASIC;
+    for (int j = 0; j < n; j++) {
+      if (M->colLower[j] >= 0.0) {
+        M->status[j] = ST_LOWER;
+      } else if (M->colUpper[j] <= 0.0) {
+        M->status[j] = ST_UPPER;
+      } else if (M->colLower[j] < -1.0e20 && M->colUpper[j] > 1.0e20) {
+        M->status[j] = ST_UPPER; /* free: reference uses isFree; here bothFake bounds, see header */
+      } else if (fabs(M->colLower[j]) < fabs(M->colUpper[j])) {
+        M->status[j] = ST_LOWER;
+      } else {
+        M->status[j] = ST_UPPER;
+      }
+    }
+  }
+  for (int i = 0; i < N; i++) {
+    int st = getStatus(M, i);
+    M->status[i] = (unsigned char)st; /* clear fake/flag bits */
+    if (st == ST_LOWER || st == ST_FIXED)
+      M->sol[i] = M->lower[i];
+    else if (st == ST_UPPER)
+      M->sol[i] = M->upper[i];
+    else if (st != ST_BASIC)
+      M->sol[i] = 0.0;
+    if (st != ST_BASIC && M->lower[i] == M->upper[i])
+      setStatus(M, i, ST_FIXED);
+    if (st == ST_LOWER && M->lower[i] < -1.0e20 && M->upper[i] < 1.0e20) {
+      setStatus(M, i, ST_UPPER);
+      M->sol[i] = M->upper[i];
+    } else if (st == ST_UPPER && M->upper[i] > 1.0e20 && M->lower[i] > -1.0e20) {
+      setStatus(M, i, ST_LOWER);
+      M->sol[i] = M->lower[i];
+    }
+  }
+  M->problemStatus = -1;
+  M->numberIterations = 0;
+  M->numberRefactorizations = 0;
+  M->logCount = 0;
+  M->numberFake = 0;
+  M->numberChanged = 0;
+  M->numberTimesOptimal = 0;
+  M->pivotRow = -1;
+  M->numberInfeasible = 0;
+  M->haveSavedWeights = 0;
+  M->objectiveValue = 0.0;
+  M->largestPrimalError = M->largestDualError = 0.0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  if (factorize(M)) {
+    M->problemStatus = 4;
+    return 4;
+  }
+  {
+    double dummy = 0.0;
+    changeBounds(M, 1, NULL, &dummy);
+  }
+  gutsOfSolution(M);
+  int lastCleaned = 0;
+  int factorType = 0;
+  while (M->problemStatus < 0) {
+    for (int i = 0; i < m; i++)
+      M->rowWork0[i] = M->rowWork1[i] = M->rowWork2[i] = M->rowWork3[i] = 0.0;
+    M->numberPi = M->numberColNz = M->numberW = 0;
+    statusOfProblemInDual(M, &lastCleaned, factorType);
+    factorType = 1;
+    if (M->problemStatus < 0) {
+      M->problemStatus = -1;
+      whileIterating(M);
+    }
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  M->seconds = (double)(t1.tv_sec - t0.tv_sec) + 1.0e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  if (M->problemStatus == 0 || M->problemStatus == 3) {
+    /* finish(): true objective from original costs */
+    double objective = 0.0;
+    for (int j = 0; j < n; j++)
+      objective += M->obj[j] * M->sol[j];
+    M->objectiveValue = objective;
+  }
+  return M->problemStatus;
+}
+
+int orc_number_iterations(const OrcModel *M) { return M->numberIterations; }
+double orc_objective_value(const OrcModel *M) { return M->objectiveValue; }
+int orc_number_refactorizations(const OrcModel *M) { return M->numberRefactorizations; }
+double orc_iteration_seconds(const OrcModel *M) { return M->seconds; }
+void orc_get_solution(const OrcModel *M, double *s) { memcpy(s, M->sol, sizeof(double) * (size_t)(M->m + M->n)); }
+void orc_get_reduced_costs(const OrcModel *M, double *d) { memcpy(d, M->dj, sizeof(double) * (size_t)(M->m + M->n)); }
+void orc_get_status(const OrcModel *M, unsigned char *s) { memcpy(s, M->status, (size_t)(M->m + M->n)); }
+void orc_get_pivot_variable(const OrcModel *M, int *p) { memcpy(p, M->pivotVariable, sizeof(int) * (size_t)M->m); }
+void orc_get_row_duals(const OrcModel *M, double *d) { memcpy(d, M->dj + M->n, sizeof(double) * (size_t)M->m); }
+int orc_get_pivot_log(const OrcModel *M, OrcPivotRecord *out, int maxRecords)
+{
+  int count = M->logCount < maxRecords ? M->logCount : maxRecords;
+  if (out)
+    memcpy(out, M->log, sizeof(OrcPivotRecord) * (size_t)count);
+  return M->logCount;
+}

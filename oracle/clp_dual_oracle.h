@@ -1,0 +1,108 @@
+/*
+ * clp_dual_oracle.h -- CPU ORACLE for the revised dual simplex iteration path of coin-or/Clp.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and the
+ * `cpu_baseline` leg of bench.py may load it.  The product (clp_amd/, libclpgpu.so) never links,
+ * imports or calls anything in oracle/.
+ *
+ * It is a plain-C restatement (written from scratch, no reference source copied) of the algorithm in
+ *   src/ClpSimplexDual.cpp   (whileIterating :973, updateDualsInDual :2430, dualRow :2962,
+ *                             changeBounds :3148, dualColumn0 :3665, dualColumn :4192,
+ *                             statusOfProblemInDual :4996, flipBounds :6345, originalBound :6403,
+ *                             changeBound :6445)
+ *   src/ClpPackedMatrix.cpp  (times :296, transposeTimes :362, transposeTimesByColumn :961,
+ *                             gutsOfTransposeTimesUnscaled fused pass :1799, add :4874)
+ *   src/ClpDualRowSteepest.cpp (pivotRow :179, updateWeights :375, updatePrimalSolution :630,
+ *                             saveWeights :773, unrollWeights :1022)
+ *   src/ClpDualRowDantzig.cpp (pivotRow :56)
+ *   src/ClpSimplex.cpp       (computePrimals :914, computeDuals :1164, housekeeping :2065,
+ *                             checkPrimalSolution :2989, checkDualSolution :3070)
+ *   src/CoinAbcDenseFactorization.cpp (factor :216, replaceColumnPart3 :480, updateColumn :571,
+ *                             updateColumnTranspose :634) -- the only LU whose source is in tree.
+ *
+ * PARITY PINNING: the reference cannot be built here (CoinUtils is absent),
+ * and nothing in the reference's tests pins a pivot sequence, tableau row, FTRAN/BTRAN vector or
+ * DSE weight.  What IS pinned (tests/test_oracle_golden.py): the 3x5 basis solution of
+ * src/unitTest.cpp:1470-1482, the AFIRO optimum -4.6475314286e+02 (src/unitTest.cpp:480-485,
+ * :1898-1975) with KKT residuals, and the generated-instance optima of
+ * test/test_racing_reference.txt.  For pivot sequences: "parity unpinned".
+ */
+#ifndef CLP_DUAL_ORACLE_H
+#define CLP_DUAL_ORACLE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct OrcModel OrcModel;
+
+/* one record per simplex iteration (shape of CLP_SIMPLEX_HOUSE2, src/ClpMessage.cpp:48) */
+typedef struct {
+  int iteration;   /* 1-based, value of numberIterations_ after housekeeping */
+  int sequenceIn;  /* [0,n) structural, [n,n+m) row slack */
+  int sequenceOut;
+  int pivotRow;
+  int numberFlipped;
+  int reserved;
+  double theta;
+  double alpha;
+  double dualOut;
+  double objective;
+} OrcPivotRecord;
+
+OrcModel *orc_create(int numberRows, int numberColumns, const int *columnStart, const int *rowIndex,
+                     const double *element, const double *columnLower, const double *columnUpper,
+                     const double *objective, const double *rowLower, const double *rowUpper);
+void orc_destroy(OrcModel *model);
+
+/* options: "pivot_rule" 0=Dantzig 1=steepest; "max_iterations"; "max_pivots" (refactor frequency);
+ * "dual_bound"; "primal_tolerance"; "dual_tolerance"; "log_level"; "random_seed" */
+int orc_set_option(OrcModel *model, const char *name, double value);
+
+/* optional starting basis: status[0..n+m) with ClpSimplex::Status codes (src/ClpSimplex.hpp:119) */
+void orc_set_status(OrcModel *model, const unsigned char *status);
+
+/* ClpSimplex::dual(): returns problemStatus 0 optimal,1 primal infeasible,2 dual infeasible,
+ * 3 iteration limit, 4 numerical trouble */
+int orc_dual(OrcModel *model);
+
+int orc_number_iterations(const OrcModel *model);
+double orc_objective_value(const OrcModel *model);
+int orc_number_refactorizations(const OrcModel *model);
+/* copies n+m doubles, [columns | rows] */
+void orc_get_solution(const OrcModel *model, double *solution);
+void orc_get_reduced_costs(const OrcModel *model, double *dj);
+void orc_get_status(const OrcModel *model, unsigned char *status);
+void orc_get_pivot_variable(const OrcModel *model, int *pivotVariable);
+void orc_get_row_duals(const OrcModel *model, double *dual);
+int orc_get_pivot_log(const OrcModel *model, OrcPivotRecord *out, int maxRecords);
+double orc_iteration_seconds(const OrcModel *model);
+
+/* ---- unit-level entry points used by the kernel parity tests ---- */
+
+/* y += scalar * A * x   (ClpPackedMatrix::times :296) */
+void orc_times(const OrcModel *model, double scalar, const double *x, double *y);
+/* y += scalar * A^T * x (ClpPackedMatrix::transposeTimes :362) */
+void orc_transpose_times(const OrcModel *model, double scalar, const double *x, double *y);
+
+/* Row pricing by column with the fused first ratio-test pass
+ * (ClpPackedMatrix::transposeTimesByColumn :1007-1090 + gutsOfTransposeTimesUnscaled :1799).
+ * pi is PACKED (piIndex/piValue, as produced by BTRAN); status/dj are [columns|rows].
+ * Outputs: tableau row column part (outIndex/outValue ascending column), candidate list
+ * (candIndex = sequence numbers, rows first then columns; candValue = alpha with sign),
+ * upperTheta.  Returns number of column nonzeros. */
+int orc_price_row_fused(const OrcModel *model, int numberPi, const int *piIndex, const double *piValue,
+                        const unsigned char *status, const double *dj, double zeroTolerance,
+                        double dualTolerance, double acceptablePivot, int *outIndex, double *outValue,
+                        int *numberCandidates, int *candIndex, double *candValue, double *upperTheta);
+
+/* factorization of the basis given by status (basic==1): returns 0 or -1 singular; fills pivotVariable */
+int orc_factorize(OrcModel *model, const unsigned char *status, int *pivotVariable);
+/* in-place dense (length m) solves with the current factorization (+ eta file) */
+void orc_ftran(OrcModel *model, double *region);
+void orc_btran(OrcModel *model, double *region);
+int orc_replace_column(OrcModel *model, const double *updatedColumn, int pivotRow, double alpha);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
