@@ -1,0 +1,135 @@
+// device_state.h -- layout of the device-resident simplex state of libclpgpu (gfx950 only).
+//
+// Everything the per-iteration loop touches lives in HBM; the host sees only the small control
+// block `Ctrl` (pinned mirror) and syncs the rim arrays at refactorization boundaries
+// ("host mirrors to sync at refactor boundaries").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace clpgpu {
+
+// ClpSimplex::Status (reference src/ClpSimplex.hpp:119-126)
+enum : int { ST_FREE = 0, ST_BASIC = 1, ST_UPPER = 2, ST_LOWER = 3, ST_SUPER = 4, ST_FIXED = 5 };
+// ClpSimplexDual::FakeBound, bits 3-4 of the status byte
+enum : int { FAKE_NONE = 0, FAKE_LOWER = 1, FAKE_UPPER = 2, FAKE_BOTH = 3 };
+constexpr unsigned char FLAGGED_BIT = 64;
+
+// Ctrl::state while the device loop is running / why it stopped
+enum : int {
+  RUN = -1,
+  EXIT_NO_PIVOT_ROW = 100,  // dualRow found nothing (ClpSimplexDual.cpp:2080)
+  EXIT_NO_INCOMING = 101,   // ratio test found nothing (:1869)
+  EXIT_ALPHA_CHECK = 102,   // btran/ftran alpha disagree (:1451)
+  EXIT_REFACTOR = 103,      // housekeeping asked for a refactorization (:1849)
+  EXIT_MAX_ITERATIONS = 104,
+  EXIT_BACKWARDS = 105,     // objective going backwards (:1574)
+  EXIT_BAD_UPDATE = 106,    // replaceColumn says singular (:1618)
+  EXIT_STEP_LIMIT = 107     // bench stepping: requested number of pivots done
+};
+
+struct Ctrl {
+  int state;
+  int numberIterations;
+  int pivots;  // basis updates since the last refactorization
+  int k;       // size of the nucleus (number of basic structurals)
+  int pivotRow, sequenceIn, sequenceOut, directionIn, directionOut;
+  int lastPivotRow;
+  int numberInfeasible;
+  int numberCandidates;
+  int numberFlips;
+  int numberAppend;
+  int updateCase;  // 0 struct->struct, 1 slack out/struct in, 2 struct out/slack in, 3 slack->slack
+  int slotColOut;  // col-slot of a leaving structural
+  int slotRowIn;   // row-slot of the row whose slack enters
+  int rowOfSlackOut;
+  int maximumPivots, maximumIterations, forceFactorization, stepLimit;
+  int numberChanged;
+  int logCount, logCapacity;
+  int pivotRule;
+  int lastBadIteration;
+  int badSumPivots;
+  int modifyCosts;
+  unsigned int seed;
+  int kcap;
+  int scratchCount;  // generic compaction total
+  double alpha, theta, dualOut, dualIn, valueIn, valueOut, lowerIn, upperIn, lowerOut, upperOut;
+  double btranAlpha, movement;
+  double objectiveValue, objectiveChange;
+  double upperTheta, acceptablePivot, acceptablePivotBase;
+  double primalTolerance, dualTolerance, zeroTolerance, dualBound, largeValue;
+  double largestPrimalError, largestDualError;
+  double saveSumDual;
+  double norm;
+  double bestPossible;
+  double scratchSum;
+  double statPriceBytes, statPriceLaunches;
+};
+
+struct PivotRecord {  // == clpgpu_pivot_record
+  int iteration, sequenceIn, sequenceOut, pivotRow, numberFlipped, reserved;
+  double theta, alpha, dualOut, objective;
+};
+
+// All device pointers of one context.  Passed by value to kernels.
+struct Dev {
+  int m, n, N;
+  int firstColumn, lastColumn;  // priced column range (multi-GPU shard)
+  // A by column (ClpPackedMatrix / CoinPackedMatrix layout)
+  const int *colStart;
+  const int *row;
+  const double *elem;
+  // A by row, each row partitioned [basic structurals | nonbasic]; cross indices keep the
+  // partition maintainable in O(column length) per pivot (cf. ClpPackedMatrix3::swapOne)
+  const int *rowStart;
+  int *ccol;
+  double *relem;
+  int *csrToCsc;
+  int *cscToCsr;
+  int *basicCount;
+  // rim arrays [columns | rows]
+  double *lower, *upper, *cost, *dj, *sol;
+  const double *origLower, *origUpper;
+  unsigned char *status;
+  // basis bookkeeping
+  int *pivotVariable;  // [m] sequence at basis position p
+  int *posOfSlack;     // [m] position of the basic slack of row i, or -1
+  int *slotOfRow;      // [m] row-slot of a nucleus row, or -1
+  int *slotOfCol;      // [n] col-slot of a basic structural, or -1
+  int *slotRow;        // [kcap]
+  int *slotCol;        // [kcap]
+  int *slotPos;        // [kcap] basis position of col-slot
+  double *Minv;        // [kcap*ld] row-major: x_K[sc] = sum_sr Minv[sc*ld+sr] * v_R[sr]
+  int ld;
+  // work vectors
+  double *vecC;      // [m] BTRAN input by position
+  double *rho;       // [m] BTRAN result by row, |.|<=zeroTolerance flushed (the packed pi)
+  double *piNeg;     // [m] -rho (what the pricing kernel gathers)
+  double *alphaCol;  // [n] tableau row, column part (0 where skipped)
+  double *vecV1, *vecV2;  // [m] FTRAN inputs by row
+  double *w, *tau, *x3;   // [m] FTRAN results by position
+  double *flipRhs;        // [m]
+  double *slotA, *slotB, *slotC, *slotD, *slotE, *slotF;  // [kcap] nucleus-sized scratch
+  double *rhoSlot;   // [kcap] unpruned rho on nucleus rows (for the rank-1 update)
+  double *partial;   // gemvT partials [(kcap/64+1) * kcap]
+  // dual row pivot
+  double *weights, *altWeights, *infeas, *weightBySeq;
+  int *infIndex;
+  // ratio test
+  unsigned char *candFlag;  // [N] by key (rows first, then columns)
+  int *candSeq;
+  double *candAlpha;
+  int *candTag;
+  unsigned char *candLive;
+  int *blockCount, *blockOffset;
+  double *blockMin, *blockSum;
+  int *flipSeq;
+  int *appendFlag;  // [m]
+  // refactorization scratch
+  double *workW, *workX;  // [kcap*ld]
+  int *perm;
+  Ctrl *ctrl;
+  PivotRecord *log;
+};
+
+}  // namespace clpgpu

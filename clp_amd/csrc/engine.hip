@@ -1,0 +1,1856 @@
+// engine.hip -- host side of libclpgpu.so: owns the device state, drives the kernel chain of one
+// pivot, and restates the *control plane* of ClpSimplexDual (statusOfProblemInDual, the exit
+// handling of whileIterating) on host mirrors that are synced only at refactorization boundaries.
+// There is no CPU compute fallback: every function that does arithmetic on the problem calls a
+// HIP kernel of kernels.hip, and clpgpu_create() fails when no HIP device is present.
+#include "kernels.hip"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "../../include/clpgpu.h"
+
+using namespace clpgpu;
+
+#define HIPCHECK(expr)                                                                             \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) {                                                                        \
+      setError("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);         \
+      return -99;                                                                                  \
+    }                                                                                              \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+struct clpgpu_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string error;
+  // ---- problem (host copies)
+  int m = 0, n = 0, N = 0;
+  long nnz = 0;
+  std::vector<int> colStart, row;
+  std::vector<double> elem;
+  std::vector<double> colLower, colUpper, obj, rowLower, rowUpper;
+  std::vector<int> rowStart;
+  // ---- host mirrors of the rim (valid after pull())
+  std::vector<double> lower, upper, cost, dj, sol, origLower, origUpper;
+  std::vector<unsigned char> status;
+  std::vector<int> pivotVariable;
+  bool haveStatus = false;
+  std::vector<unsigned char> userStatus;
+  // ---- options / ClpSimplex scalars
+  double primalTolerance = 1.0e-7, dualTolerance = 1.0e-7, dualToleranceBase = 1.0e-7, dualBound = 1.0e10;
+  double zeroTolerance = 1.0e-13, acceptablePivot = 1.0e-8, largeValue = 1.0e15;
+  int maximumIterations = 2147483647, pivotRule = 1, maximumPivots = 200, logLevel = 0, checkEvery = 1;
+  unsigned int seed = 1234567u;
+  int timing = 0;
+  // ---- state
+  int problemStatus = -1, numberIterations = 0, numberRefactorizations = 0;
+  double objectiveValue = 0.0;
+  double largestPrimalError = 0.0, largestDualError = 0.0;
+  double sumPrimalInfeasibilities = 0.0, sumDualInfeasibilities = 0.0, sumOfRelaxedPrimalInfeasibilities = 0.0,
+         sumOfRelaxedDualInfeasibilities = 0.0;
+  int numberPrimalInfeasibilities = 0, numberDualInfeasibilities = 0;
+  int numberFake = 0, numberChanged = 0, numberTimesOptimal = 0, forceFactorization = -1, lastBadIteration = -999999;
+  int lastCleaned = 0, factorType = 0;
+  bool started = false, needStatus = true, weightsInitialized = false;
+  int pivots = 0, kNucleus = 0;
+  // ---- device
+  Dev D;
+  Ctrl *hCtrl = nullptr;  // pinned
+  std::vector<void *> allocations;
+  int kcap = 0, ld = 0;
+  int *dKcol = nullptr, *dLocalOfRow = nullptr, *dInfo = nullptr;
+  int logCapacity = 0;
+  // ---- stats
+  clpgpu_stats stats;
+  std::vector<hipEvent_t> evStart, evStop;
+  int evUsed = 0;
+  double seconds = 0.0;
+
+  void setError(const char *fmt, ...)
+  {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    error = buf;
+    if (logLevel > 0)
+      fprintf(stderr, "clpgpu: %s\n", buf);
+  }
+
+  template <typename T> int dalloc(T *&p, size_t count)
+  {
+    void *q = nullptr;
+    size_t bytes = sizeof(T) * (count ? count : 1);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) {
+      setError("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+      return -99;
+    }
+    (void)hipMemsetAsync(q, 0, bytes, stream);
+    allocations.push_back(q);
+    p = (T *)q;
+    return 0;
+  }
+  template <typename T> int h2d(T *dst, const T *src, size_t count)
+  {
+    hipError_t e = hipMemcpyAsync((void *)dst, src, sizeof(T) * count, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) {
+      setError("h2d failed: %s", hipGetErrorString(e));
+      return -99;
+    }
+    return 0;
+  }
+  template <typename T> int d2h(T *dst, const T *src, size_t count)
+  {
+    hipError_t e = hipMemcpyAsync(dst, (const void *)src, sizeof(T) * count, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
+      setError("d2h failed: %s", hipGetErrorString(e));
+      return -99;
+    }
+    return 0;
+  }
+  int sync()
+  {
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
+      setError("stream sync failed: %s", hipGetErrorString(e));
+      return -99;
+    }
+    return 0;
+  }
+
+  int loadProblem(int m_, int n_, const int *cs, const int *ri, const double *el, const double *cl, const double *cu,
+                  const double *ob, const double *rl, const double *ru);
+  int allocNucleus(int kNeeded);
+  int pushCtrl();
+  int pullCtrl();
+  int pushRim();
+  int pullRim(bool all);
+  int startup();
+  int factorize();
+  int ftranDevice(const double *vRow, double *xPos);
+  int btranDevice(const double *cPos, double *yRow);
+  int gutsOfSolution();
+  void checkPrimalSolution();
+  void checkDualSolution();
+  int changeBounds(int initialize, double &changeCost);
+  int numberAtFakeBound() const;
+  int updateDualsFullRecompute();
+  int saveWeights(int mode);
+  int statusOfProblemInDual(int type);
+  int launchIteration();
+  int whileIterating(int stepTarget);
+  int run(int maxSteps);
+  void finish();
+  int priceRow(int numberPi, const int *piIndex, const double *piValue, const unsigned char *st, const double *djv,
+               double zeroTol, double dualTol, double accPivot, int *numberOut, int *outIndex, double *outValue,
+               int *numberCand, int *candIndex, double *candValue, double *upperTheta);
+};
+
+// ---------------------------------------------------------------------------------------------
+int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, const double *el, const double *cl,
+                                const double *cu, const double *ob, const double *rl, const double *ru)
+{
+  m = m_;
+  n = n_;
+  N = m + n;
+  nnz = cs[n];
+  colStart.assign(cs, cs + n + 1);
+  row.assign(ri, ri + nnz);
+  elem.assign(el, el + nnz);
+  colLower.assign(cl, cl + n);
+  colUpper.assign(cu, cu + n);
+  obj.assign(ob, ob + n);
+  rowLower.assign(rl, rl + m);
+  rowUpper.assign(ru, ru + m);
+  // row copy (ClpSimplex::createRim builds rowCopy_, src/ClpSimplex.cpp:3648) with cross indices
+  rowStart.assign(m + 1, 0);
+  for (long p = 0; p < nnz; p++)
+    rowStart[row[p] + 1]++;
+  for (int i = 0; i < m; i++)
+    rowStart[i + 1] += rowStart[i];
+  std::vector<int> ccol(nnz), csrToCsc(nnz), cscToCsr(nnz), fill(rowStart.begin(), rowStart.end() - 1);
+  std::vector<double> relem(nnz);
+  for (int j = 0; j < n; j++)
+    for (int p = colStart[j]; p < colStart[j + 1]; p++) {
+      int q = fill[row[p]]++;
+      ccol[q] = j;
+      relem[q] = elem[p];
+      csrToCsc[q] = p;
+      cscToCsr[p] = q;
+    }
+  memset(&D, 0, sizeof(D));
+  D.m = m;
+  D.n = n;
+  D.N = N;
+  D.firstColumn = 0;
+  D.lastColumn = n;
+  int *dColStart, *dRow, *dRowStart;
+  double *dElem;
+  int rc = 0;
+  rc |= dalloc(dColStart, n + 1);
+  rc |= dalloc(dRow, nnz);
+  rc |= dalloc(dElem, nnz);
+  rc |= dalloc(dRowStart, m + 1);
+  rc |= dalloc(D.ccol, nnz);
+  rc |= dalloc(D.relem, nnz);
+  rc |= dalloc(D.csrToCsc, nnz);
+  rc |= dalloc(D.cscToCsr, nnz);
+  rc |= dalloc(D.basicCount, m);
+  if (rc)
+    return rc;
+  rc |= h2d(dColStart, colStart.data(), n + 1);
+  rc |= h2d(dRow, row.data(), nnz);
+  rc |= h2d(dElem, elem.data(), nnz);
+  rc |= h2d(dRowStart, rowStart.data(), m + 1);
+  rc |= h2d(D.ccol, ccol.data(), nnz);
+  rc |= h2d(D.relem, relem.data(), nnz);
+  rc |= h2d(D.csrToCsc, csrToCsc.data(), nnz);
+  rc |= h2d(D.cscToCsr, cscToCsr.data(), nnz);
+  D.colStart = dColStart;
+  D.row = dRow;
+  D.elem = dElem;
+  D.rowStart = dRowStart;
+  double *dOrigLower, *dOrigUpper;
+  rc |= dalloc(D.lower, N);
+  rc |= dalloc(D.upper, N);
+  rc |= dalloc(D.cost, N);
+  rc |= dalloc(D.dj, N);
+  rc |= dalloc(D.sol, N);
+  rc |= dalloc(dOrigLower, N);
+  rc |= dalloc(dOrigUpper, N);
+  rc |= dalloc(D.status, N);
+  rc |= dalloc(D.pivotVariable, m);
+  rc |= dalloc(D.posOfSlack, m);
+  rc |= dalloc(D.slotOfRow, m);
+  rc |= dalloc(D.slotOfCol, n);
+  rc |= dalloc(D.vecC, m);
+  rc |= dalloc(D.rho, m);
+  rc |= dalloc(D.piNeg, m);
+  rc |= dalloc(D.alphaCol, n);
+  rc |= dalloc(D.vecV1, m);
+  rc |= dalloc(D.vecV2, m);
+  rc |= dalloc(D.w, m);
+  rc |= dalloc(D.tau, m);
+  rc |= dalloc(D.x3, m);
+  rc |= dalloc(D.flipRhs, m);
+  rc |= dalloc(D.weights, m);
+  rc |= dalloc(D.altWeights, m);
+  rc |= dalloc(D.infeas, m);
+  rc |= dalloc(D.weightBySeq, N);
+  rc |= dalloc(D.infIndex, m);
+  rc |= dalloc(D.candFlag, N);
+  rc |= dalloc(D.candSeq, N);
+  rc |= dalloc(D.candAlpha, N);
+  rc |= dalloc(D.candTag, N);
+  rc |= dalloc(D.candLive, N);
+  int nb = cdiv(m, PRICE_BLOCK) + cdiv(n, PRICE_BLOCK) + 2;
+  rc |= dalloc(D.blockCount, nb);
+  rc |= dalloc(D.blockOffset, nb);
+  rc |= dalloc(D.blockMin, nb);
+  rc |= dalloc(D.blockSum, nb);
+  rc |= dalloc(D.flipSeq, N);
+  rc |= dalloc(D.appendFlag, m);
+  rc |= dalloc(D.ctrl, 1);
+  rc |= dalloc(dLocalOfRow, m);
+  rc |= dalloc(dInfo, 4);
+  if (rc)
+    return rc;
+  D.origLower = dOrigLower;
+  D.origUpper = dOrigUpper;
+  origLower.resize(N);
+  origUpper.resize(N);
+  for (int j = 0; j < n; j++) {
+    origLower[j] = colLower[j];
+    origUpper[j] = colUpper[j];
+  }
+  for (int i = 0; i < m; i++) {
+    origLower[n + i] = rowLower[i];
+    origUpper[n + i] = rowUpper[i];
+  }
+  rc |= h2d(dOrigLower, origLower.data(), N);
+  rc |= h2d(dOrigUpper, origUpper.data(), N);
+  lower.resize(N);
+  upper.resize(N);
+  cost.resize(N);
+  dj.assign(N, 0.0);
+  sol.assign(N, 0.0);
+  status.assign(N, 0);
+  pivotVariable.assign(m, 0);
+  hipError_t e = hipHostMalloc((void **)&hCtrl, sizeof(Ctrl), hipHostMallocDefault);
+  if (e != hipSuccess) {
+    setError("hipHostMalloc failed: %s", hipGetErrorString(e));
+    return -99;
+  }
+  memset(hCtrl, 0, sizeof(Ctrl));
+  rc |= sync();
+  started = false;
+  return rc;
+}
+
+int clpgpu_context::allocNucleus(int kNeeded)
+{
+  int want = kNeeded + maximumPivots + 16;
+  if (want <= kcap)
+    return 0;
+  // growth never happens inside the iteration loop: k grows by at most one per pivot and a
+  // refactorization comes at least every maximumPivots pivots
+  kcap = want + want / 4;
+  ld = (kcap + 63) & ~63;
+  D.ld = ld;
+  int rc = 0;
+  size_t mat = (size_t)kcap * ld;
+  rc |= dalloc(D.Minv, mat);
+  rc |= dalloc(D.workW, mat);
+  rc |= dalloc(D.workX, mat);
+  rc |= dalloc(D.partial, (size_t)(kcap / 64 + 2) * ld);
+  rc |= dalloc(D.slotRow, kcap);
+  rc |= dalloc(D.slotCol, kcap);
+  rc |= dalloc(D.slotPos, kcap);
+  rc |= dalloc(D.slotA, kcap);
+  rc |= dalloc(D.slotB, kcap);
+  rc |= dalloc(D.slotC, kcap);
+  rc |= dalloc(D.slotD, kcap);
+  rc |= dalloc(D.slotE, kcap);
+  rc |= dalloc(D.slotF, kcap);
+  rc |= dalloc(D.rhoSlot, kcap);
+  rc |= dalloc(D.perm, kcap);
+  rc |= dalloc(dKcol, kcap);
+  return rc;
+}
+
+int clpgpu_context::pushCtrl()
+{
+  return h2d(D.ctrl, hCtrl, 1);
+}
+int clpgpu_context::pullCtrl()
+{
+  return d2h(hCtrl, D.ctrl, 1);
+}
+int clpgpu_context::pushRim()
+{
+  int rc = 0;
+  rc |= h2d(D.lower, lower.data(), N);
+  rc |= h2d(D.upper, upper.data(), N);
+  rc |= h2d(D.cost, cost.data(), N);
+  rc |= h2d(D.dj, dj.data(), N);
+  rc |= h2d(D.sol, sol.data(), N);
+  rc |= h2d(D.status, status.data(), N);
+  return rc;
+}
+int clpgpu_context::pullRim(bool all)
+{
+  int rc = 0;
+  if (all) {
+    rc |= d2h(lower.data(), D.lower, N);
+    rc |= d2h(upper.data(), D.upper, N);
+    rc |= d2h(cost.data(), D.cost, N);
+    rc |= d2h(status.data(), D.status, N);
+    rc |= d2h(pivotVariable.data(), D.pivotVariable, m);
+  }
+  rc |= d2h(dj.data(), D.dj, N);
+  rc |= d2h(sol.data(), D.sol, N);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Refactorization: ClpFactorization::factorize (src/ClpFactorization.cpp:1649) -- collect basic
+// rows then columns, nucleus inversion on the device, pivotVariable from the pivot order.
+// ---------------------------------------------------------------------------------------------
+int clpgpu_context::factorize()
+{
+  std::vector<int> kcol, rrows, localOfRow(m, -1);
+  int numberBasic = 0;
+  for (int i = 0; i < m; i++) {
+    if ((status[n + i] & 7) == ST_BASIC)
+      numberBasic++;
+    else {
+      localOfRow[i] = (int)rrows.size();
+      rrows.push_back(i);
+    }
+  }
+  for (int j = 0; j < n; j++)
+    if ((status[j] & 7) == ST_BASIC) {
+      kcol.push_back(j);
+      numberBasic++;
+    }
+  if (numberBasic != m || kcol.size() != rrows.size()) {
+    setError("factorize: %d basic variables for %d rows", numberBasic, m);
+    return -2;
+  }
+  const int k = (int)kcol.size();
+  int rc = allocNucleus(k);
+  if (rc)
+    return rc;
+  numberRefactorizations++;
+  std::vector<int> perm(k);
+  if (k) {
+    rc |= h2d(dKcol, kcol.data(), k);
+    rc |= h2d(dLocalOfRow, localOfRow.data(), m);
+    for (int i = 0; i < k; i++)
+      perm[i] = i;
+    rc |= h2d(D.perm, perm.data(), k);
+    int zero4[4] = { 0, 0, 0, 0 };
+    rc |= h2d(dInfo, zero4, 4);
+    size_t mat = (size_t)k * ld;
+    hipLaunchKernelGGL(k_zero, dim3(cdiv((int)mat, 256)), dim3(256), 0, stream, D.workW, (int)mat);
+    hipLaunchKernelGGL(k_zero, dim3(cdiv((int)mat, 256)), dim3(256), 0, stream, D.workX, (int)mat);
+    hipLaunchKernelGGL(k_gather_nucleus, dim3(k), dim3(64), 0, stream, D, dKcol, dLocalOfRow, k);
+    hipLaunchKernelGGL(k_identity, dim3(cdiv(k, 256)), dim3(256), 0, stream, D, k);
+    dim3 g2(cdiv(k, 256), k < 1024 ? k : 1024);
+    for (int i = 0; i < k; i++) {
+      hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(1024), 0, stream, D, i, k, dInfo);
+      hipLaunchKernelGGL(k_gj_swap, dim3(cdiv(k, 256)), dim3(256), 0, stream, D, i, k, dInfo);
+      hipLaunchKernelGGL(k_gj_mult, dim3(cdiv(k, 256)), dim3(256), 0, stream, D, i, k, dInfo);
+      hipLaunchKernelGGL(k_gj_elim, g2, dim3(256), 0, stream, D, i, k, dInfo);
+    }
+    hipLaunchKernelGGL(k_gj_finish, g2, dim3(256), 0, stream, D, k);
+    int info[4];
+    rc |= d2h(info, dInfo, 4);
+    if (rc)
+      return rc;
+    if (info[0]) {
+      setError("factorize: singular nucleus at step %d of %d", info[0] - 1, k);
+      return -1;
+    }
+    rc |= d2h(perm.data(), D.perm, k);
+  }
+  // bookkeeping arrays
+  std::vector<int> posOfSlack(m, -1), slotOfRow(m, -1), slotOfCol(n, -1), slotRow(k), slotCol(k), slotPos(k);
+  for (int i = 0; i < m; i++)
+    if (localOfRow[i] < 0) {
+      posOfSlack[i] = i;
+      pivotVariable[i] = n + i;
+    }
+  for (int c = 0; c < k; c++) {
+    int pos = rrows[perm[c]];
+    slotCol[c] = kcol[c];
+    slotPos[c] = pos;
+    slotOfCol[kcol[c]] = c;
+    pivotVariable[pos] = kcol[c];
+    slotRow[c] = rrows[c];
+    slotOfRow[rrows[c]] = c;
+  }
+  rc |= h2d(D.posOfSlack, posOfSlack.data(), m);
+  rc |= h2d(D.slotOfRow, slotOfRow.data(), m);
+  rc |= h2d(D.slotOfCol, slotOfCol.data(), n);
+  if (k) {
+    rc |= h2d(D.slotRow, slotRow.data(), k);
+    rc |= h2d(D.slotCol, slotCol.data(), k);
+    rc |= h2d(D.slotPos, slotPos.data(), k);
+  }
+  rc |= h2d(D.pivotVariable, pivotVariable.data(), m);
+  // row copy partition [basic | nonbasic]: rebuilt on the host (refactorization boundary only)
+  {
+    std::vector<int> ccol(nnz), csrToCsc(nnz), cscToCsr(nnz), basicCount(m, 0);
+    std::vector<double> relem(nnz);
+    std::vector<int> head(rowStart.begin(), rowStart.end() - 1), tail(rowStart.begin() + 1, rowStart.end());
+    for (int j = 0; j < n; j++) {
+      bool basic = slotOfCol[j] >= 0;
+      for (int p = colStart[j]; p < colStart[j + 1]; p++) {
+        int i = row[p];
+        int q = basic ? head[i]++ : --tail[i];
+        ccol[q] = j;
+        relem[q] = elem[p];
+        csrToCsc[q] = p;
+        cscToCsr[p] = q;
+        if (basic)
+          basicCount[i]++;
+      }
+    }
+    rc |= h2d(D.ccol, ccol.data(), nnz);
+    rc |= h2d(D.relem, relem.data(), nnz);
+    rc |= h2d(D.csrToCsc, csrToCsc.data(), nnz);
+    rc |= h2d(D.cscToCsr, cscToCsr.data(), nnz);
+    rc |= h2d(D.basicCount, basicCount.data(), m);
+    rc |= sync();
+  }
+  kNucleus = k;
+  pivots = 0;
+  hCtrl->k = k;
+  hCtrl->pivots = 0;
+  hCtrl->kcap = kcap;
+  return rc;
+}
+
+// generic dense solves (used at refactorization boundaries and by the C-ABI plug-in calls)
+int clpgpu_context::ftranDevice(const double *vRow, double *xPos)
+{
+  const int k = hCtrl->k;
+  if (k) {
+    hipLaunchKernelGGL(k_ftran_gather, dim3(cdiv(k, 256)), dim3(256), 0, stream, D, vRow, (const double *)nullptr, D.slotA,
+                       (double *)nullptr, 0);
+    hipLaunchKernelGGL(k_gemv2, dim3(cdiv(k, 4)), dim3(256), 0, stream, D, (const double *)D.slotA, (const double *)nullptr,
+                       D.slotC, (double *)nullptr, 0);
+  }
+  hipLaunchKernelGGL(k_ftran_scatter, dim3(cdiv(m + k, 256)), dim3(256), 0, stream, D, vRow, (const double *)nullptr,
+                     (const double *)D.slotC, (const double *)nullptr, xPos, (double *)nullptr, 0);
+  return 0;
+}
+int clpgpu_context::btranDevice(const double *cPos, double *yRow)
+{
+  const int k = hCtrl->k;
+  hipLaunchKernelGGL(k_btran_slack, dim3(cdiv(m, 256)), dim3(256), 0, stream, D, cPos, yRow, 0);
+  if (k) {
+    hipLaunchKernelGGL(k_btran_t, dim3(cdiv(k, 256)), dim3(256), 0, stream, D, cPos, (const double *)yRow, D.slotA, 0);
+    hipLaunchKernelGGL(k_gemvT_partial, dim3(cdiv(k, 256), cdiv(k, 64)), dim3(256), 0, stream, D, (const double *)D.slotA, 0);
+    hipLaunchKernelGGL(k_gemvT_final, dim3(cdiv(k, 256)), dim3(256), 0, stream, D, yRow, 0, 0);
+  }
+  return 0;
+}
+
+// ClpSimplex::gutsOfSolution (src/ClpSimplex.cpp:574): computePrimals :914, computeDuals :1164 on
+// the device, then the infeasibility sums on the host mirrors.
+int clpgpu_context::gutsOfSolution()
+{
+  int rc = pushCtrl();
+  const int g = cdiv(m, 256);
+  hipLaunchKernelGGL(k_zero_basic, dim3(g), dim3(256), 0, stream, D);
+  hipLaunchKernelGGL(k_primal_rhs, dim3(g), dim3(256), 0, stream, D, D.vecV2);
+  ftranDevice(D.vecV2, D.x3);
+  hipLaunchKernelGGL(k_store_basic, dim3(g), dim3(256), 0, stream, D, (const double *)D.x3);
+  hipLaunchKernelGGL(k_basic_costs, dim3(g), dim3(256), 0, stream, D, D.tau);
+  btranDevice(D.tau, D.vecV2);
+  hipLaunchKernelGGL(k_djs, dim3(cdiv(N, 256)), dim3(256), 0, stream, D, (const double *)D.vecV2);
+  // errors: residuals of the two solves (computed from the device results on the host mirrors)
+  std::vector<double> rhs(m), xB(m), y(m);
+  rc |= d2h(rhs.data(), D.vecV2, m);  // y (duals) now in vecV2
+  y = rhs;
+  rc |= pullRim(false);
+  hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, stream, D.vecV2, m);
+  hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, stream, D.tau, m);
+  hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, stream, D.x3, m);
+  // largestPrimalError: max |(A x - s)_i| over all rows (nonbasic + basic), i.e. B x_B - rhs
+  {
+    std::vector<double> act(m, 0.0);
+    for (int j = 0; j < n; j++) {
+      double v = sol[j];
+      if (v != 0.0)
+        for (int p = colStart[j]; p < colStart[j + 1]; p++)
+          act[row[p]] += v * elem[p];
+    }
+    double largest = 0.0;
+    for (int i = 0; i < m; i++)
+      largest = fmax(largest, fabs(act[i] - sol[n + i]));
+    largestPrimalError = largest;
+  }
+  // largestDualError: max over basics of |dj| (should be zero)
+  {
+    double largest = 0.0;
+    for (int i = 0; i < m; i++)
+      largest = fmax(largest, fabs(dj[pivotVariable[i]]));
+    largestDualError = largest;
+  }
+  checkPrimalSolution();
+  checkDualSolution();
+  return rc;
+}
+
+// ClpSimplex::checkPrimalSolution (src/ClpSimplex.cpp:2989)
+void clpgpu_context::checkPrimalSolution()
+{
+  double relaxedTolerance = primalTolerance + fmin(1.0e-2, largestPrimalError);
+  objectiveValue = 0.0;
+  sumPrimalInfeasibilities = 0.0;
+  numberPrimalInfeasibilities = 0;
+  sumOfRelaxedPrimalInfeasibilities = 0.0;
+  for (int pass = 0; pass < 2; pass++) {
+    int lo = pass ? 0 : n, hi = pass ? n : N;
+    for (int i = lo; i < hi; i++) {
+      double infeasibility = 0.0;
+      objectiveValue += sol[i] * cost[i];
+      if (sol[i] > upper[i])
+        infeasibility = sol[i] - upper[i];
+      else if (sol[i] < lower[i])
+        infeasibility = lower[i] - sol[i];
+      if (infeasibility > primalTolerance) {
+        sumPrimalInfeasibilities += infeasibility - primalTolerance;
+        if (infeasibility > relaxedTolerance)
+          sumOfRelaxedPrimalInfeasibilities += infeasibility - relaxedTolerance;
+        numberPrimalInfeasibilities++;
+      }
+    }
+  }
+}
+
+// ClpSimplex::checkDualSolution (src/ClpSimplex.cpp:3070)
+void clpgpu_context::checkDualSolution()
+{
+  double relaxedTolerance = dualTolerance + fmin(1.0e-2, largestDualError);
+  sumDualInfeasibilities = 0.0;
+  numberDualInfeasibilities = 0;
+  sumOfRelaxedDualInfeasibilities = 0.0;
+  for (int pass = 0; pass < 2; pass++) {
+    int lo = pass ? n : 0, hi = pass ? N : n;
+    for (int i = lo; i < hi; i++) {
+      if ((status[i] & 7) != ST_BASIC && !(status[i] & FLAGGED_BIT)) {
+        double distanceUp = upper[i] - sol[i], distanceDown = sol[i] - lower[i], value = dj[i];
+        if (distanceUp > primalTolerance && value < 0.0) {
+          double v = -value;
+          if (v > dualTolerance) {
+            sumDualInfeasibilities += v - dualTolerance;
+            if (v > relaxedTolerance)
+              sumOfRelaxedDualInfeasibilities += v - relaxedTolerance;
+            numberDualInfeasibilities++;
+          }
+        }
+        if (distanceDown > primalTolerance && value > 0.0) {
+          if (value > dualTolerance) {
+            sumDualInfeasibilities += value - dualTolerance;
+            if (value > relaxedTolerance)
+              sumOfRelaxedDualInfeasibilities += value - relaxedTolerance;
+            numberDualInfeasibilities++;
+          }
+        }
+      }
+    }
+  }
+}
+
+static inline int getFake(unsigned char s) { return (s >> 3) & 3; }
+static inline unsigned char withFake(unsigned char s, int f) { return (unsigned char)((s & ~24) | (f << 3)); }
+static inline unsigned char withStatus(unsigned char s, int st) { return (unsigned char)((s & ~7) | st); }
+
+// ClpSimplexDual::changeBounds (src/ClpSimplexDual.cpp:3148-3512) on the host mirrors
+int clpgpu_context::changeBounds(int initialize, double &changeCost)
+{
+  numberFake = 0;
+  if (!initialize) {
+    int numberInfeasibilities = 0;
+    double newBound = 5.0 * dualBound;
+    changeCost = 0.0;
+    for (int i = 0; i < N; i++) {
+      lower[i] = origLower[i];
+      upper[i] = origUpper[i];
+    }
+    for (int i = 0; i < N; i++) {
+      double value = sol[i];
+      status[i] = withFake(status[i], FAKE_NONE);
+      int st = status[i] & 7;
+      if (st == ST_UPPER) {
+        if (fabs(value - upper[i]) > primalTolerance) {
+          if (fabs(dj[i]) > 1.0e-9)
+            numberInfeasibilities++;
+          else
+            status[i] = withStatus(status[i], ST_SUPER);
+        }
+      } else if (st == ST_LOWER) {
+        if (fabs(value - lower[i]) > primalTolerance) {
+          if (fabs(dj[i]) > 1.0e-9)
+            numberInfeasibilities++;
+          else
+            status[i] = withStatus(status[i], ST_SUPER);
+        }
+      }
+    }
+    if (numberInfeasibilities) {
+      for (int i = 0; i < N; i++) {
+        double lowerValue = lower[i], upperValue = upper[i], newLowerValue, newUpperValue;
+        int st = status[i] & 7;
+        if (st == ST_UPPER || st == ST_LOWER) {
+          double value = sol[i];
+          if (value - lowerValue <= upperValue - value) {
+            newLowerValue = fmax(lowerValue, value - 0.666667 * newBound);
+            newUpperValue = fmin(upperValue, newLowerValue + newBound);
+          } else {
+            newUpperValue = fmin(upperValue, value + 0.666667 * newBound);
+            newLowerValue = fmax(lowerValue, newUpperValue - newBound);
+          }
+          if (newLowerValue > lowerValue) {
+            if (newUpperValue < upperValue) {
+              status[i] = withFake(status[i], FAKE_BOTH);
+              if (st == ST_LOWER) {
+                newLowerValue = value;
+                newUpperValue = fmin(upperValue, newLowerValue + newBound);
+              } else {
+                newUpperValue = value;
+                newLowerValue = fmax(lowerValue, newUpperValue - newBound);
+              }
+              numberFake++;
+            } else {
+              status[i] = withFake(status[i], FAKE_LOWER);
+              numberFake++;
+            }
+          } else if (newUpperValue < upperValue) {
+            status[i] = withFake(status[i], FAKE_UPPER);
+            numberFake++;
+          }
+          lower[i] = newLowerValue;
+          upper[i] = newUpperValue;
+          sol[i] = (st == ST_UPPER) ? newUpperValue : newLowerValue;
+          double movement = sol[i] - value;
+          if (movement)
+            changeCost += movement * cost[i];
+        }
+      }
+      dualBound = newBound;
+    } else {
+      numberInfeasibilities = -1;
+    }
+    return numberInfeasibilities;
+  }
+  if (initialize == 3) {
+    for (int i = 0; i < N; i++)
+      if (getFake(status[i]) != FAKE_NONE) {
+        lower[i] = origLower[i];
+        upper[i] = origUpper[i];
+        status[i] = withFake(status[i], FAKE_NONE);
+      }
+  }
+  double testBound = 0.999999 * dualBound;
+  for (int i = 0; i < N; i++) {
+    int st = status[i] & 7;
+    if (st == ST_UPPER || st == ST_LOWER) {
+      double lowerValue = lower[i], upperValue = upper[i], value = sol[i];
+      if (lowerValue > -largeValue || upperValue < largeValue) {
+        if (fabs(lowerValue - value) <= fabs(upperValue - value)) {
+          if (upperValue > lowerValue + testBound) {
+            if (getFake(status[i]) == FAKE_NONE)
+              numberFake++;
+            upper[i] = lowerValue + dualBound;
+            status[i] = withFake(status[i], FAKE_UPPER);
+          }
+        } else {
+          if (lowerValue < upperValue - testBound) {
+            if (getFake(status[i]) == FAKE_NONE)
+              numberFake++;
+            lower[i] = upperValue - dualBound;
+            status[i] = withFake(status[i], FAKE_LOWER);
+          }
+        }
+        sol[i] = (st == ST_UPPER) ? upper[i] : lower[i];
+      } else {
+        lower[i] = -0.5 * dualBound;
+        upper[i] = 0.5 * dualBound;
+        status[i] = withStatus(withFake(status[i], FAKE_BOTH), ST_UPPER);
+        numberFake++;
+        sol[i] = 0.5 * dualBound;
+      }
+    } else if (st == ST_BASIC) {
+      status[i] = withFake(status[i], FAKE_NONE);
+      double gap = upper[i] - lower[i];
+      if (gap > 0.5 * dualBound && gap < 2.0 * dualBound) {
+        lower[i] = origLower[i];
+        upper[i] = origUpper[i];
+      }
+    }
+  }
+  return 1;
+}
+
+int clpgpu_context::numberAtFakeBound() const
+{
+  int count = 0;
+  for (int i = 0; i < N; i++) {
+    int f = getFake(status[i]), st = status[i] & 7;
+    if (st == ST_UPPER && (f == FAKE_UPPER || f == FAKE_BOTH))
+      count++;
+    else if (st == ST_LOWER && (f == FAKE_LOWER || f == FAKE_BOTH))
+      count++;
+  }
+  return count;
+}
+
+// ClpSimplexDual::updateDualsInDual(..., fullRecompute = true) (:2648-2868) + flipBounds, on the
+// host mirrors: only runs at refactorization boundaries, the basic solution is recomputed on the
+// device afterwards, so the rhs movement it would produce is not needed.
+int clpgpu_context::updateDualsFullRecompute()
+{
+  double tolerance = dualTolerance + fmin(1.0e-2, largestDualError);
+  int numberFlips = 0;
+  for (int i = 0; i < N; i++) {
+    double value = dj[i];
+    int st = status[i] & 7;
+    if (st == ST_UPPER) {
+      if (value > tolerance) {
+        double movement = lower[i] - upper[i];
+        if (fabs(movement) > dualBound && getFake(status[i]) == FAKE_NONE) {
+          status[i] = withFake(status[i], FAKE_LOWER);
+          lower[i] = upper[i] - dualBound;
+          numberFake++;
+        }
+        status[i] = withStatus(status[i], ST_LOWER);
+        sol[i] = lower[i];
+        numberFlips++;
+      } else if (value > -tolerance && getFake(status[i]) == FAKE_UPPER) {
+        status[i] = withStatus(status[i], ST_LOWER);
+        sol[i] = lower[i];
+      }
+    } else if (st == ST_LOWER) {
+      if (value < -tolerance) {
+        double movement = upper[i] - lower[i];
+        if (fabs(movement) > dualBound && getFake(status[i]) == FAKE_NONE) {
+          status[i] = withFake(status[i], FAKE_UPPER);
+          upper[i] = lower[i] + dualBound;
+          numberFake++;
+        }
+        status[i] = withStatus(status[i], ST_UPPER);
+        sol[i] = upper[i];
+        numberFlips++;
+      } else if (value < tolerance && getFake(status[i]) == FAKE_LOWER) {
+        status[i] = withStatus(status[i], ST_UPPER);
+        sol[i] = upper[i];
+      }
+    }
+  }
+  return numberFlips;
+}
+
+// ClpDualRowSteepest::saveWeights (src/ClpDualRowSteepest.cpp:773): 1 = before factorization,
+// 2/4 = after (restore by sequence, rebuild infeasibilities), 3 = just redo infeasibilities
+int clpgpu_context::saveWeights(int mode)
+{
+  const int g = cdiv(m, 256);
+  if (mode == 1) {
+    if (pivotRule && weightsInitialized) {
+      hipLaunchKernelGGL(k_fill, dim3(cdiv(N, 256)), dim3(256), 0, stream, D.weightBySeq, -1.0, N);
+      hipLaunchKernelGGL(k_weights_to_seq, dim3(g), dim3(256), 0, stream, D);
+    }
+    return 0;
+  }
+  if (!pivotRule)
+    return 0;
+  if (mode == 2 || mode == 4) {
+    hipLaunchKernelGGL(k_weights_from_seq, dim3(g), dim3(256), 0, stream, D, weightsInitialized ? 0 : 1);
+    weightsInitialized = true;
+  }
+  // rebuild the list in ascending position order
+  hCtrl->numberInfeasible = 0;
+  int rc = pushCtrl();
+  hipLaunchKernelGGL(k_infeas_flags, dim3(g), dim3(256), 0, stream, D);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, g, 2, 0);
+  hipLaunchKernelGGL(k_append_scatter, dim3(g), dim3(256), 0, stream, D, 0, 0);
+  hipLaunchKernelGGL(k_infeas_finish, dim3(1), dim3(1), 0, stream, D);
+  rc |= pullCtrl();
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// startup: ClpSimplexDual::startupSolve (:230) -> ClpSimplex::startup (src/ClpSimplex.cpp:9430):
+// createRim, all-slack basis unless a status array was given, factorize, changeBounds(1),
+// gutsOfSolution.
+// ---------------------------------------------------------------------------------------------
+int clpgpu_context::startup()
+{
+  for (int j = 0; j < n; j++) {
+    lower[j] = colLower[j];
+    upper[j] = colUpper[j];
+    cost[j] = obj[j];
+  }
+  for (int i = 0; i < m; i++) {
+    lower[n + i] = rowLower[i];
+    upper[n + i] = rowUpper[i];
+    cost[n + i] = 0.0;
+  }
+  if (haveStatus) {
+    status = userStatus;
+  } else {
+    // ClpSimplex::allSlackBasis (src/ClpSimplex.cpp:7831)
+    for (int i = 0; i < m; i++)
+      status[n + i] = ST_BASIC;
+    for (int j = 0; j < n; j++) {
+      if (colLower[j] >= 0.0)
+        status[j] = ST_LOWER;
+      else if (colUpper[j] <= 0.0)
+        status[j] = ST_UPPER;
+      else if (colLower[j] < -1.0e20 && colUpper[j] > 1.0e20)
+        status[j] = ST_UPPER;  // free: given bothFake bounds by changeBounds(1)
+      else if (fabs(colLower[j]) < fabs(colUpper[j]))
+        status[j] = ST_LOWER;
+      else
+        status[j] = ST_UPPER;
+    }
+  }
+  for (int i = 0; i < N; i++) {
+    int st = status[i] & 7;
+    status[i] = (unsigned char)st;
+    if (st == ST_LOWER || st == ST_FIXED)
+      sol[i] = lower[i];
+    else if (st == ST_UPPER)
+      sol[i] = upper[i];
+    else if (st != ST_BASIC)
+      sol[i] = 0.0;
+    if (st != ST_BASIC && lower[i] == upper[i])
+      status[i] = withStatus(status[i], ST_FIXED);
+    if (st == ST_LOWER && lower[i] < -1.0e20 && upper[i] < 1.0e20) {
+      status[i] = withStatus(status[i], ST_UPPER);
+      sol[i] = upper[i];
+    } else if (st == ST_UPPER && upper[i] > 1.0e20 && lower[i] > -1.0e20) {
+      status[i] = withStatus(status[i], ST_LOWER);
+      sol[i] = lower[i];
+    }
+    dj[i] = 0.0;
+  }
+  problemStatus = -1;
+  numberIterations = 0;
+  numberRefactorizations = 0;
+  numberFake = numberChanged = numberTimesOptimal = 0;
+  forceFactorization = -1;
+  lastBadIteration = -999999;
+  lastCleaned = 0;
+  factorType = 0;
+  weightsInitialized = false;
+  largestPrimalError = largestDualError = 0.0;
+  objectiveValue = 0.0;
+  dualTolerance = dualToleranceBase;
+  memset(&stats, 0, sizeof(stats));
+  if (logCapacity < 65536) {
+    logCapacity = 1 << 20;
+    int rc = dalloc(D.log, logCapacity);
+    if (rc)
+      return rc;
+  }
+  // control block
+  memset(hCtrl, 0, sizeof(Ctrl));
+  hCtrl->state = EXIT_REFACTOR;
+  hCtrl->pivotRow = -1;
+  hCtrl->sequenceIn = hCtrl->sequenceOut = -1;
+  hCtrl->maximumPivots = maximumPivots;
+  hCtrl->maximumIterations = maximumIterations;
+  hCtrl->forceFactorization = -1;
+  hCtrl->stepLimit = -1;
+  hCtrl->logCapacity = logCapacity;
+  hCtrl->pivotRule = pivotRule;
+  hCtrl->lastBadIteration = lastBadIteration;
+  hCtrl->seed = seed;
+  hCtrl->acceptablePivotBase = acceptablePivot;
+  hCtrl->primalTolerance = primalTolerance;
+  hCtrl->dualTolerance = dualTolerance;
+  hCtrl->zeroTolerance = zeroTolerance;
+  hCtrl->dualBound = dualBound;
+  hCtrl->largeValue = largeValue;
+  int rc = pushCtrl();
+  rc |= factorize();
+  if (rc) {
+    problemStatus = 4;
+    return rc;
+  }
+  double dummy = 0.0;
+  changeBounds(1, dummy);
+  rc |= pushRim();
+  rc |= gutsOfSolution();
+  started = true;
+  needStatus = true;
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ClpSimplexDual::statusOfProblemInDual (:4996-6343), host control plane; arithmetic on the
+// device (factorize, gutsOfSolution).  Restates the branches that can be reached without
+// perturbation, values pass, Cbc options or primal fall-back.
+// ---------------------------------------------------------------------------------------------
+int clpgpu_context::statusOfProblemInDual(int type)
+{
+  int rc = 0;
+  int numberPivots = pivots;
+  int tentativeStatus = problemStatus;
+  bool weightsSaved = false;
+  double changeCost = 0.0;
+  if (problemStatus > -3 || numberPivots > 0) {
+    rc |= saveWeights(1);
+    weightsSaved = true;
+    if (type) {
+      rc |= pullRim(true);
+      int frc = factorize();
+      if (frc) {
+        problemStatus = 4;  // singular: the reference restores the previous basis and flags (:5064-5125)
+        return frc;
+      }
+    }
+    if (problemStatus != -4 || numberPivots > 10)
+      problemStatus = -3;
+  }
+  if (type)
+    rc |= gutsOfSolution();
+  int situationChanged = 0;
+  bool needCleanFake = false, dirty = false;
+  double saveDualBound = dualBound;
+  while (problemStatus <= -3 && saveDualBound == dualBound) {
+    int cleanDuals = 0;
+    if (situationChanged != 0)
+      cleanDuals = 1;
+    int numberChangedBounds = 0;
+    int doOriginalTolerance = 0;
+    if (lastCleaned == numberIterations)
+      doOriginalTolerance = 1;
+    if (sumOfRelaxedDualInfeasibilities == 0.0 && sumOfRelaxedPrimalInfeasibilities == 0.0) {
+      numberDualInfeasibilities = 0;
+      sumDualInfeasibilities = 0.0;
+      numberPrimalInfeasibilities = 0;
+      sumPrimalInfeasibilities = 0.0;
+    }
+    if (numberDualInfeasibilities == 0 || problemStatus == -4) {
+      if (numberPrimalInfeasibilities == 0) {
+        numberChangedBounds = (dualBound < 1.0e20) ? changeBounds(0, changeCost) : 0;
+        dirty = true;
+        if (numberChangedBounds <= 0 && !numberDualInfeasibilities) {
+          if (lastCleaned < numberIterations && numberTimesOptimal < 4) {
+            doOriginalTolerance = 2;
+            numberTimesOptimal++;
+            if (numberTimesOptimal == 1)
+              dualTolerance = dualToleranceBase;
+            else
+              dualTolerance = dualToleranceBase * pow(2.0, numberTimesOptimal - 1);
+            cleanDuals = 2;
+          } else {
+            problemStatus = 0;  // optimal
+          }
+        } else {
+          cleanDuals = 1;
+          if (doOriginalTolerance == 1) {
+            if (dualBound > 1.0e17)
+              problemStatus = 2;
+            else
+              problemStatus = -3;
+          } else {
+            doOriginalTolerance = 2;
+          }
+        }
+      }
+      if (problemStatus == -4 || problemStatus == -5) {
+        numberChangedBounds = changeBounds(0, changeCost);
+        needCleanFake = true;
+        dirty = true;
+        if ((numberChangedBounds <= 0 || dualBound > 1.0e20 || (largestPrimalError > 1.0 && dualBound > 1.0e17))
+            && (numberPivots < 4 || sumPrimalInfeasibilities > 1.0e-6)) {
+          problemStatus = 1;
+          if (!numberPrimalInfeasibilities) {
+            problemStatus = -1;
+            doOriginalTolerance = 2;
+          }
+        } else {
+          problemStatus = -1;
+          cleanDuals = 1;
+          if (numberChangedBounds <= 0)
+            doOriginalTolerance = 2;
+        }
+      }
+    } else {
+      cleanDuals = 1;
+    }
+    if (problemStatus < 0) {
+      if (doOriginalTolerance == 2) {
+        lastCleaned = numberIterations;
+        numberChanged = 0;
+        for (int j = 0; j < n; j++)
+          cost[j] = obj[j];
+        for (int i = 0; i < m; i++)
+          cost[n + i] = 0.0;
+        // computeDuals with the original costs, on the device
+        rc |= pushRim();
+        rc |= gutsOfSolution();
+        if (cleanDuals != 2) {
+          changeBounds(3, changeCost);
+          needCleanFake = true;
+          cleanDuals = 2;
+          dirty = true;
+        }
+      }
+      if (cleanDuals == 1 || (cleanDuals == 2 && !numberDualInfeasibilities)) {
+        updateDualsFullRecompute();
+        rc |= pushRim();
+        rc |= gutsOfSolution();
+        if (updateDualsFullRecompute()) {
+          rc |= pushRim();
+          rc |= gutsOfSolution();
+        }
+        dirty = false;
+        if (numberDualInfeasibilities) {
+          if ((numberPrimalInfeasibilities || numberPivots) && problemStatus != 10)
+            problemStatus = -1;
+          else
+            problemStatus = 10;
+        } else if (situationChanged == 2) {
+          problemStatus = -1;
+          changeBounds(3, changeCost);
+          dirty = true;
+        }
+        situationChanged = 0;
+      } else {
+        if (cleanDuals != 2)
+          problemStatus = -1;
+        else
+          problemStatus = 10;
+      }
+    }
+  }
+  if (tentativeStatus != -2 && tentativeStatus != -1) {
+    int numberFlagged = 0;
+    for (int iRow = 0; iRow < m; iRow++) {
+      int iPivot = pivotVariable[iRow];
+      if (status[iPivot] & FLAGGED_BIT) {
+        numberFlagged++;
+        status[iPivot] &= (unsigned char)~FLAGGED_BIT;
+        dirty = true;
+      }
+    }
+    if (numberFlagged && !numberPivots) {
+      if (numberTimesOptimal < 3) {
+        numberTimesOptimal++;
+        problemStatus = -1;
+      } else {
+        problemStatus = 10;
+      }
+    }
+  }
+  if (problemStatus < 0) {
+    if (needCleanFake) {
+      double dummy = 0.0;
+      changeBounds(3, dummy);
+      dirty = true;
+    }
+    if (dirty)
+      rc |= pushRim();
+    if (weightsSaved) {
+      if (tentativeStatus > -3)
+        rc |= saveWeights((type < 2) ? 2 : 4);
+      else
+        rc |= saveWeights(3);
+    }
+  } else if (dirty) {
+    rc |= pushRim();
+  }
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one pivot = this fixed chain of launches (graph-capturable: every decision is on the device)
+// ---------------------------------------------------------------------------------------------
+int clpgpu_context::launchIteration()
+{
+  const int nbRows = cdiv(m, PRICE_BLOCK);
+  const int nbCols = cdiv(D.lastColumn - D.firstColumn, PRICE_BLOCK);
+  const int nb = nbRows + nbCols;
+  const int gm = cdiv(m, 256);
+  const int kc = kcap;  // launch extents use the capacity; kernels read the live k from ctrl
+  const int gk = cdiv(kc, 256);
+  // CHUZR
+  hipLaunchKernelGGL(k_chuzr, dim3(1), dim3(1024), 0, stream, D);
+  // BTRAN
+  hipLaunchKernelGGL(k_btran_slack, dim3(gm), dim3(256), 0, stream, D, (const double *)D.vecC, D.rho, 1);
+  hipLaunchKernelGGL(k_btran_t, dim3(gk), dim3(256), 0, stream, D, (const double *)D.vecC, (const double *)D.rho, D.slotA, 1);
+  hipLaunchKernelGGL(k_gemvT_partial, dim3(gk, cdiv(kc, 64)), dim3(256), 0, stream, D, (const double *)D.slotA, 1);
+  hipLaunchKernelGGL(k_gemvT_final, dim3(gk), dim3(256), 0, stream, D, D.rho, 1, 1);
+  hipLaunchKernelGGL(k_rho_finish, dim3(gm), dim3(256), 0, stream, D);
+  // PRICE + first ratio pass
+  if (timing && evUsed < (int)evStart.size())
+    (void)hipEventRecord(evStart[evUsed], stream);
+  hipLaunchKernelGGL(k_price, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
+  if (timing && evUsed < (int)evStart.size())
+    (void)hipEventRecord(evStop[evUsed++], stream);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1);
+  hipLaunchKernelGGL(k_cand_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
+  // CHUZC
+  hipLaunchKernelGGL(k_dual_column, dim3(1), dim3(1024), 0, stream, D);
+  // FTRAN of the entering column and of rho (DSE)
+  hipLaunchKernelGGL(k_unpack_in, dim3(1), dim3(256), 0, stream, D);
+  hipLaunchKernelGGL(k_ftran_gather, dim3(gk), dim3(256), 0, stream, D, (const double *)D.vecV1, (const double *)D.rho, D.slotA,
+                     D.slotB, 1);
+  hipLaunchKernelGGL(k_gemv2, dim3(cdiv(kc, 4)), dim3(256), 0, stream, D, (const double *)D.slotA, (const double *)D.slotB,
+                     D.slotC, D.slotD, 1);
+  hipLaunchKernelGGL(k_ftran_scatter, dim3(cdiv(m + kc, 256)), dim3(256), 0, stream, D, (const double *)D.vecV1,
+                     (const double *)D.rho, (const double *)D.slotC, (const double *)D.slotD, D.w, D.tau, 1);
+  hipLaunchKernelGGL(k_norm_alpha, dim3(1), dim3(1024), 0, stream, D);
+  hipLaunchKernelGGL(k_weights, dim3(gm), dim3(256), 0, stream, D);
+  // dual update, flips
+  hipLaunchKernelGGL(k_dj_update, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 1, 1);
+  hipLaunchKernelGGL(k_flip_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
+  hipLaunchKernelGGL(k_flip_apply, dim3(1), dim3(256), 0, stream, D);
+  // FTRAN of the flip rhs + primal update (all no-ops without flips)
+  hipLaunchKernelGGL(k_ftran_gather, dim3(gk), dim3(256), 0, stream, D, (const double *)D.flipRhs, (const double *)nullptr,
+                     D.slotA, (double *)nullptr, 2);
+  hipLaunchKernelGGL(k_gemv2, dim3(cdiv(kc, 4)), dim3(256), 0, stream, D, (const double *)D.slotA, (const double *)nullptr,
+                     D.slotC, (double *)nullptr, 2);
+  hipLaunchKernelGGL(k_ftran_scatter, dim3(cdiv(m + kc, 256)), dim3(256), 0, stream, D, (const double *)D.flipRhs,
+                     (const double *)nullptr, (const double *)D.slotC, (const double *)nullptr, D.x3, (double *)nullptr, 2);
+  hipLaunchKernelGGL(k_primal_update, dim3(gm), dim3(256), 0, stream, D, 1);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, gm, 2, 1);
+  hipLaunchKernelGGL(k_append_scatter, dim3(gm), dim3(256), 0, stream, D, 1, 1);
+  hipLaunchKernelGGL(k_after_primal, dim3(1), dim3(1), 0, stream, D, gm, 1);
+  hipLaunchKernelGGL(k_zero_if_flips, dim3(gm), dim3(256), 0, stream, D, D.flipRhs, m);
+  hipLaunchKernelGGL(k_flip_bounds, dim3(32), dim3(256), 0, stream, D);
+  // basis update of the nucleus inverse
+  hipLaunchKernelGGL(k_update_vectors, dim3(gk), dim3(256), 0, stream, D);
+  hipLaunchKernelGGL(k_rank1, dim3(cdiv(kc, 256), kc < 512 ? kc : 512), dim3(256), 0, stream, D);
+  hipLaunchKernelGGL(k_rank1_fix, dim3(cdiv(kc + 1, 256)), dim3(256), 0, stream, D);
+  hipLaunchKernelGGL(k_rank1_fix2, dim3(gk), dim3(256), 0, stream, D);
+  // primal update with the entering column
+  hipLaunchKernelGGL(k_primal_update, dim3(gm), dim3(256), 0, stream, D, 0);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, gm, 2, 1);
+  hipLaunchKernelGGL(k_append_scatter, dim3(gm), dim3(256), 0, stream, D, 0, 1);
+  hipLaunchKernelGGL(k_after_primal, dim3(1), dim3(1), 0, stream, D, gm, 0);
+  hipLaunchKernelGGL(k_house, dim3(1), dim3(256), 0, stream, D);
+  return 0;
+}
+
+// ClpSimplexDual::whileIterating (:973-2384): the loop body runs on the device; this is the exit
+// handling.  Returns 0 when the caller should go to statusOfProblemInDual, 1 on step limit.
+int clpgpu_context::whileIterating(int stepTarget)
+{
+  // push the scalars the device needs for this run of iterations
+  hCtrl->state = RUN;
+  hCtrl->stepLimit = stepTarget;
+  hCtrl->saveSumDual = sumDualInfeasibilities;
+  hCtrl->largestPrimalError = largestPrimalError;
+  hCtrl->largestDualError = largestDualError;
+  hCtrl->dualTolerance = dualTolerance;
+  hCtrl->dualBound = dualBound;
+  hCtrl->objectiveValue = objectiveValue;
+  hCtrl->numberIterations = numberIterations;
+  hCtrl->forceFactorization = forceFactorization;
+  hCtrl->numberChanged = numberChanged;
+  hCtrl->lastBadIteration = lastBadIteration;
+  hCtrl->maximumPivots = maximumPivots;
+  hCtrl->maximumIterations = maximumIterations;
+  int rc = pushCtrl();
+  if (timing && evStart.empty()) {
+    evStart.resize(checkEvery);
+    evStop.resize(checkEvery);
+    for (int i = 0; i < checkEvery; i++) {
+      (void)hipEventCreate(&evStart[i]);
+      (void)hipEventCreate(&evStop[i]);
+    }
+  }
+  while (!rc) {
+    evUsed = 0;
+    int itersBefore = hCtrl->numberIterations;
+    for (int b = 0; b < checkEvery; b++)
+      launchIteration();
+    rc |= pullCtrl();
+    if (timing) {
+      int done = hCtrl->numberIterations - itersBefore;
+      int timed = hCtrl->state == RUN ? evUsed : (done + 1 < evUsed ? done + 1 : evUsed);
+      for (int i = 0; i < timed; i++) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, evStart[i], evStop[i]) == hipSuccess) {
+          stats.price_ms += ms;
+          stats.price_launches++;
+        }
+      }
+    }
+    if (hCtrl->state != RUN)
+      break;
+  }
+  if (rc)
+    return rc;
+  // pull scalars back
+  numberIterations = hCtrl->numberIterations;
+  objectiveValue = hCtrl->objectiveValue;
+  pivots = hCtrl->pivots;
+  forceFactorization = hCtrl->forceFactorization;
+  numberChanged = hCtrl->numberChanged;
+  acceptablePivot = hCtrl->acceptablePivotBase;
+  seed = hCtrl->seed;
+  const int state = hCtrl->state;
+  const int g = cdiv(m, 256);
+  if (state != EXIT_REFACTOR && state != EXIT_STEP_LIMIT && state != EXIT_MAX_ITERATIONS) {
+    // the pivot was abandoned part-way: k_house did not clear the sparse work vectors
+    hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, stream, D.vecC, m);
+    hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, stream, D.vecV1, m);
+    hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, stream, D.flipRhs, m);
+  }
+  switch (state) {
+  case EXIT_STEP_LIMIT:
+    return 1;
+  case EXIT_REFACTOR:
+    problemStatus = -2;
+    break;
+  case EXIT_MAX_ITERATIONS:
+    problemStatus = 3;
+    break;
+  case EXIT_ALPHA_CHECK: {
+    // :1451-1500
+    hipLaunchKernelGGL(k_unroll_weights, dim3(g), dim3(256), 0, stream, D);
+    if (pivots) {
+      problemStatus = -2;
+    } else {
+      rc |= pullRim(true);
+      status[hCtrl->sequenceOut] |= FLAGGED_BIT;
+      rc |= pushRim();
+      lastBadIteration = numberIterations;
+      if (fabs(hCtrl->alpha) < 1.0e-10 && fabs(hCtrl->btranAlpha) < 1.0e-8 && numberIterations > 100)
+        problemStatus = 1;
+      else
+        problemStatus = -2;  // the reference `continue`s with the same factorization; a refresh is equivalent here
+    }
+    break;
+  }
+  case EXIT_BACKWARDS:
+    hipLaunchKernelGGL(k_unroll_weights, dim3(g), dim3(256), 0, stream, D);
+    problemStatus = -2;
+    break;
+  case EXIT_BAD_UPDATE: {
+    // updateStatus == 2 (:1618-1659)
+    hipLaunchKernelGGL(k_unroll_weights, dim3(g), dim3(256), 0, stream, D);
+    if (pivots) {
+      problemStatus = -2;
+    } else {
+      rc |= pullRim(true);
+      status[hCtrl->sequenceOut] |= FLAGGED_BIT;
+      rc |= pushRim();
+      lastBadIteration = numberIterations;
+      problemStatus = -2;
+    }
+    break;
+  }
+  case EXIT_NO_INCOMING: {
+    // no incoming column is valid (:1869-2079)
+    problemStatus = -2;
+    // "if (sequenceIn_ < 0 && acceptablePivot <= acceptablePivot_) if (!pivots) problemStatus_ = 1" (:1328)
+    if (hCtrl->acceptablePivot <= acceptablePivot && !pivots)
+      problemStatus = 1;
+    if (pivots < 2 && acceptablePivot <= 1.0e-8 && acceptablePivot > 0.0) {
+      rc |= pullRim(true);
+      double dualTest = 1.0e13;
+      if (!numberAtFakeBound())
+        dualTest = 0.0;
+      if (hCtrl->bestPossible < 1.0e-11 && dualBound > dualTest) {
+        problemStatus = 1;
+      } else if (pivots == 0) {
+        problemStatus = -4;
+      }
+    }
+    acceptablePivot = fabs(acceptablePivot);
+    if (pivots < 5 && acceptablePivot > 1.0e-8)
+      acceptablePivot = 1.0e-8;
+    hCtrl->acceptablePivotBase = acceptablePivot;
+    break;
+  }
+  case EXIT_NO_PIVOT_ROW: {
+    // no pivot row (:2080-2331)
+    if (!pivots) {
+      rc |= pullRim(true);
+      problemStatus = -1;
+      if (numberPrimalInfeasibilities)
+        problemStatus = -4;
+      bool anyFlagged = false;
+      for (int iRow = 0; iRow < m && !anyFlagged; iRow++)
+        anyFlagged = (status[pivotVariable[iRow]] & FLAGGED_BIT) != 0;
+      int fake = 0;
+      for (int i = 0; i < N; i++)
+        fake += getFake(status[i]) != FAKE_NONE;
+      numberFake = fake;
+      if (numberFake || numberDualInfeasibilities) {
+        problemStatus = -5;
+      } else if (anyFlagged) {
+        problemStatus = -5;
+      } else {
+        problemStatus = 0;
+        numberPrimalInfeasibilities = 0;
+        sumPrimalInfeasibilities = 0.0;
+        numberDualInfeasibilities = 0;
+        sumDualInfeasibilities = 0.0;
+        if (numberChanged) {
+          numberChanged = 0;
+          for (int j = 0; j < n; j++)
+            cost[j] = obj[j];
+          for (int i = 0; i < m; i++)
+            cost[n + i] = 0.0;
+          rc |= pushRim();
+          rc |= gutsOfSolution();
+          if (numberDualInfeasibilities)
+            problemStatus = 10;
+        }
+      }
+    } else {
+      problemStatus = -3;
+      int half = (pivots + 1) >> 1;
+      if (forceFactorization < 0 || half < forceFactorization)
+        forceFactorization = half;
+    }
+    break;
+  }
+  default:
+    setError("unexpected device state %d", state);
+    problemStatus = 4;
+    break;
+  }
+  return rc;
+}
+
+void clpgpu_context::finish()
+{
+  pullRim(true);
+  if (problemStatus == 0 || problemStatus == 3) {
+    double objective = 0.0;
+    for (int j = 0; j < n; j++)
+      objective += obj[j] * sol[j];
+    objectiveValue = objective;
+  }
+}
+
+int clpgpu_context::run(int maxSteps)
+{
+  auto t0 = std::chrono::steady_clock::now();
+  int rc = 0;
+  if (!started) {
+    rc = startup();
+    if (rc)
+      return problemStatus = 4;
+  }
+  int stepTarget = (maxSteps < 0) ? -1 : numberIterations + maxSteps;
+  int result = -1;
+  while (problemStatus < 0) {
+    if (needStatus) {
+      rc = statusOfProblemInDual(factorType);
+      factorType = 1;
+      needStatus = false;
+      if (rc) {
+        if (problemStatus < 0)
+          problemStatus = 4;
+        break;
+      }
+      if (problemStatus >= 0)
+        break;
+    }
+    problemStatus = -1;
+    rc = whileIterating(stepTarget);
+    if (rc == 1) {
+      result = -1;
+      auto t1 = std::chrono::steady_clock::now();
+      seconds += std::chrono::duration<double>(t1 - t0).count();
+      return result;
+    }
+    if (rc) {
+      problemStatus = 4;
+      break;
+    }
+    needStatus = true;
+  }
+  finish();
+  auto t1 = std::chrono::steady_clock::now();
+  seconds += std::chrono::duration<double>(t1 - t0).count();
+  return problemStatus;
+}
+
+// ---------------------------------------------------------------------------------------------
+// plug-in level pricing call (ClpMatrixBase::transposeTimes surface): host arrays in and out
+// ---------------------------------------------------------------------------------------------
+int clpgpu_context::priceRow(int numberPi, const int *piIndex, const double *piValue, const unsigned char *st,
+                             const double *djv, double zeroTol, double dualTol, double accPivot, int *numberOut,
+                             int *outIndex, double *outValue, int *numberCand, int *candIndex, double *candValue,
+                             double *upperTheta)
+{
+  std::vector<double> rho(m, 0.0), piNeg(m, 0.0);
+  for (int i = 0; i < numberPi; i++) {
+    rho[piIndex[i]] = piValue[i];
+    piNeg[piIndex[i]] = -piValue[i];
+  }
+  int rc = 0;
+  rc |= h2d(D.rho, rho.data(), m);
+  rc |= h2d(D.piNeg, piNeg.data(), m);
+  rc |= h2d(D.status, st, N);
+  rc |= h2d(D.dj, djv, N);
+  memset(hCtrl, 0, sizeof(Ctrl));
+  hCtrl->state = RUN;
+  hCtrl->dualTolerance = dualTol;
+  hCtrl->zeroTolerance = zeroTol;
+  hCtrl->acceptablePivot = accPivot;
+  rc |= pushCtrl();
+  const int nbRows = cdiv(m, PRICE_BLOCK);
+  const int nbCols = cdiv(D.lastColumn - D.firstColumn, PRICE_BLOCK);
+  const int nb = nbRows + nbCols;
+  hipLaunchKernelGGL(k_zero, dim3(cdiv(n, 256)), dim3(256), 0, stream, D.alphaCol, n);
+  hipLaunchKernelGGL(k_price, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1);
+  hipLaunchKernelGGL(k_cand_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
+  rc |= pullCtrl();
+  std::vector<double> alpha(n);
+  rc |= d2h(alpha.data(), D.alphaCol, n);
+  int count = 0;
+  for (int j = 0; j < n; j++)
+    if (alpha[j] != 0.0) {
+      outIndex[count] = j;
+      outValue[count++] = alpha[j];
+    }
+  *numberOut = count;
+  *numberCand = hCtrl->numberCandidates;
+  *upperTheta = hCtrl->upperTheta;
+  if (hCtrl->numberCandidates) {
+    rc |= d2h(candIndex, D.candSeq, hCtrl->numberCandidates);
+    rc |= d2h(candValue, D.candAlpha, hCtrl->numberCandidates);
+  }
+  // leave the work vectors clean
+  hipLaunchKernelGGL(k_zero, dim3(cdiv(m, 256)), dim3(256), 0, stream, D.rho, m);
+  hipLaunchKernelGGL(k_zero, dim3(cdiv(m, 256)), dim3(256), 0, stream, D.piNeg, m);
+  rc |= sync();
+  return rc;
+}
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+clpgpu_context *clpgpu_create(int device)
+{
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    fprintf(stderr, "clpgpu_create: no HIP device available (this library has no CPU fallback)\n");
+    return nullptr;
+  }
+  if (device < 0 || device >= count)
+    return nullptr;
+  if (hipSetDevice(device) != hipSuccess)
+    return nullptr;
+  clpgpu_context *ctx = new clpgpu_context();
+  ctx->device = device;
+  if (hipStreamCreate(&ctx->stream) != hipSuccess) {
+    delete ctx;
+    return nullptr;
+  }
+  memset(&ctx->stats, 0, sizeof(ctx->stats));
+  memset(&ctx->D, 0, sizeof(ctx->D));
+  return ctx;
+}
+
+void clpgpu_destroy(clpgpu_context *ctx)
+{
+  if (!ctx)
+    return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (void *p : ctx->allocations)
+    (void)hipFree(p);
+  if (ctx->hCtrl)
+    (void)hipHostFree(ctx->hCtrl);
+  for (auto &e : ctx->evStart)
+    (void)hipEventDestroy(e);
+  for (auto &e : ctx->evStop)
+    (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *clpgpu_last_error(const clpgpu_context *ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+void *clpgpu_stream(clpgpu_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int clpgpu_load_problem(clpgpu_context *ctx, int numberRows, int numberColumns, const int *columnStart, const int *rowIndex,
+                        const double *element, const double *columnLower, const double *columnUpper, const double *objective,
+                        const double *rowLower, const double *rowUpper)
+{
+  if (!ctx)
+    return -99;
+  (void)hipSetDevice(ctx->device);
+  return ctx->loadProblem(numberRows, numberColumns, columnStart, rowIndex, element, columnLower, columnUpper, objective,
+                          rowLower, rowUpper);
+}
+
+int clpgpu_set_column_range(clpgpu_context *ctx, int firstColumn, int lastColumn)
+{
+  if (!ctx || firstColumn < 0 || lastColumn > ctx->n || firstColumn > lastColumn)
+    return -1;
+  ctx->D.firstColumn = firstColumn;
+  ctx->D.lastColumn = lastColumn;
+  return 0;
+}
+
+int clpgpu_times(clpgpu_context *ctx, double scalar, const double *x, double *y)
+{
+  if (!ctx)
+    return -99;
+  // needs the row copy in its load-time state or any partition: order inside a row does not matter
+  int rc = 0;
+  rc |= ctx->h2d(ctx->D.alphaCol, x, ctx->n);
+  rc |= ctx->h2d(ctx->D.x3, y, ctx->m);
+  hipLaunchKernelGGL(k_times, dim3(cdiv(ctx->m, 256)), dim3(256), 0, ctx->stream, ctx->D, scalar, (const double *)ctx->D.alphaCol,
+                     ctx->D.x3);
+  rc |= ctx->d2h(y, ctx->D.x3, ctx->m);
+  hipLaunchKernelGGL(k_zero, dim3(cdiv(ctx->m, 256)), dim3(256), 0, ctx->stream, ctx->D.x3, ctx->m);
+  hipLaunchKernelGGL(k_zero, dim3(cdiv(ctx->n, 256)), dim3(256), 0, ctx->stream, ctx->D.alphaCol, ctx->n);
+  rc |= ctx->sync();
+  return rc;
+}
+
+int clpgpu_transpose_times(clpgpu_context *ctx, double scalar, const double *x, double *y)
+{
+  if (!ctx)
+    return -99;
+  int rc = 0;
+  rc |= ctx->h2d(ctx->D.x3, x, ctx->m);
+  rc |= ctx->h2d(ctx->D.alphaCol, y, ctx->n);
+  hipLaunchKernelGGL(k_transpose_times, dim3(cdiv(ctx->n, 256)), dim3(256), 0, ctx->stream, ctx->D, scalar,
+                     (const double *)ctx->D.x3, ctx->D.alphaCol);
+  rc |= ctx->d2h(y, ctx->D.alphaCol, ctx->n);
+  hipLaunchKernelGGL(k_zero, dim3(cdiv(ctx->m, 256)), dim3(256), 0, ctx->stream, ctx->D.x3, ctx->m);
+  hipLaunchKernelGGL(k_zero, dim3(cdiv(ctx->n, 256)), dim3(256), 0, ctx->stream, ctx->D.alphaCol, ctx->n);
+  rc |= ctx->sync();
+  return rc;
+}
+
+int clpgpu_price_row(clpgpu_context *ctx, int numberPi, const int *piIndex, const double *piValue, const unsigned char *status,
+                     const double *dj, double zeroTolerance, double dualTolerance, double acceptablePivot, int *numberOut,
+                     int *outIndex, double *outValue, int *numberCandidates, int *candIndex, double *candValue,
+                     double *upperTheta)
+{
+  if (!ctx)
+    return -99;
+  return ctx->priceRow(numberPi, piIndex, piValue, status, dj, zeroTolerance, dualTolerance, acceptablePivot, numberOut, outIndex,
+                       outValue, numberCandidates, candIndex, candValue, upperTheta);
+}
+
+int clpgpu_factorize(clpgpu_context *ctx, const unsigned char *status, int *pivotVariable)
+{
+  if (!ctx)
+    return -99;
+  ctx->status.assign(status, status + ctx->N);
+  if (!ctx->hCtrl->zeroTolerance)
+    ctx->hCtrl->zeroTolerance = ctx->zeroTolerance;
+  int rc = ctx->pushCtrl();
+  rc |= ctx->h2d(ctx->D.status, ctx->status.data(), ctx->N);
+  if (rc)
+    return rc;
+  rc = ctx->factorize();
+  if (!rc) {
+    rc = ctx->pushCtrl();
+    if (pivotVariable)
+      memcpy(pivotVariable, ctx->pivotVariable.data(), sizeof(int) * (size_t)ctx->m);
+  }
+  return rc;
+}
+
+int clpgpu_ftran(clpgpu_context *ctx, double *region)
+{
+  if (!ctx)
+    return -99;
+  int rc = ctx->h2d(ctx->D.vecV2, region, ctx->m);
+  ctx->ftranDevice(ctx->D.vecV2, ctx->D.x3);
+  rc |= ctx->d2h(region, ctx->D.x3, ctx->m);
+  hipLaunchKernelGGL(k_zero, dim3(cdiv(ctx->m, 256)), dim3(256), 0, ctx->stream, ctx->D.vecV2, ctx->m);
+  hipLaunchKernelGGL(k_zero, dim3(cdiv(ctx->m, 256)), dim3(256), 0, ctx->stream, ctx->D.x3, ctx->m);
+  rc |= ctx->sync();
+  return rc;
+}
+
+int clpgpu_btran(clpgpu_context *ctx, double *region)
+{
+  if (!ctx)
+    return -99;
+  int rc = ctx->h2d(ctx->D.tau, region, ctx->m);
+  ctx->btranDevice(ctx->D.tau, ctx->D.vecV2);
+  rc |= ctx->d2h(region, ctx->D.vecV2, ctx->m);
+  hipLaunchKernelGGL(k_zero, dim3(cdiv(ctx->m, 256)), dim3(256), 0, ctx->stream, ctx->D.vecV2, ctx->m);
+  hipLaunchKernelGGL(k_zero, dim3(cdiv(ctx->m, 256)), dim3(256), 0, ctx->stream, ctx->D.tau, ctx->m);
+  rc |= ctx->sync();
+  return rc;
+}
+
+// CoinOtherFactorization::replaceColumn surface: the rank-1 nucleus update needs w = B^-1 a_q and
+// rho = B^-T e_p, both recomputed here from the device state (a Clp adapter passes the same two
+// vectors it already holds; this standalone form keeps the C ABI to PODs).
+int clpgpu_replace_column(clpgpu_context *ctx, int pivotRow, int sequenceIn, double pivotCheck, double acceptablePivot)
+{
+  if (!ctx)
+    return -99;
+  (void)pivotCheck;
+  (void)acceptablePivot;
+  const int m = ctx->m, n = ctx->n;
+  Ctrl *h = ctx->hCtrl;
+  if (h->pivots >= ctx->maximumPivots)
+    return 5;
+  if (h->k + 2 >= ctx->kcap)
+    return 3;
+  // stage the two solves through the same kernels the iteration uses
+  std::vector<double> c(m, 0.0), v(m, 0.0);
+  c[pivotRow] = 1.0;
+  if (sequenceIn >= n)
+    v[sequenceIn - n] = -1.0;
+  else
+    for (int p = ctx->colStart[sequenceIn]; p < ctx->colStart[sequenceIn + 1]; p++)
+      v[ctx->row[p]] = ctx->elem[p];
+  int rc = 0;
+  rc |= ctx->h2d(ctx->D.vecC, c.data(), m);
+  rc |= ctx->h2d(ctx->D.vecV1, v.data(), m);
+  int seqOut = ctx->pivotVariable[pivotRow];
+  h->state = RUN;
+  h->pivotRow = pivotRow;
+  h->sequenceIn = sequenceIn;
+  h->sequenceOut = seqOut;
+  h->directionOut = 1;
+  h->zeroTolerance = 0.0;  // keep rho unpruned for the plug-in form
+  rc |= ctx->pushCtrl();
+  const int gm = cdiv(m, 256), kc = ctx->kcap, gk = cdiv(kc, 256);
+  hipStream_t s = ctx->stream;
+  Dev &D = ctx->D;
+  hipLaunchKernelGGL(k_btran_slack, dim3(gm), dim3(256), 0, s, D, (const double *)D.vecC, D.rho, 1);
+  hipLaunchKernelGGL(k_btran_t, dim3(gk), dim3(256), 0, s, D, (const double *)D.vecC, (const double *)D.rho, D.slotA, 1);
+  hipLaunchKernelGGL(k_gemvT_partial, dim3(gk, cdiv(kc, 64)), dim3(256), 0, s, D, (const double *)D.slotA, 1);
+  hipLaunchKernelGGL(k_gemvT_final, dim3(gk), dim3(256), 0, s, D, D.rho, 1, 1);
+  hipLaunchKernelGGL(k_ftran_gather, dim3(gk), dim3(256), 0, s, D, (const double *)D.vecV1, (const double *)nullptr, D.slotA,
+                     (double *)nullptr, 1);
+  hipLaunchKernelGGL(k_gemv2, dim3(cdiv(kc, 4)), dim3(256), 0, s, D, (const double *)D.slotA, (const double *)nullptr, D.slotC,
+                     (double *)nullptr, 1);
+  hipLaunchKernelGGL(k_ftran_scatter, dim3(cdiv(m + kc, 256)), dim3(256), 0, s, D, (const double *)D.vecV1,
+                     (const double *)nullptr, (const double *)D.slotC, (const double *)nullptr, D.w, (double *)nullptr, 1);
+  double alpha = 0.0;
+  rc |= ctx->d2h(&alpha, D.w + pivotRow, 1);
+  if (rc)
+    return rc;
+  if (fabs(alpha) < ctx->zeroTolerance) {
+    h->state = EXIT_BAD_UPDATE;
+    hipLaunchKernelGGL(k_zero, dim3(gm), dim3(256), 0, s, D.vecC, m);
+    hipLaunchKernelGGL(k_zero, dim3(gm), dim3(256), 0, s, D.vecV1, m);
+    hipLaunchKernelGGL(k_zero, dim3(gm), dim3(256), 0, s, D.rho, m);
+    ctx->sync();
+    return 2;
+  }
+  rc |= ctx->pullCtrl();
+  h->alpha = alpha;
+  int inStruct = sequenceIn < n, outStruct = seqOut < n;
+  std::vector<int> slotOfCol(n), slotOfRow(m);
+  rc |= ctx->d2h(slotOfCol.data(), D.slotOfCol, n);
+  rc |= ctx->d2h(slotOfRow.data(), D.slotOfRow, m);
+  h->updateCase = outStruct ? (inStruct ? 0 : 2) : (inStruct ? 1 : 3);
+  h->slotColOut = outStruct ? slotOfCol[seqOut] : -1;
+  h->rowOfSlackOut = outStruct ? -1 : (seqOut - n);
+  h->slotRowIn = inStruct ? -1 : slotOfRow[sequenceIn - n];
+  h->zeroTolerance = ctx->zeroTolerance;
+  // k_house also advances the iteration bookkeeping; give it neutral scalars
+  h->theta = 0.0;
+  h->dualOut = 0.0;
+  h->directionIn = 1;
+  h->lowerIn = h->upperIn = h->valueIn = 0.0;
+  h->lowerOut = h->upperOut = 0.0;
+  h->objectiveChange = 0.0;
+  h->maximumIterations = 2147483647;
+  h->maximumPivots = ctx->maximumPivots;
+  h->logCapacity = 0;
+  rc |= ctx->pushCtrl();
+  hipLaunchKernelGGL(k_update_vectors, dim3(gk), dim3(256), 0, s, D);
+  hipLaunchKernelGGL(k_rank1, dim3(cdiv(kc, 256), kc < 512 ? kc : 512), dim3(256), 0, s, D);
+  hipLaunchKernelGGL(k_rank1_fix, dim3(cdiv(kc + 1, 256)), dim3(256), 0, s, D);
+  hipLaunchKernelGGL(k_rank1_fix2, dim3(gk), dim3(256), 0, s, D);
+  // bookkeeping only (positions, slots, row copy partition)
+  std::vector<double> saveSol(2), saveDj(2);
+  hipLaunchKernelGGL(k_house, dim3(1), dim3(256), 0, s, D);
+  rc |= ctx->pullCtrl();
+  rc |= ctx->d2h(ctx->pivotVariable.data(), D.pivotVariable, m);
+  hipLaunchKernelGGL(k_zero, dim3(gm), dim3(256), 0, s, D.rho, m);
+  hipLaunchKernelGGL(k_zero, dim3(gm), dim3(256), 0, s, D.w, m);
+  rc |= ctx->sync();
+  ctx->pivots = h->pivots;
+  return rc ? rc : 0;
+}
+
+int clpgpu_pivots(const clpgpu_context *ctx) { return ctx ? ctx->hCtrl->pivots : 0; }
+
+int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
+{
+  if (!ctx)
+    return -99;
+  if (!strcmp(name, "pivot_rule")) ctx->pivotRule = (int)v;
+  else if (!strcmp(name, "max_iterations")) ctx->maximumIterations = (int)v;
+  else if (!strcmp(name, "max_pivots")) ctx->maximumPivots = (int)v;
+  else if (!strcmp(name, "dual_bound")) ctx->dualBound = v;
+  else if (!strcmp(name, "primal_tolerance")) ctx->primalTolerance = v;
+  else if (!strcmp(name, "dual_tolerance")) ctx->dualTolerance = ctx->dualToleranceBase = v;
+  else if (!strcmp(name, "random_seed")) ctx->seed = (unsigned int)v;
+  else if (!strcmp(name, "log_level")) ctx->logLevel = (int)v;
+  else if (!strcmp(name, "check_every")) ctx->checkEvery = (int)v < 1 ? 1 : (int)v;
+  else if (!strcmp(name, "timing")) ctx->timing = (int)v;
+  else return -1;
+  return 0;
+}
+
+int clpgpu_set_status(clpgpu_context *ctx, const unsigned char *status)
+{
+  if (!ctx)
+    return -99;
+  ctx->userStatus.assign(status, status + ctx->N);
+  ctx->haveStatus = true;
+  return 0;
+}
+
+int clpgpu_dual(clpgpu_context *ctx)
+{
+  if (!ctx)
+    return -99;
+  (void)hipSetDevice(ctx->device);
+  ctx->started = false;
+  ctx->seconds = 0.0;
+  return ctx->run(-1);
+}
+
+int clpgpu_dual_steps(clpgpu_context *ctx, int iterations)
+{
+  if (!ctx)
+    return -99;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->started && ctx->problemStatus >= 0)
+    return ctx->problemStatus;
+  return ctx->run(iterations);
+}
+
+int clpgpu_number_iterations(const clpgpu_context *ctx) { return ctx ? ctx->numberIterations : 0; }
+double clpgpu_objective_value(const clpgpu_context *ctx) { return ctx ? ctx->objectiveValue : 0.0; }
+
+int clpgpu_get_solution(clpgpu_context *ctx, double *solution)
+{
+  if (!ctx)
+    return -99;
+  return ctx->d2h(solution, ctx->D.sol, ctx->N);
+}
+int clpgpu_get_reduced_costs(clpgpu_context *ctx, double *dj)
+{
+  if (!ctx)
+    return -99;
+  return ctx->d2h(dj, ctx->D.dj, ctx->N);
+}
+int clpgpu_get_status(clpgpu_context *ctx, unsigned char *status)
+{
+  if (!ctx)
+    return -99;
+  return ctx->d2h(status, ctx->D.status, ctx->N);
+}
+int clpgpu_get_pivot_variable(clpgpu_context *ctx, int *pivotVariable)
+{
+  if (!ctx)
+    return -99;
+  return ctx->d2h(pivotVariable, ctx->D.pivotVariable, ctx->m);
+}
+int clpgpu_get_pivot_log(clpgpu_context *ctx, clpgpu_pivot_record *out, int maxRecords)
+{
+  if (!ctx)
+    return -99;
+  if (ctx->pullCtrl())
+    return -99;
+  int total = ctx->hCtrl->logCount;
+  int avail = total < ctx->logCapacity ? total : ctx->logCapacity;
+  int count = avail < maxRecords ? avail : maxRecords;
+  if (out && count > 0)
+    if (ctx->d2h((PivotRecord *)out, ctx->D.log, count))
+      return -99;
+  return total;
+}
+int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
+{
+  if (!ctx || !stats)
+    return -99;
+  if (ctx->pullCtrl())
+    return -99;
+  *stats = ctx->stats;
+  stats->price_bytes = ctx->hCtrl->statPriceBytes;
+  if (!ctx->timing)
+    stats->price_launches = (long)ctx->hCtrl->statPriceLaunches;
+  stats->total_ms = ctx->seconds * 1.0e3;
+  stats->iterations = ctx->numberIterations;
+  stats->refactorizations = ctx->numberRefactorizations;
+  return 0;
+}
+
+}  // extern "C"

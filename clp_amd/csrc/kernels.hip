@@ -1,0 +1,1943 @@
+// kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for one pivot of the revised
+// dual simplex.  Each kernel cites the reference loop it replaces (paths relative to the Clp tree).
+//
+// Rules followed throughout:
+//  * every kernel of the iteration chain starts with `if (ctrl->state != RUN) return;` -- control
+//    flow lives on the device, the host only polls the control block;
+//  * no floating-point atomics and fixed reduction trees: results are deterministic run to run;
+//  * compiled with -ffp-contract=off so per-column dot products are the same sequence of IEEE
+//    operations as the reference's scalar loops (bit-identical tableau rows).
+#include "device_state.h"
+
+namespace clpgpu {
+
+#define WAVE 64
+constexpr double REALLY_TINY = 1.0e-100;  // COIN_INDEXED_REALLY_TINY_ELEMENT
+constexpr double DEVEX_TRY_NORM = 1.0e-4; // src/ClpSimplex.hpp:2056
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ inline double waveSum(double v)
+{
+  for (int o = 32; o > 0; o >>= 1)
+    v += __shfl_down(v, o);
+  return v;  // valid in lane 0; fixed tree => deterministic
+}
+__device__ inline double waveMin(double v)
+{
+  for (int o = 32; o > 0; o >>= 1)
+    v = fmin(v, __shfl_down(v, o));
+  return v;
+}
+// block-wide deterministic sum; result valid in every thread. blockDim.x multiple of 64, <= 1024
+__device__ inline double blockSum(double v, double *sh /*[16]*/)
+{
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  v = waveSum(v);
+  __syncthreads();
+  if (lane == 0)
+    sh[wv] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int i = 0; i < nw; i++)
+    t += sh[i];
+  return t;
+}
+__device__ inline double blockMin(double v, double *sh)
+{
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  v = waveMin(v);
+  __syncthreads();
+  if (lane == 0)
+    sh[wv] = v;
+  __syncthreads();
+  double t = sh[0];
+  for (int i = 1; i < nw; i++)
+    t = fmin(t, sh[i]);
+  return t;
+}
+// block argmax of (value, smallest key wins ties); value <= floorValue => none (key stays -1)
+__device__ inline void blockArgMax(double &value, int &key, double *shv, int *shk)
+{
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int o = 32; o > 0; o >>= 1) {
+    double ov = __shfl_down(value, o);
+    int ok = __shfl_down(key, o);
+    if (ok >= 0 && (key < 0 || ov > value || (ov == value && ok < key))) {
+      value = ov;
+      key = ok;
+    }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    shv[wv] = value;
+    shk[wv] = key;
+  }
+  __syncthreads();
+  value = shv[0];
+  key = shk[0];
+  for (int i = 1; i < nw; i++) {
+    if (shk[i] >= 0 && (key < 0 || shv[i] > value || (shv[i] == value && shk[i] < key))) {
+      value = shv[i];
+      key = shk[i];
+    }
+  }
+}
+// exclusive rank of `flag` inside the block (threads in index order) + block total
+__device__ inline int blockRank(int flag, int &total, int *sh /*[17]*/)
+{
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  unsigned long long mask = __ballot(flag);
+  int rank = __popcll(mask & ((1ull << lane) - 1ull));
+  __syncthreads();
+  if (lane == 0)
+    sh[wv] = __popcll(mask);
+  __syncthreads();
+  int base = 0;
+  total = 0;
+  for (int i = 0; i < nw; i++) {
+    if (i < wv)
+      base += sh[i];
+    total += sh[i];
+  }
+  return base + rank;
+}
+
+__device__ inline double randomDouble(Ctrl *c)
+{
+  // CoinThreadRandom::randomDouble, 32-bit LCG form [CoinUtils, not in the reference tree]
+  c->seed = 1664525u * c->seed + 1013904223u;
+  return ((double)c->seed) / 4294967296.0;
+}
+
+// =============================================================================================
+// CHUZR -- ClpDualRowSteepest::pivotRow (src/ClpDualRowSteepest.cpp:179-364, full scan) or
+// ClpDualRowDantzig::pivotRow (src/ClpDualRowDantzig.cpp:56-92), then the scalar part of
+// ClpSimplexDual::dualRow (src/ClpSimplexDual.cpp:3079-3102) and the acceptablePivot choice of
+// whileIterating (:1270-1278).  One workgroup: the list is at most m long and is read once.
+// =============================================================================================
+__global__ void __launch_bounds__(1024) k_chuzr(Dev D)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ double shv[16];
+  __shared__ int shk[16];
+  __shared__ double s_tolerance;
+  __shared__ int s_number, s_start, s_last;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    s_number = 0;
+    s_start = 0;
+    s_tolerance = 0.0;
+    s_last = -1;
+  }
+  if (tid == 0 && c->stepLimit >= 0 && c->numberIterations >= c->stepLimit) {
+    c->state = EXIT_STEP_LIMIT;
+  } else if (tid == 0) {
+    int last = c->pivotRow;  // model_->pivotRow(): persists across refactorizations
+    double tolerance = c->primalTolerance;
+    if (c->pivotRule) {
+      tolerance = tolerance + fmin(1.0e-2, c->largestPrimalError);
+      tolerance = fmin(1000.0, tolerance);
+      tolerance *= tolerance;
+      if (last >= 0 && last < D.m) {
+        int iPivot = D.pivotVariable[last];
+        double value = D.sol[iPivot], lower = D.lower[iPivot], upper = D.upper[iPivot];
+        if (value > upper + tolerance) {
+          value -= upper;
+          value *= value;
+          if (D.infeas[last] == 0.0)
+            D.infIndex[c->numberInfeasible++] = last;
+          D.infeas[last] = value;
+        } else if (value < lower - tolerance) {
+          value -= lower;
+          value *= value;
+          if (D.infeas[last] == 0.0)
+            D.infIndex[c->numberInfeasible++] = last;
+          D.infeas[last] = value;
+        } else if (D.infeas[last] != 0.0) {
+          D.infeas[last] = REALLY_TINY;
+        }
+      }
+      if (c->numberIterations < c->lastBadIteration + 200) {
+        if (c->largestDualError > c->largestPrimalError)
+          tolerance *= fmin(c->largestDualError / c->largestPrimalError, 1000.0);
+      }
+      int number = c->numberInfeasible;
+      double dstart = ((double)number) * randomDouble(c);
+      s_number = number;
+      s_start = (int)dstart;
+    } else {
+      if (c->largestPrimalError > 1.0e-8)
+        tolerance *= c->largestPrimalError / 1.0e-8;
+      s_number = D.m;
+      s_start = 0;
+    }
+    s_tolerance = tolerance;
+    s_last = last;
+  }
+  __syncthreads();
+  if (c->state != RUN)
+    return;
+  const double tolerance = s_tolerance;
+  const int number = s_number, start = s_start, last = s_last;
+  double best = 0.0;
+  int bestKey = -1;  // key = rank in scan order (smaller = scanned earlier)
+  int bestRow = -1;
+  for (int i = tid; i < number; i += blockDim.x) {
+    if (c->pivotRule) {
+      int iRow = D.infIndex[i];
+      double value = D.infeas[iRow];
+      if (value > tolerance) {
+        double weight = fmin(D.weights[iRow], 1.0e50);
+        if (iRow == last)
+          value *= 1.0e-10;  // last pivot row is the last resort (:302-307)
+        int iSequence = D.pivotVariable[iRow];
+        if (!(D.status[iSequence] & FLAGGED_BIT)) {
+          double s = D.sol[iSequence];
+          if (s > D.upper[iSequence] + tolerance || s < D.lower[iSequence] - tolerance) {
+            double ratio = value / weight;
+            int rank = i - start;
+            if (rank < 0)
+              rank += number;
+            if (ratio > best || (ratio == best && bestKey >= 0 && rank < bestKey)) {
+              best = ratio;
+              bestKey = rank;
+              bestRow = iRow;
+            }
+          }
+        }
+      }
+    } else {
+      int iSequence = D.pivotVariable[i];
+      double value = D.sol[iSequence];
+      double infeas = fmax(value - D.upper[iSequence], D.lower[iSequence] - value);
+      if (infeas > tolerance && !(D.status[iSequence] & FLAGGED_BIT)) {
+        if (infeas > best || (infeas == best && bestKey >= 0 && i < bestKey)) {
+          best = infeas;
+          bestKey = i;
+          bestRow = i;
+        }
+      }
+    }
+  }
+  // block argmax carries the scan rank as key; recover the row through a second shared slot
+  __shared__ int shRow[16];
+  {
+    int lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+    for (int o = 32; o > 0; o >>= 1) {
+      double ov = __shfl_down(best, o);
+      int ok = __shfl_down(bestKey, o);
+      int orow = __shfl_down(bestRow, o);
+      if (ok >= 0 && (bestKey < 0 || ov > best || (ov == best && ok < bestKey))) {
+        best = ov;
+        bestKey = ok;
+        bestRow = orow;
+      }
+    }
+    if (lane == 0) {
+      shv[wv] = best;
+      shk[wv] = bestKey;
+      shRow[wv] = bestRow;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int i = 1; i < nw; i++) {
+        if (shk[i] >= 0 && (bestKey < 0 || shv[i] > best || (shv[i] == best && shk[i] < bestKey))) {
+          best = shv[i];
+          bestKey = shk[i];
+          bestRow = shRow[i];
+        }
+      }
+    }
+  }
+  if (tid == 0) {
+    int chosen = bestRow;
+    c->pivotRow = chosen;
+    if (chosen < 0) {
+      c->state = EXIT_NO_PIVOT_ROW;
+    } else {
+      int seqOut = D.pivotVariable[chosen];
+      c->sequenceOut = seqOut;
+      double valueOut = D.sol[seqOut], lowerOut = D.lower[seqOut], upperOut = D.upper[seqOut];
+      c->valueOut = valueOut;
+      c->lowerOut = lowerOut;
+      c->upperOut = upperOut;
+      if (valueOut > upperOut) {
+        c->directionOut = -1;
+        c->dualOut = valueOut - upperOut;
+      } else if (valueOut < lowerOut) {
+        c->directionOut = 1;
+        c->dualOut = lowerOut - valueOut;
+      } else if (valueOut - lowerOut < upperOut - valueOut) {
+        c->directionOut = 1;
+        c->dualOut = lowerOut - valueOut;
+      } else {
+        c->directionOut = -1;
+        c->dualOut = valueOut - upperOut;
+      }
+      // acceptablePivot (:1270-1278)
+      double acceptablePivot = 1.0e-1 * c->acceptablePivotBase;
+      if (c->numberIterations > 100)
+        acceptablePivot = c->acceptablePivotBase;
+      if (c->pivots > 10 || (c->pivots && c->saveSumDual != 0.0))
+        acceptablePivot = 1.0e+3 * c->acceptablePivotBase;
+      else if (c->pivots > 5)
+        acceptablePivot = 1.0e+2 * c->acceptablePivotBase;
+      else if (c->pivots)
+        acceptablePivot = c->acceptablePivotBase;
+      c->acceptablePivot = acceptablePivot;
+      D.vecC[chosen] = (double)c->directionOut;  // BTRAN input: directionOut * e_r (:1286)
+      c->sequenceIn = -1;
+      c->numberFlips = 0;
+      c->objectiveChange = 0.0;
+    }
+  }
+}
+
+// =============================================================================================
+// BTRAN  y = B^-T c  for the nucleus representation  B^-1 = [slack part | Minv] :
+//   y_i   = -c[pos(slack i)]                         rows whose slack is basic  (slack column -e_i)
+//   t_sc  = c[pos(col sc)] - sum_{i in S} a_{i,col} y_i
+//   y_R   = Minv^T t
+// Stands in for ClpFactorization::updateColumnTranspose (src/ClpFactorization.cpp:2993) ->
+// CoinAbcDenseFactorization::updateColumnTranspose (src/CoinAbcDenseFactorization.cpp:634).
+// =============================================================================================
+__global__ void k_btran_slack(Dev D, const double *cvec, double *y, int iter)
+{
+  if (iter && D.ctrl->state != RUN)
+    return;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < D.m) {
+    int p = D.posOfSlack[i];
+    y[i] = (p >= 0) ? cvec[p] * -1.0 : 0.0;
+  }
+}
+
+__global__ void k_btran_t(Dev D, const double *cvec, const double *y, double *t, int iter)
+{
+  if (iter && D.ctrl->state != RUN)
+    return;
+  int sc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sc < D.ctrl->k) {
+    int col = D.slotCol[sc];
+    double value = cvec[D.slotPos[sc]];
+    for (int p = D.colStart[col]; p < D.colStart[col + 1]; p++) {
+      int r = D.row[p];
+      if (D.slotOfRow[r] < 0)
+        value -= y[r] * D.elem[p];
+    }
+    t[sc] = value;
+  }
+}
+
+// partial[chunk][sr] = sum_{sc in chunk (64 rows), ascending} Minv[sc][sr] * t[sc]
+__global__ void k_gemvT_partial(Dev D, const double *t, int iter)
+{
+  if (iter && D.ctrl->state != RUN)
+    return;
+  const int k = D.ctrl->k;
+  int sr = blockIdx.x * blockDim.x + threadIdx.x;
+  int chunk = blockIdx.y;
+  int sc0 = chunk * 64;
+  if (sc0 >= k || sr >= k)
+    return;
+  int sc1 = min(sc0 + 64, k);
+  double acc = 0.0;
+  const double *Mp = D.Minv + (size_t)sc0 * D.ld + sr;
+  for (int sc = sc0; sc < sc1; sc++) {
+    acc += *Mp * t[sc];
+    Mp += D.ld;
+  }
+  D.partial[(size_t)chunk * D.ld + sr] = acc;
+}
+
+// y[slotRow[sr]] = sum_chunks partial; mode 1 = iteration BTRAN: flush tiny, fill rho/piNeg/rhoSlot
+__global__ void k_gemvT_final(Dev D, double *y, int mode, int iter)
+{
+  if (iter && D.ctrl->state != RUN)
+    return;
+  const int k = D.ctrl->k;
+  int sr = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sr >= k)
+    return;
+  int nchunk = (k + 63) >> 6;
+  double acc = 0.0;
+  for (int ch = 0; ch < nchunk; ch++)
+    acc += D.partial[(size_t)ch * D.ld + sr];
+  if (mode == 1)
+    D.rhoSlot[sr] = acc;
+  y[D.slotRow[sr]] = acc;
+}
+
+// flush |rho| <= zeroTolerance (the packed BTRAN result drops them) and build piNeg = -rho
+__global__ void k_rho_finish(Dev D)
+{
+  if (D.ctrl->state != RUN)
+    return;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < D.m) {
+    double v = D.rho[i];
+    if (fabs(v) <= D.ctrl->zeroTolerance)
+      v = 0.0;
+    D.rho[i] = v;
+    D.piNeg[i] = -v;
+  }
+}
+
+// =============================================================================================
+// Row pricing by column, fused with the first ratio-test pass.
+//   ClpPackedMatrix::transposeTimesByColumn  src/ClpPackedMatrix.cpp:1007-1090 (row part, pi negate)
+//   ClpPackedMatrix::gutsOfTransposeTimesUnscaled (fused variant) :1799-1993 (column part)
+// key space: [0,m) rows (slacks), [m,m+n) columns; one thread per key, 256 keys per workgroup.
+// v1 kernel: one lane walks one column sequentially (bit-identical summation order).
+// Writes alphaCol[j], candFlag[key], per-block candidate count and per-block min ratio.
+// =============================================================================================
+#define PRICE_BLOCK 256
+__global__ void __launch_bounds__(PRICE_BLOCK) k_price(Dev D, int nbRows)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ double shd[16];
+  __shared__ int shi[17];
+  const double dualT = -c->dualTolerance;
+  const double acceptablePivot = c->acceptablePivot;
+  const double zeroTolerance = c->zeroTolerance;
+  const double tentativeTheta = 1.0e15;  // ClpPackedMatrix.cpp:1857
+  int flag = 0;
+  double ratio = 1.0e31;
+  double bytes = 0.0;
+  if ((int)blockIdx.x < nbRows) {
+    int i = blockIdx.x * PRICE_BLOCK + threadIdx.x;
+    if (i < D.m) {
+      double value = D.rho[i];
+      if (value != 0.0) {
+        int iStatus = (D.status[D.n + i] & 3) - 1;
+        if (iStatus > 0) {
+          double mult = (iStatus == 1) ? -1.0 : 1.0;
+          double alpha = value * mult;
+          if (alpha > 0.0) {
+            double oldValue = D.dj[D.n + i] * mult;
+            double v2 = oldValue - tentativeTheta * alpha;
+            if (v2 < dualT) {
+              flag = 1;
+              if (alpha >= acceptablePivot)
+                ratio = (oldValue - dualT) / alpha;
+            }
+          }
+        }
+      }
+      D.candFlag[i] = (unsigned char)flag;
+    }
+  } else {
+    int j = D.firstColumn + ((int)blockIdx.x - nbRows) * PRICE_BLOCK + threadIdx.x;
+    if (j < D.lastColumn) {
+      int wanted = (D.status[j] & 3) - 1;
+      double value = 0.0;
+      if (wanted) {
+        const int start = D.colStart[j], end = D.colStart[j + 1];
+        for (int p = start; p < end; p++)
+          value += D.piNeg[D.row[p]] * D.elem[p];
+        bytes = 12.0 * (end - start) + 4.0;
+        if (fabs(value) > zeroTolerance) {
+          bytes += 20.0;
+          if (wanted > 0) {
+            double mult = (wanted == 1) ? -1.0 : 1.0;
+            double alpha = value * mult;
+            if (alpha > 0.0) {
+              double oldValue = D.dj[j] * mult;
+              double v2 = oldValue - tentativeTheta * alpha;
+              if (v2 < dualT) {
+                flag = 1;
+                if (alpha >= acceptablePivot)
+                  ratio = (oldValue - dualT) / alpha;
+              }
+            }
+          }
+        } else {
+          value = 0.0;
+        }
+      }
+      D.alphaCol[j] = value;
+      D.candFlag[D.m + j] = (unsigned char)flag;
+    }
+  }
+  int total;
+  blockRank(flag, total, shi);
+  double bmin = blockMin(ratio, shd);
+  double bsum = blockSum(bytes, shd);
+  if (threadIdx.x == 0) {
+    D.blockCount[blockIdx.x] = total;
+    D.blockMin[blockIdx.x] = bmin;
+    D.blockSum[blockIdx.x] = bsum;
+  }
+}
+
+// exclusive scan over per-block counts (<= 1M/256 blocks), min over per-block ratios
+// what: 0 candidates (-> numberCandidates, upperTheta), 1 flips, 2 infeasibility-list appends
+__global__ void __launch_bounds__(1024) k_scan_blocks(Dev D, int nb, int what, int iter)
+{
+  Ctrl *c = D.ctrl;
+  if (iter && c->state != RUN)
+    return;
+  __shared__ int shi[17];
+  __shared__ double shd[16];
+  __shared__ int s_base;
+  if (threadIdx.x == 0)
+    s_base = 0;
+  __syncthreads();
+  double vmin = 1.0e31;
+  double bytes = 0.0;
+  for (int b0 = 0; b0 < nb; b0 += blockDim.x) {
+    int b = b0 + threadIdx.x;
+    int cnt = (b < nb) ? D.blockCount[b] : 0;
+    if (what == 0 && b < nb) {
+      vmin = fmin(vmin, D.blockMin[b]);
+      bytes += D.blockSum[b];
+    }
+    // inclusive scan inside the block via wave ballots is for flags only; counts need a real scan
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int v = cnt;
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(v, o);
+      if (lane >= o)
+        v += t;
+    }
+    __syncthreads();
+    if (lane == 63)
+      shi[wv] = v;
+    __syncthreads();
+    int base = s_base;
+    for (int i = 0; i < wv; i++)
+      base += shi[i];
+    if (b < nb)
+      D.blockOffset[b] = base + v - cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tot = 0;
+      for (int i = 0; i < nw; i++)
+        tot += shi[i];
+      s_base += tot;
+    }
+    __syncthreads();
+  }
+  if (what == 0) {
+    vmin = blockMin(vmin, shd);
+    bytes = blockSum(bytes, shd);
+  }
+  if (threadIdx.x == 0) {
+    if (what == 0) {
+      c->numberCandidates = s_base;
+      c->upperTheta = vmin;
+      // algorithmic bytes of this pricing launch: per scanned column 12*len+4 (+20 per
+      // emitted nonzero), plus status 1*n, pi 8*m, one extra colStart
+      c->statPriceBytes += bytes + (double)(D.lastColumn - D.firstColumn) + 8.0 * D.m + 4.0;
+      c->statPriceLaunches += 1.0;
+    } else if (what == 1) {
+      c->numberFlips = s_base;
+    } else {
+      c->numberAppend = s_base;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(PRICE_BLOCK) k_cand_scatter(Dev D, int nbRows)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ int shi[17];
+  int flag = 0, seq = -1;
+  double alpha = 0.0;
+  if ((int)blockIdx.x < nbRows) {
+    int i = blockIdx.x * PRICE_BLOCK + threadIdx.x;
+    if (i < D.m && D.candFlag[i]) {
+      flag = 1;
+      seq = D.n + i;
+      alpha = D.rho[i];
+    }
+  } else {
+    int j = D.firstColumn + ((int)blockIdx.x - nbRows) * PRICE_BLOCK + threadIdx.x;
+    if (j < D.lastColumn && D.candFlag[D.m + j]) {
+      flag = 1;
+      seq = j;
+      alpha = D.alphaCol[j];
+    }
+  }
+  int total;
+  int rank = blockRank(flag, total, shi);
+  if (flag) {
+    int o = D.blockOffset[blockIdx.x] + rank;
+    D.candSeq[o] = seq;
+    D.candAlpha[o] = alpha;
+  }
+}
+
+// =============================================================================================
+// Dual ratio test -- ClpSimplexDual::dualColumn  src/ClpSimplexDual.cpp:4192-4927 (bound-flipping
+// long-step test, pass 0 already fused into pricing: the spareIntArray_[0]==-2 path :4273-4281).
+// One workgroup walks the candidate list once per pass.  The reference's two ping-pong lists are
+// represented by per-candidate state: live[i] (still in the "remaining" list) and tag[i] (id of the
+// pass that moved it to a "swapped" list); sid[a] is the id of the swapped set held by list a.
+// List order (needed only for "first largest |alpha| wins", :4533) is candidate index order.
+// =============================================================================================
+struct DcReduce {
+  double thru, incr, bestPivot, upperTheta, sumBad;
+  int bestIdx;
+};
+
+__global__ void __launch_bounds__(1024) k_dual_column(Dev D)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ double shA[16], shB[16], shC[16], shD[16], shE[16];
+  __shared__ int shK[16];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int nc = c->numberCandidates;
+  const double acceptablePivot = c->acceptablePivot;
+  const double dualTolerance = c->dualTolerance;
+  const double newTolerance = dualTolerance;
+  const double absDualOut = fabs(c->dualOut);
+  if (!nc) {
+    if (tid == 0) {
+      c->sequenceIn = -1;
+      c->alpha = 0.0;
+      c->bestPossible = 0.0;
+      c->state = EXIT_NO_INCOMING;
+    }
+    return;
+  }
+  for (int i = tid; i < nc; i += nthr) {
+    D.candLive[i] = 1;
+    D.candTag[i] = -1;
+  }
+  __syncthreads();
+  // all scalars are kept redundantly in every thread (all inputs come from block reductions)
+  double totalThru = 0.0, bestEverPivot = acceptablePivot, increaseInObjective = 0.0;
+  int lastIdx = -1;
+  double upperTheta = c->upperTheta;
+  int modifyCosts = 0, badSumPivots = 0;
+  int iFlip = 0;
+  int sid[2] = { -1, -1 };
+  int passId = 0;
+  int seqIdx = -1;  // candidate index of sequenceIn_
+  double theta = 1.0e50;
+  double tentativeTheta = fmax(10.0 * upperTheta, 1.0e-7);
+  const double lastPivot = 0.0;  // never updated in the reference either (:4207)
+  while (tentativeTheta < 1.0e22) {
+    // ---- coarse pass (:4355-4417)
+    double thruThis = 0.0, increaseInThis = 0.0, bestPivot = acceptablePivot, ut = 1.0e50;
+    int bestIdx = -1;
+    for (int i = tid; i < nc; i += nthr) {
+      if (!D.candLive[i])
+        continue;
+      int iSequence = D.candSeq[i];
+      double alpha = D.candAlpha[i];
+      double oldValue = D.dj[iSequence];
+      double value = oldValue - tentativeTheta * alpha;
+      if (alpha < 0.0) {
+        if (value > newTolerance) {
+          double range = D.upper[iSequence] - D.lower[iSequence];
+          thruThis -= range * alpha;
+          increaseInThis -= (oldValue + dualTolerance) * range;
+          D.candLive[i] = 0;
+          D.candTag[i] = passId;
+          if (fabs(alpha) > bestPivot) {
+            bestPivot = fabs(alpha);
+            bestIdx = i;
+          }
+        } else if (-alpha >= acceptablePivot) {
+          ut = fmin(ut, (oldValue - newTolerance) / alpha);
+        }
+      } else {
+        if (value < -newTolerance) {
+          double range = D.upper[iSequence] - D.lower[iSequence];
+          thruThis += range * alpha;
+          increaseInThis += (oldValue - dualTolerance) * range;
+          D.candLive[i] = 0;
+          D.candTag[i] = passId;
+          if (fabs(alpha) > bestPivot) {
+            bestPivot = fabs(alpha);
+            bestIdx = i;
+          }
+        } else if (alpha >= acceptablePivot) {
+          ut = fmin(ut, (oldValue + newTolerance) / alpha);
+        }
+      }
+    }
+    thruThis = blockSum(thruThis, shA);
+    increaseInThis = blockSum(increaseInThis, shB);
+    upperTheta = blockMin(ut, shC);
+    blockArgMax(bestPivot, bestIdx, shD, shK);
+    if (bestIdx < 0)
+      bestPivot = acceptablePivot;
+    sid[1 - iFlip] = passId;
+    double check = fabs(totalThru + thruThis);
+    check += 1.0e-8 + 1.0e-10 * check;
+    if (check >= absDualOut || increaseInObjective + increaseInThis < 0.0) {
+      // ---- pivot in this batch: the list becomes the swapped set of this pass (:4427-4434)
+      for (int i = tid; i < nc; i += nthr)
+        D.candLive[i] = (D.candTag[i] == passId) ? 1 : 0;
+      __syncthreads();
+      int iTry;
+      const int MAXTRY = 100;
+      for (iTry = 0; iTry < MAXTRY; iTry++) {
+        passId++;
+        ut = 1.0e50;
+        for (int i = tid; i < nc; i += nthr) {
+          if (!D.candLive[i])
+            continue;
+          int iSequence = D.candSeq[i];
+          double alpha = D.candAlpha[i];
+          double oldValue = D.dj[iSequence];
+          if (alpha < 0.0) {
+            if (-alpha >= acceptablePivot)
+              ut = fmin(ut, (oldValue - newTolerance) / alpha);
+          } else {
+            if (alpha >= acceptablePivot)
+              ut = fmin(ut, (oldValue + newTolerance) / alpha);
+          }
+        }
+        upperTheta = blockMin(ut, shC);
+        bestPivot = acceptablePivot;
+        bestIdx = -1;
+        double sumBadPivots = 0.0;
+        badSumPivots = 0;
+        upperTheta *= 1.0000000001;
+        thruThis = 0.0;
+        increaseInThis = 0.0;
+        for (int i = tid; i < nc; i += nthr) {
+          if (!D.candLive[i])
+            continue;
+          int iSequence = D.candSeq[i];
+          double alpha = D.candAlpha[i];
+          double djv = D.dj[iSequence];
+          double value = djv - upperTheta * alpha;
+          double badDj = 0.0;
+          int addToSwapped = 0;
+          if (alpha < 0.0) {
+            if (value >= 0.0) {
+              addToSwapped = 1;
+              badDj = -djv - dualTolerance;
+            }
+          } else {
+            if (value <= 0.0) {
+              addToSwapped = 1;
+              badDj = djv - dualTolerance;
+            }
+          }
+          if (addToSwapped) {
+            D.candLive[i] = 0;
+            D.candTag[i] = passId;
+            double absAlpha = fabs(alpha);
+            if (absAlpha > bestPivot) {
+              bestPivot = absAlpha;
+              bestIdx = i;
+            }
+            if (absAlpha < acceptablePivot && upperTheta < 1.0e20) {
+              if (alpha < 0.0) {
+                if (value > dualTolerance) {
+                  double gap = D.upper[iSequence] - D.lower[iSequence];
+                  sumBadPivots += (gap < 1.0e20) ? value * gap : 1.0e20;
+                }
+              } else {
+                if (value < -dualTolerance) {
+                  double gap = D.upper[iSequence] - D.lower[iSequence];
+                  sumBadPivots += (gap < 1.0e20) ? -(value * gap) : 1.0e20;
+                }
+              }
+            }
+            double range = D.upper[iSequence] - D.lower[iSequence];
+            thruThis += range * fabs(alpha);
+            increaseInThis += badDj * range;
+          }
+        }
+        thruThis = blockSum(thruThis, shA);
+        increaseInThis = blockSum(increaseInThis, shB);
+        sumBadPivots = blockSum(sumBadPivots, shE);
+        blockArgMax(bestPivot, bestIdx, shD, shK);
+        if (bestIdx < 0)
+          bestPivot = acceptablePivot;
+        seqIdx = bestIdx;
+        if (bestIdx >= 0)
+          theta = D.dj[D.candSeq[bestIdx]] / D.candAlpha[bestIdx];
+        if (sumBadPivots > 1.0e4) {
+          if (c->pivots > 3) {
+            badSumPivots = 1;
+            break;
+          }
+        }
+        sid[1 - iFlip] = passId;
+        double increase = (absDualOut - totalThru) * theta;
+        increase += increaseInObjective;
+        if (theta < 0.0)
+          thruThis += absDualOut;  // force using this one
+        if (increaseInObjective < 0.0 && increase < 0.0 && lastIdx >= 0) {
+          bestPivot = 0.0;
+        } else {
+          totalThru += thruThis;
+          increaseInObjective += increaseInThis;
+        }
+        if (bestPivot < 0.1 * bestEverPivot && bestEverPivot > 1.0e-6 && (bestPivot < 1.0e-3 || totalThru * 2.0 > absDualOut)) {
+          seqIdx = lastIdx;
+          iFlip = 1 - iFlip;
+          break;
+        } else if (seqIdx == -1 && upperTheta > c->largeValue) {
+          if (lastPivot > acceptablePivot) {
+            seqIdx = lastIdx;
+            iFlip = 1 - iFlip;
+          }
+          break;
+        } else if (totalThru >= absDualOut) {
+          modifyCosts = 1;
+          break;
+        } else {
+          lastIdx = seqIdx;
+          if (bestPivot > bestEverPivot)
+            bestEverPivot = bestPivot;
+          iFlip = 1 - iFlip;
+          modifyCosts = 1;
+        }
+      }
+      if (iTry == MAXTRY)
+        iFlip = 1 - iFlip;
+      break;
+    } else {
+      // ---- skip this lot (:4640-4657)
+      if (bestPivot > 1.0e-3 || bestPivot > bestEverPivot) {
+        bestEverPivot = bestPivot;
+        lastIdx = bestIdx;
+      } else {
+        sid[1 - iFlip] = sid[iFlip];  // keep old swapped
+      }
+      increaseInObjective += increaseInThis;
+      iFlip = 1 - iFlip;
+      tentativeTheta = 2.0 * upperTheta;
+      totalThru += thruThis;
+      passId++;
+    }
+  }
+  if (seqIdx < 0 && lastIdx >= 0) {
+    seqIdx = lastIdx;
+    iFlip = 1 - iFlip;
+  }
+  double minimumTheta = (c->upperOut > c->lowerOut) ? 1.0e-18 : 0.0;
+  int sequenceIn = -1;
+  double alphaIn = 0.0;
+  if (seqIdx >= 0) {
+    iFlip = 1 - iFlip;
+    alphaIn = D.candAlpha[seqIdx];
+    sequenceIn = D.candSeq[seqIdx];
+    double oldValue = D.dj[sequenceIn];
+    theta = fmax(oldValue / alphaIn, 0.0);
+    if (theta < minimumTheta && fabs(alphaIn) < 1.0e5)
+      theta = minimumTheta;
+    if (modifyCosts && !badSumPivots) {
+      // cost shifting so everything that went through stays dual feasible (:4705-4772)
+      const int sidFinal = sid[iFlip];
+      int changed = 0;
+      __syncthreads();
+      for (int i = tid; i < nc; i += nthr) {
+        if (D.candTag[i] != sidFinal)
+          continue;
+        int iSequence = D.candSeq[i];
+        double alpha = D.candAlpha[i];
+        double djv = D.dj[iSequence];
+        double value = djv - theta * alpha;
+        if (alpha < 0.0) {
+          if (value > dualTolerance) {
+            double modification = alpha * theta - djv + newTolerance;
+            D.dj[iSequence] = djv + modification;
+            D.cost[iSequence] += modification;
+            if (modification != 0.0)
+              changed++;
+          }
+        } else {
+          if (-value > dualTolerance) {
+            double modification = alpha * theta - djv - newTolerance;
+            D.dj[iSequence] = djv + modification;
+            D.cost[iSequence] += modification;
+            if (modification != 0.0)
+              changed++;
+          }
+        }
+      }
+      double ch = blockSum((double)changed, shA);
+      if (tid == 0)
+        c->numberChanged += (int)ch;
+      __syncthreads();
+    }
+  }
+  if (badSumPivots && c->pivots) {
+    sequenceIn = -1;
+    if (tid == 0)
+      c->acceptablePivotBase = -c->acceptablePivotBase;
+  }
+  if (tid == 0) {
+    c->badSumPivots = badSumPivots;
+    c->modifyCosts = modifyCosts;
+    if (sequenceIn >= 0) {
+      c->sequenceIn = sequenceIn;
+      c->alpha = alphaIn;
+      c->theta = theta;
+      double lowerIn = D.lower[sequenceIn], upperIn = D.upper[sequenceIn], valueIn = D.sol[sequenceIn];
+      double dualIn = D.dj[sequenceIn];
+      // modify cost so the incoming dj is exactly theta*alpha (:4796-4834)
+      double modification = theta * alphaIn - dualIn;
+      double moveObjective = fabs(modification * valueIn);
+      double smallMove = fmax(fabs(c->objectiveValue), 1.0e-3);
+      if (moveObjective > smallMove)
+        modification *= smallMove / moveObjective;
+      if (badSumPivots)
+        modification = 0.0;
+      dualIn += modification;
+      D.dj[sequenceIn] = dualIn;
+      D.cost[sequenceIn] += modification;
+      if (modification != 0.0)
+        c->numberChanged++;
+      c->dualIn = dualIn;
+      c->valueIn = valueIn;
+      if (alphaIn < 0.0) {
+        c->directionIn = -1;
+        upperIn = valueIn;
+      } else {
+        c->directionIn = 1;
+        lowerIn = valueIn;
+      }
+      c->lowerIn = lowerIn;
+      c->upperIn = upperIn;
+      c->bestPossible = fabs(alphaIn);  // the |alpha|<1e-6 rescan (:4851) is done by the host on exit
+      c->btranAlpha = -alphaIn * c->directionOut;
+    } else {
+      c->sequenceIn = -1;
+      c->alpha = 0.0;
+      c->bestPossible = 0.0;
+      c->state = EXIT_NO_INCOMING;
+    }
+  }
+}
+
+// =============================================================================================
+// FTRAN  x = B^-1 v :  x_K = Minv v_R ;  x[pos(slack i)] = sum_{j in K} a_ij x_j - v_i
+// Stands in for ClpFactorization::updateColumn / updateTwoColumnsFT (src/ClpFactorization.cpp:2803,
+// :2889) -> CoinAbcDenseFactorization::updateColumn (src/CoinAbcDenseFactorization.cpp:571).
+// Two right-hand sides share one sweep over Minv (the entering column and the DSE vector).
+// =============================================================================================
+__global__ void k_unpack_in(Dev D)
+{
+  // ClpSimplex::unpackPacked (src/ClpSimplex.cpp:3439-3495): a_q, or -e_i for a slack
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  int q = c->sequenceIn;
+  if (q >= D.n) {
+    if (threadIdx.x == 0)
+      D.vecV1[q - D.n] = -1.0;
+  } else {
+    for (int p = D.colStart[q] + threadIdx.x; p < D.colStart[q + 1]; p += blockDim.x)
+      D.vecV1[D.row[p]] = D.elem[p];
+  }
+}
+
+__global__ void k_ftran_gather(Dev D, const double *v1, const double *v2, double *g1, double *g2, int iter)
+{
+  if (iter && D.ctrl->state != RUN)
+    return;
+  if (iter == 2 && D.ctrl->numberFlips == 0)
+    return;
+  int sr = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sr < D.ctrl->k) {
+    int r = D.slotRow[sr];
+    g1[sr] = v1[r];
+    if (v2)
+      g2[sr] = v2[r];
+  }
+}
+
+// one wave per nucleus row: x[sc] = sum_sr Minv[sc][sr] * g[sr]; lanes stride the row (coalesced)
+__global__ void __launch_bounds__(256) k_gemv2(Dev D, const double *g1, const double *g2, double *x1, double *x2, int iter)
+{
+  if (iter && D.ctrl->state != RUN)
+    return;
+  if (iter == 2 && D.ctrl->numberFlips == 0)
+    return;
+  const int k = D.ctrl->k;
+  const int lane = threadIdx.x & 63;
+  const int wavesPerBlock = blockDim.x >> 6;
+  for (int sc = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6); sc < k; sc += gridDim.x * wavesPerBlock) {
+    const double *Mrow = D.Minv + (size_t)sc * D.ld;
+    double a1 = 0.0, a2 = 0.0;
+    if (g2) {
+      for (int sr = lane; sr < k; sr += 64) {
+        double mv = Mrow[sr];
+        a1 += mv * g1[sr];
+        a2 += mv * g2[sr];
+      }
+      a2 = waveSum(a2);
+    } else {
+      for (int sr = lane; sr < k; sr += 64)
+        a1 += Mrow[sr] * g1[sr];
+    }
+    a1 = waveSum(a1);
+    if (lane == 0) {
+      x1[sc] = a1;
+      if (g2)
+        x2[sc] = a2;
+    }
+  }
+}
+
+// scatter nucleus results to basis positions and do the slack rows through the partitioned row copy
+__global__ void k_ftran_scatter(Dev D, const double *v1, const double *v2, const double *xk1, const double *xk2, double *x1,
+                                double *x2, int iter)
+{
+  if (iter && D.ctrl->state != RUN)
+    return;
+  if (iter == 2 && D.ctrl->numberFlips == 0)
+    return;
+  const int k = D.ctrl->k;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < D.m) {
+    int p = D.posOfSlack[t];
+    if (p >= 0) {
+      double a1 = 0.0, a2 = 0.0;
+      int s = D.rowStart[t], e = s + D.basicCount[t];
+      for (int q = s; q < e; q++) {
+        int sc = D.slotOfCol[D.ccol[q]];
+        double a = D.relem[q];
+        a1 += a * xk1[sc];
+        if (v2)
+          a2 += a * xk2[sc];
+      }
+      x1[p] = a1 - v1[t];
+      if (v2)
+        x2[p] = a2 - v2[t];
+    }
+  } else if (t < D.m + k) {
+    int sc = t - D.m;
+    int p = D.slotPos[sc];
+    x1[p] = xk1[sc];
+    if (v2)
+      x2[p] = xk2[sc];
+  }
+}
+
+// =============================================================================================
+// DSE: norm, alpha check and weight update -- ClpDualRowSteepest::updateWeights
+// (src/ClpDualRowSteepest.cpp:375-540) and the accuracy test of whileIterating (:1447-1501).
+// =============================================================================================
+__global__ void __launch_bounds__(1024) k_norm_alpha(Dev D)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ double sh[16];
+  double acc = 0.0;
+  if (c->pivotRule) {
+    for (int i = threadIdx.x; i < D.m; i += blockDim.x) {
+      double v = D.rho[i];
+      acc += v * v;
+    }
+    acc = blockSum(acc, sh);
+  }
+  if (threadIdx.x == 0) {
+    double alphaOld = c->alpha;  // from the ratio test (btran side)
+    double norm = acc / (alphaOld * alphaOld);
+    c->norm = norm;
+    double alpha = D.w[c->pivotRow];
+    double btranAlpha = c->btranAlpha;
+    double checkValue = 1.0e-7;
+    if (c->largestPrimalError > 10.0)
+      checkValue = fmin(1.0e-4, 1.0e-8 * c->largestPrimalError);
+    // multiplier uses the old alpha (model_->alpha() inside updateWeights)
+    c->scratchSum = 2.0 / alphaOld;
+    if (fabs(btranAlpha) < 1.0e-12 || fabs(alpha) < 1.0e-12 || fabs(btranAlpha - alpha) > checkValue * (1.0 + fabs(alpha))) {
+      int bad = 1;
+      if (!c->pivots) {
+        double test;
+        if (fabs(btranAlpha) < 1.0e-8 || fabs(alpha) < 1.0e-8)
+          test = 1.0e-1 * fabs(alpha);
+        else
+          test = 1.0e-4 * (1.0 + fabs(alpha));
+        if (!(fabs(btranAlpha) < 1.0e-12 || fabs(alpha) < 1.0e-12 || fabs(btranAlpha - alpha) > test))
+          bad = 0;  // accepted under the relaxed criterion (:1466-1471)
+      }
+      if (bad) {
+        c->alpha = alpha;
+        c->state = EXIT_ALPHA_CHECK;
+        return;
+      }
+    }
+    c->alpha = alpha;
+  }
+}
+
+__global__ void k_weights(Dev D)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN || !c->pivotRule)
+    return;
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= D.m)
+    return;
+  double theta = D.w[p];
+  if (theta != 0.0) {
+    double devex = D.weights[p];
+    D.altWeights[p] = devex;
+    double norm = c->norm, multiplier = c->scratchSum;
+    if (p == c->pivotRow) {
+      devex = (norm < DEVEX_TRY_NORM) ? DEVEX_TRY_NORM : norm;
+    } else {
+      double value = D.tau[p];
+      devex += theta * (theta * norm + value * multiplier);
+      if (devex < DEVEX_TRY_NORM)
+        devex = DEVEX_TRY_NORM;
+    }
+    D.weights[p] = devex;
+  }
+}
+
+// ClpDualRowSteepest::unrollWeights (:1022): w is still intact when the host asks for this
+__global__ void k_unroll_weights(Dev D)
+{
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < D.m && D.w[p] != 0.0)
+    D.weights[p] = D.altWeights[p];
+}
+
+// =============================================================================================
+// Dual update + flip detection -- ClpSimplexDual::updateDualsInDual fast path
+// (src/ClpSimplexDual.cpp:2454-2592).  Key space as in pricing.  candFlag doubles as flip flag.
+// =============================================================================================
+__global__ void __launch_bounds__(PRICE_BLOCK) k_dj_update(Dev D, int nbRows)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ int shi[17];
+  const double theta = c->theta;
+  const double tolerance = c->dualTolerance + fmin(1.0e-2, c->largestDualError);
+  const int seqIn = c->sequenceIn;
+  int flag = 0;
+  if ((int)blockIdx.x < nbRows) {
+    int i = blockIdx.x * PRICE_BLOCK + threadIdx.x;
+    if (i < D.m) {
+      double alphaI = D.rho[i];
+      int seq = D.n + i;
+      if (alphaI != 0.0 && seq != seqIn) {
+        int iStatus = (D.status[seq] & 3) - 1;
+        if (iStatus) {
+          double value = D.dj[seq] - theta * alphaI;
+          D.dj[seq] = value;
+          double mult = (iStatus == 1) ? -1.0 : ((iStatus == 2) ? 1.0 : 0.0);
+          value *= mult;
+          if (value < -tolerance)
+            flag = 1;
+        }
+      }
+      D.candFlag[i] = (unsigned char)flag;
+    }
+  } else {
+    int j = D.firstColumn + ((int)blockIdx.x - nbRows) * PRICE_BLOCK + threadIdx.x;
+    if (j < D.lastColumn) {
+      double alphaI = D.alphaCol[j];
+      if (alphaI != 0.0 && j != seqIn) {
+        int iStatus = (D.status[j] & 3) - 1;
+        if (iStatus) {
+          double value = D.dj[j] - theta * alphaI;
+          D.dj[j] = value;
+          double mult = (iStatus == 1) ? -1.0 : ((iStatus == 2) ? 1.0 : -1.0);
+          value *= mult;
+          if (value < -tolerance && iStatus > 0)
+            flag = 1;
+        }
+      }
+      D.candFlag[D.m + j] = (unsigned char)flag;
+    }
+  }
+  int total;
+  blockRank(flag, total, shi);
+  if (threadIdx.x == 0)
+    D.blockCount[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(PRICE_BLOCK) k_flip_scatter(Dev D, int nbRows)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN || c->numberFlips == 0)
+    return;
+  __shared__ int shi[17];
+  int flag = 0, seq = -1;
+  if ((int)blockIdx.x < nbRows) {
+    int i = blockIdx.x * PRICE_BLOCK + threadIdx.x;
+    if (i < D.m && D.candFlag[i]) {
+      flag = 1;
+      seq = D.n + i;
+    }
+  } else {
+    int j = D.firstColumn + ((int)blockIdx.x - nbRows) * PRICE_BLOCK + threadIdx.x;
+    if (j < D.lastColumn && D.candFlag[D.m + j]) {
+      flag = 1;
+      seq = j;
+    }
+  }
+  int total;
+  int rank = blockRank(flag, total, shi);
+  if (flag)
+    D.flipSeq[D.blockOffset[blockIdx.x] + rank] = seq;
+}
+
+// movement of each flip into the dense rhs (matrix_->add, src/ClpPackedMatrix.cpp:4874), in list
+// order, entries of one column in parallel (distinct rows) => deterministic
+__global__ void __launch_bounds__(256) k_flip_apply(Dev D)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN || c->numberFlips == 0)
+    return;
+  double changeObj = 0.0;
+  for (int f = 0; f < c->numberFlips; f++) {
+    int seq = D.flipSeq[f];
+    int iStatus = (D.status[seq] & 3) - 1;
+    if (seq >= D.n) {
+      double mult = (iStatus == 1) ? -1.0 : 1.0;
+      double movement = mult * (D.lower[seq] - D.upper[seq]);
+      if (threadIdx.x == 0) {
+        changeObj -= movement * D.cost[seq];
+        D.flipRhs[seq - D.n] += movement;
+      }
+    } else {
+      double mult = (iStatus == 1) ? -1.0 : 1.0;
+      double movement = mult * (D.upper[seq] - D.lower[seq]);
+      if (threadIdx.x == 0)
+        changeObj += movement * D.cost[seq];
+      for (int p = D.colStart[seq] + threadIdx.x; p < D.colStart[seq + 1]; p += blockDim.x)
+        D.flipRhs[D.row[p]] += movement * D.elem[p];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    c->objectiveChange += changeObj;
+}
+
+// ClpSimplexDual::flipBounds (:6345-6401)
+__global__ void k_flip_bounds(Dev D)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < c->numberFlips; f += gridDim.x * blockDim.x) {
+    int seq = D.flipSeq[f];
+    int st = D.status[seq] & 7;
+    if (st == ST_UPPER) {
+      D.status[seq] = (unsigned char)((D.status[seq] & ~7) | ST_LOWER);
+      D.sol[seq] = D.lower[seq];
+    } else if (st == ST_LOWER) {
+      D.status[seq] = (unsigned char)((D.status[seq] & ~7) | ST_UPPER);
+      D.sol[seq] = D.upper[seq];
+    }
+  }
+}
+
+// =============================================================================================
+// Primal update -- ClpDualRowSteepest::updatePrimalSolution (src/ClpDualRowSteepest.cpp:630-763)
+// x_B -= ratio * vec ; refresh squared infeasibilities ; new entries are appended to the list in
+// ascending position order (count / scan / scatter keeps CoinIndexedVector's insertion order).
+// which: 0 -> vec = w, ratio = ctrl.movement ; 1 -> vec = x3 (flip FTRAN), ratio = 1
+// =============================================================================================
+__global__ void __launch_bounds__(256) k_primal_update(Dev D, int which)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  if (which == 1 && c->numberFlips == 0)
+    return;
+  __shared__ double shd[16];
+  __shared__ int shi[17];
+  const double *vec = which ? D.x3 : D.w;
+  const double ratio = which ? 1.0 : c->movement;
+  const double tolerance = c->primalTolerance;
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  double changeObj = 0.0;
+  int append = 0;
+  if (p < D.m) {
+    double v = vec[p];
+    if (v != 0.0) {
+      int iPivot = D.pivotVariable[p];
+      double value = D.sol[iPivot];
+      double change = ratio * v;
+      value -= change;
+      changeObj -= change * D.cost[iPivot];
+      D.sol[iPivot] = value;
+      if (c->pivotRule) {
+        double lower = D.lower[iPivot], upper = D.upper[iPivot];
+        double old = D.infeas[p];
+        if (value < lower - tolerance) {
+          value -= lower;
+          value *= value;
+          if (old == 0.0)
+            append = 1;
+          D.infeas[p] = value;
+        } else if (value > upper + tolerance) {
+          value -= upper;
+          value *= value;
+          if (old == 0.0)
+            append = 1;
+          D.infeas[p] = value;
+        } else if (old != 0.0) {
+          D.infeas[p] = REALLY_TINY;
+        }
+      }
+    }
+    D.appendFlag[p] = append;
+  }
+  int total;
+  blockRank(append, total, shi);
+  double s = blockSum(changeObj, shd);
+  if (threadIdx.x == 0) {
+    D.blockCount[blockIdx.x] = total;
+    D.blockSum[blockIdx.x] = s;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_append_scatter(Dev D, int which, int iter)
+{
+  const Ctrl *c = D.ctrl;
+  if ((iter && c->state != RUN) || c->numberAppend == 0)
+    return;
+  if (iter && which == 1 && c->numberFlips == 0)
+    return;
+  __shared__ int shi[17];
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  int flag = (p < D.m) ? D.appendFlag[p] : 0;
+  int total;
+  int rank = blockRank(flag, total, shi);
+  if (flag)
+    D.infIndex[c->numberInfeasible + D.blockOffset[blockIdx.x] + rank] = p;
+}
+
+// scalar tail of updatePrimalSolution + the scalar block of whileIterating between the two
+// primal updates (:1531-1588): objective change, dualOut recompute, movement, backwards check,
+// the pivot-size gate of replaceColumn (CoinAbcDenseFactorization::checkReplacePart2 :470).
+__global__ void k_after_primal(Dev D, int nb, int which)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  if (which == 1 && c->numberFlips == 0) {
+    // no flips: just the scalar block
+  } else {
+    double s = 0.0;
+    for (int b = 0; b < nb; b++)
+      s += D.blockSum[b];
+    c->objectiveChange += s;
+    c->numberInfeasible += c->numberAppend;
+    c->numberAppend = 0;
+    if (c->pivotRule) {
+      int iRow = c->pivotRow;
+      if (D.infeas[iRow] != 0.0)
+        D.infeas[iRow] = REALLY_TINY;
+    }
+  }
+  if (which == 1) {
+    double oldDualOut = c->dualOut;
+    if (c->numberFlips) {
+      c->valueOut = D.sol[c->sequenceOut];
+      if (c->directionOut < 0)
+        c->dualOut = c->valueOut - c->upperOut;
+      else
+        c->dualOut = c->lowerOut - c->valueOut;
+    }
+    double alpha = c->alpha;
+    c->movement = -c->dualOut * c->directionOut / alpha;
+    double movementOld = oldDualOut * c->directionOut / alpha;
+    if (c->objectiveChange + fabs(movementOld * c->dualIn) < -fmax(1.0e-5, 1.0e-12 * fabs(c->objectiveValue))) {
+      if (c->pivots) {
+        c->state = EXIT_BACKWARDS;
+        return;
+      }
+    }
+    if (fabs(alpha) < c->zeroTolerance || fabs(c->dualOut) > 1.0e50) {
+      c->state = EXIT_BAD_UPDATE;
+      return;
+    }
+    if (c->theta < 0.0)
+      c->theta = 0.0;
+    // classify the basis change for the nucleus update
+    int seqIn = c->sequenceIn, seqOut = c->sequenceOut;
+    int inStruct = seqIn < D.n, outStruct = seqOut < D.n;
+    c->updateCase = outStruct ? (inStruct ? 0 : 2) : (inStruct ? 1 : 3);
+    c->slotColOut = outStruct ? D.slotOfCol[seqOut] : -1;
+    c->rowOfSlackOut = outStruct ? -1 : (seqOut - D.n);
+    c->slotRowIn = inStruct ? -1 : D.slotOfRow[seqIn - D.n];
+  }
+}
+
+// =============================================================================================
+// Basis update on the nucleus inverse (the Forrest-Tomlin stand-in,
+// ClpFactorization::replaceColumn src/ClpFactorization.cpp:2584).  With w = B^-1 a_q (by col-slot),
+// rho = B^-T(dir e_p) (by row-slot, unpruned) and g = dir*rho/alpha, all four pivot types are
+//     Minv[i][j] -= w_i * g_j          (one rank-1 sweep, k^2 reads + writes)
+// followed by a row/column fix-up:   struct->struct: row a := g ;  slack out/struct in: append row g,
+// column w/alpha, corner -1/alpha ;  struct out/slack in: delete row a, column b ;  slack->slack:
+// column b := w/alpha.
+// =============================================================================================
+__global__ void k_update_vectors(Dev D)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < c->k) {
+    D.slotE[s] = D.w[D.slotPos[s]];                             // w by col-slot
+    D.slotF[s] = ((double)c->directionOut) * D.rhoSlot[s] / c->alpha;  // g by row-slot
+  }
+}
+
+__global__ void __launch_bounds__(256) k_rank1(Dev D)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  const int k = c->k;
+  // 2D tiling: blockIdx.y strides rows, x strides columns (coalesced along the row)
+  for (int i = blockIdx.y; i < k; i += gridDim.y) {
+    double wi = D.slotE[i];
+    if (wi == 0.0)
+      continue;
+    double *Mrow = D.Minv + (size_t)i * D.ld;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < k; j += gridDim.x * blockDim.x)
+      Mrow[j] -= wi * D.slotF[j];
+  }
+}
+
+__global__ void k_rank1_fix(Dev D)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  const int k = c->k;
+  const int ucase = c->updateCase;
+  const double alpha = c->alpha;
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ucase == 0) {
+    int a = c->slotColOut;
+    if (s < k)
+      D.Minv[(size_t)a * D.ld + s] = D.slotF[s];
+  } else if (ucase == 1) {
+    if (s < k) {
+      D.Minv[(size_t)k * D.ld + s] = D.slotF[s];
+      D.Minv[(size_t)s * D.ld + k] = D.slotE[s] / alpha;
+    } else if (s == k) {
+      D.Minv[(size_t)k * D.ld + k] = -1.0 / alpha;
+    }
+  } else if (ucase == 2) {
+    // delete col-slot a (a matrix row) and row-slot b (a matrix column): move the last ones in
+    int a = c->slotColOut, b = c->slotRowIn, last = k - 1;
+    if (s < k) {
+      // first the column move (within every row), then the row move; rows a/last handled once
+      double vlast = D.Minv[(size_t)s * D.ld + last];
+      if (b != last)
+        D.Minv[(size_t)s * D.ld + b] = vlast;
+    }
+  } else {
+    int b = c->slotRowIn;
+    if (s < k)
+      D.Minv[(size_t)s * D.ld + b] = D.slotE[s] / alpha;
+  }
+}
+// second half of the delete: copy matrix row `last` over row a (after the column move)
+__global__ void k_rank1_fix2(Dev D)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN || c->updateCase != 2)
+    return;
+  const int k = c->k;
+  int a = c->slotColOut, last = k - 1;
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a != last && s < k)
+    D.Minv[(size_t)a * D.ld + s] = D.Minv[(size_t)last * D.ld + s];
+}
+
+// =============================================================================================
+// Housekeeping -- tail of whileIterating (:1679-1713, :1828-1829), ClpSimplex::housekeeping
+// (src/ClpSimplex.cpp:2065-2489), basis bookkeeping of the nucleus, row-copy partition
+// maintenance and the pivot log record.  One workgroup; entry loops are thread-parallel.
+// =============================================================================================
+__device__ inline void rowCopySwap(const Dev &D, int e, int b)
+{
+  if (e == b)
+    return;
+  int ce = D.ccol[e], cb = D.ccol[b];
+  double ve = D.relem[e], vb = D.relem[b];
+  int pe = D.csrToCsc[e], pb = D.csrToCsc[b];
+  D.ccol[e] = cb;
+  D.relem[e] = vb;
+  D.csrToCsc[e] = pb;
+  D.cscToCsr[pb] = e;
+  D.ccol[b] = ce;
+  D.relem[b] = ve;
+  D.csrToCsc[b] = pe;
+  D.cscToCsr[pe] = b;
+}
+
+__global__ void __launch_bounds__(256) k_house(Dev D)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  const int tid = threadIdx.x;
+  const int seqIn = c->sequenceIn, seqOut = c->sequenceOut, pivotRow = c->pivotRow;
+  const int n = D.n;
+  // ---- row copy partition: leaving structural goes to the nonbasic part, entering to the basic
+  if (seqOut < n) {
+    for (int p = D.colStart[seqOut] + tid; p < D.colStart[seqOut + 1]; p += blockDim.x) {
+      int r = D.row[p];
+      int e = D.cscToCsr[p];
+      int b = D.rowStart[r] + D.basicCount[r] - 1;
+      rowCopySwap(D, e, b);
+      D.basicCount[r] -= 1;
+    }
+  }
+  __syncthreads();
+  if (seqIn < n) {
+    for (int p = D.colStart[seqIn] + tid; p < D.colStart[seqIn + 1]; p += blockDim.x) {
+      int r = D.row[p];
+      int e = D.cscToCsr[p];
+      int b = D.rowStart[r] + D.basicCount[r];
+      rowCopySwap(D, e, b);
+      D.basicCount[r] += 1;
+    }
+  }
+  // ---- clear the sparse work vectors of this iteration
+  if (seqIn < n) {
+    for (int p = D.colStart[seqIn] + tid; p < D.colStart[seqIn + 1]; p += blockDim.x)
+      D.vecV1[D.row[p]] = 0.0;
+  } else if (tid == 0) {
+    D.vecV1[seqIn - n] = 0.0;
+  }
+  __syncthreads();
+  if (tid != 0)
+    return;
+  D.vecC[pivotRow] = 0.0;
+  // ---- nucleus bookkeeping
+  int k = c->k;
+  const int ucase = c->updateCase;
+  if (ucase == 0) {
+    int a = c->slotColOut;
+    D.slotOfCol[seqOut] = -1;
+    D.slotOfCol[seqIn] = a;
+    D.slotCol[a] = seqIn;  // position unchanged (== pivotRow)
+  } else if (ucase == 1) {
+    int r = c->rowOfSlackOut;  // its slack leaves the basis: row joins the nucleus
+    D.posOfSlack[r] = -1;
+    D.slotOfRow[r] = k;
+    D.slotRow[k] = r;
+    D.slotOfCol[seqIn] = k;
+    D.slotCol[k] = seqIn;
+    D.slotPos[k] = pivotRow;
+    k++;
+  } else if (ucase == 2) {
+    int a = c->slotColOut, b = c->slotRowIn, last = k - 1;
+    int rIn = seqIn - n;
+    D.slotOfCol[seqOut] = -1;
+    D.slotOfRow[rIn] = -1;
+    D.posOfSlack[rIn] = pivotRow;
+    if (a != last) {
+      int colLast = D.slotCol[last];
+      D.slotCol[a] = colLast;
+      D.slotPos[a] = D.slotPos[last];
+      D.slotOfCol[colLast] = a;
+    }
+    if (b != last) {
+      int rowLast = D.slotRow[last];
+      D.slotRow[b] = rowLast;
+      D.slotOfRow[rowLast] = b;
+    }
+    k--;
+  } else {
+    int b = c->slotRowIn;
+    int rIn = seqIn - n, rOut = c->rowOfSlackOut;
+    D.posOfSlack[rOut] = -1;
+    D.posOfSlack[rIn] = pivotRow;
+    D.slotOfRow[rIn] = -1;
+    D.slotOfRow[rOut] = b;
+    D.slotRow[b] = rOut;
+  }
+  c->k = k;
+  // ---- whileIterating :1687-1712
+  double dualOut = c->dualOut / c->alpha;
+  dualOut *= -c->directionOut;
+  c->dualOut = dualOut;
+  D.dj[seqIn] = 0.0;
+  double oldValue = c->valueIn;
+  double valueIn = (c->directionIn == -1) ? c->upperIn + dualOut : c->lowerIn + dualOut;
+  c->valueIn = valueIn;
+  double objectiveChange = c->objectiveChange + D.cost[seqIn] * (valueIn - oldValue);
+  double valueOut;
+  if (c->directionOut > 0) {
+    valueOut = c->lowerOut;
+    D.dj[seqOut] = c->theta;
+  } else {
+    valueOut = c->upperOut;
+    D.dj[seqOut] = -c->theta;
+  }
+  c->valueOut = valueOut;
+  D.sol[seqOut] = valueOut;
+  // ---- housekeeping (ClpSimplex.cpp:2065-2140)
+  c->numberIterations++;
+  D.pivotVariable[pivotRow] = seqIn;
+  D.sol[seqIn] = valueIn;
+  unsigned char stIn = D.status[seqIn], stOut = D.status[seqOut];
+  if (seqIn != seqOut) {
+    stIn = (unsigned char)((stIn & ~7) | ST_BASIC);
+    if (D.upper[seqOut] - D.lower[seqOut] > 0) {
+      if (fabs(valueOut - D.lower[seqOut]) < fabs(valueOut - D.upper[seqOut]))
+        stOut = (unsigned char)((stOut & ~7) | ST_LOWER);
+      else
+        stOut = (unsigned char)((stOut & ~7) | ST_UPPER);
+    } else {
+      stOut = (unsigned char)((stOut & ~7) | ST_FIXED);
+    }
+    D.sol[seqOut] = valueOut;
+  }
+  // originalBound(sequenceIn) / changeBound(sequenceOut) (ClpSimplexDual.cpp:6403, :6445)
+  if ((stIn >> 3) & 3) {
+    stIn = (unsigned char)(stIn & ~24);
+    D.lower[seqIn] = D.origLower[seqIn];
+    D.upper[seqIn] = D.origUpper[seqIn];
+  }
+  {
+    double oldLower = D.lower[seqOut], oldUpper = D.upper[seqOut], value = D.sol[seqOut];
+    stOut = (unsigned char)(stOut & ~24);
+    double lowerValue = D.origLower[seqOut], upperValue = D.origUpper[seqOut];
+    if (value == oldLower) {
+      if (upperValue > oldLower + c->dualBound) {
+        D.upper[seqOut] = oldLower + c->dualBound;
+        stOut = (unsigned char)(stOut | (FAKE_UPPER << 3));
+      }
+    } else if (value == oldUpper) {
+      if (lowerValue < oldUpper - c->dualBound) {
+        D.lower[seqOut] = oldUpper - c->dualBound;
+        stOut = (unsigned char)(stOut | (FAKE_LOWER << 3));
+      }
+    }
+  }
+  D.status[seqIn] = stIn;
+  D.status[seqOut] = stOut;
+  c->objectiveValue += objectiveChange;
+  c->pivots++;
+  // ---- pivot log (CLP_SIMPLEX_HOUSE2, src/ClpMessage.cpp:48)
+  if (c->logCount < c->logCapacity) {
+    PivotRecord *r = &D.log[c->logCount];
+    r->iteration = c->numberIterations;
+    r->sequenceIn = seqIn;
+    r->sequenceOut = seqOut;
+    r->pivotRow = pivotRow;
+    r->numberFlipped = c->numberFlips;
+    r->reserved = ucase;
+    r->theta = c->theta;
+    r->alpha = c->alpha;
+    r->dualOut = dualOut;
+    r->objective = c->objectiveValue;
+  }
+  c->logCount++;
+  // ---- refactorization decision (ClpSimplex.cpp:2435-2488)
+  if (c->numberIterations >= c->maximumIterations) {
+    c->state = EXIT_MAX_ITERATIONS;
+    return;
+  }
+  int numberPivots = c->pivots;
+  if (numberPivots == c->maximumPivots || c->maximumPivots < 2) {
+    c->state = EXIT_REFACTOR;
+  } else if (c->forceFactorization > 0 && numberPivots == c->forceFactorization) {
+    c->forceFactorization = (3 + 5 * c->forceFactorization) / 4;
+    if (c->forceFactorization > c->maximumPivots)
+      c->forceFactorization = -1;
+    c->state = EXIT_REFACTOR;
+  } else if (c->numberIterations > 1000 + 10 * (D.m + (D.n >> 2))) {
+    double random = randomDouble(c);
+    while (random < 0.45)
+      random *= 2.0;
+    int maxNumber = (c->forceFactorization < 0) ? c->maximumPivots : min(c->forceFactorization, c->maximumPivots);
+    if (numberPivots >= random * maxNumber)
+      c->state = EXIT_REFACTOR;
+  }
+  if (c->state == RUN && c->k + 2 >= c->kcap)
+    c->state = EXIT_REFACTOR;  // nucleus storage nearly full: host regrows it at the refactorization
+}
+
+__global__ void k_zero(double *p, int n)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    p[i] = 0.0;
+}
+__global__ void k_zero_if_flips(Dev D, double *p, int n)
+{
+  if (D.ctrl->numberFlips == 0)
+    return;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    p[i] = 0.0;
+}
+
+// =============================================================================================
+// Refactorization of the nucleus: gather C = A[R,K], Gauss-Jordan with partial pivoting whose
+// arithmetic on the not-yet-pivoted rows is exactly the right-looking LU of
+// CoinAbcDenseFactorization::factor (src/CoinAbcDenseFactorization.cpp:262-313): multiplier
+// l_j = a_ji * (1/pivot), a_jc -= a_ic * l_j, first-largest pivot in physical row order.
+// The same row operations applied to the identity give X with X*C = D, so Minv = D^-1 X.
+// =============================================================================================
+__global__ void k_gather_nucleus(Dev D, const int *kcol, const int *localOfRow, int k)
+{
+  // one block per nucleus column
+  int cidx = blockIdx.x;
+  if (cidx >= k)
+    return;
+  int j = kcol[cidx];
+  for (int p = D.colStart[j] + threadIdx.x; p < D.colStart[j + 1]; p += blockDim.x) {
+    int r = localOfRow[D.row[p]];
+    if (r >= 0)
+      D.workW[(size_t)r * D.ld + cidx] = D.elem[p];
+  }
+}
+__global__ void k_identity(Dev D, int k)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < k)
+    D.workX[(size_t)i * D.ld + i] = 1.0;
+}
+
+// pivot search in column i among physical rows >= i (first largest, > zeroTolerance)
+__global__ void __launch_bounds__(1024) k_gj_pivot(Dev D, int i, int k, int *info /*[0]=singular flag, [1]=pivot row*/)
+{
+  __shared__ double shv[16];
+  __shared__ int shk[16];
+  if (info[0])
+    return;
+  double best = D.ctrl->zeroTolerance;
+  int key = -1;
+  for (int j = i + threadIdx.x; j < k; j += blockDim.x) {
+    double v = fabs(D.workW[(size_t)j * D.ld + i]);
+    if (v > best) {
+      best = v;
+      key = j;
+    }
+  }
+  blockArgMax(best, key, shv, shk);
+  if (threadIdx.x == 0) {
+    if (key < 0)
+      info[0] = 1 + i;
+    info[1] = key;
+  }
+}
+// swap physical rows i and pivot row in W and X, record permutation, store multipliers
+__global__ void k_gj_swap(Dev D, int i, int k, int *info)
+{
+  if (info[0])
+    return;
+  int iRow = info[1];
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (iRow != i && j < k) {
+    size_t a = (size_t)i * D.ld + j, b = (size_t)iRow * D.ld + j;
+    double t = D.workW[a];
+    D.workW[a] = D.workW[b];
+    D.workW[b] = t;
+    t = D.workX[a];
+    D.workX[a] = D.workX[b];
+    D.workX[b] = t;
+  }
+  if (j == 0 && iRow != i) {
+    int t = D.perm[i];
+    D.perm[i] = D.perm[iRow];
+    D.perm[iRow] = t;
+  }
+}
+// multipliers l_r = W[r][i] * (1/pivot) for every row r != i (kept in slotA), pivot inverse in slotB[i]
+__global__ void k_gj_mult(Dev D, int i, int k, int *info)
+{
+  if (info[0])
+    return;
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < k) {
+    double pivotValue = 1.0 / D.workW[(size_t)i * D.ld + i];
+    if (r == i) {
+      D.slotB[i] = pivotValue;
+      D.slotA[r] = 0.0;
+    } else {
+      D.slotA[r] = D.workW[(size_t)r * D.ld + i] * pivotValue;
+    }
+  }
+}
+// row_r -= l_r * row_i  for all r != i, on W (columns > i) and X (all columns)
+__global__ void __launch_bounds__(256) k_gj_elim(Dev D, int i, int k, int *info)
+{
+  if (info[0])
+    return;
+  const double *Wi = D.workW + (size_t)i * D.ld;
+  const double *Xi = D.workX + (size_t)i * D.ld;
+  for (int r = blockIdx.y; r < k; r += gridDim.y) {
+    if (r == i)
+      continue;
+    double l = D.slotA[r];
+    if (l == 0.0)
+      continue;
+    double *Wr = D.workW + (size_t)r * D.ld;
+    double *Xr = D.workX + (size_t)r * D.ld;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < k; j += gridDim.x * blockDim.x) {
+      if (j > i)
+        Wr[j] -= Wi[j] * l;
+      Xr[j] -= Xi[j] * l;
+    }
+  }
+}
+// Minv = D^-1 X
+__global__ void __launch_bounds__(256) k_gj_finish(Dev D, int k)
+{
+  for (int r = blockIdx.y; r < k; r += gridDim.y) {
+    double inv = D.slotB[r];
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < k; j += gridDim.x * blockDim.x)
+      D.Minv[(size_t)r * D.ld + j] = D.workX[(size_t)r * D.ld + j] * inv;
+  }
+}
+
+// =============================================================================================
+// full-length matrix products for the resync after a refactorization
+//   ClpPackedMatrix::times :296 (by the row copy: deterministic, no atomics)
+//   ClpPackedMatrix::transposeTimes :362
+// =============================================================================================
+__global__ void k_times(Dev D, double scalar, const double *x, double *y)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < D.m) {
+    double acc = 0.0;
+    for (int q = D.rowStart[i]; q < D.rowStart[i + 1]; q++)
+      acc += D.relem[q] * x[D.ccol[q]];
+    y[i] += scalar * acc;
+  }
+}
+__global__ void k_transpose_times(Dev D, double scalar, const double *x, double *y)
+{
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < D.n) {
+    double value = 0.0;
+    for (int p = D.colStart[j]; p < D.colStart[j + 1]; p++)
+      value += x[D.row[p]] * D.elem[p];
+    y[j] += value * scalar;
+  }
+}
+
+// computePrimals helpers (src/ClpSimplex.cpp:914): zero basics, rhs = rowActivity - A x_N
+__global__ void k_zero_basic(Dev D)
+{
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < D.m)
+    D.sol[D.pivotVariable[p]] = 0.0;
+}
+__global__ void k_primal_rhs(Dev D, double *rhs)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < D.m) {
+    double acc = 0.0;
+    for (int q = D.rowStart[i]; q < D.rowStart[i + 1]; q++)
+      acc += D.relem[q] * D.sol[D.ccol[q]];
+    rhs[i] = -acc + D.sol[D.n + i];
+  }
+}
+__global__ void k_store_basic(Dev D, const double *x)
+{
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < D.m)
+    D.sol[D.pivotVariable[p]] = x[p];
+}
+// computeDuals helpers (src/ClpSimplex.cpp:1164)
+__global__ void k_basic_costs(Dev D, double *cB)
+{
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < D.m)
+    cB[p] = D.cost[D.pivotVariable[p]];
+}
+__global__ void k_djs(Dev D, const double *y)
+{
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < D.n) {
+    double value = 0.0;
+    for (int p = D.colStart[t]; p < D.colStart[t + 1]; p++)
+      value += y[D.row[p]] * D.elem[p];
+    D.dj[t] = D.cost[t] + value * -1.0;
+  } else if (t < D.N) {
+    D.dj[t] = y[t - D.n] + D.cost[t];
+  }
+}
+
+// saveWeights (src/ClpDualRowSteepest.cpp:773): weights follow their sequence across a
+// refactorization; mode >= 2 rebuilds the infeasibility list in ascending position order
+__global__ void k_weights_to_seq(Dev D)
+{
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < D.m)
+    D.weightBySeq[D.pivotVariable[p]] = D.weights[p];
+}
+__global__ void k_weights_from_seq(Dev D, int initialize)
+{
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < D.m) {
+    double wgt = 1.0;
+    if (!initialize) {
+      wgt = D.weightBySeq[D.pivotVariable[p]];
+      if (wgt < 0.0)
+        wgt = 1.0;  // "odd": was not basic at save time
+      else if (wgt < DEVEX_TRY_NORM)
+        wgt = DEVEX_TRY_NORM;
+    }
+    D.weights[p] = wgt;
+  }
+}
+__global__ void k_fill(double *p, double v, int n)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    p[i] = v;
+}
+__global__ void __launch_bounds__(256) k_infeas_flags(Dev D)
+{
+  __shared__ int shi[17];
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  int flag = 0;
+  if (p < D.m) {
+    const double tolerance = D.ctrl->primalTolerance;
+    int iPivot = D.pivotVariable[p];
+    double value = D.sol[iPivot], lower = D.lower[iPivot], upper = D.upper[iPivot];
+    double inf = 0.0;
+    if (value < lower - tolerance) {
+      value -= lower;
+      inf = value * value;
+      flag = 1;
+    } else if (value > upper + tolerance) {
+      value -= upper;
+      inf = value * value;
+      flag = 1;
+    }
+    D.infeas[p] = inf;
+    D.appendFlag[p] = flag;
+  }
+  int total;
+  blockRank(flag, total, shi);
+  if (threadIdx.x == 0)
+    D.blockCount[blockIdx.x] = total;
+}
+__global__ void k_infeas_finish(Dev D)
+{
+  D.ctrl->numberInfeasible = D.ctrl->numberAppend;
+  D.ctrl->numberAppend = 0;
+}
+__global__ void k_set_state(Dev D, int state)
+{
+  D.ctrl->state = state;
+}
+
+}  // namespace clpgpu

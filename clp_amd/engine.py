@@ -1,0 +1,250 @@
+"""ctypes binding of libclpgpu.so (include/clpgpu.h) with a ClpSimplex-shaped surface.
+
+This is plumbing: every numerical operation happens in the HIP library.  There is no CPU fallback --
+importing works without a GPU (so the C ABI can be inspected), but constructing a
+:class:`ClpGpuSimplex` raises when the library or a HIP device is missing.
+
+Method names follow the reference's ClpSimplex / ClpModel API (src/ClpSimplex.hpp, src/ClpModel.hpp):
+``loadProblem``, ``dual``, ``setMaximumIterations``, ``objectiveValue``, ``primalColumnSolution``,
+``primalRowSolution``, ``dualColumnSolution``, ``dualRowSolution``, ``statusArray``, ``numberIterations``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libclpgpu.so")
+_LIB = None
+
+PIVOT_DTYPE = np.dtype([("iteration", "i4"), ("sequenceIn", "i4"), ("sequenceOut", "i4"), ("pivotRow", "i4"),
+                        ("numberFlipped", "i4"), ("reserved", "i4"), ("theta", "f8"), ("alpha", "f8"),
+                        ("dualOut", "f8"), ("objective", "f8")])
+
+
+class Stats(C.Structure):
+    _fields_ = [("price_ms", C.c_double), ("price_launches", C.c_long), ("price_bytes", C.c_double),
+                ("total_ms", C.c_double), ("iterations", C.c_long), ("refactorizations", C.c_long)]
+
+
+# every symbol include/clpgpu.h declares (tests/test_abi.py checks the library exports all of them)
+ABI_SYMBOLS = [
+    "clpgpu_create", "clpgpu_destroy", "clpgpu_last_error", "clpgpu_stream", "clpgpu_load_problem",
+    "clpgpu_set_column_range", "clpgpu_times", "clpgpu_transpose_times", "clpgpu_price_row", "clpgpu_factorize",
+    "clpgpu_ftran", "clpgpu_btran", "clpgpu_replace_column", "clpgpu_pivots", "clpgpu_set_option",
+    "clpgpu_set_status", "clpgpu_dual", "clpgpu_dual_steps", "clpgpu_number_iterations", "clpgpu_objective_value",
+    "clpgpu_get_solution", "clpgpu_get_reduced_costs", "clpgpu_get_status", "clpgpu_get_pivot_variable",
+    "clpgpu_get_pivot_log", "clpgpu_get_stats",
+]
+
+
+def build(force: bool = False) -> str:
+    """Compile libclpgpu.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(src_dir, f) for f in ("engine.hip", "kernels.hip", "device_state.h")]
+    srcs.append(os.path.join(_HERE, "..", "include", "clpgpu.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", src_dir, "-s"])
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(the HIP extension is the product; there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        p = C.c_void_p
+        ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+        dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+        up = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+        L.clpgpu_create.restype = p
+        L.clpgpu_create.argtypes = [C.c_int]
+        L.clpgpu_destroy.argtypes = [p]
+        L.clpgpu_last_error.restype = C.c_char_p
+        L.clpgpu_last_error.argtypes = [p]
+        L.clpgpu_stream.restype = p
+        L.clpgpu_stream.argtypes = [p]
+        L.clpgpu_load_problem.argtypes = [p, C.c_int, C.c_int, ip, ip, dp, dp, dp, dp, dp, dp]
+        L.clpgpu_set_column_range.argtypes = [p, C.c_int, C.c_int]
+        L.clpgpu_times.argtypes = [p, C.c_double, dp, dp]
+        L.clpgpu_transpose_times.argtypes = [p, C.c_double, dp, dp]
+        L.clpgpu_price_row.argtypes = [p, C.c_int, ip, dp, up, dp, C.c_double, C.c_double, C.c_double,
+                                       C.POINTER(C.c_int), ip, dp, C.POINTER(C.c_int), ip, dp, C.POINTER(C.c_double)]
+        L.clpgpu_factorize.argtypes = [p, up, ip]
+        L.clpgpu_ftran.argtypes = [p, dp]
+        L.clpgpu_btran.argtypes = [p, dp]
+        L.clpgpu_replace_column.argtypes = [p, C.c_int, C.c_int, C.c_double, C.c_double]
+        L.clpgpu_pivots.argtypes = [p]
+        L.clpgpu_set_option.argtypes = [p, C.c_char_p, C.c_double]
+        L.clpgpu_set_status.argtypes = [p, up]
+        L.clpgpu_dual.argtypes = [p]
+        L.clpgpu_dual_steps.argtypes = [p, C.c_int]
+        L.clpgpu_number_iterations.argtypes = [p]
+        L.clpgpu_objective_value.argtypes = [p]
+        L.clpgpu_objective_value.restype = C.c_double
+        L.clpgpu_get_solution.argtypes = [p, dp]
+        L.clpgpu_get_reduced_costs.argtypes = [p, dp]
+        L.clpgpu_get_status.argtypes = [p, up]
+        L.clpgpu_get_pivot_variable.argtypes = [p, ip]
+        L.clpgpu_get_pivot_log.argtypes = [p, C.c_void_p, C.c_int]
+        L.clpgpu_get_stats.argtypes = [p, C.POINTER(Stats)]
+        _LIB = L
+    return _LIB
+
+
+class ClpGpuSimplex:
+    """Engine-mode driver: ClpSimplex::dual() on one MI355X (precedent: ClpSimplex::dealWithAbc)."""
+
+    def __init__(self, device: int = 0):
+        self._h = lib().clpgpu_create(int(device))
+        if not self._h:
+            raise RuntimeError("clpgpu_create failed: no usable HIP device (gfx950) -- libclpgpu has no CPU fallback")
+        self.m = self.n = 0
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h and _LIB is not None:
+            _LIB.clpgpu_destroy(h)
+            self._h = None
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {lib().clpgpu_last_error(self._h).decode()}")
+
+    # ---- ClpModel / ClpSimplex surface --------------------------------------------------------
+    def loadProblem(self, lp):
+        c = np.ascontiguousarray
+        self.m, self.n = int(lp.m), int(lp.n)
+        self._check(lib().clpgpu_load_problem(
+            self._h, self.m, self.n, c(lp.col_start, dtype=np.int32), c(lp.row, dtype=np.int32),
+            c(lp.elem, dtype=np.float64), c(lp.col_lower, dtype=np.float64), c(lp.col_upper, dtype=np.float64),
+            c(lp.obj, dtype=np.float64), c(lp.row_lower, dtype=np.float64), c(lp.row_upper, dtype=np.float64)),
+            "clpgpu_load_problem")
+        return self
+
+    def set_option(self, name, value):
+        if lib().clpgpu_set_option(self._h, name.encode(), float(value)) != 0:
+            raise KeyError(name)
+
+    def setMaximumIterations(self, value):
+        self.set_option("max_iterations", value)
+
+    def setDualRowPivotAlgorithm(self, name):
+        self.set_option("pivot_rule", {"dantzig": 0, "steepest": 1}[name])
+
+    def setColumnRange(self, first, last):
+        self._check(lib().clpgpu_set_column_range(self._h, int(first), int(last)), "clpgpu_set_column_range")
+
+    def setStatusArray(self, status):
+        self._check(lib().clpgpu_set_status(self._h, np.ascontiguousarray(status, dtype=np.uint8)), "clpgpu_set_status")
+
+    def dual(self):
+        return lib().clpgpu_dual(self._h)
+
+    def dual_steps(self, iterations):
+        return lib().clpgpu_dual_steps(self._h, int(iterations))
+
+    def numberIterations(self):
+        return lib().clpgpu_number_iterations(self._h)
+
+    def objectiveValue(self):
+        return lib().clpgpu_objective_value(self._h)
+
+    def _vec(self, fn, dtype=np.float64, size=None):
+        out = np.zeros(size or (self.m + self.n), dtype=dtype)
+        self._check(getattr(lib(), fn)(self._h, out), fn)
+        return out
+
+    def solution(self):
+        return self._vec("clpgpu_get_solution")
+
+    def primalColumnSolution(self):
+        return self.solution()[: self.n]
+
+    def primalRowSolution(self):
+        return self.solution()[self.n:]
+
+    def reducedCosts(self):
+        return self._vec("clpgpu_get_reduced_costs")
+
+    def dualColumnSolution(self):
+        return self.reducedCosts()[: self.n]
+
+    def dualRowSolution(self):
+        return self.reducedCosts()[self.n:]
+
+    def statusArray(self):
+        return self._vec("clpgpu_get_status", np.uint8)
+
+    def pivotVariable(self):
+        return self._vec("clpgpu_get_pivot_variable", np.int32, self.m)
+
+    def pivotLog(self):
+        total = lib().clpgpu_get_pivot_log(self._h, None, 0)
+        out = np.zeros(max(total, 0), dtype=PIVOT_DTYPE)
+        if total > 0:
+            lib().clpgpu_get_pivot_log(self._h, out.ctypes.data_as(C.c_void_p), total)
+        return out
+
+    def stats(self):
+        s = Stats()
+        self._check(lib().clpgpu_get_stats(self._h, C.byref(s)), "clpgpu_get_stats")
+        return {f: getattr(s, f) for f, _ in Stats._fields_}
+
+    def stream(self):
+        return lib().clpgpu_stream(self._h)
+
+    # ---- plug-in level calls (ClpMatrixBase / CoinOtherFactorization surfaces) -------------------
+    def times(self, scalar, x, y):
+        y = np.array(y, dtype=np.float64)
+        self._check(lib().clpgpu_times(self._h, float(scalar), np.ascontiguousarray(x, dtype=np.float64), y), "clpgpu_times")
+        return y
+
+    def transposeTimes(self, scalar, x, y):
+        y = np.array(y, dtype=np.float64)
+        self._check(lib().clpgpu_transpose_times(self._h, float(scalar), np.ascontiguousarray(x, dtype=np.float64), y),
+                    "clpgpu_transpose_times")
+        return y
+
+    def priceRow(self, pi_index, pi_value, status, dj, zero_tol=1e-13, dual_tol=1e-7, acceptable_pivot=1e-9):
+        n, m = self.n, self.m
+        out_i = np.zeros(n, np.int32)
+        out_v = np.zeros(n)
+        cand_i = np.zeros(n + m, np.int32)
+        cand_v = np.zeros(n + m)
+        nout, ncand, upper = C.c_int(0), C.c_int(0), C.c_double(0.0)
+        pi_index = np.ascontiguousarray(pi_index, dtype=np.int32)
+        self._check(lib().clpgpu_price_row(self._h, len(pi_index), pi_index, np.ascontiguousarray(pi_value, dtype=np.float64),
+                                           np.ascontiguousarray(status, dtype=np.uint8),
+                                           np.ascontiguousarray(dj, dtype=np.float64), zero_tol, dual_tol, acceptable_pivot,
+                                           C.byref(nout), out_i, out_v, C.byref(ncand), cand_i, cand_v, C.byref(upper)),
+                    "clpgpu_price_row")
+        return (out_i[:nout.value].copy(), out_v[:nout.value].copy(), cand_i[:ncand.value].copy(),
+                cand_v[:ncand.value].copy(), upper.value)
+
+    def factorize(self, status):
+        pv = np.zeros(self.m, np.int32)
+        rc = lib().clpgpu_factorize(self._h, np.ascontiguousarray(status, dtype=np.uint8), pv)
+        return rc, pv
+
+    def ftran(self, v):
+        v = np.array(v, dtype=np.float64)
+        self._check(lib().clpgpu_ftran(self._h, v), "clpgpu_ftran")
+        return v
+
+    def btran(self, v):
+        v = np.array(v, dtype=np.float64)
+        self._check(lib().clpgpu_btran(self._h, v), "clpgpu_btran")
+        return v
+
+    def replaceColumn(self, pivot_row, sequence_in):
+        return lib().clpgpu_replace_column(self._h, int(pivot_row), int(sequence_in), 0.0, 1e-8)
+
+    def pivots(self):
+        return lib().clpgpu_pivots(self._h)

@@ -1,0 +1,138 @@
+/*
+ * clpgpu.h -- C ABI of libclpgpu.so, the MI355X (gfx950) dual-simplex iteration engine.
+ *
+ * Drop-in boundary for the per-iteration hot path of coin-or/Clp's revised dual simplex
+ * (SURVEY.md section 8b).  Plain C: POD pointers and sizes only, no C++/torch types, no exceptions,
+ * every call synchronous at return, `int` status codes mirroring the reference's.  One context per
+ * ClpSimplex; contexts are independent.  Host arrays are the caller's; the engine keeps device copies.
+ *
+ * Each entry point cites the reference interface it stands in for (file:line under the reference
+ * tree).  INTEGRATION.md shows the C++ adapter classes (ClpPackedMatrix / ClpDualRowPivot /
+ * CoinOtherFactorization subclasses and the dealWithAbc-style engine swap) a Clp maintainer would
+ * add to bind them.
+ *
+ * Conventions (identical to ClpSimplex): sequences [0,n) = structural columns, [n,n+m) = row
+ * slacks, slack column = -e_i (src/ClpSimplex.cpp:3442-3474); rim arrays are [columns | rows]
+ * (src/ClpSimplex.hpp:1864-1922); status byte = ClpSimplex::Status in the low 3 bits
+ * (src/ClpSimplex.hpp:119-133), bits 3-4 fake-bound flags, bit 6 "flagged".
+ */
+#ifndef CLPGPU_H
+#define CLPGPU_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct clpgpu_context clpgpu_context;
+
+/* per-iteration record, the shape of CLP_SIMPLEX_HOUSE2 (src/ClpMessage.cpp:48,
+ * emitted src/ClpSimplex.cpp:2227-2236) */
+typedef struct {
+  int iteration;
+  int sequenceIn;
+  int sequenceOut;
+  int pivotRow;
+  int numberFlipped;
+  int reserved;
+  double theta;
+  double alpha;
+  double dualOut;
+  double objective;
+} clpgpu_pivot_record;
+
+/* per-kernel-class device timings gathered with hipEvents on the engine's stream */
+typedef struct {
+  double price_ms;      /* sum over launches of the row-pricing kernel */
+  long price_launches;
+  double price_bytes;   /* algorithmic bytes moved by those launches (SURVEY 8d formula) */
+  double total_ms;      /* whole clpgpu_dual wall time */
+  long iterations;
+  long refactorizations;
+} clpgpu_stats;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+/* device = HIP device ordinal.  Returns NULL when no gfx950 device / HIP runtime is usable:
+ * there is no CPU fallback. */
+clpgpu_context *clpgpu_create(int device);
+void clpgpu_destroy(clpgpu_context *ctx);
+const char *clpgpu_last_error(const clpgpu_context *ctx);
+/* HIP stream (hipStream_t as void*) the engine launches on; for event timing by callers */
+void *clpgpu_stream(clpgpu_context *ctx);
+
+/* ---- ClpMatrixBase / ClpPackedMatrix surface (src/ClpMatrixBase.hpp:38-546) ------------ */
+/* ClpSimplex::loadProblem(const ClpMatrixBase&, collb, colub, obj, rowlb, rowub)
+ * (src/ClpSimplex.hpp:237): CSC A as CoinPackedMatrix stores it + original bounds/costs. */
+int clpgpu_load_problem(clpgpu_context *ctx, int numberRows, int numberColumns, const int *columnStart,
+                        const int *rowIndex, const double *element, const double *columnLower,
+                        const double *columnUpper, const double *objective, const double *rowLower,
+                        const double *rowUpper);
+/* column-range shard for multi-GPU pricing (ABOCA_LITE chunking,
+ * src/ClpPackedMatrix.cpp:1823-1854): this context prices only columns [first, last). */
+int clpgpu_set_column_range(clpgpu_context *ctx, int firstColumn, int lastColumn);
+
+/* ClpMatrixBase::times(scalar, x, y) (:275; ClpPackedMatrix.cpp:296): y += scalar*A*x */
+int clpgpu_times(clpgpu_context *ctx, double scalar, const double *x, double *y);
+/* ClpMatrixBase::transposeTimes(scalar, x, y) (:287; ClpPackedMatrix.cpp:362): y += scalar*A^T*x */
+int clpgpu_transpose_times(clpgpu_context *ctx, double scalar, const double *x, double *y);
+
+/* ClpMatrixBase::transposeTimes(model, scalar=-1, x, y, z) (:308; ClpPackedMatrix.cpp:706) on the
+ * by-column path with the fused first ratio-test pass (ClpPackedMatrix.cpp:1799-1993, requested
+ * through spareIntArray_[0]==1, ClpSimplexDual.cpp:1290-1308).
+ * in : packed pi (numberPi, piIndex, piValue), status[n+m], dj[n+m] (the current rim state)
+ * out: tableau row column part (outIndex ascending, outValue; returns count via *numberOut),
+ *      candidate list (candIndex = sequence numbers, rows first then columns ascending; candValue =
+ *      alpha with sign), *upperTheta (spareDoubleArray_[0]). */
+int clpgpu_price_row(clpgpu_context *ctx, int numberPi, const int *piIndex, const double *piValue,
+                     const unsigned char *status, const double *dj, double zeroTolerance,
+                     double dualTolerance, double acceptablePivot, int *numberOut, int *outIndex,
+                     double *outValue, int *numberCandidates, int *candIndex, double *candValue,
+                     double *upperTheta);
+
+/* ---- ClpFactorization / CoinOtherFactorization surface (src/ClpFactorization.hpp:34-551) - */
+/* ClpFactorization::factorize (src/ClpFactorization.cpp:1649): status[n+m] gives the basic set.
+ * Fills pivotVariable[m].  Returns 0 OK, -1 singular, -2 wrong number of basics, -99 memory
+ * (src/ClpFactorization.hpp:53). */
+int clpgpu_factorize(clpgpu_context *ctx, const unsigned char *status, int *pivotVariable);
+/* updateColumn (:2803) FTRAN, dense region of length m, in place (row space -> basis positions) */
+int clpgpu_ftran(clpgpu_context *ctx, double *region);
+/* updateColumnTranspose (:2993) BTRAN, dense length m in place (positions -> row space) */
+int clpgpu_btran(clpgpu_context *ctx, double *region);
+/* replaceColumn (:2584): basis position pivotRow leaves, `sequenceIn` enters.  The engine reruns
+ * the two solves it needs on the device.  Returns 0 OK, 2 singular, 3 no room, 5 max pivots
+ * (src/ClpFactorization.hpp:83). */
+int clpgpu_replace_column(clpgpu_context *ctx, int pivotRow, int sequenceIn, double pivotCheck,
+                          double acceptablePivot);
+int clpgpu_pivots(const clpgpu_context *ctx);
+
+/* ---- whole-engine mode (precedent: ClpSimplex::dealWithAbc, src/ClpSolve.cpp:555-833) ---- */
+/* options by name (ClpSimplex setters): "pivot_rule" 0 Dantzig (ClpDualRowDantzig) / 1 steepest
+ * (ClpDualRowSteepest); "max_iterations" (setMaximumIterations); "max_pivots"
+ * (factorization maximumPivots); "dual_bound"; "primal_tolerance"; "dual_tolerance";
+ * "random_seed"; "log_level"; "check_every" (host polls the device control block every N
+ * iterations). */
+int clpgpu_set_option(clpgpu_context *ctx, const char *name, double value);
+/* optional warm start (ClpSimplex::statusArray) */
+int clpgpu_set_status(clpgpu_context *ctx, const unsigned char *status);
+/* ClpSimplex::dual() (src/ClpSimplex.cpp:5631 -> ClpSimplexDual::dual :637): returns problemStatus
+ * 0 optimal, 1 primal infeasible, 2 dual infeasible, 3 iteration limit, 4 numerical trouble,
+ * 10 "needs primal clean-up" (src/ClpSimplex.cpp:5808). */
+int clpgpu_dual(clpgpu_context *ctx);
+/* Run at most `iterations` further pivots from the current device state (bench stepping);
+ * the first call performs startup.  Returns problemStatus, or -1 if still iterating. */
+int clpgpu_dual_steps(clpgpu_context *ctx, int iterations);
+
+int clpgpu_number_iterations(const clpgpu_context *ctx);
+double clpgpu_objective_value(const clpgpu_context *ctx);
+/* n+m doubles each, [columns | rows] */
+int clpgpu_get_solution(clpgpu_context *ctx, double *solution);
+int clpgpu_get_reduced_costs(clpgpu_context *ctx, double *dj);
+int clpgpu_get_status(clpgpu_context *ctx, unsigned char *status);
+int clpgpu_get_pivot_variable(clpgpu_context *ctx, int *pivotVariable);
+/* returns total number of records; copies min(total, maxRecords) */
+int clpgpu_get_pivot_log(clpgpu_context *ctx, clpgpu_pivot_record *out, int maxRecords);
+int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Development battery run on the GPU box: HIP engine vs the CPU oracle with verbose diagnostics.
+(tests/ holds the pytest versions; this prints more when something diverges.)"""
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from clp_amd import problems as P  # noqa: E402
+from clp_amd.engine import ClpGpuSimplex  # noqa: E402
+from clp_amd.mps import read_mps  # noqa: E402
+from oracle.oracle import OracleSimplex  # noqa: E402
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b) / (1.0 + np.abs(b)))) if len(a) else 0.0
+
+
+def check_matrix_ops(lp):
+    g = ClpGpuSimplex().loadProblem(lp)
+    o = OracleSimplex(lp)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(lp.n)
+    y = rng.standard_normal(lp.m)
+    e1 = rel(g.times(-1.0, x, y), o.times(-1.0, x, y))
+    xr = rng.standard_normal(lp.m)
+    yc = rng.standard_normal(lp.n)
+    gt, ot = g.transposeTimes(-1.0, xr, yc), o.transpose_times(-1.0, xr, yc)
+    print(f"  times rel {e1:.2e}  transposeTimes bit-identical {np.array_equal(gt, ot)} rel {rel(gt, ot):.2e}")
+
+
+def check_price(lp, seed=3, density=0.3):
+    g = ClpGpuSimplex().loadProblem(lp)
+    o = OracleSimplex(lp)
+    rng = np.random.default_rng(seed)
+    m, n = lp.m, lp.n
+    npi = max(1, int(density * m))
+    idx = np.sort(rng.choice(m, npi, replace=False)).astype(np.int32)
+    val = rng.standard_normal(npi)
+    status = rng.choice([1, 2, 3, 5], size=n + m, p=[0.2, 0.3, 0.45, 0.05]).astype(np.uint8)
+    dj = np.where((status & 3) == 2, -1.0, 1.0) * rng.uniform(0, 2, n + m)
+    a = g.priceRow(idx, val, status, dj)
+    b = o.price_row_fused(idx, val, status, dj)
+    ok = all(np.array_equal(x, y) for x, y in zip(a[:4], b[:4])) and a[4] == b[4]
+    print(f"  price: nnz {len(a[0])}/{len(b[0])} cand {len(a[2])}/{len(b[2])} upperTheta {a[4]!r}/{b[4]!r} bit-identical {ok}")
+    if not ok:
+        for k in range(4):
+            if not np.array_equal(a[k], b[k]):
+                nn = min(len(a[k]), len(b[k]))
+                bad = np.nonzero(a[k][:nn] != b[k][:nn])[0]
+                print("   field", k, "len", len(a[k]), len(b[k]), "first diff", bad[:5], a[k][bad[:3]], b[k][bad[:3]])
+    return ok
+
+
+def random_basis(lp, rng, nstruct):
+    m, n = lp.m, lp.n
+    status = np.full(n + m, 3, np.uint8)
+    status[n:] = 1
+    cols = rng.choice(n, nstruct, replace=False)
+    rows = rng.choice(m, nstruct, replace=False)
+    status[cols] = 1
+    status[n + rows] = 3
+    return status
+
+
+def check_factor(lp, nstruct, seed=5, updates=6):
+    g = ClpGpuSimplex().loadProblem(lp)
+    o = OracleSimplex(lp)
+    rng = np.random.default_rng(seed)
+    status = random_basis(lp, rng, nstruct)
+    rc_g, pv_g = g.factorize(status)
+    rc_o, pv_o = o.factorize(status)
+    print(f"  factor k={nstruct}: rc {rc_g}/{rc_o} pivotVariable identical {np.array_equal(pv_g, pv_o)}")
+    if rc_g or rc_o:
+        return False
+    ok = np.array_equal(pv_g, pv_o)
+    for t in range(2):
+        v = rng.standard_normal(lp.m) * (rng.random(lp.m) < 0.5)
+        e1 = rel(g.ftran(v), o.ftran(v))
+        e2 = rel(g.btran(v), o.btran(v))
+        print(f"    ftran rel {e1:.2e} btran rel {e2:.2e}")
+        ok &= e1 < 1e-9 and e2 < 1e-9
+    # a few basis changes through replaceColumn (all four pivot types)
+    pv = pv_o.copy()
+    basic = set(int(x) for x in pv)
+    for t in range(updates):
+        for attempt in range(50):
+            q = int(rng.integers(0, lp.n + lp.m))
+            if q in basic:
+                continue
+            col = np.zeros(lp.m)
+            if q >= lp.n:
+                col[q - lp.n] = -1.0
+            else:
+                s, e = lp.col_start[q], lp.col_start[q + 1]
+                col[lp.row[s:e]] = lp.elem[s:e]
+            w = o.ftran(col)
+            cand = np.nonzero(np.abs(w) > 0.1)[0]
+            if len(cand):
+                break
+        else:
+            break
+        p = int(cand[rng.integers(0, len(cand))])
+        out = int(pv[p])
+        rg = g.replaceColumn(p, q)
+        ro = o.replace_column(w, p, w[p])
+        basic.discard(out)
+        basic.add(q)
+        pv[p] = q
+        v = rng.standard_normal(lp.m)
+        e1 = rel(g.ftran(v), o.ftran(v))
+        e2 = rel(g.btran(v), o.btran(v))
+        kind = ("S" if out >= lp.n else "C") + "->" + ("S" if q >= lp.n else "C")
+        print(f"    update {t} out {kind} rc {rg}/{ro} alpha {w[p]:.3g}  ftran rel {e1:.2e} btran rel {e2:.2e}")
+        ok &= e1 < 1e-8 and e2 < 1e-8
+    return ok
+
+
+def compare_solve(lp, rule=1, max_iter=None, **opts):
+    o = OracleSimplex(lp)
+    o.set_option("pivot_rule", rule)
+    g = ClpGpuSimplex().loadProblem(lp)
+    g.set_option("pivot_rule", rule)
+    for k, v in opts.items():
+        o.set_option(k, v)
+        g.set_option(k, v)
+    if max_iter:
+        o.set_option("max_iterations", max_iter)
+        g.set_option("max_iterations", max_iter)
+    t0 = time.time()
+    so = o.dual()
+    t1 = time.time()
+    sg = g.dual()
+    t2 = time.time()
+    lo, lg = o.pivot_log(), g.pivotLog()
+    nn = min(len(lo), len(lg))
+    same = (lo["sequenceIn"][:nn] == lg["sequenceIn"][:nn]) & (lo["sequenceOut"][:nn] == lg["sequenceOut"][:nn])
+    first = int(np.argmin(same)) if not same.all() else -1
+    objrel = abs(o.objective - g.objectiveValue()) / (1.0 + abs(o.objective))
+    solrel = rel(g.solution(), o.solution())
+    print(f"  {lp.name:16s} rule {rule}: status {sg}/{so} iters {g.numberIterations()}/{o.iterations} "
+          f"obj {g.objectiveValue():.10g}/{o.objective:.10g} rel {objrel:.1e} sol rel {solrel:.1e} "
+          f"pivots identical {first < 0 and len(lo) == len(lg)} (first diff {first}) "
+          f"t gpu {t2 - t1:.2f}s cpu {t1 - t0:.2f}s it/s gpu {g.numberIterations() / max(t2 - t1, 1e-9):.0f}")
+    if first >= 0:
+        for i in range(max(0, first - 2), min(nn, first + 3)):
+            print("     ", i, "gpu", tuple(lg[i])[:5], f"{lg[i]['theta']:.6g} {lg[i]['alpha']:.6g}", "| cpu",
+                  tuple(lo[i])[:5], f"{lo[i]['theta']:.6g} {lo[i]['alpha']:.6g}")
+    return first < 0 and len(lo) == len(lg) and sg == so and objrel < 1e-8
+
+
+def main():
+    which = sys.argv[1:] or ["ops", "factor", "solve"]
+    afiro = read_mps(os.path.join(ROOT, "tests", "golden", "afiro.mps"))
+    small = P.sparse_lp(300, 1200, 8, seed=11)
+    dense = P.dense_lp(120, 150, seed=12)
+    results = {}
+    if "ops" in which:
+        for lp in (afiro, small, dense):
+            print(lp.name)
+            try:
+                check_matrix_ops(lp)
+                results[lp.name + ":price"] = check_price(lp)
+                results[lp.name + ":price-sparse"] = check_price(lp, seed=4, density=0.02)
+            except Exception:
+                traceback.print_exc()
+                results[lp.name + ":ops"] = False
+    if "factor" in which:
+        for lp, ks in ((afiro, (0, 5)), (small, (0, 40)), (dense, (30, 100))):
+            print(lp.name)
+            for k in ks:
+                try:
+                    results[f"{lp.name}:factor{k}"] = check_factor(lp, k)
+                except Exception:
+                    traceback.print_exc()
+                    results[f"{lp.name}:factor{k}"] = False
+    if "solve" in which:
+        cases = [(afiro, {}), (P.unit_test_3x5(), {}), (P.nqueens(8), {}), (dense, {}), (small, {}),
+                 (P.tsp_mtz(20, 42), {}), (P.ufl(10, 30, 99), {}), (P.infeasible(10), {})]
+        for lp, opts in cases:
+            for rule in (0, 1):
+                try:
+                    results[f"{lp.name}:dual{rule}"] = compare_solve(lp, rule, **opts)
+                except Exception:
+                    traceback.print_exc()
+                    results[f"{lp.name}:dual{rule}"] = False
+    if "big" in which:
+        lp = P.sparse_lp(5000, 20000, 20, seed=21)
+        results["sparse5k:dual1"] = compare_solve(lp, 1, max_iter=3000)
+        lp = P.dense_lp(1000, 1000, seed=22)
+        results["dense1k:dual1"] = compare_solve(lp, 1, max_iter=3000)
+    bad = [k for k, v in results.items() if not v]
+    print("SUMMARY:", len(results) - len(bad), "ok,", len(bad), "bad", bad)
+
+
+if __name__ == "__main__":
+    main()
