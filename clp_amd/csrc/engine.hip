@@ -1228,13 +1228,15 @@ int clpgpu_context::whileIterating(int stepTarget)
   }
   while (!rc) {
     evUsed = 0;
-    int itersBefore = hCtrl->numberIterations;
+    double launchesBefore = hCtrl->statPriceLaunches;
     for (int b = 0; b < checkEvery; b++)
       launchIteration();
     rc |= pullCtrl();
     if (timing) {
-      int done = hCtrl->numberIterations - itersBefore;
-      int timed = hCtrl->state == RUN ? evUsed : (done + 1 < evUsed ? done + 1 : evUsed);
+      // the device counts a pricing launch only while the loop is live; those are the first ones
+      int timed = (int)(hCtrl->statPriceLaunches - launchesBefore);
+      if (timed > evUsed)
+        timed = evUsed;
       for (int i = 0; i < timed; i++) {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, evStart[i], evStop[i]) == hipSuccess) {

@@ -1,0 +1,85 @@
+"""CPU tests of host-side logic: MPS reader, instance generators, column-range sharding."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from clp_amd import problems as P
+from clp_amd.mps import read_mps
+from clp_amd.sharding import column_ranges, merge_candidates
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_afiro_shape(afiro):
+    # Netlib AFIRO: 27 rows, 32 columns, 83 constraint nonzeros (SURVEY.md 8 header)
+    assert (afiro.m, afiro.n, len(afiro.elem)) == (27, 32, 83)
+    assert np.count_nonzero(afiro.obj) == 5
+    assert np.sum(afiro.row_lower == afiro.row_upper) == 8  # E rows
+
+
+def test_reference_example_mps_if_present():
+    path = "/root/reference/examples/hello.mps"
+    if not os.path.exists(path):
+        pytest.skip("reference tree not mounted (GPU box)")
+    lp = read_mps(path)
+    assert (lp.m, lp.n) == (21, 53)
+
+
+def test_generators_are_deterministic_and_sorted():
+    a, b = P.sparse_lp(200, 700, 6, seed=5), P.sparse_lp(200, 700, 6, seed=5)
+    assert np.array_equal(a.row, b.row) and np.array_equal(a.elem, b.elem)
+    for j in range(a.n):
+        r = a.row[a.col_start[j]:a.col_start[j + 1]]
+        assert np.all(np.diff(r) > 0)  # distinct, ascending
+    assert np.all(np.abs(a.elem) >= 0.05)
+    d = P.dense_lp(30, 40, seed=1)
+    assert len(d.elem) == 1200 and np.all(d.obj > 0)
+
+
+def test_synthetic_is_feasible_by_construction():
+    lp = P.sparse_lp(150, 500, 5, seed=8)
+    A = sp.csc_matrix((lp.elem, lp.row, lp.col_start), shape=(lp.m, lp.n))
+    mid = 0.5 * (lp.row_lower + lp.row_upper)
+    # some x in the box reaches the middle of every row range (least squares sanity)
+    assert np.all(lp.row_upper - lp.row_lower > 0)
+    assert np.all(lp.col_lower == 0)
+    assert A.shape == (150, 500) and np.isfinite(mid).all()
+
+
+def test_column_ranges_partition():
+    for n, r in ((200000, 8), (32, 3), (5, 8)):
+        rng = column_ranges(n, r)
+        assert rng[0][0] == 0 and rng[-1][1] == n
+        assert all(rng[i][1] == rng[i + 1][0] for i in range(r - 1))
+        sizes = [b - a for a, b in rng]
+        assert max(sizes) - min(sizes) <= 256 * r or n < 256 * r
+
+
+def test_merge_candidates_equals_unsharded(built):
+    """Rank-major concatenation of per-shard candidate lists + min of upperTheta reproduces the
+    single-shard result (reference reduce: src/ClpPackedMatrix.cpp:1848-1854)."""
+    from oracle.oracle import OracleSimplex
+
+    lp = P.sparse_lp(200, 900, 6, seed=4)
+    o = OracleSimplex(lp)
+    rng = np.random.default_rng(2)
+    m, n = lp.m, lp.n
+    idx = np.sort(rng.choice(m, 50, replace=False)).astype(np.int32)
+    val = rng.standard_normal(50)
+    status = rng.choice([1, 2, 3], size=n + m, p=[0.2, 0.3, 0.5]).astype(np.uint8)
+    dj = np.where((status & 3) == 2, -1.0, 1.0) * rng.uniform(0, 2, n + m)
+    full = o.price_row_fused(idx, val, status, dj)
+    parts = []
+    for r, (a, b) in enumerate(column_ranges(n, 4)):
+        st = status.copy()
+        st[:a] = 1  # columns outside the shard look basic -> skipped
+        st[b:n] = 1
+        if r:
+            st[n:] = 1  # the row (slack) part belongs to rank 0
+        parts.append(o.price_row_fused(idx, val, st, dj))
+    merged = merge_candidates(parts)
+    for k in range(4):
+        assert np.array_equal(merged[k], full[k])
+    assert merged[4] == full[4]
