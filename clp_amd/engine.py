@@ -58,6 +58,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(the HIP extension is the product; there is no CPU fallback)")
+        # PyTorch-ROCm bundles its own libamdhip64.so.7; two HIP runtimes in one process do not see the
+        # same devices.  Importing torch first makes the loader bind libclpgpu.so to the runtime torch
+        # already mapped (same SONAME), so torch.cuda / torch.distributed and the engine share it.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch is plumbing, not a dependency of the engine
+            pass
         L = C.CDLL(LIB_PATH)
         p = C.c_void_p
         ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
