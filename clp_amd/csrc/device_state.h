@@ -64,6 +64,9 @@ struct Ctrl {
   double bestPossible;
   double scratchSum;
   double statPriceBytes, statPriceLaunches;
+  // CHUZR hand-over between its three kernels
+  double chuzrTolerance;
+  int chuzrNumber, chuzrStart, chuzrLast, chuzrPad;
 };
 
 struct PivotRecord {  // == clpgpu_pivot_record
@@ -125,6 +128,18 @@ struct Dev {
   double *blockMin, *blockSum;
   int *flipSeq;
   int *appendFlag;  // [m]
+  // sliced-ELL copy of the priced column range: slice = 64 columns (one wave), entry t of the
+  // slice's lane l at sellStart[slice] + t*64 + l; columns sorted by length so padding is ~1%
+  const int *sellStart;  // [numSlices+1]
+  const int *sellCol;    // [numSlices*64] original column, -1 padding
+  const int *sellLen;    // [numSlices*64]
+  const int *sellRow;
+  const double *sellElem;
+  int numSlices;
+  double *sellMin, *sellBytes;  // per pricing workgroup
+  double *chzBest;
+  int *chzKey, *chzRow;
+  double *normPartial;
   // refactorization scratch
   double *workW, *workX;  // [kcap*ld]
   int *perm;

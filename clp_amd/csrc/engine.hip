@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <string>
 #include <vector>
@@ -63,6 +64,7 @@ struct clpgpu_context {
   int numberFake = 0, numberChanged = 0, numberTimesOptimal = 0, forceFactorization = -1, lastBadIteration = -999999;
   int lastCleaned = 0, factorType = 0;
   bool started = false, needStatus = true, weightsInitialized = false;
+  bool rebuildRowCopy = true;  // the device keeps the [basic|nonbasic] row partition current between refactorizations
   int pivots = 0, kNucleus = 0;
   // ---- device
   Dev D;
@@ -70,6 +72,10 @@ struct clpgpu_context {
   std::vector<void *> allocations;
   int kcap = 0, ld = 0;
   int *dKcol = nullptr, *dLocalOfRow = nullptr, *dInfo = nullptr;
+  int nSellBlocks = 0, nChzBlocks = 0, priceKernel = 1, useGraph = 1;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graphExec = nullptr;
+  int graphIterations = 0;
   int logCapacity = 0;
   // ---- stats
   clpgpu_stats stats;
@@ -136,6 +142,8 @@ struct clpgpu_context {
   int loadProblem(int m_, int n_, const int *cs, const int *ri, const double *el, const double *cl, const double *cu,
                   const double *ob, const double *rl, const double *ru);
   int allocNucleus(int kNeeded);
+  int buildSell();
+  void dropGraph();
   int pushCtrl();
   int pullCtrl();
   int pushRim();
@@ -153,6 +161,8 @@ struct clpgpu_context {
   int saveWeights(int mode);
   int statusOfProblemInDual(int type);
   int launchIteration();
+  int launchBatch();
+  bool capturing = false;
   int whileIterating(int stepTarget);
   int run(int maxSteps);
   void finish();
@@ -266,6 +276,11 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   rc |= dalloc(D.flipSeq, N);
   rc |= dalloc(D.appendFlag, m);
   rc |= dalloc(D.ctrl, 1);
+  nChzBlocks = cdiv(m, 256 * CHZ_ITEMS);
+  rc |= dalloc(D.chzBest, nChzBlocks);
+  rc |= dalloc(D.chzKey, nChzBlocks);
+  rc |= dalloc(D.chzRow, nChzBlocks);
+  rc |= dalloc(D.normPartial, cdiv(m, 256));
   rc |= dalloc(dLocalOfRow, m);
   rc |= dalloc(dInfo, 4);
   if (rc)
@@ -297,9 +312,93 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
     return -99;
   }
   memset(hCtrl, 0, sizeof(Ctrl));
+  rc |= buildSell();
   rc |= sync();
   started = false;
   return rc;
+}
+
+// Sliced-ELL copy of the priced column range (the coalescing-friendly layout of SURVEY.md 8f.2,
+// cf. ClpPackedMatrix3's blocks of equal-length columns, src/ClpPackedMatrix.cpp:6732-7235).
+// Columns are sorted by length (stable) so a 64-column slice is padded by ~1% only; the order of
+// the entries inside a column is untouched, so the summation order per column is the CSC order.
+int clpgpu_context::buildSell()
+{
+  const int first = D.firstColumn, last = D.lastColumn, count = last - first;
+  std::vector<int> order(count);
+  for (int i = 0; i < count; i++)
+    order[i] = first + i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    return (colStart[a + 1] - colStart[a]) > (colStart[b + 1] - colStart[b]);
+  });
+  const int numSlices = cdiv(count, 64);
+  std::vector<int> sellStart(numSlices + 1, 0), sellCol((size_t)numSlices * 64, -1), sellLen((size_t)numSlices * 64, 0);
+  for (int s = 0; s < numSlices; s++) {
+    int maxLen = 0;
+    for (int l = 0; l < 64; l++) {
+      int i = s * 64 + l;
+      if (i < count) {
+        int j = order[i];
+        sellCol[i] = j;
+        sellLen[i] = colStart[j + 1] - colStart[j];
+        maxLen = std::max(maxLen, sellLen[i]);
+      }
+    }
+    maxLen = (maxLen + SELL_U - 1) / SELL_U * SELL_U;
+    sellStart[s + 1] = sellStart[s] + maxLen * 64;
+  }
+  const size_t total = (size_t)sellStart[numSlices];
+  std::vector<int> sellRow(total ? total : 1, 0);
+  std::vector<double> sellElem(total ? total : 1, 0.0);
+  for (int s = 0; s < numSlices; s++)
+    for (int l = 0; l < 64; l++) {
+      int i = s * 64 + l;
+      if (i >= count)
+        continue;
+      int j = order[i];
+      size_t base = (size_t)sellStart[s] + l;
+      for (int p = colStart[j], t = 0; p < colStart[j + 1]; p++, t++) {
+        sellRow[base + (size_t)t * 64] = row[p];
+        sellElem[base + (size_t)t * 64] = elem[p];
+      }
+    }
+  int *dStart, *dCol, *dLen, *dRow;
+  double *dElem;
+  int rc = 0;
+  rc |= dalloc(dStart, numSlices + 1);
+  rc |= dalloc(dCol, (size_t)numSlices * 64);
+  rc |= dalloc(dLen, (size_t)numSlices * 64);
+  rc |= dalloc(dRow, sellRow.size());
+  rc |= dalloc(dElem, sellElem.size());
+  nSellBlocks = cdiv(numSlices, 4);
+  rc |= dalloc(D.sellMin, nSellBlocks);
+  rc |= dalloc(D.sellBytes, nSellBlocks);
+  if (rc)
+    return rc;
+  rc |= h2d(dStart, sellStart.data(), numSlices + 1);
+  rc |= h2d(dCol, sellCol.data(), sellCol.size());
+  rc |= h2d(dLen, sellLen.data(), sellLen.size());
+  rc |= h2d(dRow, sellRow.data(), sellRow.size());
+  rc |= h2d(dElem, sellElem.data(), sellElem.size());
+  rc |= sync();
+  D.sellStart = dStart;
+  D.sellCol = dCol;
+  D.sellLen = dLen;
+  D.sellRow = dRow;
+  D.sellElem = dElem;
+  D.numSlices = numSlices;
+  dropGraph();
+  return rc;
+}
+
+void clpgpu_context::dropGraph()
+{
+  if (graphExec)
+    (void)hipGraphExecDestroy(graphExec);
+  if (graph)
+    (void)hipGraphDestroy(graph);
+  graphExec = nullptr;
+  graph = nullptr;
 }
 
 int clpgpu_context::allocNucleus(int kNeeded)
@@ -330,6 +429,7 @@ int clpgpu_context::allocNucleus(int kNeeded)
   rc |= dalloc(D.rhoSlot, kcap);
   rc |= dalloc(D.perm, kcap);
   rc |= dalloc(dKcol, kcap);
+  dropGraph();
   return rc;
 }
 
@@ -454,30 +554,34 @@ int clpgpu_context::factorize()
     rc |= h2d(D.slotPos, slotPos.data(), k);
   }
   rc |= h2d(D.pivotVariable, pivotVariable.data(), m);
+  if (rebuildRowCopy) {
   // row copy partition [basic | nonbasic]: rebuilt on the host (refactorization boundary only)
-  {
-    std::vector<int> ccol(nnz), csrToCsc(nnz), cscToCsr(nnz), basicCount(m, 0);
-    std::vector<double> relem(nnz);
-    std::vector<int> head(rowStart.begin(), rowStart.end() - 1), tail(rowStart.begin() + 1, rowStart.end());
-    for (int j = 0; j < n; j++) {
-      bool basic = slotOfCol[j] >= 0;
-      for (int p = colStart[j]; p < colStart[j + 1]; p++) {
-        int i = row[p];
-        int q = basic ? head[i]++ : --tail[i];
-        ccol[q] = j;
-        relem[q] = elem[p];
-        csrToCsc[q] = p;
-        cscToCsr[p] = q;
-        if (basic)
-          basicCount[i]++;
+    {
+      std::vector<int> ccol(nnz), csrToCsc(nnz), cscToCsr(nnz), basicCount(m, 0);
+      std::vector<double> relem(nnz);
+      std::vector<int> head(rowStart.begin(), rowStart.end() - 1), tail(rowStart.begin() + 1, rowStart.end());
+      for (int j = 0; j < n; j++) {
+        bool basic = slotOfCol[j] >= 0;
+        for (int p = colStart[j]; p < colStart[j + 1]; p++) {
+          int i = row[p];
+          int q = basic ? head[i]++ : --tail[i];
+          ccol[q] = j;
+          relem[q] = elem[p];
+          csrToCsc[q] = p;
+          cscToCsr[p] = q;
+          if (basic)
+            basicCount[i]++;
+        }
       }
+      rc |= h2d(D.ccol, ccol.data(), nnz);
+      rc |= h2d(D.relem, relem.data(), nnz);
+      rc |= h2d(D.csrToCsc, csrToCsc.data(), nnz);
+      rc |= h2d(D.cscToCsr, cscToCsr.data(), nnz);
+      rc |= h2d(D.basicCount, basicCount.data(), m);
+      rc |= sync();
     }
-    rc |= h2d(D.ccol, ccol.data(), nnz);
-    rc |= h2d(D.relem, relem.data(), nnz);
-    rc |= h2d(D.csrToCsc, csrToCsc.data(), nnz);
-    rc |= h2d(D.cscToCsr, cscToCsr.data(), nnz);
-    rc |= h2d(D.basicCount, basicCount.data(), m);
-    rc |= sync();
+  
+  rebuildRowCopy = false;
   }
   kNucleus = k;
   pivots = 0;
@@ -534,18 +638,14 @@ int clpgpu_context::gutsOfSolution()
   hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, stream, D.vecV2, m);
   hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, stream, D.tau, m);
   hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, stream, D.x3, m);
-  // largestPrimalError: max |(A x - s)_i| over all rows (nonbasic + basic), i.e. B x_B - rhs
+  // largestPrimalError: max |(A x - s)_i| over all rows, reduced per block on the device
   {
-    std::vector<double> act(m, 0.0);
-    for (int j = 0; j < n; j++) {
-      double v = sol[j];
-      if (v != 0.0)
-        for (int p = colStart[j]; p < colStart[j + 1]; p++)
-          act[row[p]] += v * elem[p];
-    }
+    hipLaunchKernelGGL(k_primal_residual, dim3(g), dim3(256), 0, stream, D);
+    std::vector<double> part(g);
+    rc |= d2h(part.data(), D.normPartial, g);
     double largest = 0.0;
-    for (int i = 0; i < m; i++)
-      largest = fmax(largest, fabs(act[i] - sol[n + i]));
+    for (int b = 0; b < g; b++)
+      largest = fmax(largest, part[b]);
     largestPrimalError = largest;
   }
   // largestDualError: max over basics of |dj| (should be zero)
@@ -832,7 +932,7 @@ int clpgpu_context::saveWeights(int mode)
   hCtrl->numberInfeasible = 0;
   int rc = pushCtrl();
   hipLaunchKernelGGL(k_infeas_flags, dim3(g), dim3(256), 0, stream, D);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, g, 2, 0);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, g, 2, 0, 0);
   hipLaunchKernelGGL(k_append_scatter, dim3(g), dim3(256), 0, stream, D, 0, 0);
   hipLaunchKernelGGL(k_infeas_finish, dim3(1), dim3(1), 0, stream, D);
   rc |= pullCtrl();
@@ -913,6 +1013,7 @@ int clpgpu_context::startup()
     int rc = dalloc(D.log, logCapacity);
     if (rc)
       return rc;
+    dropGraph();
   }
   // control block
   memset(hCtrl, 0, sizeof(Ctrl));
@@ -933,6 +1034,7 @@ int clpgpu_context::startup()
   hCtrl->zeroTolerance = zeroTolerance;
   hCtrl->dualBound = dualBound;
   hCtrl->largeValue = largeValue;
+  rebuildRowCopy = true;
   int rc = pushCtrl();
   rc |= factorize();
   if (rc) {
@@ -1138,21 +1240,32 @@ int clpgpu_context::launchIteration()
   const int gm = cdiv(m, 256);
   const int kc = kcap;  // launch extents use the capacity; kernels read the live k from ctrl
   const int gk = cdiv(kc, 256);
+  const bool ev = timing && !capturing && evUsed < (int)evStart.size();
   // CHUZR
-  hipLaunchKernelGGL(k_chuzr, dim3(1), dim3(1024), 0, stream, D);
+  hipLaunchKernelGGL(k_chuzr_pre, dim3(1), dim3(64), 0, stream, D);
+  hipLaunchKernelGGL(k_chuzr_scan, dim3(nChzBlocks), dim3(256), 0, stream, D);
+  hipLaunchKernelGGL(k_chuzr_final, dim3(1), dim3(256), 0, stream, D, nChzBlocks);
   // BTRAN
   hipLaunchKernelGGL(k_btran_slack, dim3(gm), dim3(256), 0, stream, D, (const double *)D.vecC, D.rho, 1);
-  hipLaunchKernelGGL(k_btran_t, dim3(gk), dim3(256), 0, stream, D, (const double *)D.vecC, (const double *)D.rho, D.slotA, 1);
-  hipLaunchKernelGGL(k_gemvT_partial, dim3(gk, cdiv(kc, 64)), dim3(256), 0, stream, D, (const double *)D.slotA, 1);
+  hipLaunchKernelGGL(k_btran_t2, dim3(cdiv(kc, 4)), dim3(256), 0, stream, D, (const double *)D.vecC, (const double *)D.rho, D.slotA, 1);
+  hipLaunchKernelGGL(k_gemvT_partial2, dim3(gk, cdiv(kc, 64)), dim3(256), 0, stream, D, (const double *)D.slotA, 1);
   hipLaunchKernelGGL(k_gemvT_final, dim3(gk), dim3(256), 0, stream, D, D.rho, 1, 1);
-  hipLaunchKernelGGL(k_rho_finish, dim3(gm), dim3(256), 0, stream, D);
+  hipLaunchKernelGGL(k_rho_finish2, dim3(gm), dim3(256), 0, stream, D);
   // PRICE + first ratio pass
-  if (timing && evUsed < (int)evStart.size())
+  if (ev)
     (void)hipEventRecord(evStart[evUsed], stream);
-  hipLaunchKernelGGL(k_price, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
-  if (timing && evUsed < (int)evStart.size())
-    (void)hipEventRecord(evStop[evUsed++], stream);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1);
+  if (priceKernel == 1) {
+    hipLaunchKernelGGL(k_price_sell, dim3(nSellBlocks), dim3(256), 0, stream, D);
+    if (ev)
+      (void)hipEventRecord(evStop[evUsed++], stream);
+    hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1, nSellBlocks);
+  } else {
+    hipLaunchKernelGGL(k_price, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
+    if (ev)
+      (void)hipEventRecord(evStop[evUsed++], stream);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1, 0);
+  }
   hipLaunchKernelGGL(k_cand_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
   // CHUZC
   hipLaunchKernelGGL(k_dual_column, dim3(1), dim3(1024), 0, stream, D);
@@ -1164,11 +1277,11 @@ int clpgpu_context::launchIteration()
                      D.slotC, D.slotD, 1);
   hipLaunchKernelGGL(k_ftran_scatter, dim3(cdiv(m + kc, 256)), dim3(256), 0, stream, D, (const double *)D.vecV1,
                      (const double *)D.rho, (const double *)D.slotC, (const double *)D.slotD, D.w, D.tau, 1);
-  hipLaunchKernelGGL(k_norm_alpha, dim3(1), dim3(1024), 0, stream, D);
+  hipLaunchKernelGGL(k_norm_alpha2, dim3(1), dim3(256), 0, stream, D, gm);
   hipLaunchKernelGGL(k_weights, dim3(gm), dim3(256), 0, stream, D);
   // dual update, flips
   hipLaunchKernelGGL(k_dj_update, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 1, 1);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 1, 1, 0);
   hipLaunchKernelGGL(k_flip_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
   hipLaunchKernelGGL(k_flip_apply, dim3(1), dim3(256), 0, stream, D);
   // FTRAN of the flip rhs + primal update (all no-ops without flips)
@@ -1179,9 +1292,9 @@ int clpgpu_context::launchIteration()
   hipLaunchKernelGGL(k_ftran_scatter, dim3(cdiv(m + kc, 256)), dim3(256), 0, stream, D, (const double *)D.flipRhs,
                      (const double *)nullptr, (const double *)D.slotC, (const double *)nullptr, D.x3, (double *)nullptr, 2);
   hipLaunchKernelGGL(k_primal_update, dim3(gm), dim3(256), 0, stream, D, 1);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, gm, 2, 1);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, gm, 2, 1, 0);
   hipLaunchKernelGGL(k_append_scatter, dim3(gm), dim3(256), 0, stream, D, 1, 1);
-  hipLaunchKernelGGL(k_after_primal, dim3(1), dim3(1), 0, stream, D, gm, 1);
+  hipLaunchKernelGGL(k_after_primal2, dim3(1), dim3(256), 0, stream, D, gm, 1);
   hipLaunchKernelGGL(k_zero_if_flips, dim3(gm), dim3(256), 0, stream, D, D.flipRhs, m);
   hipLaunchKernelGGL(k_flip_bounds, dim3(32), dim3(256), 0, stream, D);
   // basis update of the nucleus inverse
@@ -1191,10 +1304,52 @@ int clpgpu_context::launchIteration()
   hipLaunchKernelGGL(k_rank1_fix2, dim3(gk), dim3(256), 0, stream, D);
   // primal update with the entering column
   hipLaunchKernelGGL(k_primal_update, dim3(gm), dim3(256), 0, stream, D, 0);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, gm, 2, 1);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, gm, 2, 1, 0);
   hipLaunchKernelGGL(k_append_scatter, dim3(gm), dim3(256), 0, stream, D, 0, 1);
-  hipLaunchKernelGGL(k_after_primal, dim3(1), dim3(1), 0, stream, D, gm, 0);
+  hipLaunchKernelGGL(k_after_primal2, dim3(1), dim3(256), 0, stream, D, gm, 0);
   hipLaunchKernelGGL(k_house, dim3(1), dim3(256), 0, stream, D);
+  return 0;
+}
+
+// `checkEvery` pivots as one hipGraph (the chain has no host-visible decisions), replayed until
+// the device control block leaves RUN.  Re-captured whenever a captured pointer or extent changes.
+int clpgpu_context::launchBatch()
+{
+  if (!useGraph || timing) {
+    for (int b = 0; b < checkEvery; b++)
+      launchIteration();
+    return 0;
+  }
+  if (!graphExec || graphIterations != checkEvery) {
+    dropGraph();
+    capturing = true;
+    evUsed = 0;
+    hipError_t e = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) {
+      for (int b = 0; b < checkEvery; b++)
+        launchIteration();
+      e = hipStreamEndCapture(stream, &graph);
+    }
+    capturing = false;
+    if (e == hipSuccess)
+      e = hipGraphInstantiate(&graphExec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      dropGraph();
+      useGraph = 0;  // fall back to eager launches of the same chain
+      for (int b = 0; b < checkEvery; b++)
+        launchIteration();
+      return 0;
+    }
+    graphIterations = checkEvery;
+  }
+  hipError_t e = hipGraphLaunch(graphExec, stream);
+  if (e != hipSuccess) {
+    setError("hipGraphLaunch failed: %s", hipGetErrorString(e));
+    return -99;
+  }
+  if (timing)
+    evUsed = checkEvery;  // the event-record nodes of every captured pivot were replayed
   return 0;
 }
 
@@ -1229,8 +1384,7 @@ int clpgpu_context::whileIterating(int stepTarget)
   while (!rc) {
     evUsed = 0;
     double launchesBefore = hCtrl->statPriceLaunches;
-    for (int b = 0; b < checkEvery; b++)
-      launchIteration();
+    rc |= launchBatch();
     rc |= pullCtrl();
     if (timing) {
       // the device counts a pricing launch only while the loop is live; those are the first ones
@@ -1468,8 +1622,14 @@ int clpgpu_context::priceRow(int numberPi, const int *piIndex, const double *piV
   const int nbCols = cdiv(D.lastColumn - D.firstColumn, PRICE_BLOCK);
   const int nb = nbRows + nbCols;
   hipLaunchKernelGGL(k_zero, dim3(cdiv(n, 256)), dim3(256), 0, stream, D.alphaCol, n);
-  hipLaunchKernelGGL(k_price, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1);
+  if (priceKernel == 1) {
+    hipLaunchKernelGGL(k_price_sell, dim3(nSellBlocks), dim3(256), 0, stream, D);
+    hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1, nSellBlocks);
+  } else {
+    hipLaunchKernelGGL(k_price, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1, 0);
+  }
   hipLaunchKernelGGL(k_cand_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
   rc |= pullCtrl();
   std::vector<double> alpha(n);
@@ -1527,6 +1687,7 @@ void clpgpu_destroy(clpgpu_context *ctx)
     return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  ctx->dropGraph();
   for (void *p : ctx->allocations)
     (void)hipFree(p);
   if (ctx->hCtrl)
@@ -1559,7 +1720,7 @@ int clpgpu_set_column_range(clpgpu_context *ctx, int firstColumn, int lastColumn
     return -1;
   ctx->D.firstColumn = firstColumn;
   ctx->D.lastColumn = lastColumn;
-  return 0;
+  return ctx->buildSell();
 }
 
 int clpgpu_times(clpgpu_context *ctx, double scalar, const double *x, double *y)
@@ -1611,6 +1772,7 @@ int clpgpu_factorize(clpgpu_context *ctx, const unsigned char *status, int *pivo
   if (!ctx)
     return -99;
   ctx->status.assign(status, status + ctx->N);
+  ctx->rebuildRowCopy = true;
   if (!ctx->hCtrl->zeroTolerance)
     ctx->hCtrl->zeroTolerance = ctx->zeroTolerance;
   int rc = ctx->pushCtrl();
@@ -1763,8 +1925,17 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "dual_tolerance")) ctx->dualTolerance = ctx->dualToleranceBase = v;
   else if (!strcmp(name, "random_seed")) ctx->seed = (unsigned int)v;
   else if (!strcmp(name, "log_level")) ctx->logLevel = (int)v;
-  else if (!strcmp(name, "check_every")) ctx->checkEvery = (int)v < 1 ? 1 : (int)v;
-  else if (!strcmp(name, "timing")) ctx->timing = (int)v;
+  else if (!strcmp(name, "check_every")) {
+    ctx->checkEvery = (int)v < 1 ? 1 : (int)v;
+    ctx->dropGraph();
+    for (auto &e : ctx->evStart) (void)hipEventDestroy(e);
+    for (auto &e : ctx->evStop) (void)hipEventDestroy(e);
+    ctx->evStart.clear();
+    ctx->evStop.clear();
+  }
+  else if (!strcmp(name, "timing")) { ctx->timing = (int)v; ctx->dropGraph(); }
+  else if (!strcmp(name, "price_kernel")) { ctx->priceKernel = (int)v; ctx->dropGraph(); }
+  else if (!strcmp(name, "use_graph")) { ctx->useGraph = (int)v; ctx->dropGraph(); }
   else return -1;
   return 0;
 }

@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_price(Dev D, int nbRows)
 
 // exclusive scan over per-block counts (<= 1M/256 blocks), min over per-block ratios
 // what: 0 candidates (-> numberCandidates, upperTheta), 1 flips, 2 infeasibility-list appends
-__global__ void __launch_bounds__(1024) k_scan_blocks(Dev D, int nb, int what, int iter)
+__global__ void __launch_bounds__(1024) k_scan_blocks(Dev D, int nb, int what, int iter, int nSell = 0)
 {
   Ctrl *c = D.ctrl;
   if (iter && c->state != RUN)
@@ -525,6 +525,10 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(Dev D, int nb, int what, i
     __syncthreads();
   }
   if (what == 0) {
+    for (int b = threadIdx.x; b < nSell; b += blockDim.x) {
+      vmin = fmin(vmin, D.sellMin[b]);
+      bytes += D.sellBytes[b];
+    }
     vmin = blockMin(vmin, shd);
     bytes = blockSum(bytes, shd);
   }
@@ -584,39 +588,110 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_cand_scatter(Dev D, int nbRows)
 // pass that moved it to a "swapped" list); sid[a] is the id of the swapped set held by list a.
 // List order (needed only for "first largest |alpha| wins", :4533) is candidate index order.
 // =============================================================================================
-struct DcReduce {
-  double thru, incr, bestPivot, upperTheta, sumBad;
+struct DcAcc {
+  double thru, incr, ut, sumBad, bestPivot;
   int bestIdx;
 };
+// one combined block reduction (sum, sum, min, sum, argmax-first) with a single LDS exchange
+__device__ inline void dcReduce(DcAcc &a, double (*shd)[16], int *shk)
+{
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int o = 32; o > 0; o >>= 1) {
+    a.thru += __shfl_down(a.thru, o);
+    a.incr += __shfl_down(a.incr, o);
+    a.sumBad += __shfl_down(a.sumBad, o);
+    a.ut = fmin(a.ut, __shfl_down(a.ut, o));
+    double ov = __shfl_down(a.bestPivot, o);
+    int ok = __shfl_down(a.bestIdx, o);
+    if (ok >= 0 && (a.bestIdx < 0 || ov > a.bestPivot || (ov == a.bestPivot && ok < a.bestIdx))) {
+      a.bestPivot = ov;
+      a.bestIdx = ok;
+    }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    shd[0][wv] = a.thru;
+    shd[1][wv] = a.incr;
+    shd[2][wv] = a.ut;
+    shd[3][wv] = a.sumBad;
+    shd[4][wv] = a.bestPivot;
+    shk[wv] = a.bestIdx;
+  }
+  __syncthreads();
+  a.thru = a.incr = a.sumBad = 0.0;
+  a.ut = shd[2][0];
+  a.bestPivot = shd[4][0];
+  a.bestIdx = shk[0];
+  for (int i = 0; i < nw; i++) {
+    a.thru += shd[0][i];
+    a.incr += shd[1][i];
+    a.sumBad += shd[3][i];
+    a.ut = fmin(a.ut, shd[2][i]);
+    if (i && shk[i] >= 0 && (a.bestIdx < 0 || shd[4][i] > a.bestPivot || (shd[4][i] == a.bestPivot && shk[i] < a.bestIdx))) {
+      a.bestPivot = shd[4][i];
+      a.bestIdx = shk[i];
+    }
+  }
+}
 
-__global__ void __launch_bounds__(1024) k_dual_column(Dev D)
+// CPT > 0: every thread keeps CPT candidates (alpha, dj, range, state) in registers, a pass is
+// pure ALU + one block reduction; CPT == 0: candidates stay in global memory (very long rows).
+template <int CPT> __device__ void dualColumnImpl(Dev D)
 {
   Ctrl *c = D.ctrl;
-  if (c->state != RUN)
-    return;
-  __shared__ double shA[16], shB[16], shC[16], shD[16], shE[16];
-  __shared__ int shK[16];
+  __shared__ double shd[5][16];
+  __shared__ int shk[16];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int nc = c->numberCandidates;
   const double acceptablePivot = c->acceptablePivot;
   const double dualTolerance = c->dualTolerance;
   const double newTolerance = dualTolerance;
   const double absDualOut = fabs(c->dualOut);
-  if (!nc) {
-    if (tid == 0) {
-      c->sequenceIn = -1;
-      c->alpha = 0.0;
-      c->bestPossible = 0.0;
-      c->state = EXIT_NO_INCOMING;
+  constexpr int R = CPT > 0 ? CPT : 1;
+  double ra[R], rd[R], rr[R];
+  int rt[R];
+  bool rl[R];
+  if constexpr (CPT > 0) {
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      int i = tid + q * nthr;
+      rl[q] = false;
+      rt[q] = -1;
+      ra[q] = rd[q] = rr[q] = 0.0;
+      if (i < nc) {
+        int seq = D.candSeq[i];
+        ra[q] = D.candAlpha[i];
+        rd[q] = D.dj[seq];
+        rr[q] = D.upper[seq] - D.lower[seq];
+        rl[q] = true;
+      }
     }
-    return;
+  } else {
+    for (int i = tid; i < nc; i += nthr) {
+      D.candLive[i] = 1;
+      D.candTag[i] = -1;
+    }
+    __syncthreads();
   }
-  for (int i = tid; i < nc; i += nthr) {
-    D.candLive[i] = 1;
-    D.candTag[i] = -1;
-  }
-  __syncthreads();
-  // all scalars are kept redundantly in every thread (all inputs come from block reductions)
+  auto forEach = [&](auto body) {
+    if constexpr (CPT > 0) {
+#pragma unroll
+      for (int q = 0; q < R; q++) {
+        int i = tid + q * nthr;
+        if (i < nc)
+          body(i, ra[q], rd[q], rr[q], rl[q], rt[q]);
+      }
+    } else {
+      for (int i = tid; i < nc; i += nthr) {
+        int seq = D.candSeq[i];
+        bool live = D.candLive[i] != 0;
+        int tag = D.candTag[i];
+        body(i, D.candAlpha[i], D.dj[seq], D.upper[seq] - D.lower[seq], live, tag);
+        D.candLive[i] = live ? 1 : 0;
+        D.candTag[i] = tag;
+      }
+    }
+  };
   double totalThru = 0.0, bestEverPivot = acceptablePivot, increaseInObjective = 0.0;
   int lastIdx = -1;
   double upperTheta = c->upperTheta;
@@ -624,55 +699,49 @@ __global__ void __launch_bounds__(1024) k_dual_column(Dev D)
   int iFlip = 0;
   int sid[2] = { -1, -1 };
   int passId = 0;
-  int seqIdx = -1;  // candidate index of sequenceIn_
+  int seqIdx = -1;
   double theta = 1.0e50;
   double tentativeTheta = fmax(10.0 * upperTheta, 1.0e-7);
   const double lastPivot = 0.0;  // never updated in the reference either (:4207)
   while (tentativeTheta < 1.0e22) {
     // ---- coarse pass (:4355-4417)
-    double thruThis = 0.0, increaseInThis = 0.0, bestPivot = acceptablePivot, ut = 1.0e50;
-    int bestIdx = -1;
-    for (int i = tid; i < nc; i += nthr) {
-      if (!D.candLive[i])
-        continue;
-      int iSequence = D.candSeq[i];
-      double alpha = D.candAlpha[i];
-      double oldValue = D.dj[iSequence];
+    DcAcc acc = { 0.0, 0.0, 1.0e50, 0.0, acceptablePivot, -1 };
+    forEach([&](int i, double alpha, double oldValue, double range, bool &live, int &tag) {
+      if (!live)
+        return;
       double value = oldValue - tentativeTheta * alpha;
       if (alpha < 0.0) {
         if (value > newTolerance) {
-          double range = D.upper[iSequence] - D.lower[iSequence];
-          thruThis -= range * alpha;
-          increaseInThis -= (oldValue + dualTolerance) * range;
-          D.candLive[i] = 0;
-          D.candTag[i] = passId;
-          if (fabs(alpha) > bestPivot) {
-            bestPivot = fabs(alpha);
-            bestIdx = i;
+          acc.thru -= range * alpha;
+          acc.incr -= (oldValue + dualTolerance) * range;
+          live = false;
+          tag = passId;
+          if (fabs(alpha) > acc.bestPivot) {
+            acc.bestPivot = fabs(alpha);
+            acc.bestIdx = i;
           }
         } else if (-alpha >= acceptablePivot) {
-          ut = fmin(ut, (oldValue - newTolerance) / alpha);
+          acc.ut = fmin(acc.ut, (oldValue - newTolerance) / alpha);
         }
       } else {
         if (value < -newTolerance) {
-          double range = D.upper[iSequence] - D.lower[iSequence];
-          thruThis += range * alpha;
-          increaseInThis += (oldValue - dualTolerance) * range;
-          D.candLive[i] = 0;
-          D.candTag[i] = passId;
-          if (fabs(alpha) > bestPivot) {
-            bestPivot = fabs(alpha);
-            bestIdx = i;
+          acc.thru += range * alpha;
+          acc.incr += (oldValue - dualTolerance) * range;
+          live = false;
+          tag = passId;
+          if (fabs(alpha) > acc.bestPivot) {
+            acc.bestPivot = fabs(alpha);
+            acc.bestIdx = i;
           }
         } else if (alpha >= acceptablePivot) {
-          ut = fmin(ut, (oldValue + newTolerance) / alpha);
+          acc.ut = fmin(acc.ut, (oldValue + newTolerance) / alpha);
         }
       }
-    }
-    thruThis = blockSum(thruThis, shA);
-    increaseInThis = blockSum(increaseInThis, shB);
-    upperTheta = blockMin(ut, shC);
-    blockArgMax(bestPivot, bestIdx, shD, shK);
+    });
+    dcReduce(acc, shd, shk);
+    double thruThis = acc.thru, increaseInThis = acc.incr, bestPivot = acc.bestPivot;
+    int bestIdx = acc.bestIdx;
+    upperTheta = acc.ut;
     if (bestIdx < 0)
       bestPivot = acceptablePivot;
     sid[1 - iFlip] = passId;
@@ -680,42 +749,33 @@ __global__ void __launch_bounds__(1024) k_dual_column(Dev D)
     check += 1.0e-8 + 1.0e-10 * check;
     if (check >= absDualOut || increaseInObjective + increaseInThis < 0.0) {
       // ---- pivot in this batch: the list becomes the swapped set of this pass (:4427-4434)
-      for (int i = tid; i < nc; i += nthr)
-        D.candLive[i] = (D.candTag[i] == passId) ? 1 : 0;
-      __syncthreads();
+      forEach([&](int, double, double, double, bool &live, int &tag) { live = (tag == passId); });
+      if constexpr (CPT == 0)
+        __syncthreads();
       int iTry;
       const int MAXTRY = 100;
       for (iTry = 0; iTry < MAXTRY; iTry++) {
         passId++;
-        ut = 1.0e50;
-        for (int i = tid; i < nc; i += nthr) {
-          if (!D.candLive[i])
-            continue;
-          int iSequence = D.candSeq[i];
-          double alpha = D.candAlpha[i];
-          double oldValue = D.dj[iSequence];
+        DcAcc a1 = { 0.0, 0.0, 1.0e50, 0.0, acceptablePivot, -1 };
+        forEach([&](int, double alpha, double oldValue, double, bool &live, int &) {
+          if (!live)
+            return;
           if (alpha < 0.0) {
             if (-alpha >= acceptablePivot)
-              ut = fmin(ut, (oldValue - newTolerance) / alpha);
+              a1.ut = fmin(a1.ut, (oldValue - newTolerance) / alpha);
           } else {
             if (alpha >= acceptablePivot)
-              ut = fmin(ut, (oldValue + newTolerance) / alpha);
+              a1.ut = fmin(a1.ut, (oldValue + newTolerance) / alpha);
           }
-        }
-        upperTheta = blockMin(ut, shC);
-        bestPivot = acceptablePivot;
-        bestIdx = -1;
-        double sumBadPivots = 0.0;
+        });
+        dcReduce(a1, shd, shk);
+        upperTheta = a1.ut;
         badSumPivots = 0;
         upperTheta *= 1.0000000001;
-        thruThis = 0.0;
-        increaseInThis = 0.0;
-        for (int i = tid; i < nc; i += nthr) {
-          if (!D.candLive[i])
-            continue;
-          int iSequence = D.candSeq[i];
-          double alpha = D.candAlpha[i];
-          double djv = D.dj[iSequence];
+        DcAcc a2 = { 0.0, 0.0, 1.0e50, 0.0, acceptablePivot, -1 };
+        forEach([&](int i, double alpha, double djv, double range, bool &live, int &tag) {
+          if (!live)
+            return;
           double value = djv - upperTheta * alpha;
           double badDj = 0.0;
           int addToSwapped = 0;
@@ -731,35 +791,32 @@ __global__ void __launch_bounds__(1024) k_dual_column(Dev D)
             }
           }
           if (addToSwapped) {
-            D.candLive[i] = 0;
-            D.candTag[i] = passId;
+            live = false;
+            tag = passId;
             double absAlpha = fabs(alpha);
-            if (absAlpha > bestPivot) {
-              bestPivot = absAlpha;
-              bestIdx = i;
+            if (absAlpha > a2.bestPivot) {
+              a2.bestPivot = absAlpha;
+              a2.bestIdx = i;
             }
             if (absAlpha < acceptablePivot && upperTheta < 1.0e20) {
               if (alpha < 0.0) {
-                if (value > dualTolerance) {
-                  double gap = D.upper[iSequence] - D.lower[iSequence];
-                  sumBadPivots += (gap < 1.0e20) ? value * gap : 1.0e20;
-                }
+                if (value > dualTolerance)
+                  a2.sumBad += (range < 1.0e20) ? value * range : 1.0e20;
               } else {
-                if (value < -dualTolerance) {
-                  double gap = D.upper[iSequence] - D.lower[iSequence];
-                  sumBadPivots += (gap < 1.0e20) ? -(value * gap) : 1.0e20;
-                }
+                if (value < -dualTolerance)
+                  a2.sumBad += (range < 1.0e20) ? -(value * range) : 1.0e20;
               }
             }
-            double range = D.upper[iSequence] - D.lower[iSequence];
-            thruThis += range * fabs(alpha);
-            increaseInThis += badDj * range;
+            a2.thru += range * fabs(alpha);
+            a2.incr += badDj * range;
           }
-        }
-        thruThis = blockSum(thruThis, shA);
-        increaseInThis = blockSum(increaseInThis, shB);
-        sumBadPivots = blockSum(sumBadPivots, shE);
-        blockArgMax(bestPivot, bestIdx, shD, shK);
+        });
+        dcReduce(a2, shd, shk);
+        thruThis = a2.thru;
+        increaseInThis = a2.incr;
+        bestPivot = a2.bestPivot;
+        bestIdx = a2.bestIdx;
+        double sumBadPivots = a2.sumBad;
         if (bestIdx < 0)
           bestPivot = acceptablePivot;
         seqIdx = bestIdx;
@@ -841,12 +898,10 @@ __global__ void __launch_bounds__(1024) k_dual_column(Dev D)
       const int sidFinal = sid[iFlip];
       int changed = 0;
       __syncthreads();
-      for (int i = tid; i < nc; i += nthr) {
-        if (D.candTag[i] != sidFinal)
-          continue;
+      forEach([&](int i, double alpha, double djv, double, bool &, int &tag) {
+        if (tag != sidFinal)
+          return;
         int iSequence = D.candSeq[i];
-        double alpha = D.candAlpha[i];
-        double djv = D.dj[iSequence];
         double value = djv - theta * alpha;
         if (alpha < 0.0) {
           if (value > dualTolerance) {
@@ -865,10 +920,11 @@ __global__ void __launch_bounds__(1024) k_dual_column(Dev D)
               changed++;
           }
         }
-      }
-      double ch = blockSum((double)changed, shA);
+      });
+      DcAcc a3 = { (double)changed, 0.0, 1.0e50, 0.0, 0.0, -1 };
+      dcReduce(a3, shd, shk);
       if (tid == 0)
-        c->numberChanged += (int)ch;
+        c->numberChanged += (int)a3.thru;
       __syncthreads();
     }
   }
@@ -910,7 +966,7 @@ __global__ void __launch_bounds__(1024) k_dual_column(Dev D)
       }
       c->lowerIn = lowerIn;
       c->upperIn = upperIn;
-      c->bestPossible = fabs(alphaIn);  // the |alpha|<1e-6 rescan (:4851) is done by the host on exit
+      c->bestPossible = fabs(alphaIn);
       c->btranAlpha = -alphaIn * c->directionOut;
     } else {
       c->sequenceIn = -1;
@@ -919,6 +975,28 @@ __global__ void __launch_bounds__(1024) k_dual_column(Dev D)
       c->state = EXIT_NO_INCOMING;
     }
   }
+}
+
+#define DC_CPT 4
+__global__ void __launch_bounds__(1024) k_dual_column(Dev D)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  const int nc = c->numberCandidates;
+  if (!nc) {
+    if (threadIdx.x == 0) {
+      c->sequenceIn = -1;
+      c->alpha = 0.0;
+      c->bestPossible = 0.0;
+      c->state = EXIT_NO_INCOMING;
+    }
+    return;
+  }
+  if (nc <= DC_CPT * (int)blockDim.x)
+    dualColumnImpl<DC_CPT>(D);
+  else
+    dualColumnImpl<0>(D);
 }
 
 // =============================================================================================
@@ -1670,6 +1748,552 @@ __global__ void __launch_bounds__(256) k_house(Dev D)
     c->state = EXIT_REFACTOR;  // nucleus storage nearly full: host regrows it at the refactorization
 }
 
+
+// =============================================================================================
+// v2 kernels (round 1, after the first rocprof pass: profiles/r01_bench_v1_kernel_stats.txt)
+// =============================================================================================
+
+// ---- CHUZR split in three so the list scan uses the whole chip ---------------------------------
+__global__ void k_chuzr_pre(Dev D)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  if (threadIdx.x != 0)
+    return;
+  if (c->stepLimit >= 0 && c->numberIterations >= c->stepLimit) {
+    c->state = EXIT_STEP_LIMIT;
+    return;
+  }
+  int last = c->pivotRow;  // model_->pivotRow(): persists across refactorizations
+  double tolerance = c->primalTolerance;
+  if (c->pivotRule) {
+    tolerance = tolerance + fmin(1.0e-2, c->largestPrimalError);
+    tolerance = fmin(1000.0, tolerance);
+    tolerance *= tolerance;
+    if (last >= 0 && last < D.m) {
+      int iPivot = D.pivotVariable[last];
+      double value = D.sol[iPivot], lower = D.lower[iPivot], upper = D.upper[iPivot];
+      if (value > upper + tolerance) {
+        value -= upper;
+        value *= value;
+        if (D.infeas[last] == 0.0)
+          D.infIndex[c->numberInfeasible++] = last;
+        D.infeas[last] = value;
+      } else if (value < lower - tolerance) {
+        value -= lower;
+        value *= value;
+        if (D.infeas[last] == 0.0)
+          D.infIndex[c->numberInfeasible++] = last;
+        D.infeas[last] = value;
+      } else if (D.infeas[last] != 0.0) {
+        D.infeas[last] = REALLY_TINY;
+      }
+    }
+    if (c->numberIterations < c->lastBadIteration + 200) {
+      if (c->largestDualError > c->largestPrimalError)
+        tolerance *= fmin(c->largestDualError / c->largestPrimalError, 1000.0);
+    }
+    int number = c->numberInfeasible;
+    double dstart = ((double)number) * randomDouble(c);
+    c->chuzrNumber = number;
+    c->chuzrStart = (int)dstart;
+  } else {
+    if (c->largestPrimalError > 1.0e-8)
+      tolerance *= c->largestPrimalError / 1.0e-8;
+    c->chuzrNumber = D.m;
+    c->chuzrStart = 0;
+  }
+  c->chuzrTolerance = tolerance;
+  c->chuzrLast = last;
+}
+
+#define CHZ_ITEMS 4
+__global__ void __launch_bounds__(256) k_chuzr_scan(Dev D)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ double shv[4];
+  __shared__ int shk[4], shr[4];
+  const double tolerance = c->chuzrTolerance;
+  const int number = c->chuzrNumber, start = c->chuzrStart, last = c->chuzrLast;
+  double best = 0.0;
+  int bestKey = -1, bestRow = -1;
+  const int base = blockIdx.x * (256 * CHZ_ITEMS);
+#pragma unroll
+  for (int q = 0; q < CHZ_ITEMS; q++) {
+    int i = base + q * 256 + threadIdx.x;
+    if (i >= number)
+      continue;
+    if (c->pivotRule) {
+      int iRow = D.infIndex[i];
+      double value = D.infeas[iRow];
+      if (value > tolerance) {
+        double weight = fmin(D.weights[iRow], 1.0e50);
+        if (iRow == last)
+          value *= 1.0e-10;
+        int iSequence = D.pivotVariable[iRow];
+        if (!(D.status[iSequence] & FLAGGED_BIT)) {
+          double s = D.sol[iSequence];
+          if (s > D.upper[iSequence] + tolerance || s < D.lower[iSequence] - tolerance) {
+            double ratio = value / weight;
+            int rank = i - start;
+            if (rank < 0)
+              rank += number;
+            if (ratio > best || (ratio == best && bestKey >= 0 && rank < bestKey)) {
+              best = ratio;
+              bestKey = rank;
+              bestRow = iRow;
+            }
+          }
+        }
+      }
+    } else {
+      int iSequence = D.pivotVariable[i];
+      double value = D.sol[iSequence];
+      double infeas = fmax(value - D.upper[iSequence], D.lower[iSequence] - value);
+      if (infeas > tolerance && !(D.status[iSequence] & FLAGGED_BIT)) {
+        if (infeas > best || (infeas == best && bestKey >= 0 && i < bestKey)) {
+          best = infeas;
+          bestKey = i;
+          bestRow = i;
+        }
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int o = 32; o > 0; o >>= 1) {
+    double ov = __shfl_down(best, o);
+    int ok = __shfl_down(bestKey, o);
+    int orow = __shfl_down(bestRow, o);
+    if (ok >= 0 && (bestKey < 0 || ov > best || (ov == best && ok < bestKey))) {
+      best = ov;
+      bestKey = ok;
+      bestRow = orow;
+    }
+  }
+  if (lane == 0) {
+    shv[wv] = best;
+    shk[wv] = bestKey;
+    shr[wv] = bestRow;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 4; i++)
+      if (shk[i] >= 0 && (bestKey < 0 || shv[i] > best || (shv[i] == best && shk[i] < bestKey))) {
+        best = shv[i];
+        bestKey = shk[i];
+        bestRow = shr[i];
+      }
+    D.chzBest[blockIdx.x] = best;
+    D.chzKey[blockIdx.x] = bestKey;
+    D.chzRow[blockIdx.x] = bestRow;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_chuzr_final(Dev D, int nblocks)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ double shv[4];
+  __shared__ int shk[4], shr[4];
+  double best = 0.0;
+  int bestKey = -1, bestRow = -1;
+  int used = (c->chuzrNumber + 256 * CHZ_ITEMS - 1) / (256 * CHZ_ITEMS);
+  if (used > nblocks)
+    used = nblocks;
+  for (int b = threadIdx.x; b < used; b += blockDim.x) {
+    double ov = D.chzBest[b];
+    int ok = D.chzKey[b];
+    if (ok >= 0 && (bestKey < 0 || ov > best || (ov == best && ok < bestKey))) {
+      best = ov;
+      bestKey = ok;
+      bestRow = D.chzRow[b];
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int o = 32; o > 0; o >>= 1) {
+    double ov = __shfl_down(best, o);
+    int ok = __shfl_down(bestKey, o);
+    int orow = __shfl_down(bestRow, o);
+    if (ok >= 0 && (bestKey < 0 || ov > best || (ov == best && ok < bestKey))) {
+      best = ov;
+      bestKey = ok;
+      bestRow = orow;
+    }
+  }
+  if (lane == 0) {
+    shv[wv] = best;
+    shk[wv] = bestKey;
+    shr[wv] = bestRow;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0)
+    return;
+  for (int i = 1; i < 4; i++)
+    if (shk[i] >= 0 && (bestKey < 0 || shv[i] > best || (shv[i] == best && shk[i] < bestKey))) {
+      best = shv[i];
+      bestKey = shk[i];
+      bestRow = shr[i];
+    }
+  int chosen = bestRow;
+  c->pivotRow = chosen;
+  if (chosen < 0) {
+    c->state = EXIT_NO_PIVOT_ROW;
+    return;
+  }
+  int seqOut = D.pivotVariable[chosen];
+  c->sequenceOut = seqOut;
+  double valueOut = D.sol[seqOut], lowerOut = D.lower[seqOut], upperOut = D.upper[seqOut];
+  c->valueOut = valueOut;
+  c->lowerOut = lowerOut;
+  c->upperOut = upperOut;
+  if (valueOut > upperOut) {
+    c->directionOut = -1;
+    c->dualOut = valueOut - upperOut;
+  } else if (valueOut < lowerOut) {
+    c->directionOut = 1;
+    c->dualOut = lowerOut - valueOut;
+  } else if (valueOut - lowerOut < upperOut - valueOut) {
+    c->directionOut = 1;
+    c->dualOut = lowerOut - valueOut;
+  } else {
+    c->directionOut = -1;
+    c->dualOut = valueOut - upperOut;
+  }
+  double acceptablePivot = 1.0e-1 * c->acceptablePivotBase;
+  if (c->numberIterations > 100)
+    acceptablePivot = c->acceptablePivotBase;
+  if (c->pivots > 10 || (c->pivots && c->saveSumDual != 0.0))
+    acceptablePivot = 1.0e+3 * c->acceptablePivotBase;
+  else if (c->pivots > 5)
+    acceptablePivot = 1.0e+2 * c->acceptablePivotBase;
+  else if (c->pivots)
+    acceptablePivot = c->acceptablePivotBase;
+  c->acceptablePivot = acceptablePivot;
+  D.vecC[chosen] = (double)c->directionOut;
+  c->sequenceIn = -1;
+  c->numberFlips = 0;
+  c->objectiveChange = 0.0;
+}
+
+// ---- BTRAN t-vector: one wave per nucleus column (the slack part of y has a single nonzero for
+// the unit-vector BTRAN of the iteration, so the lane-parallel sum is exact there) ----------------
+__global__ void __launch_bounds__(256) k_btran_t2(Dev D, const double *cvec, const double *y, double *t, int iter)
+{
+  if (iter && D.ctrl->state != RUN)
+    return;
+  const int k = D.ctrl->k;
+  const int lane = threadIdx.x & 63;
+  int sc = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (sc >= k)
+    return;
+  int col = D.slotCol[sc];
+  double acc = 0.0;
+  for (int p = D.colStart[col] + lane; p < D.colStart[col + 1]; p += 64) {
+    int r = D.row[p];
+    if (D.slotOfRow[r] < 0)
+      acc += y[r] * D.elem[p];
+  }
+  acc = waveSum(acc);
+  if (lane == 0)
+    t[sc] = cvec[D.slotPos[sc]] - acc;
+}
+
+// gemvT partial with 8 independent loads in flight per lane
+__global__ void k_gemvT_partial2(Dev D, const double *t, int iter)
+{
+  if (iter && D.ctrl->state != RUN)
+    return;
+  const int k = D.ctrl->k;
+  int sr = blockIdx.x * blockDim.x + threadIdx.x;
+  int chunk = blockIdx.y;
+  int sc0 = chunk * 64;
+  if (sc0 >= k || sr >= k)
+    return;
+  int sc1 = min(sc0 + 64, k);
+  double acc = 0.0;
+  const double *Mp = D.Minv + (size_t)sc0 * D.ld + sr;
+  int sc = sc0;
+  for (; sc + 8 <= sc1; sc += 8) {
+    double v0 = Mp[0], v1 = Mp[D.ld], v2 = Mp[2 * (size_t)D.ld], v3 = Mp[3 * (size_t)D.ld];
+    double v4 = Mp[4 * (size_t)D.ld], v5 = Mp[5 * (size_t)D.ld], v6 = Mp[6 * (size_t)D.ld], v7 = Mp[7 * (size_t)D.ld];
+    acc += v0 * t[sc];
+    acc += v1 * t[sc + 1];
+    acc += v2 * t[sc + 2];
+    acc += v3 * t[sc + 3];
+    acc += v4 * t[sc + 4];
+    acc += v5 * t[sc + 5];
+    acc += v6 * t[sc + 6];
+    acc += v7 * t[sc + 7];
+    Mp += 8 * (size_t)D.ld;
+  }
+  for (; sc < sc1; sc++) {
+    acc += *Mp * t[sc];
+    Mp += D.ld;
+  }
+  D.partial[(size_t)chunk * D.ld + sr] = acc;
+}
+
+// rho finish + per-block partial of sum rho^2 (DSE norm)
+__global__ void __launch_bounds__(256) k_rho_finish2(Dev D)
+{
+  if (D.ctrl->state != RUN)
+    return;
+  __shared__ double sh[16];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double sq = 0.0;
+  if (i < D.m) {
+    double v = D.rho[i];
+    if (fabs(v) <= D.ctrl->zeroTolerance)
+      v = 0.0;
+    D.rho[i] = v;
+    D.piNeg[i] = -v;
+    sq = v * v;
+  }
+  double s = blockSum(sq, sh);
+  if (threadIdx.x == 0)
+    D.normPartial[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_norm_alpha2(Dev D, int nb)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ double sh[16];
+  double acc = 0.0;
+  if (c->pivotRule)
+    for (int b = threadIdx.x; b < nb; b += blockDim.x)
+      acc += D.normPartial[b];
+  acc = blockSum(acc, sh);
+  if (threadIdx.x == 0) {
+    double alphaOld = c->alpha;
+    double norm = acc / (alphaOld * alphaOld);
+    c->norm = norm;
+    double alpha = D.w[c->pivotRow];
+    double btranAlpha = c->btranAlpha;
+    double checkValue = 1.0e-7;
+    if (c->largestPrimalError > 10.0)
+      checkValue = fmin(1.0e-4, 1.0e-8 * c->largestPrimalError);
+    c->scratchSum = 2.0 / alphaOld;
+    c->alpha = alpha;
+    if (fabs(btranAlpha) < 1.0e-12 || fabs(alpha) < 1.0e-12 || fabs(btranAlpha - alpha) > checkValue * (1.0 + fabs(alpha))) {
+      int bad = 1;
+      if (!c->pivots) {
+        double test;
+        if (fabs(btranAlpha) < 1.0e-8 || fabs(alpha) < 1.0e-8)
+          test = 1.0e-1 * fabs(alpha);
+        else
+          test = 1.0e-4 * (1.0 + fabs(alpha));
+        if (!(fabs(btranAlpha) < 1.0e-12 || fabs(alpha) < 1.0e-12 || fabs(btranAlpha - alpha) > test))
+          bad = 0;
+      }
+      if (bad)
+        c->state = EXIT_ALPHA_CHECK;
+    }
+  }
+}
+
+// parallel version of the scalar tail after a primal update
+__global__ void __launch_bounds__(256) k_after_primal2(Dev D, int nb, int which)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ double sh[16];
+  const bool active = !(which == 1 && c->numberFlips == 0);
+  double s = 0.0;
+  if (active)
+    for (int b = threadIdx.x; b < nb; b += blockDim.x)
+      s += D.blockSum[b];
+  s = blockSum(s, sh);
+  if (threadIdx.x != 0)
+    return;
+  if (active) {
+    c->objectiveChange += s;
+    c->numberInfeasible += c->numberAppend;
+    c->numberAppend = 0;
+    if (c->pivotRule) {
+      int iRow = c->pivotRow;
+      if (D.infeas[iRow] != 0.0)
+        D.infeas[iRow] = REALLY_TINY;
+    }
+  }
+  if (which == 1) {
+    double oldDualOut = c->dualOut;
+    if (c->numberFlips) {
+      c->valueOut = D.sol[c->sequenceOut];
+      if (c->directionOut < 0)
+        c->dualOut = c->valueOut - c->upperOut;
+      else
+        c->dualOut = c->lowerOut - c->valueOut;
+    }
+    double alpha = c->alpha;
+    c->movement = -c->dualOut * c->directionOut / alpha;
+    double movementOld = oldDualOut * c->directionOut / alpha;
+    if (c->objectiveChange + fabs(movementOld * c->dualIn) < -fmax(1.0e-5, 1.0e-12 * fabs(c->objectiveValue))) {
+      if (c->pivots) {
+        c->state = EXIT_BACKWARDS;
+        return;
+      }
+    }
+    if (fabs(alpha) < c->zeroTolerance || fabs(c->dualOut) > 1.0e50) {
+      c->state = EXIT_BAD_UPDATE;
+      return;
+    }
+    if (c->theta < 0.0)
+      c->theta = 0.0;
+    int seqIn = c->sequenceIn, seqOut = c->sequenceOut;
+    int inStruct = seqIn < D.n, outStruct = seqOut < D.n;
+    c->updateCase = outStruct ? (inStruct ? 0 : 2) : (inStruct ? 1 : 3);
+    c->slotColOut = outStruct ? D.slotOfCol[seqOut] : -1;
+    c->rowOfSlackOut = outStruct ? -1 : (seqOut - D.n);
+    c->slotRowIn = inStruct ? -1 : D.slotOfRow[seqIn - D.n];
+  }
+}
+
+// =============================================================================================
+// Row pricing, v2: sliced-ELL (SELL-64) sweep.  One wave owns a slice of 64 columns; entry t of
+// lane l sits at sellStart[slice] + 64*t + l, so every step is one fully coalesced 512 B (elements)
+// + 256 B (row indices) wave transaction, 8 steps in flight per lane.  Each lane still adds its own
+// column's products in ascending entry order: the result is bit-identical to the reference's scalar
+// loop (ClpPackedMatrix.cpp:1872-1886) and to the v1 kernel.  Fused first ratio pass as in v1.
+// =============================================================================================
+#define SELL_U 8
+__global__ void __launch_bounds__(256) k_price_sell(Dev D)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ double shd[16];
+  const double dualT = -c->dualTolerance;
+  const double acceptablePivot = c->acceptablePivot;
+  const double zeroTolerance = c->zeroTolerance;
+  const double tentativeTheta = 1.0e15;
+  const int lane = threadIdx.x & 63;
+  const int slice = blockIdx.x * 4 + (threadIdx.x >> 6);
+  double ratio = 1.0e31, bytes = 0.0;
+  if (slice < D.numSlices) {
+    const int idx = slice * 64 + lane;
+    const int j = D.sellCol[idx];
+    int len = 0, wanted = 0;
+    if (j >= 0) {
+      wanted = (D.status[j] & 3) - 1;
+      if (wanted)
+        len = D.sellLen[idx];
+    }
+    int maxLen = len;
+    for (int o = 32; o > 0; o >>= 1)
+      maxLen = max(maxLen, __shfl_xor(maxLen, o));
+    double value = 0.0;
+    if (maxLen > 0) {
+      const int start = D.sellStart[slice];
+      const int *rp = D.sellRow + start + lane;
+      const double *ep = D.sellElem + start + lane;
+      for (int t = 0; t < maxLen; t += SELL_U) {
+        int r[SELL_U];
+        double e[SELL_U], pv[SELL_U];
+#pragma unroll
+        for (int u = 0; u < SELL_U; u++) {
+          r[u] = rp[(t + u) * 64];
+          e[u] = ep[(t + u) * 64];
+        }
+#pragma unroll
+        for (int u = 0; u < SELL_U; u++)
+          pv[u] = D.piNeg[r[u]];
+#pragma unroll
+        for (int u = 0; u < SELL_U; u++)
+          if (t + u < len)
+            value += pv[u] * e[u];
+      }
+    }
+    if (j >= 0) {
+      int flag = 0;
+      if (wanted) {
+        bytes = 12.0 * len + 4.0;
+        if (fabs(value) > zeroTolerance) {
+          bytes += 20.0;
+          if (wanted > 0) {
+            double mult = (wanted == 1) ? -1.0 : 1.0;
+            double alpha = value * mult;
+            if (alpha > 0.0) {
+              double oldValue = D.dj[j] * mult;
+              double v2 = oldValue - tentativeTheta * alpha;
+              if (v2 < dualT) {
+                flag = 1;
+                if (alpha >= acceptablePivot)
+                  ratio = (oldValue - dualT) / alpha;
+              }
+            }
+          }
+        } else {
+          value = 0.0;
+        }
+      }
+      D.alphaCol[j] = value;
+      D.candFlag[D.m + j] = (unsigned char)flag;
+    }
+  }
+  double bmin = blockMin(ratio, shd);
+  double bsum = blockSum(bytes, shd);
+  if (threadIdx.x == 0) {
+    D.sellMin[blockIdx.x] = bmin;
+    D.sellBytes[blockIdx.x] = bsum;
+  }
+}
+
+// row (slack) part of the first ratio pass + per-key-block candidate counts for the ordered
+// compaction (columns were flagged by k_price_sell in slice order; counts must be in key order)
+__global__ void __launch_bounds__(PRICE_BLOCK) k_cand_count(Dev D, int nbRows)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ double shd[16];
+  __shared__ int shi[17];
+  int flag = 0;
+  double ratio = 1.0e31;
+  if ((int)blockIdx.x < nbRows) {
+    const double dualT = -c->dualTolerance;
+    int i = blockIdx.x * PRICE_BLOCK + threadIdx.x;
+    if (i < D.m) {
+      double value = D.rho[i];
+      if (value != 0.0) {
+        int iStatus = (D.status[D.n + i] & 3) - 1;
+        if (iStatus > 0) {
+          double mult = (iStatus == 1) ? -1.0 : 1.0;
+          double alpha = value * mult;
+          if (alpha > 0.0) {
+            double oldValue = D.dj[D.n + i] * mult;
+            double v2 = oldValue - 1.0e15 * alpha;
+            if (v2 < dualT) {
+              flag = 1;
+              if (alpha >= c->acceptablePivot)
+                ratio = (oldValue - dualT) / alpha;
+            }
+          }
+        }
+      }
+      D.candFlag[i] = (unsigned char)flag;
+    }
+  } else {
+    int j = D.firstColumn + ((int)blockIdx.x - nbRows) * PRICE_BLOCK + threadIdx.x;
+    if (j < D.lastColumn)
+      flag = D.candFlag[D.m + j];
+  }
+  int total;
+  blockRank(flag, total, shi);
+  double bmin = blockMin(ratio, shd);
+  if (threadIdx.x == 0) {
+    D.blockCount[blockIdx.x] = total;
+    D.blockMin[blockIdx.x] = bmin;
+    D.blockSum[blockIdx.x] = 0.0;
+  }
+}
+
 __global__ void k_zero(double *p, int n)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1847,6 +2471,23 @@ __global__ void k_primal_rhs(Dev D, double *rhs)
       acc += D.relem[q] * D.sol[D.ccol[q]];
     rhs[i] = -acc + D.sol[D.n + i];
   }
+}
+// max |(A x)_i - s_i| per block (largestPrimalError of computePrimals)
+__global__ void __launch_bounds__(256) k_primal_residual(Dev D)
+{
+  __shared__ double sh[16];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double r = 0.0;
+  if (i < D.m) {
+    double acc = 0.0;
+    for (int q = D.rowStart[i]; q < D.rowStart[i + 1]; q++)
+      acc += D.relem[q] * D.sol[D.ccol[q]];
+    r = fabs(acc - D.sol[D.n + i]);
+  }
+  // max via min of negatives
+  double mx = -blockMin(-r, sh);
+  if (threadIdx.x == 0)
+    D.normPartial[blockIdx.x] = mx;
 }
 __global__ void k_store_basic(Dev D, const double *x)
 {
