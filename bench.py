@@ -69,6 +69,11 @@ def main():
     eng = ClpGpuSimplex(local_rank).loadProblem(lp)
     eng.set_option("pivot_rule", args.pivot_rule)
     eng.set_option("check_every", args.check_every)
+    if os.environ.get("CLPGPU_PRICE_KERNEL"):
+        eng.set_option("price_kernel", int(os.environ["CLPGPU_PRICE_KERNEL"]))
+    for kv in filter(None, os.environ.get("CLPGPU_OPTS", "").split(",")):  # experiment knobs, e.g. max_pivots=475
+        key, val = kv.split("=")
+        eng.set_option(key, float(val))
     if distributed:
         from clp_amd.multigpu import attach_communicator
 

@@ -108,6 +108,7 @@ struct Dev {
   double *vecC;      // [m] BTRAN input by position
   double *rho;       // [m] BTRAN result by row, |.|<=zeroTolerance flushed (the packed pi)
   double *piNeg;     // [m] -rho (what the pricing kernel gathers)
+  unsigned long long *piBits;  // [(m+63)/64 + 4] bitmap of the nonzero rows of pi
   double *alphaCol;  // [n] tableau row, column part (0 where skipped)
   double *vecV1, *vecV2;  // [m] FTRAN inputs by row
   double *w, *tau, *x3;   // [m] FTRAN results by position

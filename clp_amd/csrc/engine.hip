@@ -72,7 +72,7 @@ struct clpgpu_context {
   std::vector<void *> allocations;
   int kcap = 0, ld = 0;
   int *dKcol = nullptr, *dLocalOfRow = nullptr, *dInfo = nullptr;
-  int nSellBlocks = 0, nChzBlocks = 0, priceKernel = 1, useGraph = 1;
+  int nSellBlocks = 0, nChzBlocks = 0, priceKernel = 2, useGraph = 1;
   hipGraph_t graph = nullptr;
   hipGraphExec_t graphExec = nullptr;
   int graphIterations = 0;
@@ -251,6 +251,7 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   rc |= dalloc(D.vecC, m);
   rc |= dalloc(D.rho, m);
   rc |= dalloc(D.piNeg, m);
+  rc |= dalloc(D.piBits, (size_t)(m + 63) / 64 + 8);
   rc |= dalloc(D.alphaCol, n);
   rc |= dalloc(D.vecV1, m);
   rc |= dalloc(D.vecV2, m);
@@ -513,9 +514,7 @@ int clpgpu_context::factorize()
     hipLaunchKernelGGL(k_identity, dim3(cdiv(k, 256)), dim3(256), 0, stream, D, k);
     dim3 g2(cdiv(k, 256), k < 1024 ? k : 1024);
     for (int i = 0; i < k; i++) {
-      hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(1024), 0, stream, D, i, k, dInfo);
-      hipLaunchKernelGGL(k_gj_swap, dim3(cdiv(k, 256)), dim3(256), 0, stream, D, i, k, dInfo);
-      hipLaunchKernelGGL(k_gj_mult, dim3(cdiv(k, 256)), dim3(256), 0, stream, D, i, k, dInfo);
+      hipLaunchKernelGGL(k_gj_step, dim3(1), dim3(1024), 0, stream, D, i, k, dInfo);
       hipLaunchKernelGGL(k_gj_elim, g2, dim3(256), 0, stream, D, i, k, dInfo);
     }
     hipLaunchKernelGGL(k_gj_finish, g2, dim3(256), 0, stream, D, k);
@@ -1246,16 +1245,14 @@ int clpgpu_context::launchIteration()
   hipLaunchKernelGGL(k_chuzr_scan, dim3(nChzBlocks), dim3(256), 0, stream, D);
   hipLaunchKernelGGL(k_chuzr_final, dim3(1), dim3(256), 0, stream, D, nChzBlocks);
   // BTRAN
-  hipLaunchKernelGGL(k_btran_slack, dim3(gm), dim3(256), 0, stream, D, (const double *)D.vecC, D.rho, 1);
-  hipLaunchKernelGGL(k_btran_t2, dim3(cdiv(kc, 4)), dim3(256), 0, stream, D, (const double *)D.vecC, (const double *)D.rho, D.slotA, 1);
+  hipLaunchKernelGGL(k_btran_t3, dim3(gk), dim3(256), 0, stream, D);
   hipLaunchKernelGGL(k_gemvT_partial2, dim3(gk, cdiv(kc, 64)), dim3(256), 0, stream, D, (const double *)D.slotA, 1);
-  hipLaunchKernelGGL(k_gemvT_final, dim3(gk), dim3(256), 0, stream, D, D.rho, 1, 1);
-  hipLaunchKernelGGL(k_rho_finish2, dim3(gm), dim3(256), 0, stream, D);
+  hipLaunchKernelGGL(k_rho_finish3, dim3(gm), dim3(256), 0, stream, D);
   // PRICE + first ratio pass
   if (ev)
     (void)hipEventRecord(evStart[evUsed], stream);
-  if (priceKernel == 1) {
-    hipLaunchKernelGGL(k_price_sell, dim3(nSellBlocks), dim3(256), 0, stream, D);
+  if (priceKernel >= 1) {
+    hipLaunchKernelGGL(k_price_sell, dim3(nSellBlocks), dim3(256), (m > 64 * SELL_BITS_MAX || priceKernel < 2) ? 0 : (size_t)((m + 63) / 64) * 8, stream, D, (m > 64 * SELL_BITS_MAX && priceKernel > 1) ? 1 : priceKernel);
     if (ev)
       (void)hipEventRecord(evStop[evUsed++], stream);
     hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
@@ -1268,9 +1265,9 @@ int clpgpu_context::launchIteration()
   }
   hipLaunchKernelGGL(k_cand_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
   // CHUZC
+  hipLaunchKernelGGL(k_dual_column_small, dim3(1), dim3(64), 0, stream, D);
   hipLaunchKernelGGL(k_dual_column, dim3(1), dim3(1024), 0, stream, D);
   // FTRAN of the entering column and of rho (DSE)
-  hipLaunchKernelGGL(k_unpack_in, dim3(1), dim3(256), 0, stream, D);
   hipLaunchKernelGGL(k_ftran_gather, dim3(gk), dim3(256), 0, stream, D, (const double *)D.vecV1, (const double *)D.rho, D.slotA,
                      D.slotB, 1);
   hipLaunchKernelGGL(k_gemv2, dim3(cdiv(kc, 4)), dim3(256), 0, stream, D, (const double *)D.slotA, (const double *)D.slotB,
@@ -1283,7 +1280,7 @@ int clpgpu_context::launchIteration()
   hipLaunchKernelGGL(k_dj_update, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
   hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 1, 1, 0);
   hipLaunchKernelGGL(k_flip_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
-  hipLaunchKernelGGL(k_flip_apply, dim3(1), dim3(256), 0, stream, D);
+  hipLaunchKernelGGL(k_flip_apply, dim3(1), dim3(64), 0, stream, D);
   // FTRAN of the flip rhs + primal update (all no-ops without flips)
   hipLaunchKernelGGL(k_ftran_gather, dim3(gk), dim3(256), 0, stream, D, (const double *)D.flipRhs, (const double *)nullptr,
                      D.slotA, (double *)nullptr, 2);
@@ -1295,10 +1292,7 @@ int clpgpu_context::launchIteration()
   hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, gm, 2, 1, 0);
   hipLaunchKernelGGL(k_append_scatter, dim3(gm), dim3(256), 0, stream, D, 1, 1);
   hipLaunchKernelGGL(k_after_primal2, dim3(1), dim3(256), 0, stream, D, gm, 1);
-  hipLaunchKernelGGL(k_zero_if_flips, dim3(gm), dim3(256), 0, stream, D, D.flipRhs, m);
-  hipLaunchKernelGGL(k_flip_bounds, dim3(32), dim3(256), 0, stream, D);
   // basis update of the nucleus inverse
-  hipLaunchKernelGGL(k_update_vectors, dim3(gk), dim3(256), 0, stream, D);
   hipLaunchKernelGGL(k_rank1, dim3(cdiv(kc, 256), kc < 512 ? kc : 512), dim3(256), 0, stream, D);
   hipLaunchKernelGGL(k_rank1_fix, dim3(cdiv(kc + 1, 256)), dim3(256), 0, stream, D);
   hipLaunchKernelGGL(k_rank1_fix2, dim3(gk), dim3(256), 0, stream, D);
@@ -1622,8 +1616,8 @@ int clpgpu_context::priceRow(int numberPi, const int *piIndex, const double *piV
   const int nbCols = cdiv(D.lastColumn - D.firstColumn, PRICE_BLOCK);
   const int nb = nbRows + nbCols;
   hipLaunchKernelGGL(k_zero, dim3(cdiv(n, 256)), dim3(256), 0, stream, D.alphaCol, n);
-  if (priceKernel == 1) {
-    hipLaunchKernelGGL(k_price_sell, dim3(nSellBlocks), dim3(256), 0, stream, D);
+  if (priceKernel >= 1) {
+    hipLaunchKernelGGL(k_price_sell, dim3(nSellBlocks), dim3(256), 0, stream, D, 1);
     hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1, nSellBlocks);
   } else {
@@ -1895,7 +1889,6 @@ int clpgpu_replace_column(clpgpu_context *ctx, int pivotRow, int sequenceIn, dou
   h->maximumPivots = ctx->maximumPivots;
   h->logCapacity = 0;
   rc |= ctx->pushCtrl();
-  hipLaunchKernelGGL(k_update_vectors, dim3(gk), dim3(256), 0, s, D);
   hipLaunchKernelGGL(k_rank1, dim3(cdiv(kc, 256), kc < 512 ? kc : 512), dim3(256), 0, s, D);
   hipLaunchKernelGGL(k_rank1_fix, dim3(cdiv(kc + 1, 256)), dim3(256), 0, s, D);
   hipLaunchKernelGGL(k_rank1_fix2, dim3(gk), dim3(256), 0, s, D);

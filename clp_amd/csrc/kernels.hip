@@ -636,17 +636,46 @@ __device__ inline void dcReduce(DcAcc &a, double (*shd)[16], int *shk)
 
 // CPT > 0: every thread keeps CPT candidates (alpha, dj, range, state) in registers, a pass is
 // pure ALU + one block reduction; CPT == 0: candidates stay in global memory (very long rows).
-template <int CPT> __device__ void dualColumnImpl(Dev D)
+// all-lanes result of the combined reduction inside one wave (no LDS, no barrier)
+__device__ inline void dcReduceWave(DcAcc &a)
+{
+  for (int o = 32; o > 0; o >>= 1) {
+    a.thru += __shfl_down(a.thru, o);
+    a.incr += __shfl_down(a.incr, o);
+    a.sumBad += __shfl_down(a.sumBad, o);
+    a.ut = fmin(a.ut, __shfl_down(a.ut, o));
+    double ov = __shfl_down(a.bestPivot, o);
+    int ok = __shfl_down(a.bestIdx, o);
+    if (ok >= 0 && (a.bestIdx < 0 || ov > a.bestPivot || (ov == a.bestPivot && ok < a.bestIdx))) {
+      a.bestPivot = ov;
+      a.bestIdx = ok;
+    }
+  }
+  a.thru = __shfl(a.thru, 0);
+  a.incr = __shfl(a.incr, 0);
+  a.sumBad = __shfl(a.sumBad, 0);
+  a.ut = __shfl(a.ut, 0);
+  a.bestPivot = __shfl(a.bestPivot, 0);
+  a.bestIdx = __shfl(a.bestIdx, 0);
+}
+
+template <int CPT, bool ONEWAVE> __device__ void dualColumnImpl(Dev D)
 {
   Ctrl *c = D.ctrl;
   __shared__ double shd[5][16];
   __shared__ int shk[16];
-  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int tid = threadIdx.x, nthr = ONEWAVE ? 64 : blockDim.x;
   const int nc = c->numberCandidates;
   const double acceptablePivot = c->acceptablePivot;
   const double dualTolerance = c->dualTolerance;
   const double newTolerance = dualTolerance;
   const double absDualOut = fabs(c->dualOut);
+  auto reduce = [&](DcAcc &a) {
+    if constexpr (ONEWAVE)
+      dcReduceWave(a);
+    else
+      dcReduce(a, shd, shk);
+  };
   constexpr int R = CPT > 0 ? CPT : 1;
   double ra[R], rd[R], rr[R];
   int rt[R];
@@ -738,7 +767,7 @@ template <int CPT> __device__ void dualColumnImpl(Dev D)
         }
       }
     });
-    dcReduce(acc, shd, shk);
+    reduce(acc);
     double thruThis = acc.thru, increaseInThis = acc.incr, bestPivot = acc.bestPivot;
     int bestIdx = acc.bestIdx;
     upperTheta = acc.ut;
@@ -768,7 +797,7 @@ template <int CPT> __device__ void dualColumnImpl(Dev D)
               a1.ut = fmin(a1.ut, (oldValue + newTolerance) / alpha);
           }
         });
-        dcReduce(a1, shd, shk);
+        reduce(a1);
         upperTheta = a1.ut;
         badSumPivots = 0;
         upperTheta *= 1.0000000001;
@@ -811,7 +840,7 @@ template <int CPT> __device__ void dualColumnImpl(Dev D)
             a2.incr += badDj * range;
           }
         });
-        dcReduce(a2, shd, shk);
+        reduce(a2);
         thruThis = a2.thru;
         increaseInThis = a2.incr;
         bestPivot = a2.bestPivot;
@@ -897,7 +926,6 @@ template <int CPT> __device__ void dualColumnImpl(Dev D)
       // cost shifting so everything that went through stays dual feasible (:4705-4772)
       const int sidFinal = sid[iFlip];
       int changed = 0;
-      __syncthreads();
       forEach([&](int i, double alpha, double djv, double, bool &, int &tag) {
         if (tag != sidFinal)
           return;
@@ -922,16 +950,22 @@ template <int CPT> __device__ void dualColumnImpl(Dev D)
         }
       });
       DcAcc a3 = { (double)changed, 0.0, 1.0e50, 0.0, 0.0, -1 };
-      dcReduce(a3, shd, shk);
+      reduce(a3);
       if (tid == 0)
         c->numberChanged += (int)a3.thru;
-      __syncthreads();
     }
   }
   if (badSumPivots && c->pivots) {
     sequenceIn = -1;
     if (tid == 0)
       c->acceptablePivotBase = -c->acceptablePivotBase;
+  }
+  if (sequenceIn >= D.n) {
+    if (tid == 0)
+      D.vecV1[sequenceIn - D.n] = -1.0;
+  } else if (sequenceIn >= 0) {
+    for (int p = D.colStart[sequenceIn] + tid; p < D.colStart[sequenceIn + 1]; p += nthr)
+      D.vecV1[D.row[p]] = D.elem[p];
   }
   if (tid == 0) {
     c->badSumPivots = badSumPivots;
@@ -978,7 +1012,9 @@ template <int CPT> __device__ void dualColumnImpl(Dev D)
 }
 
 #define DC_CPT 4
-__global__ void __launch_bounds__(1024) k_dual_column(Dev D)
+#define DC_SMALL (8 * 64)
+// typical sparse tableau row: one wave, candidates in registers, shuffle-only reductions
+__global__ void __launch_bounds__(64) k_dual_column_small(Dev D)
 {
   Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -993,10 +1029,22 @@ __global__ void __launch_bounds__(1024) k_dual_column(Dev D)
     }
     return;
   }
-  if (nc <= DC_CPT * (int)blockDim.x)
-    dualColumnImpl<DC_CPT>(D);
-  else
-    dualColumnImpl<0>(D);
+  if (nc <= DC_SMALL)
+    dualColumnImpl<8, true>(D);
+}
+__global__ void __launch_bounds__(1024) k_dual_column(Dev D)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  const int nc = c->numberCandidates;
+  if (nc <= DC_SMALL)
+    return;  // handled (or rejected) by k_dual_column_small
+  if (nc <= DC_CPT * (int)blockDim.x) {
+    dualColumnImpl<DC_CPT, false>(D);
+  } else {
+    dualColumnImpl<0, false>(D);
+  }
 }
 
 // =============================================================================================
@@ -1339,6 +1387,22 @@ __global__ void __launch_bounds__(256) k_primal_update(Dev D, int which)
   const double ratio = which ? 1.0 : c->movement;
   const double tolerance = c->primalTolerance;
   int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (which == 0) {
+    // ClpSimplexDual::flipBounds (:6345-6401), after the backwards check of the scalar block
+    for (int f = p; f < c->numberFlips; f += gridDim.x * blockDim.x) {
+      int seq = D.flipSeq[f];
+      int st = D.status[seq] & 7;
+      if (st == ST_UPPER) {
+        D.status[seq] = (unsigned char)((D.status[seq] & ~7) | ST_LOWER);
+        D.sol[seq] = D.lower[seq];
+      } else if (st == ST_LOWER) {
+        D.status[seq] = (unsigned char)((D.status[seq] & ~7) | ST_UPPER);
+        D.sol[seq] = D.upper[seq];
+      }
+    }
+  } else if (p < D.m) {
+    D.flipRhs[p] = 0.0;  // consumed by the flip FTRAN
+  }
   double changeObj = 0.0;
   int append = 0;
   if (p < D.m) {
@@ -1481,14 +1545,15 @@ __global__ void __launch_bounds__(256) k_rank1(Dev D)
   if (c->state != RUN)
     return;
   const int k = c->k;
-  // 2D tiling: blockIdx.y strides rows, x strides columns (coalesced along the row)
-  for (int i = blockIdx.y; i < k; i += gridDim.y) {
-    double wi = D.slotE[i];
-    if (wi == 0.0)
-      continue;
-    double *Mrow = D.Minv + (size_t)i * D.ld;
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < k; j += gridDim.x * blockDim.x)
-      Mrow[j] -= wi * D.slotF[j];
+  const double dir = (double)c->directionOut, alpha = c->alpha;
+  // blockIdx.x * 256 + thread = column j (coalesced along the row), blockIdx.y strides rows
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < k; j += gridDim.x * blockDim.x) {
+    const double gj = dir * D.rhoSlot[j] / alpha;
+    for (int i = blockIdx.y; i < k; i += gridDim.y) {
+      double wi = D.w[D.slotPos[i]];
+      if (wi != 0.0)
+        D.Minv[(size_t)i * D.ld + j] -= wi * gj;
+    }
   }
 }
 
@@ -1501,14 +1566,19 @@ __global__ void k_rank1_fix(Dev D)
   const int ucase = c->updateCase;
   const double alpha = c->alpha;
   int s = blockIdx.x * blockDim.x + threadIdx.x;
+  double slotFs = 0.0, slotEs = 0.0;
+  if (s < k) {
+    slotFs = ((double)c->directionOut) * D.rhoSlot[s] / alpha;  // g by row-slot
+    slotEs = D.w[D.slotPos[s]];                                  // w by col-slot
+  }
   if (ucase == 0) {
     int a = c->slotColOut;
     if (s < k)
-      D.Minv[(size_t)a * D.ld + s] = D.slotF[s];
+      D.Minv[(size_t)a * D.ld + s] = slotFs;
   } else if (ucase == 1) {
     if (s < k) {
-      D.Minv[(size_t)k * D.ld + s] = D.slotF[s];
-      D.Minv[(size_t)s * D.ld + k] = D.slotE[s] / alpha;
+      D.Minv[(size_t)k * D.ld + s] = slotFs;
+      D.Minv[(size_t)s * D.ld + k] = slotEs / alpha;
     } else if (s == k) {
       D.Minv[(size_t)k * D.ld + k] = -1.0 / alpha;
     }
@@ -1524,7 +1594,7 @@ __global__ void k_rank1_fix(Dev D)
   } else {
     int b = c->slotRowIn;
     if (s < k)
-      D.Minv[(size_t)s * D.ld + b] = D.slotE[s] / alpha;
+      D.Minv[(size_t)s * D.ld + b] = slotEs / alpha;
   }
 }
 // second half of the delete: copy matrix row `last` over row a (after the column move)
@@ -2002,6 +2072,73 @@ __global__ void __launch_bounds__(256) k_btran_t2(Dev D, const double *cvec, con
     t[sc] = cvec[D.slotPos[sc]] - acc;
 }
 
+// iteration BTRAN, t-vector: the input is dir*e_p, so y_S has at most one nonzero (row of the
+// leaving slack) and t follows analytically -- no pass over the slack rows needed.
+__global__ void k_btran_t3(Dev D)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  int sc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sc >= c->k)
+    return;
+  const double dir = (double)c->directionOut;
+  const int seqOut = c->sequenceOut;
+  double value = 0.0;
+  if (seqOut < D.n) {
+    if (D.slotOfCol[seqOut] == sc)
+      value = dir;
+  } else {
+    const int rOut = seqOut - D.n;
+    const double y = dir * -1.0;  // y_rOut = -c[pos]
+    const int col = D.slotCol[sc];
+    const int s = D.rowStart[rOut], e = s + D.basicCount[rOut];
+    for (int q = s; q < e; q++)
+      if (D.ccol[q] == col)
+        value -= y * D.relem[q];
+  }
+  D.slotA[sc] = value;
+}
+
+// iteration BTRAN, back end: rho[i] = slack part or sum of the gemvT partials, flush tiny, piNeg,
+// rhoSlot (unpruned, for the nucleus update) and the per-block partial of sum rho^2 (DSE norm)
+__global__ void __launch_bounds__(256) k_rho_finish3(Dev D)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ double sh[16];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double sq = 0.0;
+  if (i < D.m) {
+    double v;
+    int sr = D.slotOfRow[i];
+    if (sr >= 0) {
+      const int k = c->k;
+      int nchunk = (k + 63) >> 6;
+      v = 0.0;
+      for (int ch = 0; ch < nchunk; ch++)
+        v += D.partial[(size_t)ch * D.ld + sr];
+      D.rhoSlot[sr] = v;
+    } else {
+      int p = D.posOfSlack[i];
+      v = (p >= 0) ? D.vecC[p] * -1.0 : 0.0;
+    }
+    if (fabs(v) <= c->zeroTolerance)
+      v = 0.0;
+    D.rho[i] = v;
+    D.piNeg[i] = -v;
+    sq = v * v;
+  }
+  // bitmap of the nonzero rows of pi, one 64-bit word per wave (the pricing kernel keeps it in LDS)
+  unsigned long long mask = __ballot(sq != 0.0);
+  if ((threadIdx.x & 63) == 0 && i < D.m + 63)
+    D.piBits[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = mask;
+  double s = blockSum(sq, sh);
+  if (threadIdx.x == 0)
+    D.normPartial[blockIdx.x] = s;
+}
+
 // gemvT partial with 8 independent loads in flight per lane
 __global__ void k_gemvT_partial2(Dev D, const double *t, int iter)
 {
@@ -2163,11 +2300,12 @@ __global__ void __launch_bounds__(256) k_after_primal2(Dev D, int nb, int which)
 // loop (ClpPackedMatrix.cpp:1872-1886) and to the v1 kernel.  Fused first ratio pass as in v1.
 // =============================================================================================
 #define SELL_U 8
-__global__ void __launch_bounds__(256) k_price_sell(Dev D)
+#define SELL_BITS_MAX 8192  // 64-bit words of the pi bitmap kept in LDS (rows <= 524288)
+// PIPE: software-pipelined loads; NT: non-temporal matrix loads; BITS: gather pi only where the
+// row's bit is set (pi is sparse for most pivots: the gather traffic scales with nnz(pi)/m)
+template <bool PIPE, bool NT, bool BITS> __device__ inline void priceSellBody(Dev D, unsigned long long *bits)
 {
   const Ctrl *c = D.ctrl;
-  if (c->state != RUN)
-    return;
   __shared__ double shd[16];
   const double dualT = -c->dualTolerance;
   const double acceptablePivot = c->acceptablePivot;
@@ -2175,6 +2313,19 @@ __global__ void __launch_bounds__(256) k_price_sell(Dev D)
   const double tentativeTheta = 1.0e15;
   const int lane = threadIdx.x & 63;
   const int slice = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwords = (D.m + 63) >> 6;
+  if (BITS) {
+    for (int w = threadIdx.x; w < nwords; w += blockDim.x)
+      bits[w] = D.piBits[w];
+    __syncthreads();
+  }
+  auto piAt = [&](int r) -> double {
+    if (BITS) {
+      return ((bits[r >> 6] >> (r & 63)) & 1ull) ? D.piNeg[r] : 0.0;
+    } else {
+      return D.piNeg[r];
+    }
+  };
   double ratio = 1.0e31, bytes = 0.0;
   if (slice < D.numSlices) {
     const int idx = slice * 64 + lane;
@@ -2193,21 +2344,57 @@ __global__ void __launch_bounds__(256) k_price_sell(Dev D)
       const int start = D.sellStart[slice];
       const int *rp = D.sellRow + start + lane;
       const double *ep = D.sellElem + start + lane;
-      for (int t = 0; t < maxLen; t += SELL_U) {
-        int r[SELL_U];
-        double e[SELL_U], pv[SELL_U];
+      if (PIPE) {
+        int r0[SELL_U];
+        double e0[SELL_U];
 #pragma unroll
         for (int u = 0; u < SELL_U; u++) {
-          r[u] = rp[(t + u) * 64];
-          e[u] = ep[(t + u) * 64];
+          r0[u] = NT ? __builtin_nontemporal_load(&rp[u * 64]) : rp[u * 64];
+          e0[u] = NT ? __builtin_nontemporal_load(&ep[u * 64]) : ep[u * 64];
         }
+        for (int t = 0; t < maxLen; t += SELL_U) {
+          int r1[SELL_U];
+          double e1[SELL_U], pv[SELL_U];
+          const bool more = t + SELL_U < maxLen;
+          if (more) {
 #pragma unroll
-        for (int u = 0; u < SELL_U; u++)
-          pv[u] = D.piNeg[r[u]];
+            for (int u = 0; u < SELL_U; u++) {
+              r1[u] = NT ? __builtin_nontemporal_load(&rp[(t + SELL_U + u) * 64]) : rp[(t + SELL_U + u) * 64];
+              e1[u] = NT ? __builtin_nontemporal_load(&ep[(t + SELL_U + u) * 64]) : ep[(t + SELL_U + u) * 64];
+            }
+          }
 #pragma unroll
-        for (int u = 0; u < SELL_U; u++)
-          if (t + u < len)
-            value += pv[u] * e[u];
+          for (int u = 0; u < SELL_U; u++)
+            pv[u] = piAt(r0[u]);
+#pragma unroll
+          for (int u = 0; u < SELL_U; u++)
+            if (t + u < len)
+              value += pv[u] * e0[u];
+          if (more) {
+#pragma unroll
+            for (int u = 0; u < SELL_U; u++) {
+              r0[u] = r1[u];
+              e0[u] = e1[u];
+            }
+          }
+        }
+      } else {
+        for (int t = 0; t < maxLen; t += SELL_U) {
+          int r[SELL_U];
+          double e[SELL_U], pv[SELL_U];
+#pragma unroll
+          for (int u = 0; u < SELL_U; u++) {
+            r[u] = NT ? __builtin_nontemporal_load(&rp[(t + u) * 64]) : rp[(t + u) * 64];
+            e[u] = NT ? __builtin_nontemporal_load(&ep[(t + u) * 64]) : ep[(t + u) * 64];
+          }
+#pragma unroll
+          for (int u = 0; u < SELL_U; u++)
+            pv[u] = piAt(r[u]);
+#pragma unroll
+          for (int u = 0; u < SELL_U; u++)
+            if (t + u < len)
+              value += pv[u] * e[u];
+        }
       }
     }
     if (j >= 0) {
@@ -2242,6 +2429,31 @@ __global__ void __launch_bounds__(256) k_price_sell(Dev D)
   if (threadIdx.x == 0) {
     D.sellMin[blockIdx.x] = bmin;
     D.sellBytes[blockIdx.x] = bsum;
+  }
+}
+
+// variant: 1 plain, 2 bitmap, 3 pipelined+bitmap, 4 pipelined+nt+bitmap, 5 nt+bitmap
+__global__ void __launch_bounds__(256) k_price_sell(Dev D, int variant)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sellBits[];  // (m+63)/64 words for variants >= 2
+  if (D.ctrl->state != RUN)
+    return;
+  switch (variant) {
+  case 2:
+    priceSellBody<false, false, true>(D, sellBits);
+    break;
+  case 3:
+    priceSellBody<true, false, true>(D, sellBits);
+    break;
+  case 4:
+    priceSellBody<true, true, true>(D, sellBits);
+    break;
+  case 5:
+    priceSellBody<false, true, true>(D, sellBits);
+    break;
+  default:
+    priceSellBody<false, false, false>(D, sellBits);
+    break;
   }
 }
 
@@ -2389,6 +2601,61 @@ __global__ void k_gj_mult(Dev D, int i, int k, int *info)
   int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r < k) {
     double pivotValue = 1.0 / D.workW[(size_t)i * D.ld + i];
+    if (r == i) {
+      D.slotB[i] = pivotValue;
+      D.slotA[r] = 0.0;
+    } else {
+      D.slotA[r] = D.workW[(size_t)r * D.ld + i] * pivotValue;
+    }
+  }
+}
+// pivot search + row swap + multipliers of one elimination step, one workgroup
+__global__ void __launch_bounds__(1024) k_gj_step(Dev D, int i, int k, int *info)
+{
+  __shared__ double shv[16];
+  __shared__ int shk[16];
+  __shared__ int s_row;
+  if (info[0])
+    return;
+  double best = D.ctrl->zeroTolerance;
+  int key = -1;
+  for (int j = i + threadIdx.x; j < k; j += blockDim.x) {
+    double v = fabs(D.workW[(size_t)j * D.ld + i]);
+    if (v > best) {
+      best = v;
+      key = j;
+    }
+  }
+  blockArgMax(best, key, shv, shk);
+  if (threadIdx.x == 0) {
+    if (key < 0)
+      info[0] = 1 + i;
+    info[1] = key;
+    s_row = key;
+  }
+  __syncthreads();
+  const int iRow = s_row;
+  if (iRow < 0)
+    return;
+  if (iRow != i) {
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+      size_t a = (size_t)i * D.ld + j, b = (size_t)iRow * D.ld + j;
+      double t = D.workW[a];
+      D.workW[a] = D.workW[b];
+      D.workW[b] = t;
+      t = D.workX[a];
+      D.workX[a] = D.workX[b];
+      D.workX[b] = t;
+    }
+    if (threadIdx.x == 0) {
+      int t = D.perm[i];
+      D.perm[i] = D.perm[iRow];
+      D.perm[iRow] = t;
+    }
+  }
+  __syncthreads();
+  const double pivotValue = 1.0 / D.workW[(size_t)i * D.ld + i];
+  for (int r = threadIdx.x; r < k; r += blockDim.x) {
     if (r == i) {
       D.slotB[i] = pivotValue;
       D.slotA[r] = 0.0;
