@@ -60,6 +60,13 @@ struct OrcModel {
   int m, n;
   int *colStart, *row;
   double *elem;
+  int *rowStart, *rcol; /* row copy (ClpSimplex::createRim builds rowCopy_, src/ClpSimplex.cpp:3648) */
+  double *relem;
+  double *alphaDense; /* [n] scratch of the by-row path */
+  unsigned char *touched;
+  int *touchList;
+  int priceByRow; /* 1: choose by row / by column like ClpPackedMatrix::transposeTimes :727-754 */
+  long pricedByRow, pricedByColumn;
   double *colLower, *colUpper, *obj, *rowLower, *rowUpper;
   /* rim arrays [columns | rows], src/ClpSimplex.hpp:1864-1922 */
   double *lower, *upper, *cost, *dj, *sol;
@@ -151,6 +158,28 @@ OrcModel *orc_create(int m, int n, const int *colStart, const int *row, const do
   memcpy(M->row, row, sizeof(int) * (size_t)nz);
   M->elem = (double *)malloc(sizeof(double) * (size_t)(nz > 0 ? nz : 1));
   memcpy(M->elem, elem, sizeof(double) * (size_t)nz);
+  M->rowStart = (int *)calloc((size_t)m + 2, sizeof(int));
+  M->rcol = (int *)malloc(sizeof(int) * (size_t)(nz > 0 ? nz : 1));
+  M->relem = (double *)malloc(sizeof(double) * (size_t)(nz > 0 ? nz : 1));
+  for (int p = 0; p < nz; p++)
+    M->rowStart[row[p] + 1]++;
+  for (int i = 0; i < m; i++)
+    M->rowStart[i + 1] += M->rowStart[i];
+  {
+    int *fill = (int *)malloc(sizeof(int) * (size_t)(m + 1));
+    memcpy(fill, M->rowStart, sizeof(int) * (size_t)m);
+    for (int j = 0; j < n; j++)
+      for (int p = colStart[j]; p < colStart[j + 1]; p++) {
+        int q = fill[row[p]]++;
+        M->rcol[q] = j;
+        M->relem[q] = elem[p];
+      }
+    free(fill);
+  }
+  M->alphaDense = (double *)calloc((size_t)n + 1, sizeof(double));
+  M->touched = (unsigned char *)calloc((size_t)n + 1, 1);
+  M->touchList = (int *)malloc(sizeof(int) * (size_t)(n + 1));
+  M->priceByRow = 1;
 #define DUP(dst, src, cnt)                                    \
   dst = (double *)malloc(sizeof(double) * (size_t)((cnt) + 1)); \
   memcpy(dst, src, sizeof(double) * (size_t)(cnt))
@@ -231,6 +260,7 @@ void orc_destroy(OrcModel *M)
   if (!M)
     return;
   free(M->colStart); free(M->row); free(M->elem);
+  free(M->rowStart); free(M->rcol); free(M->relem); free(M->alphaDense); free(M->touched); free(M->touchList);
   free(M->colLower); free(M->colUpper); free(M->obj); free(M->rowLower); free(M->rowUpper);
   free(M->lower); free(M->upper); free(M->cost); free(M->dj); free(M->sol); free(M->status);
   free(M->pivotVariable);
@@ -254,6 +284,7 @@ int orc_set_option(OrcModel *M, const char *name, double v)
   else if (!strcmp(name, "dual_tolerance")) M->dualTolerance = M->dualToleranceBase = v;
   else if (!strcmp(name, "log_level")) M->logLevel = (int)v;
   else if (!strcmp(name, "random_seed")) M->seed = (unsigned int)v;
+  else if (!strcmp(name, "price_by_row")) M->priceByRow = (int)v;
   else return -1;
   return 0;
 }
@@ -332,6 +363,90 @@ static int priceRowFused(const OrcModel *M, int numberPi, const int *piIndex, co
     }
   }
   int numberNonZero = 0;
+  /* by row or by column?  ClpPackedMatrix::transposeTimes :727-754 (packed pi, no column copy) */
+  int byRow = 0;
+  if (M->priceByRow) {
+    double factor = 0.5;
+    if ((double)n * sizeof(double) > 1000000.0) {
+      if (M->m * 10 < n)
+        factor *= 0.333333333;
+      else if (M->m * 4 < n)
+        factor *= 0.5;
+      else if (M->m * 2 < n)
+        factor *= 0.66666666667;
+    }
+    byRow = !(numberPi > factor * M->m);
+  }
+  OrcModel *MM = (OrcModel *)M; /* scratch arrays and counters only */
+  if (byRow) {
+    /* ClpPackedMatrix::transposeTimesByRow :1307 / gutsOfTransposeTimesByRowGE3 :5176: accumulate
+       pi_i * row_i into a dense scratch, first-touch list.  pi is walked in ascending row order so
+       every alpha_j receives its terms in the same order as the by-column loop (zero terms omitted):
+       the values are bit-identical; the touched list is then sorted so the output order is too. */
+    MM->pricedByRow++;
+    int nTouched = 0;
+    for (int i = 0; i < numberPi; i++) {
+      int iRow = piIndex[i];
+      double piv = -piValue[i];
+      for (int q = M->rowStart[iRow]; q < M->rowStart[iRow + 1]; q++) {
+        int j = M->rcol[q];
+        if (!((status[j] & 3) - 1))
+          continue;
+        if (!MM->touched[j]) {
+          MM->touched[j] = 1;
+          MM->touchList[nTouched++] = j;
+        }
+        MM->alphaDense[j] += piv * M->relem[q];
+      }
+    }
+    /* ascending column order (insertion sort on small lists, qsort otherwise) */
+    if (nTouched > 1) {
+      int *a = MM->touchList;
+      if (nTouched < 64) {
+        for (int x = 1; x < nTouched; x++) {
+          int v = a[x], y = x - 1;
+          while (y >= 0 && a[y] > v) {
+            a[y + 1] = a[y];
+            y--;
+          }
+          a[y + 1] = v;
+        }
+      } else {
+        /* counting pass through the touched flags keeps it O(n) worst case */
+        int w = 0;
+        for (int j = 0; j < n && w < nTouched; j++)
+          if (MM->touched[j])
+            a[w++] = j;
+      }
+    }
+    for (int t = 0; t < nTouched; t++) {
+      int iColumn = MM->touchList[t];
+      int wanted = (status[iColumn] & 3) - 1;
+      double value = MM->alphaDense[iColumn];
+      MM->alphaDense[iColumn] = 0.0;
+      MM->touched[iColumn] = 0;
+      if (fabs(value) > zeroTolerance) {
+        outValue[numberNonZero] = value;
+        outIndex[numberNonZero++] = iColumn;
+        if (wanted > 0) {
+          double mult = multiplier[wanted - 1];
+          double alpha = value * mult;
+          if (alpha > 0.0) {
+            double oldValue = dj[iColumn] * mult;
+            double value2 = oldValue - tentativeTheta * alpha;
+            if (value2 < dualT) {
+              value2 = oldValue - upperTheta * alpha;
+              if (value2 < dualT && alpha >= acceptablePivot)
+                upperTheta = (oldValue - dualT) / alpha;
+              candValue[numberRemaining] = alpha * mult;
+              candIndex[numberRemaining++] = iColumn;
+            }
+          }
+        }
+      }
+    }
+  } else {
+  MM->pricedByColumn++;
   for (int iColumn = 0; iColumn < n; iColumn++) {
     int wanted = (status[iColumn] & 3) - 1;
     if (wanted) {
@@ -358,6 +473,7 @@ static int priceRowFused(const OrcModel *M, int numberPi, const int *piIndex, co
         }
       }
     }
+  }
   }
   for (int i = 0; i < numberPi; i++)
     piDense[piIndex[i]] = 0.0;
