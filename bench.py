@@ -74,7 +74,7 @@ def main():
     for kv in filter(None, os.environ.get("CLPGPU_OPTS", "").split(",")):  # experiment knobs, e.g. max_pivots=475
         key, val = kv.split("=")
         eng.set_option(key, float(val))
-    if distributed:
+    if distributed or os.environ.get("CLPGPU_FORCE_COMM"):
         from clp_amd.multigpu import attach_communicator
 
         attach_communicator(eng, rank, world)

@@ -77,7 +77,8 @@ struct PivotRecord {  // == clpgpu_pivot_record
 // All device pointers of one context.  Passed by value to kernels.
 struct Dev {
   int m, n, N;
-  int firstColumn, lastColumn;  // priced column range (multi-GPU shard)
+  int firstColumn, lastColumn;  // column keys handled by the N-wide kernels (candidates, dj update)
+  int priceFirst, priceLast;    // columns this GPU prices (its SELL copy); == key range on one GPU
   // A by column (ClpPackedMatrix / CoinPackedMatrix layout)
   const int *colStart;
   const int *row;

@@ -5,6 +5,7 @@
 // HIP kernel of kernels.hip, and clpgpu_create() fails when no HIP device is present.
 #include "kernels.hip"
 
+#include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -73,6 +74,12 @@ struct clpgpu_context {
   int kcap = 0, ld = 0;
   int *dKcol = nullptr, *dLocalOfRow = nullptr, *dInfo = nullptr;
   int nSellBlocks = 0, nChzBlocks = 0, priceKernel = 2, useGraph = 1;
+  // ---- multi-GPU (RCCL resolved at run time; a single-GPU build has no link dependency on it)
+  int rank = 0, nranks = 1, shardChunk = 0;
+  bool commActive = false;
+  void *comm = nullptr;
+  int (*ncclAllGatherFn)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  int (*ncclCommDestroyFn)(void *) = nullptr;
   hipGraph_t graph = nullptr;
   hipGraphExec_t graphExec = nullptr;
   int graphIterations = 0;
@@ -209,6 +216,8 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   D.N = N;
   D.firstColumn = 0;
   D.lastColumn = n;
+  D.priceFirst = 0;
+  D.priceLast = n;
   int *dColStart, *dRow, *dRowStart;
   double *dElem;
   int rc = 0;
@@ -252,7 +261,7 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   rc |= dalloc(D.rho, m);
   rc |= dalloc(D.piNeg, m);
   rc |= dalloc(D.piBits, (size_t)(m + 63) / 64 + 8);
-  rc |= dalloc(D.alphaCol, n);
+  rc |= dalloc(D.alphaCol, (size_t)n + 8 * 256 + 64);
   rc |= dalloc(D.vecV1, m);
   rc |= dalloc(D.vecV2, m);
   rc |= dalloc(D.w, m);
@@ -264,7 +273,7 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   rc |= dalloc(D.infeas, m);
   rc |= dalloc(D.weightBySeq, N);
   rc |= dalloc(D.infIndex, m);
-  rc |= dalloc(D.candFlag, N);
+  rc |= dalloc(D.candFlag, (size_t)N + 8 * 256 + 64);
   rc |= dalloc(D.candSeq, N);
   rc |= dalloc(D.candAlpha, N);
   rc |= dalloc(D.candTag, N);
@@ -325,7 +334,7 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
 // the entries inside a column is untouched, so the summation order per column is the CSC order.
 int clpgpu_context::buildSell()
 {
-  const int first = D.firstColumn, last = D.lastColumn, count = last - first;
+  const int first = D.priceFirst, last = D.priceLast, count = last - first;
   std::vector<int> order(count);
   for (int i = 0; i < count; i++)
     order[i] = first + i;
@@ -1252,10 +1261,18 @@ int clpgpu_context::launchIteration()
   if (ev)
     (void)hipEventRecord(evStart[evUsed], stream);
   if (priceKernel >= 1) {
-    hipLaunchKernelGGL(k_price_sell, dim3(nSellBlocks), dim3(256), (m > 64 * SELL_BITS_MAX || priceKernel < 2) ? 0 : (size_t)((m + 63) / 64) * 8, stream, D, (m > 64 * SELL_BITS_MAX && priceKernel > 1) ? 1 : priceKernel);
+    if (nSellBlocks > 0)
+      hipLaunchKernelGGL(k_price_sell, dim3(nSellBlocks), dim3(256), (m > 64 * SELL_BITS_MAX || priceKernel < 2) ? 0 : (size_t)((m + 63) / 64) * 8, stream, D, (m > 64 * SELL_BITS_MAX && priceKernel > 1) ? 1 : priceKernel);
     if (ev)
       (void)hipEventRecord(evStop[evUsed++], stream);
-    hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
+    if (commActive) {
+      // exchange step of the column-sharded pricing: every rank contributes its slice of
+      // the tableau row and of the first-pass flags, in place; everything after is replicated
+      const size_t chunk = (size_t)shardChunk;
+      ncclAllGatherFn(D.alphaCol + (size_t)rank * chunk, D.alphaCol, chunk, 8 /* ncclFloat64 */, comm, stream);
+      ncclAllGatherFn(D.candFlag + D.m + (size_t)rank * chunk, D.candFlag + D.m, chunk, 1 /* ncclUint8 */, comm, stream);
+    }
+    hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, commActive ? 1 : 0);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1, nSellBlocks);
   } else {
     hipLaunchKernelGGL(k_price, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
@@ -1617,8 +1634,9 @@ int clpgpu_context::priceRow(int numberPi, const int *piIndex, const double *piV
   const int nb = nbRows + nbCols;
   hipLaunchKernelGGL(k_zero, dim3(cdiv(n, 256)), dim3(256), 0, stream, D.alphaCol, n);
   if (priceKernel >= 1) {
-    hipLaunchKernelGGL(k_price_sell, dim3(nSellBlocks), dim3(256), 0, stream, D, 1);
-    hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
+    if (nSellBlocks > 0)
+      hipLaunchKernelGGL(k_price_sell, dim3(nSellBlocks), dim3(256), 0, stream, D, 1);
+    hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, 0);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1, nSellBlocks);
   } else {
     hipLaunchKernelGGL(k_price, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
@@ -1682,6 +1700,8 @@ void clpgpu_destroy(clpgpu_context *ctx)
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   ctx->dropGraph();
+  if (ctx->comm && ctx->ncclCommDestroyFn)
+    ctx->ncclCommDestroyFn(ctx->comm);
   for (void *p : ctx->allocations)
     (void)hipFree(p);
   if (ctx->hCtrl)
@@ -1712,8 +1732,8 @@ int clpgpu_set_column_range(clpgpu_context *ctx, int firstColumn, int lastColumn
 {
   if (!ctx || firstColumn < 0 || lastColumn > ctx->n || firstColumn > lastColumn)
     return -1;
-  ctx->D.firstColumn = firstColumn;
-  ctx->D.lastColumn = lastColumn;
+  ctx->D.firstColumn = ctx->D.priceFirst = firstColumn;
+  ctx->D.lastColumn = ctx->D.priceLast = lastColumn;
   return ctx->buildSell();
 }
 
@@ -1905,6 +1925,72 @@ int clpgpu_replace_column(clpgpu_context *ctx, int pivotRow, int sequenceIn, dou
 }
 
 int clpgpu_pivots(const clpgpu_context *ctx) { return ctx ? ctx->hCtrl->pivots : 0; }
+
+// ---- multi-GPU: RCCL communicator for the column-sharded pricing exchange -------------------
+static void *rcclHandle()
+{
+  static void *h = nullptr;
+  if (!h)
+    h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h)
+    h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  return h;
+}
+
+int clpgpu_comm_unique_id(void *id128)
+{
+  void *h = rcclHandle();
+  if (!h)
+    return -1;
+  typedef int (*fn_t)(void *);
+  fn_t f = (fn_t)dlsym(h, "ncclGetUniqueId");
+  if (!f)
+    return -1;
+  return f(id128);
+}
+
+int clpgpu_comm_init(clpgpu_context *ctx, int rank, int nranks, const void *id128)
+{
+  if (!ctx || nranks < 1 || rank < 0 || rank >= nranks || nranks > 8)
+    return -1;
+  if (nranks == 1 && !getenv("CLPGPU_FORCE_COMM"))
+    return 0;  // (the env knob exercises the RCCL path with a one-rank communicator on a 1-GPU box)
+  void *h = rcclHandle();
+  if (!h) {
+    ctx->setError("librccl not found");
+    return -1;
+  }
+  struct UniqueId { char internal[128]; } id;
+  memcpy(&id, id128, sizeof(id));
+  typedef int (*init_t)(void **, int, UniqueId, int);
+  init_t initFn = (init_t)dlsym(h, "ncclCommInitRank");
+  ctx->ncclAllGatherFn = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(h, "ncclAllGather");
+  ctx->ncclCommDestroyFn = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+  if (!initFn || !ctx->ncclAllGatherFn) {
+    ctx->setError("RCCL symbols missing");
+    return -1;
+  }
+  (void)hipSetDevice(ctx->device);
+  int rc = initFn(&ctx->comm, nranks, id, rank);
+  if (rc != 0) {
+    ctx->setError("ncclCommInitRank failed (%d)", rc);
+    ctx->comm = nullptr;
+    return -1;
+  }
+  // equal, 256-aligned shards so the in-place all-gather needs no displacements
+  int chunk = (ctx->n + nranks - 1) / nranks;
+  chunk = (chunk + PRICE_BLOCK - 1) / PRICE_BLOCK * PRICE_BLOCK;
+  ctx->rank = rank;
+  ctx->nranks = nranks;
+  ctx->commActive = true;
+  ctx->shardChunk = chunk;
+  ctx->D.firstColumn = 0;
+  ctx->D.lastColumn = ctx->n;
+  ctx->D.priceFirst = std::min(rank * chunk, ctx->n);
+  ctx->D.priceLast = std::min((rank + 1) * chunk, ctx->n);
+  ctx->useGraph = 0;  // collectives are enqueued between kernels; keep the eager chain
+  return ctx->buildSell();
+}
 
 int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
 {

@@ -2459,7 +2459,7 @@ __global__ void __launch_bounds__(256) k_price_sell(Dev D, int variant)
 
 // row (slack) part of the first ratio pass + per-key-block candidate counts for the ordered
 // compaction (columns were flagged by k_price_sell in slice order; counts must be in key order)
-__global__ void __launch_bounds__(PRICE_BLOCK) k_cand_count(Dev D, int nbRows)
+__global__ void __launch_bounds__(PRICE_BLOCK) k_cand_count(Dev D, int nbRows, int recomputeRatio)
 {
   const Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -2493,8 +2493,19 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_cand_count(Dev D, int nbRows)
     }
   } else {
     int j = D.firstColumn + ((int)blockIdx.x - nbRows) * PRICE_BLOCK + threadIdx.x;
-    if (j < D.lastColumn)
+    if (j < D.lastColumn) {
       flag = D.candFlag[D.m + j];
+      if (flag && recomputeRatio) {
+        // same expressions as the pricing kernel, so the min over all ranks' columns is bit-identical
+        int wanted = (D.status[j] & 3) - 1;
+        double mult = (wanted == 1) ? -1.0 : 1.0;
+        double alpha = D.alphaCol[j] * mult;
+        if (alpha >= c->acceptablePivot) {
+          double oldValue = D.dj[j] * mult;
+          ratio = (oldValue - (-c->dualTolerance)) / alpha;
+        }
+      }
+    }
   }
   int total;
   blockRank(flag, total, shi);

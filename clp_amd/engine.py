@@ -33,7 +33,7 @@ class Stats(C.Structure):
 # every symbol include/clpgpu.h declares (tests/test_abi.py checks the library exports all of them)
 ABI_SYMBOLS = [
     "clpgpu_create", "clpgpu_destroy", "clpgpu_last_error", "clpgpu_stream", "clpgpu_load_problem",
-    "clpgpu_set_column_range", "clpgpu_times", "clpgpu_transpose_times", "clpgpu_price_row", "clpgpu_factorize",
+    "clpgpu_set_column_range", "clpgpu_comm_unique_id", "clpgpu_comm_init", "clpgpu_times", "clpgpu_transpose_times", "clpgpu_price_row", "clpgpu_factorize",
     "clpgpu_ftran", "clpgpu_btran", "clpgpu_replace_column", "clpgpu_pivots", "clpgpu_set_option",
     "clpgpu_set_status", "clpgpu_dual", "clpgpu_dual_steps", "clpgpu_number_iterations", "clpgpu_objective_value",
     "clpgpu_get_solution", "clpgpu_get_reduced_costs", "clpgpu_get_status", "clpgpu_get_pivot_variable",
@@ -79,6 +79,8 @@ def lib():
         L.clpgpu_stream.argtypes = [p]
         L.clpgpu_load_problem.argtypes = [p, C.c_int, C.c_int, ip, ip, dp, dp, dp, dp, dp, dp]
         L.clpgpu_set_column_range.argtypes = [p, C.c_int, C.c_int]
+        L.clpgpu_comm_unique_id.argtypes = [C.c_char_p]
+        L.clpgpu_comm_init.argtypes = [p, C.c_int, C.c_int, C.c_char_p]
         L.clpgpu_times.argtypes = [p, C.c_double, dp, dp]
         L.clpgpu_transpose_times.argtypes = [p, C.c_double, dp, dp]
         L.clpgpu_price_row.argtypes = [p, C.c_int, ip, dp, up, dp, C.c_double, C.c_double, C.c_double,

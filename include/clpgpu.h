@@ -70,6 +70,15 @@ int clpgpu_load_problem(clpgpu_context *ctx, int numberRows, int numberColumns, 
  * src/ClpPackedMatrix.cpp:1823-1854): this context prices only columns [first, last). */
 int clpgpu_set_column_range(clpgpu_context *ctx, int firstColumn, int lastColumn);
 
+/* Multi-GPU engine mode: one process per GPU; rank 0 obtains an id with clpgpu_comm_unique_id
+ * (128 bytes, ncclUniqueId), every rank calls clpgpu_comm_init with the same id.  The context then
+ * prices columns [rank*chunk, (rank+1)*chunk) only and exchanges its slice of the tableau row with an
+ * RCCL all-gather each pivot (the reduce of src/ClpPackedMatrix.cpp:1848-1854 / the per-block
+ * combine of src/AbcSimplexDual.cpp:1623-1634, done as a gather because everything downstream of
+ * the row is replicated).  RCCL is resolved with dlopen, so single-GPU use has no dependency on it. */
+int clpgpu_comm_unique_id(void *id128);
+int clpgpu_comm_init(clpgpu_context *ctx, int rank, int nranks, const void *id128);
+
 /* ClpMatrixBase::times(scalar, x, y) (:275; ClpPackedMatrix.cpp:296): y += scalar*A*x */
 int clpgpu_times(clpgpu_context *ctx, double scalar, const double *x, double *y);
 /* ClpMatrixBase::transposeTimes(scalar, x, y) (:287; ClpPackedMatrix.cpp:362): y += scalar*A^T*x */
