@@ -69,6 +69,9 @@ def main():
     eng = ClpGpuSimplex(local_rank).loadProblem(lp)
     eng.set_option("pivot_rule", args.pivot_rule)
     eng.set_option("check_every", args.check_every)
+    # refactorization frequency as ClpSimplex::initialSolve sets it (defaultFactorizationFrequency:
+    # 475 at m = 50 000); the CPU baseline below uses the same value
+    eng.set_option("max_pivots", 0)
     if os.environ.get("CLPGPU_PRICE_KERNEL"):
         eng.set_option("price_kernel", int(os.environ["CLPGPU_PRICE_KERNEL"]))
     for kv in filter(None, os.environ.get("CLPGPU_OPTS", "").split(",")):  # experiment knobs, e.g. max_pivots=475
@@ -123,6 +126,7 @@ def main():
 
         o = OracleSimplex(lp)
         o.set_option("pivot_rule", args.pivot_rule)
+        o.set_option("max_pivots", 0)
         n_cpu = args.cpu_iterations if args.cpu_iterations > 0 else args.warmup + args.steps
         o.set_option("max_iterations", n_cpu)
         o.dual()

@@ -67,6 +67,8 @@ struct Ctrl {
   // CHUZR hand-over between its three kernels
   double chuzrTolerance;
   int chuzrNumber, chuzrStart, chuzrLast, chuzrPad;
+  int classCount[4];
+  int tCount, tPad;  // ratio-test candidates by breakpoint class (k_cand_scatter)
 };
 
 struct PivotRecord {  // == clpgpu_pivot_record
@@ -115,6 +117,8 @@ struct Dev {
   double *w, *tau, *x3;   // [m] FTRAN results by position
   double *flipRhs;        // [m]
   double *slotA, *slotB, *slotC, *slotD, *slotE, *slotF;  // [kcap] nucleus-sized scratch
+  int *tIndex;       // [m] nonzero col-slots of the BTRAN t-vector
+  double *tValue;
   double *rhoSlot;   // [kcap] unpruned rho on nucleus rows (for the rank-1 update)
   double *partial;   // gemvT partials [(kcap/64+1) * kcap]
   // dual row pivot

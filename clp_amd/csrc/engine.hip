@@ -261,6 +261,8 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   rc |= dalloc(D.rho, m);
   rc |= dalloc(D.piNeg, m);
   rc |= dalloc(D.piBits, (size_t)(m + 63) / 64 + 8);
+  rc |= dalloc(D.tIndex, (size_t)n + 1);
+  rc |= dalloc(D.tValue, (size_t)n + 1);
   rc |= dalloc(D.alphaCol, (size_t)n + 8 * 256 + 64);
   rc |= dalloc(D.vecV1, m);
   rc |= dalloc(D.vecV2, m);
@@ -1249,13 +1251,11 @@ int clpgpu_context::launchIteration()
   const int kc = kcap;  // launch extents use the capacity; kernels read the live k from ctrl
   const int gk = cdiv(kc, 256);
   const bool ev = timing && !capturing && evUsed < (int)evStart.size();
-  // CHUZR
+  // CHUZR (+ the analytic front end of the BTRAN)
   hipLaunchKernelGGL(k_chuzr_pre, dim3(1), dim3(64), 0, stream, D);
   hipLaunchKernelGGL(k_chuzr_scan, dim3(nChzBlocks), dim3(256), 0, stream, D);
-  hipLaunchKernelGGL(k_chuzr_final, dim3(1), dim3(256), 0, stream, D, nChzBlocks);
+  hipLaunchKernelGGL(k_chuzr_final_btran, dim3(1), dim3(256), 0, stream, D, nChzBlocks);
   // BTRAN
-  hipLaunchKernelGGL(k_btran_t3, dim3(gk), dim3(256), 0, stream, D);
-  hipLaunchKernelGGL(k_gemvT_partial2, dim3(gk, cdiv(kc, 64)), dim3(256), 0, stream, D, (const double *)D.slotA, 1);
   hipLaunchKernelGGL(k_rho_finish3, dim3(gm), dim3(256), 0, stream, D);
   // PRICE + first ratio pass
   if (ev)
@@ -1281,44 +1281,31 @@ int clpgpu_context::launchIteration()
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1, 0);
   }
   hipLaunchKernelGGL(k_cand_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
-  // CHUZC
+  // CHUZC (also unpacks the entering column)
   hipLaunchKernelGGL(k_dual_column_small, dim3(1), dim3(64), 0, stream, D);
   hipLaunchKernelGGL(k_dual_column, dim3(1), dim3(1024), 0, stream, D);
   // FTRAN of the entering column and of rho (DSE)
-  hipLaunchKernelGGL(k_ftran_gather, dim3(gk), dim3(256), 0, stream, D, (const double *)D.vecV1, (const double *)D.rho, D.slotA,
-                     D.slotB, 1);
-  hipLaunchKernelGGL(k_gemv2, dim3(cdiv(kc, 4)), dim3(256), 0, stream, D, (const double *)D.slotA, (const double *)D.slotB,
+  hipLaunchKernelGGL(k_gemv2g, dim3(cdiv(kc, 4)), dim3(256), 0, stream, D, (const double *)D.vecV1, (const double *)D.rho,
                      D.slotC, D.slotD, 1);
   hipLaunchKernelGGL(k_ftran_scatter, dim3(cdiv(m + kc, 256)), dim3(256), 0, stream, D, (const double *)D.vecV1,
                      (const double *)D.rho, (const double *)D.slotC, (const double *)D.slotD, D.w, D.tau, 1);
-  hipLaunchKernelGGL(k_norm_alpha2, dim3(1), dim3(256), 0, stream, D, gm);
-  hipLaunchKernelGGL(k_weights, dim3(gm), dim3(256), 0, stream, D);
-  // dual update, flips
-  hipLaunchKernelGGL(k_dj_update, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 1, 1, 0);
+  // DSE weights + dual update + flip detection, then flip scan + alpha accuracy test
+  hipLaunchKernelGGL(k_weights_dj, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, gm);
+  hipLaunchKernelGGL(k_scan_flips_alpha, dim3(1), dim3(1024), 0, stream, D, nb);
   hipLaunchKernelGGL(k_flip_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
-  hipLaunchKernelGGL(k_flip_apply, dim3(1), dim3(64), 0, stream, D);
-  // FTRAN of the flip rhs + primal update (all no-ops without flips)
-  hipLaunchKernelGGL(k_ftran_gather, dim3(gk), dim3(256), 0, stream, D, (const double *)D.flipRhs, (const double *)nullptr,
-                     D.slotA, (double *)nullptr, 2);
-  hipLaunchKernelGGL(k_gemv2, dim3(cdiv(kc, 4)), dim3(256), 0, stream, D, (const double *)D.slotA, (const double *)nullptr,
+  hipLaunchKernelGGL(k_flip_apply, dim3(1), dim3(64), 0, stream, D, gm);
+  // FTRAN of the flip rhs fused with its primal update (no-ops without flips)
+  hipLaunchKernelGGL(k_gemv2g, dim3(cdiv(kc, 4)), dim3(256), 0, stream, D, (const double *)D.flipRhs, (const double *)nullptr,
                      D.slotC, (double *)nullptr, 2);
-  hipLaunchKernelGGL(k_ftran_scatter, dim3(cdiv(m + kc, 256)), dim3(256), 0, stream, D, (const double *)D.flipRhs,
-                     (const double *)nullptr, (const double *)D.slotC, (const double *)nullptr, D.x3, (double *)nullptr, 2);
-  hipLaunchKernelGGL(k_primal_update, dim3(gm), dim3(256), 0, stream, D, 1);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, gm, 2, 1, 0);
-  hipLaunchKernelGGL(k_append_scatter, dim3(gm), dim3(256), 0, stream, D, 1, 1);
-  hipLaunchKernelGGL(k_after_primal2, dim3(1), dim3(256), 0, stream, D, gm, 1);
-  // basis update of the nucleus inverse
+  hipLaunchKernelGGL(k_ftran_scatter_flip, dim3(cdiv(m + kc, 256)), dim3(256), 0, stream, D, (const double *)D.slotC);
+  hipLaunchKernelGGL(k_scan_tail, dim3(1), dim3(1024), 0, stream, D, gm, cdiv(m + kc, 256), 1);
+  hipLaunchKernelGGL(k_append_scatter_abs, dim3(gm), dim3(256), 0, stream, D, 1);
+  // basis update of the nucleus inverse, primal update with the entering column
   hipLaunchKernelGGL(k_rank1, dim3(cdiv(kc, 256), kc < 512 ? kc : 512), dim3(256), 0, stream, D);
-  hipLaunchKernelGGL(k_rank1_fix, dim3(cdiv(kc + 1, 256)), dim3(256), 0, stream, D);
-  hipLaunchKernelGGL(k_rank1_fix2, dim3(gk), dim3(256), 0, stream, D);
-  // primal update with the entering column
   hipLaunchKernelGGL(k_primal_update, dim3(gm), dim3(256), 0, stream, D, 0);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, gm, 2, 1, 0);
-  hipLaunchKernelGGL(k_append_scatter, dim3(gm), dim3(256), 0, stream, D, 0, 1);
-  hipLaunchKernelGGL(k_after_primal2, dim3(1), dim3(256), 0, stream, D, gm, 0);
-  hipLaunchKernelGGL(k_house, dim3(1), dim3(256), 0, stream, D);
+  hipLaunchKernelGGL(k_scan_tail, dim3(1), dim3(1024), 0, stream, D, gm, gm, 0);
+  hipLaunchKernelGGL(k_append_scatter_abs, dim3(gm), dim3(256), 0, stream, D, 0);
+  hipLaunchKernelGGL(k_fix_house, dim3(1), dim3(256), 0, stream, D);
   return 0;
 }
 
@@ -1998,7 +1985,22 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
     return -99;
   if (!strcmp(name, "pivot_rule")) ctx->pivotRule = (int)v;
   else if (!strcmp(name, "max_iterations")) ctx->maximumIterations = (int)v;
-  else if (!strcmp(name, "max_pivots")) ctx->maximumPivots = (int)v;
+  else if (!strcmp(name, "max_pivots")) {
+    if (v > 0) {
+      ctx->maximumPivots = (int)v;
+    } else {
+      // ClpSimplex::defaultFactorizationFrequency (src/ClpSimplex.cpp:11401-11429, ABC_CLP_DEFAULTS 1),
+      // what ClpSimplex::initialSolve installs before calling dual() (src/ClpSolve.cpp:1574)
+      int mm = ctx->m, f;
+      if (mm < 10000)
+        f = 75 + mm / 50;
+      else if (mm < 100000)
+        f = 75 + 200 + (mm - 10000) / 200;
+      else
+        f = 1000;
+      ctx->maximumPivots = f < 1000 ? f : 1000;
+    }
+  }
   else if (!strcmp(name, "dual_bound")) ctx->dualBound = v;
   else if (!strcmp(name, "primal_tolerance")) ctx->primalTolerance = v;
   else if (!strcmp(name, "dual_tolerance")) ctx->dualTolerance = ctx->dualToleranceBase = v;
@@ -2088,6 +2090,17 @@ int clpgpu_get_pivot_log(clpgpu_context *ctx, clpgpu_pivot_record *out, int maxR
     if (ctx->d2h((PivotRecord *)out, ctx->D.log, count))
       return -99;
   return total;
+}
+int clpgpu_get_row_weights(clpgpu_context *ctx, double *weights, double *infeasibility)
+{
+  if (!ctx)
+    return -99;
+  int rc = 0;
+  if (weights)
+    rc |= ctx->d2h(weights, ctx->D.weights, ctx->m);
+  if (infeasibility)
+    rc |= ctx->d2h(infeasibility, ctx->D.infeas, ctx->m);
+  return rc;
 }
 int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
 {

@@ -536,6 +536,7 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(Dev D, int nb, int what, i
     if (what == 0) {
       c->numberCandidates = s_base;
       c->upperTheta = vmin;
+      c->classCount[0] = c->classCount[1] = c->classCount[2] = 0;
       // algorithmic bytes of this pricing launch: per scanned column 12*len+4 (+20 per
       // emitted nonzero), plus status 1*n, pi 8*m, one extra colStart
       c->statPriceBytes += bytes + (double)(D.lastColumn - D.firstColumn) + 8.0 * D.m + 4.0;
@@ -573,10 +574,24 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_cand_scatter(Dev D, int nbRows)
   }
   int total;
   int rank = blockRank(flag, total, shi);
+  int cls = 3;
   if (flag) {
     int o = D.blockOffset[blockIdx.x] + rank;
     D.candSeq[o] = seq;
     D.candAlpha[o] = alpha;
+    // breakpoint of the coarse ratio passes (ClpSimplexDual.cpp:4384 / :4412) against theta0
+    const double tol = c->dualTolerance;
+    const double djv = D.dj[seq];
+    const double x = (alpha < 0.0) ? (djv - tol) / alpha : (djv + tol) / alpha;
+    const double theta0 = fmax(10.0 * c->upperTheta, 1.0e-7);
+    cls = (x <= theta0 * 8.0) ? 0 : ((x <= theta0 * 256.0) ? 1 : ((x <= theta0 * 16384.0) ? 2 : 3));
+    D.candLive[o] = (unsigned char)cls;
+  }
+  // per-class totals (integer atomics: order independent)
+  for (int j = 0; j < 3; j++) {
+    unsigned long long mk = __ballot(cls == j);
+    if ((threadIdx.x & 63) == 0 && mk)
+      atomicAdd(&D.ctrl->classCount[j], (int)__popcll(mk));
   }
 }
 
@@ -659,13 +674,14 @@ __device__ inline void dcReduceWave(DcAcc &a)
   a.bestIdx = __shfl(a.bestIdx, 0);
 }
 
-template <int CPT, bool ONEWAVE> __device__ void dualColumnImpl(Dev D)
+template <int CPT, bool ONEWAVE, bool MAPPED = false>
+__device__ bool dualColumnImpl(Dev D, const int *map = nullptr, int count = -1, double tauGuard = 0.0)
 {
   Ctrl *c = D.ctrl;
   __shared__ double shd[5][16];
   __shared__ int shk[16];
   const int tid = threadIdx.x, nthr = ONEWAVE ? 64 : blockDim.x;
-  const int nc = c->numberCandidates;
+  const int nc = MAPPED ? count : c->numberCandidates;  // MAPPED: a prefiltered working set (see k_dual_column)
   const double acceptablePivot = c->acceptablePivot;
   const double dualTolerance = c->dualTolerance;
   const double newTolerance = dualTolerance;
@@ -678,16 +694,19 @@ template <int CPT, bool ONEWAVE> __device__ void dualColumnImpl(Dev D)
   };
   constexpr int R = CPT > 0 ? CPT : 1;
   double ra[R], rd[R], rr[R];
-  int rt[R];
+  int rt[R], ri[R];
   bool rl[R];
   if constexpr (CPT > 0) {
 #pragma unroll
     for (int q = 0; q < R; q++) {
-      int i = tid + q * nthr;
+      int pos = tid + q * nthr;
       rl[q] = false;
       rt[q] = -1;
+      ri[q] = -1;
       ra[q] = rd[q] = rr[q] = 0.0;
-      if (i < nc) {
+      if (pos < nc) {
+        int i = MAPPED ? map[pos] : pos;  // original candidate index: the list order for ties
+        ri[q] = i;
         int seq = D.candSeq[i];
         ra[q] = D.candAlpha[i];
         rd[q] = D.dj[seq];
@@ -706,9 +725,8 @@ template <int CPT, bool ONEWAVE> __device__ void dualColumnImpl(Dev D)
     if constexpr (CPT > 0) {
 #pragma unroll
       for (int q = 0; q < R; q++) {
-        int i = tid + q * nthr;
-        if (i < nc)
-          body(i, ra[q], rd[q], rr[q], rl[q], rt[q]);
+        if (ri[q] >= 0)
+          body(ri[q], ra[q], rd[q], rr[q], rl[q], rt[q]);
       }
     } else {
       for (int i = tid; i < nc; i += nthr) {
@@ -733,6 +751,10 @@ template <int CPT, bool ONEWAVE> __device__ void dualColumnImpl(Dev D)
   double tentativeTheta = fmax(10.0 * upperTheta, 1.0e-7);
   const double lastPivot = 0.0;  // never updated in the reference either (:4207)
   while (tentativeTheta < 1.0e22) {
+    // a prefiltered run is only valid while theta stays below the threshold every excluded
+    // candidate is known to exceed; otherwise the caller redoes the test on the full list
+    if (MAPPED && tentativeTheta >= tauGuard)
+      return false;
     // ---- coarse pass (:4355-4417)
     DcAcc acc = { 0.0, 0.0, 1.0e50, 0.0, acceptablePivot, -1 };
     forEach([&](int i, double alpha, double oldValue, double range, bool &live, int &tag) {
@@ -1009,6 +1031,7 @@ template <int CPT, bool ONEWAVE> __device__ void dualColumnImpl(Dev D)
       c->state = EXIT_NO_INCOMING;
     }
   }
+  return true;
 }
 
 #define DC_CPT 4
@@ -1029,9 +1052,17 @@ __global__ void __launch_bounds__(64) k_dual_column_small(Dev D)
     }
     return;
   }
-  if (nc <= DC_SMALL)
+  if (nc <= 4 * 64)
+    dualColumnImpl<4, true>(D);
+  else if (nc <= DC_SMALL)
     dualColumnImpl<8, true>(D);
 }
+// Long candidate lists (dense tableau rows, up to ~n/2 entries).  Only the few dozen candidates
+// with the smallest breakpoints ever take part in the passes; the rest only bound theta from above.
+// k_cand_scatter classified every candidate by its breakpoint against theta0 * {2^3, 2^8, 2^14};
+// the largest class prefix that fits in registers becomes the working set, the test runs on it, and
+// is repeated on the full list only if theta ever reaches the class threshold (exact either way).
+#define DC_WS_CAP (DC_CPT * 1024)
 __global__ void __launch_bounds__(1024) k_dual_column(Dev D)
 {
   Ctrl *c = D.ctrl;
@@ -1040,6 +1071,65 @@ __global__ void __launch_bounds__(1024) k_dual_column(Dev D)
   const int nc = c->numberCandidates;
   if (nc <= DC_SMALL)
     return;  // handled (or rejected) by k_dual_column_small
+  __shared__ int wsIdx[DC_WS_CAP];
+  __shared__ int shw[17];
+  __shared__ int s_done;
+  const int tid = threadIdx.x;
+  int cum[3];
+  cum[0] = c->classCount[0];
+  cum[1] = cum[0] + c->classCount[1];
+  cum[2] = cum[1] + c->classCount[2];
+  int J = -1;
+  for (int j = 0; j < 3; j++)
+    if (cum[j] <= DC_WS_CAP && cum[j] < nc)
+      J = j;
+  if (J >= 0 && cum[J] > 0) {
+    const int ws = cum[J];
+    const double theta0 = fmax(10.0 * c->upperTheta, 1.0e-7);
+    const double tau = theta0 * (J == 0 ? 8.0 : (J == 1 ? 256.0 : 16384.0));
+    // ordered compaction of the working set (thread t owns a contiguous slice of the list)
+    const int per = (nc + (int)blockDim.x - 1) / (int)blockDim.x;
+    const int lo = min(nc, tid * per), hi = min(nc, lo + per);
+    int cnt = 0;
+    for (int i = lo; i < hi; i++)
+      cnt += (D.candLive[i] <= J);
+    const int lane = tid & 63, wv = tid >> 6;
+    int v = cnt;
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(v, o);
+      if (lane >= o)
+        v += t;
+    }
+    if (lane == 63)
+      shw[wv] = v;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < wv; i++)
+      base += shw[i];
+    int o = base + v - cnt;
+    for (int i = lo; i < hi; i++)
+      if (D.candLive[i] <= J)
+        wsIdx[o++] = i;
+    if (tid == 0)
+      s_done = 0;
+    __syncthreads();
+    bool ok;
+    if (ws <= DC_SMALL) {
+      ok = true;
+      if (tid < 64) {
+        ok = dualColumnImpl<8, true, true>(D, wsIdx, ws, tau);
+        if (tid == 0)
+          s_done = ok ? 1 : 0;
+      }
+      __syncthreads();
+      ok = s_done != 0;
+    } else {
+      ok = dualColumnImpl<DC_CPT, false, true>(D, wsIdx, ws, tau);
+    }
+    if (ok)
+      return;
+    __syncthreads();
+  }
   if (nc <= DC_CPT * (int)blockDim.x) {
     dualColumnImpl<DC_CPT, false>(D);
   } else {
@@ -1319,7 +1409,7 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_flip_scatter(Dev D, int nbRows)
 
 // movement of each flip into the dense rhs (matrix_->add, src/ClpPackedMatrix.cpp:4874), in list
 // order, entries of one column in parallel (distinct rows) => deterministic
-__global__ void __launch_bounds__(256) k_flip_apply(Dev D)
+__global__ void __launch_bounds__(256) k_flip_apply(Dev D, int nbPos)
 {
   Ctrl *c = D.ctrl;
   if (c->state != RUN || c->numberFlips == 0)
@@ -1347,6 +1437,8 @@ __global__ void __launch_bounds__(256) k_flip_apply(Dev D)
   }
   if (threadIdx.x == 0)
     c->objectiveChange += changeObj;
+  for (int b = threadIdx.x; b < nbPos; b += blockDim.x)
+    D.blockCount[b] = 0;
 }
 
 // ClpSimplexDual::flipBounds (:6345-6401)
@@ -1632,11 +1724,9 @@ __device__ inline void rowCopySwap(const Dev &D, int e, int b)
   D.cscToCsr[pe] = b;
 }
 
-__global__ void __launch_bounds__(256) k_house(Dev D)
+__device__ void houseBody(Dev D)
 {
   Ctrl *c = D.ctrl;
-  if (c->state != RUN)
-    return;
   const int tid = threadIdx.x;
   const int seqIn = c->sequenceIn, seqOut = c->sequenceOut, pivotRow = c->pivotRow;
   const int n = D.n;
@@ -1786,7 +1876,7 @@ __global__ void __launch_bounds__(256) k_house(Dev D)
     r->sequenceOut = seqOut;
     r->pivotRow = pivotRow;
     r->numberFlipped = c->numberFlips;
-    r->reserved = ucase;
+    r->reserved = c->numberCandidates;  // length of the ratio-test candidate list (diagnostics)
     r->theta = c->theta;
     r->alpha = c->alpha;
     r->dualOut = dualOut;
@@ -2114,11 +2204,11 @@ __global__ void __launch_bounds__(256) k_rho_finish3(Dev D)
     double v;
     int sr = D.slotOfRow[i];
     if (sr >= 0) {
-      const int k = c->k;
-      int nchunk = (k + 63) >> 6;
+      // y_R = Minv^T t with t given as a short list: read only those rows of Minv
+      const int tc = c->tCount;
       v = 0.0;
-      for (int ch = 0; ch < nchunk; ch++)
-        v += D.partial[(size_t)ch * D.ld + sr];
+      for (int q = 0; q < tc; q++)
+        v += D.Minv[(size_t)D.tIndex[q] * D.ld + sr] * D.tValue[q];
       D.rhoSlot[sr] = v;
     } else {
       int p = D.posOfSlack[i];
@@ -2515,6 +2605,560 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_cand_count(Dev D, int nbRows, i
     D.blockMin[blockIdx.x] = bmin;
     D.blockSum[blockIdx.x] = 0.0;
   }
+}
+
+
+// =============================================================================================
+// v4 fusions: fewer grid-wide dependencies per pivot (each launch costs ~4 us on 256 CUs)
+// =============================================================================================
+
+// k_chuzr_final + k_btran_t3 in one workgroup
+__global__ void __launch_bounds__(256) k_chuzr_final_btran(Dev D, int nblocks)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ double shv[4];
+  __shared__ int shk[4], shr[4];
+  __shared__ int s_ok;
+  double best = 0.0;
+  int bestKey = -1, bestRow = -1;
+  int used = (c->chuzrNumber + 256 * CHZ_ITEMS - 1) / (256 * CHZ_ITEMS);
+  if (used > nblocks)
+    used = nblocks;
+  for (int b = threadIdx.x; b < used; b += blockDim.x) {
+    double ov = D.chzBest[b];
+    int ok = D.chzKey[b];
+    if (ok >= 0 && (bestKey < 0 || ov > best || (ov == best && ok < bestKey))) {
+      best = ov;
+      bestKey = ok;
+      bestRow = D.chzRow[b];
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int o = 32; o > 0; o >>= 1) {
+    double ov = __shfl_down(best, o);
+    int ok = __shfl_down(bestKey, o);
+    int orow = __shfl_down(bestRow, o);
+    if (ok >= 0 && (bestKey < 0 || ov > best || (ov == best && ok < bestKey))) {
+      best = ov;
+      bestKey = ok;
+      bestRow = orow;
+    }
+  }
+  if (lane == 0) {
+    shv[wv] = best;
+    shk[wv] = bestKey;
+    shr[wv] = bestRow;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 4; i++)
+      if (shk[i] >= 0 && (bestKey < 0 || shv[i] > best || (shv[i] == best && shk[i] < bestKey))) {
+        best = shv[i];
+        bestKey = shk[i];
+        bestRow = shr[i];
+      }
+    int chosen = bestRow;
+    c->pivotRow = chosen;
+    s_ok = chosen >= 0;
+    if (chosen < 0) {
+      c->state = EXIT_NO_PIVOT_ROW;
+    } else {
+      int seqOut = D.pivotVariable[chosen];
+      c->sequenceOut = seqOut;
+      double valueOut = D.sol[seqOut], lowerOut = D.lower[seqOut], upperOut = D.upper[seqOut];
+      c->valueOut = valueOut;
+      c->lowerOut = lowerOut;
+      c->upperOut = upperOut;
+      if (valueOut > upperOut) {
+        c->directionOut = -1;
+        c->dualOut = valueOut - upperOut;
+      } else if (valueOut < lowerOut) {
+        c->directionOut = 1;
+        c->dualOut = lowerOut - valueOut;
+      } else if (valueOut - lowerOut < upperOut - valueOut) {
+        c->directionOut = 1;
+        c->dualOut = lowerOut - valueOut;
+      } else {
+        c->directionOut = -1;
+        c->dualOut = valueOut - upperOut;
+      }
+      double acceptablePivot = 1.0e-1 * c->acceptablePivotBase;
+      if (c->numberIterations > 100)
+        acceptablePivot = c->acceptablePivotBase;
+      if (c->pivots > 10 || (c->pivots && c->saveSumDual != 0.0))
+        acceptablePivot = 1.0e+3 * c->acceptablePivotBase;
+      else if (c->pivots > 5)
+        acceptablePivot = 1.0e+2 * c->acceptablePivotBase;
+      else if (c->pivots)
+        acceptablePivot = c->acceptablePivotBase;
+      c->acceptablePivot = acceptablePivot;
+      D.vecC[chosen] = (double)c->directionOut;
+      c->sequenceIn = -1;
+      c->numberFlips = 0;
+      c->objectiveChange = 0.0;
+    }
+  }
+  __syncthreads();
+  if (!s_ok)
+    return;
+  // BTRAN t-vector for dir*e_p (see k_btran_t3), kept as a short list: t has one nonzero when a
+  // structural leaves, and one per basic entry of the leaving slack's row otherwise
+  const double dir = (double)c->directionOut;
+  const int seqOut = c->sequenceOut;
+  if (seqOut < D.n) {
+    if (threadIdx.x == 0) {
+      D.tIndex[0] = D.slotOfCol[seqOut];
+      D.tValue[0] = dir;
+      c->tCount = 1;
+    }
+  } else {
+    const int rOut = seqOut - D.n;
+    const double y = dir * -1.0;
+    const int s = D.rowStart[rOut], cnt = D.basicCount[rOut];
+    // ascending col-slot order so the later sum matches the dense form; rows are short
+    for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
+      int sc = D.slotOfCol[D.ccol[s + q]];
+      int rank = 0;
+      for (int q2 = 0; q2 < cnt; q2++) {
+        int sc2 = D.slotOfCol[D.ccol[s + q2]];
+        rank += (sc2 < sc);
+      }
+      D.tIndex[rank] = sc;
+      D.tValue[rank] = 0.0 - y * D.relem[s + q];
+    }
+    if (threadIdx.x == 0)
+      c->tCount = cnt;
+  }
+}
+
+// one kernel for every candidate count: <= 1024 one wave (16 per lane), <= 4096 four waves
+__global__ void __launch_bounds__(256) k_dual_column_fused(Dev D)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  const int nc = c->numberCandidates;
+  if (!nc) {
+    if (threadIdx.x == 0) {
+      c->sequenceIn = -1;
+      c->alpha = 0.0;
+      c->bestPossible = 0.0;
+      c->state = EXIT_NO_INCOMING;
+    }
+    return;
+  }
+  if (nc <= 16 * 64) {
+    if (threadIdx.x < 64)
+      dualColumnImpl<16, true>(D);
+  } else if (nc <= 16 * 256) {
+    dualColumnImpl<16, false>(D);
+  } else {
+    dualColumnImpl<0, false>(D);
+  }
+}
+
+// FTRAN nucleus GEMV with the gather of the right-hand side folded in
+__global__ void __launch_bounds__(256) k_gemv2g(Dev D, const double *v1, const double *v2, double *x1, double *x2, int iter)
+{
+  if (iter && D.ctrl->state != RUN)
+    return;
+  if (iter == 2 && D.ctrl->numberFlips == 0)
+    return;
+  const int k = D.ctrl->k;
+  const int lane = threadIdx.x & 63;
+  const int wavesPerBlock = blockDim.x >> 6;
+  for (int sc = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6); sc < k; sc += gridDim.x * wavesPerBlock) {
+    const double *Mrow = D.Minv + (size_t)sc * D.ld;
+    double a1 = 0.0, a2 = 0.0;
+    if (v2) {
+      for (int sr = lane; sr < k; sr += 64) {
+        double mv = Mrow[sr];
+        int r = D.slotRow[sr];
+        a1 += mv * v1[r];
+        a2 += mv * v2[r];
+      }
+      a2 = waveSum(a2);
+    } else {
+      for (int sr = lane; sr < k; sr += 64)
+        a1 += Mrow[sr] * v1[D.slotRow[sr]];
+    }
+    a1 = waveSum(a1);
+    if (lane == 0) {
+      x1[sc] = a1;
+      if (v2)
+        x2[sc] = a2;
+    }
+  }
+}
+
+// DSE weight update (positions) and dual update + flip detection (keys) in one N-wide pass.
+// The alpha check runs afterwards (k_scan_flips_alpha); on failure the host unrolls the weights and
+// refactorizes, which recomputes every dj, exactly as the reference does after its `break` (:1456).
+__global__ void __launch_bounds__(PRICE_BLOCK) k_weights_dj(Dev D, int nbRows, int nbNorm)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ int shi[17];
+  __shared__ double shd[16];
+  const double theta = c->theta;
+  const double tolerance = c->dualTolerance + fmin(1.0e-2, c->largestDualError);
+  const int seqIn = c->sequenceIn;
+  int flag = 0;
+  if ((int)blockIdx.x < nbRows) {
+    // every row block needs the DSE norm: sum of the per-block partials of sum rho^2
+    double norm = 0.0, multiplier = 0.0;
+    if (c->pivotRule) {
+      double acc = 0.0;
+      for (int b = threadIdx.x; b < nbNorm; b += blockDim.x)
+        acc += D.normPartial[b];
+      acc = blockSum(acc, shd);
+      double alphaOld = c->alpha;
+      norm = acc / (alphaOld * alphaOld);
+      multiplier = 2.0 / alphaOld;
+    }
+    int i = blockIdx.x * PRICE_BLOCK + threadIdx.x;
+    if (i < D.m) {
+      if (c->pivotRule) {
+        double thetaW = D.w[i];
+        if (thetaW != 0.0) {
+          double devex = D.weights[i];
+          D.altWeights[i] = devex;
+          if (i == c->pivotRow) {
+            devex = (norm < DEVEX_TRY_NORM) ? DEVEX_TRY_NORM : norm;
+          } else {
+            devex += thetaW * (thetaW * norm + D.tau[i] * multiplier);
+            if (devex < DEVEX_TRY_NORM)
+              devex = DEVEX_TRY_NORM;
+          }
+          D.weights[i] = devex;
+        }
+      }
+      double alphaI = D.rho[i];
+      int seq = D.n + i;
+      if (alphaI != 0.0 && seq != seqIn) {
+        int iStatus = (D.status[seq] & 3) - 1;
+        if (iStatus) {
+          double value = D.dj[seq] - theta * alphaI;
+          D.dj[seq] = value;
+          double mult = (iStatus == 1) ? -1.0 : ((iStatus == 2) ? 1.0 : 0.0);
+          value *= mult;
+          if (value < -tolerance)
+            flag = 1;
+        }
+      }
+      D.candFlag[i] = (unsigned char)flag;
+    }
+  } else {
+    int j = D.firstColumn + ((int)blockIdx.x - nbRows) * PRICE_BLOCK + threadIdx.x;
+    if (j < D.lastColumn) {
+      double alphaI = D.alphaCol[j];
+      if (alphaI != 0.0 && j != seqIn) {
+        int iStatus = (D.status[j] & 3) - 1;
+        if (iStatus) {
+          double value = D.dj[j] - theta * alphaI;
+          D.dj[j] = value;
+          double mult = (iStatus == 1) ? -1.0 : ((iStatus == 2) ? 1.0 : -1.0);
+          value *= mult;
+          if (value < -tolerance && iStatus > 0)
+            flag = 1;
+        }
+      }
+      D.candFlag[D.m + j] = (unsigned char)flag;
+    }
+  }
+  int total;
+  blockRank(flag, total, shi);
+  if (threadIdx.x == 0)
+    D.blockCount[blockIdx.x] = total;
+}
+
+// flip-count scan + the btran/ftran alpha accuracy test (whileIterating :1447-1501)
+__global__ void __launch_bounds__(1024) k_scan_flips_alpha(Dev D, int nb)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ int shi[17];
+  __shared__ int s_base;
+  if (threadIdx.x == 0)
+    s_base = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < nb; b0 += blockDim.x) {
+    int b = b0 + threadIdx.x;
+    int cnt = (b < nb) ? D.blockCount[b] : 0;
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int v = cnt;
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(v, o);
+      if (lane >= o)
+        v += t;
+    }
+    __syncthreads();
+    if (lane == 63)
+      shi[wv] = v;
+    __syncthreads();
+    int base = s_base;
+    for (int i = 0; i < wv; i++)
+      base += shi[i];
+    if (b < nb)
+      D.blockOffset[b] = base + v - cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tot = 0;
+      for (int i = 0; i < nw; i++)
+        tot += shi[i];
+      s_base += tot;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0)
+    return;
+  c->numberFlips = s_base;
+  double alpha = D.w[c->pivotRow];
+  double btranAlpha = c->btranAlpha;
+  double checkValue = 1.0e-7;
+  if (c->largestPrimalError > 10.0)
+    checkValue = fmin(1.0e-4, 1.0e-8 * c->largestPrimalError);
+  c->alpha = alpha;
+  if (fabs(btranAlpha) < 1.0e-12 || fabs(alpha) < 1.0e-12 || fabs(btranAlpha - alpha) > checkValue * (1.0 + fabs(alpha))) {
+    int bad = 1;
+    if (!c->pivots) {
+      double test;
+      if (fabs(btranAlpha) < 1.0e-8 || fabs(alpha) < 1.0e-8)
+        test = 1.0e-1 * fabs(alpha);
+      else
+        test = 1.0e-4 * (1.0 + fabs(alpha));
+      if (!(fabs(btranAlpha) < 1.0e-12 || fabs(alpha) < 1.0e-12 || fabs(btranAlpha - alpha) > test))
+        bad = 0;
+    }
+    if (bad)
+      c->state = EXIT_ALPHA_CHECK;
+  }
+}
+
+// flip FTRAN back end fused with the primal update by the flip movement (ratio 1.0): the thread
+// that produces x[p] applies it.  Appends are counted per position block with integer atomics
+// (blockCount zeroed by k_flip_apply); objective partials are per launch block (fixed mapping).
+__global__ void __launch_bounds__(256) k_ftran_scatter_flip(Dev D, const double *xk)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN || c->numberFlips == 0)
+    return;
+  __shared__ double shd[16];
+  const int k = c->k;
+  const double tolerance = c->primalTolerance;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int p = -1;
+  double v = 0.0;
+  if (t < D.m) {
+    p = D.posOfSlack[t];
+    if (p >= 0) {
+      double a1 = 0.0;
+      int s = D.rowStart[t], e = s + D.basicCount[t];
+      for (int q = s; q < e; q++)
+        a1 += D.relem[q] * xk[D.slotOfCol[D.ccol[q]]];
+      v = a1 - D.flipRhs[t];
+    }
+    D.flipRhs[t] = 0.0;  // consumed (the nucleus rows were read by k_gemv2g)
+  } else if (t < D.m + k) {
+    int sc = t - D.m;
+    p = D.slotPos[sc];
+    v = xk[sc];
+  }
+  double changeObj = 0.0;
+  if (p >= 0) {
+    int append = 0;
+    if (v != 0.0) {
+      int iPivot = D.pivotVariable[p];
+      double value = D.sol[iPivot];
+      value -= v;
+      changeObj -= v * D.cost[iPivot];
+      D.sol[iPivot] = value;
+      if (c->pivotRule) {
+        double lower = D.lower[iPivot], upper = D.upper[iPivot];
+        double old = D.infeas[p];
+        if (value < lower - tolerance) {
+          value -= lower;
+          value *= value;
+          if (old == 0.0)
+            append = 1;
+          D.infeas[p] = value;
+        } else if (value > upper + tolerance) {
+          value -= upper;
+          value *= value;
+          if (old == 0.0)
+            append = 1;
+          D.infeas[p] = value;
+        } else if (old != 0.0) {
+          D.infeas[p] = REALLY_TINY;
+        }
+      }
+    }
+    D.appendFlag[p] = append;
+    if (append)
+      atomicAdd(&D.blockCount[p >> 8], 1);
+  }
+  double s = blockSum(changeObj, shd);
+  if (threadIdx.x == 0)
+    D.blockSum[blockIdx.x] = s;
+}
+
+// append scan with absolute offsets + the scalar tail that used to be k_after_primal2
+__global__ void __launch_bounds__(1024) k_scan_tail(Dev D, int nbCount, int nbSum, int which)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ int shi[17];
+  __shared__ double shd[16];
+  __shared__ int s_base;
+  const bool active = !(which == 1 && c->numberFlips == 0);
+  if (threadIdx.x == 0)
+    s_base = c->numberInfeasible;
+  __syncthreads();
+  if (active) {
+    for (int b0 = 0; b0 < nbCount; b0 += blockDim.x) {
+      int b = b0 + threadIdx.x;
+      int cnt = (b < nbCount) ? D.blockCount[b] : 0;
+      int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+      int v = cnt;
+      for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(v, o);
+        if (lane >= o)
+          v += t;
+      }
+      __syncthreads();
+      if (lane == 63)
+        shi[wv] = v;
+      __syncthreads();
+      int base = s_base;
+      for (int i = 0; i < wv; i++)
+        base += shi[i];
+      if (b < nbCount)
+        D.blockOffset[b] = base + v - cnt;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int i = 0; i < nw; i++)
+          tot += shi[i];
+        s_base += tot;
+      }
+      __syncthreads();
+    }
+  }
+  double s = 0.0;
+  if (active)
+    for (int b = threadIdx.x; b < nbSum; b += blockDim.x)
+      s += D.blockSum[b];
+  s = blockSum(s, shd);
+  if (threadIdx.x != 0)
+    return;
+  if (active) {
+    c->objectiveChange += s;
+    c->numberAppend = s_base - c->numberInfeasible;
+    c->numberInfeasible = s_base;
+    if (c->pivotRule) {
+      int iRow = c->pivotRow;
+      if (D.infeas[iRow] != 0.0)
+        D.infeas[iRow] = REALLY_TINY;
+    }
+  } else {
+    c->numberAppend = 0;
+  }
+  if (which == 1) {
+    double oldDualOut = c->dualOut;
+    if (c->numberFlips) {
+      c->valueOut = D.sol[c->sequenceOut];
+      if (c->directionOut < 0)
+        c->dualOut = c->valueOut - c->upperOut;
+      else
+        c->dualOut = c->lowerOut - c->valueOut;
+    }
+    double alpha = c->alpha;
+    c->movement = -c->dualOut * c->directionOut / alpha;
+    double movementOld = oldDualOut * c->directionOut / alpha;
+    if (c->objectiveChange + fabs(movementOld * c->dualIn) < -fmax(1.0e-5, 1.0e-12 * fabs(c->objectiveValue))) {
+      if (c->pivots) {
+        c->state = EXIT_BACKWARDS;
+        return;
+      }
+    }
+    if (fabs(alpha) < c->zeroTolerance || fabs(c->dualOut) > 1.0e50) {
+      c->state = EXIT_BAD_UPDATE;
+      return;
+    }
+    if (c->theta < 0.0)
+      c->theta = 0.0;
+    int seqIn = c->sequenceIn, seqOut = c->sequenceOut;
+    int inStruct = seqIn < D.n, outStruct = seqOut < D.n;
+    c->updateCase = outStruct ? (inStruct ? 0 : 2) : (inStruct ? 1 : 3);
+    c->slotColOut = outStruct ? D.slotOfCol[seqOut] : -1;
+    c->rowOfSlackOut = outStruct ? -1 : (seqOut - D.n);
+    c->slotRowIn = inStruct ? -1 : D.slotOfRow[seqIn - D.n];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_append_scatter_abs(Dev D, int which)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN || c->numberAppend == 0)
+    return;
+  if (which == 1 && c->numberFlips == 0)
+    return;
+  __shared__ int shi[17];
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  int flag = (p < D.m) ? D.appendFlag[p] : 0;
+  int total;
+  int rank = blockRank(flag, total, shi);
+  if (flag)
+    D.infIndex[D.blockOffset[blockIdx.x] + rank] = p;
+}
+
+__global__ void __launch_bounds__(256) k_house(Dev D)
+{
+  if (D.ctrl->state != RUN)
+    return;
+  houseBody(D);
+}
+
+// row/column fix-up of the nucleus update (k_rank1_fix + k_rank1_fix2) and housekeeping, one workgroup
+__global__ void __launch_bounds__(256) k_fix_house(Dev D)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  const int k = c->k;
+  const int ucase = c->updateCase;
+  const double alpha = c->alpha;
+  const double dir = (double)c->directionOut;
+  const int a = c->slotColOut, b = c->slotRowIn, last = k - 1;
+  for (int s = threadIdx.x; s < k; s += blockDim.x) {
+    double slotFs = dir * D.rhoSlot[s] / alpha;  // g by row-slot
+    double slotEs = D.w[D.slotPos[s]];           // w by col-slot
+    if (ucase == 0) {
+      D.Minv[(size_t)a * D.ld + s] = slotFs;
+    } else if (ucase == 1) {
+      D.Minv[(size_t)k * D.ld + s] = slotFs;
+      D.Minv[(size_t)s * D.ld + k] = slotEs / alpha;
+    } else if (ucase == 2) {
+      if (b != last)
+        D.Minv[(size_t)s * D.ld + b] = D.Minv[(size_t)s * D.ld + last];
+    } else {
+      D.Minv[(size_t)s * D.ld + b] = slotEs / alpha;
+    }
+  }
+  if (ucase == 1 && threadIdx.x == 0)
+    D.Minv[(size_t)k * D.ld + k] = -1.0 / alpha;
+  __syncthreads();
+  if (ucase == 2 && a != last) {
+    for (int s = threadIdx.x; s < k; s += blockDim.x)
+      D.Minv[(size_t)a * D.ld + s] = D.Minv[(size_t)last * D.ld + s];
+  }
+  __syncthreads();
+  houseBody(D);
 }
 
 __global__ void k_zero(double *p, int n)

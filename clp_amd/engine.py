@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "clpgpu_ftran", "clpgpu_btran", "clpgpu_replace_column", "clpgpu_pivots", "clpgpu_set_option",
     "clpgpu_set_status", "clpgpu_dual", "clpgpu_dual_steps", "clpgpu_number_iterations", "clpgpu_objective_value",
     "clpgpu_get_solution", "clpgpu_get_reduced_costs", "clpgpu_get_status", "clpgpu_get_pivot_variable",
-    "clpgpu_get_pivot_log", "clpgpu_get_stats",
+    "clpgpu_get_pivot_log", "clpgpu_get_row_weights", "clpgpu_get_stats",
 ]
 
 
@@ -102,6 +102,7 @@ def lib():
         L.clpgpu_get_status.argtypes = [p, up]
         L.clpgpu_get_pivot_variable.argtypes = [p, ip]
         L.clpgpu_get_pivot_log.argtypes = [p, C.c_void_p, C.c_int]
+        L.clpgpu_get_row_weights.argtypes = [p, dp, dp]
         L.clpgpu_get_stats.argtypes = [p, C.POINTER(Stats)]
         _LIB = L
     return _LIB
@@ -200,6 +201,11 @@ class ClpGpuSimplex:
         if total > 0:
             lib().clpgpu_get_pivot_log(self._h, out.ctypes.data_as(C.c_void_p), total)
         return out
+
+    def rowWeights(self):
+        w, inf = np.zeros(self.m), np.zeros(self.m)
+        self._check(lib().clpgpu_get_row_weights(self._h, w, inf), "clpgpu_get_row_weights")
+        return w, inf
 
     def stats(self):
         s = Stats()

@@ -139,6 +139,9 @@ int clpgpu_get_status(clpgpu_context *ctx, unsigned char *status);
 int clpgpu_get_pivot_variable(clpgpu_context *ctx, int *pivotVariable);
 /* returns total number of records; copies min(total, maxRecords) */
 int clpgpu_get_pivot_log(clpgpu_context *ctx, clpgpu_pivot_record *out, int maxRecords);
+/* dual steepest-edge reference weights and squared infeasibilities by basis position
+ * (ClpDualRowSteepest::weights_, infeasible_; src/ClpDualRowSteepest.hpp) -- diagnostics */
+int clpgpu_get_row_weights(clpgpu_context *ctx, double *weights, double *infeasibility);
 int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats);
 
 #ifdef __cplusplus

@@ -278,7 +278,20 @@ int orc_set_option(OrcModel *M, const char *name, double v)
 {
   if (!strcmp(name, "pivot_rule")) M->pivotRule = (int)v;
   else if (!strcmp(name, "max_iterations")) M->maximumIterations = (int)v;
-  else if (!strcmp(name, "max_pivots")) M->maximumPivots = (int)v;
+  else if (!strcmp(name, "max_pivots")) {
+    if (v > 0) {
+      M->maximumPivots = (int)v;
+    } else { /* ClpSimplex::defaultFactorizationFrequency, src/ClpSimplex.cpp:11401-11429 */
+      int mm = M->m, f;
+      if (mm < 10000)
+        f = 75 + mm / 50;
+      else if (mm < 100000)
+        f = 75 + 200 + (mm - 10000) / 200;
+      else
+        f = 1000;
+      M->maximumPivots = f < 1000 ? f : 1000;
+    }
+  }
   else if (!strcmp(name, "dual_bound")) M->dualBound = v;
   else if (!strcmp(name, "primal_tolerance")) M->primalTolerance = v;
   else if (!strcmp(name, "dual_tolerance")) M->dualTolerance = M->dualToleranceBase = v;
@@ -2583,6 +2596,11 @@ void orc_get_reduced_costs(const OrcModel *M, double *d) { memcpy(d, M->dj, size
 void orc_get_status(const OrcModel *M, unsigned char *s) { memcpy(s, M->status, (size_t)(M->m + M->n)); }
 void orc_get_pivot_variable(const OrcModel *M, int *p) { memcpy(p, M->pivotVariable, sizeof(int) * (size_t)M->m); }
 void orc_get_row_duals(const OrcModel *M, double *d) { memcpy(d, M->dj + M->n, sizeof(double) * (size_t)M->m); }
+void orc_get_row_weights(const OrcModel *M, double *w, double *inf)
+{
+  memcpy(w, M->weights, sizeof(double) * (size_t)M->m);
+  memcpy(inf, M->infeas, sizeof(double) * (size_t)M->m);
+}
 int orc_get_pivot_log(const OrcModel *M, OrcPivotRecord *out, int maxRecords)
 {
   int count = M->logCount < maxRecords ? M->logCount : maxRecords;

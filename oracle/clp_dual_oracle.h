@@ -75,6 +75,7 @@ void orc_get_status(const OrcModel *model, unsigned char *status);
 void orc_get_pivot_variable(const OrcModel *model, int *pivotVariable);
 void orc_get_row_duals(const OrcModel *model, double *dual);
 int orc_get_pivot_log(const OrcModel *model, OrcPivotRecord *out, int maxRecords);
+void orc_get_row_weights(const OrcModel *model, double *weights, double *infeasibility);
 double orc_iteration_seconds(const OrcModel *model);
 
 /* ---- unit-level entry points used by the kernel parity tests ---- */

@@ -60,6 +60,7 @@ def lib():
         L.orc_get_status.argtypes = [p, up]
         L.orc_get_pivot_variable.argtypes = [p, ip]
         L.orc_get_pivot_log.argtypes = [p, C.c_void_p, C.c_int]
+        L.orc_get_row_weights.argtypes = [p, dp, dp]
         L.orc_times.argtypes = [p, C.c_double, dp, dp]
         L.orc_transpose_times.argtypes = [p, C.c_double, dp, dp]
         L.orc_price_row_fused.argtypes = [p, C.c_int, ip, dp, up, dp, C.c_double, C.c_double, C.c_double, ip, dp,
@@ -135,6 +136,11 @@ class OracleSimplex:
 
     def row_duals(self):
         return self._vec("orc_get_row_duals", size=self.m)
+
+    def row_weights(self):
+        w, inf = np.zeros(self.m), np.zeros(self.m)
+        lib().orc_get_row_weights(self._h, w, inf)
+        return w, inf
 
     def pivot_log(self):
         count = lib().orc_get_pivot_log(self._h, None, 0)
