@@ -120,6 +120,13 @@ def main():
     per_launch_s = price_ms * 1e-3 / max(launches, 1)
     achieved = per_launch_bytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
 
+    # HBM traffic of the same kernel from PMC counters: collected in separate rocprofv3 --pmc passes
+    # (profiles/r01_pmc_price_sell.txt) -- counters cannot be read from inside this process
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_price_sell.json")
+    if os.path.exists(pmc_path) and (args.rows, args.cols, args.nnz_per_col) == (50000, 200000, 50) and world == 1:
+        traffic = json.load(open(pmc_path))["traffic_bytes_per_launch"]
+
     cpu = None
     if rank == 0 and args.cpu_iterations != 0:
         from oracle.oracle import OracleSimplex
@@ -156,7 +163,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_price (row pricing by column + first ratio pass)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "bytes_per_launch": per_launch_bytes, "us_per_launch": per_launch_s * 1e6,
-                         "launches": int(launches), "traffic": None},
+                         "launches": int(launches), "traffic": traffic},
             "cpu_baseline": cpu,
             "refactorizations": int(s1["refactorizations"]),
         }
