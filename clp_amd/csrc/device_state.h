@@ -134,6 +134,7 @@ struct Dev {
   double *blockMin, *blockSum;
   int *flipSeq;
   int *appendFlag;  // [m]
+  int *touchCount;  // [m] contributors per row while the flip rhs is assembled (zero otherwise)
   // sliced-ELL copy of the priced column range: slice = 64 columns (one wave), entry t of the
   // slice's lane l at sellStart[slice] + t*64 + l; columns sorted by length so padding is ~1%
   const int *sellStart;  // [numSlices+1]

@@ -287,6 +287,7 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   rc |= dalloc(D.blockSum, nb);
   rc |= dalloc(D.flipSeq, N);
   rc |= dalloc(D.appendFlag, m);
+  rc |= dalloc(D.touchCount, m);
   rc |= dalloc(D.ctrl, 1);
   nChzBlocks = cdiv(m, 256 * CHZ_ITEMS);
   rc |= dalloc(D.chzBest, nChzBlocks);
@@ -1284,26 +1285,22 @@ int clpgpu_context::launchIteration()
   // CHUZC (also unpacks the entering column)
   hipLaunchKernelGGL(k_dual_column_small, dim3(1), dim3(64), 0, stream, D);
   hipLaunchKernelGGL(k_dual_column, dim3(1), dim3(1024), 0, stream, D);
-  // FTRAN of the entering column and of rho (DSE)
-  hipLaunchKernelGGL(k_gemv2g, dim3(cdiv(kc, 4)), dim3(256), 0, stream, D, (const double *)D.vecV1, (const double *)D.rho,
-                     D.slotC, D.slotD, 1);
-  hipLaunchKernelGGL(k_ftran_scatter, dim3(cdiv(m + kc, 256)), dim3(256), 0, stream, D, (const double *)D.vecV1,
-                     (const double *)D.rho, (const double *)D.slotC, (const double *)D.slotD, D.w, D.tau, 1);
-  // DSE weights + dual update + flip detection, then flip scan + alpha accuracy test
-  hipLaunchKernelGGL(k_weights_dj, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, gm);
-  hipLaunchKernelGGL(k_scan_flips_alpha, dim3(1), dim3(1024), 0, stream, D, nb);
+  // dual update + flip detection (needs only theta), flip list, flip right-hand side
+  hipLaunchKernelGGL(k_dj_flags, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
+  hipLaunchKernelGGL(k_scan_flips, dim3(1), dim3(1024), 0, stream, D, nb);
   hipLaunchKernelGGL(k_flip_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
-  hipLaunchKernelGGL(k_flip_apply, dim3(1), dim3(64), 0, stream, D, gm);
-  // FTRAN of the flip rhs fused with its primal update (no-ops without flips)
-  hipLaunchKernelGGL(k_gemv2g, dim3(cdiv(kc, 4)), dim3(256), 0, stream, D, (const double *)D.flipRhs, (const double *)nullptr,
-                     D.slotC, (double *)nullptr, 2);
-  hipLaunchKernelGGL(k_ftran_scatter_flip, dim3(cdiv(m + kc, 256)), dim3(256), 0, stream, D, (const double *)D.slotC);
-  hipLaunchKernelGGL(k_scan_tail, dim3(1), dim3(1024), 0, stream, D, gm, cdiv(m + kc, 256), 1);
+  hipLaunchKernelGGL(k_flip_apply2, dim3(1), dim3(1024), 0, stream, D, gm);
+  // one FTRAN sweep for the entering column, rho (DSE) and the flip rhs; the back end also applies
+  // the flip part of the primal update
+  hipLaunchKernelGGL(k_gemv3g, dim3(cdiv(kc, 4)), dim3(256), 0, stream, D);
+  hipLaunchKernelGGL(k_ftran_scatter3, dim3(cdiv(m + kc, 256)), dim3(256), 0, stream, D);
+  hipLaunchKernelGGL(k_weights2, dim3(gm), dim3(256), 0, stream, D, gm);
+  hipLaunchKernelGGL(k_scan_tail, dim3(1), dim3(1024), 0, stream, D, gm, cdiv(m + kc, 256), 1, 1);
   hipLaunchKernelGGL(k_append_scatter_abs, dim3(gm), dim3(256), 0, stream, D, 1);
   // basis update of the nucleus inverse, primal update with the entering column
   hipLaunchKernelGGL(k_rank1, dim3(cdiv(kc, 256), kc < 512 ? kc : 512), dim3(256), 0, stream, D);
   hipLaunchKernelGGL(k_primal_update, dim3(gm), dim3(256), 0, stream, D, 0);
-  hipLaunchKernelGGL(k_scan_tail, dim3(1), dim3(1024), 0, stream, D, gm, gm, 0);
+  hipLaunchKernelGGL(k_scan_tail, dim3(1), dim3(1024), 0, stream, D, gm, gm, 0, 0);
   hipLaunchKernelGGL(k_append_scatter_abs, dim3(gm), dim3(256), 0, stream, D, 0);
   hipLaunchKernelGGL(k_fix_house, dim3(1), dim3(256), 0, stream, D);
   return 0;

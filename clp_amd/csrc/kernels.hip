@@ -3007,7 +3007,7 @@ __global__ void __launch_bounds__(256) k_ftran_scatter_flip(Dev D, const double 
 }
 
 // append scan with absolute offsets + the scalar tail that used to be k_after_primal2
-__global__ void __launch_bounds__(1024) k_scan_tail(Dev D, int nbCount, int nbSum, int which)
+__global__ void __launch_bounds__(1024) k_scan_tail(Dev D, int nbCount, int nbSum, int which, int alphaTest = 0)
 {
   Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -3069,6 +3069,31 @@ __global__ void __launch_bounds__(1024) k_scan_tail(Dev D, int nbCount, int nbSu
     c->numberAppend = 0;
   }
   if (which == 1) {
+    if (alphaTest) {
+      // btran/ftran alpha accuracy test (whileIterating :1447-1501)
+      double alphaNew = D.w[c->pivotRow];
+      double btranAlpha = c->btranAlpha;
+      double checkValue = 1.0e-7;
+      if (c->largestPrimalError > 10.0)
+        checkValue = fmin(1.0e-4, 1.0e-8 * c->largestPrimalError);
+      c->alpha = alphaNew;
+      if (fabs(btranAlpha) < 1.0e-12 || fabs(alphaNew) < 1.0e-12 || fabs(btranAlpha - alphaNew) > checkValue * (1.0 + fabs(alphaNew))) {
+        int bad = 1;
+        if (!c->pivots) {
+          double test;
+          if (fabs(btranAlpha) < 1.0e-8 || fabs(alphaNew) < 1.0e-8)
+            test = 1.0e-1 * fabs(alphaNew);
+          else
+            test = 1.0e-4 * (1.0 + fabs(alphaNew));
+          if (!(fabs(btranAlpha) < 1.0e-12 || fabs(alphaNew) < 1.0e-12 || fabs(btranAlpha - alphaNew) > test))
+            bad = 0;
+        }
+        if (bad) {
+          c->state = EXIT_ALPHA_CHECK;
+          return;
+        }
+      }
+    }
     double oldDualOut = c->dualOut;
     if (c->numberFlips) {
       c->valueOut = D.sol[c->sequenceOut];
@@ -3159,6 +3184,462 @@ __global__ void __launch_bounds__(256) k_fix_house(Dev D)
   }
   __syncthreads();
   houseBody(D);
+}
+
+
+// =============================================================================================
+// v5: flips are known as soon as theta is (they do not depend on the FTRAN), so the flip right-hand
+// side joins the entering column and the DSE vector in ONE three-vector FTRAN sweep over Minv.
+// =============================================================================================
+
+// dual update + flip detection only (the weights need the FTRAN and come later)
+__global__ void __launch_bounds__(PRICE_BLOCK) k_dj_flags(Dev D, int nbRows)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ int shi[17];
+  const double theta = c->theta;
+  const double tolerance = c->dualTolerance + fmin(1.0e-2, c->largestDualError);
+  const int seqIn = c->sequenceIn;
+  int flag = 0;
+  if ((int)blockIdx.x < nbRows) {
+    int i = blockIdx.x * PRICE_BLOCK + threadIdx.x;
+    if (i < D.m) {
+      double alphaI = D.rho[i];
+      int seq = D.n + i;
+      if (alphaI != 0.0 && seq != seqIn) {
+        int iStatus = (D.status[seq] & 3) - 1;
+        if (iStatus) {
+          double value = D.dj[seq] - theta * alphaI;
+          D.dj[seq] = value;
+          double mult = (iStatus == 1) ? -1.0 : ((iStatus == 2) ? 1.0 : 0.0);
+          value *= mult;
+          if (value < -tolerance)
+            flag = 1;
+        }
+      }
+      D.candFlag[i] = (unsigned char)flag;
+    }
+  } else {
+    int j = D.firstColumn + ((int)blockIdx.x - nbRows) * PRICE_BLOCK + threadIdx.x;
+    if (j < D.lastColumn) {
+      double alphaI = D.alphaCol[j];
+      if (alphaI != 0.0 && j != seqIn) {
+        int iStatus = (D.status[j] & 3) - 1;
+        if (iStatus) {
+          double value = D.dj[j] - theta * alphaI;
+          D.dj[j] = value;
+          double mult = (iStatus == 1) ? -1.0 : ((iStatus == 2) ? 1.0 : -1.0);
+          value *= mult;
+          if (value < -tolerance && iStatus > 0)
+            flag = 1;
+        }
+      }
+      D.candFlag[D.m + j] = (unsigned char)flag;
+    }
+  }
+  int total;
+  blockRank(flag, total, shi);
+  if (threadIdx.x == 0)
+    D.blockCount[blockIdx.x] = total;
+}
+
+// Flip right-hand side, all flips at once (matrix_->add per flipped column, src/ClpPackedMatrix.cpp
+// :4874).  One workgroup; thread e owns one (flip, entry) pair.  Rows hit by a single flip are stored
+// directly; rows hit by several flips are collected, ordered by (row, flip) and summed in flip order,
+// so the result is bit-identical to the sequential loop of the reference whatever the schedule.
+// sequential form (very many flips or dense columns): flips in order, entries of one column in parallel
+__device__ void flipSequential(Dev D)
+{
+  Ctrl *c = D.ctrl;
+  const int nf = c->numberFlips;
+  const int tid = threadIdx.x;
+  double changeObj = 0.0;
+  for (int f = 0; f < nf; f++) {
+    int seq = D.flipSeq[f];
+    int iStatus = (D.status[seq] & 3) - 1;
+    double mult = (iStatus == 1) ? -1.0 : 1.0;
+    if (seq >= D.n) {
+      double movement = mult * (D.lower[seq] - D.upper[seq]);
+      if (tid == 0) {
+        changeObj -= movement * D.cost[seq];
+        D.flipRhs[seq - D.n] += movement;
+      }
+    } else {
+      double movement = mult * (D.upper[seq] - D.lower[seq]);
+      if (tid == 0)
+        changeObj += movement * D.cost[seq];
+      for (int p = D.colStart[seq] + tid; p < D.colStart[seq + 1]; p += blockDim.x)
+        D.flipRhs[D.row[p]] += movement * D.elem[p];
+    }
+    __syncthreads();
+  }
+  if (tid == 0)
+    c->objectiveChange += changeObj;
+}
+#define FLIP_MAX_FLIPS 1024
+#define FLIP_MAX_ENTRIES 8192
+#define FLIP_MAX_COLLIDE 1024
+__global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  const int nf = c->numberFlips;
+  const int tid = threadIdx.x;
+  // counters of k_ftran_scatter3's appends (position blocks) are reset here, flips or not
+  for (int b = tid; b < nbPos; b += blockDim.x)
+    D.blockCount[b] = 0;
+  if (nf == 0)
+    return;
+  __shared__ double s_mv[FLIP_MAX_FLIPS];
+  __shared__ int s_start[FLIP_MAX_FLIPS + 1];
+  __shared__ int s_cRow[FLIP_MAX_COLLIDE], s_cFlip[FLIP_MAX_COLLIDE], s_cSorted[FLIP_MAX_COLLIDE];
+  __shared__ double s_cVal[FLIP_MAX_COLLIDE];
+  __shared__ int s_nCollide, s_total;
+  __shared__ double shd[16];
+  bool fallback = nf > FLIP_MAX_FLIPS;
+  double changeObj = 0.0;
+  if (!fallback) {
+    // per-flip scalars
+    for (int f = tid; f < nf; f += blockDim.x) {
+      int seq = D.flipSeq[f];
+      int iStatus = (D.status[seq] & 3) - 1;
+      double mult = (iStatus == 1) ? -1.0 : 1.0;
+      double mv;
+      int len;
+      if (seq >= D.n) {
+        mv = mult * (D.lower[seq] - D.upper[seq]);
+        changeObj -= mv * D.cost[seq];
+        len = 1;
+      } else {
+        mv = mult * (D.upper[seq] - D.lower[seq]);
+        changeObj += mv * D.cost[seq];
+        len = D.colStart[seq + 1] - D.colStart[seq];
+      }
+      s_mv[f] = mv;
+      s_start[f + 1] = len;
+    }
+    if (tid == 0) {
+      s_start[0] = 0;
+      s_nCollide = 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int acc = 0;
+      for (int f = 0; f < nf; f++) {
+        acc += s_start[f + 1];
+        s_start[f + 1] = acc;
+      }
+      s_total = acc;
+    }
+    __syncthreads();
+    fallback = s_total > FLIP_MAX_ENTRIES;
+  }
+  if (fallback) {
+    flipSequential(D);
+    return;
+  }
+  const int total = s_total;
+  // phase 1: count the contributors of every touched row (touchCount is all zero between calls)
+  int myRow[FLIP_MAX_ENTRIES / 1024], myFlip[FLIP_MAX_ENTRIES / 1024];
+  double myVal[FLIP_MAX_ENTRIES / 1024];
+#pragma unroll
+  for (int q = 0; q < FLIP_MAX_ENTRIES / 1024; q++) {
+    int e = tid + q * 1024;
+    myRow[q] = -1;
+    if (e < total) {
+      int lo = 0, hi = nf;  // largest f with s_start[f] <= e
+      while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (s_start[mid] <= e)
+          lo = mid;
+        else
+          hi = mid;
+      }
+      int f = lo;
+      int seq = D.flipSeq[f];
+      int r;
+      double v;
+      if (seq >= D.n) {
+        r = seq - D.n;
+        v = s_mv[f];
+      } else {
+        int p = D.colStart[seq] + (e - s_start[f]);
+        r = D.row[p];
+        v = s_mv[f] * D.elem[p];
+      }
+      myRow[q] = r;
+      myFlip[q] = f;
+      myVal[q] = v;
+      atomicAdd(&D.touchCount[r], 1);
+    }
+  }
+  __syncthreads();
+  {
+    // how many entries share their row with another flip?  dense columns collide everywhere:
+    // clean up and take the sequential form instead
+    double nColl = 0.0;
+#pragma unroll
+    for (int q = 0; q < FLIP_MAX_ENTRIES / 1024; q++)
+      if (myRow[q] >= 0 && atomicAdd(&D.touchCount[myRow[q]], 0) > 1)
+        nColl += 1.0;
+    nColl = blockSum(nColl, shd);
+    if (nColl > (double)FLIP_MAX_COLLIDE) {
+#pragma unroll
+      for (int q = 0; q < FLIP_MAX_ENTRIES / 1024; q++)
+        if (myRow[q] >= 0)
+          D.touchCount[myRow[q]] = 0;
+      __syncthreads();
+      flipSequential(D);
+      return;
+    }
+  }
+  // phase 2: single contributors store, the others queue up
+  bool overflow = false;
+#pragma unroll
+  for (int q = 0; q < FLIP_MAX_ENTRIES / 1024; q++) {
+    if (myRow[q] >= 0) {
+      int cnt = atomicAdd(&D.touchCount[myRow[q]], 0);
+      if (cnt == 1) {
+        D.flipRhs[myRow[q]] += myVal[q];
+      } else {
+        int o = atomicAdd(&s_nCollide, 1);
+        if (o < FLIP_MAX_COLLIDE) {
+          s_cRow[o] = myRow[q];
+          s_cFlip[o] = myFlip[q];
+          s_cVal[o] = myVal[q];
+        } else {
+          overflow = true;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int ncol = min(s_nCollide, FLIP_MAX_COLLIDE);
+  // phase 3: order the collisions by (row, flip) with a rank sort, then one thread per row segment
+  for (int i = tid; i < ncol; i += blockDim.x) {
+    int r = s_cRow[i], f = s_cFlip[i], rank = 0;
+    for (int j = 0; j < ncol; j++) {
+      int rj = s_cRow[j], fj = s_cFlip[j];
+      rank += (rj < r) || (rj == r && fj < f);
+    }
+    s_cSorted[rank] = i;
+  }
+  __syncthreads();
+  for (int i = tid; i < ncol; i += blockDim.x) {
+    int e = s_cSorted[i];
+    int r = s_cRow[e];
+    if (i == 0 || s_cRow[s_cSorted[i - 1]] != r) {
+      double acc = D.flipRhs[r];
+      for (int j = i; j < ncol && s_cRow[s_cSorted[j]] == r; j++)
+        acc += s_cVal[s_cSorted[j]];
+      D.flipRhs[r] = acc;
+    }
+  }
+  // phase 4: clean the counters
+#pragma unroll
+  for (int q = 0; q < FLIP_MAX_ENTRIES / 1024; q++)
+    if (myRow[q] >= 0)
+      D.touchCount[myRow[q]] = 0;
+  double s = blockSum(changeObj, shd);
+  if (tid == 0) {
+    c->objectiveChange += s;
+    if (overflow || s_nCollide > FLIP_MAX_COLLIDE)
+      c->state = EXIT_BAD_UPDATE;  // cannot happen with the caps above unless thousands of flips collide
+  }
+}
+
+// three right-hand sides in one sweep over Minv: entering column, DSE vector (rho), flip rhs
+__global__ void __launch_bounds__(256) k_gemv3g(Dev D)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  const int k = c->k;
+  const bool doTau = c->pivotRule != 0, doFlip = c->numberFlips != 0;
+  const int lane = threadIdx.x & 63;
+  const int wavesPerBlock = blockDim.x >> 6;
+  for (int sc = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6); sc < k; sc += gridDim.x * wavesPerBlock) {
+    const double *Mrow = D.Minv + (size_t)sc * D.ld;
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int sr = lane; sr < k; sr += 64) {
+      double mv = Mrow[sr];
+      int r = D.slotRow[sr];
+      a1 += mv * D.vecV1[r];
+      if (doTau)
+        a2 += mv * D.rho[r];
+      if (doFlip)
+        a3 += mv * D.flipRhs[r];
+    }
+    a1 = waveSum(a1);
+    a2 = waveSum(a2);
+    a3 = waveSum(a3);
+    if (lane == 0) {
+      D.slotC[sc] = a1;
+      D.slotD[sc] = a2;
+      D.slotE[sc] = a3;
+    }
+  }
+}
+
+// back end of the three FTRANs: w, tau and -- when there are flips -- x3 together with the primal
+// update it drives (ratio 1.0, ClpSimplexDual.cpp:1535-1536)
+__global__ void __launch_bounds__(256) k_ftran_scatter3(Dev D)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ double shd[16];
+  const int k = c->k;
+  const bool doFlip = c->numberFlips != 0;
+  const double tolerance = c->primalTolerance;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int p = -1;
+  double x1 = 0.0, x2 = 0.0, x3 = 0.0;
+  if (t < D.m) {
+    p = D.posOfSlack[t];
+    if (p >= 0) {
+      double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      int s = D.rowStart[t], e = s + D.basicCount[t];
+      for (int q = s; q < e; q++) {
+        int sc = D.slotOfCol[D.ccol[q]];
+        double a = D.relem[q];
+        a1 += a * D.slotC[sc];
+        a2 += a * D.slotD[sc];
+        if (doFlip)
+          a3 += a * D.slotE[sc];
+      }
+      x1 = a1 - D.vecV1[t];
+      x2 = a2 - D.rho[t];
+      if (doFlip)
+        x3 = a3 - D.flipRhs[t];
+    }
+    if (doFlip)
+      D.flipRhs[t] = 0.0;  // consumed (nucleus rows were read by k_gemv3g)
+  } else if (t < D.m + k) {
+    int sc = t - D.m;
+    p = D.slotPos[sc];
+    x1 = D.slotC[sc];
+    x2 = D.slotD[sc];
+    x3 = D.slotE[sc];
+  }
+  double changeObj = 0.0;
+  if (p >= 0) {
+    D.w[p] = x1;
+    D.tau[p] = x2;
+    if (doFlip) {
+      int append = 0;
+      if (x3 != 0.0) {
+        int iPivot = D.pivotVariable[p];
+        double value = D.sol[iPivot];
+        value -= x3;
+        changeObj -= x3 * D.cost[iPivot];
+        D.sol[iPivot] = value;
+        if (c->pivotRule) {
+          double lower = D.lower[iPivot], upper = D.upper[iPivot];
+          double old = D.infeas[p];
+          if (value < lower - tolerance) {
+            value -= lower;
+            value *= value;
+            if (old == 0.0)
+              append = 1;
+            D.infeas[p] = value;
+          } else if (value > upper + tolerance) {
+            value -= upper;
+            value *= value;
+            if (old == 0.0)
+              append = 1;
+            D.infeas[p] = value;
+          } else if (old != 0.0) {
+            D.infeas[p] = REALLY_TINY;
+          }
+        }
+      }
+      D.appendFlag[p] = append;
+      if (append)
+        atomicAdd(&D.blockCount[p >> 8], 1);
+    }
+  }
+  double s = blockSum(changeObj, shd);
+  if (threadIdx.x == 0)
+    D.blockSum[blockIdx.x] = s;
+}
+
+// DSE weight update (needs w, tau) -- positions only
+__global__ void __launch_bounds__(256) k_weights2(Dev D, int nbNorm)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN || !c->pivotRule)
+    return;
+  __shared__ double shd[16];
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < nbNorm; b += blockDim.x)
+    acc += D.normPartial[b];
+  acc = blockSum(acc, shd);
+  const double alphaOld = c->alpha;  // still the ratio-test alpha: the accuracy test comes after
+  const double norm = acc / (alphaOld * alphaOld);
+  const double multiplier = 2.0 / alphaOld;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < D.m) {
+    double thetaW = D.w[i];
+    if (thetaW != 0.0) {
+      double devex = D.weights[i];
+      D.altWeights[i] = devex;
+      if (i == c->pivotRow) {
+        devex = (norm < DEVEX_TRY_NORM) ? DEVEX_TRY_NORM : norm;
+      } else {
+        devex += thetaW * (thetaW * norm + D.tau[i] * multiplier);
+        if (devex < DEVEX_TRY_NORM)
+          devex = DEVEX_TRY_NORM;
+      }
+      D.weights[i] = devex;
+    }
+  }
+}
+
+// flip-count scan only (the accuracy test moved to k_scan_tail(which = 1), after the FTRAN)
+__global__ void __launch_bounds__(1024) k_scan_flips(Dev D, int nb)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ int shi[17];
+  __shared__ int s_base;
+  if (threadIdx.x == 0)
+    s_base = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < nb; b0 += blockDim.x) {
+    int b = b0 + threadIdx.x;
+    int cnt = (b < nb) ? D.blockCount[b] : 0;
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int v = cnt;
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(v, o);
+      if (lane >= o)
+        v += t;
+    }
+    __syncthreads();
+    if (lane == 63)
+      shi[wv] = v;
+    __syncthreads();
+    int base = s_base;
+    for (int i = 0; i < wv; i++)
+      base += shi[i];
+    if (b < nb)
+      D.blockOffset[b] = base + v - cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tot = 0;
+      for (int i = 0; i < nw; i++)
+        tot += shi[i];
+      s_base += tot;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    c->numberFlips = s_base;
 }
 
 __global__ void k_zero(double *p, int n)
