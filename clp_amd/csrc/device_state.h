@@ -68,7 +68,7 @@ struct Ctrl {
   double chuzrTolerance;
   int chuzrNumber, chuzrStart, chuzrLast, chuzrPad;
   int classCount[4];
-  int tCount, tPad;  // ratio-test candidates by breakpoint class (k_cand_scatter)
+  int tCount, preDone;  // ratio-test candidates by breakpoint class (k_cand_scatter)
 };
 
 struct PivotRecord {  // == clpgpu_pivot_record

@@ -167,7 +167,7 @@ struct clpgpu_context {
   int updateDualsFullRecompute();
   int saveWeights(int mode);
   int statusOfProblemInDual(int type);
-  int launchIteration();
+  int launchIteration(bool firstOfBatch);
   int launchBatch();
   bool capturing = false;
   int whileIterating(int stepTarget);
@@ -1243,7 +1243,7 @@ int clpgpu_context::statusOfProblemInDual(int type)
 // ---------------------------------------------------------------------------------------------
 // one pivot = this fixed chain of launches (graph-capturable: every decision is on the device)
 // ---------------------------------------------------------------------------------------------
-int clpgpu_context::launchIteration()
+int clpgpu_context::launchIteration(bool firstOfBatch)
 {
   const int nbRows = cdiv(m, PRICE_BLOCK);
   const int nbCols = cdiv(D.lastColumn - D.firstColumn, PRICE_BLOCK);
@@ -1253,7 +1253,8 @@ int clpgpu_context::launchIteration()
   const int gk = cdiv(kc, 256);
   const bool ev = timing && !capturing && evUsed < (int)evStart.size();
   // CHUZR (+ the analytic front end of the BTRAN)
-  hipLaunchKernelGGL(k_chuzr_pre, dim3(1), dim3(64), 0, stream, D);
+  if (firstOfBatch)
+    hipLaunchKernelGGL(k_chuzr_pre, dim3(1), dim3(64), 0, stream, D);
   hipLaunchKernelGGL(k_chuzr_scan, dim3(nChzBlocks), dim3(256), 0, stream, D);
   hipLaunchKernelGGL(k_chuzr_final_btran, dim3(1), dim3(256), 0, stream, D, nChzBlocks);
   // BTRAN
@@ -1292,9 +1293,8 @@ int clpgpu_context::launchIteration()
   hipLaunchKernelGGL(k_flip_apply2, dim3(1), dim3(1024), 0, stream, D, gm);
   // one FTRAN sweep for the entering column, rho (DSE) and the flip rhs; the back end also applies
   // the flip part of the primal update
-  hipLaunchKernelGGL(k_gemv3g, dim3(cdiv(kc, 4)), dim3(256), 0, stream, D);
-  hipLaunchKernelGGL(k_ftran_scatter3, dim3(cdiv(m + kc, 256)), dim3(256), 0, stream, D);
-  hipLaunchKernelGGL(k_weights2, dim3(gm), dim3(256), 0, stream, D, gm);
+  hipLaunchKernelGGL(k_gemv3g, dim3(cdiv(kc, 16)), dim3(256), 0, stream, D);
+  hipLaunchKernelGGL(k_ftran_scatter3, dim3(cdiv(m + kc, 256)), dim3(256), 0, stream, D, gm);
   hipLaunchKernelGGL(k_scan_tail, dim3(1), dim3(1024), 0, stream, D, gm, cdiv(m + kc, 256), 1, 1);
   hipLaunchKernelGGL(k_append_scatter_abs, dim3(gm), dim3(256), 0, stream, D, 1);
   // basis update of the nucleus inverse, primal update with the entering column
@@ -1312,7 +1312,7 @@ int clpgpu_context::launchBatch()
 {
   if (!useGraph || timing) {
     for (int b = 0; b < checkEvery; b++)
-      launchIteration();
+      launchIteration(b == 0);
     return 0;
   }
   if (!graphExec || graphIterations != checkEvery) {
@@ -1322,7 +1322,7 @@ int clpgpu_context::launchBatch()
     hipError_t e = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal);
     if (e == hipSuccess) {
       for (int b = 0; b < checkEvery; b++)
-        launchIteration();
+        launchIteration(b == 0);
       e = hipStreamEndCapture(stream, &graph);
     }
     capturing = false;
@@ -1333,7 +1333,7 @@ int clpgpu_context::launchBatch()
       dropGraph();
       useGraph = 0;  // fall back to eager launches of the same chain
       for (int b = 0; b < checkEvery; b++)
-        launchIteration();
+        launchIteration(b == 0);
       return 0;
     }
     graphIterations = checkEvery;

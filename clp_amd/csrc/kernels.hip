@@ -1914,13 +1914,9 @@ __device__ void houseBody(Dev D)
 // =============================================================================================
 
 // ---- CHUZR split in three so the list scan uses the whole chip ---------------------------------
-__global__ void k_chuzr_pre(Dev D)
+__device__ void chuzrPreBody(Dev D)
 {
   Ctrl *c = D.ctrl;
-  if (c->state != RUN)
-    return;
-  if (threadIdx.x != 0)
-    return;
   if (c->stepLimit >= 0 && c->numberIterations >= c->stepLimit) {
     c->state = EXIT_STEP_LIMIT;
     return;
@@ -1966,6 +1962,22 @@ __global__ void k_chuzr_pre(Dev D)
   }
   c->chuzrTolerance = tolerance;
   c->chuzrLast = last;
+  c->preDone = 1;
+}
+
+// Start-of-pivot scalars of CHUZR.  Runs standalone at the head of a batch; inside a batch the
+// previous pivot's k_fix_house has already done it (preDone) -- unless a host-side refactorization
+// intervened, in which case that tail never ran.
+__global__ void k_chuzr_pre(Dev D)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  if (threadIdx.x != 0)
+    return;
+  if (c->preDone)
+    return;
+  chuzrPreBody(D);
 }
 
 #define CHZ_ITEMS 4
@@ -2661,6 +2673,7 @@ __global__ void __launch_bounds__(256) k_chuzr_final_btran(Dev D, int nblocks)
       }
     int chosen = bestRow;
     c->pivotRow = chosen;
+    c->preDone = 0;
     s_ok = chosen >= 0;
     if (chosen < 0) {
       c->state = EXIT_NO_PIVOT_ROW;
@@ -3184,6 +3197,9 @@ __global__ void __launch_bounds__(256) k_fix_house(Dev D)
   }
   __syncthreads();
   houseBody(D);
+  // head of the next pivot (only if this one ended normally and no exit was raised)
+  if (threadIdx.x == 0 && D.ctrl->state == RUN)
+    chuzrPreBody(D);
 }
 
 
@@ -3451,42 +3467,66 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos)
   }
 }
 
-// three right-hand sides in one sweep over Minv: entering column, DSE vector (rho), flip rhs
+// three right-hand sides in one sweep over Minv: entering column, DSE vector (rho), flip rhs.
+// The gathered right-hand sides (v[slotRow[sr]]) are staged once per workgroup in LDS (chunks of
+// GEMV_TILE slots), each wave then streams GEMV_ROWS rows of Minv against them.
+#define GEMV_TILE 2048
+#define GEMV_ROWS 4
 __global__ void __launch_bounds__(256) k_gemv3g(Dev D)
 {
   const Ctrl *c = D.ctrl;
   if (c->state != RUN)
     return;
+  __shared__ double s1[GEMV_TILE], s2[GEMV_TILE], s3[GEMV_TILE];
   const int k = c->k;
   const bool doTau = c->pivotRule != 0, doFlip = c->numberFlips != 0;
-  const int lane = threadIdx.x & 63;
-  const int wavesPerBlock = blockDim.x >> 6;
-  for (int sc = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6); sc < k; sc += gridDim.x * wavesPerBlock) {
-    const double *Mrow = D.Minv + (size_t)sc * D.ld;
-    double a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    for (int sr = lane; sr < k; sr += 64) {
-      double mv = Mrow[sr];
-      int r = D.slotRow[sr];
-      a1 += mv * D.vecV1[r];
-      if (doTau)
-        a2 += mv * D.rho[r];
-      if (doFlip)
-        a3 += mv * D.flipRhs[r];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int rowsPerBlock = 4 * GEMV_ROWS;
+  for (int base = blockIdx.x * rowsPerBlock; base < k; base += gridDim.x * rowsPerBlock) {
+    double a1[GEMV_ROWS], a2[GEMV_ROWS], a3[GEMV_ROWS];
+#pragma unroll
+    for (int q = 0; q < GEMV_ROWS; q++)
+      a1[q] = a2[q] = a3[q] = 0.0;
+    for (int t0 = 0; t0 < k; t0 += GEMV_TILE) {
+      const int tn = min(GEMV_TILE, k - t0);
+      __syncthreads();
+      for (int i = threadIdx.x; i < tn; i += blockDim.x) {
+        int r = D.slotRow[t0 + i];
+        s1[i] = D.vecV1[r];
+        s2[i] = doTau ? D.rho[r] : 0.0;
+        s3[i] = doFlip ? D.flipRhs[r] : 0.0;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < GEMV_ROWS; q++) {
+        int sc = base + wv * GEMV_ROWS + q;
+        if (sc < k) {
+          const double *Mrow = D.Minv + (size_t)sc * D.ld + t0;
+          for (int i = lane; i < tn; i += 64) {
+            double mv = Mrow[i];
+            a1[q] += mv * s1[i];
+            a2[q] += mv * s2[i];
+            a3[q] += mv * s3[i];
+          }
+        }
+      }
     }
-    a1 = waveSum(a1);
-    a2 = waveSum(a2);
-    a3 = waveSum(a3);
-    if (lane == 0) {
-      D.slotC[sc] = a1;
-      D.slotD[sc] = a2;
-      D.slotE[sc] = a3;
+#pragma unroll
+    for (int q = 0; q < GEMV_ROWS; q++) {
+      int sc = base + wv * GEMV_ROWS + q;
+      double r1 = waveSum(a1[q]), r2 = waveSum(a2[q]), r3 = waveSum(a3[q]);
+      if (lane == 0 && sc < k) {
+        D.slotC[sc] = r1;
+        D.slotD[sc] = r2;
+        D.slotE[sc] = r3;
+      }
     }
   }
 }
 
 // back end of the three FTRANs: w, tau and -- when there are flips -- x3 together with the primal
 // update it drives (ratio 1.0, ClpSimplexDual.cpp:1535-1536)
-__global__ void __launch_bounds__(256) k_ftran_scatter3(Dev D)
+__global__ void __launch_bounds__(256) k_ftran_scatter3(Dev D, int nbNorm)
 {
   const Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -3525,10 +3565,34 @@ __global__ void __launch_bounds__(256) k_ftran_scatter3(Dev D)
     x2 = D.slotD[sc];
     x3 = D.slotE[sc];
   }
+  // DSE norm for the weight update (ClpDualRowSteepest::updateWeights :516-538): sum of the
+  // per-block partials of sum rho^2; alpha is still the ratio-test alpha here
+  double norm = 0.0, multiplier = 0.0;
+  if (c->pivotRule) {
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < nbNorm; b += blockDim.x)
+      acc += D.normPartial[b];
+    acc = blockSum(acc, shd);
+    const double alphaOld = c->alpha;
+    norm = acc / (alphaOld * alphaOld);
+    multiplier = 2.0 / alphaOld;
+  }
   double changeObj = 0.0;
   if (p >= 0) {
     D.w[p] = x1;
     D.tau[p] = x2;
+    if (c->pivotRule && x1 != 0.0) {
+      double devex = D.weights[p];
+      D.altWeights[p] = devex;
+      if (p == c->pivotRow) {
+        devex = (norm < DEVEX_TRY_NORM) ? DEVEX_TRY_NORM : norm;
+      } else {
+        devex += x1 * (x1 * norm + x2 * multiplier);
+        if (devex < DEVEX_TRY_NORM)
+          devex = DEVEX_TRY_NORM;
+      }
+      D.weights[p] = devex;
+    }
     if (doFlip) {
       int append = 0;
       if (x3 != 0.0) {
