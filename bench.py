@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--pivot-rule", type=int, default=1)
     ap.add_argument("--cpu-iterations", type=int, default=-1, help="pivots for the CPU baseline (-1 auto, 0 skip)")
     ap.add_argument("--check-every", type=int, default=16)
+    ap.add_argument("--workload", default="sparse", choices=["sparse", "dense", "netlib"],
+                    help="sparse = BASELINE configs[3] (default, the quoted metric); dense = configs[2]; netlib = power-law variant")
     args = ap.parse_args()
 
     import numpy as np
@@ -64,7 +66,12 @@ def main():
     from clp_amd.engine import ClpGpuSimplex
 
     t0 = time.time()
-    lp = P.sparse_lp(args.rows, args.cols, args.nnz_per_col)
+    if args.workload == "dense":
+        lp = P.dense_lp(args.rows, args.cols)
+    elif args.workload == "netlib":
+        lp = P.netlib_shaped_lp(args.rows, args.cols, args.rows * args.cols // 1000)
+    else:
+        lp = P.sparse_lp(args.rows, args.cols, args.nnz_per_col)
     gen_s = time.time() - t0
     eng = ClpGpuSimplex(local_rank).loadProblem(lp)
     eng.set_option("pivot_rule", args.pivot_rule)
@@ -124,7 +131,7 @@ def main():
     # (profiles/r01_pmc_price_sell.txt) -- counters cannot be read from inside this process
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_price_sell.json")
-    if os.path.exists(pmc_path) and (args.rows, args.cols, args.nnz_per_col) == (50000, 200000, 50) and world == 1:
+    if os.path.exists(pmc_path) and (args.workload, args.rows, args.cols, args.nnz_per_col) == ("sparse", 50000, 200000, 50) and world == 1:
         traffic = json.load(open(pmc_path))["traffic_bytes_per_launch"]
 
     cpu = None
@@ -155,12 +162,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"sparse LP {lp.m}x{lp.n}, {len(lp.elem)} nonzeros (BASELINE.json configs[3]), "
+            "config": {"workload": f"{args.workload} LP {lp.m}x{lp.n}, {len(lp.elem)} nonzeros (BASELINE.json configs[3]), "
                                    "steepest-edge dual from the slack basis" if args.pivot_rule else "Dantzig dual",
                        "rows": int(lp.m), "cols": int(lp.n), "nnz": int(len(lp.elem)),
                        "parallelism": f"column-range pricing x{world}" if world > 1 else "1 GPU",
                        "check_every": args.check_every, "generate_s": round(gen_s, 1)},
-            "roofline": {"bound": "hbm", "kernel": "k_price (row pricing by column + first ratio pass)",
+            "roofline": {"bound": "hbm", "kernel": "k_price_sell (row pricing by column, SELL-64, fused first ratio pass)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "bytes_per_launch": per_launch_bytes, "us_per_launch": per_launch_s * 1e6,
                          "launches": int(launches), "traffic": traffic},

@@ -73,7 +73,8 @@ struct clpgpu_context {
   std::vector<void *> allocations;
   int kcap = 0, ld = 0;
   int *dKcol = nullptr, *dLocalOfRow = nullptr, *dInfo = nullptr;
-  int nSellBlocks = 0, nChzBlocks = 0, priceKernel = 2, useGraph = 1;
+  int nSellBlocks = 0, nChzBlocks = 0, priceKernel = 2, useGraph = 1, nWideBlocks = 1;
+  bool widePricing = false;
   // ---- multi-GPU (RCCL resolved at run time; a single-GPU build has no link dependency on it)
   int rank = 0, nranks = 1, shardChunk = 0;
   bool commActive = false;
@@ -384,8 +385,10 @@ int clpgpu_context::buildSell()
   rc |= dalloc(dRow, sellRow.size());
   rc |= dalloc(dElem, sellElem.size());
   nSellBlocks = cdiv(numSlices, 4);
-  rc |= dalloc(D.sellMin, nSellBlocks);
-  rc |= dalloc(D.sellBytes, nSellBlocks);
+  widePricing = count > 0 && (double)nnz / (double)n >= 256.0;
+  nWideBlocks = std::min(WIDE_BLOCKS, std::max(1, cdiv(count, 4)));
+  rc |= dalloc(D.sellMin, std::max(nSellBlocks, WIDE_BLOCKS));
+  rc |= dalloc(D.sellBytes, std::max(nSellBlocks, WIDE_BLOCKS));
   if (rc)
     return rc;
   rc |= h2d(dStart, sellStart.data(), numSlices + 1);
@@ -1263,7 +1266,9 @@ int clpgpu_context::launchIteration(bool firstOfBatch)
   if (ev)
     (void)hipEventRecord(evStart[evUsed], stream);
   if (priceKernel >= 1) {
-    if (nSellBlocks > 0)
+    if (widePricing && priceKernel != 1)
+      hipLaunchKernelGGL(k_price_wide, dim3(nWideBlocks), dim3(256), 0, stream, D);
+    else if (nSellBlocks > 0)
       hipLaunchKernelGGL(k_price_sell, dim3(nSellBlocks), dim3(256), (m > 64 * SELL_BITS_MAX || priceKernel < 2) ? 0 : (size_t)((m + 63) / 64) * 8, stream, D, (m > 64 * SELL_BITS_MAX && priceKernel > 1) ? 1 : priceKernel);
     if (ev)
       (void)hipEventRecord(evStop[evUsed++], stream);
@@ -1275,7 +1280,7 @@ int clpgpu_context::launchIteration(bool firstOfBatch)
       ncclAllGatherFn(D.candFlag + D.m + (size_t)rank * chunk, D.candFlag + D.m, chunk, 1 /* ncclUint8 */, comm, stream);
     }
     hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, commActive ? 1 : 0);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1, nSellBlocks);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1, (widePricing && priceKernel != 1) ? nWideBlocks : nSellBlocks);
   } else {
     hipLaunchKernelGGL(k_price, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
     if (ev)

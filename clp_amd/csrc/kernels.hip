@@ -2559,6 +2559,68 @@ __global__ void __launch_bounds__(256) k_price_sell(Dev D, int variant)
   }
 }
 
+// Row pricing for long columns (dense or few-column LPs): one lane per column cannot fill the chip
+// when n < ~10^5, so here a whole wave strides one CSC column (coalesced) and reduces.  The per-column
+// sum is then a fixed 64-way tree instead of the reference's sequential order: deterministic, but
+// only equal to the oracle to rounding (used when the mean column length is >= 256).
+#define WIDE_BLOCKS 4096
+__global__ void __launch_bounds__(256) k_price_wide(Dev D)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ double shd[16];
+  const double dualT = -c->dualTolerance;
+  const double acceptablePivot = c->acceptablePivot;
+  const double zeroTolerance = c->zeroTolerance;
+  const int lane = threadIdx.x & 63;
+  double ratio = 1.0e31, bytes = 0.0;
+  for (int j = D.priceFirst + blockIdx.x * 4 + (threadIdx.x >> 6); j < D.priceLast; j += gridDim.x * 4) {
+    int wanted = (D.status[j] & 3) - 1;
+    double value = 0.0;
+    int flag = 0;
+    if (wanted) {
+      const int start = D.colStart[j], end = D.colStart[j + 1];
+      double acc = 0.0;
+      for (int p = start + lane; p < end; p += 64)
+        acc += D.piNeg[D.row[p]] * D.elem[p];
+      value = waveSum(acc);
+      value = __shfl(value, 0);
+      if (lane == 0)
+        bytes += 12.0 * (end - start) + 4.0;
+      if (fabs(value) > zeroTolerance) {
+        if (lane == 0)
+          bytes += 20.0;
+        if (wanted > 0) {
+          double mult = (wanted == 1) ? -1.0 : 1.0;
+          double alpha = value * mult;
+          if (alpha > 0.0) {
+            double oldValue = D.dj[j] * mult;
+            double v2 = oldValue - 1.0e15 * alpha;
+            if (v2 < dualT) {
+              flag = 1;
+              if (alpha >= acceptablePivot)
+                ratio = fmin(ratio, (oldValue - dualT) / alpha);
+            }
+          }
+        }
+      } else {
+        value = 0.0;
+      }
+    }
+    if (lane == 0) {
+      D.alphaCol[j] = value;
+      D.candFlag[D.m + j] = (unsigned char)flag;
+    }
+  }
+  double bmin = blockMin(ratio, shd);
+  double bsum = blockSum(bytes, shd);
+  if (threadIdx.x == 0) {
+    D.sellMin[blockIdx.x] = bmin;
+    D.sellBytes[blockIdx.x] = bsum;
+  }
+}
+
 // row (slack) part of the first ratio pass + per-key-block candidate counts for the ordered
 // compaction (columns were flagged by k_price_sell in slice order; counts must be in key order)
 __global__ void __launch_bounds__(PRICE_BLOCK) k_cand_count(Dev D, int nbRows, int recomputeRatio)

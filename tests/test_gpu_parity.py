@@ -238,6 +238,17 @@ def test_degenerate_reference_instances(gpu_cls, case, rule):
     kkt(lp, g)
 
 
+@pytest.mark.parametrize("rule", [0, 1])
+def test_netlib_shaped_fake_bounds(gpu_cls, rule):
+    """Power-law columns, 20% equality rows, 10% columns without upper bound (fake bounds,
+    ClpSimplexDual::changeBounds :3148) and entries spanning 1e-3..1e3: objective / KKT parity."""
+    lp = P.netlib_shaped_lp(300, 1000, 8000, seed=9)
+    g, sg, o, so = solve_both(gpu_cls, lp, rule)
+    assert sg == so == 0
+    assert abs(g.objectiveValue() - o.objective) <= 1e-7 * (1 + abs(o.objective))
+    kkt(lp, g, tol=1e-5)
+
+
 @pytest.mark.parametrize("n", [10, 50])
 def test_infeasible(gpu_cls, n):
     g, sg, o, so = solve_both(gpu_cls, P.infeasible(n), 1)
