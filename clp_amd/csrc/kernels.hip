@@ -2562,7 +2562,7 @@ __global__ void __launch_bounds__(256) k_price_sell(Dev D, int variant)
 // Row pricing for long columns (dense or few-column LPs): one lane per column cannot fill the chip
 // when n < ~10^5, so here a whole wave strides one CSC column (coalesced) and reduces.  The per-column
 // sum is then a fixed 64-way tree instead of the reference's sequential order: deterministic, but
-// only equal to the oracle to rounding (used when the mean column length is >= 256).
+// only equal to the sequential sum to rounding (used when the mean column length is >= 256).
 #define WIDE_BLOCKS 4096
 __global__ void __launch_bounds__(256) k_price_wide(Dev D)
 {
