@@ -69,6 +69,11 @@ struct Ctrl {
   int chuzrNumber, chuzrStart, chuzrLast, chuzrPad;
   int classCount[4];
   int tCount, preDone;  // ratio-test candidates by breakpoint class (k_cand_scatter)
+  long long dbg[16];    // development counters (CLPGPU_DEBUG_STATS)
+  int ticket[8];        // "last workgroup done" counters (always 0 between launches)
+  int flipAppend, numberAppend1;
+  int appendGo, appendPad;
+  double tailAlpha, tailValueOut;  // w[pivotRow] / sol[sequenceOut] handed to the serial tail of k_ftran_scatter3  // this pivot's primal update completed: its list appends may be scattered  // unordered append count of k_dj_flags (ordered later by k_flip_apply2)
 };
 
 struct PivotRecord {  // == clpgpu_pivot_record
@@ -131,9 +136,12 @@ struct Dev {
   int *candTag;
   unsigned char *candLive;
   int *blockCount, *blockOffset;
+  int *classBlock;  // [3 * blocks] ratio-test breakpoint classes per compaction block
   double *blockMin, *blockSum;
   int *flipSeq;
+  int *flipKey;  // [FLIP_LIST_CAP] flagged bound flips in arrival order, as compaction keys
   int *appendFlag;  // [m]
+  int *appendFlag1, *blockOffset1;  // the same for the flip part of the primal update (scattered together later)
   int *touchCount;  // [m] contributors per row while the flip rhs is assembled (zero otherwise)
   // sliced-ELL copy of the priced column range: slice = 64 columns (one wave), entry t of the
   // slice's lane l at sellStart[slice] + t*64 + l; columns sorted by length so padding is ~1%
@@ -150,6 +158,9 @@ struct Dev {
   // refactorization scratch
   double *workW, *workX;  // [kcap*ld]
   int *perm;
+  double *gjL;  // [kcap * 32] multipliers of the current block (blocked re-inversion)
+  double *gjU;  // [32 * 2*ld]  pivot-row values of the current block
+  int *gjPiv;   // [32]
   Ctrl *ctrl;
   PivotRecord *log;
 };

@@ -73,8 +73,9 @@ struct clpgpu_context {
   std::vector<void *> allocations;
   int kcap = 0, ld = 0;
   int *dKcol = nullptr, *dLocalOfRow = nullptr, *dInfo = nullptr;
-  int nSellBlocks = 0, nChzBlocks = 0, priceKernel = 2, useGraph = 1, nWideBlocks = 1;
+  int nSellBlocks = 0, nChzBlocks = 0, priceKernel = 6, useGraph = 1, nWideBlocks = 1;
   bool widePricing = false;
+  int blockedRefactor = 1;
   // ---- multi-GPU (RCCL resolved at run time; a single-GPU build has no link dependency on it)
   int rank = 0, nranks = 1, shardChunk = 0;
   bool commActive = false;
@@ -284,10 +285,14 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   int nb = cdiv(m, PRICE_BLOCK) + cdiv(n, PRICE_BLOCK) + 2;
   rc |= dalloc(D.blockCount, nb);
   rc |= dalloc(D.blockOffset, nb);
+  rc |= dalloc(D.classBlock, 3 * (size_t)nb);
   rc |= dalloc(D.blockMin, nb);
   rc |= dalloc(D.blockSum, nb);
   rc |= dalloc(D.flipSeq, N);
+  rc |= dalloc(D.flipKey, FLIP_LIST_CAP);
   rc |= dalloc(D.appendFlag, m);
+  rc |= dalloc(D.appendFlag1, m);
+  rc |= dalloc(D.blockOffset1, cdiv(m, 256) + 2);
   rc |= dalloc(D.touchCount, m);
   rc |= dalloc(D.ctrl, 1);
   nChzBlocks = cdiv(m, 256 * CHZ_ITEMS);
@@ -444,6 +449,9 @@ int clpgpu_context::allocNucleus(int kNeeded)
   rc |= dalloc(D.slotF, kcap);
   rc |= dalloc(D.rhoSlot, kcap);
   rc |= dalloc(D.perm, kcap);
+  rc |= dalloc(D.gjL, (size_t)kcap * GJ_B);
+  rc |= dalloc(D.gjU, (size_t)GJ_B * 2 * ld);
+  rc |= dalloc(D.gjPiv, GJ_B);
   rc |= dalloc(dKcol, kcap);
   dropGraph();
   return rc;
@@ -528,9 +536,29 @@ int clpgpu_context::factorize()
     hipLaunchKernelGGL(k_gather_nucleus, dim3(k), dim3(64), 0, stream, D, dKcol, dLocalOfRow, k);
     hipLaunchKernelGGL(k_identity, dim3(cdiv(k, 256)), dim3(256), 0, stream, D, k);
     dim3 g2(cdiv(k, 256), k < 1024 ? k : 1024);
-    for (int i = 0; i < k; i++) {
-      hipLaunchKernelGGL(k_gj_step, dim3(1), dim3(1024), 0, stream, D, i, k, dInfo);
-      hipLaunchKernelGGL(k_gj_elim, g2, dim3(256), 0, stream, D, i, k, dInfo);
+    if (blockedRefactor) {
+      // panel width: the register-resident panel kernel holds rows-per-thread x width doubles
+      const int bs = k <= 1024 ? 32 : (k <= 3072 ? 16 : GJ_B);
+      for (int i0 = 0; i0 < k; i0 += bs) {
+        const int b = std::min(bs, k - i0);
+        const int ncols = (k - (i0 + b)) + k;
+        if (k <= 1024)
+          hipLaunchKernelGGL((k_gj_panel_reg<1, 32>), dim3(1), dim3(1024), 0, stream, D, i0, b, k, dInfo);
+        else if (k <= 2048)
+          hipLaunchKernelGGL((k_gj_panel_reg<2, 16>), dim3(1), dim3(1024), 0, stream, D, i0, b, k, dInfo);
+        else if (k <= 3072)
+          hipLaunchKernelGGL((k_gj_panel_reg<3, 16>), dim3(1), dim3(1024), 0, stream, D, i0, b, k, dInfo);
+        else
+          hipLaunchKernelGGL(k_gj_panel, dim3(1), dim3(1024), 0, stream, D, i0, b, k, dInfo);
+        hipLaunchKernelGGL(k_gj_rowswaps, dim3(cdiv(ncols, 256)), dim3(256), 0, stream, D, i0, b, k, dInfo);
+        hipLaunchKernelGGL(k_gj_upanel, dim3(cdiv(ncols, 256)), dim3(256), 0, stream, D, i0, b, k, dInfo);
+        hipLaunchKernelGGL(k_gj_trail, dim3(cdiv(ncols, 256), cdiv(k, GJ_ROWS)), dim3(256), 0, stream, D, i0, b, k, dInfo);
+      }
+    } else {
+      for (int i = 0; i < k; i++) {
+        hipLaunchKernelGGL(k_gj_step, dim3(1), dim3(1024), 0, stream, D, i, k, dInfo);
+        hipLaunchKernelGGL(k_gj_elim, g2, dim3(256), 0, stream, D, i, k, dInfo);
+      }
     }
     hipLaunchKernelGGL(k_gj_finish, g2, dim3(256), 0, stream, D, k);
     int info[4];
@@ -1279,8 +1307,9 @@ int clpgpu_context::launchIteration(bool firstOfBatch)
       ncclAllGatherFn(D.alphaCol + (size_t)rank * chunk, D.alphaCol, chunk, 8 /* ncclFloat64 */, comm, stream);
       ncclAllGatherFn(D.candFlag + D.m + (size_t)rank * chunk, D.candFlag + D.m, chunk, 1 /* ncclUint8 */, comm, stream);
     }
-    hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, commActive ? 1 : 0);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1, (widePricing && priceKernel != 1) ? nWideBlocks : nSellBlocks);
+    // the last workgroup to finish also scans the block counts (no separate launch)
+    hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, commActive ? 1 : 0,
+                       (widePricing && priceKernel != 1) ? nWideBlocks : nSellBlocks);
   } else {
     hipLaunchKernelGGL(k_price, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
     if (ev)
@@ -1289,25 +1318,20 @@ int clpgpu_context::launchIteration(bool firstOfBatch)
   }
   hipLaunchKernelGGL(k_cand_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
   // CHUZC (also unpacks the entering column)
-  hipLaunchKernelGGL(k_dual_column_small, dim3(1), dim3(64), 0, stream, D);
-  hipLaunchKernelGGL(k_dual_column, dim3(1), dim3(1024), 0, stream, D);
+  hipLaunchKernelGGL(k_dual_column, dim3(1), dim3(DC_THREADS), 0, stream, D, nb);
   // dual update + flip detection (needs only theta), flip list, flip right-hand side
   hipLaunchKernelGGL(k_dj_flags, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
-  hipLaunchKernelGGL(k_scan_flips, dim3(1), dim3(1024), 0, stream, D, nb);
-  hipLaunchKernelGGL(k_flip_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
   hipLaunchKernelGGL(k_flip_apply2, dim3(1), dim3(1024), 0, stream, D, gm);
   // one FTRAN sweep for the entering column, rho (DSE) and the flip rhs; the back end also applies
   // the flip part of the primal update
-  hipLaunchKernelGGL(k_gemv3g, dim3(cdiv(kc, 16)), dim3(256), 0, stream, D);
+  hipLaunchKernelGGL(k_gemv3g, dim3(cdiv(kc, 4)), dim3(1024), 0, stream, D);
   hipLaunchKernelGGL(k_ftran_scatter3, dim3(cdiv(m + kc, 256)), dim3(256), 0, stream, D, gm);
-  hipLaunchKernelGGL(k_scan_tail, dim3(1), dim3(1024), 0, stream, D, gm, cdiv(m + kc, 256), 1, 1);
-  hipLaunchKernelGGL(k_append_scatter_abs, dim3(gm), dim3(256), 0, stream, D, 1);
   // basis update of the nucleus inverse, primal update with the entering column
   hipLaunchKernelGGL(k_rank1, dim3(cdiv(kc, 256), kc < 512 ? kc : 512), dim3(256), 0, stream, D);
   hipLaunchKernelGGL(k_primal_update, dim3(gm), dim3(256), 0, stream, D, 0);
-  hipLaunchKernelGGL(k_scan_tail, dim3(1), dim3(1024), 0, stream, D, gm, gm, 0, 0);
-  hipLaunchKernelGGL(k_append_scatter_abs, dim3(gm), dim3(256), 0, stream, D, 0);
-  hipLaunchKernelGGL(k_fix_house, dim3(1), dim3(256), 0, stream, D);
+  // workgroup 0: fix-ups of the basis update, housekeeping, head of the next CHUZR; the others
+  // scatter this pivot's new primal infeasibilities into the list
+  hipLaunchKernelGGL(k_fix_house, dim3(1 + gm), dim3(256), 0, stream, D);
   return 0;
 }
 
@@ -1625,8 +1649,7 @@ int clpgpu_context::priceRow(int numberPi, const int *piIndex, const double *piV
   if (priceKernel >= 1) {
     if (nSellBlocks > 0)
       hipLaunchKernelGGL(k_price_sell, dim3(nSellBlocks), dim3(256), 0, stream, D, 1);
-    hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, 0);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1, nSellBlocks);
+    hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, 0, nSellBlocks);
   } else {
     hipLaunchKernelGGL(k_price, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1, 0);
@@ -2019,6 +2042,7 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "timing")) { ctx->timing = (int)v; ctx->dropGraph(); }
   else if (!strcmp(name, "price_kernel")) { ctx->priceKernel = (int)v; ctx->dropGraph(); }
   else if (!strcmp(name, "use_graph")) { ctx->useGraph = (int)v; ctx->dropGraph(); }
+  else if (!strcmp(name, "blocked_refactor")) ctx->blockedRefactor = (int)v;
   else return -1;
   return 0;
 }
@@ -2111,6 +2135,11 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
   if (ctx->pullCtrl())
     return -99;
   *stats = ctx->stats;
+  if (getenv("CLPGPU_DEBUG_STATS")) {
+    const long long *g = ctx->hCtrl->dbg;
+    fprintf(stderr, "clpgpu dbg: dc small %lld big %lld passes %lld tries %lld sumNc %lld mapped %lld full %lld ticksSmall %lld ticksBig %lld\n",
+            g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8]);
+  }
   stats->price_bytes = ctx->hCtrl->statPriceBytes;
   if (!ctx->timing)
     stats->price_launches = (long)ctx->hCtrl->statPriceLaunches;

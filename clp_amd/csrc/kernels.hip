@@ -104,6 +104,45 @@ __device__ inline int blockRank(int flag, int &total, int *sh /*[17]*/)
   return base + rank;
 }
 
+// coherent (L1-bypassing) loads: data written by other workgroups of the same launch
+__device__ inline int ldc(const int *p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline double ldc(const double *p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// coherent (write-through) stores: results another workgroup of the same launch will read with ldc()
+__device__ inline void stc(int *p, int v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void stc(double *p, double v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// "last workgroup done": true in exactly one workgroup of the launch, after every workgroup has
+// published its results.  Lets the serial tail of a grid-wide pass (scan of the per-block counts,
+// scalar bookkeeping) run inside the same launch.  The eight XCDs have separate L2s, so a
+// device-scope fence here would write back each L2 once per workgroup; instead everything the tail
+// reads is published with stc() (write-through) and read with ldc(), and the ticket only has to wait
+// for those stores to complete.
+__device__ inline bool lastBlockDone(Ctrl *c, int slot)
+{
+  __shared__ int s_last;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = __hip_atomic_fetch_add(&c->ticket[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == (int)gridDim.x - 1);
+    if (s_last)
+      __hip_atomic_store(&c->ticket[slot], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  return s_last != 0;
+}
+__device__ inline void scanTailBody(const Dev &D, int nbCount, int nbSum, int which, int alphaTest);
 __device__ inline double randomDouble(Ctrl *c)
 {
   // CoinThreadRandom::randomDouble, 32-bit LCG form [CoinUtils, not in the reference tree]
@@ -292,6 +331,8 @@ __global__ void __launch_bounds__(1024) k_chuzr(Dev D)
       D.vecC[chosen] = (double)c->directionOut;  // BTRAN input: directionOut * e_r (:1286)
       c->sequenceIn = -1;
       c->numberFlips = 0;
+      c->flipAppend = 0;
+      c->appendGo = 0;
       c->objectiveChange = 0.0;
     }
   }
@@ -478,11 +519,9 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_price(Dev D, int nbRows)
 
 // exclusive scan over per-block counts (<= 1M/256 blocks), min over per-block ratios
 // what: 0 candidates (-> numberCandidates, upperTheta), 1 flips, 2 infeasibility-list appends
-__global__ void __launch_bounds__(1024) k_scan_blocks(Dev D, int nb, int what, int iter, int nSell = 0)
+__device__ inline void scanBlocksBody(const Dev &D, int nb, int what, int nSell)
 {
   Ctrl *c = D.ctrl;
-  if (iter && c->state != RUN)
-    return;
   __shared__ int shi[17];
   __shared__ double shd[16];
   __shared__ int s_base;
@@ -493,10 +532,10 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(Dev D, int nb, int what, i
   double bytes = 0.0;
   for (int b0 = 0; b0 < nb; b0 += blockDim.x) {
     int b = b0 + threadIdx.x;
-    int cnt = (b < nb) ? D.blockCount[b] : 0;
+    int cnt = (b < nb) ? ldc(&D.blockCount[b]) : 0;
     if (what == 0 && b < nb) {
-      vmin = fmin(vmin, D.blockMin[b]);
-      bytes += D.blockSum[b];
+      vmin = fmin(vmin, ldc(&D.blockMin[b]));
+      bytes += ldc(&D.blockSum[b]);
     }
     // inclusive scan inside the block via wave ballots is for flags only; counts need a real scan
     int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -536,7 +575,6 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(Dev D, int nb, int what, i
     if (what == 0) {
       c->numberCandidates = s_base;
       c->upperTheta = vmin;
-      c->classCount[0] = c->classCount[1] = c->classCount[2] = 0;
       // algorithmic bytes of this pricing launch: per scanned column 12*len+4 (+20 per
       // emitted nonzero), plus status 1*n, pi 8*m, one extra colStart
       c->statPriceBytes += bytes + (double)(D.lastColumn - D.firstColumn) + 8.0 * D.m + 4.0;
@@ -547,6 +585,12 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(Dev D, int nb, int what, i
       c->numberAppend = s_base;
     }
   }
+}
+__global__ void __launch_bounds__(1024) k_scan_blocks(Dev D, int nb, int what, int iter, int nSell = 0)
+{
+  if (iter && D.ctrl->state != RUN)
+    return;
+  scanBlocksBody(D, nb, what, nSell);
 }
 
 __global__ void __launch_bounds__(PRICE_BLOCK) k_cand_scatter(Dev D, int nbRows)
@@ -587,11 +631,19 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_cand_scatter(Dev D, int nbRows)
     cls = (x <= theta0 * 8.0) ? 0 : ((x <= theta0 * 256.0) ? 1 : ((x <= theta0 * 16384.0) ? 2 : 3));
     D.candLive[o] = (unsigned char)cls;
   }
-  // per-class totals (integer atomics: order independent)
+  // per-class counts of this block (summed by the ratio test when it needs them)
+  __shared__ int shc[PRICE_BLOCK / 64][3];
   for (int j = 0; j < 3; j++) {
     unsigned long long mk = __ballot(cls == j);
-    if ((threadIdx.x & 63) == 0 && mk)
-      atomicAdd(&D.ctrl->classCount[j], (int)__popcll(mk));
+    if ((threadIdx.x & 63) == 0)
+      shc[threadIdx.x >> 6][j] = (int)__popcll(mk);
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    int s = 0;
+    for (int w = 0; w < PRICE_BLOCK / 64; w++)
+      s += shc[w][threadIdx.x];
+    D.classBlock[3 * blockIdx.x + threadIdx.x] = s;
   }
 }
 
@@ -604,25 +656,83 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_cand_scatter(Dev D, int nbRows)
 // List order (needed only for "first largest |alpha| wins", :4533) is candidate index order.
 // =============================================================================================
 struct DcAcc {
-  double thru, incr, ut, sumBad, bestPivot;
+  double thru, incr, ut, sumBad, bestPivot, ut2;
   int bestIdx;
+  double bestDj, bestAlpha;  // dj and signed alpha of the argmax (travel with it when F_BESTV)
 };
-// one combined block reduction (sum, sum, min, sum, argmax-first) with a single LDS exchange
-__device__ inline void dcReduce(DcAcc &a, double (*shd)[16], int *shk)
+enum { F_THRU = 1, F_INCR = 2, F_UT = 4, F_BAD = 8, F_BEST = 16, F_UT2 = 32, F_BESTV = 64 };
+// butterfly exchange inside a wave: stages 0-3 stay inside a 16-lane row (DPP quad_perm xor 1,
+// xor 2, row_half_mirror, row_mirror), stages 4-5 cross rows.  Both partners combine the same two
+// values with a commutative operation, so every lane ends with bit-identical results and no
+// broadcast is needed; the tree is fixed => deterministic.
+template <int STAGE> __device__ inline int xchgI(int v)
 {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int o = 32; o > 0; o >>= 1) {
-    a.thru += __shfl_down(a.thru, o);
-    a.incr += __shfl_down(a.incr, o);
-    a.sumBad += __shfl_down(a.sumBad, o);
-    a.ut = fmin(a.ut, __shfl_down(a.ut, o));
-    double ov = __shfl_down(a.bestPivot, o);
-    int ok = __shfl_down(a.bestIdx, o);
+  if constexpr (STAGE == 0)
+    return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);
+  else if constexpr (STAGE == 1)
+    return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);
+  else if constexpr (STAGE == 2)
+    return __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false);
+  else if constexpr (STAGE == 3)
+    return __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false);
+  else if constexpr (STAGE == 4)
+    return __shfl_xor(v, 16);
+  else
+    return __shfl_xor(v, 32);
+}
+template <int STAGE> __device__ inline double xchgD(double v)
+{
+  if constexpr (STAGE < 4)
+    return __hiloint2double(xchgI<STAGE>(__double2hiint(v)), xchgI<STAGE>(__double2loint(v)));
+  else
+    return __shfl_xor(v, STAGE == 4 ? 16 : 32);
+}
+template <int F, int STAGE> __device__ inline void dcStage(DcAcc &a)
+{
+  if constexpr (F & F_THRU)
+    a.thru += xchgD<STAGE>(a.thru);
+  if constexpr (F & F_INCR)
+    a.incr += xchgD<STAGE>(a.incr);
+  if constexpr (F & F_BAD)
+    a.sumBad += xchgD<STAGE>(a.sumBad);
+  if constexpr (F & F_UT)
+    a.ut = fmin(a.ut, xchgD<STAGE>(a.ut));
+  if constexpr (F & F_UT2)
+    a.ut2 = fmin(a.ut2, xchgD<STAGE>(a.ut2));
+  if constexpr (F & F_BEST) {
+    double ov = xchgD<STAGE>(a.bestPivot);
+    int ok = xchgI<STAGE>(a.bestIdx);
+    double od = 0.0, oa = 0.0;
+    if constexpr (F & F_BESTV) {
+      od = xchgD<STAGE>(a.bestDj);
+      oa = xchgD<STAGE>(a.bestAlpha);
+    }
     if (ok >= 0 && (a.bestIdx < 0 || ov > a.bestPivot || (ov == a.bestPivot && ok < a.bestIdx))) {
       a.bestPivot = ov;
       a.bestIdx = ok;
+      if constexpr (F & F_BESTV) {
+        a.bestDj = od;
+        a.bestAlpha = oa;
+      }
     }
   }
+}
+// all-lanes result of the combined reduction (sum, sum, min, sum, argmax-first, min) inside one
+// wave: no LDS, no barrier
+template <int F> __device__ inline void dcReduceWave(DcAcc &a)
+{
+  dcStage<F, 0>(a);
+  dcStage<F, 1>(a);
+  dcStage<F, 2>(a);
+  dcStage<F, 3>(a);
+  dcStage<F, 4>(a);
+  dcStage<F, 5>(a);
+}
+// the same across a workgroup with a single LDS exchange
+template <int F> __device__ inline void dcReduce(DcAcc &a, double (*shd)[16], int *shk)
+{
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  dcReduceWave<F>(a);
   __syncthreads();
   if (lane == 0) {
     shd[0][wv] = a.thru;
@@ -630,55 +740,48 @@ __device__ inline void dcReduce(DcAcc &a, double (*shd)[16], int *shk)
     shd[2][wv] = a.ut;
     shd[3][wv] = a.sumBad;
     shd[4][wv] = a.bestPivot;
+    shd[5][wv] = a.ut2;
+    shd[6][wv] = a.bestDj;
+    shd[7][wv] = a.bestAlpha;
     shk[wv] = a.bestIdx;
   }
   __syncthreads();
   a.thru = a.incr = a.sumBad = 0.0;
   a.ut = shd[2][0];
+  a.ut2 = shd[5][0];
   a.bestPivot = shd[4][0];
   a.bestIdx = shk[0];
+  a.bestDj = shd[6][0];
+  a.bestAlpha = shd[7][0];
   for (int i = 0; i < nw; i++) {
-    a.thru += shd[0][i];
-    a.incr += shd[1][i];
-    a.sumBad += shd[3][i];
-    a.ut = fmin(a.ut, shd[2][i]);
-    if (i && shk[i] >= 0 && (a.bestIdx < 0 || shd[4][i] > a.bestPivot || (shd[4][i] == a.bestPivot && shk[i] < a.bestIdx))) {
-      a.bestPivot = shd[4][i];
-      a.bestIdx = shk[i];
+    if constexpr (F & F_THRU)
+      a.thru += shd[0][i];
+    if constexpr (F & F_INCR)
+      a.incr += shd[1][i];
+    if constexpr (F & F_BAD)
+      a.sumBad += shd[3][i];
+    if constexpr (F & F_UT)
+      a.ut = fmin(a.ut, shd[2][i]);
+    if constexpr (F & F_UT2)
+      a.ut2 = fmin(a.ut2, shd[5][i]);
+    if constexpr (F & F_BEST) {
+      if (i && shk[i] >= 0 && (a.bestIdx < 0 || shd[4][i] > a.bestPivot || (shd[4][i] == a.bestPivot && shk[i] < a.bestIdx))) {
+        a.bestPivot = shd[4][i];
+        a.bestIdx = shk[i];
+        a.bestDj = shd[6][i];
+        a.bestAlpha = shd[7][i];
+      }
     }
   }
 }
 
 // CPT > 0: every thread keeps CPT candidates (alpha, dj, range, state) in registers, a pass is
-// pure ALU + one block reduction; CPT == 0: candidates stay in global memory (very long rows).
-// all-lanes result of the combined reduction inside one wave (no LDS, no barrier)
-__device__ inline void dcReduceWave(DcAcc &a)
-{
-  for (int o = 32; o > 0; o >>= 1) {
-    a.thru += __shfl_down(a.thru, o);
-    a.incr += __shfl_down(a.incr, o);
-    a.sumBad += __shfl_down(a.sumBad, o);
-    a.ut = fmin(a.ut, __shfl_down(a.ut, o));
-    double ov = __shfl_down(a.bestPivot, o);
-    int ok = __shfl_down(a.bestIdx, o);
-    if (ok >= 0 && (a.bestIdx < 0 || ov > a.bestPivot || (ov == a.bestPivot && ok < a.bestIdx))) {
-      a.bestPivot = ov;
-      a.bestIdx = ok;
-    }
-  }
-  a.thru = __shfl(a.thru, 0);
-  a.incr = __shfl(a.incr, 0);
-  a.sumBad = __shfl(a.sumBad, 0);
-  a.ut = __shfl(a.ut, 0);
-  a.bestPivot = __shfl(a.bestPivot, 0);
-  a.bestIdx = __shfl(a.bestIdx, 0);
-}
-
+// pure ALU + one reduction; CPT == 0: candidates stay in global memory (very long rows).
 template <int CPT, bool ONEWAVE, bool MAPPED = false>
-__device__ bool dualColumnImpl(Dev D, const int *map = nullptr, int count = -1, double tauGuard = 0.0)
+__device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nullptr, int count = -1, double tauGuard = 0.0)
 {
   Ctrl *c = D.ctrl;
-  __shared__ double shd[5][16];
+  __shared__ double shd[8][16];
   __shared__ int shk[16];
   const int tid = threadIdx.x, nthr = ONEWAVE ? 64 : blockDim.x;
   const int nc = MAPPED ? count : c->numberCandidates;  // MAPPED: a prefiltered working set (see k_dual_column)
@@ -686,15 +789,23 @@ __device__ bool dualColumnImpl(Dev D, const int *map = nullptr, int count = -1, 
   const double dualTolerance = c->dualTolerance;
   const double newTolerance = dualTolerance;
   const double absDualOut = fabs(c->dualOut);
-  auto reduce = [&](DcAcc &a) {
+  auto reduce = [&](DcAcc &a, auto fields) {
+    constexpr int F = decltype(fields)::value;
     if constexpr (ONEWAVE)
-      dcReduceWave(a);
+      dcReduceWave<F>(a);
     else
-      dcReduce(a, shd, shk);
+      dcReduce<F>(a, shd, shk);
   };
   constexpr int R = CPT > 0 ? CPT : 1;
-  double ra[R], rd[R], rr[R];
+  double ra[R], rd[R], rr[R], rq[R];
   int rt[R], ri[R];
+  // a candidate's breakpoint (:4392/:4410 and :4448/:4455 compute the same quotient every pass);
+  // 1e50 (never the minimum) when |alpha| is below the acceptable pivot
+  auto breakpoint = [&](double alpha, double djv) {
+    if (alpha < 0.0)
+      return (-alpha >= acceptablePivot) ? (djv - newTolerance) / alpha : 1.0e50;
+    return (alpha >= acceptablePivot) ? (djv + newTolerance) / alpha : 1.0e50;
+  };
   bool rl[R];
   if constexpr (CPT > 0) {
 #pragma unroll
@@ -704,6 +815,7 @@ __device__ bool dualColumnImpl(Dev D, const int *map = nullptr, int count = -1, 
       rt[q] = -1;
       ri[q] = -1;
       ra[q] = rd[q] = rr[q] = 0.0;
+      rq[q] = 1.0e50;
       if (pos < nc) {
         int i = MAPPED ? map[pos] : pos;  // original candidate index: the list order for ties
         ri[q] = i;
@@ -711,6 +823,7 @@ __device__ bool dualColumnImpl(Dev D, const int *map = nullptr, int count = -1, 
         ra[q] = D.candAlpha[i];
         rd[q] = D.dj[seq];
         rr[q] = D.upper[seq] - D.lower[seq];
+        rq[q] = breakpoint(ra[q], rd[q]);
         rl[q] = true;
       }
     }
@@ -726,14 +839,15 @@ __device__ bool dualColumnImpl(Dev D, const int *map = nullptr, int count = -1, 
 #pragma unroll
       for (int q = 0; q < R; q++) {
         if (ri[q] >= 0)
-          body(ri[q], ra[q], rd[q], rr[q], rl[q], rt[q]);
+          body(ri[q], ra[q], rd[q], rr[q], rq[q], rl[q], rt[q]);
       }
     } else {
       for (int i = tid; i < nc; i += nthr) {
         int seq = D.candSeq[i];
         bool live = D.candLive[i] != 0;
         int tag = D.candTag[i];
-        body(i, D.candAlpha[i], D.dj[seq], D.upper[seq] - D.lower[seq], live, tag);
+        double alpha = D.candAlpha[i], djv = D.dj[seq];
+        body(i, alpha, djv, D.upper[seq] - D.lower[seq], breakpoint(alpha, djv), live, tag);
         D.candLive[i] = live ? 1 : 0;
         D.candTag[i] = tag;
       }
@@ -750,14 +864,19 @@ __device__ bool dualColumnImpl(Dev D, const int *map = nullptr, int count = -1, 
   double theta = 1.0e50;
   double tentativeTheta = fmax(10.0 * upperTheta, 1.0e-7);
   const double lastPivot = 0.0;  // never updated in the reference either (:4207)
+  long long dbgT0 = wall_clock64();
+  int dbgPasses = 0, dbgTries = 0;
   while (tentativeTheta < 1.0e22) {
+    dbgPasses++;
     // a prefiltered run is only valid while theta stays below the threshold every excluded
     // candidate is known to exceed; otherwise the caller redoes the test on the full list
     if (MAPPED && tentativeTheta >= tauGuard)
       return false;
     // ---- coarse pass (:4355-4417)
-    DcAcc acc = { 0.0, 0.0, 1.0e50, 0.0, acceptablePivot, -1 };
-    forEach([&](int i, double alpha, double oldValue, double range, bool &live, int &tag) {
+    // ut2: smallest breakpoint among the candidates this pass swaps -- the first upperTheta of
+    // the inner loop below, should the pivot turn out to be in this batch (:4441-4462)
+    DcAcc acc = { 0.0, 0.0, 1.0e50, 0.0, acceptablePivot, 1.0e50, -1, 0.0, 0.0 };
+    forEach([&](int i, double alpha, double oldValue, double range, double ratio, bool &live, int &tag) {
       if (!live)
         return;
       double value = oldValue - tentativeTheta * alpha;
@@ -771,8 +890,9 @@ __device__ bool dualColumnImpl(Dev D, const int *map = nullptr, int count = -1, 
             acc.bestPivot = fabs(alpha);
             acc.bestIdx = i;
           }
-        } else if (-alpha >= acceptablePivot) {
-          acc.ut = fmin(acc.ut, (oldValue - newTolerance) / alpha);
+          acc.ut2 = fmin(acc.ut2, ratio);
+        } else {
+          acc.ut = fmin(acc.ut, ratio);
         }
       } else {
         if (value < -newTolerance) {
@@ -784,12 +904,13 @@ __device__ bool dualColumnImpl(Dev D, const int *map = nullptr, int count = -1, 
             acc.bestPivot = fabs(alpha);
             acc.bestIdx = i;
           }
-        } else if (alpha >= acceptablePivot) {
-          acc.ut = fmin(acc.ut, (oldValue + newTolerance) / alpha);
+          acc.ut2 = fmin(acc.ut2, ratio);
+        } else {
+          acc.ut = fmin(acc.ut, ratio);
         }
       }
     });
-    reduce(acc);
+    reduce(acc, std::integral_constant<int, F_THRU | F_INCR | F_UT | F_BEST | F_UT2>());
     double thruThis = acc.thru, increaseInThis = acc.incr, bestPivot = acc.bestPivot;
     int bestIdx = acc.bestIdx;
     upperTheta = acc.ut;
@@ -800,31 +921,22 @@ __device__ bool dualColumnImpl(Dev D, const int *map = nullptr, int count = -1, 
     check += 1.0e-8 + 1.0e-10 * check;
     if (check >= absDualOut || increaseInObjective + increaseInThis < 0.0) {
       // ---- pivot in this batch: the list becomes the swapped set of this pass (:4427-4434)
-      forEach([&](int, double, double, double, bool &live, int &tag) { live = (tag == passId); });
+      forEach([&](int, double, double, double, double, bool &live, int &tag) { live = (tag == passId); });
       if constexpr (CPT == 0)
         __syncthreads();
       int iTry;
       const int MAXTRY = 100;
+      double nextUt = acc.ut2;
       for (iTry = 0; iTry < MAXTRY; iTry++) {
         passId++;
-        DcAcc a1 = { 0.0, 0.0, 1.0e50, 0.0, acceptablePivot, -1 };
-        forEach([&](int, double alpha, double oldValue, double, bool &live, int &) {
-          if (!live)
-            return;
-          if (alpha < 0.0) {
-            if (-alpha >= acceptablePivot)
-              a1.ut = fmin(a1.ut, (oldValue - newTolerance) / alpha);
-          } else {
-            if (alpha >= acceptablePivot)
-              a1.ut = fmin(a1.ut, (oldValue + newTolerance) / alpha);
-          }
-        });
-        reduce(a1);
-        upperTheta = a1.ut;
+        dbgTries++;
+        // smallest remaining breakpoint of the live set (:4441-4462); it was computed by the pass
+        // that produced the live set (the coarse pass, or the previous trip's removal pass)
+        upperTheta = nextUt;
         badSumPivots = 0;
         upperTheta *= 1.0000000001;
-        DcAcc a2 = { 0.0, 0.0, 1.0e50, 0.0, acceptablePivot, -1 };
-        forEach([&](int i, double alpha, double djv, double range, bool &live, int &tag) {
+        DcAcc a2 = { 0.0, 0.0, 1.0e50, 0.0, acceptablePivot, 1.0e50, -1, 0.0, 0.0 };
+        forEach([&](int i, double alpha, double djv, double range, double ratio, bool &live, int &tag) {
           if (!live)
             return;
           double value = djv - upperTheta * alpha;
@@ -848,6 +960,8 @@ __device__ bool dualColumnImpl(Dev D, const int *map = nullptr, int count = -1, 
             if (absAlpha > a2.bestPivot) {
               a2.bestPivot = absAlpha;
               a2.bestIdx = i;
+              a2.bestDj = djv;
+              a2.bestAlpha = alpha;
             }
             if (absAlpha < acceptablePivot && upperTheta < 1.0e20) {
               if (alpha < 0.0) {
@@ -860,9 +974,12 @@ __device__ bool dualColumnImpl(Dev D, const int *map = nullptr, int count = -1, 
             }
             a2.thru += range * fabs(alpha);
             a2.incr += badDj * range;
+          } else {
+            a2.ut = fmin(a2.ut, ratio);
           }
         });
-        reduce(a2);
+        reduce(a2, std::integral_constant<int, F_THRU | F_INCR | F_UT | F_BAD | F_BEST | F_BESTV>());
+        nextUt = a2.ut;
         thruThis = a2.thru;
         increaseInThis = a2.incr;
         bestPivot = a2.bestPivot;
@@ -872,7 +989,7 @@ __device__ bool dualColumnImpl(Dev D, const int *map = nullptr, int count = -1, 
           bestPivot = acceptablePivot;
         seqIdx = bestIdx;
         if (bestIdx >= 0)
-          theta = D.dj[D.candSeq[bestIdx]] / D.candAlpha[bestIdx];
+          theta = a2.bestDj / a2.bestAlpha;  // dj / alpha of the chosen candidate (:4566)
         if (sumBadPivots > 1.0e4) {
           if (c->pivots > 3) {
             badSumPivots = 1;
@@ -948,7 +1065,7 @@ __device__ bool dualColumnImpl(Dev D, const int *map = nullptr, int count = -1, 
       // cost shifting so everything that went through stays dual feasible (:4705-4772)
       const int sidFinal = sid[iFlip];
       int changed = 0;
-      forEach([&](int i, double alpha, double djv, double, bool &, int &tag) {
+      forEach([&](int i, double alpha, double djv, double, double, bool &, int &tag) {
         if (tag != sidFinal)
           return;
         int iSequence = D.candSeq[i];
@@ -971,8 +1088,8 @@ __device__ bool dualColumnImpl(Dev D, const int *map = nullptr, int count = -1, 
           }
         }
       });
-      DcAcc a3 = { (double)changed, 0.0, 1.0e50, 0.0, 0.0, -1 };
-      reduce(a3);
+      DcAcc a3 = { (double)changed, 0.0, 1.0e50, 0.0, 0.0, 1.0e50, -1, 0.0, 0.0 };
+      reduce(a3, std::integral_constant<int, F_THRU>());
       if (tid == 0)
         c->numberChanged += (int)a3.thru;
     }
@@ -990,6 +1107,12 @@ __device__ bool dualColumnImpl(Dev D, const int *map = nullptr, int count = -1, 
       D.vecV1[D.row[p]] = D.elem[p];
   }
   if (tid == 0) {
+    c->dbg[ONEWAVE ? 0 : 1]++;
+    c->dbg[2] += dbgPasses;
+    c->dbg[3] += dbgTries;
+    c->dbg[4] += nc;
+    c->dbg[ONEWAVE ? 7 : 8] += wall_clock64() - dbgT0;
+    c->dbg[MAPPED ? 5 : 6]++;
     c->badSumPivots = badSumPivots;
     c->modifyCosts = modifyCosts;
     if (sequenceIn >= 0) {
@@ -1034,17 +1157,28 @@ __device__ bool dualColumnImpl(Dev D, const int *map = nullptr, int count = -1, 
   return true;
 }
 
-#define DC_CPT 4
+#define DC_CPT 8
+#define DC_THREADS 512
 #define DC_SMALL (8 * 64)
-// typical sparse tableau row: one wave, candidates in registers, shuffle-only reductions
-__global__ void __launch_bounds__(64) k_dual_column_small(Dev D)
+#define DC_WS_CAP (DC_CPT * DC_THREADS)
+// One launch, 512 threads (256 VGPRs per lane available: no spills).
+//  * typical sparse tableau row (<= 512 candidates): wave 0 alone, candidates in registers,
+//    reductions are register butterflies -- no LDS, no barrier;
+//  * long candidate lists (dense rows, up to ~n/2 entries): only the few dozen candidates with the
+//    smallest breakpoints ever take part in the passes, the rest only bound theta from above.
+//    k_cand_scatter classified every candidate by its breakpoint against theta0 * {2^3, 2^8, 2^14};
+//    the largest class prefix that fits in registers becomes the working set, the test runs on it,
+//    and is repeated on the full list only if theta ever reaches the class threshold (exact either
+//    way).
+__global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass)
 {
   Ctrl *c = D.ctrl;
   if (c->state != RUN)
     return;
   const int nc = c->numberCandidates;
+  const int tid = threadIdx.x;
   if (!nc) {
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
       c->sequenceIn = -1;
       c->alpha = 0.0;
       c->bestPossible = 0.0;
@@ -1052,33 +1186,39 @@ __global__ void __launch_bounds__(64) k_dual_column_small(Dev D)
     }
     return;
   }
-  if (nc <= 4 * 64)
-    dualColumnImpl<4, true>(D);
-  else if (nc <= DC_SMALL)
-    dualColumnImpl<8, true>(D);
-}
-// Long candidate lists (dense tableau rows, up to ~n/2 entries).  Only the few dozen candidates
-// with the smallest breakpoints ever take part in the passes; the rest only bound theta from above.
-// k_cand_scatter classified every candidate by its breakpoint against theta0 * {2^3, 2^8, 2^14};
-// the largest class prefix that fits in registers becomes the working set, the test runs on it, and
-// is repeated on the full list only if theta ever reaches the class threshold (exact either way).
-#define DC_WS_CAP (DC_CPT * 1024)
-__global__ void __launch_bounds__(1024) k_dual_column(Dev D)
-{
-  Ctrl *c = D.ctrl;
-  if (c->state != RUN)
+  if (nc <= DC_SMALL) {
+    if (tid < 64) {
+      if (nc <= 4 * 64)
+        dualColumnImpl<4, true>(D);
+      else
+        dualColumnImpl<8, true>(D);
+    }
     return;
-  const int nc = c->numberCandidates;
-  if (nc <= DC_SMALL)
-    return;  // handled (or rejected) by k_dual_column_small
+  }
   __shared__ int wsIdx[DC_WS_CAP];
   __shared__ int shw[17];
   __shared__ int s_done;
-  const int tid = threadIdx.x;
-  int cum[3];
-  cum[0] = c->classCount[0];
-  cum[1] = cum[0] + c->classCount[1];
-  cum[2] = cum[1] + c->classCount[2];
+  __shared__ int shCls[DC_THREADS / 64][3];
+  int cum[3] = { 0, 0, 0 };
+  for (int b = tid; b < nbClass; b += blockDim.x) {
+    cum[0] += D.classBlock[3 * b];
+    cum[1] += D.classBlock[3 * b + 1];
+    cum[2] += D.classBlock[3 * b + 2];
+  }
+  for (int j = 0; j < 3; j++) {
+    for (int o = 32; o > 0; o >>= 1)
+      cum[j] += __shfl_xor(cum[j], o);
+    if ((tid & 63) == 0)
+      shCls[tid >> 6][j] = cum[j];
+  }
+  __syncthreads();
+  for (int j = 0; j < 3; j++) {
+    cum[j] = 0;
+    for (int w = 0; w < DC_THREADS / 64; w++)
+      cum[j] += shCls[w][j];
+  }
+  cum[1] += cum[0];
+  cum[2] += cum[1];
   int J = -1;
   for (int j = 0; j < 3; j++)
     if (cum[j] <= DC_WS_CAP && cum[j] < nc)
@@ -1115,7 +1255,6 @@ __global__ void __launch_bounds__(1024) k_dual_column(Dev D)
     __syncthreads();
     bool ok;
     if (ws <= DC_SMALL) {
-      ok = true;
       if (tid < 64) {
         ok = dualColumnImpl<8, true, true>(D, wsIdx, ws, tau);
         if (tid == 0)
@@ -1527,14 +1666,20 @@ __global__ void __launch_bounds__(256) k_primal_update(Dev D, int which)
       }
     }
     D.appendFlag[p] = append;
+    // the leaving row stays on the list with a tiny value (:705-706); done by its owner here
+    if (which == 0 && c->pivotRule && p == c->pivotRow && D.infeas[p] != 0.0)
+      D.infeas[p] = REALLY_TINY;
   }
   int total;
   blockRank(append, total, shi);
   double s = blockSum(changeObj, shd);
   if (threadIdx.x == 0) {
-    D.blockCount[blockIdx.x] = total;
-    D.blockSum[blockIdx.x] = s;
+    stc(&D.blockCount[blockIdx.x], total);
+    stc(&D.blockSum[blockIdx.x], s);
   }
+  // serial tail (offsets of the appends, objective change) in the last workgroup to finish
+  if (which == 0 && lastBlockDone(D.ctrl, 2))
+    scanTailBody(D, gridDim.x, gridDim.x, 0, 0);
 }
 
 __global__ void __launch_bounds__(256) k_append_scatter(Dev D, int which, int iter)
@@ -2148,6 +2293,8 @@ __global__ void __launch_bounds__(256) k_chuzr_final(Dev D, int nblocks)
   D.vecC[chosen] = (double)c->directionOut;
   c->sequenceIn = -1;
   c->numberFlips = 0;
+  c->flipAppend = 0;
+  c->appendGo = 0;
   c->objectiveChange = 0.0;
 }
 
@@ -2405,7 +2552,7 @@ __global__ void __launch_bounds__(256) k_after_primal2(Dev D, int nb, int which)
 #define SELL_BITS_MAX 8192  // 64-bit words of the pi bitmap kept in LDS (rows <= 524288)
 // PIPE: software-pipelined loads; NT: non-temporal matrix loads; BITS: gather pi only where the
 // row's bit is set (pi is sparse for most pivots: the gather traffic scales with nnz(pi)/m)
-template <bool PIPE, bool NT, bool BITS> __device__ inline void priceSellBody(Dev D, unsigned long long *bits)
+template <bool PIPE, bool NT, bool BITS, bool COND = false> __device__ inline void priceSellBody(Dev D, unsigned long long *bits)
 {
   const Ctrl *c = D.ctrl;
   __shared__ double shd[16];
@@ -2416,10 +2563,27 @@ template <bool PIPE, bool NT, bool BITS> __device__ inline void priceSellBody(De
   const int lane = threadIdx.x & 63;
   const int slice = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nwords = (D.m + 63) >> 6;
+  bool sparsePi = false;
   if (BITS) {
-    for (int w = threadIdx.x; w < nwords; w += blockDim.x)
-      bits[w] = D.piBits[w];
-    __syncthreads();
+    int pop = 0;
+    for (int w = threadIdx.x; w < nwords; w += blockDim.x) {
+      unsigned long long word = D.piBits[w];
+      bits[w] = word;
+      pop += __popcll(word);
+    }
+    if (COND) {
+      // nnz(pi) decides between the conditional-fetch loop and the plain stream (uniform per launch)
+      __shared__ int shPop[4];
+      for (int o = 32; o > 0; o >>= 1)
+        pop += __shfl_xor(pop, o);
+      if ((threadIdx.x & 63) == 0)
+        shPop[threadIdx.x >> 6] = pop;
+      __syncthreads();
+      pop = shPop[0] + shPop[1] + shPop[2] + shPop[3];
+      sparsePi = 12 * (long long)pop < (long long)D.m;
+    } else {
+      __syncthreads();
+    }
   }
   auto piAt = [&](int r) -> double {
     if (BITS) {
@@ -2479,6 +2643,31 @@ template <bool PIPE, bool NT, bool BITS> __device__ inline void priceSellBody(De
               e0[u] = e1[u];
             }
           }
+        }
+      } else if (COND && sparsePi) {
+        // pi is sparse: stream the row indices, fetch element and pi only where the row's bit is
+        // set.  Skipped products are exact zeros in the unconditional loop, so the sum is the same.
+        for (int t = 0; t < maxLen; t += SELL_U) {
+          int r[SELL_U];
+          double e[SELL_U], pv[SELL_U];
+          bool hit[SELL_U];
+#pragma unroll
+          for (int u = 0; u < SELL_U; u++)
+            r[u] = rp[(t + u) * 64];
+#pragma unroll
+          for (int u = 0; u < SELL_U; u++) {
+            hit[u] = (t + u < len) && ((bits[r[u] >> 6] >> (r[u] & 63)) & 1ull);
+            e[u] = 0.0;
+            pv[u] = 0.0;
+            if (hit[u]) {
+              e[u] = ep[(t + u) * 64];
+              pv[u] = D.piNeg[r[u]];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < SELL_U; u++)
+            if (hit[u])
+              value += pv[u] * e[u];
         }
       } else {
         for (int t = 0; t < maxLen; t += SELL_U) {
@@ -2553,6 +2742,9 @@ __global__ void __launch_bounds__(256) k_price_sell(Dev D, int variant)
   case 5:
     priceSellBody<false, true, true>(D, sellBits);
     break;
+  case 6:
+    priceSellBody<false, false, true, true>(D, sellBits);
+    break;
   default:
     priceSellBody<false, false, false>(D, sellBits);
     break;
@@ -2623,7 +2815,7 @@ __global__ void __launch_bounds__(256) k_price_wide(Dev D)
 
 // row (slack) part of the first ratio pass + per-key-block candidate counts for the ordered
 // compaction (columns were flagged by k_price_sell in slice order; counts must be in key order)
-__global__ void __launch_bounds__(PRICE_BLOCK) k_cand_count(Dev D, int nbRows, int recomputeRatio)
+__global__ void __launch_bounds__(PRICE_BLOCK) k_cand_count(Dev D, int nbRows, int recomputeRatio, int nSell)
 {
   const Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -2675,10 +2867,12 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_cand_count(Dev D, int nbRows, i
   blockRank(flag, total, shi);
   double bmin = blockMin(ratio, shd);
   if (threadIdx.x == 0) {
-    D.blockCount[blockIdx.x] = total;
-    D.blockMin[blockIdx.x] = bmin;
-    D.blockSum[blockIdx.x] = 0.0;
+    stc(&D.blockCount[blockIdx.x], total);
+    stc(&D.blockMin[blockIdx.x], bmin);
+    stc(&D.blockSum[blockIdx.x], 0.0);
   }
+  if (lastBlockDone(D.ctrl, 0))
+    scanBlocksBody(D, gridDim.x, 0, nSell);
 }
 
 
@@ -2772,6 +2966,8 @@ __global__ void __launch_bounds__(256) k_chuzr_final_btran(Dev D, int nblocks)
       D.vecC[chosen] = (double)c->directionOut;
       c->sequenceIn = -1;
       c->numberFlips = 0;
+      c->flipAppend = 0;
+      c->appendGo = 0;
       c->objectiveChange = 0.0;
     }
   }
@@ -2805,32 +3001,6 @@ __global__ void __launch_bounds__(256) k_chuzr_final_btran(Dev D, int nblocks)
     }
     if (threadIdx.x == 0)
       c->tCount = cnt;
-  }
-}
-
-// one kernel for every candidate count: <= 1024 one wave (16 per lane), <= 4096 four waves
-__global__ void __launch_bounds__(256) k_dual_column_fused(Dev D)
-{
-  Ctrl *c = D.ctrl;
-  if (c->state != RUN)
-    return;
-  const int nc = c->numberCandidates;
-  if (!nc) {
-    if (threadIdx.x == 0) {
-      c->sequenceIn = -1;
-      c->alpha = 0.0;
-      c->bestPossible = 0.0;
-      c->state = EXIT_NO_INCOMING;
-    }
-    return;
-  }
-  if (nc <= 16 * 64) {
-    if (threadIdx.x < 64)
-      dualColumnImpl<16, true>(D);
-  } else if (nc <= 16 * 256) {
-    dualColumnImpl<16, false>(D);
-  } else {
-    dualColumnImpl<0, false>(D);
   }
 }
 
@@ -3082,11 +3252,9 @@ __global__ void __launch_bounds__(256) k_ftran_scatter_flip(Dev D, const double 
 }
 
 // append scan with absolute offsets + the scalar tail that used to be k_after_primal2
-__global__ void __launch_bounds__(1024) k_scan_tail(Dev D, int nbCount, int nbSum, int which, int alphaTest = 0)
+__device__ inline void scanTailBody(const Dev &D, int nbCount, int nbSum, int which, int alphaTest)
 {
   Ctrl *c = D.ctrl;
-  if (c->state != RUN)
-    return;
   __shared__ int shi[17];
   __shared__ double shd[16];
   __shared__ int s_base;
@@ -3097,7 +3265,7 @@ __global__ void __launch_bounds__(1024) k_scan_tail(Dev D, int nbCount, int nbSu
   if (active) {
     for (int b0 = 0; b0 < nbCount; b0 += blockDim.x) {
       int b = b0 + threadIdx.x;
-      int cnt = (b < nbCount) ? D.blockCount[b] : 0;
+      int cnt = (b < nbCount) ? ldc(&D.blockCount[b]) : 0;
       int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
       int v = cnt;
       for (int o = 1; o < 64; o <<= 1) {
@@ -3113,7 +3281,7 @@ __global__ void __launch_bounds__(1024) k_scan_tail(Dev D, int nbCount, int nbSu
       for (int i = 0; i < wv; i++)
         base += shi[i];
       if (b < nbCount)
-        D.blockOffset[b] = base + v - cnt;
+        (which == 1 ? D.blockOffset1 : D.blockOffset)[b] = base + v - cnt;
       __syncthreads();
       if (threadIdx.x == 0) {
         int tot = 0;
@@ -3127,26 +3295,26 @@ __global__ void __launch_bounds__(1024) k_scan_tail(Dev D, int nbCount, int nbSu
   double s = 0.0;
   if (active)
     for (int b = threadIdx.x; b < nbSum; b += blockDim.x)
-      s += D.blockSum[b];
+      s += ldc(&D.blockSum[b]);
   s = blockSum(s, shd);
   if (threadIdx.x != 0)
     return;
   if (active) {
     c->objectiveChange += s;
-    c->numberAppend = s_base - c->numberInfeasible;
-    c->numberInfeasible = s_base;
-    if (c->pivotRule) {
-      int iRow = c->pivotRow;
-      if (D.infeas[iRow] != 0.0)
-        D.infeas[iRow] = REALLY_TINY;
+    if (which == 1)
+      c->numberAppend1 = s_base - c->numberInfeasible;
+    else {
+      c->numberAppend = s_base - c->numberInfeasible;
+      c->appendGo = 1;
     }
+    c->numberInfeasible = s_base;
   } else {
-    c->numberAppend = 0;
+    c->numberAppend1 = 0;
   }
   if (which == 1) {
     if (alphaTest) {
       // btran/ftran alpha accuracy test (whileIterating :1447-1501)
-      double alphaNew = D.w[c->pivotRow];
+      double alphaNew = ldc(&c->tailAlpha);
       double btranAlpha = c->btranAlpha;
       double checkValue = 1.0e-7;
       if (c->largestPrimalError > 10.0)
@@ -3171,7 +3339,7 @@ __global__ void __launch_bounds__(1024) k_scan_tail(Dev D, int nbCount, int nbSu
     }
     double oldDualOut = c->dualOut;
     if (c->numberFlips) {
-      c->valueOut = D.sol[c->sequenceOut];
+      c->valueOut = ldc(&c->tailValueOut);
       if (c->directionOut < 0)
         c->dualOut = c->valueOut - c->upperOut;
       else
@@ -3200,7 +3368,6 @@ __global__ void __launch_bounds__(1024) k_scan_tail(Dev D, int nbCount, int nbSu
     c->slotRowIn = inStruct ? -1 : D.slotOfRow[seqIn - D.n];
   }
 }
-
 __global__ void __launch_bounds__(256) k_append_scatter_abs(Dev D, int which)
 {
   const Ctrl *c = D.ctrl;
@@ -3228,6 +3395,32 @@ __global__ void __launch_bounds__(256) k_house(Dev D)
 __global__ void __launch_bounds__(256) k_fix_house(Dev D)
 {
   const Ctrl *c = D.ctrl;
+  if (blockIdx.x > 0) {
+    // (gated by appendGo, not by state: workgroup 0 may raise an exit for the NEXT pivot while
+    // these are still starting, and this pivot's entries must reach the list regardless)
+    if (!c->appendGo)
+      return;
+    // new entries of the infeasibility list (ClpDualRowSteepest::updatePrimalSolution :630-744 adds
+    // them as it goes: first those of the flip update, then those of the main update, each in
+    // position order); the offsets come from the two scans
+    __shared__ int shi[17];
+    const int blk = blockIdx.x - 1;
+    const int p = blk * blockDim.x + threadIdx.x;
+    int total;
+    if (c->numberFlips != 0 && c->numberAppend1 != 0) {
+      int flag = (p < D.m) ? D.appendFlag1[p] : 0;
+      int rank = blockRank(flag, total, shi);
+      if (flag)
+        D.infIndex[D.blockOffset1[blk] + rank] = p;
+    }
+    if (c->numberAppend != 0) {
+      int flag = (p < D.m) ? D.appendFlag[p] : 0;
+      int rank = blockRank(flag, total, shi);
+      if (flag)
+        D.infIndex[D.blockOffset[blk] + rank] = p;
+    }
+    return;
+  }
   if (c->state != RUN)
     return;
   const int k = c->k;
@@ -3271,16 +3464,16 @@ __global__ void __launch_bounds__(256) k_fix_house(Dev D)
 // =============================================================================================
 
 // dual update + flip detection only (the weights need the FTRAN and come later)
+#define FLIP_LIST_CAP 4096
 __global__ void __launch_bounds__(PRICE_BLOCK) k_dj_flags(Dev D, int nbRows)
 {
-  const Ctrl *c = D.ctrl;
+  Ctrl *c = D.ctrl;
   if (c->state != RUN)
     return;
-  __shared__ int shi[17];
   const double theta = c->theta;
   const double tolerance = c->dualTolerance + fmin(1.0e-2, c->largestDualError);
   const int seqIn = c->sequenceIn;
-  int flag = 0;
+  int flag = 0, key = -1;
   if ((int)blockIdx.x < nbRows) {
     int i = blockIdx.x * PRICE_BLOCK + threadIdx.x;
     if (i < D.m) {
@@ -3298,6 +3491,7 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_dj_flags(Dev D, int nbRows)
         }
       }
       D.candFlag[i] = (unsigned char)flag;
+      key = i;
     }
   } else {
     int j = D.firstColumn + ((int)blockIdx.x - nbRows) * PRICE_BLOCK + threadIdx.x;
@@ -3315,12 +3509,24 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_dj_flags(Dev D, int nbRows)
         }
       }
       D.candFlag[D.m + j] = (unsigned char)flag;
+      key = D.m + j;
     }
   }
-  int total;
-  blockRank(flag, total, shi);
-  if (threadIdx.x == 0)
-    D.blockCount[blockIdx.x] = total;
+  // flips are few: append them in arrival order (one atomic per wave that has any); k_flip_apply2
+  // puts them in list order (rows, then columns ascending) before anything depends on the order
+  unsigned long long mk = __ballot(flag);
+  if (mk) {
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0)
+      base = atomicAdd(&c->flipAppend, (int)__popcll(mk));
+    base = __shfl(base, 0);
+    if (flag) {
+      int o = base + __popcll(mk & ((1ull << lane) - 1ull));
+      if (o < FLIP_LIST_CAP)
+        D.flipKey[o] = key;
+    }
+  }
 }
 
 // Flip right-hand side, all flips at once (matrix_->add per flipped column, src/ClpPackedMatrix.cpp
@@ -3328,10 +3534,9 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_dj_flags(Dev D, int nbRows)
 // directly; rows hit by several flips are collected, ordered by (row, flip) and summed in flip order,
 // so the result is bit-identical to the sequential loop of the reference whatever the schedule.
 // sequential form (very many flips or dense columns): flips in order, entries of one column in parallel
-__device__ void flipSequential(Dev D)
+__device__ void flipSequential(const Dev &D, int nf)
 {
   Ctrl *c = D.ctrl;
-  const int nf = c->numberFlips;
   const int tid = threadIdx.x;
   double changeObj = 0.0;
   for (int f = 0; f < nf; f++) {
@@ -3364,13 +3569,78 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos)
   Ctrl *c = D.ctrl;
   if (c->state != RUN)
     return;
-  const int nf = c->numberFlips;
   const int tid = threadIdx.x;
   // counters of k_ftran_scatter3's appends (position blocks) are reset here, flips or not
   for (int b = tid; b < nbPos; b += blockDim.x)
     D.blockCount[b] = 0;
-  if (nf == 0)
-    return;
+  const int nraw = c->flipAppend;
+  if (nraw == 0)
+    return;  // numberFlips was zeroed by CHUZR
+  // ---- the flip list in reference order (rows first, then columns ascending)
+  __shared__ int s_seq[FLIP_LIST_CAP];
+  __shared__ int shw[17];
+  int nf;
+  if (nraw <= FLIP_LIST_CAP) {
+    for (int i = tid; i < nraw; i += blockDim.x)
+      s_seq[i] = D.flipKey[i];
+    __syncthreads();
+    int myKey[FLIP_LIST_CAP / 1024], myRank[FLIP_LIST_CAP / 1024];
+#pragma unroll
+    for (int q = 0; q < FLIP_LIST_CAP / 1024; q++) {
+      int i = tid + q * 1024;
+      myKey[q] = -1;
+      myRank[q] = 0;
+      if (i < nraw) {
+        int key = s_seq[i], rank = 0;
+        for (int j = 0; j < nraw; j++)
+          rank += s_seq[j] < key;  // keys are distinct
+        myKey[q] = key;
+        myRank[q] = rank;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < FLIP_LIST_CAP / 1024; q++) {
+      if (myKey[q] >= 0) {
+        int seq = myKey[q] < D.m ? D.n + myKey[q] : myKey[q] - D.m;
+        s_seq[myRank[q]] = seq;
+        D.flipSeq[myRank[q]] = seq;
+      }
+    }
+    nf = nraw;
+  } else {
+    // more flips than the append buffer holds: ordered compaction of the flags by this workgroup
+    const int N = D.m + D.n;
+    const int per = (N + (int)blockDim.x - 1) / (int)blockDim.x;
+    const int lo = min(N, tid * per), hi = min(N, lo + per);
+    int cnt = 0;
+    for (int i = lo; i < hi; i++)
+      cnt += D.candFlag[i] != 0 && (i < D.m || (i - D.m >= D.firstColumn && i - D.m < D.lastColumn));
+    const int lane = tid & 63, wv = tid >> 6;
+    int v = cnt;
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(v, o);
+      if (lane >= o)
+        v += t;
+    }
+    if (lane == 63)
+      shw[wv] = v;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); i++) {
+      if (i < wv)
+        base += shw[i];
+      tot += shw[i];
+    }
+    int o = base + v - cnt;
+    for (int i = lo; i < hi; i++)
+      if (D.candFlag[i] != 0 && (i < D.m || (i - D.m >= D.firstColumn && i - D.m < D.lastColumn)))
+        D.flipSeq[o++] = i < D.m ? D.n + i : i - D.m;
+    nf = tot;
+  }
+  if (tid == 0)
+    c->numberFlips = nf;
+  __syncthreads();
   __shared__ double s_mv[FLIP_MAX_FLIPS];
   __shared__ int s_start[FLIP_MAX_FLIPS + 1];
   __shared__ int s_cRow[FLIP_MAX_COLLIDE], s_cFlip[FLIP_MAX_COLLIDE], s_cSorted[FLIP_MAX_COLLIDE];
@@ -3382,7 +3652,7 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos)
   if (!fallback) {
     // per-flip scalars
     for (int f = tid; f < nf; f += blockDim.x) {
-      int seq = D.flipSeq[f];
+      int seq = s_seq[f];
       int iStatus = (D.status[seq] & 3) - 1;
       double mult = (iStatus == 1) ? -1.0 : 1.0;
       double mv;
@@ -3416,7 +3686,7 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos)
     fallback = s_total > FLIP_MAX_ENTRIES;
   }
   if (fallback) {
-    flipSequential(D);
+    flipSequential(D, nf);
     return;
   }
   const int total = s_total;
@@ -3437,7 +3707,7 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos)
           hi = mid;
       }
       int f = lo;
-      int seq = D.flipSeq[f];
+      int seq = s_seq[f];
       int r;
       double v;
       if (seq >= D.n) {
@@ -3470,7 +3740,7 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos)
         if (myRow[q] >= 0)
           D.touchCount[myRow[q]] = 0;
       __syncthreads();
-      flipSequential(D);
+      flipSequential(D, nf);
       return;
     }
   }
@@ -3533,22 +3803,21 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos)
 // The gathered right-hand sides (v[slotRow[sr]]) are staged once per workgroup in LDS (chunks of
 // GEMV_TILE slots), each wave then streams GEMV_ROWS rows of Minv against them.
 #define GEMV_TILE 2048
-#define GEMV_ROWS 4
-__global__ void __launch_bounds__(256) k_gemv3g(Dev D)
+#define GEMV_ROWS 1
+__global__ void __launch_bounds__(1024) k_gemv3g(Dev D)
 {
   const Ctrl *c = D.ctrl;
   if (c->state != RUN)
     return;
   __shared__ double s1[GEMV_TILE], s2[GEMV_TILE], s3[GEMV_TILE];
+  __shared__ double part[16][3];
   const int k = c->k;
   const bool doTau = c->pivotRule != 0, doFlip = c->numberFlips != 0;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int rowsPerBlock = 4 * GEMV_ROWS;
-  for (int base = blockIdx.x * rowsPerBlock; base < k; base += gridDim.x * rowsPerBlock) {
-    double a1[GEMV_ROWS], a2[GEMV_ROWS], a3[GEMV_ROWS];
-#pragma unroll
-    for (int q = 0; q < GEMV_ROWS; q++)
-      a1[q] = a2[q] = a3[q] = 0.0;
+  const int rowInBlock = wv >> 2, li = (wv & 3) * 64 + lane;  // 4 waves share one row of Minv
+  for (int base = blockIdx.x * 4; base < k; base += gridDim.x * 4) {
+    const int sc = base + rowInBlock;
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0;
     for (int t0 = 0; t0 < k; t0 += GEMV_TILE) {
       const int tn = min(GEMV_TILE, k - t0);
       __syncthreads();
@@ -3559,29 +3828,27 @@ __global__ void __launch_bounds__(256) k_gemv3g(Dev D)
         s3[i] = doFlip ? D.flipRhs[r] : 0.0;
       }
       __syncthreads();
-#pragma unroll
-      for (int q = 0; q < GEMV_ROWS; q++) {
-        int sc = base + wv * GEMV_ROWS + q;
-        if (sc < k) {
-          const double *Mrow = D.Minv + (size_t)sc * D.ld + t0;
-          for (int i = lane; i < tn; i += 64) {
-            double mv = Mrow[i];
-            a1[q] += mv * s1[i];
-            a2[q] += mv * s2[i];
-            a3[q] += mv * s3[i];
-          }
+      if (sc < k) {
+        const double *Mrow = D.Minv + (size_t)sc * D.ld + t0;
+        for (int i = li; i < tn; i += 256) {
+          double mv = Mrow[i];
+          a1 += mv * s1[i];
+          a2 += mv * s2[i];
+          a3 += mv * s3[i];
         }
       }
     }
-#pragma unroll
-    for (int q = 0; q < GEMV_ROWS; q++) {
-      int sc = base + wv * GEMV_ROWS + q;
-      double r1 = waveSum(a1[q]), r2 = waveSum(a2[q]), r3 = waveSum(a3[q]);
-      if (lane == 0 && sc < k) {
-        D.slotC[sc] = r1;
-        D.slotD[sc] = r2;
-        D.slotE[sc] = r3;
-      }
+    double r1 = waveSum(a1), r2 = waveSum(a2), r3 = waveSum(a3);
+    if (lane == 0) {
+      part[wv][0] = r1;
+      part[wv][1] = r2;
+      part[wv][2] = r3;
+    }
+    __syncthreads();
+    if ((wv & 3) == 0 && lane < 3 && sc < k) {
+      double r = ((part[wv][lane] + part[wv + 1][lane]) + part[wv + 2][lane]) + part[wv + 3][lane];
+      double *dst = lane == 0 ? D.slotC : (lane == 1 ? D.slotD : D.slotE);
+      dst[sc] = r;
     }
   }
 }
@@ -3683,14 +3950,28 @@ __global__ void __launch_bounds__(256) k_ftran_scatter3(Dev D, int nbNorm)
           }
         }
       }
-      D.appendFlag[p] = append;
+      D.appendFlag1[p] = append;
       if (append)
         atomicAdd(&D.blockCount[p >> 8], 1);
+    }
+    if (p == c->pivotRow) {
+      // hand-over to the serial tail: alpha from the FTRAN, the leaving variable's value after the
+      // flip update; the leaving row keeps a tiny entry on the list (:705-706)
+      stc(&D.ctrl->tailAlpha, x1);
+      if (doFlip) {
+        stc(&D.ctrl->tailValueOut, D.sol[D.pivotVariable[p]]);
+        if (c->pivotRule && D.infeas[p] != 0.0)
+          D.infeas[p] = REALLY_TINY;
+      }
     }
   }
   double s = blockSum(changeObj, shd);
   if (threadIdx.x == 0)
-    D.blockSum[blockIdx.x] = s;
+    stc(&D.blockSum[blockIdx.x], s);
+  // serial tail in the last workgroup to finish: append offsets, objective change, the btran/ftran
+  // alpha test and the scalar set-up of the basis update
+  if (lastBlockDone(D.ctrl, 1))
+    scanTailBody(D, nbNorm, gridDim.x, 1, 1);
 }
 
 // DSE weight update (needs w, tau) -- positions only
@@ -3948,6 +4229,340 @@ __global__ void __launch_bounds__(256) k_gj_elim(Dev D, int i, int k, int *info)
     }
   }
 }
+// ---- blocked form of the same elimination (GJ_B steps per launch group).  Every element still
+// receives its updates one step at a time in step order (multiply, then subtract), so W, X, the
+// pivot choices and therefore Minv and pivotVariable are bit-identical to the step-by-step kernels
+// above; what changes is that W and X are read and written once per block instead of once per step.
+#define GJ_B 32
+// panel: pivot search, row swap, multipliers and the updates of the panel's own columns, one workgroup
+__global__ void __launch_bounds__(1024) k_gj_panel(Dev D, int i0, int b, int k, int *info)
+{
+  __shared__ double shv[16];
+  __shared__ int shk[16];
+  __shared__ int s_row;
+  __shared__ double s_prow[GJ_B];
+  __shared__ double s_inv;
+  if (info[0])
+    return;
+  const int tid = threadIdx.x;
+  for (int s = 0; s < b; s++) {
+    const int i = i0 + s;
+    double best = D.ctrl->zeroTolerance;
+    int key = -1;
+    for (int j = i + tid; j < k; j += blockDim.x) {
+      double v = fabs(D.workW[(size_t)j * D.ld + i]);
+      if (v > best) {
+        best = v;
+        key = j;
+      }
+    }
+    blockArgMax(best, key, shv, shk);
+    if (tid == 0) {
+      s_row = key;
+      if (key < 0)
+        info[0] = 1 + i;
+      D.gjPiv[s] = key;
+    }
+    __syncthreads();
+    const int iRow = s_row;
+    if (iRow < 0)
+      return;
+    if (iRow != i) {
+      if (tid < b) {
+        size_t a = (size_t)i * D.ld + i0 + tid, c2 = (size_t)iRow * D.ld + i0 + tid;
+        double t = D.workW[a];
+        D.workW[a] = D.workW[c2];
+        D.workW[c2] = t;
+      } else if (tid >= 64 && tid - 64 < s) {
+        int t2 = tid - 64;
+        double t = D.gjL[(size_t)i * GJ_B + t2];
+        D.gjL[(size_t)i * GJ_B + t2] = D.gjL[(size_t)iRow * GJ_B + t2];
+        D.gjL[(size_t)iRow * GJ_B + t2] = t;
+      } else if (tid == 128) {
+        int t = D.perm[i];
+        D.perm[i] = D.perm[iRow];
+        D.perm[iRow] = t;
+      }
+    }
+    __syncthreads();
+    if (tid < b)
+      s_prow[tid] = D.workW[(size_t)i * D.ld + i0 + tid];
+    if (tid == 0) {
+      double inv = 1.0 / D.workW[(size_t)i * D.ld + i];
+      s_inv = inv;
+      D.slotB[i] = inv;
+    }
+    __syncthreads();
+    const double inv = s_inv;
+    for (int r = tid; r < k; r += blockDim.x) {
+      if (r == i) {
+        D.gjL[(size_t)r * GJ_B + s] = 0.0;
+      } else {
+        double *Wr = D.workW + (size_t)r * D.ld + i0;
+        double l = Wr[s] * inv;
+        D.gjL[(size_t)r * GJ_B + s] = l;
+        if (l != 0.0)
+          for (int t = s + 1; t < b; t++)
+            Wr[t] -= s_prow[t] * l;
+      }
+    }
+    __syncthreads();
+  }
+}
+// register-resident panel: thread t owns rows t, t+1024, ... (k <= 1024*GJ_RPT) and keeps their
+// GJ_B panel values in registers for all steps.  Rows never move between threads: each row carries
+// the position the reference's row interchanges would have put it at (pos), the pivot search
+// compares positions for "first largest wins", and only the pivot row travels (through LDS).  The
+// multipliers are stored under the row's home index as they are produced; the few rows whose final
+// position differs are permuted once at the end.  Same arithmetic, same pivots as k_gj_panel.  The
+// panel's own columns are dead after the block (only L, the pivots and the trailing columns are
+// used), so nothing is written back to W.
+struct GjShared {
+  double shv[16];
+  int shk[16];
+  int row;
+  int nMoved;
+  double prow[GJ_B];
+  int movedPos[2 * GJ_B];
+  double movedL[2 * GJ_B][GJ_B];
+};
+// one elimination step with the step index a compile-time constant (keeps v[][] in registers);
+// returns false when the panel turned out singular
+template <int S, int GJ_RPT, int BB>
+__device__ __forceinline__ bool gjPanelStep(const Dev &D, double (&v)[GJ_RPT][BB], int (&pos)[GJ_RPT], GjShared &sh, int i0, int k,
+                                            int *info)
+{
+  const int tid = threadIdx.x;
+  const int i = i0 + S;
+  double best = D.ctrl->zeroTolerance;
+  int key = -1;
+#pragma unroll
+  for (int q = 0; q < GJ_RPT; q++) {
+    if (pos[q] >= i) {  // rows beyond k carry pos = -1
+      double a = fabs(v[q][S]);
+      if (a > best || (a == best && key >= 0 && pos[q] < key)) {
+        best = a;
+        key = pos[q];
+      }
+    }
+  }
+  blockArgMax(best, key, sh.shv, sh.shk);
+  if (tid == 0) {
+    sh.row = key;
+    if (key < 0)
+      info[0] = 1 + i;
+    D.gjPiv[S] = key;
+  }
+  __syncthreads();
+  const int iRow = sh.row;
+  if (iRow < 0)
+    return false;
+  // the pivot row publishes itself and takes position i; the row that sat at i goes to iRow
+#pragma unroll
+  for (int q = 0; q < GJ_RPT; q++) {
+    if (pos[q] == iRow) {
+#pragma unroll
+      for (int t = 0; t < BB; t++)
+        sh.prow[t] = v[q][t];
+      pos[q] = i;
+    } else if (pos[q] == i) {
+      pos[q] = iRow;
+    }
+  }
+  __syncthreads();
+  const double inv = 1.0 / sh.prow[S];
+  if (tid == 0)
+    D.slotB[i] = inv;
+#pragma unroll
+  for (int q = 0; q < GJ_RPT; q++) {
+    const int r = tid + q * 1024;
+    if (r < k) {
+      if (pos[q] == i) {
+        D.gjL[(size_t)r * GJ_B + S] = 0.0;
+      } else {
+        double l = v[q][S] * inv;
+        D.gjL[(size_t)r * GJ_B + S] = l;
+        if (l != 0.0) {
+#pragma unroll
+          for (int t = S + 1; t < BB; t++)
+            v[q][t] -= sh.prow[t] * l;
+        }
+      }
+    }
+  }
+  // no barrier here: prow is next written after the two barriers of the next pivot search
+  return true;
+}
+template <int S, int GJ_RPT, int BB> struct GjPanelRun {
+  static __device__ __forceinline__ bool run(const Dev &D, double (&v)[GJ_RPT][BB], int (&pos)[GJ_RPT], GjShared &sh, int i0, int b,
+                                             int k, int *info)
+  {
+    if (S >= b)
+      return true;
+    if (!gjPanelStep<S, GJ_RPT, BB>(D, v, pos, sh, i0, k, info))
+      return false;
+    return GjPanelRun<S + 1, GJ_RPT, BB>::run(D, v, pos, sh, i0, b, k, info);
+  }
+};
+template <int GJ_RPT, int BB> struct GjPanelRun<BB, GJ_RPT, BB> {
+  static __device__ __forceinline__ bool run(const Dev &, double (&)[GJ_RPT][BB], int (&)[GJ_RPT], GjShared &, int, int, int, int *)
+  {
+    return true;
+  }
+};
+template <int GJ_RPT, int BB> __global__ void __launch_bounds__(1024) k_gj_panel_reg(Dev D, int i0, int b, int k, int *info)
+{
+  __shared__ GjShared sh;
+  if (info[0])
+    return;
+  const int tid = threadIdx.x;
+  double v[GJ_RPT][BB];
+  int pos[GJ_RPT], permOld[GJ_RPT];
+#pragma unroll
+  for (int q = 0; q < GJ_RPT; q++) {
+    int r = tid + q * 1024;
+    pos[q] = r < k ? r : -1;
+    permOld[q] = r < k ? D.perm[r] : 0;
+#pragma unroll
+    for (int t = 0; t < BB; t++)
+      v[q][t] = (r < k && t < b) ? D.workW[(size_t)r * D.ld + i0 + t] : 0.0;
+  }
+  if (tid == 0)
+    sh.nMoved = 0;
+  if (!GjPanelRun<0, GJ_RPT, BB>::run(D, v, pos, sh, i0, b, k, info))
+    return;
+  __syncthreads();
+  // rows that ended at another position: move their multipliers and their perm entry there
+#pragma unroll
+  for (int q = 0; q < GJ_RPT; q++) {
+    int r = tid + q * 1024;
+    if (r < k && pos[q] != r) {
+      int slot = atomicAdd(&sh.nMoved, 1);
+      sh.movedPos[slot] = pos[q];
+      for (int t = 0; t < b; t++)
+        sh.movedL[slot][t] = D.gjL[(size_t)r * GJ_B + t];
+      D.perm[pos[q]] = permOld[q];
+    }
+  }
+  __syncthreads();
+  const int nMoved = sh.nMoved;
+  for (int e = tid; e < nMoved * b; e += 1024) {
+    int slot = e / b, t = e - slot * b;
+    D.gjL[(size_t)sh.movedPos[slot] * GJ_B + t] = sh.movedL[slot][t];
+  }
+}
+// the block's row swaps applied to everything outside the panel: W columns >= i0+b and all of X
+__global__ void k_gj_rowswaps(Dev D, int i0, int b, int k, int *info)
+{
+  if (info[0])
+    return;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nW = k - (i0 + b);
+  double *base;
+  int c;
+  if (t < nW) {
+    base = D.workW;
+    c = i0 + b + t;
+  } else if (t < nW + k) {
+    base = D.workX;
+    c = t - nW;
+  } else {
+    return;
+  }
+  for (int s = 0; s < b; s++) {
+    int i = i0 + s, iRow = D.gjPiv[s];
+    if (iRow != i) {
+      size_t a = (size_t)i * D.ld + c, a2 = (size_t)iRow * D.ld + c;
+      double v = base[a];
+      base[a] = base[a2];
+      base[a2] = v;
+    }
+  }
+}
+// U[s][c]: value of pivot row i0+s in column c at the time of step s
+__global__ void k_gj_upanel(Dev D, int i0, int b, int k, int *info)
+{
+  if (info[0])
+    return;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nW = k - (i0 + b);
+  const double *base;
+  int c;
+  if (t < nW) {
+    base = D.workW;
+    c = i0 + b + t;
+  } else if (t < nW + k) {
+    base = D.workX;
+    c = t - nW;
+  } else {
+    return;
+  }
+  double u[GJ_B];
+#pragma unroll
+  for (int s = 0; s < GJ_B; s++) {
+    u[s] = 0.0;
+    if (s < b) {
+      double a = base[(size_t)(i0 + s) * D.ld + c];
+      const double *Lr = D.gjL + (size_t)(i0 + s) * GJ_B;
+#pragma unroll
+      for (int s2 = 0; s2 < s; s2++) {
+        double l = Lr[s2];
+        if (l != 0.0)
+          a -= u[s2] * l;
+      }
+      u[s] = a;
+      D.gjU[(size_t)s * (2 * D.ld) + t] = a;
+    }
+  }
+}
+// every element outside the panel: a -= U[s][c] * L[r][s] for s = 0..b-1 in order (skipping r == i0+s)
+#define GJ_ROWS 32
+__global__ void __launch_bounds__(256) k_gj_trail(Dev D, int i0, int b, int k, int *info)
+{
+  if (info[0])
+    return;
+  __shared__ double sL[GJ_ROWS][GJ_B];
+  const int r0 = blockIdx.y * GJ_ROWS;
+  for (int e = threadIdx.x; e < GJ_ROWS * GJ_B; e += blockDim.x) {
+    int rr = e / GJ_B, s = e % GJ_B;
+    sL[rr][s] = (r0 + rr < k && s < b) ? D.gjL[(size_t)(r0 + rr) * GJ_B + s] : 0.0;
+  }
+  __syncthreads();
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nW = k - (i0 + b);
+  double *base;
+  int c;
+  if (t < nW) {
+    base = D.workW;
+    c = i0 + b + t;
+  } else if (t < nW + k) {
+    base = D.workX;
+    c = t - nW;
+  } else {
+    return;
+  }
+  double u[GJ_B];
+#pragma unroll
+  for (int s = 0; s < GJ_B; s++)
+    u[s] = (s < b) ? D.gjU[(size_t)s * (2 * D.ld) + t] : 0.0;
+  const int rEnd = min(GJ_ROWS, k - r0);
+  for (int rr = 0; rr < rEnd; rr++) {
+    const int r = r0 + rr;
+    double a = base[(size_t)r * D.ld + c];
+    bool changed = false;
+#pragma unroll
+    for (int s = 0; s < GJ_B; s++) {
+      double l = sL[rr][s];
+      if (l != 0.0 && r != i0 + s) {
+        a -= u[s] * l;
+        changed = true;
+      }
+    }
+    if (changed)
+      base[(size_t)r * D.ld + c] = a;
+  }
+}
+
 // Minv = D^-1 X
 __global__ void __launch_bounds__(256) k_gj_finish(Dev D, int k)
 {
