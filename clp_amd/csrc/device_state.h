@@ -71,6 +71,7 @@ struct Ctrl {
   int tCount, preDone;  // ratio-test candidates by breakpoint class (k_cand_scatter)
   long long dbg[16];    // development counters (CLPGPU_DEBUG_STATS)
   int ticket[8];        // "last workgroup done" counters (always 0 between launches)
+  int ticketGroup[4][64];  // first level of the same: one counter per 32 workgroups (<= 2048 workgroups)
   int flipAppend, numberAppend1;
   int appendGo, appendPad;
   double tailAlpha, tailValueOut;  // w[pivotRow] / sol[sequenceOut] handed to the serial tail of k_ftran_scatter3  // this pivot's primal update completed: its list appends may be scattered  // unordered append count of k_dj_flags (ordered later by k_flip_apply2)

@@ -538,16 +538,18 @@ int clpgpu_context::factorize()
     dim3 g2(cdiv(k, 256), k < 1024 ? k : 1024);
     if (blockedRefactor) {
       // panel width: the register-resident panel kernel holds rows-per-thread x width doubles
-      const int bs = k <= 1024 ? 32 : (k <= 3072 ? 16 : GJ_B);
+      const int bs = k <= 1024 ? 32 : (k <= 3072 ? 16 : (k <= 4096 ? 8 : GJ_B));
       for (int i0 = 0; i0 < k; i0 += bs) {
         const int b = std::min(bs, k - i0);
         const int ncols = (k - (i0 + b)) + k;
         if (k <= 1024)
-          hipLaunchKernelGGL((k_gj_panel_reg<1, 32>), dim3(1), dim3(1024), 0, stream, D, i0, b, k, dInfo);
+          hipLaunchKernelGGL((k_gj_panel_reg<2, 32, 512>), dim3(1), dim3(512), 0, stream, D, i0, b, k, dInfo);
         else if (k <= 2048)
-          hipLaunchKernelGGL((k_gj_panel_reg<2, 16>), dim3(1), dim3(1024), 0, stream, D, i0, b, k, dInfo);
+          hipLaunchKernelGGL((k_gj_panel_reg<4, 16, 512>), dim3(1), dim3(512), 0, stream, D, i0, b, k, dInfo);
         else if (k <= 3072)
-          hipLaunchKernelGGL((k_gj_panel_reg<3, 16>), dim3(1), dim3(1024), 0, stream, D, i0, b, k, dInfo);
+          hipLaunchKernelGGL((k_gj_panel_reg<6, 16, 512>), dim3(1), dim3(512), 0, stream, D, i0, b, k, dInfo);
+        else if (k <= 4096)
+          hipLaunchKernelGGL((k_gj_panel_reg<8, 8, 512>), dim3(1), dim3(512), 0, stream, D, i0, b, k, dInfo);
         else
           hipLaunchKernelGGL(k_gj_panel, dim3(1), dim3(1024), 0, stream, D, i0, b, k, dInfo);
         hipLaunchKernelGGL(k_gj_rowswaps, dim3(cdiv(ncols, 256)), dim3(256), 0, stream, D, i0, b, k, dInfo);
@@ -1307,9 +1309,13 @@ int clpgpu_context::launchIteration(bool firstOfBatch)
       ncclAllGatherFn(D.alphaCol + (size_t)rank * chunk, D.alphaCol, chunk, 8 /* ncclFloat64 */, comm, stream);
       ncclAllGatherFn(D.candFlag + D.m + (size_t)rank * chunk, D.candFlag + D.m, chunk, 1 /* ncclUint8 */, comm, stream);
     }
-    // the last workgroup to finish also scans the block counts (no separate launch)
-    hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, commActive ? 1 : 0,
-                       (widePricing && priceKernel != 1) ? nWideBlocks : nSellBlocks);
+    {
+      const int nSell = (widePricing && priceKernel != 1) ? nWideBlocks : nSellBlocks;
+      const bool fuse = nb <= 256;  // small grids: the last workgroup scans the counts itself
+      hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, commActive ? 1 : 0, fuse ? nSell : -1);
+      if (!fuse)
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1, nSell);
+    }
   } else {
     hipLaunchKernelGGL(k_price, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
     if (ev)
@@ -2137,8 +2143,8 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
   *stats = ctx->stats;
   if (getenv("CLPGPU_DEBUG_STATS")) {
     const long long *g = ctx->hCtrl->dbg;
-    fprintf(stderr, "clpgpu dbg: dc small %lld big %lld passes %lld tries %lld sumNc %lld mapped %lld full %lld ticksSmall %lld ticksBig %lld\n",
-            g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8]);
+    fprintf(stderr, "clpgpu dbg: dc small %lld big %lld passes %lld tries %lld sumNc %lld mapped %lld full %lld ticksSmall %lld ticksBig %lld | flip iters %lld flips %lld entries %lld sequential %lld\n",
+            g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9], g[10], g[11], g[12]);
   }
   stats->price_bytes = ctx->hCtrl->statPriceBytes;
   if (!ctx->timing)

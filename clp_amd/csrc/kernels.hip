@@ -134,10 +134,24 @@ __device__ inline bool lastBlockDone(Ctrl *c, int slot)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   if (threadIdx.x == 0) {
-    int t = __hip_atomic_fetch_add(&c->ticket[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == (int)gridDim.x - 1);
-    if (s_last)
+    // two-level count (atomics on one address serialise at ~15 ns each across the XCDs): first the
+    // counter of this workgroup's group of 32, then -- last of the group only -- the launch counter
+    const int g = blockIdx.x >> 5, ngroups = ((int)gridDim.x + 31) >> 5;
+    const int gsize = min(32, (int)gridDim.x - (g << 5));
+    int last = 0;
+    int *gc = &c->ticketGroup[slot][g & 63];
+    if (ngroups > 64) {
+      // (launches beyond 2048 workgroups: single level)
+      int t = __hip_atomic_fetch_add(&c->ticket[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = (t == (int)gridDim.x - 1);
+    } else if (__hip_atomic_fetch_add(gc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
+      __hip_atomic_store(gc, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int t = __hip_atomic_fetch_add(&c->ticket[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = (t == ngroups - 1);
+    }
+    if (last)
       __hip_atomic_store(&c->ticket[slot], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = last;
   }
   __syncthreads();
   return s_last != 0;
@@ -519,7 +533,8 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_price(Dev D, int nbRows)
 
 // exclusive scan over per-block counts (<= 1M/256 blocks), min over per-block ratios
 // what: 0 candidates (-> numberCandidates, upperTheta), 1 flips, 2 infeasibility-list appends
-__device__ inline void scanBlocksBody(const Dev &D, int nb, int what, int nSell)
+// COHERENT: run by the last workgroup of the launch that produced the counts (ldc loads)
+template <bool COHERENT> __device__ inline void scanBlocksBody(const Dev &D, int nb, int what, int nSell)
 {
   Ctrl *c = D.ctrl;
   __shared__ int shi[17];
@@ -530,44 +545,109 @@ __device__ inline void scanBlocksBody(const Dev &D, int nb, int what, int nSell)
   __syncthreads();
   double vmin = 1.0e31;
   double bytes = 0.0;
-  for (int b0 = 0; b0 < nb; b0 += blockDim.x) {
-    int b = b0 + threadIdx.x;
-    int cnt = (b < nb) ? ldc(&D.blockCount[b]) : 0;
-    if (what == 0 && b < nb) {
-      vmin = fmin(vmin, ldc(&D.blockMin[b]));
-      bytes += ldc(&D.blockSum[b]);
+  const int T = blockDim.x, tid = threadIdx.x;
+  const int per = (nb + T - 1) / T;
+  if (per <= 8) {
+    // one round of loads: thread t owns `per` consecutive blocks, everything it needs is requested
+    // before anything is used (the coherent loads are slow and would otherwise queue up serially)
+    const int lo = min(nb, tid * per), hi = min(nb, lo + per);
+    int cnt[8];
+    double mn[8], sm[8], smin[4], sbytes[4];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int bb = lo + u;
+      cnt[u] = bb < hi ? (COHERENT ? ldc(&D.blockCount[bb]) : D.blockCount[bb]) : 0;
+      mn[u] = (what == 0 && bb < hi) ? (COHERENT ? ldc(&D.blockMin[bb]) : D.blockMin[bb]) : 1.0e31;
+      sm[u] = (what == 0 && bb < hi) ? (COHERENT ? ldc(&D.blockSum[bb]) : D.blockSum[bb]) : 0.0;
     }
-    // inclusive scan inside the block via wave ballots is for flags only; counts need a real scan
-    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    int v = cnt;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int bb = tid + u * T;
+      smin[u] = (what == 0 && bb < nSell) ? D.sellMin[bb] : 1.0e31;
+      sbytes[u] = (what == 0 && bb < nSell) ? D.sellBytes[bb] : 0.0;
+    }
+    int local = 0;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      local += cnt[u];
+      vmin = fmin(vmin, mn[u]);
+      bytes += sm[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      vmin = fmin(vmin, smin[u]);
+      bytes += sbytes[u];
+    }
+    if (what == 0)
+      for (int bb = tid + 4 * T; bb < nSell; bb += T) {
+        vmin = fmin(vmin, D.sellMin[bb]);
+        bytes += D.sellBytes[bb];
+      }
+    const int lane = tid & 63, wv = tid >> 6, nw = T >> 6;
+    int v = local;
     for (int o = 1; o < 64; o <<= 1) {
       int t = __shfl_up(v, o);
       if (lane >= o)
         v += t;
     }
-    __syncthreads();
     if (lane == 63)
       shi[wv] = v;
     __syncthreads();
-    int base = s_base;
-    for (int i = 0; i < wv; i++)
-      base += shi[i];
-    if (b < nb)
-      D.blockOffset[b] = base + v - cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int tot = 0;
-      for (int i = 0; i < nw; i++)
-        tot += shi[i];
-      s_base += tot;
+    int base = 0, tot = 0;
+    for (int i = 0; i < nw; i++) {
+      if (i < wv)
+        base += shi[i];
+      tot += shi[i];
     }
-    __syncthreads();
+    int o = base + v - local;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      if (lo + u < hi)
+        D.blockOffset[lo + u] = o;
+      o += cnt[u];
+    }
+    if (tid == 0)
+      s_base = tot;
+  } else {
+    for (int b0 = 0; b0 < nb; b0 += blockDim.x) {
+      int b = b0 + threadIdx.x;
+      int cnt = (b < nb) ? (COHERENT ? ldc(&D.blockCount[b]) : D.blockCount[b]) : 0;
+      if (what == 0 && b < nb) {
+        vmin = fmin(vmin, (COHERENT ? ldc(&D.blockMin[b]) : D.blockMin[b]));
+        bytes += (COHERENT ? ldc(&D.blockSum[b]) : D.blockSum[b]);
+      }
+      int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+      int v = cnt;
+      for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(v, o);
+        if (lane >= o)
+          v += t;
+      }
+      __syncthreads();
+      if (lane == 63)
+        shi[wv] = v;
+      __syncthreads();
+      int base = s_base;
+      for (int i = 0; i < wv; i++)
+        base += shi[i];
+      if (b < nb)
+        D.blockOffset[b] = base + v - cnt;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int i = 0; i < nw; i++)
+          tot += shi[i];
+        s_base += tot;
+      }
+      __syncthreads();
+    }
+    if (what == 0)
+      for (int b = threadIdx.x; b < nSell; b += blockDim.x) {
+        vmin = fmin(vmin, D.sellMin[b]);
+        bytes += D.sellBytes[b];
+      }
   }
   if (what == 0) {
-    for (int b = threadIdx.x; b < nSell; b += blockDim.x) {
-      vmin = fmin(vmin, D.sellMin[b]);
-      bytes += D.sellBytes[b];
-    }
     vmin = blockMin(vmin, shd);
     bytes = blockSum(bytes, shd);
   }
@@ -590,7 +670,7 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(Dev D, int nb, int what, i
 {
   if (iter && D.ctrl->state != RUN)
     return;
-  scanBlocksBody(D, nb, what, nSell);
+  scanBlocksBody<false>(D, nb, what, nSell);
 }
 
 __global__ void __launch_bounds__(PRICE_BLOCK) k_cand_scatter(Dev D, int nbRows)
@@ -2871,8 +2951,10 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_cand_count(Dev D, int nbRows, i
     stc(&D.blockMin[blockIdx.x], bmin);
     stc(&D.blockSum[blockIdx.x], 0.0);
   }
-  if (lastBlockDone(D.ctrl, 0))
-    scanBlocksBody(D, gridDim.x, 0, nSell);
+  // nSell >= 0: the last workgroup to finish also scans the block counts.  (Only pays for small
+  // grids -- across ~1000 workgroups the ticket + coherent-load latency exceeds a launch.)
+  if (nSell >= 0 && lastBlockDone(D.ctrl, 0))
+    scanBlocksBody<true>(D, gridDim.x, 0, nSell);
 }
 
 
@@ -3259,13 +3341,16 @@ __device__ inline void scanTailBody(const Dev &D, int nbCount, int nbSum, int wh
   __shared__ double shd[16];
   __shared__ int s_base;
   const bool active = !(which == 1 && c->numberFlips == 0);
+  // request this thread's first count and partial sum right away (slow coherent loads), use later
+  const int cnt0 = (active && (int)threadIdx.x < nbCount) ? ldc(&D.blockCount[threadIdx.x]) : 0;
+  const double sum0 = (active && (int)threadIdx.x < nbSum) ? ldc(&D.blockSum[threadIdx.x]) : 0.0;
   if (threadIdx.x == 0)
     s_base = c->numberInfeasible;
   __syncthreads();
   if (active) {
     for (int b0 = 0; b0 < nbCount; b0 += blockDim.x) {
       int b = b0 + threadIdx.x;
-      int cnt = (b < nbCount) ? ldc(&D.blockCount[b]) : 0;
+      int cnt = b0 == 0 ? cnt0 : ((b < nbCount) ? ldc(&D.blockCount[b]) : 0);
       int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
       int v = cnt;
       for (int o = 1; o < 64; o <<= 1) {
@@ -3293,9 +3378,11 @@ __device__ inline void scanTailBody(const Dev &D, int nbCount, int nbSum, int wh
     }
   }
   double s = 0.0;
-  if (active)
-    for (int b = threadIdx.x; b < nbSum; b += blockDim.x)
+  if (active) {
+    s += sum0;
+    for (int b = threadIdx.x + blockDim.x; b < nbSum; b += blockDim.x)
       s += ldc(&D.blockSum[b]);
+  }
   s = blockSum(s, shd);
   if (threadIdx.x != 0)
     return;
@@ -3564,6 +3651,9 @@ __device__ void flipSequential(const Dev &D, int nf)
 #define FLIP_MAX_FLIPS 1024
 #define FLIP_MAX_ENTRIES 8192
 #define FLIP_MAX_COLLIDE 1024
+#define FLIP_HASH_BITS 14
+#define FLIP_HASH_ROW 0x3fffffff
+#define FLIP_HASH_MULTI 0x40000000
 __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos)
 {
   Ctrl *c = D.ctrl;
@@ -3573,6 +3663,7 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos)
   // counters of k_ftran_scatter3's appends (position blocks) are reset here, flips or not
   for (int b = tid; b < nbPos; b += blockDim.x)
     D.blockCount[b] = 0;
+  const int key0 = D.flipKey[tid];  // requested together with the count (stale beyond it)
   const int nraw = c->flipAppend;
   if (nraw == 0)
     return;  // numberFlips was zeroed by CHUZR
@@ -3581,7 +3672,9 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos)
   __shared__ int shw[17];
   int nf;
   if (nraw <= FLIP_LIST_CAP) {
-    for (int i = tid; i < nraw; i += blockDim.x)
+    if (tid < nraw)
+      s_seq[tid] = key0;
+    for (int i = tid + blockDim.x; i < nraw; i += blockDim.x)
       s_seq[i] = D.flipKey[i];
     __syncthreads();
     int myKey[FLIP_LIST_CAP / 1024], myRank[FLIP_LIST_CAP / 1024];
@@ -3638,10 +3731,16 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos)
         D.flipSeq[o++] = i < D.m ? D.n + i : i - D.m;
     nf = tot;
   }
-  if (tid == 0)
+  if (tid == 0) {
     c->numberFlips = nf;
+    c->dbg[9]++;
+    c->dbg[10] += nf;
+  }
   __syncthreads();
   __shared__ double s_mv[FLIP_MAX_FLIPS];
+  __shared__ int s_hash[1 << FLIP_HASH_BITS];  // 0 empty, else (row + 1) | MULTI
+  for (int i = tid; i < (1 << FLIP_HASH_BITS); i += blockDim.x)
+    s_hash[i] = 0;
   __shared__ int s_start[FLIP_MAX_FLIPS + 1];
   __shared__ int s_cRow[FLIP_MAX_COLLIDE], s_cFlip[FLIP_MAX_COLLIDE], s_cSorted[FLIP_MAX_COLLIDE];
   __shared__ double s_cVal[FLIP_MAX_COLLIDE];
@@ -3686,17 +3785,23 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos)
     fallback = s_total > FLIP_MAX_ENTRIES;
   }
   if (fallback) {
+    if (tid == 0)
+      c->dbg[12]++;
     flipSequential(D, nf);
     return;
   }
   const int total = s_total;
-  // phase 1: count the contributors of every touched row (touchCount is all zero between calls)
-  int myRow[FLIP_MAX_ENTRIES / 1024], myFlip[FLIP_MAX_ENTRIES / 1024];
+  if (tid == 0)
+    c->dbg[11] += total;
+  // phase 1: every (flip, entry) pair finds its row in an LDS hash table; a row reached by more
+  // than one flip gets the MULTI mark.  (flipRhs is all zero on entry: k_ftran_scatter3 clears it.)
+  int myRow[FLIP_MAX_ENTRIES / 1024], myFlip[FLIP_MAX_ENTRIES / 1024], mySlot[FLIP_MAX_ENTRIES / 1024];
   double myVal[FLIP_MAX_ENTRIES / 1024];
 #pragma unroll
   for (int q = 0; q < FLIP_MAX_ENTRIES / 1024; q++) {
     int e = tid + q * 1024;
     myRow[q] = -1;
+    mySlot[q] = 0;
     if (e < total) {
       int lo = 0, hi = nf;  // largest f with s_start[f] <= e
       while (hi - lo > 1) {
@@ -3721,51 +3826,53 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos)
       myRow[q] = r;
       myFlip[q] = f;
       myVal[q] = v;
-      atomicAdd(&D.touchCount[r], 1);
+      unsigned h = ((unsigned)r * 2654435761u) >> (32 - FLIP_HASH_BITS);
+      while (true) {
+        int old = atomicCAS(&s_hash[h], 0, r + 1);
+        if (old == 0)
+          break;
+        if ((old & FLIP_HASH_ROW) == r + 1) {
+          atomicOr(&s_hash[h], FLIP_HASH_MULTI);
+          break;
+        }
+        h = (h + 1) & ((1u << FLIP_HASH_BITS) - 1u);
+      }
+      mySlot[q] = (int)h;
     }
   }
   __syncthreads();
   {
     // how many entries share their row with another flip?  dense columns collide everywhere:
-    // clean up and take the sequential form instead
+    // take the sequential form instead
     double nColl = 0.0;
 #pragma unroll
     for (int q = 0; q < FLIP_MAX_ENTRIES / 1024; q++)
-      if (myRow[q] >= 0 && atomicAdd(&D.touchCount[myRow[q]], 0) > 1)
+      if (myRow[q] >= 0 && (s_hash[mySlot[q]] & FLIP_HASH_MULTI))
         nColl += 1.0;
     nColl = blockSum(nColl, shd);
     if (nColl > (double)FLIP_MAX_COLLIDE) {
-#pragma unroll
-      for (int q = 0; q < FLIP_MAX_ENTRIES / 1024; q++)
-        if (myRow[q] >= 0)
-          D.touchCount[myRow[q]] = 0;
-      __syncthreads();
+      if (tid == 0)
+        c->dbg[12]++;
       flipSequential(D, nf);
       return;
     }
   }
   // phase 2: single contributors store, the others queue up
-  bool overflow = false;
 #pragma unroll
   for (int q = 0; q < FLIP_MAX_ENTRIES / 1024; q++) {
     if (myRow[q] >= 0) {
-      int cnt = atomicAdd(&D.touchCount[myRow[q]], 0);
-      if (cnt == 1) {
-        D.flipRhs[myRow[q]] += myVal[q];
+      if (!(s_hash[mySlot[q]] & FLIP_HASH_MULTI)) {
+        D.flipRhs[myRow[q]] = 0.0 + myVal[q];
       } else {
         int o = atomicAdd(&s_nCollide, 1);
-        if (o < FLIP_MAX_COLLIDE) {
-          s_cRow[o] = myRow[q];
-          s_cFlip[o] = myFlip[q];
-          s_cVal[o] = myVal[q];
-        } else {
-          overflow = true;
-        }
+        s_cRow[o] = myRow[q];
+        s_cFlip[o] = myFlip[q];
+        s_cVal[o] = myVal[q];
       }
     }
   }
   __syncthreads();
-  const int ncol = min(s_nCollide, FLIP_MAX_COLLIDE);
+  const int ncol = s_nCollide;
   // phase 3: order the collisions by (row, flip) with a rank sort, then one thread per row segment
   for (int i = tid; i < ncol; i += blockDim.x) {
     int r = s_cRow[i], f = s_cFlip[i], rank = 0;
@@ -3780,23 +3887,15 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos)
     int e = s_cSorted[i];
     int r = s_cRow[e];
     if (i == 0 || s_cRow[s_cSorted[i - 1]] != r) {
-      double acc = D.flipRhs[r];
+      double acc = 0.0;
       for (int j = i; j < ncol && s_cRow[s_cSorted[j]] == r; j++)
         acc += s_cVal[s_cSorted[j]];
       D.flipRhs[r] = acc;
     }
   }
-  // phase 4: clean the counters
-#pragma unroll
-  for (int q = 0; q < FLIP_MAX_ENTRIES / 1024; q++)
-    if (myRow[q] >= 0)
-      D.touchCount[myRow[q]] = 0;
   double s = blockSum(changeObj, shd);
-  if (tid == 0) {
+  if (tid == 0)
     c->objectiveChange += s;
-    if (overflow || s_nCollide > FLIP_MAX_COLLIDE)
-      c->state = EXIT_BAD_UPDATE;  // cannot happen with the caps above unless thousands of flips collide
-  }
 }
 
 // three right-hand sides in one sweep over Minv: entering column, DSE vector (rho), flip rhs.
@@ -4327,14 +4426,14 @@ struct GjShared {
   double movedL[2 * GJ_B][GJ_B];
 };
 // one elimination step with the step index a compile-time constant (keeps v[][] in registers);
-// returns false when the panel turned out singular
-template <int S, int GJ_RPT, int BB>
+// returns false when the panel turned out singular.  Two barriers per step.
+template <int S, int GJ_RPT, int BB, int NT>
 __device__ __forceinline__ bool gjPanelStep(const Dev &D, double (&v)[GJ_RPT][BB], int (&pos)[GJ_RPT], GjShared &sh, int i0, int k,
-                                            int *info)
+                                            int *info, double zeroTolerance)
 {
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = i0 + S;
-  double best = D.ctrl->zeroTolerance;
+  double best = zeroTolerance;
   int key = -1;
 #pragma unroll
   for (int q = 0; q < GJ_RPT; q++) {
@@ -4346,15 +4445,37 @@ __device__ __forceinline__ bool gjPanelStep(const Dev &D, double (&v)[GJ_RPT][BB
       }
     }
   }
-  blockArgMax(best, key, sh.shv, sh.shk);
-  if (tid == 0) {
-    sh.row = key;
-    if (key < 0)
-      info[0] = 1 + i;
-    D.gjPiv[S] = key;
+  // argmax, smallest position wins ties: butterfly inside the wave, partials through LDS, then the
+  // same butterfly over the (<= 16) partials in every wave -- all threads end with the result
+  auto combine = [&](double ov, int ok) {
+    if (ok >= 0 && (key < 0 || ov > best || (ov == best && ok < key))) {
+      best = ov;
+      key = ok;
+    }
+  };
+  combine(xchgD<0>(best), xchgI<0>(key));
+  combine(xchgD<1>(best), xchgI<1>(key));
+  combine(xchgD<2>(best), xchgI<2>(key));
+  combine(xchgD<3>(best), xchgI<3>(key));
+  combine(xchgD<4>(best), xchgI<4>(key));
+  combine(xchgD<5>(best), xchgI<5>(key));
+  if (lane == 0) {
+    sh.shv[wv] = best;
+    sh.shk[wv] = key;
   }
   __syncthreads();
-  const int iRow = sh.row;
+  best = sh.shv[lane & 15];
+  key = (lane & 15) < NT / 64 ? sh.shk[lane & 15] : -1;
+  combine(xchgD<0>(best), xchgI<0>(key));
+  combine(xchgD<1>(best), xchgI<1>(key));
+  combine(xchgD<2>(best), xchgI<2>(key));
+  combine(xchgD<3>(best), xchgI<3>(key));
+  const int iRow = key;
+  if (tid == 0) {
+    if (iRow < 0)
+      info[0] = 1 + i;
+    D.gjPiv[S] = iRow;
+  }
   if (iRow < 0)
     return false;
   // the pivot row publishes itself and takes position i; the row that sat at i goes to iRow
@@ -4375,7 +4496,7 @@ __device__ __forceinline__ bool gjPanelStep(const Dev &D, double (&v)[GJ_RPT][BB
     D.slotB[i] = inv;
 #pragma unroll
   for (int q = 0; q < GJ_RPT; q++) {
-    const int r = tid + q * 1024;
+    const int r = tid + q * NT;
     if (r < k) {
       if (pos[q] == i) {
         D.gjL[(size_t)r * GJ_B + S] = 0.0;
@@ -4390,27 +4511,30 @@ __device__ __forceinline__ bool gjPanelStep(const Dev &D, double (&v)[GJ_RPT][BB
       }
     }
   }
-  // no barrier here: prow is next written after the two barriers of the next pivot search
+  // no barrier here: the partials and prow are next written after a barrier every wave has passed
   return true;
 }
-template <int S, int GJ_RPT, int BB> struct GjPanelRun {
+template <int S, int GJ_RPT, int BB, int NT> struct GjPanelRun {
   static __device__ __forceinline__ bool run(const Dev &D, double (&v)[GJ_RPT][BB], int (&pos)[GJ_RPT], GjShared &sh, int i0, int b,
-                                             int k, int *info)
+                                             int k, int *info, double zeroTolerance)
   {
     if (S >= b)
       return true;
-    if (!gjPanelStep<S, GJ_RPT, BB>(D, v, pos, sh, i0, k, info))
+    if (!gjPanelStep<S, GJ_RPT, BB, NT>(D, v, pos, sh, i0, k, info, zeroTolerance))
       return false;
-    return GjPanelRun<S + 1, GJ_RPT, BB>::run(D, v, pos, sh, i0, b, k, info);
+    return GjPanelRun<S + 1, GJ_RPT, BB, NT>::run(D, v, pos, sh, i0, b, k, info, zeroTolerance);
   }
 };
-template <int GJ_RPT, int BB> struct GjPanelRun<BB, GJ_RPT, BB> {
-  static __device__ __forceinline__ bool run(const Dev &, double (&)[GJ_RPT][BB], int (&)[GJ_RPT], GjShared &, int, int, int, int *)
+template <int GJ_RPT, int BB, int NT> struct GjPanelRun<BB, GJ_RPT, BB, NT> {
+  static __device__ __forceinline__ bool run(const Dev &, double (&)[GJ_RPT][BB], int (&)[GJ_RPT], GjShared &, int, int, int, int *,
+                                             double)
   {
     return true;
   }
 };
-template <int GJ_RPT, int BB> __global__ void __launch_bounds__(1024) k_gj_panel_reg(Dev D, int i0, int b, int k, int *info)
+// NT threads own GJ_RPT rows each (k <= NT * GJ_RPT); fewer, fatter waves keep the per-step control
+// overhead (which is what bounds this single-workgroup kernel) low
+template <int GJ_RPT, int BB, int NT> __global__ void __launch_bounds__(NT) k_gj_panel_reg(Dev D, int i0, int b, int k, int *info)
 {
   __shared__ GjShared sh;
   if (info[0])
@@ -4420,7 +4544,7 @@ template <int GJ_RPT, int BB> __global__ void __launch_bounds__(1024) k_gj_panel
   int pos[GJ_RPT], permOld[GJ_RPT];
 #pragma unroll
   for (int q = 0; q < GJ_RPT; q++) {
-    int r = tid + q * 1024;
+    int r = tid + q * NT;
     pos[q] = r < k ? r : -1;
     permOld[q] = r < k ? D.perm[r] : 0;
 #pragma unroll
@@ -4429,13 +4553,13 @@ template <int GJ_RPT, int BB> __global__ void __launch_bounds__(1024) k_gj_panel
   }
   if (tid == 0)
     sh.nMoved = 0;
-  if (!GjPanelRun<0, GJ_RPT, BB>::run(D, v, pos, sh, i0, b, k, info))
+  if (!GjPanelRun<0, GJ_RPT, BB, NT>::run(D, v, pos, sh, i0, b, k, info, D.ctrl->zeroTolerance))
     return;
   __syncthreads();
   // rows that ended at another position: move their multipliers and their perm entry there
 #pragma unroll
   for (int q = 0; q < GJ_RPT; q++) {
-    int r = tid + q * 1024;
+    int r = tid + q * NT;
     if (r < k && pos[q] != r) {
       int slot = atomicAdd(&sh.nMoved, 1);
       sh.movedPos[slot] = pos[q];
@@ -4446,7 +4570,7 @@ template <int GJ_RPT, int BB> __global__ void __launch_bounds__(1024) k_gj_panel
   }
   __syncthreads();
   const int nMoved = sh.nMoved;
-  for (int e = tid; e < nMoved * b; e += 1024) {
+  for (int e = tid; e < nMoved * b; e += NT) {
     int slot = e / b, t = e - slot * b;
     D.gjL[(size_t)sh.movedPos[slot] * GJ_B + t] = sh.movedL[slot][t];
   }

@@ -16,5 +16,20 @@ def main(path, header=""):
         print(f"{r[0][:62]:62s} {r[1]:8d} {r[2]:12.0f} {r[3]:10.2f} {r[4]:8.2f} {r[5]:10.2f} {100 * r[2] / tot:6.2f}")
 
 
+def counters(path, header=""):
+    """per-kernel summary of a --pmc pass: counter, dispatches, avg / min / max of the counter value"""
+    cur = sqlite3.connect(path).cursor()
+    rows = cur.execute("select kernel_name, counter_name, count(*), avg(value), min(value), max(value) from counters_collection "
+                       "group by kernel_name, counter_name order by 4 desc").fetchall()
+    if header:
+        print(header)
+    print(f"{'kernel':50s} {'counter':12s} {'dispatches':>10s} {'avg':>12s} {'min':>10s} {'max':>12s}")
+    for r in rows[:16]:
+        print(f"{r[0][:50]:50s} {r[1]:12s} {r[2]:10d} {r[3]:12.1f} {r[4]:10.1f} {r[5]:12.1f}")
+
+
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "")
+    if sys.argv[1] == "--pmc":
+        counters(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "")
+    else:
+        main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "")
