@@ -28,8 +28,20 @@ def counters(path, header=""):
         print(f"{r[0][:50]:50s} {r[1]:12s} {r[2]:10d} {r[3]:12.1f} {r[4]:10.1f} {r[5]:12.1f}")
 
 
+def last_dispatches(path, kernel, count):
+    """mean counter value over the last `count` dispatches of `kernel` (the bench's timed-with-events leg)"""
+    cur = sqlite3.connect(path).cursor()
+    rows = cur.execute("select counter_name, value from counters_collection where kernel_name like ? order by dispatch_id desc limit ?",
+                       (f"%{kernel}%", count)).fetchall()
+    vals = [r[1] for r in rows]
+    print(f"{kernel}: {rows[0][0] if rows else '-'} mean over last {len(vals)} dispatches = {sum(vals) / max(len(vals), 1):.1f} "
+          f"(min {min(vals):.1f}, max {max(vals):.1f})")
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "--pmc":
+    if sys.argv[1] == "--last":
+        last_dispatches(sys.argv[2], sys.argv[3], int(sys.argv[4]))
+    elif sys.argv[1] == "--pmc":
         counters(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "")
     else:
         main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "")
