@@ -126,6 +126,7 @@ struct Dev {
   int *tIndex;       // [m] nonzero col-slots of the BTRAN t-vector
   double *tValue;
   double *rhoSlot;   // [kcap] unpruned rho on nucleus rows (for the rank-1 update)
+  double *slotV1, *rhoSlotF, *flipSlot;  // [kcap] the three FTRAN right-hand sides by nucleus row-slot (entering column, pruned rho, flip rhs)
   double *partial;   // gemvT partials [(kcap/64+1) * kcap]
   // dual row pivot
   double *weights, *altWeights, *infeas, *weightBySeq;

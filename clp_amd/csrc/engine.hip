@@ -448,6 +448,9 @@ int clpgpu_context::allocNucleus(int kNeeded)
   rc |= dalloc(D.slotE, kcap);
   rc |= dalloc(D.slotF, kcap);
   rc |= dalloc(D.rhoSlot, kcap);
+  rc |= dalloc(D.slotV1, kcap);
+  rc |= dalloc(D.rhoSlotF, kcap);
+  rc |= dalloc(D.flipSlot, kcap);
   rc |= dalloc(D.perm, kcap);
   rc |= dalloc(D.gjL, (size_t)kcap * GJ_B);
   rc |= dalloc(D.gjU, (size_t)GJ_B * 2 * ld);
@@ -1449,6 +1452,8 @@ int clpgpu_context::whileIterating(int stepTarget)
     hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, stream, D.vecC, m);
     hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, stream, D.vecV1, m);
     hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, stream, D.flipRhs, m);
+    hipLaunchKernelGGL(k_zero, dim3(cdiv(kcap, 256)), dim3(256), 0, stream, D.slotV1, kcap);
+    hipLaunchKernelGGL(k_zero, dim3(cdiv(kcap, 256)), dim3(256), 0, stream, D.flipSlot, kcap);
   }
   switch (state) {
   case EXIT_STEP_LIMIT:

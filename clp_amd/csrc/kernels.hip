@@ -1179,12 +1179,25 @@ __device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nu
     if (tid == 0)
       c->acceptablePivotBase = -c->acceptablePivotBase;
   }
+  // unpack the entering column (ClpSimplex::unpackPacked :3439-3495): by row, and by nucleus
+  // row-slot for the FTRAN sweep
   if (sequenceIn >= D.n) {
-    if (tid == 0)
-      D.vecV1[sequenceIn - D.n] = -1.0;
+    if (tid == 0) {
+      const int r = sequenceIn - D.n;
+      D.vecV1[r] = -1.0;
+      const int sr = D.slotOfRow[r];
+      if (sr >= 0)
+        D.slotV1[sr] = -1.0;
+    }
   } else if (sequenceIn >= 0) {
-    for (int p = D.colStart[sequenceIn] + tid; p < D.colStart[sequenceIn + 1]; p += nthr)
-      D.vecV1[D.row[p]] = D.elem[p];
+    for (int p = D.colStart[sequenceIn] + tid; p < D.colStart[sequenceIn + 1]; p += nthr) {
+      const int r = D.row[p];
+      const double e = D.elem[p];
+      D.vecV1[r] = e;
+      const int sr = D.slotOfRow[r];
+      if (sr >= 0)
+        D.slotV1[sr] = e;
+    }
   }
   if (tid == 0) {
     c->dbg[ONEWAVE ? 0 : 1]++;
@@ -1867,7 +1880,7 @@ __global__ void __launch_bounds__(256) k_rank1(Dev D)
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < k; j += gridDim.x * blockDim.x) {
     const double gj = dir * D.rhoSlot[j] / alpha;
     for (int i = blockIdx.y; i < k; i += gridDim.y) {
-      double wi = D.w[D.slotPos[i]];
+      double wi = D.slotC[i];  // w by column-slot, as the FTRAN sweep left it (== w[slotPos[i]])
       if (wi != 0.0)
         D.Minv[(size_t)i * D.ld + j] -= wi * gj;
     }
@@ -2457,6 +2470,8 @@ __global__ void __launch_bounds__(256) k_rho_finish3(Dev D)
       v = 0.0;
     D.rho[i] = v;
     D.piNeg[i] = -v;
+    if (sr >= 0)
+      D.rhoSlotF[sr] = v;
     sq = v * v;
   }
   // bitmap of the nonzero rows of pi, one 64-bit word per wave (the pricing kernel keeps it in LDS)
@@ -3517,7 +3532,7 @@ __global__ void __launch_bounds__(256) k_fix_house(Dev D)
   const int a = c->slotColOut, b = c->slotRowIn, last = k - 1;
   for (int s = threadIdx.x; s < k; s += blockDim.x) {
     double slotFs = dir * D.rhoSlot[s] / alpha;  // g by row-slot
-    double slotEs = D.w[D.slotPos[s]];           // w by col-slot
+    double slotEs = D.slotC[s];                  // w by col-slot (== w[slotPos[s]])
     if (ucase == 0) {
       D.Minv[(size_t)a * D.ld + s] = slotFs;
     } else if (ucase == 1) {
@@ -3634,14 +3649,25 @@ __device__ void flipSequential(const Dev &D, int nf)
       double movement = mult * (D.lower[seq] - D.upper[seq]);
       if (tid == 0) {
         changeObj -= movement * D.cost[seq];
-        D.flipRhs[seq - D.n] += movement;
+        const int r = seq - D.n;
+        const double nv = D.flipRhs[r] + movement;
+        D.flipRhs[r] = nv;
+        const int sr = D.slotOfRow[r];
+        if (sr >= 0)
+          D.flipSlot[sr] = nv;
       }
     } else {
       double movement = mult * (D.upper[seq] - D.lower[seq]);
       if (tid == 0)
         changeObj += movement * D.cost[seq];
-      for (int p = D.colStart[seq] + tid; p < D.colStart[seq + 1]; p += blockDim.x)
-        D.flipRhs[D.row[p]] += movement * D.elem[p];
+      for (int p = D.colStart[seq] + tid; p < D.colStart[seq + 1]; p += blockDim.x) {
+        const int r = D.row[p];
+        const double nv = D.flipRhs[r] + movement * D.elem[p];
+        D.flipRhs[r] = nv;
+        const int sr = D.slotOfRow[r];
+        if (sr >= 0)
+          D.flipSlot[sr] = nv;
+      }
     }
     __syncthreads();
   }
@@ -3862,7 +3888,11 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos)
   for (int q = 0; q < FLIP_MAX_ENTRIES / 1024; q++) {
     if (myRow[q] >= 0) {
       if (!(s_hash[mySlot[q]] & FLIP_HASH_MULTI)) {
-        D.flipRhs[myRow[q]] = 0.0 + myVal[q];
+        const double nv = 0.0 + myVal[q];
+        D.flipRhs[myRow[q]] = nv;
+        const int sr = D.slotOfRow[myRow[q]];
+        if (sr >= 0)
+          D.flipSlot[sr] = nv;
       } else {
         int o = atomicAdd(&s_nCollide, 1);
         s_cRow[o] = myRow[q];
@@ -3891,6 +3921,9 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos)
       for (int j = i; j < ncol && s_cRow[s_cSorted[j]] == r; j++)
         acc += s_cVal[s_cSorted[j]];
       D.flipRhs[r] = acc;
+      const int sr = D.slotOfRow[r];
+      if (sr >= 0)
+        D.flipSlot[sr] = acc;
     }
   }
   double s = blockSum(changeObj, shd);
@@ -3899,8 +3932,9 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos)
 }
 
 // three right-hand sides in one sweep over Minv: entering column, DSE vector (rho), flip rhs.
-// The gathered right-hand sides (v[slotRow[sr]]) are staged once per workgroup in LDS (chunks of
-// GEMV_TILE slots), each wave then streams GEMV_ROWS rows of Minv against them.
+// The right-hand sides are kept by nucleus row-slot by their producers (k_dual_column, k_rho_finish3,
+// k_flip_apply2), staged once per workgroup in LDS (chunks of GEMV_TILE slots); four waves then
+// stream each row of Minv against them.
 #define GEMV_TILE 2048
 #define GEMV_ROWS 1
 __global__ void __launch_bounds__(1024) k_gemv3g(Dev D)
@@ -3921,10 +3955,9 @@ __global__ void __launch_bounds__(1024) k_gemv3g(Dev D)
       const int tn = min(GEMV_TILE, k - t0);
       __syncthreads();
       for (int i = threadIdx.x; i < tn; i += blockDim.x) {
-        int r = D.slotRow[t0 + i];
-        s1[i] = D.vecV1[r];
-        s2[i] = doTau ? D.rho[r] : 0.0;
-        s3[i] = doFlip ? D.flipRhs[r] : 0.0;
+        s1[i] = D.slotV1[t0 + i];
+        s2[i] = doTau ? D.rhoSlotF[t0 + i] : 0.0;
+        s3[i] = doFlip ? D.flipSlot[t0 + i] : 0.0;
       }
       __syncthreads();
       if (sc < k) {
@@ -3992,6 +4025,9 @@ __global__ void __launch_bounds__(256) k_ftran_scatter3(Dev D, int nbNorm)
     x1 = D.slotC[sc];
     x2 = D.slotD[sc];
     x3 = D.slotE[sc];
+    D.slotV1[sc] = 0.0;  // right-hand sides by slot: consumed by k_gemv3g
+    if (doFlip)
+      D.flipSlot[sc] = 0.0;
   }
   // DSE norm for the weight update (ClpDualRowSteepest::updateWeights :516-538): sum of the
   // per-block partials of sum rho^2; alpha is still the ratio-test alpha here
