@@ -70,10 +70,12 @@ struct Ctrl {
   int classCount[4];
   int tCount, preDone;  // ratio-test candidates by breakpoint class (k_cand_scatter)
   long long dbg[16];    // development counters (CLPGPU_DEBUG_STATS)
+  long long dbg2[8];    // phase clocks of k_flip_apply2
   int ticket[8];        // "last workgroup done" counters (always 0 between launches)
   int ticketGroup[4][64];  // first level of the same: one counter per 32 workgroups (<= 2048 workgroups)
   int flipAppend, numberAppend1;
   int appendGo, appendPad;
+  int updGo[2], updK, updPad;  // basis-update branch: go flag per pivot parity, k at the time of the fork
   double tailAlpha, tailValueOut;  // w[pivotRow] / sol[sequenceOut] handed to the serial tail of k_ftran_scatter3  // this pivot's primal update completed: its list appends may be scattered  // unordered append count of k_dj_flags (ordered later by k_flip_apply2)
 };
 

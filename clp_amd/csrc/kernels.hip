@@ -156,7 +156,7 @@ __device__ inline bool lastBlockDone(Ctrl *c, int slot)
   __syncthreads();
   return s_last != 0;
 }
-__device__ inline void scanTailBody(const Dev &D, int nbCount, int nbSum, int which, int alphaTest);
+__device__ inline void scanTailBody(const Dev &D, int nbCount, int nbSum, int which, int alphaTest, int parity);
 __device__ inline double randomDouble(Ctrl *c)
 {
   // CoinThreadRandom::randomDouble, 32-bit LCG form [CoinUtils, not in the reference tree]
@@ -1772,7 +1772,7 @@ __global__ void __launch_bounds__(256) k_primal_update(Dev D, int which)
   }
   // serial tail (offsets of the appends, objective change) in the last workgroup to finish
   if (which == 0 && lastBlockDone(D.ctrl, 2))
-    scanTailBody(D, gridDim.x, gridDim.x, 0, 0);
+    scanTailBody(D, gridDim.x, gridDim.x, 0, 0, -1);
 }
 
 __global__ void __launch_bounds__(256) k_append_scatter(Dev D, int which, int iter)
@@ -1869,12 +1869,13 @@ __global__ void k_update_vectors(Dev D)
   }
 }
 
-__global__ void __launch_bounds__(256) k_rank1(Dev D)
+__global__ void __launch_bounds__(256) k_rank1(Dev D, int parity = -1)
 {
   const Ctrl *c = D.ctrl;
-  if (c->state != RUN)
+  // parity >= 0: forked beside the rest of the pivot -- gated by the go flag the FTRAN tail set
+  if (parity >= 0 ? !c->updGo[parity] : c->state != RUN)
     return;
-  const int k = c->k;
+  const int k = parity >= 0 ? c->updK : c->k;
   const double dir = (double)c->directionOut, alpha = c->alpha;
   // blockIdx.x * 256 + thread = column j (coalesced along the row), blockIdx.y strides rows
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < k; j += gridDim.x * blockDim.x) {
@@ -3349,7 +3350,7 @@ __global__ void __launch_bounds__(256) k_ftran_scatter_flip(Dev D, const double 
 }
 
 // append scan with absolute offsets + the scalar tail that used to be k_after_primal2
-__device__ inline void scanTailBody(const Dev &D, int nbCount, int nbSum, int which, int alphaTest)
+__device__ inline void scanTailBody(const Dev &D, int nbCount, int nbSum, int which, int alphaTest, int parity)
 {
   Ctrl *c = D.ctrl;
   __shared__ int shi[17];
@@ -3468,6 +3469,12 @@ __device__ inline void scanTailBody(const Dev &D, int nbCount, int nbSum, int wh
     c->slotColOut = outStruct ? D.slotOfCol[seqOut] : -1;
     c->rowOfSlackOut = outStruct ? -1 : (seqOut - D.n);
     c->slotRowIn = inStruct ? -1 : D.slotOfRow[seqIn - D.n];
+    // the basis update of this pivot may go ahead (it runs beside the primal update, housekeeping
+    // and the next CHUZR, so it must not look at the live state or the live k)
+    if (parity >= 0) {
+      c->updK = c->k;
+      c->updGo[parity] = 1;
+    }
   }
 }
 __global__ void __launch_bounds__(256) k_append_scatter_abs(Dev D, int which)
@@ -3494,7 +3501,51 @@ __global__ void __launch_bounds__(256) k_house(Dev D)
 }
 
 // row/column fix-up of the nucleus update (k_rank1_fix + k_rank1_fix2) and housekeeping, one workgroup
-__global__ void __launch_bounds__(256) k_fix_house(Dev D)
+// fix-ups that complete the rank-1 update of the nucleus inverse for the four pivot types (see
+// k_rank1); runs after k_rank1 on the basis-update branch
+__device__ inline void minvFixBody(const Dev &D, int parity)
+{
+  Ctrl *c = D.ctrl;
+  if (!c->updGo[parity])
+    return;
+  const int k = c->updK;
+  const int ucase = c->updateCase;
+  const double alpha = c->alpha;
+  const double dir = (double)c->directionOut;
+  const int a = c->slotColOut, b = c->slotRowIn, last = k - 1;
+  for (int s = threadIdx.x; s < k; s += blockDim.x) {
+    double slotFs = dir * D.rhoSlot[s] / alpha;  // g by row-slot
+    double slotEs = D.slotC[s];                  // w by col-slot (== w[slotPos[s]])
+    if (ucase == 0) {
+      D.Minv[(size_t)a * D.ld + s] = slotFs;
+    } else if (ucase == 1) {
+      D.Minv[(size_t)k * D.ld + s] = slotFs;
+      D.Minv[(size_t)s * D.ld + k] = slotEs / alpha;
+    } else if (ucase == 2) {
+      if (b != last)
+        D.Minv[(size_t)s * D.ld + b] = D.Minv[(size_t)s * D.ld + last];
+    } else {
+      D.Minv[(size_t)s * D.ld + b] = slotEs / alpha;
+    }
+  }
+  if (ucase == 1 && threadIdx.x == 0)
+    D.Minv[(size_t)k * D.ld + k] = -1.0 / alpha;
+  __syncthreads();
+  if (ucase == 2 && a != last) {
+    for (int s = threadIdx.x; s < k; s += blockDim.x)
+      D.Minv[(size_t)a * D.ld + s] = D.Minv[(size_t)last * D.ld + s];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    c->updGo[parity] = 0;
+}
+
+__global__ void __launch_bounds__(256) k_minv_fix(Dev D, int parity)
+{
+  minvFixBody(D, parity);
+}
+
+__global__ void __launch_bounds__(256) k_fix_house(Dev D, int parity, int doFix)
 {
   const Ctrl *c = D.ctrl;
   if (blockIdx.x > 0) {
@@ -3525,34 +3576,11 @@ __global__ void __launch_bounds__(256) k_fix_house(Dev D)
   }
   if (c->state != RUN)
     return;
-  const int k = c->k;
-  const int ucase = c->updateCase;
-  const double alpha = c->alpha;
-  const double dir = (double)c->directionOut;
-  const int a = c->slotColOut, b = c->slotRowIn, last = k - 1;
-  for (int s = threadIdx.x; s < k; s += blockDim.x) {
-    double slotFs = dir * D.rhoSlot[s] / alpha;  // g by row-slot
-    double slotEs = D.slotC[s];                  // w by col-slot (== w[slotPos[s]])
-    if (ucase == 0) {
-      D.Minv[(size_t)a * D.ld + s] = slotFs;
-    } else if (ucase == 1) {
-      D.Minv[(size_t)k * D.ld + s] = slotFs;
-      D.Minv[(size_t)s * D.ld + k] = slotEs / alpha;
-    } else if (ucase == 2) {
-      if (b != last)
-        D.Minv[(size_t)s * D.ld + b] = D.Minv[(size_t)s * D.ld + last];
-    } else {
-      D.Minv[(size_t)s * D.ld + b] = slotEs / alpha;
-    }
+  if (doFix) {
+    // single-stream form: the fix-ups of the basis update run here, after k_rank1
+    minvFixBody(D, parity);
+    __syncthreads();
   }
-  if (ucase == 1 && threadIdx.x == 0)
-    D.Minv[(size_t)k * D.ld + k] = -1.0 / alpha;
-  __syncthreads();
-  if (ucase == 2 && a != last) {
-    for (int s = threadIdx.x; s < k; s += blockDim.x)
-      D.Minv[(size_t)a * D.ld + s] = D.Minv[(size_t)last * D.ld + s];
-  }
-  __syncthreads();
   houseBody(D);
   // head of the next pivot (only if this one ended normally and no exit was raised)
   if (threadIdx.x == 0 && D.ctrl->state == RUN)
@@ -3937,6 +3965,8 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos)
 // stream each row of Minv against them.
 #define GEMV_TILE 2048
 #define GEMV_ROWS 1
+#define GEMV_WPR 2                      // waves per row of Minv
+#define GEMV_RPB (16 / GEMV_WPR)        // rows per 1024-thread workgroup
 __global__ void __launch_bounds__(1024) k_gemv3g(Dev D)
 {
   const Ctrl *c = D.ctrl;
@@ -3947,8 +3977,8 @@ __global__ void __launch_bounds__(1024) k_gemv3g(Dev D)
   const int k = c->k;
   const bool doTau = c->pivotRule != 0, doFlip = c->numberFlips != 0;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int rowInBlock = wv >> 2, li = (wv & 3) * 64 + lane;  // 4 waves share one row of Minv
-  for (int base = blockIdx.x * 4; base < k; base += gridDim.x * 4) {
+  const int rowInBlock = wv / GEMV_WPR, li = (wv % GEMV_WPR) * 64 + lane;
+  for (int base = blockIdx.x * GEMV_RPB; base < k; base += gridDim.x * GEMV_RPB) {
     const int sc = base + rowInBlock;
     double a1 = 0.0, a2 = 0.0, a3 = 0.0;
     for (int t0 = 0; t0 < k; t0 += GEMV_TILE) {
@@ -3962,7 +3992,8 @@ __global__ void __launch_bounds__(1024) k_gemv3g(Dev D)
       __syncthreads();
       if (sc < k) {
         const double *Mrow = D.Minv + (size_t)sc * D.ld + t0;
-        for (int i = li; i < tn; i += 256) {
+#pragma unroll 4
+        for (int i = li; i < tn; i += 64 * GEMV_WPR) {
           double mv = Mrow[i];
           a1 += mv * s1[i];
           a2 += mv * s2[i];
@@ -3977,8 +4008,11 @@ __global__ void __launch_bounds__(1024) k_gemv3g(Dev D)
       part[wv][2] = r3;
     }
     __syncthreads();
-    if ((wv & 3) == 0 && lane < 3 && sc < k) {
-      double r = ((part[wv][lane] + part[wv + 1][lane]) + part[wv + 2][lane]) + part[wv + 3][lane];
+    if ((wv % GEMV_WPR) == 0 && lane < 3 && sc < k) {
+      double r = part[wv][lane];
+#pragma unroll
+      for (int u = 1; u < GEMV_WPR; u++)
+        r += part[wv + u][lane];
       double *dst = lane == 0 ? D.slotC : (lane == 1 ? D.slotD : D.slotE);
       dst[sc] = r;
     }
@@ -3987,7 +4021,7 @@ __global__ void __launch_bounds__(1024) k_gemv3g(Dev D)
 
 // back end of the three FTRANs: w, tau and -- when there are flips -- x3 together with the primal
 // update it drives (ratio 1.0, ClpSimplexDual.cpp:1535-1536)
-__global__ void __launch_bounds__(256) k_ftran_scatter3(Dev D, int nbNorm)
+__global__ void __launch_bounds__(256) k_ftran_scatter3(Dev D, int nbNorm, int parity)
 {
   const Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -4106,7 +4140,7 @@ __global__ void __launch_bounds__(256) k_ftran_scatter3(Dev D, int nbNorm)
   // serial tail in the last workgroup to finish: append offsets, objective change, the btran/ftran
   // alpha test and the scalar set-up of the basis update
   if (lastBlockDone(D.ctrl, 1))
-    scanTailBody(D, nbNorm, gridDim.x, 1, 1);
+    scanTailBody(D, nbNorm, gridDim.x, 1, 1, parity);
 }
 
 // DSE weight update (needs w, tau) -- positions only
