@@ -143,6 +143,7 @@ struct Dev {
   int *classBlock;  // [3 * blocks] ratio-test breakpoint classes per compaction block
   double *blockMin, *blockSum;
   int *flipSeq;
+  double *rowDot;  // [3m] wide-row mode: slack-row parts of the three FTRANs (k_slack_dots)
   int *flipKey;  // [FLIP_LIST_CAP] flagged bound flips in arrival order, as compaction keys
   int *appendFlag;  // [m]
   int *appendFlag1, *blockOffset1;  // the same for the flip part of the primal update (scattered together later)

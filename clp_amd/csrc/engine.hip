@@ -75,6 +75,8 @@ struct clpgpu_context {
   int *dKcol = nullptr, *dLocalOfRow = nullptr, *dInfo = nullptr;
   int nSellBlocks = 0, nChzBlocks = 0, priceKernel = 6, useGraph = 1, nWideBlocks = 1;
   bool widePricing = false;
+  int maxColumnLength = 1;
+  bool wideRows = false;  // mean row length >= 256 (dense LPs): wave-per-row / split-k variants of the row-wise stages
   int blockedRefactor = 1;
   // basis update (rank-1 sweep + fix-ups of Minv) on a second stream beside primal update,
   // housekeeping and the next CHUZR; joined before the next BTRAN reads Minv
@@ -297,6 +299,7 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   rc |= dalloc(D.blockSum, nb);
   rc |= dalloc(D.flipSeq, N);
   rc |= dalloc(D.flipKey, FLIP_LIST_CAP);
+  rc |= dalloc(D.rowDot, 3 * (size_t)m);
   rc |= dalloc(D.appendFlag, m);
   rc |= dalloc(D.appendFlag1, m);
   rc |= dalloc(D.blockOffset1, cdiv(m, 256) + 2);
@@ -398,6 +401,11 @@ int clpgpu_context::buildSell()
   rc |= dalloc(dElem, sellElem.size());
   nSellBlocks = cdiv(numSlices, 4);
   widePricing = count > 0 && (double)nnz / (double)n >= 256.0;
+  // (whole-matrix figures, so that every rank of a column-sharded run takes the same variants)
+  wideRows = m > 0 && (double)colStart[n] / (double)m >= 256.0;
+  maxColumnLength = 1;
+  for (int j = 0; j < n; j++)
+    maxColumnLength = std::max(maxColumnLength, colStart[j + 1] - colStart[j]);
   nWideBlocks = std::min(WIDE_BLOCKS, std::max(1, cdiv(count, 4)));
   rc |= dalloc(D.sellMin, std::max(nSellBlocks, WIDE_BLOCKS));
   rc |= dalloc(D.sellBytes, std::max(nSellBlocks, WIDE_BLOCKS));
@@ -1307,10 +1315,12 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   if (firstOfBatch)
     hipLaunchKernelGGL(k_chuzr_pre, dim3(1), dim3(64), 0, stream, D);
   hipLaunchKernelGGL(k_chuzr_scan, dim3(nChzBlocks), dim3(256), 0, stream, D);
-  hipLaunchKernelGGL(k_chuzr_final_btran, dim3(1), dim3(256), 0, stream, D, nChzBlocks);
+  hipLaunchKernelGGL(k_chuzr_final_btran, dim3(1), dim3(256), 0, stream, D, nChzBlocks, wideRows ? 1 : 0);
   // BTRAN (reads Minv: the previous pivot's basis-update branch must have finished)
   joinUpdateBranch();
-  hipLaunchKernelGGL(k_rho_finish3, dim3(gm), dim3(256), 0, stream, D);
+  if (wideRows)
+    hipLaunchKernelGGL(k_gemvT_partial2, dim3(cdiv(kc, 256), cdiv(kc, 64)), dim3(256), 0, stream, D, (const double *)D.slotA, 1);
+  hipLaunchKernelGGL(k_rho_finish3, dim3(gm), dim3(256), 0, stream, D, wideRows ? 1 : 0);
   // PRICE + first ratio pass
   if (ev)
     (void)hipEventRecord(evStart[evUsed], stream);
@@ -1350,7 +1360,9 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   // one FTRAN sweep for the entering column, rho (DSE) and the flip rhs; the back end also applies
   // the flip part of the primal update
   hipLaunchKernelGGL(k_gemv3g, dim3(cdiv(kc, GEMV_RPB)), dim3(1024), 0, stream, D);
-  hipLaunchKernelGGL(k_ftran_scatter3, dim3(cdiv(m + kc, 256)), dim3(256), 0, stream, D, gm, parity);
+  if (wideRows)
+    hipLaunchKernelGGL(k_slack_dots, dim3(cdiv(m, 4)), dim3(256), 0, stream, D);
+  hipLaunchKernelGGL(k_ftran_scatter3, dim3(cdiv(m + kc, 256)), dim3(256), 0, stream, D, gm, parity, wideRows ? 1 : 0);
   // basis update of the nucleus inverse: needs only what the FTRAN tail left (w and rho by slot, the
   // update scalars), nothing downstream needs Minv before the next BTRAN -> its own branch
   {
@@ -1372,7 +1384,13 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   hipLaunchKernelGGL(k_primal_update, dim3(gm), dim3(256), 0, stream, D, 0);
   // workgroup 0: fix-ups of the basis update, housekeeping, head of the next CHUZR; the others
   // scatter this pivot's new primal infeasibilities into the list
-  hipLaunchKernelGGL(k_fix_house, dim3(1 + gm), dim3(256), 0, stream, D, parity, (forkUpdate && stream2) ? 0 : 1);
+  if (wideRows) {
+    // long columns: the row-copy partition moves of the leaving and the entering column, one thread
+    // per entry over the whole chip (workgroup 0 of k_fix_house then skips them)
+    hipLaunchKernelGGL(k_house_col, dim3(cdiv(maxColumnLength, 256)), dim3(256), 0, stream, D, 0);
+    hipLaunchKernelGGL(k_house_col, dim3(cdiv(maxColumnLength, 256)), dim3(256), 0, stream, D, 1);
+  }
+  hipLaunchKernelGGL(k_fix_house, dim3(2 + gm), dim3(256), 0, stream, D, parity, (forkUpdate && stream2) ? 0 : 1, wideRows ? 1 : 0);
   return 0;
 }
 

@@ -1963,14 +1963,40 @@ __device__ inline void rowCopySwap(const Dev &D, int e, int b)
   D.cscToCsr[pe] = b;
 }
 
-__device__ void houseBody(Dev D)
+// wide mode: one of the two column moves of houseBody, one thread per entry (distinct rows)
+__global__ void __launch_bounds__(256) k_house_col(Dev D, int which)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  const int seq = which ? c->sequenceIn : c->sequenceOut;
+  if (seq >= D.n)
+    return;
+  const int p = D.colStart[seq] + blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= D.colStart[seq + 1])
+    return;
+  const int r = D.row[p];
+  const int e = D.cscToCsr[p];
+  if (which == 0) {
+    const int b = D.rowStart[r] + D.basicCount[r] - 1;
+    rowCopySwap(D, e, b);
+    D.basicCount[r] -= 1;
+  } else {
+    const int b = D.rowStart[r] + D.basicCount[r];
+    rowCopySwap(D, e, b);
+    D.basicCount[r] += 1;
+  }
+}
+
+__device__ void houseBody(Dev D, int skipColumns = 0)
 {
   Ctrl *c = D.ctrl;
   const int tid = threadIdx.x;
   const int seqIn = c->sequenceIn, seqOut = c->sequenceOut, pivotRow = c->pivotRow;
   const int n = D.n;
   // ---- row copy partition: leaving structural goes to the nonbasic part, entering to the basic
-  if (seqOut < n) {
+  // (skipColumns: already done by k_house_col)
+  if (!skipColumns && seqOut < n) {
     for (int p = D.colStart[seqOut] + tid; p < D.colStart[seqOut + 1]; p += blockDim.x) {
       int r = D.row[p];
       int e = D.cscToCsr[p];
@@ -1980,7 +2006,7 @@ __device__ void houseBody(Dev D)
     }
   }
   __syncthreads();
-  if (seqIn < n) {
+  if (!skipColumns && seqIn < n) {
     for (int p = D.colStart[seqIn] + tid; p < D.colStart[seqIn + 1]; p += blockDim.x) {
       int r = D.row[p];
       int e = D.cscToCsr[p];
@@ -2239,15 +2265,18 @@ __global__ void __launch_bounds__(256) k_chuzr_scan(Dev D)
       continue;
     if (c->pivotRule) {
       int iRow = D.infIndex[i];
+      // everything indexed by the row is requested together (one round trip, not three)
       double value = D.infeas[iRow];
+      const double rawWeight = D.weights[iRow];
+      const int iSequence = D.pivotVariable[iRow];
       if (value > tolerance) {
-        double weight = fmin(D.weights[iRow], 1.0e50);
+        double weight = fmin(rawWeight, 1.0e50);
         if (iRow == last)
           value *= 1.0e-10;
-        int iSequence = D.pivotVariable[iRow];
-        if (!(D.status[iSequence] & FLAGGED_BIT)) {
-          double s = D.sol[iSequence];
-          if (s > D.upper[iSequence] + tolerance || s < D.lower[iSequence] - tolerance) {
+        const unsigned char st = D.status[iSequence];
+        const double s = D.sol[iSequence], up = D.upper[iSequence], lo = D.lower[iSequence];
+        if (!(st & FLAGGED_BIT)) {
+          if (s > up + tolerance || s < lo - tolerance) {
             double ratio = value / weight;
             int rank = i - start;
             if (rank < 0)
@@ -2445,7 +2474,7 @@ __global__ void k_btran_t3(Dev D)
 
 // iteration BTRAN, back end: rho[i] = slack part or sum of the gemvT partials, flush tiny, piNeg,
 // rhoSlot (unpruned, for the nucleus update) and the per-block partial of sum rho^2 (DSE norm)
-__global__ void __launch_bounds__(256) k_rho_finish3(Dev D)
+__global__ void __launch_bounds__(256) k_rho_finish3(Dev D, int wide = 0)
 {
   const Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -2460,8 +2489,15 @@ __global__ void __launch_bounds__(256) k_rho_finish3(Dev D)
       // y_R = Minv^T t with t given as a short list: read only those rows of Minv
       const int tc = c->tCount;
       v = 0.0;
-      for (int q = 0; q < tc; q++)
-        v += D.Minv[(size_t)D.tIndex[q] * D.ld + sr] * D.tValue[q];
+      if (wide) {
+        // per-chunk partials of Minv^T t from k_gemvT_partial2, summed in chunk order
+        const int nchunk = (c->k + 63) >> 6;
+        for (int ch = 0; ch < nchunk; ch++)
+          v += D.partial[(size_t)ch * D.ld + sr];
+      } else {
+        for (int q = 0; q < tc; q++)
+          v += D.Minv[(size_t)D.tIndex[q] * D.ld + sr] * D.tValue[q];
+      }
       D.rhoSlot[sr] = v;
     } else {
       int p = D.posOfSlack[i];
@@ -2979,7 +3015,7 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_cand_count(Dev D, int nbRows, i
 // =============================================================================================
 
 // k_chuzr_final + k_btran_t3 in one workgroup
-__global__ void __launch_bounds__(256) k_chuzr_final_btran(Dev D, int nblocks)
+__global__ void __launch_bounds__(256) k_chuzr_final_btran(Dev D, int nblocks, int wide = 0)
 {
   Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -3076,6 +3112,27 @@ __global__ void __launch_bounds__(256) k_chuzr_final_btran(Dev D, int nblocks)
   // structural leaves, and one per basic entry of the leaving slack's row otherwise
   const double dir = (double)c->directionOut;
   const int seqOut = c->sequenceOut;
+  if (wide) {
+    // long rows (dense LPs): t as a dense vector by column-slot for the split GEMV^T
+    // (k_gemvT_partial2); the list form below would be as long as the nucleus
+    const int k = c->k;
+    for (int s = threadIdx.x; s < k; s += blockDim.x)
+      D.slotA[s] = 0.0;
+    __syncthreads();
+    if (seqOut < D.n) {
+      if (threadIdx.x == 0)
+        D.slotA[D.slotOfCol[seqOut]] = dir;
+    } else {
+      const int rOut = seqOut - D.n;
+      const double y = dir * -1.0;
+      const int s = D.rowStart[rOut], cnt = D.basicCount[rOut];
+      for (int q = threadIdx.x; q < cnt; q += blockDim.x)
+        D.slotA[D.slotOfCol[D.ccol[s + q]]] = 0.0 - y * D.relem[s + q];
+    }
+    if (threadIdx.x == 0)
+      c->tCount = -1;
+    return;
+  }
   if (seqOut < D.n) {
     if (threadIdx.x == 0) {
       D.tIndex[0] = D.slotOfCol[seqOut];
@@ -3545,10 +3602,18 @@ __global__ void __launch_bounds__(256) k_minv_fix(Dev D, int parity)
   minvFixBody(D, parity);
 }
 
-__global__ void __launch_bounds__(256) k_fix_house(Dev D, int parity, int doFix)
+__global__ void __launch_bounds__(256) k_fix_house(Dev D, int parity, int doFix, int wide = 0)
 {
   const Ctrl *c = D.ctrl;
-  if (blockIdx.x > 0) {
+  if (blockIdx.x == 1) {
+    // single-stream form: the fix-ups of the basis update (after k_rank1) run in their own
+    // workgroup beside the housekeeping; they use the go flag and k saved by the FTRAN tail, not
+    // the live values workgroup 0 is changing
+    if (doFix)
+      minvFixBody(D, parity);
+    return;
+  }
+  if (blockIdx.x > 1) {
     // (gated by appendGo, not by state: workgroup 0 may raise an exit for the NEXT pivot while
     // these are still starting, and this pivot's entries must reach the list regardless)
     if (!c->appendGo)
@@ -3557,17 +3622,17 @@ __global__ void __launch_bounds__(256) k_fix_house(Dev D, int parity, int doFix)
     // them as it goes: first those of the flip update, then those of the main update, each in
     // position order); the offsets come from the two scans
     __shared__ int shi[17];
-    const int blk = blockIdx.x - 1;
-    const int p = blk * blockDim.x + threadIdx.x;
+    const int blk = blockIdx.x - 2;
+    const int p = blk * 256 + threadIdx.x;  // list blocks are 256 positions whatever the launch width
     int total;
     if (c->numberFlips != 0 && c->numberAppend1 != 0) {
-      int flag = (p < D.m) ? D.appendFlag1[p] : 0;
+      int flag = (threadIdx.x < 256 && p < D.m) ? D.appendFlag1[p] : 0;
       int rank = blockRank(flag, total, shi);
       if (flag)
         D.infIndex[D.blockOffset1[blk] + rank] = p;
     }
     if (c->numberAppend != 0) {
-      int flag = (p < D.m) ? D.appendFlag[p] : 0;
+      int flag = (threadIdx.x < 256 && p < D.m) ? D.appendFlag[p] : 0;
       int rank = blockRank(flag, total, shi);
       if (flag)
         D.infIndex[D.blockOffset[blk] + rank] = p;
@@ -3576,12 +3641,7 @@ __global__ void __launch_bounds__(256) k_fix_house(Dev D, int parity, int doFix)
   }
   if (c->state != RUN)
     return;
-  if (doFix) {
-    // single-stream form: the fix-ups of the basis update run here, after k_rank1
-    minvFixBody(D, parity);
-    __syncthreads();
-  }
-  houseBody(D);
+  houseBody(D, wide);
   // head of the next pivot (only if this one ended normally and no exit was raised)
   if (threadIdx.x == 0 && D.ctrl->state == RUN)
     chuzrPreBody(D);
@@ -4021,7 +4081,40 @@ __global__ void __launch_bounds__(1024) k_gemv3g(Dev D)
 
 // back end of the three FTRANs: w, tau and -- when there are flips -- x3 together with the primal
 // update it drives (ratio 1.0, ClpSimplexDual.cpp:1535-1536)
-__global__ void __launch_bounds__(256) k_ftran_scatter3(Dev D, int nbNorm, int parity)
+// wide-row mode (dense LPs): the slack-row parts of the three FTRANs, one wave per row striding the
+// basic partition of the row copy (fixed 64-way tree per row: deterministic, equal to the sequential
+// sum to rounding)
+__global__ void __launch_bounds__(256) k_slack_dots(Dev D)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  const bool doFlip = c->numberFlips != 0;
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= D.m || D.posOfSlack[t] < 0)
+    return;
+  const int s = D.rowStart[t], e = s + D.basicCount[t];
+  double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  for (int q = s + lane; q < e; q += 64) {
+    const int sc = D.slotOfCol[D.ccol[q]];
+    const double a = D.relem[q];
+    a1 += a * D.slotC[sc];
+    a2 += a * D.slotD[sc];
+    if (doFlip)
+      a3 += a * D.slotE[sc];
+  }
+  a1 = waveSum(a1);
+  a2 = waveSum(a2);
+  a3 = waveSum(a3);
+  if (lane == 0) {
+    D.rowDot[3 * (size_t)t] = a1;
+    D.rowDot[3 * (size_t)t + 1] = a2;
+    D.rowDot[3 * (size_t)t + 2] = a3;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_ftran_scatter3(Dev D, int nbNorm, int parity, int wide = 0)
 {
   const Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -4038,18 +4131,46 @@ __global__ void __launch_bounds__(256) k_ftran_scatter3(Dev D, int nbNorm, int p
     if (p >= 0) {
       double a1 = 0.0, a2 = 0.0, a3 = 0.0;
       int s = D.rowStart[t], e = s + D.basicCount[t];
-      for (int q = s; q < e; q++) {
-        int sc = D.slotOfCol[D.ccol[q]];
-        double a = D.relem[q];
-        a1 += a * D.slotC[sc];
-        a2 += a * D.slotD[sc];
-        if (doFlip)
-          a3 += a * D.slotE[sc];
+      const double v1t = D.vecV1[t], rhot = D.rho[t], flipt = doFlip ? D.flipRhs[t] : 0.0;
+      // four entries per trip: column, then slot, then the three slot values are each requested
+      // together (the chain is three dependent loads deep); the adds stay in entry order
+      if (wide) {
+        a1 = D.rowDot[3 * (size_t)t];
+        a2 = D.rowDot[3 * (size_t)t + 1];
+        a3 = D.rowDot[3 * (size_t)t + 2];
+        e = s;
       }
-      x1 = a1 - D.vecV1[t];
-      x2 = a2 - D.rho[t];
+      for (int q = s; q < e; q += 4) {
+        int cc[4], sc[4];
+        double a[4], c1[4], c2[4], c3[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          cc[u] = (q + u < e) ? D.ccol[q + u] : -1;
+          a[u] = (q + u < e) ? D.relem[q + u] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          sc[u] = cc[u] >= 0 ? D.slotOfCol[cc[u]] : 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          c1[u] = D.slotC[sc[u]];
+          c2[u] = D.slotD[sc[u]];
+          c3[u] = doFlip ? D.slotE[sc[u]] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (cc[u] >= 0) {
+            a1 += a[u] * c1[u];
+            a2 += a[u] * c2[u];
+            if (doFlip)
+              a3 += a[u] * c3[u];
+          }
+        }
+      }
+      x1 = a1 - v1t;
+      x2 = a2 - rhot;
       if (doFlip)
-        x3 = a3 - D.flipRhs[t];
+        x3 = a3 - flipt;
     }
     if (doFlip)
       D.flipRhs[t] = 0.0;  // consumed (nucleus rows were read by k_gemv3g)
