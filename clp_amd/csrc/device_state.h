@@ -74,7 +74,7 @@ struct Ctrl {
   int ticket[8];        // "last workgroup done" counters (always 0 between launches)
   int ticketGroup[4][64];  // first level of the same: one counter per 32 workgroups (<= 2048 workgroups)
   int flipAppend, numberAppend1;
-  int appendGo, appendPad;
+  int appendGo, flipDense;  // flipDense: this pivot's flip rhs is left to k_flip_dense
   int updGo[2], updK, updPad;  // basis-update branch: go flag per pivot parity, k at the time of the fork
   double tailAlpha, tailValueOut;  // w[pivotRow] / sol[sequenceOut] handed to the serial tail of k_ftran_scatter3  // this pivot's primal update completed: its list appends may be scattered  // unordered append count of k_dj_flags (ordered later by k_flip_apply2)
 };
@@ -143,6 +143,7 @@ struct Dev {
   int *classBlock;  // [3 * blocks] ratio-test breakpoint classes per compaction block
   double *blockMin, *blockSum;
   int *flipSeq;
+  double *flipMv;  // [FLIP_MAX_FLIPS] movement of each flip, list order (dense-column mode)
   double *rowDot;  // [3m] wide-row mode: slack-row parts of the three FTRANs (k_slack_dots)
   int *flipKey;  // [FLIP_LIST_CAP] flagged bound flips in arrival order, as compaction keys
   int *appendFlag;  // [m]

@@ -76,6 +76,7 @@ struct clpgpu_context {
   int nSellBlocks = 0, nChzBlocks = 0, priceKernel = 6, useGraph = 1, nWideBlocks = 1;
   bool widePricing = false;
   int maxColumnLength = 1;
+  bool denseColumns = false;  // every column holds all m rows in ascending order
   bool wideRows = false;  // mean row length >= 256 (dense LPs): wave-per-row / split-k variants of the row-wise stages
   int blockedRefactor = 1;
   // basis update (rank-1 sweep + fix-ups of Minv) on a second stream beside primal update,
@@ -300,6 +301,7 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   rc |= dalloc(D.flipSeq, N);
   rc |= dalloc(D.flipKey, FLIP_LIST_CAP);
   rc |= dalloc(D.rowDot, 3 * (size_t)m);
+  rc |= dalloc(D.flipMv, FLIP_MAX_FLIPS);
   rc |= dalloc(D.appendFlag, m);
   rc |= dalloc(D.appendFlag1, m);
   rc |= dalloc(D.blockOffset1, cdiv(m, 256) + 2);
@@ -406,6 +408,13 @@ int clpgpu_context::buildSell()
   maxColumnLength = 1;
   for (int j = 0; j < n; j++)
     maxColumnLength = std::max(maxColumnLength, colStart[j + 1] - colStart[j]);
+  denseColumns = wideRows && (size_t)colStart[n] == (size_t)m * (size_t)n;
+  for (int j = 0; j < n && denseColumns; j++)
+    for (int p = colStart[j], i = 0; p < colStart[j + 1]; p++, i++)
+      if (row[p] != i) {
+        denseColumns = false;
+        break;
+      }
   nWideBlocks = std::min(WIDE_BLOCKS, std::max(1, cdiv(count, 4)));
   rc |= dalloc(D.sellMin, std::max(nSellBlocks, WIDE_BLOCKS));
   rc |= dalloc(D.sellBytes, std::max(nSellBlocks, WIDE_BLOCKS));
@@ -1326,7 +1335,7 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
     (void)hipEventRecord(evStart[evUsed], stream);
   if (priceKernel >= 1) {
     if (widePricing && priceKernel != 1)
-      hipLaunchKernelGGL(k_price_wide, dim3(nWideBlocks), dim3(256), 0, stream, D);
+      hipLaunchKernelGGL(k_price_wide, dim3(nWideBlocks), dim3(256), 0, stream, D, denseColumns ? 1 : 0);
     else if (nSellBlocks > 0)
       hipLaunchKernelGGL(k_price_sell, dim3(nSellBlocks), dim3(256), (m > 64 * SELL_BITS_MAX || priceKernel < 2) ? 0 : (size_t)((m + 63) / 64) * 8, stream, D, (m > 64 * SELL_BITS_MAX && priceKernel > 1) ? 1 : priceKernel);
     if (ev)
@@ -1356,7 +1365,9 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   hipLaunchKernelGGL(k_dual_column, dim3(1), dim3(DC_THREADS), 0, stream, D, nb);
   // dual update + flip detection (needs only theta), flip list, flip right-hand side
   hipLaunchKernelGGL(k_dj_flags, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
-  hipLaunchKernelGGL(k_flip_apply2, dim3(1), dim3(1024), 0, stream, D, gm);
+  hipLaunchKernelGGL(k_flip_apply2, dim3(1), dim3(1024), 0, stream, D, gm, denseColumns ? 1 : 0);
+  if (denseColumns)
+    hipLaunchKernelGGL(k_flip_dense, dim3(gm), dim3(256), 0, stream, D);
   // one FTRAN sweep for the entering column, rho (DSE) and the flip rhs; the back end also applies
   // the flip part of the primal update
   hipLaunchKernelGGL(k_gemv3g, dim3(cdiv(kc, GEMV_RPB)), dim3(1024), 0, stream, D);

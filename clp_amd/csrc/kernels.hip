@@ -346,6 +346,7 @@ __global__ void __launch_bounds__(1024) k_chuzr(Dev D)
       c->sequenceIn = -1;
       c->numberFlips = 0;
       c->flipAppend = 0;
+      c->flipDense = 0;
       c->appendGo = 0;
       c->objectiveChange = 0.0;
     }
@@ -2417,6 +2418,7 @@ __global__ void __launch_bounds__(256) k_chuzr_final(Dev D, int nblocks)
   c->sequenceIn = -1;
   c->numberFlips = 0;
   c->flipAppend = 0;
+  c->flipDense = 0;
   c->appendGo = 0;
   c->objectiveChange = 0.0;
 }
@@ -2888,7 +2890,7 @@ __global__ void __launch_bounds__(256) k_price_sell(Dev D, int variant)
 // sum is then a fixed 64-way tree instead of the reference's sequential order: deterministic, but
 // only equal to the sequential sum to rounding (used when the mean column length is >= 256).
 #define WIDE_BLOCKS 4096
-__global__ void __launch_bounds__(256) k_price_wide(Dev D)
+__global__ void __launch_bounds__(256) k_price_wide(Dev D, int denseColumns = 0)
 {
   const Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -2906,8 +2908,14 @@ __global__ void __launch_bounds__(256) k_price_wide(Dev D)
     if (wanted) {
       const int start = D.colStart[j], end = D.colStart[j + 1];
       double acc = 0.0;
-      for (int p = start + lane; p < end; p += 64)
-        acc += D.piNeg[D.row[p]] * D.elem[p];
+      if (denseColumns) {
+        // full, row-ordered columns: the row index is the position, no index stream
+        for (int p = start + lane; p < end; p += 64)
+          acc += D.piNeg[p - start] * D.elem[p];
+      } else {
+        for (int p = start + lane; p < end; p += 64)
+          acc += D.piNeg[D.row[p]] * D.elem[p];
+      }
       value = waveSum(acc);
       value = __shfl(value, 0);
       if (lane == 0)
@@ -3101,6 +3109,7 @@ __global__ void __launch_bounds__(256) k_chuzr_final_btran(Dev D, int nblocks, i
       c->sequenceIn = -1;
       c->numberFlips = 0;
       c->flipAppend = 0;
+      c->flipDense = 0;
       c->appendGo = 0;
       c->objectiveChange = 0.0;
     }
@@ -3768,7 +3777,35 @@ __device__ void flipSequential(const Dev &D, int nf)
 #define FLIP_HASH_BITS 14
 #define FLIP_HASH_ROW 0x3fffffff
 #define FLIP_HASH_MULTI 0x40000000
-__global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos)
+// dense-column mode (every column holds all m rows in order): flip right-hand side with one thread
+// per row, flips in list order -- the same adds in the same order as the sequential form
+__global__ void __launch_bounds__(256) k_flip_dense(Dev D)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN || !c->flipDense)
+    return;
+  const int nf = c->numberFlips;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= D.m)
+    return;
+  double acc = 0.0;
+  for (int f = 0; f < nf; f++) {
+    const int seq = D.flipSeq[f];
+    const double mv = D.flipMv[f];
+    if (seq >= D.n) {
+      if (seq - D.n == r)
+        acc += mv;
+    } else {
+      acc += mv * D.elem[D.colStart[seq] + r];
+    }
+  }
+  D.flipRhs[r] = acc;
+  const int sr = D.slotOfRow[r];
+  if (sr >= 0)
+    D.flipSlot[sr] = acc;
+}
+
+__global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos, int denseColumns = 0)
 {
   Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -3897,6 +3934,18 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos)
     }
     __syncthreads();
     fallback = s_total > FLIP_MAX_ENTRIES;
+    if (fallback && denseColumns) {
+      // every column is a full, row-ordered column: the right-hand side is a row-parallel sweep
+      // (k_flip_dense); hand over the movements and finish the scalar part here
+      for (int f = tid; f < nf; f += blockDim.x)
+        D.flipMv[f] = s_mv[f];
+      double s = blockSum(changeObj, shd);
+      if (tid == 0) {
+        c->objectiveChange += s;
+        c->flipDense = 1;
+      }
+      return;
+    }
   }
   if (fallback) {
     if (tid == 0)
@@ -4096,13 +4145,35 @@ __global__ void __launch_bounds__(256) k_slack_dots(Dev D)
     return;
   const int s = D.rowStart[t], e = s + D.basicCount[t];
   double a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  for (int q = s + lane; q < e; q += 64) {
-    const int sc = D.slotOfCol[D.ccol[q]];
-    const double a = D.relem[q];
-    a1 += a * D.slotC[sc];
-    a2 += a * D.slotD[sc];
-    if (doFlip)
-      a3 += a * D.slotE[sc];
+  // four strides per trip so that each level of the column -> slot -> value chain is one round of
+  // loads instead of four
+  for (int q0 = s + lane; q0 < e; q0 += 256) {
+    int cc[4], sc[4];
+    double a[4], c1[4], c2[4], c3[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int q = q0 + 64 * u;
+      cc[u] = q < e ? D.ccol[q] : -1;
+      a[u] = q < e ? D.relem[q] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      sc[u] = cc[u] >= 0 ? D.slotOfCol[cc[u]] : 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      c1[u] = D.slotC[sc[u]];
+      c2[u] = D.slotD[sc[u]];
+      c3[u] = doFlip ? D.slotE[sc[u]] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (cc[u] >= 0) {
+        a1 += a[u] * c1[u];
+        a2 += a[u] * c2[u];
+        if (doFlip)
+          a3 += a[u] * c3[u];
+      }
+    }
   }
   a1 = waveSum(a1);
   a2 = waveSum(a2);
