@@ -205,8 +205,11 @@ def test_afiro_identical_pivot_sequence(gpu_cls, afiro, rule):
     kkt(afiro, g)
 
 
+# dense 300x400: mean row and column length >= 256 -> the wide-row / wide-column / dense-column kernel
+# variants; sparse 60x30000: long rows with short columns (wide-row variants alone)
 @pytest.mark.parametrize("maker,args", [("dense_lp", (120, 150, 12)), ("sparse_lp", (300, 1200, 8, 11)),
-                                        ("sparse_lp", (1500, 6000, 10, 31))])
+                                        ("sparse_lp", (1500, 6000, 10, 31)), ("dense_lp", (300, 400, 5)),
+                                        ("sparse_lp", (60, 30000, 6, 5))])
 @pytest.mark.parametrize("rule", [0, 1])
 def test_random_lp_identical_pivot_sequence(gpu_cls, maker, args, rule):
     lp = getattr(P, maker)(*args)
