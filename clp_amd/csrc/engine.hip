@@ -311,7 +311,7 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   rc |= dalloc(D.chzBest, nChzBlocks);
   rc |= dalloc(D.chzKey, nChzBlocks);
   rc |= dalloc(D.chzRow, nChzBlocks);
-  rc |= dalloc(D.normPartial, cdiv(m, 256));
+  rc |= dalloc(D.normPartial, cdiv(m, 4) + 1);
   rc |= dalloc(dLocalOfRow, m);
   rc |= dalloc(dInfo, 4);
   if (rc)
@@ -681,7 +681,8 @@ int clpgpu_context::btranDevice(const double *cPos, double *yRow)
   const int k = hCtrl->k;
   hipLaunchKernelGGL(k_btran_slack, dim3(cdiv(m, 256)), dim3(256), 0, stream, D, cPos, yRow, 0);
   if (k) {
-    hipLaunchKernelGGL(k_btran_t, dim3(cdiv(k, 256)), dim3(256), 0, stream, D, cPos, (const double *)yRow, D.slotA, 0);
+    hipLaunchKernelGGL(k_btran_t, dim3(widePricing ? cdiv(k, 4) : cdiv(k, 256)), dim3(256), 0, stream, D, cPos, (const double *)yRow, D.slotA, 0,
+                       widePricing ? 1 : 0);
     hipLaunchKernelGGL(k_gemvT_partial, dim3(cdiv(k, 256), cdiv(k, 64)), dim3(256), 0, stream, D, (const double *)D.slotA, 0);
     hipLaunchKernelGGL(k_gemvT_final, dim3(cdiv(k, 256)), dim3(256), 0, stream, D, yRow, 0, 0);
   }
@@ -695,12 +696,15 @@ int clpgpu_context::gutsOfSolution()
   int rc = pushCtrl();
   const int g = cdiv(m, 256);
   hipLaunchKernelGGL(k_zero_basic, dim3(g), dim3(256), 0, stream, D);
-  hipLaunchKernelGGL(k_primal_rhs, dim3(g), dim3(256), 0, stream, D, D.vecV2);
+  hipLaunchKernelGGL(k_primal_rhs, dim3(wideRows ? cdiv(m, 4) : g), dim3(256), 0, stream, D, D.vecV2, wideRows ? 1 : 0);
   ftranDevice(D.vecV2, D.x3);
   hipLaunchKernelGGL(k_store_basic, dim3(g), dim3(256), 0, stream, D, (const double *)D.x3);
   hipLaunchKernelGGL(k_basic_costs, dim3(g), dim3(256), 0, stream, D, D.tau);
   btranDevice(D.tau, D.vecV2);
-  hipLaunchKernelGGL(k_djs, dim3(cdiv(N, 256)), dim3(256), 0, stream, D, (const double *)D.vecV2);
+  if (widePricing)
+    hipLaunchKernelGGL(k_djs, dim3(cdiv(n, 4) + cdiv(m, 256)), dim3(256), 0, stream, D, (const double *)D.vecV2, 1);
+  else
+    hipLaunchKernelGGL(k_djs, dim3(cdiv(N, 256)), dim3(256), 0, stream, D, (const double *)D.vecV2, 0);
   // errors: residuals of the two solves (computed from the device results on the host mirrors)
   std::vector<double> rhs(m), xB(m), y(m);
   rc |= d2h(rhs.data(), D.vecV2, m);  // y (duals) now in vecV2
@@ -711,11 +715,12 @@ int clpgpu_context::gutsOfSolution()
   hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, stream, D.x3, m);
   // largestPrimalError: max |(A x - s)_i| over all rows, reduced per block on the device
   {
-    hipLaunchKernelGGL(k_primal_residual, dim3(g), dim3(256), 0, stream, D);
-    std::vector<double> part(g);
-    rc |= d2h(part.data(), D.normPartial, g);
+    const int gr = wideRows ? cdiv(m, 4) : g;
+    hipLaunchKernelGGL(k_primal_residual, dim3(gr), dim3(256), 0, stream, D, wideRows ? 1 : 0);
+    std::vector<double> part(gr);
+    rc |= d2h(part.data(), D.normPartial, gr);
     double largest = 0.0;
-    for (int b = 0; b < g; b++)
+    for (int b = 0; b < gr; b++)
       largest = fmax(largest, part[b]);
     largestPrimalError = largest;
   }

@@ -372,10 +372,27 @@ __global__ void k_btran_slack(Dev D, const double *cvec, double *y, int iter)
   }
 }
 
-__global__ void k_btran_t(Dev D, const double *cvec, const double *y, double *t, int iter)
+__global__ void k_btran_t(Dev D, const double *cvec, const double *y, double *t, int iter, int wide = 0)
 {
   if (iter && D.ctrl->state != RUN)
     return;
+  if (wide) {
+    // long columns: a wave per column-slot (fixed 64-way tree)
+    const int sc = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (sc < D.ctrl->k) {
+      const int col = D.slotCol[sc];
+      double acc = 0.0;
+      for (int p = D.colStart[col] + lane; p < D.colStart[col + 1]; p += 64) {
+        int r = D.row[p];
+        if (D.slotOfRow[r] < 0)
+          acc += y[r] * D.elem[p];
+      }
+      acc = waveSum(acc);
+      if (lane == 0)
+        t[sc] = cvec[D.slotPos[sc]] - acc;
+    }
+    return;
+  }
   int sc = blockIdx.x * blockDim.x + threadIdx.x;
   if (sc < D.ctrl->k) {
     int col = D.slotCol[sc];
@@ -4992,8 +5009,21 @@ __global__ void k_zero_basic(Dev D)
   if (p < D.m)
     D.sol[D.pivotVariable[p]] = 0.0;
 }
-__global__ void k_primal_rhs(Dev D, double *rhs)
+__global__ void k_primal_rhs(Dev D, double *rhs, int wide = 0)
 {
+  if (wide) {
+    // long rows: a wave per row (fixed 64-way tree)
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i < D.m) {
+      double acc = 0.0;
+      for (int q = D.rowStart[i] + lane; q < D.rowStart[i + 1]; q += 64)
+        acc += D.relem[q] * D.sol[D.ccol[q]];
+      acc = waveSum(acc);
+      if (lane == 0)
+        rhs[i] = -acc + D.sol[D.n + i];
+    }
+    return;
+  }
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < D.m) {
     double acc = 0.0;
@@ -5003,12 +5033,23 @@ __global__ void k_primal_rhs(Dev D, double *rhs)
   }
 }
 // max |(A x)_i - s_i| per block (largestPrimalError of computePrimals)
-__global__ void __launch_bounds__(256) k_primal_residual(Dev D)
+__global__ void __launch_bounds__(256) k_primal_residual(Dev D, int wide = 0)
 {
   __shared__ double sh[16];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   double r = 0.0;
-  if (i < D.m) {
+  if (wide) {
+    // long rows: a wave per row, 4 rows per workgroup
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row < D.m) {
+      double acc = 0.0;
+      for (int q = D.rowStart[row] + lane; q < D.rowStart[row + 1]; q += 64)
+        acc += D.relem[q] * D.sol[D.ccol[q]];
+      acc = waveSum(acc);
+      if (lane == 0)
+        r = fabs(acc - D.sol[D.n + row]);
+    }
+  } else if (i < D.m) {
     double acc = 0.0;
     for (int q = D.rowStart[i]; q < D.rowStart[i + 1]; q++)
       acc += D.relem[q] * D.sol[D.ccol[q]];
@@ -5032,8 +5073,25 @@ __global__ void k_basic_costs(Dev D, double *cB)
   if (p < D.m)
     cB[p] = D.cost[D.pivotVariable[p]];
 }
-__global__ void k_djs(Dev D, const double *y)
+__global__ void k_djs(Dev D, const double *y, int wide = 0)
 {
+  if (wide) {
+    // long columns: a wave per structural column; the slack part keeps a thread per row
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (w < D.n) {
+      double acc = 0.0;
+      for (int p = D.colStart[w] + lane; p < D.colStart[w + 1]; p += 64)
+        acc += y[D.row[p]] * D.elem[p];
+      acc = waveSum(acc);
+      if (lane == 0)
+        D.dj[w] = D.cost[w] + acc * -1.0;
+    } else {
+      const int t = D.n + (w - D.n) * 64 + lane;
+      if (t < D.N)
+        D.dj[t] = y[t - D.n] + D.cost[t];
+    }
+    return;
+  }
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < D.n) {
     double value = 0.0;
