@@ -1325,6 +1325,7 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   const int kc = kcap;  // launch extents use the capacity; kernels read the live k from ctrl
   const int gk = cdiv(kc, 256);
   const bool ev = timing && !capturing && evUsed < (int)evStart.size();
+  int selfScanSell = -1;
   // CHUZR (+ the analytic front end of the BTRAN)
   if (firstOfBatch)
     hipLaunchKernelGGL(k_chuzr_pre, dim3(1), dim3(64), 0, stream, D);
@@ -1356,8 +1357,7 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
       const int nSell = (widePricing && priceKernel != 1) ? nWideBlocks : nSellBlocks;
       const bool fuse = nb <= 256;  // small grids: the last workgroup scans the counts itself
       hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, commActive ? 1 : 0, fuse ? nSell : -1);
-      if (!fuse)
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1, nSell);
+      selfScanSell = fuse ? -1 : nSell;  // large grids: k_cand_scatter scans for itself, no scan launch
     }
   } else {
     hipLaunchKernelGGL(k_price, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
@@ -1365,7 +1365,7 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
       (void)hipEventRecord(evStop[evUsed++], stream);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1, 0);
   }
-  hipLaunchKernelGGL(k_cand_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
+  hipLaunchKernelGGL(k_cand_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, selfScanSell);
   // CHUZC (also unpacks the entering column)
   hipLaunchKernelGGL(k_dual_column, dim3(1), dim3(DC_THREADS), 0, stream, D, nb);
   // dual update + flip detection (needs only theta), flip list, flip right-hand side

@@ -44,6 +44,21 @@ __device__ inline double blockSum(double v, double *sh /*[16]*/)
     t += sh[i];
   return t;
 }
+// block-wide integer sum; result valid in every thread
+__device__ inline int blockSumInt(int v, int *sh /*[17]*/)
+{
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int o = 32; o > 0; o >>= 1)
+    v += __shfl_xor(v, o);
+  __syncthreads();
+  if (lane == 0)
+    sh[wv] = v;
+  __syncthreads();
+  int t = 0;
+  for (int i = 0; i < nw; i++)
+    t += sh[i];
+  return t;
+}
 __device__ inline double blockMin(double v, double *sh)
 {
   int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -691,12 +706,16 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(Dev D, int nb, int what, i
   scanBlocksBody<false>(D, nb, what, nSell);
 }
 
-__global__ void __launch_bounds__(PRICE_BLOCK) k_cand_scatter(Dev D, int nbRows)
+// nSell >= 0: no separate scan launch -- every workgroup that has candidates sums the counts of the
+// workgroups before it and takes the min over all first-pass ratios itself (a few thousand L2 reads,
+// all in parallel); workgroup 0 also leaves the totals in the control block for the ratio test.
+__global__ void __launch_bounds__(PRICE_BLOCK) k_cand_scatter(Dev D, int nbRows, int nSell = -1)
 {
-  const Ctrl *c = D.ctrl;
+  Ctrl *c = D.ctrl;
   if (c->state != RUN)
     return;
   __shared__ int shi[17];
+  __shared__ double shd[16];
   int flag = 0, seq = -1;
   double alpha = 0.0;
   if ((int)blockIdx.x < nbRows) {
@@ -716,16 +735,80 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_cand_scatter(Dev D, int nbRows)
   }
   int total;
   int rank = blockRank(flag, total, shi);
+  int offset;
+  double upperTheta;
+  if (nSell >= 0) {
+    offset = 0;
+    upperTheta = 1.0e31;
+    if (total > 0 || blockIdx.x == 0) {  // uniform per workgroup
+      const int nb = gridDim.x, me = blockIdx.x, tid = threadIdx.x;
+      int pre = 0, all = 0;
+      double vmin = 1.0e31, bytes = 0.0;
+      if (nb <= 8 * PRICE_BLOCK && nSell <= 8 * PRICE_BLOCK) {
+        int cnt[8];
+        double mn[8], sm[8], smn[8], sby[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int b = tid + u * PRICE_BLOCK;
+          cnt[u] = b < nb ? D.blockCount[b] : 0;
+          mn[u] = b < nb ? D.blockMin[b] : 1.0e31;
+          sm[u] = (me == 0 && b < nb) ? D.blockSum[b] : 0.0;
+          smn[u] = b < nSell ? D.sellMin[b] : 1.0e31;
+          sby[u] = (me == 0 && b < nSell) ? D.sellBytes[b] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int b = tid + u * PRICE_BLOCK;
+          all += cnt[u];
+          if (b < me)
+            pre += cnt[u];
+          vmin = fmin(vmin, fmin(mn[u], smn[u]));
+          bytes += sm[u] + sby[u];
+        }
+      } else {
+        for (int b = tid; b < nb; b += PRICE_BLOCK) {
+          const int cnt = D.blockCount[b];
+          all += cnt;
+          if (b < me)
+            pre += cnt;
+          vmin = fmin(vmin, D.blockMin[b]);
+          if (me == 0)
+            bytes += D.blockSum[b];
+        }
+        for (int b = tid; b < nSell; b += PRICE_BLOCK) {
+          vmin = fmin(vmin, D.sellMin[b]);
+          if (me == 0)
+            bytes += D.sellBytes[b];
+        }
+      }
+      offset = blockSumInt(pre, shi);
+      upperTheta = blockMin(vmin, shd);
+      if (me == 0) {
+        all = blockSumInt(all, shi);
+        bytes = blockSum(bytes, shd);
+        if (tid == 0) {
+          c->numberCandidates = all;
+          c->upperTheta = upperTheta;
+          // algorithmic bytes of this pricing launch, as in scanBlocksBody
+          c->statPriceBytes += bytes + (double)(D.lastColumn - D.firstColumn) + 8.0 * D.m + 4.0;
+          c->statPriceLaunches += 1.0;
+        }
+      }
+    }
+  } else {
+    offset = D.blockOffset[blockIdx.x];
+    upperTheta = c->upperTheta;
+  }
   int cls = 3;
   if (flag) {
-    int o = D.blockOffset[blockIdx.x] + rank;
+    int o = offset + rank;
     D.candSeq[o] = seq;
     D.candAlpha[o] = alpha;
     // breakpoint of the coarse ratio passes (ClpSimplexDual.cpp:4384 / :4412) against theta0
     const double tol = c->dualTolerance;
     const double djv = D.dj[seq];
     const double x = (alpha < 0.0) ? (djv - tol) / alpha : (djv + tol) / alpha;
-    const double theta0 = fmax(10.0 * c->upperTheta, 1.0e-7);
+    const double theta0 = fmax(10.0 * upperTheta, 1.0e-7);
     cls = (x <= theta0 * 8.0) ? 0 : ((x <= theta0 * 256.0) ? 1 : ((x <= theta0 * 16384.0) ? 2 : 3));
     D.candLive[o] = (unsigned char)cls;
   }
