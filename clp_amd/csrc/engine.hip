@@ -1382,22 +1382,20 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   // basis update of the nucleus inverse: needs only what the FTRAN tail left (w and rho by slot, the
   // update scalars), nothing downstream needs Minv before the next BTRAN -> its own branch
   {
-    hipStream_t us = stream;
+    const int gx = cdiv(kc, 256), gy = kc < 512 ? kc : 512;
     if (forkUpdate && stream2) {
       (void)hipEventRecord(evFork, stream);
       (void)hipStreamWaitEvent(stream2, evFork, 0);
-      us = stream2;
-    }
-    hipLaunchKernelGGL(k_rank1, dim3(cdiv(kc, 256), kc < 512 ? kc : 512), dim3(256), 0, us, D, parity);
-    if (us != stream)
-      hipLaunchKernelGGL(k_minv_fix, dim3(1), dim3(256), 0, us, D, parity);
-    if (us != stream) {
+      hipLaunchKernelGGL(k_rank1, dim3(gx, gy), dim3(256), 0, stream2, D, parity);
+      hipLaunchKernelGGL(k_minv_fix, dim3(1), dim3(256), 0, stream2, D, parity);
       (void)hipEventRecord(evJoin, stream2);
       sidePending = true;
+      hipLaunchKernelGGL(k_primal_update, dim3(gm), dim3(256), 0, stream, D, 0);
+    } else {
+      // one launch: primal update with the entering column + rank-1 sweep of the nucleus inverse
+      hipLaunchKernelGGL(k_primal_rank1, dim3(gm + gx * gy), dim3(256), 0, stream, D, parity, gm, gx, gy);
     }
   }
-  // primal update with the entering column
-  hipLaunchKernelGGL(k_primal_update, dim3(gm), dim3(256), 0, stream, D, 0);
   // workgroup 0: fix-ups of the basis update, housekeeping, head of the next CHUZR; the others
   // scatter this pivot's new primal infeasibilities into the list
   if (wideRows) {

@@ -143,22 +143,28 @@ __device__ inline void stc(double *p, double v)
 // device-scope fence here would write back each L2 once per workgroup; instead everything the tail
 // reads is published with stc() (write-through) and read with ldc(), and the ticket only has to wait
 // for those stores to complete.
-__device__ inline bool lastBlockDone(Ctrl *c, int slot)
+// (nblocks / me: the participating workgroups and this one's index among them, when only a leading
+// part of the grid takes part)
+__device__ inline bool lastBlockDone(Ctrl *c, int slot, int nblocks = -1, int me = -1)
 {
+  if (nblocks < 0) {
+    nblocks = gridDim.x;
+    me = blockIdx.x;
+  }
   __shared__ int s_last;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   if (threadIdx.x == 0) {
     // two-level count (atomics on one address serialise at ~15 ns each across the XCDs): first the
     // counter of this workgroup's group of 32, then -- last of the group only -- the launch counter
-    const int g = blockIdx.x >> 5, ngroups = ((int)gridDim.x + 31) >> 5;
-    const int gsize = min(32, (int)gridDim.x - (g << 5));
+    const int g = me >> 5, ngroups = (nblocks + 31) >> 5;
+    const int gsize = min(32, nblocks - (g << 5));
     int last = 0;
     int *gc = &c->ticketGroup[slot][g & 63];
     if (ngroups > 64) {
       // (launches beyond 2048 workgroups: single level)
       int t = __hip_atomic_fetch_add(&c->ticket[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      last = (t == (int)gridDim.x - 1);
+      last = (t == nblocks - 1);
     } else if (__hip_atomic_fetch_add(gc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
       __hip_atomic_store(gc, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int t = __hip_atomic_fetch_add(&c->ticket[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1799,7 +1805,8 @@ __global__ void k_flip_bounds(Dev D)
 // ascending position order (count / scan / scatter keeps CoinIndexedVector's insertion order).
 // which: 0 -> vec = w, ratio = ctrl.movement ; 1 -> vec = x3 (flip FTRAN), ratio = 1
 // =============================================================================================
-__global__ void __launch_bounds__(256) k_primal_update(Dev D, int which)
+// bid / nblk: this workgroup's index and the number of workgroups doing the primal update
+__device__ inline void primalUpdateBody(const Dev &D, int which, int bid, int nblk)
 {
   const Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -1811,10 +1818,10 @@ __global__ void __launch_bounds__(256) k_primal_update(Dev D, int which)
   const double *vec = which ? D.x3 : D.w;
   const double ratio = which ? 1.0 : c->movement;
   const double tolerance = c->primalTolerance;
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  int p = bid * blockDim.x + threadIdx.x;
   if (which == 0) {
     // ClpSimplexDual::flipBounds (:6345-6401), after the backwards check of the scalar block
-    for (int f = p; f < c->numberFlips; f += gridDim.x * blockDim.x) {
+    for (int f = p; f < c->numberFlips; f += nblk * blockDim.x) {
       int seq = D.flipSeq[f];
       int st = D.status[seq] & 7;
       if (st == ST_UPPER) {
@@ -1868,12 +1875,17 @@ __global__ void __launch_bounds__(256) k_primal_update(Dev D, int which)
   blockRank(append, total, shi);
   double s = blockSum(changeObj, shd);
   if (threadIdx.x == 0) {
-    stc(&D.blockCount[blockIdx.x], total);
-    stc(&D.blockSum[blockIdx.x], s);
+    stc(&D.blockCount[bid], total);
+    stc(&D.blockSum[bid], s);
   }
   // serial tail (offsets of the appends, objective change) in the last workgroup to finish
-  if (which == 0 && lastBlockDone(D.ctrl, 2))
-    scanTailBody(D, gridDim.x, gridDim.x, 0, 0, -1);
+  if (which == 0 && lastBlockDone(D.ctrl, 2, nblk, bid))
+    scanTailBody(D, nblk, nblk, 0, 0, -1);
+}
+
+__global__ void __launch_bounds__(256) k_primal_update(Dev D, int which)
+{
+  primalUpdateBody(D, which, blockIdx.x, gridDim.x);
 }
 
 __global__ void __launch_bounds__(256) k_append_scatter(Dev D, int which, int iter)
@@ -1970,7 +1982,7 @@ __global__ void k_update_vectors(Dev D)
   }
 }
 
-__global__ void __launch_bounds__(256) k_rank1(Dev D, int parity = -1)
+__device__ inline void rank1Body(const Dev &D, int parity, int bx, int by, int gx, int gy)
 {
   const Ctrl *c = D.ctrl;
   // parity >= 0: forked beside the rest of the pivot -- gated by the go flag the FTRAN tail set
@@ -1978,14 +1990,31 @@ __global__ void __launch_bounds__(256) k_rank1(Dev D, int parity = -1)
     return;
   const int k = parity >= 0 ? c->updK : c->k;
   const double dir = (double)c->directionOut, alpha = c->alpha;
-  // blockIdx.x * 256 + thread = column j (coalesced along the row), blockIdx.y strides rows
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < k; j += gridDim.x * blockDim.x) {
+  // bx * 256 + thread = column j (coalesced along the row), by strides rows
+  for (int j = bx * blockDim.x + threadIdx.x; j < k; j += gx * blockDim.x) {
     const double gj = dir * D.rhoSlot[j] / alpha;
-    for (int i = blockIdx.y; i < k; i += gridDim.y) {
+    for (int i = by; i < k; i += gy) {
       double wi = D.slotC[i];  // w by column-slot, as the FTRAN sweep left it (== w[slotPos[i]])
       if (wi != 0.0)
         D.Minv[(size_t)i * D.ld + j] -= wi * gj;
     }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_rank1(Dev D, int parity = -1)
+{
+  rank1Body(D, parity, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+}
+// primal update and rank-1 sweep of the nucleus inverse in one launch: both only need what the
+// FTRAN tail left behind and touch disjoint data.  Workgroups [0, nPrimal) do the primal update (and
+// its serial tail), the rest the gx x gy tiles of the rank-1 sweep.
+__global__ void __launch_bounds__(256) k_primal_rank1(Dev D, int parity, int nPrimal, int gx, int gy)
+{
+  if ((int)blockIdx.x < nPrimal) {
+    primalUpdateBody(D, 0, blockIdx.x, nPrimal);
+  } else {
+    const int id = blockIdx.x - nPrimal;
+    rank1Body(D, parity, id % gx, id / gx, gx, gy);
   }
 }
 
