@@ -1335,15 +1335,19 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   joinUpdateBranch();
   if (wideRows)
     hipLaunchKernelGGL(k_gemvT_partial2, dim3(cdiv(kc, 256), cdiv(kc, 64)), dim3(256), 0, stream, D, (const double *)D.slotA, 1);
-  hipLaunchKernelGGL(k_rho_finish3, dim3(gm), dim3(256), 0, stream, D, wideRows ? 1 : 0);
+  // (not column-sharded: the candidate counts come from this kernel and the pricing kernel, there
+  // is no separate counting launch)
+  const bool countInPrice = priceKernel >= 1 && !commActive && nb > 256;
+  hipLaunchKernelGGL(k_rho_finish3, dim3(gm), dim3(256), 0, stream, D, wideRows ? 1 : 0, countInPrice ? nbCols : -1);
   // PRICE + first ratio pass
   if (ev)
     (void)hipEventRecord(evStart[evUsed], stream);
   if (priceKernel >= 1) {
     if (widePricing && priceKernel != 1)
-      hipLaunchKernelGGL(k_price_wide, dim3(nWideBlocks), dim3(256), 0, stream, D, denseColumns ? 1 : 0);
+      hipLaunchKernelGGL(k_price_wide, dim3(nWideBlocks), dim3(256), 0, stream, D, denseColumns ? 1 : 0, countInPrice ? 1 : 0);
     else if (nSellBlocks > 0)
-      hipLaunchKernelGGL(k_price_sell, dim3(nSellBlocks), dim3(256), (m > 64 * SELL_BITS_MAX || priceKernel < 2) ? 0 : (size_t)((m + 63) / 64) * 8, stream, D, (m > 64 * SELL_BITS_MAX && priceKernel > 1) ? 1 : priceKernel);
+      hipLaunchKernelGGL(k_price_sell, dim3(nSellBlocks), dim3(256), (m > 64 * SELL_BITS_MAX || priceKernel < 2) ? 0 : (size_t)((m + 63) / 64) * 8, stream, D, (m > 64 * SELL_BITS_MAX && priceKernel > 1) ? 1 : priceKernel,
+                         countInPrice ? 1 : 0);
     if (ev)
       (void)hipEventRecord(evStop[evUsed++], stream);
     if (commActive) {
@@ -1356,7 +1360,8 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
     {
       const int nSell = (widePricing && priceKernel != 1) ? nWideBlocks : nSellBlocks;
       const bool fuse = nb <= 256;  // small grids: the last workgroup scans the counts itself
-      hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, commActive ? 1 : 0, fuse ? nSell : -1);
+      if (!countInPrice)
+        hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, commActive ? 1 : 0, fuse ? nSell : -1);
       selfScanSell = fuse ? -1 : nSell;  // large grids: k_cand_scatter scans for itself, no scan launch
     }
   } else {

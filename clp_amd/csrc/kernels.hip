@@ -2605,7 +2605,7 @@ __global__ void k_btran_t3(Dev D)
 
 // iteration BTRAN, back end: rho[i] = slack part or sum of the gemvT partials, flush tiny, piNeg,
 // rhoSlot (unpruned, for the nucleus update) and the per-block partial of sum rho^2 (DSE norm)
-__global__ void __launch_bounds__(256) k_rho_finish3(Dev D, int wide = 0)
+__global__ void __launch_bounds__(256) k_rho_finish3(Dev D, int wide = 0, int nbCols = -1)
 {
   const Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -2649,6 +2649,48 @@ __global__ void __launch_bounds__(256) k_rho_finish3(Dev D, int wide = 0)
   double s = blockSum(sq, sh);
   if (threadIdx.x == 0)
     D.normPartial[blockIdx.x] = s;
+  if (nbCols >= 0) {
+    // first ratio pass for the row (slack) part of the tableau row, as the pricing kernel does it
+    // for the columns (ClpPackedMatrix.cpp:1007-1090); candidate counts of the compaction blocks:
+    // this block's rows here, the column blocks are zeroed for the pricing kernel's atomics
+    __shared__ int shi[17];
+    int flag = 0;
+    double ratio = 1.0e31;
+    if (i < D.m) {
+      const double dualT = -c->dualTolerance;
+      const double value = D.rho[i];
+      if (value != 0.0) {
+        int iStatus = (D.status[D.n + i] & 3) - 1;
+        if (iStatus > 0) {
+          double mult = (iStatus == 1) ? -1.0 : 1.0;
+          double alpha = value * mult;
+          if (alpha > 0.0) {
+            double oldValue = D.dj[D.n + i] * mult;
+            double v2 = oldValue - 1.0e15 * alpha;
+            if (v2 < dualT) {
+              flag = 1;
+              if (alpha >= c->acceptablePivot)
+                ratio = (oldValue - dualT) / alpha;
+            }
+          }
+        }
+      }
+      D.candFlag[i] = (unsigned char)flag;
+    }
+    int total;
+    blockRank(flag, total, shi);
+    double bmin = blockMin(ratio, sh);
+    if (threadIdx.x == 0) {
+      D.blockCount[blockIdx.x] = total;
+      D.blockMin[blockIdx.x] = bmin;
+      D.blockSum[blockIdx.x] = 0.0;
+    }
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < nbCols; g += gridDim.x * blockDim.x) {
+      D.blockCount[gridDim.x + g] = 0;
+      D.blockMin[gridDim.x + g] = 1.0e31;
+      D.blockSum[gridDim.x + g] = 0.0;
+    }
+  }
 }
 
 // gemvT partial with 8 independent loads in flight per lane
@@ -2815,7 +2857,8 @@ __global__ void __launch_bounds__(256) k_after_primal2(Dev D, int nb, int which)
 #define SELL_BITS_MAX 8192  // 64-bit words of the pi bitmap kept in LDS (rows <= 524288)
 // PIPE: software-pipelined loads; NT: non-temporal matrix loads; BITS: gather pi only where the
 // row's bit is set (pi is sparse for most pivots: the gather traffic scales with nnz(pi)/m)
-template <bool PIPE, bool NT, bool BITS, bool COND = false> __device__ inline void priceSellBody(Dev D, unsigned long long *bits)
+template <bool PIPE, bool NT, bool BITS, bool COND = false>
+__device__ inline void priceSellBody(Dev D, unsigned long long *bits, int countCols = 0)
 {
   const Ctrl *c = D.ctrl;
   __shared__ double shd[16];
@@ -2976,6 +3019,9 @@ template <bool PIPE, bool NT, bool BITS, bool COND = false> __device__ inline vo
       }
       D.alphaCol[j] = value;
       D.candFlag[D.m + j] = (unsigned char)flag;
+      // candidate count of the column's compaction block (integer atomic: order independent)
+      if (flag && countCols)
+        atomicAdd(&D.blockCount[((D.m + PRICE_BLOCK - 1) / PRICE_BLOCK) + ((j - D.firstColumn) / PRICE_BLOCK)], 1);
     }
   }
   double bmin = blockMin(ratio, shd);
@@ -2987,29 +3033,29 @@ template <bool PIPE, bool NT, bool BITS, bool COND = false> __device__ inline vo
 }
 
 // variant: 1 plain, 2 bitmap, 3 pipelined+bitmap, 4 pipelined+nt+bitmap, 5 nt+bitmap
-__global__ void __launch_bounds__(256) k_price_sell(Dev D, int variant)
+__global__ void __launch_bounds__(256) k_price_sell(Dev D, int variant, int countCols = 0)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned long long sellBits[];  // (m+63)/64 words for variants >= 2
   if (D.ctrl->state != RUN)
     return;
   switch (variant) {
   case 2:
-    priceSellBody<false, false, true>(D, sellBits);
+    priceSellBody<false, false, true>(D, sellBits, countCols);
     break;
   case 3:
-    priceSellBody<true, false, true>(D, sellBits);
+    priceSellBody<true, false, true>(D, sellBits, countCols);
     break;
   case 4:
-    priceSellBody<true, true, true>(D, sellBits);
+    priceSellBody<true, true, true>(D, sellBits, countCols);
     break;
   case 5:
-    priceSellBody<false, true, true>(D, sellBits);
+    priceSellBody<false, true, true>(D, sellBits, countCols);
     break;
   case 6:
-    priceSellBody<false, false, true, true>(D, sellBits);
+    priceSellBody<false, false, true, true>(D, sellBits, countCols);
     break;
   default:
-    priceSellBody<false, false, false>(D, sellBits);
+    priceSellBody<false, false, false>(D, sellBits, countCols);
     break;
   }
 }
@@ -3019,7 +3065,7 @@ __global__ void __launch_bounds__(256) k_price_sell(Dev D, int variant)
 // sum is then a fixed 64-way tree instead of the reference's sequential order: deterministic, but
 // only equal to the sequential sum to rounding (used when the mean column length is >= 256).
 #define WIDE_BLOCKS 4096
-__global__ void __launch_bounds__(256) k_price_wide(Dev D, int denseColumns = 0)
+__global__ void __launch_bounds__(256) k_price_wide(Dev D, int denseColumns = 0, int countCols = 0)
 {
   const Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -3072,6 +3118,8 @@ __global__ void __launch_bounds__(256) k_price_wide(Dev D, int denseColumns = 0)
     if (lane == 0) {
       D.alphaCol[j] = value;
       D.candFlag[D.m + j] = (unsigned char)flag;
+      if (flag && countCols)
+        atomicAdd(&D.blockCount[((D.m + PRICE_BLOCK - 1) / PRICE_BLOCK) + ((j - D.firstColumn) / PRICE_BLOCK)], 1);
     }
   }
   double bmin = blockMin(ratio, shd);
