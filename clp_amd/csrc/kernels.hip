@@ -11,7 +11,6 @@
 
 namespace clpgpu {
 
-#define WAVE 64
 constexpr double REALLY_TINY = 1.0e-100;  // COIN_INDEXED_REALLY_TINY_ELEMENT
 constexpr double DEVEX_TRY_NORM = 1.0e-4; // src/ClpSimplex.hpp:2056
 
@@ -186,195 +185,6 @@ __device__ inline double randomDouble(Ctrl *c)
 }
 
 // =============================================================================================
-// CHUZR -- ClpDualRowSteepest::pivotRow (src/ClpDualRowSteepest.cpp:179-364, full scan) or
-// ClpDualRowDantzig::pivotRow (src/ClpDualRowDantzig.cpp:56-92), then the scalar part of
-// ClpSimplexDual::dualRow (src/ClpSimplexDual.cpp:3079-3102) and the acceptablePivot choice of
-// whileIterating (:1270-1278).  One workgroup: the list is at most m long and is read once.
-// =============================================================================================
-__global__ void __launch_bounds__(1024) k_chuzr(Dev D)
-{
-  Ctrl *c = D.ctrl;
-  if (c->state != RUN)
-    return;
-  __shared__ double shv[16];
-  __shared__ int shk[16];
-  __shared__ double s_tolerance;
-  __shared__ int s_number, s_start, s_last;
-  const int tid = threadIdx.x;
-  if (tid == 0) {
-    s_number = 0;
-    s_start = 0;
-    s_tolerance = 0.0;
-    s_last = -1;
-  }
-  if (tid == 0 && c->stepLimit >= 0 && c->numberIterations >= c->stepLimit) {
-    c->state = EXIT_STEP_LIMIT;
-  } else if (tid == 0) {
-    int last = c->pivotRow;  // model_->pivotRow(): persists across refactorizations
-    double tolerance = c->primalTolerance;
-    if (c->pivotRule) {
-      tolerance = tolerance + fmin(1.0e-2, c->largestPrimalError);
-      tolerance = fmin(1000.0, tolerance);
-      tolerance *= tolerance;
-      if (last >= 0 && last < D.m) {
-        int iPivot = D.pivotVariable[last];
-        double value = D.sol[iPivot], lower = D.lower[iPivot], upper = D.upper[iPivot];
-        if (value > upper + tolerance) {
-          value -= upper;
-          value *= value;
-          if (D.infeas[last] == 0.0)
-            D.infIndex[c->numberInfeasible++] = last;
-          D.infeas[last] = value;
-        } else if (value < lower - tolerance) {
-          value -= lower;
-          value *= value;
-          if (D.infeas[last] == 0.0)
-            D.infIndex[c->numberInfeasible++] = last;
-          D.infeas[last] = value;
-        } else if (D.infeas[last] != 0.0) {
-          D.infeas[last] = REALLY_TINY;
-        }
-      }
-      if (c->numberIterations < c->lastBadIteration + 200) {
-        if (c->largestDualError > c->largestPrimalError)
-          tolerance *= fmin(c->largestDualError / c->largestPrimalError, 1000.0);
-      }
-      int number = c->numberInfeasible;
-      double dstart = ((double)number) * randomDouble(c);
-      s_number = number;
-      s_start = (int)dstart;
-    } else {
-      if (c->largestPrimalError > 1.0e-8)
-        tolerance *= c->largestPrimalError / 1.0e-8;
-      s_number = D.m;
-      s_start = 0;
-    }
-    s_tolerance = tolerance;
-    s_last = last;
-  }
-  __syncthreads();
-  if (c->state != RUN)
-    return;
-  const double tolerance = s_tolerance;
-  const int number = s_number, start = s_start, last = s_last;
-  double best = 0.0;
-  int bestKey = -1;  // key = rank in scan order (smaller = scanned earlier)
-  int bestRow = -1;
-  for (int i = tid; i < number; i += blockDim.x) {
-    if (c->pivotRule) {
-      int iRow = D.infIndex[i];
-      double value = D.infeas[iRow];
-      if (value > tolerance) {
-        double weight = fmin(D.weights[iRow], 1.0e50);
-        if (iRow == last)
-          value *= 1.0e-10;  // last pivot row is the last resort (:302-307)
-        int iSequence = D.pivotVariable[iRow];
-        if (!(D.status[iSequence] & FLAGGED_BIT)) {
-          double s = D.sol[iSequence];
-          if (s > D.upper[iSequence] + tolerance || s < D.lower[iSequence] - tolerance) {
-            double ratio = value / weight;
-            int rank = i - start;
-            if (rank < 0)
-              rank += number;
-            if (ratio > best || (ratio == best && bestKey >= 0 && rank < bestKey)) {
-              best = ratio;
-              bestKey = rank;
-              bestRow = iRow;
-            }
-          }
-        }
-      }
-    } else {
-      int iSequence = D.pivotVariable[i];
-      double value = D.sol[iSequence];
-      double infeas = fmax(value - D.upper[iSequence], D.lower[iSequence] - value);
-      if (infeas > tolerance && !(D.status[iSequence] & FLAGGED_BIT)) {
-        if (infeas > best || (infeas == best && bestKey >= 0 && i < bestKey)) {
-          best = infeas;
-          bestKey = i;
-          bestRow = i;
-        }
-      }
-    }
-  }
-  // block argmax carries the scan rank as key; recover the row through a second shared slot
-  __shared__ int shRow[16];
-  {
-    int lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
-    for (int o = 32; o > 0; o >>= 1) {
-      double ov = __shfl_down(best, o);
-      int ok = __shfl_down(bestKey, o);
-      int orow = __shfl_down(bestRow, o);
-      if (ok >= 0 && (bestKey < 0 || ov > best || (ov == best && ok < bestKey))) {
-        best = ov;
-        bestKey = ok;
-        bestRow = orow;
-      }
-    }
-    if (lane == 0) {
-      shv[wv] = best;
-      shk[wv] = bestKey;
-      shRow[wv] = bestRow;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      for (int i = 1; i < nw; i++) {
-        if (shk[i] >= 0 && (bestKey < 0 || shv[i] > best || (shv[i] == best && shk[i] < bestKey))) {
-          best = shv[i];
-          bestKey = shk[i];
-          bestRow = shRow[i];
-        }
-      }
-    }
-  }
-  if (tid == 0) {
-    int chosen = bestRow;
-    c->pivotRow = chosen;
-    if (chosen < 0) {
-      c->state = EXIT_NO_PIVOT_ROW;
-    } else {
-      int seqOut = D.pivotVariable[chosen];
-      c->sequenceOut = seqOut;
-      double valueOut = D.sol[seqOut], lowerOut = D.lower[seqOut], upperOut = D.upper[seqOut];
-      c->valueOut = valueOut;
-      c->lowerOut = lowerOut;
-      c->upperOut = upperOut;
-      if (valueOut > upperOut) {
-        c->directionOut = -1;
-        c->dualOut = valueOut - upperOut;
-      } else if (valueOut < lowerOut) {
-        c->directionOut = 1;
-        c->dualOut = lowerOut - valueOut;
-      } else if (valueOut - lowerOut < upperOut - valueOut) {
-        c->directionOut = 1;
-        c->dualOut = lowerOut - valueOut;
-      } else {
-        c->directionOut = -1;
-        c->dualOut = valueOut - upperOut;
-      }
-      // acceptablePivot (:1270-1278)
-      double acceptablePivot = 1.0e-1 * c->acceptablePivotBase;
-      if (c->numberIterations > 100)
-        acceptablePivot = c->acceptablePivotBase;
-      if (c->pivots > 10 || (c->pivots && c->saveSumDual != 0.0))
-        acceptablePivot = 1.0e+3 * c->acceptablePivotBase;
-      else if (c->pivots > 5)
-        acceptablePivot = 1.0e+2 * c->acceptablePivotBase;
-      else if (c->pivots)
-        acceptablePivot = c->acceptablePivotBase;
-      c->acceptablePivot = acceptablePivot;
-      D.vecC[chosen] = (double)c->directionOut;  // BTRAN input: directionOut * e_r (:1286)
-      c->sequenceIn = -1;
-      c->numberFlips = 0;
-      c->flipAppend = 0;
-      c->flipDense = 0;
-      c->appendGo = 0;
-      c->objectiveChange = 0.0;
-    }
-  }
-}
-
-// =============================================================================================
 // BTRAN  y = B^-T c  for the nucleus representation  B^-1 = [slack part | Minv] :
 //   y_i   = -c[pos(slack i)]                         rows whose slack is basic  (slack column -e_i)
 //   t_sc  = c[pos(col sc)] - sum_{i in S} a_{i,col} y_i
@@ -464,21 +274,6 @@ __global__ void k_gemvT_final(Dev D, double *y, int mode, int iter)
   if (mode == 1)
     D.rhoSlot[sr] = acc;
   y[D.slotRow[sr]] = acc;
-}
-
-// flush |rho| <= zeroTolerance (the packed BTRAN result drops them) and build piNeg = -rho
-__global__ void k_rho_finish(Dev D)
-{
-  if (D.ctrl->state != RUN)
-    return;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < D.m) {
-    double v = D.rho[i];
-    if (fabs(v) <= D.ctrl->zeroTolerance)
-      v = 0.0;
-    D.rho[i] = v;
-    D.piNeg[i] = -v;
-  }
 }
 
 // =============================================================================================
@@ -1476,28 +1271,6 @@ __global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass)
   }
 }
 
-// =============================================================================================
-// FTRAN  x = B^-1 v :  x_K = Minv v_R ;  x[pos(slack i)] = sum_{j in K} a_ij x_j - v_i
-// Stands in for ClpFactorization::updateColumn / updateTwoColumnsFT (src/ClpFactorization.cpp:2803,
-// :2889) -> CoinAbcDenseFactorization::updateColumn (src/CoinAbcDenseFactorization.cpp:571).
-// Two right-hand sides share one sweep over Minv (the entering column and the DSE vector).
-// =============================================================================================
-__global__ void k_unpack_in(Dev D)
-{
-  // ClpSimplex::unpackPacked (src/ClpSimplex.cpp:3439-3495): a_q, or -e_i for a slack
-  const Ctrl *c = D.ctrl;
-  if (c->state != RUN)
-    return;
-  int q = c->sequenceIn;
-  if (q >= D.n) {
-    if (threadIdx.x == 0)
-      D.vecV1[q - D.n] = -1.0;
-  } else {
-    for (int p = D.colStart[q] + threadIdx.x; p < D.colStart[q + 1]; p += blockDim.x)
-      D.vecV1[D.row[p]] = D.elem[p];
-  }
-}
-
 __global__ void k_ftran_gather(Dev D, const double *v1, const double *v2, double *g1, double *g2, int iter)
 {
   if (iter && D.ctrl->state != RUN)
@@ -1581,222 +1354,12 @@ __global__ void k_ftran_scatter(Dev D, const double *v1, const double *v2, const
   }
 }
 
-// =============================================================================================
-// DSE: norm, alpha check and weight update -- ClpDualRowSteepest::updateWeights
-// (src/ClpDualRowSteepest.cpp:375-540) and the accuracy test of whileIterating (:1447-1501).
-// =============================================================================================
-__global__ void __launch_bounds__(1024) k_norm_alpha(Dev D)
-{
-  Ctrl *c = D.ctrl;
-  if (c->state != RUN)
-    return;
-  __shared__ double sh[16];
-  double acc = 0.0;
-  if (c->pivotRule) {
-    for (int i = threadIdx.x; i < D.m; i += blockDim.x) {
-      double v = D.rho[i];
-      acc += v * v;
-    }
-    acc = blockSum(acc, sh);
-  }
-  if (threadIdx.x == 0) {
-    double alphaOld = c->alpha;  // from the ratio test (btran side)
-    double norm = acc / (alphaOld * alphaOld);
-    c->norm = norm;
-    double alpha = D.w[c->pivotRow];
-    double btranAlpha = c->btranAlpha;
-    double checkValue = 1.0e-7;
-    if (c->largestPrimalError > 10.0)
-      checkValue = fmin(1.0e-4, 1.0e-8 * c->largestPrimalError);
-    // multiplier uses the old alpha (model_->alpha() inside updateWeights)
-    c->scratchSum = 2.0 / alphaOld;
-    if (fabs(btranAlpha) < 1.0e-12 || fabs(alpha) < 1.0e-12 || fabs(btranAlpha - alpha) > checkValue * (1.0 + fabs(alpha))) {
-      int bad = 1;
-      if (!c->pivots) {
-        double test;
-        if (fabs(btranAlpha) < 1.0e-8 || fabs(alpha) < 1.0e-8)
-          test = 1.0e-1 * fabs(alpha);
-        else
-          test = 1.0e-4 * (1.0 + fabs(alpha));
-        if (!(fabs(btranAlpha) < 1.0e-12 || fabs(alpha) < 1.0e-12 || fabs(btranAlpha - alpha) > test))
-          bad = 0;  // accepted under the relaxed criterion (:1466-1471)
-      }
-      if (bad) {
-        c->alpha = alpha;
-        c->state = EXIT_ALPHA_CHECK;
-        return;
-      }
-    }
-    c->alpha = alpha;
-  }
-}
-
-__global__ void k_weights(Dev D)
-{
-  const Ctrl *c = D.ctrl;
-  if (c->state != RUN || !c->pivotRule)
-    return;
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= D.m)
-    return;
-  double theta = D.w[p];
-  if (theta != 0.0) {
-    double devex = D.weights[p];
-    D.altWeights[p] = devex;
-    double norm = c->norm, multiplier = c->scratchSum;
-    if (p == c->pivotRow) {
-      devex = (norm < DEVEX_TRY_NORM) ? DEVEX_TRY_NORM : norm;
-    } else {
-      double value = D.tau[p];
-      devex += theta * (theta * norm + value * multiplier);
-      if (devex < DEVEX_TRY_NORM)
-        devex = DEVEX_TRY_NORM;
-    }
-    D.weights[p] = devex;
-  }
-}
-
 // ClpDualRowSteepest::unrollWeights (:1022): w is still intact when the host asks for this
 __global__ void k_unroll_weights(Dev D)
 {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < D.m && D.w[p] != 0.0)
     D.weights[p] = D.altWeights[p];
-}
-
-// =============================================================================================
-// Dual update + flip detection -- ClpSimplexDual::updateDualsInDual fast path
-// (src/ClpSimplexDual.cpp:2454-2592).  Key space as in pricing.  candFlag doubles as flip flag.
-// =============================================================================================
-__global__ void __launch_bounds__(PRICE_BLOCK) k_dj_update(Dev D, int nbRows)
-{
-  const Ctrl *c = D.ctrl;
-  if (c->state != RUN)
-    return;
-  __shared__ int shi[17];
-  const double theta = c->theta;
-  const double tolerance = c->dualTolerance + fmin(1.0e-2, c->largestDualError);
-  const int seqIn = c->sequenceIn;
-  int flag = 0;
-  if ((int)blockIdx.x < nbRows) {
-    int i = blockIdx.x * PRICE_BLOCK + threadIdx.x;
-    if (i < D.m) {
-      double alphaI = D.rho[i];
-      int seq = D.n + i;
-      if (alphaI != 0.0 && seq != seqIn) {
-        int iStatus = (D.status[seq] & 3) - 1;
-        if (iStatus) {
-          double value = D.dj[seq] - theta * alphaI;
-          D.dj[seq] = value;
-          double mult = (iStatus == 1) ? -1.0 : ((iStatus == 2) ? 1.0 : 0.0);
-          value *= mult;
-          if (value < -tolerance)
-            flag = 1;
-        }
-      }
-      D.candFlag[i] = (unsigned char)flag;
-    }
-  } else {
-    int j = D.firstColumn + ((int)blockIdx.x - nbRows) * PRICE_BLOCK + threadIdx.x;
-    if (j < D.lastColumn) {
-      double alphaI = D.alphaCol[j];
-      if (alphaI != 0.0 && j != seqIn) {
-        int iStatus = (D.status[j] & 3) - 1;
-        if (iStatus) {
-          double value = D.dj[j] - theta * alphaI;
-          D.dj[j] = value;
-          double mult = (iStatus == 1) ? -1.0 : ((iStatus == 2) ? 1.0 : -1.0);
-          value *= mult;
-          if (value < -tolerance && iStatus > 0)
-            flag = 1;
-        }
-      }
-      D.candFlag[D.m + j] = (unsigned char)flag;
-    }
-  }
-  int total;
-  blockRank(flag, total, shi);
-  if (threadIdx.x == 0)
-    D.blockCount[blockIdx.x] = total;
-}
-
-__global__ void __launch_bounds__(PRICE_BLOCK) k_flip_scatter(Dev D, int nbRows)
-{
-  const Ctrl *c = D.ctrl;
-  if (c->state != RUN || c->numberFlips == 0)
-    return;
-  __shared__ int shi[17];
-  int flag = 0, seq = -1;
-  if ((int)blockIdx.x < nbRows) {
-    int i = blockIdx.x * PRICE_BLOCK + threadIdx.x;
-    if (i < D.m && D.candFlag[i]) {
-      flag = 1;
-      seq = D.n + i;
-    }
-  } else {
-    int j = D.firstColumn + ((int)blockIdx.x - nbRows) * PRICE_BLOCK + threadIdx.x;
-    if (j < D.lastColumn && D.candFlag[D.m + j]) {
-      flag = 1;
-      seq = j;
-    }
-  }
-  int total;
-  int rank = blockRank(flag, total, shi);
-  if (flag)
-    D.flipSeq[D.blockOffset[blockIdx.x] + rank] = seq;
-}
-
-// movement of each flip into the dense rhs (matrix_->add, src/ClpPackedMatrix.cpp:4874), in list
-// order, entries of one column in parallel (distinct rows) => deterministic
-__global__ void __launch_bounds__(256) k_flip_apply(Dev D, int nbPos)
-{
-  Ctrl *c = D.ctrl;
-  if (c->state != RUN || c->numberFlips == 0)
-    return;
-  double changeObj = 0.0;
-  for (int f = 0; f < c->numberFlips; f++) {
-    int seq = D.flipSeq[f];
-    int iStatus = (D.status[seq] & 3) - 1;
-    if (seq >= D.n) {
-      double mult = (iStatus == 1) ? -1.0 : 1.0;
-      double movement = mult * (D.lower[seq] - D.upper[seq]);
-      if (threadIdx.x == 0) {
-        changeObj -= movement * D.cost[seq];
-        D.flipRhs[seq - D.n] += movement;
-      }
-    } else {
-      double mult = (iStatus == 1) ? -1.0 : 1.0;
-      double movement = mult * (D.upper[seq] - D.lower[seq]);
-      if (threadIdx.x == 0)
-        changeObj += movement * D.cost[seq];
-      for (int p = D.colStart[seq] + threadIdx.x; p < D.colStart[seq + 1]; p += blockDim.x)
-        D.flipRhs[D.row[p]] += movement * D.elem[p];
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0)
-    c->objectiveChange += changeObj;
-  for (int b = threadIdx.x; b < nbPos; b += blockDim.x)
-    D.blockCount[b] = 0;
-}
-
-// ClpSimplexDual::flipBounds (:6345-6401)
-__global__ void k_flip_bounds(Dev D)
-{
-  const Ctrl *c = D.ctrl;
-  if (c->state != RUN)
-    return;
-  for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < c->numberFlips; f += gridDim.x * blockDim.x) {
-    int seq = D.flipSeq[f];
-    int st = D.status[seq] & 7;
-    if (st == ST_UPPER) {
-      D.status[seq] = (unsigned char)((D.status[seq] & ~7) | ST_LOWER);
-      D.sol[seq] = D.lower[seq];
-    } else if (st == ST_LOWER) {
-      D.status[seq] = (unsigned char)((D.status[seq] & ~7) | ST_UPPER);
-      D.sol[seq] = D.upper[seq];
-    }
-  }
 }
 
 // =============================================================================================
@@ -1902,84 +1465,6 @@ __global__ void __launch_bounds__(256) k_append_scatter(Dev D, int which, int it
   int rank = blockRank(flag, total, shi);
   if (flag)
     D.infIndex[c->numberInfeasible + D.blockOffset[blockIdx.x] + rank] = p;
-}
-
-// scalar tail of updatePrimalSolution + the scalar block of whileIterating between the two
-// primal updates (:1531-1588): objective change, dualOut recompute, movement, backwards check,
-// the pivot-size gate of replaceColumn (CoinAbcDenseFactorization::checkReplacePart2 :470).
-__global__ void k_after_primal(Dev D, int nb, int which)
-{
-  Ctrl *c = D.ctrl;
-  if (c->state != RUN)
-    return;
-  if (which == 1 && c->numberFlips == 0) {
-    // no flips: just the scalar block
-  } else {
-    double s = 0.0;
-    for (int b = 0; b < nb; b++)
-      s += D.blockSum[b];
-    c->objectiveChange += s;
-    c->numberInfeasible += c->numberAppend;
-    c->numberAppend = 0;
-    if (c->pivotRule) {
-      int iRow = c->pivotRow;
-      if (D.infeas[iRow] != 0.0)
-        D.infeas[iRow] = REALLY_TINY;
-    }
-  }
-  if (which == 1) {
-    double oldDualOut = c->dualOut;
-    if (c->numberFlips) {
-      c->valueOut = D.sol[c->sequenceOut];
-      if (c->directionOut < 0)
-        c->dualOut = c->valueOut - c->upperOut;
-      else
-        c->dualOut = c->lowerOut - c->valueOut;
-    }
-    double alpha = c->alpha;
-    c->movement = -c->dualOut * c->directionOut / alpha;
-    double movementOld = oldDualOut * c->directionOut / alpha;
-    if (c->objectiveChange + fabs(movementOld * c->dualIn) < -fmax(1.0e-5, 1.0e-12 * fabs(c->objectiveValue))) {
-      if (c->pivots) {
-        c->state = EXIT_BACKWARDS;
-        return;
-      }
-    }
-    if (fabs(alpha) < c->zeroTolerance || fabs(c->dualOut) > 1.0e50) {
-      c->state = EXIT_BAD_UPDATE;
-      return;
-    }
-    if (c->theta < 0.0)
-      c->theta = 0.0;
-    // classify the basis change for the nucleus update
-    int seqIn = c->sequenceIn, seqOut = c->sequenceOut;
-    int inStruct = seqIn < D.n, outStruct = seqOut < D.n;
-    c->updateCase = outStruct ? (inStruct ? 0 : 2) : (inStruct ? 1 : 3);
-    c->slotColOut = outStruct ? D.slotOfCol[seqOut] : -1;
-    c->rowOfSlackOut = outStruct ? -1 : (seqOut - D.n);
-    c->slotRowIn = inStruct ? -1 : D.slotOfRow[seqIn - D.n];
-  }
-}
-
-// =============================================================================================
-// Basis update on the nucleus inverse (the Forrest-Tomlin stand-in,
-// ClpFactorization::replaceColumn src/ClpFactorization.cpp:2584).  With w = B^-1 a_q (by col-slot),
-// rho = B^-T(dir e_p) (by row-slot, unpruned) and g = dir*rho/alpha, all four pivot types are
-//     Minv[i][j] -= w_i * g_j          (one rank-1 sweep, k^2 reads + writes)
-// followed by a row/column fix-up:   struct->struct: row a := g ;  slack out/struct in: append row g,
-// column w/alpha, corner -1/alpha ;  struct out/slack in: delete row a, column b ;  slack->slack:
-// column b := w/alpha.
-// =============================================================================================
-__global__ void k_update_vectors(Dev D)
-{
-  const Ctrl *c = D.ctrl;
-  if (c->state != RUN)
-    return;
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < c->k) {
-    D.slotE[s] = D.w[D.slotPos[s]];                             // w by col-slot
-    D.slotF[s] = ((double)c->directionOut) * D.rhoSlot[s] / c->alpha;  // g by row-slot
-  }
 }
 
 __device__ inline void rank1Body(const Dev &D, int parity, int bx, int by, int gx, int gy)
@@ -2305,7 +1790,7 @@ __device__ void houseBody(Dev D, int skipColumns = 0)
 
 
 // =============================================================================================
-// v2 kernels (round 1, after the first rocprof pass: profiles/r01_bench_v1_kernel_stats.txt)
+// CHUZR: head (scalar), list scan over the whole chip, final selection
 // =============================================================================================
 
 // ---- CHUZR split in three so the list scan uses the whole chip ---------------------------------
@@ -2462,147 +1947,6 @@ __global__ void __launch_bounds__(256) k_chuzr_scan(Dev D)
   }
 }
 
-__global__ void __launch_bounds__(256) k_chuzr_final(Dev D, int nblocks)
-{
-  Ctrl *c = D.ctrl;
-  if (c->state != RUN)
-    return;
-  __shared__ double shv[4];
-  __shared__ int shk[4], shr[4];
-  double best = 0.0;
-  int bestKey = -1, bestRow = -1;
-  int used = (c->chuzrNumber + 256 * CHZ_ITEMS - 1) / (256 * CHZ_ITEMS);
-  if (used > nblocks)
-    used = nblocks;
-  for (int b = threadIdx.x; b < used; b += blockDim.x) {
-    double ov = D.chzBest[b];
-    int ok = D.chzKey[b];
-    if (ok >= 0 && (bestKey < 0 || ov > best || (ov == best && ok < bestKey))) {
-      best = ov;
-      bestKey = ok;
-      bestRow = D.chzRow[b];
-    }
-  }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int o = 32; o > 0; o >>= 1) {
-    double ov = __shfl_down(best, o);
-    int ok = __shfl_down(bestKey, o);
-    int orow = __shfl_down(bestRow, o);
-    if (ok >= 0 && (bestKey < 0 || ov > best || (ov == best && ok < bestKey))) {
-      best = ov;
-      bestKey = ok;
-      bestRow = orow;
-    }
-  }
-  if (lane == 0) {
-    shv[wv] = best;
-    shk[wv] = bestKey;
-    shr[wv] = bestRow;
-  }
-  __syncthreads();
-  if (threadIdx.x != 0)
-    return;
-  for (int i = 1; i < 4; i++)
-    if (shk[i] >= 0 && (bestKey < 0 || shv[i] > best || (shv[i] == best && shk[i] < bestKey))) {
-      best = shv[i];
-      bestKey = shk[i];
-      bestRow = shr[i];
-    }
-  int chosen = bestRow;
-  c->pivotRow = chosen;
-  if (chosen < 0) {
-    c->state = EXIT_NO_PIVOT_ROW;
-    return;
-  }
-  int seqOut = D.pivotVariable[chosen];
-  c->sequenceOut = seqOut;
-  double valueOut = D.sol[seqOut], lowerOut = D.lower[seqOut], upperOut = D.upper[seqOut];
-  c->valueOut = valueOut;
-  c->lowerOut = lowerOut;
-  c->upperOut = upperOut;
-  if (valueOut > upperOut) {
-    c->directionOut = -1;
-    c->dualOut = valueOut - upperOut;
-  } else if (valueOut < lowerOut) {
-    c->directionOut = 1;
-    c->dualOut = lowerOut - valueOut;
-  } else if (valueOut - lowerOut < upperOut - valueOut) {
-    c->directionOut = 1;
-    c->dualOut = lowerOut - valueOut;
-  } else {
-    c->directionOut = -1;
-    c->dualOut = valueOut - upperOut;
-  }
-  double acceptablePivot = 1.0e-1 * c->acceptablePivotBase;
-  if (c->numberIterations > 100)
-    acceptablePivot = c->acceptablePivotBase;
-  if (c->pivots > 10 || (c->pivots && c->saveSumDual != 0.0))
-    acceptablePivot = 1.0e+3 * c->acceptablePivotBase;
-  else if (c->pivots > 5)
-    acceptablePivot = 1.0e+2 * c->acceptablePivotBase;
-  else if (c->pivots)
-    acceptablePivot = c->acceptablePivotBase;
-  c->acceptablePivot = acceptablePivot;
-  D.vecC[chosen] = (double)c->directionOut;
-  c->sequenceIn = -1;
-  c->numberFlips = 0;
-  c->flipAppend = 0;
-  c->flipDense = 0;
-  c->appendGo = 0;
-  c->objectiveChange = 0.0;
-}
-
-// ---- BTRAN t-vector: one wave per nucleus column (the slack part of y has a single nonzero for
-// the unit-vector BTRAN of the iteration, so the lane-parallel sum is exact there) ----------------
-__global__ void __launch_bounds__(256) k_btran_t2(Dev D, const double *cvec, const double *y, double *t, int iter)
-{
-  if (iter && D.ctrl->state != RUN)
-    return;
-  const int k = D.ctrl->k;
-  const int lane = threadIdx.x & 63;
-  int sc = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (sc >= k)
-    return;
-  int col = D.slotCol[sc];
-  double acc = 0.0;
-  for (int p = D.colStart[col] + lane; p < D.colStart[col + 1]; p += 64) {
-    int r = D.row[p];
-    if (D.slotOfRow[r] < 0)
-      acc += y[r] * D.elem[p];
-  }
-  acc = waveSum(acc);
-  if (lane == 0)
-    t[sc] = cvec[D.slotPos[sc]] - acc;
-}
-
-// iteration BTRAN, t-vector: the input is dir*e_p, so y_S has at most one nonzero (row of the
-// leaving slack) and t follows analytically -- no pass over the slack rows needed.
-__global__ void k_btran_t3(Dev D)
-{
-  const Ctrl *c = D.ctrl;
-  if (c->state != RUN)
-    return;
-  int sc = blockIdx.x * blockDim.x + threadIdx.x;
-  if (sc >= c->k)
-    return;
-  const double dir = (double)c->directionOut;
-  const int seqOut = c->sequenceOut;
-  double value = 0.0;
-  if (seqOut < D.n) {
-    if (D.slotOfCol[seqOut] == sc)
-      value = dir;
-  } else {
-    const int rOut = seqOut - D.n;
-    const double y = dir * -1.0;  // y_rOut = -c[pos]
-    const int col = D.slotCol[sc];
-    const int s = D.rowStart[rOut], e = s + D.basicCount[rOut];
-    for (int q = s; q < e; q++)
-      if (D.ccol[q] == col)
-        value -= y * D.relem[q];
-  }
-  D.slotA[sc] = value;
-}
-
 // iteration BTRAN, back end: rho[i] = slack part or sum of the gemvT partials, flush tiny, piNeg,
 // rhoSlot (unpruned, for the nucleus update) and the per-block partial of sum rho^2 (DSE norm)
 __global__ void __launch_bounds__(256) k_rho_finish3(Dev D, int wide = 0, int nbCols = -1)
@@ -2726,124 +2070,6 @@ __global__ void k_gemvT_partial2(Dev D, const double *t, int iter)
     Mp += D.ld;
   }
   D.partial[(size_t)chunk * D.ld + sr] = acc;
-}
-
-// rho finish + per-block partial of sum rho^2 (DSE norm)
-__global__ void __launch_bounds__(256) k_rho_finish2(Dev D)
-{
-  if (D.ctrl->state != RUN)
-    return;
-  __shared__ double sh[16];
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  double sq = 0.0;
-  if (i < D.m) {
-    double v = D.rho[i];
-    if (fabs(v) <= D.ctrl->zeroTolerance)
-      v = 0.0;
-    D.rho[i] = v;
-    D.piNeg[i] = -v;
-    sq = v * v;
-  }
-  double s = blockSum(sq, sh);
-  if (threadIdx.x == 0)
-    D.normPartial[blockIdx.x] = s;
-}
-
-__global__ void __launch_bounds__(256) k_norm_alpha2(Dev D, int nb)
-{
-  Ctrl *c = D.ctrl;
-  if (c->state != RUN)
-    return;
-  __shared__ double sh[16];
-  double acc = 0.0;
-  if (c->pivotRule)
-    for (int b = threadIdx.x; b < nb; b += blockDim.x)
-      acc += D.normPartial[b];
-  acc = blockSum(acc, sh);
-  if (threadIdx.x == 0) {
-    double alphaOld = c->alpha;
-    double norm = acc / (alphaOld * alphaOld);
-    c->norm = norm;
-    double alpha = D.w[c->pivotRow];
-    double btranAlpha = c->btranAlpha;
-    double checkValue = 1.0e-7;
-    if (c->largestPrimalError > 10.0)
-      checkValue = fmin(1.0e-4, 1.0e-8 * c->largestPrimalError);
-    c->scratchSum = 2.0 / alphaOld;
-    c->alpha = alpha;
-    if (fabs(btranAlpha) < 1.0e-12 || fabs(alpha) < 1.0e-12 || fabs(btranAlpha - alpha) > checkValue * (1.0 + fabs(alpha))) {
-      int bad = 1;
-      if (!c->pivots) {
-        double test;
-        if (fabs(btranAlpha) < 1.0e-8 || fabs(alpha) < 1.0e-8)
-          test = 1.0e-1 * fabs(alpha);
-        else
-          test = 1.0e-4 * (1.0 + fabs(alpha));
-        if (!(fabs(btranAlpha) < 1.0e-12 || fabs(alpha) < 1.0e-12 || fabs(btranAlpha - alpha) > test))
-          bad = 0;
-      }
-      if (bad)
-        c->state = EXIT_ALPHA_CHECK;
-    }
-  }
-}
-
-// parallel version of the scalar tail after a primal update
-__global__ void __launch_bounds__(256) k_after_primal2(Dev D, int nb, int which)
-{
-  Ctrl *c = D.ctrl;
-  if (c->state != RUN)
-    return;
-  __shared__ double sh[16];
-  const bool active = !(which == 1 && c->numberFlips == 0);
-  double s = 0.0;
-  if (active)
-    for (int b = threadIdx.x; b < nb; b += blockDim.x)
-      s += D.blockSum[b];
-  s = blockSum(s, sh);
-  if (threadIdx.x != 0)
-    return;
-  if (active) {
-    c->objectiveChange += s;
-    c->numberInfeasible += c->numberAppend;
-    c->numberAppend = 0;
-    if (c->pivotRule) {
-      int iRow = c->pivotRow;
-      if (D.infeas[iRow] != 0.0)
-        D.infeas[iRow] = REALLY_TINY;
-    }
-  }
-  if (which == 1) {
-    double oldDualOut = c->dualOut;
-    if (c->numberFlips) {
-      c->valueOut = D.sol[c->sequenceOut];
-      if (c->directionOut < 0)
-        c->dualOut = c->valueOut - c->upperOut;
-      else
-        c->dualOut = c->lowerOut - c->valueOut;
-    }
-    double alpha = c->alpha;
-    c->movement = -c->dualOut * c->directionOut / alpha;
-    double movementOld = oldDualOut * c->directionOut / alpha;
-    if (c->objectiveChange + fabs(movementOld * c->dualIn) < -fmax(1.0e-5, 1.0e-12 * fabs(c->objectiveValue))) {
-      if (c->pivots) {
-        c->state = EXIT_BACKWARDS;
-        return;
-      }
-    }
-    if (fabs(alpha) < c->zeroTolerance || fabs(c->dualOut) > 1.0e50) {
-      c->state = EXIT_BAD_UPDATE;
-      return;
-    }
-    if (c->theta < 0.0)
-      c->theta = 0.0;
-    int seqIn = c->sequenceIn, seqOut = c->sequenceOut;
-    int inStruct = seqIn < D.n, outStruct = seqOut < D.n;
-    c->updateCase = outStruct ? (inStruct ? 0 : 2) : (inStruct ? 1 : 3);
-    c->slotColOut = outStruct ? D.slotOfCol[seqOut] : -1;
-    c->rowOfSlackOut = outStruct ? -1 : (seqOut - D.n);
-    c->slotRowIn = inStruct ? -1 : D.slotOfRow[seqIn - D.n];
-  }
 }
 
 // =============================================================================================
@@ -3196,10 +2422,10 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_cand_count(Dev D, int nbRows, i
 
 
 // =============================================================================================
-// v4 fusions: fewer grid-wide dependencies per pivot (each launch costs ~4 us on 256 CUs)
+// Fused stages: fewer grid-wide dependencies per pivot (each launch costs ~4 us on 256 CUs)
 // =============================================================================================
 
-// k_chuzr_final + k_btran_t3 in one workgroup
+// CHUZR final selection + the analytic front end of the BTRAN in one workgroup
 __global__ void __launch_bounds__(256) k_chuzr_final_btran(Dev D, int nblocks, int wide = 0)
 {
   Ctrl *c = D.ctrl;
@@ -3294,7 +2520,7 @@ __global__ void __launch_bounds__(256) k_chuzr_final_btran(Dev D, int nblocks, i
   __syncthreads();
   if (!s_ok)
     return;
-  // BTRAN t-vector for dir*e_p (see k_btran_t3), kept as a short list: t has one nonzero when a
+  // BTRAN t-vector for dir*e_p (t = c_K - A_SK^T y_S with c = dir*e_p, y_S = -c_S), kept as a short list: t has one nonzero when a
   // structural leaves, and one per basic entry of the leaving slack's row otherwise
   const double dir = (double)c->directionOut;
   const int seqOut = c->sequenceOut;
@@ -3345,254 +2571,7 @@ __global__ void __launch_bounds__(256) k_chuzr_final_btran(Dev D, int nblocks, i
   }
 }
 
-// FTRAN nucleus GEMV with the gather of the right-hand side folded in
-__global__ void __launch_bounds__(256) k_gemv2g(Dev D, const double *v1, const double *v2, double *x1, double *x2, int iter)
-{
-  if (iter && D.ctrl->state != RUN)
-    return;
-  if (iter == 2 && D.ctrl->numberFlips == 0)
-    return;
-  const int k = D.ctrl->k;
-  const int lane = threadIdx.x & 63;
-  const int wavesPerBlock = blockDim.x >> 6;
-  for (int sc = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6); sc < k; sc += gridDim.x * wavesPerBlock) {
-    const double *Mrow = D.Minv + (size_t)sc * D.ld;
-    double a1 = 0.0, a2 = 0.0;
-    if (v2) {
-      for (int sr = lane; sr < k; sr += 64) {
-        double mv = Mrow[sr];
-        int r = D.slotRow[sr];
-        a1 += mv * v1[r];
-        a2 += mv * v2[r];
-      }
-      a2 = waveSum(a2);
-    } else {
-      for (int sr = lane; sr < k; sr += 64)
-        a1 += Mrow[sr] * v1[D.slotRow[sr]];
-    }
-    a1 = waveSum(a1);
-    if (lane == 0) {
-      x1[sc] = a1;
-      if (v2)
-        x2[sc] = a2;
-    }
-  }
-}
-
-// DSE weight update (positions) and dual update + flip detection (keys) in one N-wide pass.
-// The alpha check runs afterwards (k_scan_flips_alpha); on failure the host unrolls the weights and
-// refactorizes, which recomputes every dj, exactly as the reference does after its `break` (:1456).
-__global__ void __launch_bounds__(PRICE_BLOCK) k_weights_dj(Dev D, int nbRows, int nbNorm)
-{
-  const Ctrl *c = D.ctrl;
-  if (c->state != RUN)
-    return;
-  __shared__ int shi[17];
-  __shared__ double shd[16];
-  const double theta = c->theta;
-  const double tolerance = c->dualTolerance + fmin(1.0e-2, c->largestDualError);
-  const int seqIn = c->sequenceIn;
-  int flag = 0;
-  if ((int)blockIdx.x < nbRows) {
-    // every row block needs the DSE norm: sum of the per-block partials of sum rho^2
-    double norm = 0.0, multiplier = 0.0;
-    if (c->pivotRule) {
-      double acc = 0.0;
-      for (int b = threadIdx.x; b < nbNorm; b += blockDim.x)
-        acc += D.normPartial[b];
-      acc = blockSum(acc, shd);
-      double alphaOld = c->alpha;
-      norm = acc / (alphaOld * alphaOld);
-      multiplier = 2.0 / alphaOld;
-    }
-    int i = blockIdx.x * PRICE_BLOCK + threadIdx.x;
-    if (i < D.m) {
-      if (c->pivotRule) {
-        double thetaW = D.w[i];
-        if (thetaW != 0.0) {
-          double devex = D.weights[i];
-          D.altWeights[i] = devex;
-          if (i == c->pivotRow) {
-            devex = (norm < DEVEX_TRY_NORM) ? DEVEX_TRY_NORM : norm;
-          } else {
-            devex += thetaW * (thetaW * norm + D.tau[i] * multiplier);
-            if (devex < DEVEX_TRY_NORM)
-              devex = DEVEX_TRY_NORM;
-          }
-          D.weights[i] = devex;
-        }
-      }
-      double alphaI = D.rho[i];
-      int seq = D.n + i;
-      if (alphaI != 0.0 && seq != seqIn) {
-        int iStatus = (D.status[seq] & 3) - 1;
-        if (iStatus) {
-          double value = D.dj[seq] - theta * alphaI;
-          D.dj[seq] = value;
-          double mult = (iStatus == 1) ? -1.0 : ((iStatus == 2) ? 1.0 : 0.0);
-          value *= mult;
-          if (value < -tolerance)
-            flag = 1;
-        }
-      }
-      D.candFlag[i] = (unsigned char)flag;
-    }
-  } else {
-    int j = D.firstColumn + ((int)blockIdx.x - nbRows) * PRICE_BLOCK + threadIdx.x;
-    if (j < D.lastColumn) {
-      double alphaI = D.alphaCol[j];
-      if (alphaI != 0.0 && j != seqIn) {
-        int iStatus = (D.status[j] & 3) - 1;
-        if (iStatus) {
-          double value = D.dj[j] - theta * alphaI;
-          D.dj[j] = value;
-          double mult = (iStatus == 1) ? -1.0 : ((iStatus == 2) ? 1.0 : -1.0);
-          value *= mult;
-          if (value < -tolerance && iStatus > 0)
-            flag = 1;
-        }
-      }
-      D.candFlag[D.m + j] = (unsigned char)flag;
-    }
-  }
-  int total;
-  blockRank(flag, total, shi);
-  if (threadIdx.x == 0)
-    D.blockCount[blockIdx.x] = total;
-}
-
-// flip-count scan + the btran/ftran alpha accuracy test (whileIterating :1447-1501)
-__global__ void __launch_bounds__(1024) k_scan_flips_alpha(Dev D, int nb)
-{
-  Ctrl *c = D.ctrl;
-  if (c->state != RUN)
-    return;
-  __shared__ int shi[17];
-  __shared__ int s_base;
-  if (threadIdx.x == 0)
-    s_base = 0;
-  __syncthreads();
-  for (int b0 = 0; b0 < nb; b0 += blockDim.x) {
-    int b = b0 + threadIdx.x;
-    int cnt = (b < nb) ? D.blockCount[b] : 0;
-    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    int v = cnt;
-    for (int o = 1; o < 64; o <<= 1) {
-      int t = __shfl_up(v, o);
-      if (lane >= o)
-        v += t;
-    }
-    __syncthreads();
-    if (lane == 63)
-      shi[wv] = v;
-    __syncthreads();
-    int base = s_base;
-    for (int i = 0; i < wv; i++)
-      base += shi[i];
-    if (b < nb)
-      D.blockOffset[b] = base + v - cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int tot = 0;
-      for (int i = 0; i < nw; i++)
-        tot += shi[i];
-      s_base += tot;
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x != 0)
-    return;
-  c->numberFlips = s_base;
-  double alpha = D.w[c->pivotRow];
-  double btranAlpha = c->btranAlpha;
-  double checkValue = 1.0e-7;
-  if (c->largestPrimalError > 10.0)
-    checkValue = fmin(1.0e-4, 1.0e-8 * c->largestPrimalError);
-  c->alpha = alpha;
-  if (fabs(btranAlpha) < 1.0e-12 || fabs(alpha) < 1.0e-12 || fabs(btranAlpha - alpha) > checkValue * (1.0 + fabs(alpha))) {
-    int bad = 1;
-    if (!c->pivots) {
-      double test;
-      if (fabs(btranAlpha) < 1.0e-8 || fabs(alpha) < 1.0e-8)
-        test = 1.0e-1 * fabs(alpha);
-      else
-        test = 1.0e-4 * (1.0 + fabs(alpha));
-      if (!(fabs(btranAlpha) < 1.0e-12 || fabs(alpha) < 1.0e-12 || fabs(btranAlpha - alpha) > test))
-        bad = 0;
-    }
-    if (bad)
-      c->state = EXIT_ALPHA_CHECK;
-  }
-}
-
-// flip FTRAN back end fused with the primal update by the flip movement (ratio 1.0): the thread
-// that produces x[p] applies it.  Appends are counted per position block with integer atomics
-// (blockCount zeroed by k_flip_apply); objective partials are per launch block (fixed mapping).
-__global__ void __launch_bounds__(256) k_ftran_scatter_flip(Dev D, const double *xk)
-{
-  const Ctrl *c = D.ctrl;
-  if (c->state != RUN || c->numberFlips == 0)
-    return;
-  __shared__ double shd[16];
-  const int k = c->k;
-  const double tolerance = c->primalTolerance;
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  int p = -1;
-  double v = 0.0;
-  if (t < D.m) {
-    p = D.posOfSlack[t];
-    if (p >= 0) {
-      double a1 = 0.0;
-      int s = D.rowStart[t], e = s + D.basicCount[t];
-      for (int q = s; q < e; q++)
-        a1 += D.relem[q] * xk[D.slotOfCol[D.ccol[q]]];
-      v = a1 - D.flipRhs[t];
-    }
-    D.flipRhs[t] = 0.0;  // consumed (the nucleus rows were read by k_gemv2g)
-  } else if (t < D.m + k) {
-    int sc = t - D.m;
-    p = D.slotPos[sc];
-    v = xk[sc];
-  }
-  double changeObj = 0.0;
-  if (p >= 0) {
-    int append = 0;
-    if (v != 0.0) {
-      int iPivot = D.pivotVariable[p];
-      double value = D.sol[iPivot];
-      value -= v;
-      changeObj -= v * D.cost[iPivot];
-      D.sol[iPivot] = value;
-      if (c->pivotRule) {
-        double lower = D.lower[iPivot], upper = D.upper[iPivot];
-        double old = D.infeas[p];
-        if (value < lower - tolerance) {
-          value -= lower;
-          value *= value;
-          if (old == 0.0)
-            append = 1;
-          D.infeas[p] = value;
-        } else if (value > upper + tolerance) {
-          value -= upper;
-          value *= value;
-          if (old == 0.0)
-            append = 1;
-          D.infeas[p] = value;
-        } else if (old != 0.0) {
-          D.infeas[p] = REALLY_TINY;
-        }
-      }
-    }
-    D.appendFlag[p] = append;
-    if (append)
-      atomicAdd(&D.blockCount[p >> 8], 1);
-  }
-  double s = blockSum(changeObj, shd);
-  if (threadIdx.x == 0)
-    D.blockSum[blockIdx.x] = s;
-}
-
-// append scan with absolute offsets + the scalar tail that used to be k_after_primal2
+// append scan with absolute offsets + the scalar tail of the primal / flip updates
 __device__ inline void scanTailBody(const Dev &D, int nbCount, int nbSum, int which, int alphaTest, int parity)
 {
   Ctrl *c = D.ctrl;
@@ -3720,22 +2699,6 @@ __device__ inline void scanTailBody(const Dev &D, int nbCount, int nbSum, int wh
     }
   }
 }
-__global__ void __launch_bounds__(256) k_append_scatter_abs(Dev D, int which)
-{
-  const Ctrl *c = D.ctrl;
-  if (c->state != RUN || c->numberAppend == 0)
-    return;
-  if (which == 1 && c->numberFlips == 0)
-    return;
-  __shared__ int shi[17];
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
-  int flag = (p < D.m) ? D.appendFlag[p] : 0;
-  int total;
-  int rank = blockRank(flag, total, shi);
-  if (flag)
-    D.infIndex[D.blockOffset[blockIdx.x] + rank] = p;
-}
-
 __global__ void __launch_bounds__(256) k_house(Dev D)
 {
   if (D.ctrl->state != RUN)
@@ -3835,7 +2798,7 @@ __global__ void __launch_bounds__(256) k_fix_house(Dev D, int parity, int doFix,
 
 
 // =============================================================================================
-// v5: flips are known as soon as theta is (they do not depend on the FTRAN), so the flip right-hand
+// Flips are known as soon as theta is (they do not depend on the FTRAN), so the flip right-hand
 // side joins the entering column and the DSE vector in ONE three-vector FTRAN sweep over Minv.
 // =============================================================================================
 
@@ -4250,7 +3213,6 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos, int dens
 // k_flip_apply2), staged once per workgroup in LDS (chunks of GEMV_TILE slots); four waves then
 // stream each row of Minv against them.
 #define GEMV_TILE 2048
-#define GEMV_ROWS 1
 #define GEMV_WPR 2                      // waves per row of Minv
 #define GEMV_RPB (16 / GEMV_WPR)        // rows per 1024-thread workgroup
 __global__ void __launch_bounds__(1024) k_gemv3g(Dev D)
@@ -4512,96 +3474,12 @@ __global__ void __launch_bounds__(256) k_ftran_scatter3(Dev D, int nbNorm, int p
     scanTailBody(D, nbNorm, gridDim.x, 1, 1, parity);
 }
 
-// DSE weight update (needs w, tau) -- positions only
-__global__ void __launch_bounds__(256) k_weights2(Dev D, int nbNorm)
-{
-  const Ctrl *c = D.ctrl;
-  if (c->state != RUN || !c->pivotRule)
-    return;
-  __shared__ double shd[16];
-  double acc = 0.0;
-  for (int b = threadIdx.x; b < nbNorm; b += blockDim.x)
-    acc += D.normPartial[b];
-  acc = blockSum(acc, shd);
-  const double alphaOld = c->alpha;  // still the ratio-test alpha: the accuracy test comes after
-  const double norm = acc / (alphaOld * alphaOld);
-  const double multiplier = 2.0 / alphaOld;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < D.m) {
-    double thetaW = D.w[i];
-    if (thetaW != 0.0) {
-      double devex = D.weights[i];
-      D.altWeights[i] = devex;
-      if (i == c->pivotRow) {
-        devex = (norm < DEVEX_TRY_NORM) ? DEVEX_TRY_NORM : norm;
-      } else {
-        devex += thetaW * (thetaW * norm + D.tau[i] * multiplier);
-        if (devex < DEVEX_TRY_NORM)
-          devex = DEVEX_TRY_NORM;
-      }
-      D.weights[i] = devex;
-    }
-  }
-}
-
-// flip-count scan only (the accuracy test moved to k_scan_tail(which = 1), after the FTRAN)
-__global__ void __launch_bounds__(1024) k_scan_flips(Dev D, int nb)
-{
-  Ctrl *c = D.ctrl;
-  if (c->state != RUN)
-    return;
-  __shared__ int shi[17];
-  __shared__ int s_base;
-  if (threadIdx.x == 0)
-    s_base = 0;
-  __syncthreads();
-  for (int b0 = 0; b0 < nb; b0 += blockDim.x) {
-    int b = b0 + threadIdx.x;
-    int cnt = (b < nb) ? D.blockCount[b] : 0;
-    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    int v = cnt;
-    for (int o = 1; o < 64; o <<= 1) {
-      int t = __shfl_up(v, o);
-      if (lane >= o)
-        v += t;
-    }
-    __syncthreads();
-    if (lane == 63)
-      shi[wv] = v;
-    __syncthreads();
-    int base = s_base;
-    for (int i = 0; i < wv; i++)
-      base += shi[i];
-    if (b < nb)
-      D.blockOffset[b] = base + v - cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int tot = 0;
-      for (int i = 0; i < nw; i++)
-        tot += shi[i];
-      s_base += tot;
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0)
-    c->numberFlips = s_base;
-}
-
 __global__ void k_zero(double *p, int n)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n)
     p[i] = 0.0;
 }
-__global__ void k_zero_if_flips(Dev D, double *p, int n)
-{
-  if (D.ctrl->numberFlips == 0)
-    return;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n)
-    p[i] = 0.0;
-}
-
 // =============================================================================================
 // Refactorization of the nucleus: gather C = A[R,K], Gauss-Jordan with partial pivoting whose
 // arithmetic on the not-yet-pivoted rows is exactly the right-looking LU of
@@ -4629,67 +3507,6 @@ __global__ void k_identity(Dev D, int k)
     D.workX[(size_t)i * D.ld + i] = 1.0;
 }
 
-// pivot search in column i among physical rows >= i (first largest, > zeroTolerance)
-__global__ void __launch_bounds__(1024) k_gj_pivot(Dev D, int i, int k, int *info /*[0]=singular flag, [1]=pivot row*/)
-{
-  __shared__ double shv[16];
-  __shared__ int shk[16];
-  if (info[0])
-    return;
-  double best = D.ctrl->zeroTolerance;
-  int key = -1;
-  for (int j = i + threadIdx.x; j < k; j += blockDim.x) {
-    double v = fabs(D.workW[(size_t)j * D.ld + i]);
-    if (v > best) {
-      best = v;
-      key = j;
-    }
-  }
-  blockArgMax(best, key, shv, shk);
-  if (threadIdx.x == 0) {
-    if (key < 0)
-      info[0] = 1 + i;
-    info[1] = key;
-  }
-}
-// swap physical rows i and pivot row in W and X, record permutation, store multipliers
-__global__ void k_gj_swap(Dev D, int i, int k, int *info)
-{
-  if (info[0])
-    return;
-  int iRow = info[1];
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (iRow != i && j < k) {
-    size_t a = (size_t)i * D.ld + j, b = (size_t)iRow * D.ld + j;
-    double t = D.workW[a];
-    D.workW[a] = D.workW[b];
-    D.workW[b] = t;
-    t = D.workX[a];
-    D.workX[a] = D.workX[b];
-    D.workX[b] = t;
-  }
-  if (j == 0 && iRow != i) {
-    int t = D.perm[i];
-    D.perm[i] = D.perm[iRow];
-    D.perm[iRow] = t;
-  }
-}
-// multipliers l_r = W[r][i] * (1/pivot) for every row r != i (kept in slotA), pivot inverse in slotB[i]
-__global__ void k_gj_mult(Dev D, int i, int k, int *info)
-{
-  if (info[0])
-    return;
-  int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < k) {
-    double pivotValue = 1.0 / D.workW[(size_t)i * D.ld + i];
-    if (r == i) {
-      D.slotB[i] = pivotValue;
-      D.slotA[r] = 0.0;
-    } else {
-      D.slotA[r] = D.workW[(size_t)r * D.ld + i] * pivotValue;
-    }
-  }
-}
 // pivot search + row swap + multipliers of one elimination step, one workgroup
 __global__ void __launch_bounds__(1024) k_gj_step(Dev D, int i, int k, int *info)
 {
@@ -5324,9 +4141,4 @@ __global__ void k_infeas_finish(Dev D)
   D.ctrl->numberInfeasible = D.ctrl->numberAppend;
   D.ctrl->numberAppend = 0;
 }
-__global__ void k_set_state(Dev D, int state)
-{
-  D.ctrl->state = state;
-}
-
 }  // namespace clpgpu
