@@ -1329,8 +1329,13 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   // CHUZR (+ the analytic front end of the BTRAN)
   if (firstOfBatch)
     hipLaunchKernelGGL(k_chuzr_pre, dim3(1), dim3(64), 0, stream, D);
-  hipLaunchKernelGGL(k_chuzr_scan, dim3(nChzBlocks), dim3(256), 0, stream, D);
-  hipLaunchKernelGGL(k_chuzr_final_btran, dim3(1), dim3(256), 0, stream, D, nChzBlocks, wideRows ? 1 : 0);
+  if (nChzBlocks <= 256) {
+    // the last workgroup of the scan makes the final selection (no separate launch)
+    hipLaunchKernelGGL(k_chuzr_scan, dim3(nChzBlocks), dim3(256), 0, stream, D, wideRows ? 1 : 0);
+  } else {
+    hipLaunchKernelGGL(k_chuzr_scan, dim3(nChzBlocks), dim3(256), 0, stream, D, -1);
+    hipLaunchKernelGGL(k_chuzr_final_btran, dim3(1), dim3(256), 0, stream, D, nChzBlocks, wideRows ? 1 : 0);
+  }
   // BTRAN (reads Minv: the previous pivot's basis-update branch must have finished)
   joinUpdateBranch();
   if (wideRows)

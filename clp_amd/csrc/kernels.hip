@@ -1861,7 +1861,10 @@ __global__ void k_chuzr_pre(Dev D)
 }
 
 #define CHZ_ITEMS 4
-__global__ void __launch_bounds__(256) k_chuzr_scan(Dev D)
+template <bool COHERENT> __device__ inline void chuzrFinalBody(const Dev &D, int nblocks, int wide);
+// fuseFinal >= 0: the last workgroup to finish also makes the final selection and builds the BTRAN
+// t-vector (no separate launch); the value is the wide-row flag of that stage
+__global__ void __launch_bounds__(256) k_chuzr_scan(Dev D, int fuseFinal = -1)
 {
   const Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -1941,10 +1944,12 @@ __global__ void __launch_bounds__(256) k_chuzr_scan(Dev D)
         bestKey = shk[i];
         bestRow = shr[i];
       }
-    D.chzBest[blockIdx.x] = best;
-    D.chzKey[blockIdx.x] = bestKey;
-    D.chzRow[blockIdx.x] = bestRow;
+    stc(&D.chzBest[blockIdx.x], best);
+    stc(&D.chzKey[blockIdx.x], bestKey);
+    stc(&D.chzRow[blockIdx.x], bestRow);
   }
+  if (fuseFinal >= 0 && lastBlockDone(D.ctrl, 3))
+    chuzrFinalBody<true>(D, gridDim.x, fuseFinal);
 }
 
 // iteration BTRAN, back end: rho[i] = slack part or sum of the gemvT partials, flush tiny, piNeg,
@@ -2426,11 +2431,10 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_cand_count(Dev D, int nbRows, i
 // =============================================================================================
 
 // CHUZR final selection + the analytic front end of the BTRAN in one workgroup
-__global__ void __launch_bounds__(256) k_chuzr_final_btran(Dev D, int nblocks, int wide = 0)
+// COHERENT: run by the last workgroup of k_chuzr_scan (the per-block winners are read with ldc)
+template <bool COHERENT> __device__ inline void chuzrFinalBody(const Dev &D, int nblocks, int wide)
 {
   Ctrl *c = D.ctrl;
-  if (c->state != RUN)
-    return;
   __shared__ double shv[4];
   __shared__ int shk[4], shr[4];
   __shared__ int s_ok;
@@ -2440,12 +2444,12 @@ __global__ void __launch_bounds__(256) k_chuzr_final_btran(Dev D, int nblocks, i
   if (used > nblocks)
     used = nblocks;
   for (int b = threadIdx.x; b < used; b += blockDim.x) {
-    double ov = D.chzBest[b];
-    int ok = D.chzKey[b];
+    double ov = COHERENT ? ldc(&D.chzBest[b]) : D.chzBest[b];
+    int ok = COHERENT ? ldc(&D.chzKey[b]) : D.chzKey[b];
     if (ok >= 0 && (bestKey < 0 || ov > best || (ov == best && ok < bestKey))) {
       best = ov;
       bestKey = ok;
-      bestRow = D.chzRow[b];
+      bestRow = COHERENT ? ldc(&D.chzRow[b]) : D.chzRow[b];
     }
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -2569,6 +2573,12 @@ __global__ void __launch_bounds__(256) k_chuzr_final_btran(Dev D, int nblocks, i
     if (threadIdx.x == 0)
       c->tCount = cnt;
   }
+}
+__global__ void __launch_bounds__(256) k_chuzr_final_btran(Dev D, int nblocks, int wide = 0)
+{
+  if (D.ctrl->state != RUN)
+    return;
+  chuzrFinalBody<false>(D, nblocks, wide);
 }
 
 // append scan with absolute offsets + the scalar tail of the primal / flip updates
