@@ -81,6 +81,7 @@ struct clpgpu_context {
   int blockedRefactor = 1;
   // basis update (rank-1 sweep + fix-ups of Minv) on a second stream beside primal update,
   // housekeeping and the next CHUZR; joined before the next BTRAN reads Minv
+  int flipListCap = FLIP_LIST_CAP;  // option "flip_list_cap": smaller values force the overflow path (tests)
   int forkUpdate = 0;  // measured: 217 us/pivot forked vs 200 us single-stream (cross-stream graph edges cost more than they hide)
   hipStream_t stream2 = nullptr;
   hipEvent_t evFork = nullptr, evJoin = nullptr;
@@ -1379,8 +1380,8 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   // CHUZC (also unpacks the entering column)
   hipLaunchKernelGGL(k_dual_column, dim3(1), dim3(DC_THREADS), 0, stream, D, nb);
   // dual update + flip detection (needs only theta), flip list, flip right-hand side
-  hipLaunchKernelGGL(k_dj_flags, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
-  hipLaunchKernelGGL(k_flip_apply2, dim3(1), dim3(1024), 0, stream, D, gm, denseColumns ? 1 : 0);
+  hipLaunchKernelGGL(k_dj_flags, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, flipListCap);
+  hipLaunchKernelGGL(k_flip_apply2, dim3(1), dim3(1024), 0, stream, D, gm, denseColumns ? 1 : 0, flipListCap);
   if (denseColumns)
     hipLaunchKernelGGL(k_flip_dense, dim3(gm), dim3(256), 0, stream, D);
   // one FTRAN sweep for the entering column, rho (DSE) and the flip rhs; the back end also applies
@@ -2146,6 +2147,7 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "use_graph")) { ctx->useGraph = (int)v; ctx->dropGraph(); }
   else if (!strcmp(name, "blocked_refactor")) ctx->blockedRefactor = (int)v;
   else if (!strcmp(name, "fork_update")) { ctx->forkUpdate = (int)v; ctx->dropGraph(); }
+  else if (!strcmp(name, "flip_list_cap")) { ctx->flipListCap = std::max(1, std::min((int)v, FLIP_LIST_CAP)); ctx->dropGraph(); }
   else return -1;
   return 0;
 }

@@ -2814,7 +2814,7 @@ __global__ void __launch_bounds__(256) k_fix_house(Dev D, int parity, int doFix,
 
 // dual update + flip detection only (the weights need the FTRAN and come later)
 #define FLIP_LIST_CAP 4096
-__global__ void __launch_bounds__(PRICE_BLOCK) k_dj_flags(Dev D, int nbRows)
+__global__ void __launch_bounds__(PRICE_BLOCK) k_dj_flags(Dev D, int nbRows, int listCap = FLIP_LIST_CAP)
 {
   Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -2872,7 +2872,7 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_dj_flags(Dev D, int nbRows)
     base = __shfl(base, 0);
     if (flag) {
       int o = base + __popcll(mk & ((1ull << lane) - 1ull));
-      if (o < FLIP_LIST_CAP)
+      if (o < listCap)
         D.flipKey[o] = key;
     }
   }
@@ -2955,7 +2955,7 @@ __global__ void __launch_bounds__(256) k_flip_dense(Dev D)
     D.flipSlot[sr] = acc;
 }
 
-__global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos, int denseColumns = 0)
+__global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos, int denseColumns = 0, int listCap = FLIP_LIST_CAP)
 {
   Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -2972,7 +2972,7 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos, int dens
   __shared__ int s_seq[FLIP_LIST_CAP];
   __shared__ int shw[17];
   int nf;
-  if (nraw <= FLIP_LIST_CAP) {
+  if (nraw <= listCap) {
     if (tid < nraw)
       s_seq[tid] = key0;
     for (int i = tid + blockDim.x; i < nraw; i += blockDim.x)
@@ -3031,6 +3031,9 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos, int dens
       if (D.candFlag[i] != 0 && (i < D.m || (i - D.m >= D.firstColumn && i - D.m < D.lastColumn)))
         D.flipSeq[o++] = i < D.m ? D.n + i : i - D.m;
     nf = tot;
+    __syncthreads();
+    for (int f = tid; f < nf && f < FLIP_LIST_CAP; f += blockDim.x)
+      s_seq[f] = D.flipSeq[f];
   }
   if (tid == 0) {
     c->numberFlips = nf;

@@ -118,7 +118,10 @@ int clpgpu_pivots(const clpgpu_context *ctx);
  * (ClpDualRowSteepest); "max_iterations" (setMaximumIterations); "max_pivots"
  * (factorization maximumPivots); "dual_bound"; "primal_tolerance"; "dual_tolerance";
  * "random_seed"; "log_level"; "check_every" (host polls the device control block every N
- * iterations). */
+ * iterations).  Engine tuning / test knobs (no counterpart in the reference): "timing" (HIP events
+ * around every pricing launch), "price_kernel" (inner-loop variant of the pricing kernel, default
+ * 6), "use_graph", "blocked_refactor", "fork_update" (basis update on a second stream),
+ * "flip_list_cap" (size of the bound-flip append buffer; small values force its overflow path). */
 int clpgpu_set_option(clpgpu_context *ctx, const char *name, double value);
 /* optional warm start (ClpSimplex::statusArray) */
 int clpgpu_set_status(clpgpu_context *ctx, const unsigned char *status);

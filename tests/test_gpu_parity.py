@@ -252,6 +252,22 @@ def test_netlib_shaped_fake_bounds(gpu_cls, rule):
     kkt(lp, g, tol=1e-5)
 
 
+def test_flip_list_overflow_path_matches(gpu_cls):
+    """The bound flips of a pivot are appended unordered and put in list order afterwards; with a
+    2-entry append buffer every pivot with more flips takes the overflow path (ordered compaction of
+    the flags by one workgroup).  Same pivots, same flips, same solution as the default engine."""
+    lp = P.sparse_lp(300, 1200, 8, 11)
+    a = gpu_cls().loadProblem(lp)
+    b = gpu_cls().loadProblem(lp)
+    b.set_option("flip_list_cap", 2)
+    assert a.dual() == b.dual() == 0
+    la, lb = a.pivotLog(), b.pivotLog()
+    assert int(la["numberFlipped"].max()) > 2, "instance no longer exercises the overflow path"
+    for key in ("sequenceIn", "sequenceOut", "numberFlipped"):
+        assert np.array_equal(la[key], lb[key])
+    assert np.array_equal(a.solution(), b.solution())
+
+
 @pytest.mark.parametrize("n", [10, 50])
 def test_infeasible(gpu_cls, n):
     g, sg, o, so = solve_both(gpu_cls, P.infeasible(n), 1)
