@@ -79,6 +79,7 @@ struct clpgpu_context {
   bool denseColumns = false;  // every column holds all m rows in ascending order
   bool wideRows = false;  // mean row length >= 256 (dense LPs): wave-per-row / split-k variants of the row-wise stages
   int blockedRefactor = 1;
+  int registerPanel = 1;  // option "register_panel": 0 forces the global-memory panel kernel (used for k > 4096)
   // basis update (rank-1 sweep + fix-ups of Minv) on a second stream beside primal update,
   // housekeeping and the next CHUZR; joined before the next BTRAN reads Minv
   int flipListCap = FLIP_LIST_CAP;  // option "flip_list_cap": smaller values force the overflow path (tests)
@@ -566,17 +567,18 @@ int clpgpu_context::factorize()
     dim3 g2(cdiv(k, 256), k < 1024 ? k : 1024);
     if (blockedRefactor) {
       // panel width: the register-resident panel kernel holds rows-per-thread x width doubles
-      const int bs = k <= 1024 ? 32 : (k <= 3072 ? 16 : (k <= 4096 ? 8 : GJ_B));
+      const int kp = registerPanel ? k : 1 << 30;  // which panel kernel (and width) this k gets
+      const int bs = kp <= 1024 ? 32 : (kp <= 3072 ? 16 : (kp <= 4096 ? 8 : GJ_B));
       for (int i0 = 0; i0 < k; i0 += bs) {
         const int b = std::min(bs, k - i0);
         const int ncols = (k - (i0 + b)) + k;
-        if (k <= 1024)
+        if (kp <= 1024)
           hipLaunchKernelGGL((k_gj_panel_reg<2, 32, 512>), dim3(1), dim3(512), 0, stream, D, i0, b, k, dInfo);
-        else if (k <= 2048)
+        else if (kp <= 2048)
           hipLaunchKernelGGL((k_gj_panel_reg<4, 16, 512>), dim3(1), dim3(512), 0, stream, D, i0, b, k, dInfo);
-        else if (k <= 3072)
+        else if (kp <= 3072)
           hipLaunchKernelGGL((k_gj_panel_reg<6, 16, 512>), dim3(1), dim3(512), 0, stream, D, i0, b, k, dInfo);
-        else if (k <= 4096)
+        else if (kp <= 4096)
           hipLaunchKernelGGL((k_gj_panel_reg<8, 8, 512>), dim3(1), dim3(512), 0, stream, D, i0, b, k, dInfo);
         else
           hipLaunchKernelGGL(k_gj_panel, dim3(1), dim3(1024), 0, stream, D, i0, b, k, dInfo);
@@ -2146,6 +2148,7 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "price_kernel")) { ctx->priceKernel = (int)v; ctx->dropGraph(); }
   else if (!strcmp(name, "use_graph")) { ctx->useGraph = (int)v; ctx->dropGraph(); }
   else if (!strcmp(name, "blocked_refactor")) ctx->blockedRefactor = (int)v;
+  else if (!strcmp(name, "register_panel")) ctx->registerPanel = (int)v;
   else if (!strcmp(name, "fork_update")) { ctx->forkUpdate = (int)v; ctx->dropGraph(); }
   else if (!strcmp(name, "flip_list_cap")) { ctx->flipListCap = std::max(1, std::min((int)v, FLIP_LIST_CAP)); ctx->dropGraph(); }
   else return -1;

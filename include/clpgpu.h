@@ -120,7 +120,8 @@ int clpgpu_pivots(const clpgpu_context *ctx);
  * "random_seed"; "log_level"; "check_every" (host polls the device control block every N
  * iterations).  Engine tuning / test knobs (no counterpart in the reference): "timing" (HIP events
  * around every pricing launch), "price_kernel" (inner-loop variant of the pricing kernel, default
- * 6), "use_graph", "blocked_refactor", "fork_update" (basis update on a second stream),
+ * 6), "use_graph", "blocked_refactor", "register_panel" (re-inversion variants), "fork_update" (basis
+ * update on a second stream),
  * "flip_list_cap" (size of the bound-flip append buffer; small values force its overflow path). */
 int clpgpu_set_option(clpgpu_context *ctx, const char *name, double value);
 /* optional warm start (ClpSimplex::statusArray) */

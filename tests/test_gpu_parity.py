@@ -252,6 +252,24 @@ def test_netlib_shaped_fake_bounds(gpu_cls, rule):
     kkt(lp, g, tol=1e-5)
 
 
+@pytest.mark.parametrize("option", ["blocked_refactor", "register_panel"])
+def test_reinversion_variants_agree(gpu_cls, option):
+    """Re-inversion of the nucleus: the unblocked form, the blocked form with the global-memory panel
+    (the one nuclei beyond 4096 get) and the default blocked form with the register-resident panel do
+    the same arithmetic -- identical pivots and identical solution bits."""
+    lp = P.sparse_lp(300, 1200, 8, 11)
+    a = gpu_cls().loadProblem(lp)
+    b = gpu_cls().loadProblem(lp)
+    for g in (a, b):
+        g.set_option("max_pivots", 20)  # many refactorizations
+    b.set_option(option, 0)
+    assert a.dual() == b.dual() == 0
+    la, lb = a.pivotLog(), b.pivotLog()
+    assert np.array_equal(la["sequenceIn"], lb["sequenceIn"]) and np.array_equal(la["sequenceOut"], lb["sequenceOut"])
+    assert np.array_equal(a.pivotVariable(), b.pivotVariable())
+    assert np.array_equal(a.solution(), b.solution())
+
+
 def test_flip_list_overflow_path_matches(gpu_cls):
     """The bound flips of a pivot are appended unordered and put in list order afterwards; with a
     2-entry append buffer every pivot with more flips takes the overflow path (ordered compaction of
