@@ -157,6 +157,8 @@ struct Dev {
   const int *sellRow;
   const double *sellElem;
   int numSlices;
+  const int *longCol;  // [numLong] columns too long for a SELL lane (a wave strides each)
+  int numLong;
   double *sellMin, *sellBytes;  // per pricing workgroup
   double *chzBest;
   int *chzKey, *chzRow;

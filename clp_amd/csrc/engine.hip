@@ -73,6 +73,7 @@ struct clpgpu_context {
   std::vector<void *> allocations;
   int kcap = 0, ld = 0;
   int *dKcol = nullptr, *dLocalOfRow = nullptr, *dInfo = nullptr;
+  int nLongBlocks = 0;
   int nSellBlocks = 0, nChzBlocks = 0, priceKernel = 6, useGraph = 1, nWideBlocks = 1;
   bool widePricing = false;
   int maxColumnLength = 1;
@@ -357,13 +358,24 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
 // the entries inside a column is untouched, so the summation order per column is the CSC order.
 int clpgpu_context::buildSell()
 {
-  const int first = D.priceFirst, last = D.priceLast, count = last - first;
+  const int first = D.priceFirst, last = D.priceLast;
+  int count = last - first;
   std::vector<int> order(count);
   for (int i = 0; i < count; i++)
     order[i] = first + i;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
     return (colStart[a + 1] - colStart[a]) > (colStart[b + 1] - colStart[b]);
   });
+  // columns longer than SELL_LONG entries would keep one lane busy for len/8 dependent trips while
+  // the rest of the chip waits (power-law column counts): they leave the SELL copy and are priced by
+  // a wave each (priceLongBody).  `order` is sorted by decreasing length, so they are its prefix.
+  int nLong = 0;
+  while (nLong < count && colStart[order[nLong] + 1] - colStart[order[nLong]] > SELL_LONG)
+    nLong++;
+  std::vector<int> longCols(order.begin(), order.begin() + nLong);
+  order.erase(order.begin(), order.begin() + nLong);
+  const int countAll = count;
+  count = countAll - nLong;
   const int numSlices = cdiv(count, 64);
   std::vector<int> sellStart(numSlices + 1, 0), sellCol((size_t)numSlices * 64, -1), sellLen((size_t)numSlices * 64, 0);
   for (int s = 0; s < numSlices; s++) {
@@ -395,16 +407,18 @@ int clpgpu_context::buildSell()
         sellElem[base + (size_t)t * 64] = elem[p];
       }
     }
-  int *dStart, *dCol, *dLen, *dRow;
+  int *dStart, *dCol, *dLen, *dRow, *dLong;
   double *dElem;
   int rc = 0;
+  rc |= dalloc(dLong, (size_t)nLong + 1);
   rc |= dalloc(dStart, numSlices + 1);
   rc |= dalloc(dCol, (size_t)numSlices * 64);
   rc |= dalloc(dLen, (size_t)numSlices * 64);
   rc |= dalloc(dRow, sellRow.size());
   rc |= dalloc(dElem, sellElem.size());
   nSellBlocks = cdiv(numSlices, 4);
-  widePricing = count > 0 && (double)nnz / (double)n >= 256.0;
+  nLongBlocks = nLong;  // one workgroup per long column
+  widePricing = countAll > 0 && (double)nnz / (double)n >= 256.0;
   // (whole-matrix figures, so that every rank of a column-sharded run takes the same variants)
   wideRows = m > 0 && (double)colStart[n] / (double)m >= 256.0;
   maxColumnLength = 1;
@@ -417,11 +431,13 @@ int clpgpu_context::buildSell()
         denseColumns = false;
         break;
       }
-  nWideBlocks = std::min(WIDE_BLOCKS, std::max(1, cdiv(count, 4)));
-  rc |= dalloc(D.sellMin, std::max(nSellBlocks, WIDE_BLOCKS));
-  rc |= dalloc(D.sellBytes, std::max(nSellBlocks, WIDE_BLOCKS));
+  nWideBlocks = std::min(WIDE_BLOCKS, std::max(1, cdiv(countAll, 4)));
+  rc |= dalloc(D.sellMin, std::max(nSellBlocks + nLongBlocks, WIDE_BLOCKS));
+  rc |= dalloc(D.sellBytes, std::max(nSellBlocks + nLongBlocks, WIDE_BLOCKS));
   if (rc)
     return rc;
+  if (nLong)
+    rc |= h2d(dLong, longCols.data(), (size_t)nLong);
   rc |= h2d(dStart, sellStart.data(), numSlices + 1);
   rc |= h2d(dCol, sellCol.data(), sellCol.size());
   rc |= h2d(dLen, sellLen.data(), sellLen.size());
@@ -434,6 +450,8 @@ int clpgpu_context::buildSell()
   D.sellRow = dRow;
   D.sellElem = dElem;
   D.numSlices = numSlices;
+  D.longCol = dLong;
+  D.numLong = nLong;
   dropGraph();
   return rc;
 }
@@ -1353,9 +1371,9 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   if (priceKernel >= 1) {
     if (widePricing && priceKernel != 1)
       hipLaunchKernelGGL(k_price_wide, dim3(nWideBlocks), dim3(256), 0, stream, D, denseColumns ? 1 : 0, countInPrice ? 1 : 0);
-    else if (nSellBlocks > 0)
-      hipLaunchKernelGGL(k_price_sell, dim3(nSellBlocks), dim3(256), (m > 64 * SELL_BITS_MAX || priceKernel < 2) ? 0 : (size_t)((m + 63) / 64) * 8, stream, D, (m > 64 * SELL_BITS_MAX && priceKernel > 1) ? 1 : priceKernel,
-                         countInPrice ? 1 : 0);
+    else if (nSellBlocks + nLongBlocks > 0)
+      hipLaunchKernelGGL(k_price_sell, dim3(nSellBlocks + nLongBlocks), dim3(256), (m > 64 * SELL_BITS_MAX || priceKernel < 2) ? 0 : (size_t)((m + 63) / 64) * 8, stream, D, (m > 64 * SELL_BITS_MAX && priceKernel > 1) ? 1 : priceKernel,
+                         countInPrice ? 1 : 0, nSellBlocks);
     if (ev)
       (void)hipEventRecord(evStop[evUsed++], stream);
     if (commActive) {
@@ -1366,7 +1384,7 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
       ncclAllGatherFn(D.candFlag + D.m + (size_t)rank * chunk, D.candFlag + D.m, chunk, 1 /* ncclUint8 */, comm, stream);
     }
     {
-      const int nSell = (widePricing && priceKernel != 1) ? nWideBlocks : nSellBlocks;
+      const int nSell = (widePricing && priceKernel != 1) ? nWideBlocks : nSellBlocks + nLongBlocks;
       const bool fuse = nb <= 256;  // small grids: the last workgroup scans the counts itself
       if (!countInPrice)
         hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, commActive ? 1 : 0, fuse ? nSell : -1);
@@ -1739,9 +1757,9 @@ int clpgpu_context::priceRow(int numberPi, const int *piIndex, const double *piV
   const int nb = nbRows + nbCols;
   hipLaunchKernelGGL(k_zero, dim3(cdiv(n, 256)), dim3(256), 0, stream, D.alphaCol, n);
   if (priceKernel >= 1) {
-    if (nSellBlocks > 0)
-      hipLaunchKernelGGL(k_price_sell, dim3(nSellBlocks), dim3(256), 0, stream, D, 1);
-    hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, 0, nSellBlocks);
+    if (nSellBlocks + nLongBlocks > 0)
+      hipLaunchKernelGGL(k_price_sell, dim3(nSellBlocks + nLongBlocks), dim3(256), 0, stream, D, 1, 0, nSellBlocks);
+    hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, 0, nSellBlocks + nLongBlocks);
   } else {
     hipLaunchKernelGGL(k_price, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1, 0);

@@ -2085,6 +2085,7 @@ __global__ void k_gemvT_partial2(Dev D, const double *t, int iter)
 // loop (ClpPackedMatrix.cpp:1872-1886) and to the v1 kernel.  Fused first ratio pass as in v1.
 // =============================================================================================
 #define SELL_U 8
+#define SELL_LONG 128  // columns longer than this are priced by a wave each instead of a SELL lane
 #define SELL_BITS_MAX 8192  // 64-bit words of the pi bitmap kept in LDS (rows <= 524288)
 // PIPE: software-pipelined loads; NT: non-temporal matrix loads; BITS: gather pi only where the
 // row's bit is set (pi is sparse for most pivots: the gather traffic scales with nnz(pi)/m)
@@ -2264,8 +2265,71 @@ __device__ inline void priceSellBody(Dev D, unsigned long long *bits, int countC
 }
 
 // variant: 1 plain, 2 bitmap, 3 pipelined+bitmap, 4 pipelined+nt+bitmap, 5 nt+bitmap
-__global__ void __launch_bounds__(256) k_price_sell(Dev D, int variant, int countCols = 0)
+// long columns (see SELL_LONG): a workgroup strides one CSC column (coalesced) and reduces with a
+// fixed tree (64-way per wave, then the four waves in order) -- deterministic, equal to the
+// reference's sequential sum to rounding.  A power-law LP has a few columns with tens of thousands
+// of entries; one wave per column would leave that tail to a single wave.  Same fused first ratio
+// pass and the same per-workgroup outputs as the SELL body.
+__device__ inline void priceLongBody(const Dev &D, int blk, int countCols)
 {
+  const Ctrl *c = D.ctrl;
+  __shared__ double shd[16];
+  const double dualT = -c->dualTolerance;
+  const double acceptablePivot = c->acceptablePivot;
+  const double zeroTolerance = c->zeroTolerance;
+  double ratio = 1.0e31, bytes = 0.0;
+  if (blk < D.numLong) {  // uniform per workgroup
+    const int j = D.longCol[blk];
+    const int wanted = (D.status[j] & 3) - 1;
+    double value = 0.0;
+    int flag = 0;
+    if (wanted) {
+      const int start = D.colStart[j], end = D.colStart[j + 1];
+      double acc = 0.0;
+      for (int p = start + threadIdx.x; p < end; p += blockDim.x)
+        acc += D.piNeg[D.row[p]] * D.elem[p];
+      value = blockSum(acc, shd);
+      bytes = 12.0 * (end - start) + 4.0;
+      if (fabs(value) > zeroTolerance) {
+        bytes += 20.0;
+        if (wanted > 0) {
+          double mult = (wanted == 1) ? -1.0 : 1.0;
+          double alpha = value * mult;
+          if (alpha > 0.0) {
+            double oldValue = D.dj[j] * mult;
+            double v2 = oldValue - 1.0e15 * alpha;
+            if (v2 < dualT) {
+              flag = 1;
+              if (alpha >= acceptablePivot)
+                ratio = (oldValue - dualT) / alpha;
+            }
+          }
+        }
+      } else {
+        value = 0.0;
+      }
+    }
+    if (threadIdx.x == 0) {
+      D.alphaCol[j] = value;
+      D.candFlag[D.m + j] = (unsigned char)flag;
+      if (flag && countCols)
+        atomicAdd(&D.blockCount[((D.m + PRICE_BLOCK - 1) / PRICE_BLOCK) + ((j - D.firstColumn) / PRICE_BLOCK)], 1);
+    }
+  }
+  if (threadIdx.x == 0) {
+    D.sellMin[blockIdx.x] = ratio;
+    D.sellBytes[blockIdx.x] = bytes;
+  }
+}
+
+// workgroups [0, nSellBlocks) sweep the SELL slices, the rest the long columns
+__global__ void __launch_bounds__(256) k_price_sell(Dev D, int variant, int countCols = 0, int nSellBlocks = 1 << 30)
+{
+  if ((int)blockIdx.x >= nSellBlocks) {
+    if (D.ctrl->state == RUN)
+      priceLongBody(D, (int)blockIdx.x - nSellBlocks, countCols);
+    return;
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned long long sellBits[];  // (m+63)/64 words for variants >= 2
   if (D.ctrl->state != RUN)
     return;
