@@ -1344,7 +1344,6 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   const int nb = nbRows + nbCols;
   const int gm = cdiv(m, 256);
   const int kc = kcap;  // launch extents use the capacity; kernels read the live k from ctrl
-  const int gk = cdiv(kc, 256);
   const bool ev = timing && !capturing && evUsed < (int)evStart.size();
   int selfScanSell = -1;
   // CHUZR (+ the analytic front end of the BTRAN)

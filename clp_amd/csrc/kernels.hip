@@ -1530,7 +1530,7 @@ __global__ void k_rank1_fix(Dev D)
     }
   } else if (ucase == 2) {
     // delete col-slot a (a matrix row) and row-slot b (a matrix column): move the last ones in
-    int a = c->slotColOut, b = c->slotRowIn, last = k - 1;
+    int b = c->slotRowIn, last = k - 1;
     if (s < k) {
       // first the column move (within every row), then the row move; rows a/last handled once
       double vlast = D.Minv[(size_t)s * D.ld + last];
