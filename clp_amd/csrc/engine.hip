@@ -1053,6 +1053,12 @@ int clpgpu_context::startup()
     upper[n + i] = rowUpper[i];
     cost[n + i] = 0.0;
   }
+  // the bounds may have been replaced since the load (clpgpu_chg_*): the "original bound" copies
+  // that changeBounds / the fake-bound logic restore from follow them, on the host and on the device
+  origLower = lower;
+  origUpper = upper;
+  if (h2d(const_cast<double *>(D.origLower), origLower.data(), N) || h2d(const_cast<double *>(D.origUpper), origUpper.data(), N))
+    return -99;
   if (haveStatus) {
     status = userStatus;
   } else {
@@ -2179,6 +2185,39 @@ int clpgpu_set_status(clpgpu_context *ctx, const unsigned char *status)
   ctx->userStatus.assign(status, status + ctx->N);
   ctx->haveStatus = true;
   return 0;
+}
+
+// ClpModel::chgRowLower / chgRowUpper / chgColumnLower / chgColumnUpper / chgObjCoefficients
+// (src/ClpModel.cpp:2669-2770): whole-array replacement, the matrix stays resident; the next
+// clpgpu_dual starts from these (and from the status given with clpgpu_set_status) -- the re-solve
+// pattern of branch and bound (ClpSimplex::dual with a warm basis).
+static int changeArray(clpgpu_context *ctx, std::vector<double> &dst, const double *src, int count, double absent)
+{
+  if (!ctx)
+    return -99;
+  for (int i = 0; i < count; i++)
+    dst[i] = src ? src[i] : absent;
+  return 0;
+}
+int clpgpu_chg_row_lower(clpgpu_context *ctx, const double *rowLower)
+{
+  return ctx ? changeArray(ctx, ctx->rowLower, rowLower, ctx->m, -1.0e30) : -99;
+}
+int clpgpu_chg_row_upper(clpgpu_context *ctx, const double *rowUpper)
+{
+  return ctx ? changeArray(ctx, ctx->rowUpper, rowUpper, ctx->m, 1.0e30) : -99;
+}
+int clpgpu_chg_column_lower(clpgpu_context *ctx, const double *columnLower)
+{
+  return ctx ? changeArray(ctx, ctx->colLower, columnLower, ctx->n, 0.0) : -99;
+}
+int clpgpu_chg_column_upper(clpgpu_context *ctx, const double *columnUpper)
+{
+  return ctx ? changeArray(ctx, ctx->colUpper, columnUpper, ctx->n, 1.0e30) : -99;
+}
+int clpgpu_chg_obj_coefficients(clpgpu_context *ctx, const double *objIn)
+{
+  return ctx ? changeArray(ctx, ctx->obj, objIn, ctx->n, 0.0) : -99;
 }
 
 int clpgpu_dual(clpgpu_context *ctx)

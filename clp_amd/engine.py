@@ -38,6 +38,8 @@ ABI_SYMBOLS = [
     "clpgpu_set_status", "clpgpu_dual", "clpgpu_dual_steps", "clpgpu_number_iterations", "clpgpu_objective_value",
     "clpgpu_get_solution", "clpgpu_get_reduced_costs", "clpgpu_get_status", "clpgpu_get_pivot_variable",
     "clpgpu_get_pivot_log", "clpgpu_get_row_weights", "clpgpu_get_stats",
+    "clpgpu_chg_row_lower", "clpgpu_chg_row_upper", "clpgpu_chg_column_lower", "clpgpu_chg_column_upper",
+    "clpgpu_chg_obj_coefficients",
 ]
 
 
@@ -92,6 +94,8 @@ def lib():
         L.clpgpu_pivots.argtypes = [p]
         L.clpgpu_set_option.argtypes = [p, C.c_char_p, C.c_double]
         L.clpgpu_set_status.argtypes = [p, up]
+        for name in ("row_lower", "row_upper", "column_lower", "column_upper", "obj_coefficients"):
+            getattr(L, "clpgpu_chg_" + name).argtypes = [p, dp]
         L.clpgpu_dual.argtypes = [p]
         L.clpgpu_dual_steps.argtypes = [p, C.c_int]
         L.clpgpu_number_iterations.argtypes = [p]
@@ -153,6 +157,22 @@ class ClpGpuSimplex:
 
     def setStatusArray(self, status):
         self._check(lib().clpgpu_set_status(self._h, np.ascontiguousarray(status, dtype=np.uint8)), "clpgpu_set_status")
+
+    # ClpModel::chgRowLower ... chgObjCoefficients: new bounds / costs, matrix stays on the device
+    def chgRowLower(self, values):
+        self._check(lib().clpgpu_chg_row_lower(self._h, np.ascontiguousarray(values, dtype=np.float64)), "clpgpu_chg_row_lower")
+
+    def chgRowUpper(self, values):
+        self._check(lib().clpgpu_chg_row_upper(self._h, np.ascontiguousarray(values, dtype=np.float64)), "clpgpu_chg_row_upper")
+
+    def chgColumnLower(self, values):
+        self._check(lib().clpgpu_chg_column_lower(self._h, np.ascontiguousarray(values, dtype=np.float64)), "clpgpu_chg_column_lower")
+
+    def chgColumnUpper(self, values):
+        self._check(lib().clpgpu_chg_column_upper(self._h, np.ascontiguousarray(values, dtype=np.float64)), "clpgpu_chg_column_upper")
+
+    def chgObjCoefficients(self, values):
+        self._check(lib().clpgpu_chg_obj_coefficients(self._h, np.ascontiguousarray(values, dtype=np.float64)), "clpgpu_chg_obj_coefficients")
 
     def dual(self):
         return lib().clpgpu_dual(self._h)

@@ -124,6 +124,16 @@ int clpgpu_pivots(const clpgpu_context *ctx);
  * update on a second stream),
  * "flip_list_cap" (size of the bound-flip append buffer; small values force its overflow path). */
 int clpgpu_set_option(clpgpu_context *ctx, const char *name, double value);
+/* Whole-array replacement of bounds / costs with the matrix left resident
+ * (ClpModel::chgRowLower ... chgObjCoefficients, src/ClpModel.hpp:254-262, src/ClpModel.cpp:2669-2770;
+ * C interface Clp_chgRowLower ... src/Clp_C_Interface.h:150-158).  NULL means "no bound" / zero cost
+ * as in the reference.  The next clpgpu_dual starts from these and from the status passed with
+ * clpgpu_set_status: the warm re-solve of branch and bound. */
+int clpgpu_chg_row_lower(clpgpu_context *ctx, const double *rowLower);
+int clpgpu_chg_row_upper(clpgpu_context *ctx, const double *rowUpper);
+int clpgpu_chg_column_lower(clpgpu_context *ctx, const double *columnLower);
+int clpgpu_chg_column_upper(clpgpu_context *ctx, const double *columnUpper);
+int clpgpu_chg_obj_coefficients(clpgpu_context *ctx, const double *objIn);
 /* optional warm start (ClpSimplex::statusArray) */
 int clpgpu_set_status(clpgpu_context *ctx, const unsigned char *status);
 /* ClpSimplex::dual() (src/ClpSimplex.cpp:5631 -> ClpSimplexDual::dual :637): returns problemStatus

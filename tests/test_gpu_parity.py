@@ -252,6 +252,37 @@ def test_netlib_shaped_fake_bounds(gpu_cls, rule):
     kkt(lp, g, tol=1e-5)
 
 
+def test_warm_resolve_after_bound_change(gpu_cls):
+    """Branch-and-bound pattern: solve, tighten upper bounds with the matrix left on the device
+    (ClpModel::chgColumnUpper), re-solve dual from the previous basis.  The re-solve is warm (far
+    fewer pivots than from the slack basis), ends at the optimum the oracle finds for the modified LP
+    from the same basis, and satisfies the KKT conditions of the modified LP.  (The pivot sequences are
+    not compared: like a ClpSimplex object that is solved twice, the engine is not a fresh model on
+    the second call.)"""
+    lp = P.sparse_lp(300, 1200, 8, 11)
+    g = gpu_cls().loadProblem(lp)
+    assert g.dual() == 0
+    first_iterations = g.numberIterations()
+    status, sol = g.statusArray().copy(), g.solution()
+    branch = np.argsort(-sol[:lp.n], kind="stable")[:5]
+    assert np.all(sol[branch] > 1.0)
+    new_upper = lp.col_upper.copy()
+    new_upper[branch] = np.floor(sol[branch] * 0.5)
+    g.chgColumnUpper(new_upper)
+    g.setStatusArray(status)
+    sg = g.dual()
+    lp2 = type(lp)(lp)  # LpData is a dict with attribute access
+    lp2.col_upper = new_upper
+    o = oracle(lp2, 1)
+    o.set_status(status)
+    so = o.dual()
+    assert sg == so == 0
+    assert 0 < g.numberIterations() < first_iterations // 2
+    assert abs(g.objectiveValue() - o.objective) <= RTOL * (1 + abs(o.objective))
+    assert np.all(g.solution()[:lp.n][branch] <= new_upper[branch] + 1e-7)
+    kkt(lp2, g)
+
+
 @pytest.mark.parametrize("option", ["blocked_refactor", "register_panel"])
 def test_reinversion_variants_agree(gpu_cls, option):
     """Re-inversion of the nucleus: the unblocked form, the blocked form with the global-memory panel
