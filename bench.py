@@ -148,6 +148,14 @@ def main():
                "sample": f"first {o.iterations} pivots of the same LP from the slack basis ({o.seconds:.1f} s), "
                          "CPU oracle = C restatement of ClpSimplexDual (reference needs CoinUtils, not buildable here)"}
 
+    config_ref = {"sparse": "BASELINE.json configs[3]", "dense": "BASELINE.json configs[2]",
+                  "netlib": "Netlib-shaped variant of BASELINE.json configs[3]"}[args.workload]
+    if (args.rows, args.cols) != {"dense": (5000, 5000)}.get(args.workload, (50000, 200000)):
+        config_ref += ", non-default size"
+    # mean column length >= 256 selects the wave-per-column pricing kernel (engine.hip, widePricing)
+    price_kernel = ("k_price_wide (row pricing by column, a wave per column, fused first ratio pass)"
+                    if len(lp.elem) >= 256 * lp.n else
+                    "k_price_sell (row pricing by column, SELL-64 + a workgroup per long column, fused first ratio pass)")
     if rank == 0:
         out = {
             "metric": "dual-simplex iterations/sec",
@@ -162,12 +170,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload} LP {lp.m}x{lp.n}, {len(lp.elem)} nonzeros (BASELINE.json configs[3]), "
-                                   "steepest-edge dual from the slack basis" if args.pivot_rule else "Dantzig dual",
+            "config": {"workload": f"{args.workload} LP {lp.m}x{lp.n}, {len(lp.elem)} nonzeros ({config_ref}), "
+                                   + ("steepest-edge dual" if args.pivot_rule else "Dantzig dual") + " from the slack basis",
                        "rows": int(lp.m), "cols": int(lp.n), "nnz": int(len(lp.elem)),
                        "parallelism": f"column-range pricing x{world}" if world > 1 else "1 GPU",
                        "check_every": args.check_every, "generate_s": round(gen_s, 1)},
-            "roofline": {"bound": "hbm", "kernel": "k_price_sell (row pricing by column, SELL-64, fused first ratio pass)",
+            "roofline": {"bound": "hbm", "kernel": price_kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "bytes_per_launch": per_launch_bytes, "us_per_launch": per_launch_s * 1e6,
                          "launches": int(launches), "traffic": traffic},
