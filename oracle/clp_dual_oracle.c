@@ -771,12 +771,6 @@ static int replaceColumn(OrcModel *M, const int *wIndex, const double *wValue, i
   return 0;
 }
 
-static long factorNumberElements(const OrcModel *M)
-{
-  const Factor *F = &M->fac;
-  return (long)F->k * F->k + F->etaStart[F->nEta] + M->m;
-}
-
 int orc_factorize(OrcModel *M, const unsigned char *status, int *pivotVariable)
 {
   memcpy(M->status, status, (size_t)(M->m + M->n));
