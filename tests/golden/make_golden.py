@@ -9,6 +9,9 @@ DOES pin is asserted directly in tests/test_oracle_golden.py (objective values, 
   afiro_pivots.json : per-iteration (sequenceIn, sequenceOut) of the dual simplex on AFIRO, Dantzig
                       and steepest-edge row choice
   price_case.npz    : one fused row-pricing call on a 300x1200 sparse LP (inputs and outputs)
+  hello_lp.npz      : BASELINE config 1 (examples/hello.mps of the reference, 21 x 53, the plumbing
+                      case) as parsed arrays -- written only where /root/reference exists; the
+                      reference pins no objective for it, the stored optimum is HiGHS' and the oracle's
 """
 import json
 import os
@@ -46,7 +49,27 @@ def main():
     oi, ov, ci, cv, ut = o.price_row_fused(idx, val, status, dj)
     np.savez_compressed(os.path.join(HERE, "price_case.npz"), pi_index=idx, pi_value=val, status=status, dj=dj,
                         out_index=oi, out_value=ov, cand_index=ci, cand_value=cv, upper_theta=ut)
+    hello()
     print("golden fixtures written")
+
+
+def hello():
+    src = "/root/reference/examples/hello.mps"
+    if not os.path.exists(src):
+        return
+    from scipy.optimize import linprog
+    import scipy.sparse as sp
+
+    lp = read_mps(src)
+    o = OracleSimplex(lp)
+    assert o.dual() == 0
+    A = sp.csc_matrix((lp.elem, lp.row, lp.col_start), shape=(lp.m, lp.n))
+    r = linprog(lp.obj, A_ub=sp.vstack([A, -A]), b_ub=np.concatenate([lp.row_upper, -lp.row_lower]),
+                bounds=list(zip(lp.col_lower, lp.col_upper)), method="highs")
+    assert r.status == 0 and abs(r.fun - o.objective) < 1e-9
+    np.savez_compressed(os.path.join(HERE, "hello_lp.npz"), m=lp.m, n=lp.n, col_start=lp.col_start, row=lp.row, elem=lp.elem,
+                        col_lower=lp.col_lower, col_upper=lp.col_upper, obj=lp.obj, row_lower=lp.row_lower,
+                        row_upper=lp.row_upper, optimum=r.fun)
 
 
 if __name__ == "__main__":

@@ -54,6 +54,26 @@ def test_afiro_objective_and_kkt(built, afiro, rule):
     assert st == 0 and abs(obj - o.objective) < 1e-7
 
 
+def test_hello_plumbing_case(built):
+    """BASELINE config 1: the reference's examples/hello.mps (21 x 53, all +-1, ranges and UP bounds),
+    stored as parsed arrays by tests/golden/make_golden.py.  The reference pins no objective for it
+    (SURVEY 8c); HiGHS and the oracle agree on 0 (the slack basis is optimal: zero pivots)."""
+    from clp_amd.mps import LpData
+
+    d = np.load(os.path.join(HERE, "golden", "hello_lp.npz"))
+    lp = LpData({k: (int(d[k]) if k in ("m", "n") else d[k]) for k in d.files if k != "optimum"})
+    lp["name"] = "hello"
+    assert (lp.m, lp.n, len(lp.elem)) == (21, 53, 224)
+    for rule in (0, 1):
+        o = OracleSimplex(lp)
+        o.set_option("pivot_rule", rule)
+        assert o.dual() == 0
+        assert abs(o.objective - float(d["optimum"])) < 1e-9
+        kkt_check(lp, o)
+    st, obj = highs_objective(lp)
+    assert st == 0 and abs(obj - float(d["optimum"])) < 1e-9
+
+
 def test_afiro_pivot_log_matches_committed_golden(built, afiro):
     gold = json.load(open(os.path.join(HERE, "golden", "afiro_pivots.json")))
     for rule, name in ((0, "dantzig"), (1, "steepest")):
