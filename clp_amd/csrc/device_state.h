@@ -157,6 +157,10 @@ struct Dev {
   const int *sellRow;
   const double *sellElem;
   int numSlices;
+  // optional SELL copy with L lanes per column (k_price_sellx; option "sell_lanes")
+  const int *sxStart, *sxCol, *sxLen, *sxRow;
+  const double *sxElem;
+  int sxSlices;
   const int *longCol;  // [numLong] columns too long for a SELL lane (a wave strides each)
   int numLong;
   double *sellMin, *sellBytes;  // per pricing workgroup

@@ -83,6 +83,9 @@ struct clpgpu_context {
   int registerPanel = 1;  // option "register_panel": 0 forces the global-memory panel kernel (used for k > 4096)
   // basis update (rank-1 sweep + fix-ups of Minv) on a second stream beside primal update,
   // housekeeping and the next CHUZR; joined before the next BTRAN reads Minv
+  // option "sell_lanes" (1 default; 2/4/8 experimental): lanes per column of the pricing layout
+  int sellLanes = 1, nSxBlocks = 0;
+  int buildSellX();
   int flipListCap = FLIP_LIST_CAP;  // option "flip_list_cap": smaller values force the overflow path (tests)
   int forkUpdate = 0;  // measured: 217 us/pivot forked vs 200 us single-stream (cross-stream graph edges cost more than they hide)
   hipStream_t stream2 = nullptr;
@@ -347,6 +350,7 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   }
   memset(hCtrl, 0, sizeof(Ctrl));
   rc |= buildSell();
+  rc |= buildSellX();
   rc |= sync();
   started = false;
   return rc;
@@ -464,6 +468,92 @@ void clpgpu_context::dropGraph()
     (void)hipGraphDestroy(graph);
   graphExec = nullptr;
   graph = nullptr;
+}
+
+// SELL copy with `sellLanes` lanes per column for k_price_sellx (see the comment there).  Separate
+// from buildSell so that the default layout is untouched; long columns (> SELL_LONG) stay with
+// priceLongBody in both.
+int clpgpu_context::buildSellX()
+{
+  const int L = sellLanes;
+  nSxBlocks = 0;
+  D.sxSlices = 0;
+  if (L != 2 && L != 4 && L != 8)
+    return 0;
+  const int first = D.priceFirst, last = D.priceLast;
+  std::vector<int> order;
+  order.reserve(last - first);
+  for (int j = first; j < last; j++)
+    if (colStart[j + 1] - colStart[j] <= SELL_LONG)
+      order.push_back(j);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    return (colStart[a + 1] - colStart[a]) > (colStart[b + 1] - colStart[b]);
+  });
+  const int count = (int)order.size(), cps = 64 / L;
+  const int numSlices = cdiv(count, cps);
+  std::vector<int> sxStart(numSlices + 1, 0), sxCol((size_t)numSlices * cps, -1), sxLen((size_t)numSlices * cps, 0);
+  for (int s = 0; s < numSlices; s++) {
+    int maxSteps = 0;
+    for (int cidx = 0; cidx < cps; cidx++) {
+      int i = s * cps + cidx;
+      if (i < count) {
+        int j = order[i];
+        sxCol[i] = j;
+        sxLen[i] = colStart[j + 1] - colStart[j];
+        maxSteps = std::max(maxSteps, cdiv(sxLen[i], L));
+      }
+    }
+    maxSteps = cdiv(maxSteps, SELL_U) * SELL_U;
+    sxStart[s + 1] = sxStart[s] + maxSteps * 64;
+  }
+  const size_t total = (size_t)sxStart[numSlices];
+  std::vector<int> sxRow(total ? total : 1, 0);
+  std::vector<double> sxElem(total ? total : 1, 0.0);
+  for (int s = 0; s < numSlices; s++)
+    for (int cidx = 0; cidx < cps; cidx++) {
+      int i = s * cps + cidx;
+      if (i >= count)
+        continue;
+      int j = order[i];
+      for (int p = colStart[j], en = 0; p < colStart[j + 1]; p++, en++) {
+        // entry en of the column: sub-lane en % L at step en / L
+        size_t at = (size_t)sxStart[s] + (size_t)(en / L) * 64 + (size_t)cidx * L + (size_t)(en % L);
+        sxRow[at] = row[p];
+        sxElem[at] = elem[p];
+      }
+    }
+  int *dStart, *dCol, *dLen, *dRow;
+  double *dElem;
+  int rc = 0;
+  rc |= dalloc(dStart, numSlices + 1);
+  rc |= dalloc(dCol, sxCol.size() + 1);
+  rc |= dalloc(dLen, sxLen.size() + 1);
+  rc |= dalloc(dRow, sxRow.size());
+  rc |= dalloc(dElem, sxElem.size());
+  if (rc)
+    return rc;
+  rc |= h2d(dStart, sxStart.data(), numSlices + 1);
+  if (!sxCol.empty()) {
+    rc |= h2d(dCol, sxCol.data(), sxCol.size());
+    rc |= h2d(dLen, sxLen.data(), sxLen.size());
+  }
+  rc |= h2d(dRow, sxRow.data(), sxRow.size());
+  rc |= h2d(dElem, sxElem.data(), sxElem.size());
+  rc |= sync();
+  D.sxStart = dStart;
+  D.sxCol = dCol;
+  D.sxLen = dLen;
+  D.sxRow = dRow;
+  D.sxElem = dElem;
+  D.sxSlices = numSlices;
+  nSxBlocks = cdiv(numSlices, 4);
+  // the per-workgroup outputs of the pricing launch are indexed by workgroup
+  int *dummy = nullptr;
+  (void)dummy;
+  rc |= dalloc(D.sellMin, std::max(std::max(nSellBlocks, nSxBlocks) + nLongBlocks, WIDE_BLOCKS));
+  rc |= dalloc(D.sellBytes, std::max(std::max(nSellBlocks, nSxBlocks) + nLongBlocks, WIDE_BLOCKS));
+  dropGraph();
+  return rc;
 }
 
 int clpgpu_context::allocNucleus(int kNeeded)
@@ -1369,6 +1459,8 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   // (not column-sharded: the candidate counts come from this kernel and the pricing kernel, there
   // is no separate counting launch)
   const bool countInPrice = priceKernel >= 1 && !commActive && nb > 256;
+  // experimental multi-lane pricing layout (needs the LDS bitmap: m <= 64 * SELL_BITS_MAX)
+  const bool sellX = sellLanes > 1 && nSxBlocks > 0 && priceKernel >= 2 && !widePricing && m <= 64 * SELL_BITS_MAX;
   hipLaunchKernelGGL(k_rho_finish3, dim3(gm), dim3(256), 0, stream, D, wideRows ? 1 : 0, countInPrice ? nbCols : -1);
   // PRICE + first ratio pass
   if (ev)
@@ -1376,7 +1468,15 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   if (priceKernel >= 1) {
     if (widePricing && priceKernel != 1)
       hipLaunchKernelGGL(k_price_wide, dim3(nWideBlocks), dim3(256), 0, stream, D, denseColumns ? 1 : 0, countInPrice ? 1 : 0);
-    else if (nSellBlocks + nLongBlocks > 0)
+    else if (sellX) {
+      const size_t lds = (size_t)((m + 63) / 64) * 8;
+      if (sellLanes == 2)
+        hipLaunchKernelGGL((k_price_sellx<2>), dim3(nSxBlocks + nLongBlocks), dim3(256), lds, stream, D, countInPrice ? 1 : 0, nSxBlocks);
+      else if (sellLanes == 4)
+        hipLaunchKernelGGL((k_price_sellx<4>), dim3(nSxBlocks + nLongBlocks), dim3(256), lds, stream, D, countInPrice ? 1 : 0, nSxBlocks);
+      else
+        hipLaunchKernelGGL((k_price_sellx<8>), dim3(nSxBlocks + nLongBlocks), dim3(256), lds, stream, D, countInPrice ? 1 : 0, nSxBlocks);
+    } else if (nSellBlocks + nLongBlocks > 0)
       hipLaunchKernelGGL(k_price_sell, dim3(nSellBlocks + nLongBlocks), dim3(256), (m > 64 * SELL_BITS_MAX || priceKernel < 2) ? 0 : (size_t)((m + 63) / 64) * 8, stream, D, (m > 64 * SELL_BITS_MAX && priceKernel > 1) ? 1 : priceKernel,
                          countInPrice ? 1 : 0, nSellBlocks);
     if (ev)
@@ -1389,7 +1489,7 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
       ncclAllGatherFn(D.candFlag + D.m + (size_t)rank * chunk, D.candFlag + D.m, chunk, 1 /* ncclUint8 */, comm, stream);
     }
     {
-      const int nSell = (widePricing && priceKernel != 1) ? nWideBlocks : nSellBlocks + nLongBlocks;
+      const int nSell = (widePricing && priceKernel != 1) ? nWideBlocks : (sellX ? nSxBlocks : nSellBlocks) + nLongBlocks;
       const bool fuse = nb <= 256;  // small grids: the last workgroup scans the counts itself
       if (!countInPrice)
         hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, commActive ? 1 : 0, fuse ? nSell : -1);
@@ -1874,7 +1974,8 @@ int clpgpu_set_column_range(clpgpu_context *ctx, int firstColumn, int lastColumn
     return -1;
   ctx->D.firstColumn = ctx->D.priceFirst = firstColumn;
   ctx->D.lastColumn = ctx->D.priceLast = lastColumn;
-  return ctx->buildSell();
+  int rc = ctx->buildSell();
+  return rc ? rc : ctx->buildSellX();
 }
 
 int clpgpu_times(clpgpu_context *ctx, double scalar, const double *x, double *y)
@@ -2129,7 +2230,8 @@ int clpgpu_comm_init(clpgpu_context *ctx, int rank, int nranks, const void *id12
   ctx->D.priceFirst = std::min(rank * chunk, ctx->n);
   ctx->D.priceLast = std::min((rank + 1) * chunk, ctx->n);
   ctx->useGraph = 0;  // collectives are enqueued between kernels; keep the eager chain
-  return ctx->buildSell();
+  rc = ctx->buildSell();
+  return rc ? rc : ctx->buildSellX();
 }
 
 int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
@@ -2173,6 +2275,12 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "blocked_refactor")) ctx->blockedRefactor = (int)v;
   else if (!strcmp(name, "register_panel")) ctx->registerPanel = (int)v;
   else if (!strcmp(name, "fork_update")) { ctx->forkUpdate = (int)v; ctx->dropGraph(); }
+  else if (!strcmp(name, "sell_lanes")) {
+    ctx->sellLanes = (int)v;
+    ctx->dropGraph();
+    if (ctx->n > 0 && ctx->D.colStart)  // already loaded: build (or drop) the extra copy now
+      return ctx->buildSellX();
+  }
   else if (!strcmp(name, "flip_list_cap")) { ctx->flipListCap = std::max(1, std::min((int)v, FLIP_LIST_CAP)); ctx->dropGraph(); }
   else return -1;
   return 0;

@@ -2322,6 +2322,130 @@ __device__ inline void priceLongBody(const Dev &D, int blk, int countCols)
   }
 }
 
+// Experimental layout (option "sell_lanes" = 2, 4 or 8; not the default): L adjacent lanes share one
+// column, so a wave owns 64/L columns and a column of length len takes len/(8 L) trips instead of
+// len/8.  With one lane per column the 200 000 columns of config 4 are only 3 125 waves -- three per
+// SIMD, each doing ~10 dependent trips -- which leaves the kernel latency-bound at about a third of
+// the HBM rate; more lanes per column put more waves (and more loads) in flight.  Entry e of a column
+// sits in sub-lane e mod L at step e / L; each sub-lane adds its entries in order and the L partial
+// sums are combined by a fixed butterfly: deterministic, equal to the sequential sum to rounding
+// (NOT bit-identical to it, unlike the default layout).  Same conditional fetch, same fused ratio pass.
+template <int L> __global__ void __launch_bounds__(256) k_price_sellx(Dev D, int countCols, int nSellBlocks)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned long long bits[];
+  const Ctrl *c = D.ctrl;
+  if ((int)blockIdx.x >= nSellBlocks) {
+    if (c->state == RUN)
+      priceLongBody(D, (int)blockIdx.x - nSellBlocks, countCols);
+    return;
+  }
+  if (c->state != RUN)
+    return;
+  constexpr int CPS = 64 / L;  // columns per slice
+  __shared__ double shd[16];
+  __shared__ int shPop[4];
+  const double dualT = -c->dualTolerance;
+  const double acceptablePivot = c->acceptablePivot;
+  const double zeroTolerance = c->zeroTolerance;
+  const int lane = threadIdx.x & 63;
+  const int slice = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwords = (D.m + 63) >> 6;
+  int pop = 0;
+  for (int w = threadIdx.x; w < nwords; w += blockDim.x) {
+    unsigned long long word = D.piBits[w];
+    bits[w] = word;
+    pop += __popcll(word);
+  }
+  for (int o = 32; o > 0; o >>= 1)
+    pop += __shfl_xor(pop, o);
+  if (lane == 0)
+    shPop[threadIdx.x >> 6] = pop;
+  __syncthreads();
+  pop = shPop[0] + shPop[1] + shPop[2] + shPop[3];
+  const bool sparsePi = 12 * (long long)pop < (long long)D.m;
+  double ratio = 1.0e31, bytes = 0.0;
+  if (slice < D.sxSlices) {
+    const int col = lane / L, sub = lane % L;
+    const int idx = slice * CPS + col;
+    const int j = D.sxCol[idx];
+    int len = 0, wanted = 0;
+    if (j >= 0) {
+      wanted = (D.status[j] & 3) - 1;
+      if (wanted)
+        len = D.sxLen[idx];
+    }
+    int maxSteps = (len + L - 1) / L;
+    for (int o = 32; o > 0; o >>= 1)
+      maxSteps = max(maxSteps, __shfl_xor(maxSteps, o));
+    double value = 0.0;
+    if (maxSteps > 0) {
+      const int start = D.sxStart[slice];
+      const int *rp = D.sxRow + start + lane;
+      const double *ep = D.sxElem + start + lane;
+      for (int t = 0; t < maxSteps; t += SELL_U) {
+        int r[SELL_U];
+        double e[SELL_U], pv[SELL_U];
+        bool hit[SELL_U];
+#pragma unroll
+        for (int u = 0; u < SELL_U; u++)
+          r[u] = rp[(t + u) * 64];
+#pragma unroll
+        for (int u = 0; u < SELL_U; u++) {
+          hit[u] = ((t + u) * L + sub < len) && (!sparsePi || ((bits[r[u] >> 6] >> (r[u] & 63)) & 1ull));
+          e[u] = 0.0;
+          pv[u] = 0.0;
+          if (hit[u]) {
+            e[u] = ep[(t + u) * 64];
+            pv[u] = D.piNeg[r[u]];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < SELL_U; u++)
+          if (hit[u])
+            value += pv[u] * e[u];
+      }
+    }
+    // the L partial sums of a column (adjacent lanes), fixed butterfly: every sub-lane gets the total
+#pragma unroll
+    for (int o = 1; o < L; o <<= 1)
+      value += __shfl_xor(value, o);
+    if (j >= 0 && sub == 0) {
+      int flag = 0;
+      if (wanted) {
+        bytes = 12.0 * len + 4.0;
+        if (fabs(value) > zeroTolerance) {
+          bytes += 20.0;
+          if (wanted > 0) {
+            double mult = (wanted == 1) ? -1.0 : 1.0;
+            double alpha = value * mult;
+            if (alpha > 0.0) {
+              double oldValue = D.dj[j] * mult;
+              double v2 = oldValue - 1.0e15 * alpha;
+              if (v2 < dualT) {
+                flag = 1;
+                if (alpha >= acceptablePivot)
+                  ratio = (oldValue - dualT) / alpha;
+              }
+            }
+          }
+        } else {
+          value = 0.0;
+        }
+      }
+      D.alphaCol[j] = value;
+      D.candFlag[D.m + j] = (unsigned char)flag;
+      if (flag && countCols)
+        atomicAdd(&D.blockCount[((D.m + PRICE_BLOCK - 1) / PRICE_BLOCK) + ((j - D.firstColumn) / PRICE_BLOCK)], 1);
+    }
+  }
+  double bmin = blockMin(ratio, shd);
+  double bsum = blockSum(bytes, shd);
+  if (threadIdx.x == 0) {
+    D.sellMin[blockIdx.x] = bmin;
+    D.sellBytes[blockIdx.x] = bsum;
+  }
+}
+
 // workgroups [0, nSellBlocks) sweep the SELL slices, the rest the long columns
 __global__ void __launch_bounds__(256) k_price_sell(Dev D, int variant, int countCols = 0, int nSellBlocks = 1 << 30)
 {

@@ -122,7 +122,9 @@ int clpgpu_pivots(const clpgpu_context *ctx);
  * around every pricing launch), "price_kernel" (inner-loop variant of the pricing kernel, default
  * 6), "use_graph", "blocked_refactor", "register_panel" (re-inversion variants), "fork_update" (basis
  * update on a second stream),
- * "flip_list_cap" (size of the bound-flip append buffer; small values force its overflow path). */
+ * "flip_list_cap" (size of the bound-flip append buffer; small values force its overflow path),
+ * "sell_lanes" (1; 2/4/8 = experimental pricing layout with several lanes per column, written at
+ * the end of round 1 and not yet run on hardware). */
 int clpgpu_set_option(clpgpu_context *ctx, const char *name, double value);
 /* Whole-array replacement of bounds / costs with the matrix left resident
  * (ClpModel::chgRowLower ... chgObjCoefficients, src/ClpModel.hpp:254-262, src/ClpModel.cpp:2669-2770;
