@@ -88,6 +88,9 @@ struct OrcModel {
   int numberPrimalInfeasibilities, numberDualInfeasibilities;
   int numberFake, numberChanged, numberTimesOptimal, forceFactorization, lastBadIteration;
   unsigned int seed;
+  int scalingMode;            /* ClpModel::scaling(): 0 off (default here), 1 equilibrium, 2 geometric, 3/4 auto */
+  int scalingApplied;         /* last orc_dual really scaled (scale() returned 0) */
+  double *rowScale, *colScale; /* [m], [n] of the last scaled solve */
   Factor fac;
   /* dual row pivot */
   double *weights;      /* [m] by basis position */
@@ -264,6 +267,7 @@ void orc_destroy(OrcModel *M)
   free(M->colLower); free(M->colUpper); free(M->obj); free(M->rowLower); free(M->rowUpper);
   free(M->lower); free(M->upper); free(M->cost); free(M->dj); free(M->sol); free(M->status);
   free(M->pivotVariable);
+  free(M->rowScale); free(M->colScale);
   freeFactor(&M->fac);
   free(M->weights); free(M->infeas); free(M->infIndex); free(M->savedWeights); free(M->savedWhich);
   free(M->altWeightValue); free(M->altWeightIndex);
@@ -298,6 +302,7 @@ int orc_set_option(OrcModel *M, const char *name, double v)
   else if (!strcmp(name, "log_level")) M->logLevel = (int)v;
   else if (!strcmp(name, "random_seed")) M->seed = (unsigned int)v;
   else if (!strcmp(name, "price_by_row")) M->priceByRow = (int)v;
+  else if (!strcmp(name, "scaling")) M->scalingMode = (int)v;
   else return -1;
   return 0;
 }
@@ -2483,7 +2488,7 @@ static void statusOfProblemInDual(OrcModel *M, int *lastCleaned, int type)
 }
 
 /* ClpSimplexDual::dual :637 -> startupSolve :230 -> gutsOfDual :432 */
-int orc_dual(OrcModel *M)
+static int dualOnRim(OrcModel *M)
 {
   const int m = M->m, n = M->n, N = m + n;
   struct timespec t0, t1;
@@ -2579,6 +2584,313 @@ int orc_dual(OrcModel *M)
     M->objectiveValue = objective;
   }
   return M->problemStatus;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Scaling -- ClpPackedMatrix::scale (src/ClpPackedMatrix.cpp:4120-4760) as ClpSimplex::createRim  */
+/* calls it (matrix_->scale(this, this), src/ClpSimplex.cpp:3701), its application to bounds and     */
+/* costs (createRim :3880-3980) and the unscaling of the results.  Modes: 1 equilibrium, 2           */
+/* geometric, 3 and 4 "auto" (equilibrium first, geometric kept if its spread is more than twice     */
+/* better).  automaticScale_ (objectiveScale_/rhsScale_) is off, as by default in the reference.     */
+/* Returns 1 when the matrix is left unscaled (all |a_ij| within [0.5, 2], :4282), else 0.           */
+/* Groundwork for SURVEY 8(f)3: the HIP engine does not scale yet; not part of any parity claim.     */
+/* ------------------------------------------------------------------------------------------ */
+static int computeScaling(OrcModel *M, double *rowScale, double *columnScale)
+{
+  const int m = M->m, n = M->n;
+  char *usefulColumn = (char *)malloc((size_t)n + 1);
+  char *usedRow = (char *)calloc((size_t)m + 1, 1);
+  double largest = 0.0, smallest = 1.0e50;
+  for (int j = 0; j < n; j++) {
+    char useful = 0;
+    if (M->colUpper[j] > M->colLower[j] + 1.0e-12 || (M->haveStatus && getStatus(M, j) == ST_BASIC)) {
+      for (int p = M->colStart[j]; p < M->colStart[j + 1]; p++) {
+        double value = fabs(M->elem[p]);
+        if (value > 1.0e-20) {
+          useful = 1;
+          if (value > largest)
+            largest = value;
+          if (value < smallest)
+            smallest = value;
+        }
+      }
+    }
+    usefulColumn[j] = useful;
+  }
+  if (smallest * 1.0e12 < largest) { /* :4268 increase tolerances */
+    if (M->dualTolerance < 5.0e-7)
+      M->dualTolerance = M->dualToleranceBase = 5.0e-7;
+    if (M->primalTolerance < 5.0e-7)
+      M->primalTolerance = 5.0e-7;
+  }
+  if (smallest >= 0.5 && largest <= 2.0) { /* :4273 don't bother scaling */
+    free(usefulColumn);
+    free(usedRow);
+    return 1;
+  }
+  if (largest > 1.0e13 * smallest) { /* :4303 safer to have a smaller zero tolerance */
+    double newTolerance = smallest / largest * 0.5;
+    if (newTolerance < 1.0e-18)
+      newTolerance = 1.0e-18;
+    if (M->zeroTolerance > newTolerance)
+      M->zeroTolerance = newTolerance;
+  }
+  int scalingMethod = M->scalingMode;
+  if (scalingMethod == 4)
+    scalingMethod = 3;
+  double savedOverallRatio = 0.0;
+  const double tolerance = 5.0 * M->primalTolerance;
+  double overallLargest, overallSmallest = 1.0e20;
+  int finished = 0;
+  while (!finished) {
+    int numberPass = 3;
+    for (int i = 0; i < m; i++)
+      rowScale[i] = 1.0;
+    for (int j = 0; j < n; j++)
+      columnScale[j] = 1.0;
+    if (scalingMethod == 1 || scalingMethod == 3) {
+      /* maximum in each row (:4340) */
+      for (int i = 0; i < m; i++) {
+        largest = 1.0e-10;
+        for (int q = M->rowStart[i]; q < M->rowStart[i + 1]; q++)
+          if (usefulColumn[M->rcol[q]]) {
+            double value = fabs(M->relem[q]);
+            if (value > largest)
+              largest = value;
+          }
+        rowScale[i] = 1.0 / largest;
+      }
+    } else {
+      /* geometric mean: rows, columns, rows (:4365-4445; the last column round is skipped) */
+      while (numberPass) {
+        numberPass--;
+        for (int i = 0; i < m; i++) {
+          largest = 1.0e-50;
+          smallest = 1.0e50;
+          for (int q = M->rowStart[i]; q < M->rowStart[i + 1]; q++) {
+            int j = M->rcol[q];
+            if (usefulColumn[j]) {
+              double value = fabs(M->relem[q]) * columnScale[j];
+              if (value > largest)
+                largest = value;
+              if (value < smallest)
+                smallest = value;
+            }
+          }
+          rowScale[i] = 1.0 / sqrt(smallest * largest);
+        }
+        if (numberPass == 1)
+          break;
+        for (int j = 0; j < n; j++)
+          if (usefulColumn[j]) {
+            largest = 1.0e-50;
+            smallest = 1.0e50;
+            for (int p = M->colStart[j]; p < M->colStart[j + 1]; p++) {
+              double value = fabs(M->elem[p]) * rowScale[M->row[p]];
+              if (value > largest)
+                largest = value;
+              if (value < smallest)
+                smallest = value;
+            }
+            columnScale[j] = 1.0 / sqrt(smallest * largest);
+          }
+      }
+    }
+    /* if ranges will make horrid then scale (:4451) */
+    for (int i = 0; i < m; i++) {
+      double difference = M->rowUpper[i] - M->rowLower[i];
+      double scaledDifference = difference * rowScale[i];
+      if (scaledDifference > tolerance && scaledDifference < 1.0e-4) {
+        rowScale[i] *= 1.0e-4 / scaledDifference;
+        if (rowScale[i] > 1.0e10)
+          rowScale[i] = 1.0e10;
+        if (rowScale[i] < 1.0e-10)
+          rowScale[i] = 1.0e-10;
+      }
+    }
+    /* what the smallest would be if every column's largest were 1.0 (:4465) */
+    overallSmallest = 1.0e50;
+    for (int j = 0; j < n; j++)
+      if (usefulColumn[j]) {
+        largest = 1.0e-20;
+        smallest = 1.0e50;
+        for (int p = M->colStart[j]; p < M->colStart[j + 1]; p++) {
+          double value = fabs(M->elem[p] * rowScale[M->row[p]]);
+          if (value > largest)
+            largest = value;
+          if (value < smallest)
+            smallest = value;
+        }
+        if (overallSmallest * largest > smallest)
+          overallSmallest = smallest / largest;
+      }
+    if (scalingMethod == 1 || scalingMethod == 2) {
+      finished = 1;
+    } else if (savedOverallRatio == 0.0 && scalingMethod != 4) {
+      savedOverallRatio = overallSmallest;
+      scalingMethod = 4;
+    } else {
+      if (overallSmallest > 2.0 * savedOverallRatio)
+        finished = 1; /* geometric was better */
+      else
+        scalingMethod = 1; /* redo equilibrium */
+    }
+  }
+  /* final pass: columns scaled so that their largest is reasonable (:4528-4590) */
+  overallLargest = 1.0;
+  if (overallSmallest < 1.0e-1)
+    overallLargest = 1.0 / sqrt(overallSmallest);
+  if (overallLargest > 100.0)
+    overallLargest = 100.0;
+  overallSmallest = 1.0e50;
+  for (int j = 0; j < n; j++) {
+    if (M->colUpper[j] > M->colLower[j] + 1.0e-12 && M->colStart[j + 1] > M->colStart[j]) {
+      largest = 1.0e-20;
+      smallest = 1.0e50;
+      for (int p = M->colStart[j]; p < M->colStart[j + 1]; p++) {
+        int i = M->row[p];
+        usedRow[i] = 1;
+        double value = fabs(M->elem[p] * rowScale[i]);
+        if (value > largest)
+          largest = value;
+        if (value < smallest)
+          smallest = value;
+      }
+      columnScale[j] = overallLargest / largest;
+      double difference = M->colUpper[j] - M->colLower[j];
+      if (difference < 1.0e-5 * columnScale[j])
+        columnScale[j] = difference / 1.0e-5; /* make gap larger */
+      double value = smallest * columnScale[j];
+      if (overallSmallest > value)
+        overallSmallest = value;
+    } else {
+      columnScale[j] = 1.0;
+    }
+  }
+  for (int i = 0; i < m; i++)
+    if (!usedRow[i])
+      rowScale[i] = 1.0;
+  if (overallSmallest < 1.0e-13) { /* :4601 */
+    double newTolerance = overallSmallest * 0.5;
+    if (newTolerance < 1.0e-18)
+      newTolerance = 1.0e-18;
+    M->zeroTolerance = newTolerance;
+  }
+  free(usefulColumn);
+  free(usedRow);
+  return 0;
+}
+
+/* scaled bound as createRim builds it (src/ClpSimplex.cpp:3920-3980): infinities stay infinite */
+static void scaleBounds(double lowerValue, double upperValue, double multiplier, double primalTolerance, double *lo, double *up)
+{
+  const double INF = 1.0e30;
+  if (lowerValue > -1.0e20) {
+    *lo = lowerValue * multiplier;
+    if (upperValue >= 1.0e20) {
+      *up = INF;
+    } else {
+      *up = upperValue * multiplier;
+      if (fabs(*up - *lo) <= primalTolerance) { /* fix variables with tiny gaps */
+        if (*lo >= 0.0)
+          *up = *lo;
+        else if (*up <= 0.0)
+          *lo = *up;
+        else
+          *lo = *up = 0.0;
+      }
+    }
+  } else if (upperValue < 1.0e20) {
+    *lo = -INF;
+    *up = upperValue * multiplier;
+  } else {
+    *lo = -INF;
+    *up = INF;
+  }
+}
+
+int orc_dual(OrcModel *M)
+{
+  const int m = M->m, n = M->n;
+  M->scalingApplied = 0;
+  if (M->scalingMode <= 0)
+    return dualOnRim(M);
+  free(M->rowScale);
+  free(M->colScale);
+  M->rowScale = (double *)malloc(sizeof(double) * (size_t)(m + 1));
+  M->colScale = (double *)malloc(sizeof(double) * (size_t)(n + 1));
+  if (computeScaling(M, M->rowScale, M->colScale))
+    return dualOnRim(M); /* not scaled after all (scalingFlag_ = -scalingFlag_, src/ClpSimplex.cpp:3702) */
+  const double *rs = M->rowScale, *cs = M->colScale;
+  const int nnz = M->colStart[n];
+  /* scaled model: A_s = R A C, x_s = x / c_j, row_s = r_i * row, cost_s = c_j * cost */
+  double *elemS = (double *)malloc(sizeof(double) * (size_t)(nnz + 1));
+  double *relemS = (double *)malloc(sizeof(double) * (size_t)(nnz + 1));
+  double *clS = (double *)malloc(sizeof(double) * (size_t)(n + 1)), *cuS = (double *)malloc(sizeof(double) * (size_t)(n + 1));
+  double *objS = (double *)malloc(sizeof(double) * (size_t)(n + 1));
+  double *rlS = (double *)malloc(sizeof(double) * (size_t)(m + 1)), *ruS = (double *)malloc(sizeof(double) * (size_t)(m + 1));
+  for (int j = 0; j < n; j++) {
+    for (int p = M->colStart[j]; p < M->colStart[j + 1]; p++)
+      elemS[p] = M->elem[p] * cs[j] * rs[M->row[p]];
+    objS[j] = M->obj[j] * cs[j];
+    scaleBounds(M->colLower[j], M->colUpper[j], 1.0 / cs[j], M->primalTolerance, &clS[j], &cuS[j]);
+  }
+  for (int i = 0; i < m; i++) {
+    for (int q = M->rowStart[i]; q < M->rowStart[i + 1]; q++)
+      relemS[q] = M->relem[q] * rs[i] * cs[M->rcol[q]];
+    scaleBounds(M->rowLower[i], M->rowUpper[i], rs[i], M->primalTolerance, &rlS[i], &ruS[i]);
+  }
+  double *saveElem = M->elem, *saveRelem = M->relem, *saveCl = M->colLower, *saveCu = M->colUpper, *saveObj = M->obj,
+         *saveRl = M->rowLower, *saveRu = M->rowUpper;
+  M->elem = elemS;
+  M->relem = relemS;
+  M->colLower = clS;
+  M->colUpper = cuS;
+  M->obj = objS;
+  M->rowLower = rlS;
+  M->rowUpper = ruS;
+  int status = dualOnRim(M);
+  M->elem = saveElem;
+  M->relem = saveRelem;
+  M->colLower = saveCl;
+  M->colUpper = saveCu;
+  M->obj = saveObj;
+  M->rowLower = saveRl;
+  M->rowUpper = saveRu;
+  /* unscale: activities, reduced costs, duals (deleteRim, src/ClpSimplex.cpp:3376-3412) */
+  for (int j = 0; j < n; j++) {
+    M->sol[j] *= cs[j];
+    M->dj[j] /= cs[j];
+  }
+  for (int i = 0; i < m; i++) {
+    M->sol[n + i] /= rs[i];
+    M->dj[n + i] *= rs[i];
+  }
+  if (status == 0 || status == 3) {
+    double objective = 0.0;
+    for (int j = 0; j < n; j++)
+      objective += M->obj[j] * M->sol[j];
+    M->objectiveValue = objective;
+  }
+  M->scalingApplied = 1;
+  free(elemS);
+  free(relemS);
+  free(clS);
+  free(cuS);
+  free(objS);
+  free(rlS);
+  free(ruS);
+  return status;
+}
+
+/* scale factors of the last scaled solve (1.0 everywhere if it was not scaled); returns scalingApplied */
+int orc_get_scale_factors(const OrcModel *M, double *rowScale, double *columnScale)
+{
+  for (int i = 0; i < M->m; i++)
+    rowScale[i] = (M->scalingApplied && M->rowScale) ? M->rowScale[i] : 1.0;
+  for (int j = 0; j < M->n; j++)
+    columnScale[j] = (M->scalingApplied && M->colScale) ? M->colScale[j] : 1.0;
+  return M->scalingApplied;
 }
 
 int orc_number_iterations(const OrcModel *M) { return M->numberIterations; }

@@ -55,7 +55,11 @@ OrcModel *orc_create(int numberRows, int numberColumns, const int *columnStart, 
 void orc_destroy(OrcModel *model);
 
 /* options: "pivot_rule" 0=Dantzig 1=steepest; "max_iterations"; "max_pivots" (refactor frequency);
- * "dual_bound"; "primal_tolerance"; "dual_tolerance"; "log_level"; "random_seed" */
+ * "dual_bound"; "primal_tolerance"; "dual_tolerance"; "log_level"; "random_seed";
+ * "scaling" 0 off (default) / 1 equilibrium / 2 geometric / 3,4 auto: ClpPackedMatrix::scale
+ * (src/ClpPackedMatrix.cpp:4120) applied as createRim does; results are returned unscaled, the pivot
+ * log's theta/alpha/dualOut are in scaled units.  Groundwork for SURVEY 8(f)3 -- the HIP engine does
+ * not scale yet. */
 int orc_set_option(OrcModel *model, const char *name, double value);
 
 /* optional starting basis: status[0..n+m) with ClpSimplex::Status codes (src/ClpSimplex.hpp:119) */
@@ -77,6 +81,8 @@ void orc_get_row_duals(const OrcModel *model, double *dual);
 int orc_get_pivot_log(const OrcModel *model, OrcPivotRecord *out, int maxRecords);
 void orc_get_row_weights(const OrcModel *model, double *weights, double *infeasibility);
 double orc_iteration_seconds(const OrcModel *model);
+/* row (m) and column (n) scale factors of the last orc_dual; returns 1 if that solve was scaled */
+int orc_get_scale_factors(const OrcModel *model, double *rowScale, double *columnScale);
 
 /* ---- unit-level entry points used by the kernel parity tests ---- */
 

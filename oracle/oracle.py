@@ -61,6 +61,7 @@ def lib():
         L.orc_get_pivot_variable.argtypes = [p, ip]
         L.orc_get_pivot_log.argtypes = [p, C.c_void_p, C.c_int]
         L.orc_get_row_weights.argtypes = [p, dp, dp]
+        L.orc_get_scale_factors.argtypes = [p, dp, dp]
         L.orc_times.argtypes = [p, C.c_double, dp, dp]
         L.orc_transpose_times.argtypes = [p, C.c_double, dp, dp]
         L.orc_price_row_fused.argtypes = [p, C.c_int, ip, dp, up, dp, C.c_double, C.c_double, C.c_double, ip, dp,
@@ -141,6 +142,12 @@ class OracleSimplex:
         w, inf = np.zeros(self.m), np.zeros(self.m)
         lib().orc_get_row_weights(self._h, w, inf)
         return w, inf
+
+    def scale_factors(self):
+        """(scaled?, rowScale[m], columnScale[n]) of the last dual(): ClpPackedMatrix::scale factors"""
+        rs, cs = np.empty(self.m), np.empty(self.n)
+        applied = lib().orc_get_scale_factors(self._h, rs, cs)
+        return bool(applied), rs, cs
 
     def pivot_log(self):
         count = lib().orc_get_pivot_log(self._h, None, 0)
