@@ -12,6 +12,7 @@
  *                             changeBound :6445)
  *   src/ClpPackedMatrix.cpp  (times :296, transposeTimes :362, transposeTimesByColumn :961,
  *                             gutsOfTransposeTimesUnscaled fused pass :1799, add :4874)
+ *                             scale :4120-4760 (option "scaling"; applied as ClpSimplex::createRim :3880-3980 does)
  *   src/ClpDualRowSteepest.cpp (pivotRow :179, updateWeights :375, updatePrimalSolution :630,
  *                             saveWeights :773, unrollWeights :1022)
  *   src/ClpDualRowDantzig.cpp (pivotRow :56)
