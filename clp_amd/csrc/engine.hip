@@ -86,6 +86,11 @@ struct clpgpu_context {
   // option "sell_lanes" (1 default; 2/4/8 experimental): lanes per column of the pricing layout
   int sellLanes = 1, nSxBlocks = 0;
   int buildSellX();
+  // option "scaling" (0 off, default; 1/2/3/4 as ClpModel::scaling): set BEFORE clpgpu_load_problem.  The
+  // device then holds the scaled LP; solution getters return unscaled values, clpgpu_chg_* take unscaled ones.
+  int scalingMode = 0;
+  bool scaled = false;
+  std::vector<double> rowScale, colScale;
   int flipListCap = FLIP_LIST_CAP;  // option "flip_list_cap": smaller values force the overflow path (tests)
   int forkUpdate = 0;  // measured: 217 us/pivot forked vs 200 us single-stream (cross-stream graph edges cost more than they hide)
   hipStream_t stream2 = nullptr;
@@ -197,6 +202,202 @@ struct clpgpu_context {
 };
 
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Scaling -- ClpPackedMatrix::scale (src/ClpPackedMatrix.cpp:4120-4760) as ClpSimplex::createRim
+// calls it (src/ClpSimplex.cpp:3701): row and column factors for mode 1 (equilibrium), 2 (geometric),
+// 3/4 (auto: equilibrium first, geometric kept when its spread is more than twice better), then the
+// final column pass.  Host code (the reference does this once per solve on the CPU as well).  May
+// tighten the zero tolerance / loosen the feasibility tolerances exactly as the reference does.
+// Returns 1 when the matrix is left unscaled (every |a_ij| within [0.5, 2], :4273), else 0.
+// ---------------------------------------------------------------------------------------------
+static int computeScaleFactors(int m, int n, const int *colStart, const int *row, const double *elem, const double *colLower,
+                               const double *colUpper, const double *rowLower, const double *rowUpper, int mode,
+                               double &primalTolerance, double &dualTolerance, double &zeroTolerance, double *rowScale,
+                               double *columnScale)
+{
+  // row-ordered copy for the row passes
+  std::vector<int> rowStart(m + 1, 0), rcol(colStart[n] ? colStart[n] : 1);
+  std::vector<double> relem(colStart[n] ? colStart[n] : 1);
+  for (int p = 0; p < colStart[n]; p++)
+    rowStart[row[p] + 1]++;
+  for (int i = 0; i < m; i++)
+    rowStart[i + 1] += rowStart[i];
+  {
+    std::vector<int> fill(rowStart.begin(), rowStart.end() - 1);
+    for (int j = 0; j < n; j++)
+      for (int p = colStart[j]; p < colStart[j + 1]; p++) {
+        int q = fill[row[p]]++;
+        rcol[q] = j;
+        relem[q] = elem[p];
+      }
+  }
+  std::vector<char> usefulColumn(n, 0), usedRow(m, 0);
+  double largest = 0.0, smallest = 1.0e50;
+  for (int j = 0; j < n; j++) {
+    char useful = 0;
+    if (colUpper[j] > colLower[j] + 1.0e-12) {
+      for (int p = colStart[j]; p < colStart[j + 1]; p++) {
+        double value = fabs(elem[p]);
+        if (value > 1.0e-20) {
+          useful = 1;
+          largest = std::max(largest, value);
+          smallest = std::min(smallest, value);
+        }
+      }
+    }
+    usefulColumn[j] = useful;
+  }
+  if (smallest * 1.0e12 < largest) {  // :4268 increase tolerances
+    dualTolerance = std::max(dualTolerance, 5.0e-7);
+    primalTolerance = std::max(primalTolerance, 5.0e-7);
+  }
+  if (smallest >= 0.5 && largest <= 2.0)  // :4273 don't bother scaling
+    return 1;
+  if (largest > 1.0e13 * smallest)  // :4303 safer to have a smaller zero tolerance
+    zeroTolerance = std::min(zeroTolerance, std::max(smallest / largest * 0.5, 1.0e-18));
+  int scalingMethod = mode == 4 ? 3 : mode;
+  double savedOverallRatio = 0.0;
+  const double tolerance = 5.0 * primalTolerance;
+  double overallLargest, overallSmallest = 1.0e20;
+  bool finished = false;
+  while (!finished) {
+    int numberPass = 3;
+    std::fill(rowScale, rowScale + m, 1.0);
+    std::fill(columnScale, columnScale + n, 1.0);
+    if (scalingMethod == 1 || scalingMethod == 3) {
+      for (int i = 0; i < m; i++) {  // maximum in each row (:4340)
+        largest = 1.0e-10;
+        for (int q = rowStart[i]; q < rowStart[i + 1]; q++)
+          if (usefulColumn[rcol[q]])
+            largest = std::max(largest, fabs(relem[q]));
+        rowScale[i] = 1.0 / largest;
+      }
+    } else {
+      while (numberPass) {  // geometric mean: rows, columns, rows (:4365-4445)
+        numberPass--;
+        for (int i = 0; i < m; i++) {
+          largest = 1.0e-50;
+          smallest = 1.0e50;
+          for (int q = rowStart[i]; q < rowStart[i + 1]; q++) {
+            int j = rcol[q];
+            if (usefulColumn[j]) {
+              double value = fabs(relem[q]) * columnScale[j];
+              largest = std::max(largest, value);
+              smallest = std::min(smallest, value);
+            }
+          }
+          rowScale[i] = 1.0 / sqrt(smallest * largest);
+        }
+        if (numberPass == 1)
+          break;
+        for (int j = 0; j < n; j++)
+          if (usefulColumn[j]) {
+            largest = 1.0e-50;
+            smallest = 1.0e50;
+            for (int p = colStart[j]; p < colStart[j + 1]; p++) {
+              double value = fabs(elem[p]) * rowScale[row[p]];
+              largest = std::max(largest, value);
+              smallest = std::min(smallest, value);
+            }
+            columnScale[j] = 1.0 / sqrt(smallest * largest);
+          }
+      }
+    }
+    for (int i = 0; i < m; i++) {  // if ranges will make horrid then scale (:4451)
+      double difference = rowUpper[i] - rowLower[i];
+      double scaledDifference = difference * rowScale[i];
+      if (scaledDifference > tolerance && scaledDifference < 1.0e-4) {
+        rowScale[i] *= 1.0e-4 / scaledDifference;
+        rowScale[i] = std::max(1.0e-10, std::min(1.0e10, rowScale[i]));
+      }
+    }
+    overallSmallest = 1.0e50;  // what the smallest would be if every column's largest were 1.0 (:4465)
+    for (int j = 0; j < n; j++)
+      if (usefulColumn[j]) {
+        largest = 1.0e-20;
+        smallest = 1.0e50;
+        for (int p = colStart[j]; p < colStart[j + 1]; p++) {
+          double value = fabs(elem[p] * rowScale[row[p]]);
+          largest = std::max(largest, value);
+          smallest = std::min(smallest, value);
+        }
+        if (overallSmallest * largest > smallest)
+          overallSmallest = smallest / largest;
+      }
+    if (scalingMethod == 1 || scalingMethod == 2) {
+      finished = true;
+    } else if (savedOverallRatio == 0.0 && scalingMethod != 4) {
+      savedOverallRatio = overallSmallest;
+      scalingMethod = 4;
+    } else if (overallSmallest > 2.0 * savedOverallRatio) {
+      finished = true;  // geometric was better
+    } else {
+      scalingMethod = 1;  // redo equilibrium
+    }
+  }
+  // final pass: columns scaled so that their largest entry is reasonable (:4528-4590)
+  overallLargest = 1.0;
+  if (overallSmallest < 1.0e-1)
+    overallLargest = 1.0 / sqrt(overallSmallest);
+  overallLargest = std::min(100.0, overallLargest);
+  overallSmallest = 1.0e50;
+  for (int j = 0; j < n; j++) {
+    if (colUpper[j] > colLower[j] + 1.0e-12 && colStart[j + 1] > colStart[j]) {
+      largest = 1.0e-20;
+      smallest = 1.0e50;
+      for (int p = colStart[j]; p < colStart[j + 1]; p++) {
+        int i = row[p];
+        usedRow[i] = 1;
+        double value = fabs(elem[p] * rowScale[i]);
+        largest = std::max(largest, value);
+        smallest = std::min(smallest, value);
+      }
+      columnScale[j] = overallLargest / largest;
+      double difference = colUpper[j] - colLower[j];
+      if (difference < 1.0e-5 * columnScale[j])
+        columnScale[j] = difference / 1.0e-5;  // make gap larger
+      overallSmallest = std::min(overallSmallest, smallest * columnScale[j]);
+    } else {
+      columnScale[j] = 1.0;
+    }
+  }
+  for (int i = 0; i < m; i++)
+    if (!usedRow[i])
+      rowScale[i] = 1.0;
+  if (overallSmallest < 1.0e-13)  // :4601
+    zeroTolerance = std::max(overallSmallest * 0.5, 1.0e-18);
+  return 0;
+}
+
+// a bound pair in scaled units as createRim builds it (src/ClpSimplex.cpp:3920-3980): infinities
+// stay infinite, gaps below the primal tolerance are closed
+static void scaleBoundPair(double lowerValue, double upperValue, double multiplier, double primalTolerance, double &lo, double &up)
+{
+  const double INF = 1.0e30;
+  if (lowerValue > -1.0e20) {
+    lo = lowerValue * multiplier;
+    if (upperValue >= 1.0e20) {
+      up = INF;
+    } else {
+      up = upperValue * multiplier;
+      if (fabs(up - lo) <= primalTolerance) {
+        if (lo >= 0.0)
+          up = lo;
+        else if (up <= 0.0)
+          lo = up;
+        else
+          lo = up = 0.0;
+      }
+    }
+  } else if (upperValue < 1.0e20) {
+    lo = -INF;
+    up = upperValue * multiplier;
+  } else {
+    lo = -INF;
+    up = INF;
+  }
+}
+
 int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, const double *el, const double *cl,
                                 const double *cu, const double *ob, const double *rl, const double *ru)
 {
@@ -212,6 +413,27 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   obj.assign(ob, ob + n);
   rowLower.assign(rl, rl + m);
   rowUpper.assign(ru, ru + m);
+  scaled = false;
+  if (scalingMode > 0) {
+    // ClpSimplex::createRim with scalingFlag_ > 0 (src/ClpSimplex.cpp:3682-3702, :3880-3980): factors
+    // from the caller's matrix, then everything the engine keeps is in scaled units
+    rowScale.assign(m, 1.0);
+    colScale.assign(n, 1.0);
+    if (!computeScaleFactors(m, n, colStart.data(), row.data(), elem.data(), colLower.data(), colUpper.data(), rowLower.data(),
+                             rowUpper.data(), scalingMode, primalTolerance, dualTolerance, zeroTolerance, rowScale.data(),
+                             colScale.data())) {
+      scaled = true;
+      dualToleranceBase = dualTolerance;
+      for (int j = 0; j < n; j++) {
+        for (int p = colStart[j]; p < colStart[j + 1]; p++)
+          elem[p] = elem[p] * colScale[j] * rowScale[row[p]];
+        obj[j] *= colScale[j];
+        scaleBoundPair(cl[j], cu[j], 1.0 / colScale[j], primalTolerance, colLower[j], colUpper[j]);
+      }
+      for (int i = 0; i < m; i++)
+        scaleBoundPair(rl[i], ru[i], rowScale[i], primalTolerance, rowLower[i], rowUpper[i]);
+    }
+  }
   // row copy (ClpSimplex::createRim builds rowCopy_, src/ClpSimplex.cpp:3648) with cross indices
   rowStart.assign(m + 1, 0);
   for (long p = 0; p < nnz; p++)
@@ -2281,6 +2503,11 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
     if (ctx->n > 0 && ctx->D.colStart)  // already loaded: build (or drop) the extra copy now
       return ctx->buildSellX();
   }
+  else if (!strcmp(name, "scaling")) {
+    if (ctx->n > 0 && ctx->D.colStart)
+      return -2;  // the matrix is already on the device in its current units: set before clpgpu_load_problem
+    ctx->scalingMode = (int)v;
+  }
   else if (!strcmp(name, "flip_list_cap")) { ctx->flipListCap = std::max(1, std::min((int)v, FLIP_LIST_CAP)); ctx->dropGraph(); }
   else return -1;
   return 0;
@@ -2299,33 +2526,78 @@ int clpgpu_set_status(clpgpu_context *ctx, const unsigned char *status)
 // (src/ClpModel.cpp:2669-2770): whole-array replacement, the matrix stays resident; the next
 // clpgpu_dual starts from these (and from the status given with clpgpu_set_status) -- the re-solve
 // pattern of branch and bound (ClpSimplex::dual with a warm basis).
-static int changeArray(clpgpu_context *ctx, std::vector<double> &dst, const double *src, int count, double absent)
+// (with option "scaling" the arrays arrive in the caller's units and are kept in scaled units)
+int clpgpu_chg_row_lower(clpgpu_context *ctx, const double *rowLower)
 {
   if (!ctx)
     return -99;
-  for (int i = 0; i < count; i++)
-    dst[i] = src ? src[i] : absent;
+  for (int i = 0; i < ctx->m; i++) {
+    double v = rowLower ? rowLower[i] : -1.0e30;
+    ctx->rowLower[i] = (ctx->scaled && v > -1.0e20) ? v * ctx->rowScale[i] : v;
+  }
   return 0;
-}
-int clpgpu_chg_row_lower(clpgpu_context *ctx, const double *rowLower)
-{
-  return ctx ? changeArray(ctx, ctx->rowLower, rowLower, ctx->m, -1.0e30) : -99;
 }
 int clpgpu_chg_row_upper(clpgpu_context *ctx, const double *rowUpper)
 {
-  return ctx ? changeArray(ctx, ctx->rowUpper, rowUpper, ctx->m, 1.0e30) : -99;
+  if (!ctx)
+    return -99;
+  for (int i = 0; i < ctx->m; i++) {
+    double v = rowUpper ? rowUpper[i] : 1.0e30;
+    ctx->rowUpper[i] = (ctx->scaled && v < 1.0e20) ? v * ctx->rowScale[i] : v;
+  }
+  return 0;
 }
 int clpgpu_chg_column_lower(clpgpu_context *ctx, const double *columnLower)
 {
-  return ctx ? changeArray(ctx, ctx->colLower, columnLower, ctx->n, 0.0) : -99;
+  if (!ctx)
+    return -99;
+  for (int j = 0; j < ctx->n; j++) {
+    double v = columnLower ? columnLower[j] : 0.0;
+    ctx->colLower[j] = (ctx->scaled && v > -1.0e20) ? v / ctx->colScale[j] : v;
+  }
+  return 0;
 }
 int clpgpu_chg_column_upper(clpgpu_context *ctx, const double *columnUpper)
 {
-  return ctx ? changeArray(ctx, ctx->colUpper, columnUpper, ctx->n, 1.0e30) : -99;
+  if (!ctx)
+    return -99;
+  for (int j = 0; j < ctx->n; j++) {
+    double v = columnUpper ? columnUpper[j] : 1.0e30;
+    ctx->colUpper[j] = (ctx->scaled && v < 1.0e20) ? v / ctx->colScale[j] : v;
+  }
+  return 0;
 }
 int clpgpu_chg_obj_coefficients(clpgpu_context *ctx, const double *objIn)
 {
-  return ctx ? changeArray(ctx, ctx->obj, objIn, ctx->n, 0.0) : -99;
+  if (!ctx)
+    return -99;
+  for (int j = 0; j < ctx->n; j++) {
+    double v = objIn ? objIn[j] : 0.0;
+    ctx->obj[j] = ctx->scaled ? v * ctx->colScale[j] : v;
+  }
+  return 0;
+}
+
+// ClpPackedMatrix::scale (src/ClpPackedMatrix.cpp:4120) as a stand-alone host computation: the row
+// and column factors the engine applies when the "scaling" option is set.  No context and no device
+// needed.  Returns 1 if the matrix would be left unscaled (factors all 1), 0 otherwise, -1 on bad input.
+int clpgpu_scale_factors(int numberRows, int numberColumns, const int *columnStart, const int *rowIndex, const double *element,
+                         const double *columnLower, const double *columnUpper, const double *rowLower, const double *rowUpper,
+                         int mode, double primalTolerance, double *rowScale, double *columnScale)
+{
+  if (numberRows <= 0 || numberColumns <= 0 || !columnStart || !rowIndex || !element || !rowScale || !columnScale || mode < 1 ||
+      mode > 4)
+    return -1;
+  double dualTolerance = 1.0e-7, zeroTolerance = 1.0e-13;
+  std::fill(rowScale, rowScale + numberRows, 1.0);
+  std::fill(columnScale, columnScale + numberColumns, 1.0);
+  int rc = computeScaleFactors(numberRows, numberColumns, columnStart, rowIndex, element, columnLower, columnUpper, rowLower,
+                               rowUpper, mode, primalTolerance, dualTolerance, zeroTolerance, rowScale, columnScale);
+  if (rc) {
+    std::fill(rowScale, rowScale + numberRows, 1.0);
+    std::fill(columnScale, columnScale + numberColumns, 1.0);
+  }
+  return rc;
 }
 
 int clpgpu_dual(clpgpu_context *ctx)
@@ -2355,13 +2627,27 @@ int clpgpu_get_solution(clpgpu_context *ctx, double *solution)
 {
   if (!ctx)
     return -99;
-  return ctx->d2h(solution, ctx->D.sol, ctx->N);
+  int rc = ctx->d2h(solution, ctx->D.sol, ctx->N);
+  if (!rc && ctx->scaled) {  // unscale (ClpSimplex::deleteRim, src/ClpSimplex.cpp:3376-3412)
+    for (int j = 0; j < ctx->n; j++)
+      solution[j] *= ctx->colScale[j];
+    for (int i = 0; i < ctx->m; i++)
+      solution[ctx->n + i] /= ctx->rowScale[i];
+  }
+  return rc;
 }
 int clpgpu_get_reduced_costs(clpgpu_context *ctx, double *dj)
 {
   if (!ctx)
     return -99;
-  return ctx->d2h(dj, ctx->D.dj, ctx->N);
+  int rc = ctx->d2h(dj, ctx->D.dj, ctx->N);
+  if (!rc && ctx->scaled) {
+    for (int j = 0; j < ctx->n; j++)
+      dj[j] /= ctx->colScale[j];
+    for (int i = 0; i < ctx->m; i++)
+      dj[ctx->n + i] *= ctx->rowScale[i];
+  }
+  return rc;
 }
 int clpgpu_get_status(clpgpu_context *ctx, unsigned char *status)
 {

@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "clpgpu_get_solution", "clpgpu_get_reduced_costs", "clpgpu_get_status", "clpgpu_get_pivot_variable",
     "clpgpu_get_pivot_log", "clpgpu_get_row_weights", "clpgpu_get_stats",
     "clpgpu_chg_row_lower", "clpgpu_chg_row_upper", "clpgpu_chg_column_lower", "clpgpu_chg_column_upper",
-    "clpgpu_chg_obj_coefficients",
+    "clpgpu_chg_obj_coefficients", "clpgpu_scale_factors",
 ]
 
 
@@ -94,6 +94,7 @@ def lib():
         L.clpgpu_pivots.argtypes = [p]
         L.clpgpu_set_option.argtypes = [p, C.c_char_p, C.c_double]
         L.clpgpu_set_status.argtypes = [p, up]
+        L.clpgpu_scale_factors.argtypes = [C.c_int, C.c_int, ip, ip, dp, dp, dp, dp, dp, C.c_int, C.c_double, dp, dp]
         for name in ("row_lower", "row_upper", "column_lower", "column_upper", "obj_coefficients"):
             getattr(L, "clpgpu_chg_" + name).argtypes = [p, dp]
         L.clpgpu_dual.argtypes = [p]
@@ -110,6 +111,20 @@ def lib():
         L.clpgpu_get_stats.argtypes = [p, C.POINTER(Stats)]
         _LIB = L
     return _LIB
+
+
+def scale_factors(lp, mode=3, primal_tolerance=1.0e-7):
+    """ClpPackedMatrix::scale factors as the engine computes them (host code, no GPU needed):
+    (scaled?, rowScale[m], columnScale[n])."""
+    rs, cs = np.empty(lp.m), np.empty(lp.n)
+    rc = lib().clpgpu_scale_factors(int(lp.m), int(lp.n), np.ascontiguousarray(lp.col_start, dtype=np.int32),
+                                    np.ascontiguousarray(lp.row, dtype=np.int32), np.ascontiguousarray(lp.elem, dtype=np.float64),
+                                    np.ascontiguousarray(lp.col_lower, dtype=np.float64), np.ascontiguousarray(lp.col_upper, dtype=np.float64),
+                                    np.ascontiguousarray(lp.row_lower, dtype=np.float64), np.ascontiguousarray(lp.row_upper, dtype=np.float64),
+                                    int(mode), float(primal_tolerance), rs, cs)
+    if rc < 0:
+        raise ValueError("clpgpu_scale_factors: bad input")
+    return rc == 0, rs, cs
 
 
 class ClpGpuSimplex:

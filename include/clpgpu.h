@@ -123,7 +123,10 @@ int clpgpu_pivots(const clpgpu_context *ctx);
  * 6), "use_graph", "blocked_refactor", "register_panel" (re-inversion variants), "fork_update" (basis
  * update on a second stream),
  * "flip_list_cap" (size of the bound-flip append buffer; small values force its overflow path),
- * "sell_lanes" (1; 2/4/8 = experimental pricing layout with several lanes per column, written at
+ * "scaling" (0 off; 1/2/3/4 = ClpModel::scaling modes; must be set BEFORE clpgpu_load_problem: the
+ * device then holds the scaled LP, getters return unscaled values; engine-side plumbing written at the
+ * end of round 1 and not yet run on hardware -- the factor computation is CPU-tested against the
+ * oracle), "sell_lanes" (1; 2/4/8 = experimental pricing layout with several lanes per column, written at
  * the end of round 1 and not yet run on hardware). */
 int clpgpu_set_option(clpgpu_context *ctx, const char *name, double value);
 /* Whole-array replacement of bounds / costs with the matrix left resident
@@ -136,6 +139,14 @@ int clpgpu_chg_row_upper(clpgpu_context *ctx, const double *rowUpper);
 int clpgpu_chg_column_lower(clpgpu_context *ctx, const double *columnLower);
 int clpgpu_chg_column_upper(clpgpu_context *ctx, const double *columnUpper);
 int clpgpu_chg_obj_coefficients(clpgpu_context *ctx, const double *objIn);
+/* ClpPackedMatrix::scale (src/ClpPackedMatrix.cpp:4120-4760; ClpModel::scaling modes 1 equilibrium,
+ * 2 geometric, 3/4 auto) as a stand-alone host computation: the row / column factors the engine
+ * applies when option "scaling" is set before clpgpu_load_problem.  Needs no context and no device.
+ * Returns 1 if the matrix is left unscaled (all factors 1), 0 if scaled, -1 on bad input. */
+int clpgpu_scale_factors(int numberRows, int numberColumns, const int *columnStart, const int *rowIndex,
+                         const double *element, const double *columnLower, const double *columnUpper,
+                         const double *rowLower, const double *rowUpper, int mode, double primalTolerance,
+                         double *rowScale, double *columnScale);
 /* optional warm start (ClpSimplex::statusArray) */
 int clpgpu_set_status(clpgpu_context *ctx, const unsigned char *status);
 /* ClpSimplex::dual() (src/ClpSimplex.cpp:5631 -> ClpSimplexDual::dual :637): returns problemStatus

@@ -89,3 +89,20 @@ def test_well_scaled_matrix_is_left_alone(built):
     assert o.dual() == 0
     applied, rs, cs = o.scale_factors()
     assert not applied and np.all(rs == 1.0) and np.all(cs == 1.0)
+
+
+@pytest.mark.parametrize("name", ["afiro", "sparse300", "netlib400"])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+def test_engine_scale_factors_equal_the_oracle(built, name, mode):
+    """clpgpu_scale_factors is host code in libclpgpu.so (no device needed): the factors the engine
+    applies with option "scaling" are bit-identical to the oracle's restatement of the same routine."""
+    from clp_amd.engine import scale_factors
+
+    lp = make(name)
+    applied, rs, cs = scale_factors(lp, mode)
+    o = OracleSimplex(lp)
+    o.set_option("scaling", mode)
+    assert o.dual() == 0
+    applied_o, rs_o, cs_o = o.scale_factors()
+    assert applied == applied_o is True or (applied == applied_o)
+    assert np.array_equal(rs, rs_o) and np.array_equal(cs, cs_o)
