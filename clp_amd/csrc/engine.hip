@@ -42,6 +42,9 @@ struct clpgpu_context {
   std::vector<int> colStart, row;
   std::vector<double> elem;
   std::vector<double> colLower, colUpper, obj, rowLower, rowUpper;
+  // the caller's (unscaled) arrays: what clone / set_scales reload from and what scaling reads
+  std::vector<double> origElem, origColLower, origColUpper, origObj, origRowLower, origRowUpper;
+  bool haveExternalScales = false;  // clpgpu_set_scales: factors supplied by the caller
   std::vector<int> rowStart;
   // ---- host mirrors of the rim (valid after pull())
   std::vector<double> lower, upper, cost, dj, sol, origLower, origUpper;
@@ -52,6 +55,12 @@ struct clpgpu_context {
   // ---- options / ClpSimplex scalars
   double primalTolerance = 1.0e-7, dualTolerance = 1.0e-7, dualToleranceBase = 1.0e-7, dualBound = 1.0e10;
   double zeroTolerance = 1.0e-13, acceptablePivot = 1.0e-8, largeValue = 1.0e15;
+  // the values the caller asked for (clpgpu_set_option): a scaled load may loosen the tolerances
+  // (ClpPackedMatrix::scale :4268, :4303) and a solve changes dualBound / acceptablePivot
+  // (changeBounds, the "no incoming" exit); every load / startup starts again from these, as
+  // ClpSimplex::dual does through ClpDataSave (saveData / restoreData, src/ClpSimplex.cpp:5690)
+  double optPrimalTolerance = 1.0e-7, optDualTolerance = 1.0e-7, optZeroTolerance = 1.0e-13, optDualBound = 1.0e10,
+         optAcceptablePivot = 1.0e-8;
   int maximumIterations = 2147483647, pivotRule = 1, maximumPivots = 200, logLevel = 0, checkEvery = 1;
   unsigned int seed = 1234567u;
   int timing = 0;
@@ -170,6 +179,9 @@ struct clpgpu_context {
 
   int loadProblem(int m_, int n_, const int *cs, const int *ri, const double *el, const double *cl, const double *cu,
                   const double *ob, const double *rl, const double *ru);
+  void releaseProblem();
+  void applyShard();
+  int checkLaunches(const char *where);
   int allocNucleus(int kNeeded);
   int buildSell();
   void dropGraph();
@@ -180,6 +192,9 @@ struct clpgpu_context {
   int startup();
   int factorize();
   int ftranDevice(const double *vRow, double *xPos);
+  int ftranDevice2(const double *v1Row, const double *v2Row, double *x1Pos, double *x2Pos);
+  void preparePlugin();
+  bool rejectScaled(const char *what);
   int btranDevice(const double *cPos, double *yRow);
   int gutsOfSolution();
   void checkPrimalSolution();
@@ -401,20 +416,49 @@ static void scaleBoundPair(double lowerValue, double upperValue, double multipli
 int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, const double *el, const double *cl,
                                 const double *cu, const double *ob, const double *rl, const double *ru)
 {
+  // a second load on the same context (ClpSimplex::loadProblem on a live model) starts from scratch:
+  // the inputs are copied first, they may be this context's own host copies (clone, set_scales)
+  {
+    const long nz = cs[n_];
+    std::vector<int> cs2(cs, cs + n_ + 1), ri2(ri, ri + nz);
+    std::vector<double> el2(el, el + nz), cl2(cl, cl + n_), cu2(cu, cu + n_), ob2(ob, ob + n_), rl2(rl, rl + m_), ru2(ru, ru + m_);
+    releaseProblem();
+    colStart.swap(cs2);
+    row.swap(ri2);
+    elem.swap(el2);
+    colLower.swap(cl2);
+    colUpper.swap(cu2);
+    obj.swap(ob2);
+    rowLower.swap(rl2);
+    rowUpper.swap(ru2);
+  }
   m = m_;
   n = n_;
   N = m + n;
-  nnz = cs[n];
-  colStart.assign(cs, cs + n + 1);
-  row.assign(ri, ri + nnz);
-  elem.assign(el, el + nnz);
-  colLower.assign(cl, cl + n);
-  colUpper.assign(cu, cu + n);
-  obj.assign(ob, ob + n);
-  rowLower.assign(rl, rl + m);
-  rowUpper.assign(ru, ru + m);
+  nnz = colStart[n];
+  origElem = elem;
+  origColLower = colLower;
+  origColUpper = colUpper;
+  origObj = obj;
+  origRowLower = rowLower;
+  origRowUpper = rowUpper;
+  cl = origColLower.data();
+  cu = origColUpper.data();
+  rl = origRowLower.data();
+  ru = origRowUpper.data();
   scaled = false;
-  if (scalingMode > 0) {
+  if (haveExternalScales) {
+    // clpgpu_set_scales: the caller's factors (Clp's own rowScale_ / columnScale_) instead of computed ones
+    scaled = true;
+    for (int j = 0; j < n; j++) {
+      for (int p = colStart[j]; p < colStart[j + 1]; p++)
+        elem[p] = elem[p] * colScale[j] * rowScale[row[p]];
+      obj[j] *= colScale[j];
+      scaleBoundPair(cl[j], cu[j], 1.0 / colScale[j], primalTolerance, colLower[j], colUpper[j]);
+    }
+    for (int i = 0; i < m; i++)
+      scaleBoundPair(rl[i], ru[i], rowScale[i], primalTolerance, rowLower[i], rowUpper[i]);
+  } else if (scalingMode > 0) {
     // ClpSimplex::createRim with scalingFlag_ > 0 (src/ClpSimplex.cpp:3682-3702, :3880-3980): factors
     // from the caller's matrix, then everything the engine keeps is in scaled units
     rowScale.assign(m, 1.0);
@@ -571,11 +615,76 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
     return -99;
   }
   memset(hCtrl, 0, sizeof(Ctrl));
+  hCtrl->pivotRow = hCtrl->sequenceIn = hCtrl->sequenceOut = -1;  // model_->pivotRow() before the first pivot
+  if (commActive)
+    applyShard();  // a reload keeps the communicator; the shard follows the new column count
   rc |= buildSell();
   rc |= buildSellX();
   rc |= sync();
   started = false;
   return rc;
+}
+
+// Everything a load creates is dropped again: device allocations, the pinned control block, the
+// captured graph, the solve state.  Options set through clpgpu_set_option survive, so does the
+// communicator.
+void clpgpu_context::releaseProblem()
+{
+  if (stream)
+    (void)hipStreamSynchronize(stream);
+  dropGraph();
+  for (void *p : allocations)
+    (void)hipFree(p);
+  allocations.clear();
+  if (hCtrl)
+    (void)hipHostFree(hCtrl);
+  hCtrl = nullptr;
+  memset(&D, 0, sizeof(D));
+  kcap = ld = 0;
+  logCapacity = 0;
+  dKcol = dLocalOfRow = dInfo = nullptr;
+  nLongBlocks = nSellBlocks = nChzBlocks = nSxBlocks = 0;
+  weightsInitialized = false;
+  haveStatus = false;
+  userStatus.clear();
+  started = false;
+  needStatus = true;
+  rebuildRowCopy = true;
+  problemStatus = -1;
+  numberIterations = numberRefactorizations = 0;
+  pivots = kNucleus = 0;
+  objectiveValue = 0.0;
+  primalTolerance = optPrimalTolerance;
+  dualTolerance = dualToleranceBase = optDualTolerance;
+  zeroTolerance = optZeroTolerance;
+  dualBound = optDualBound;
+  acceptablePivot = optAcceptablePivot;
+  scaled = false;
+}
+
+// equal, 256-aligned column shards so that rank-major concatenation is the by-column order
+// (ABOCA_LITE chunking, src/ClpPackedMatrix.cpp:1823-1854); clp_amd/sharding.py mirrors the formula
+void clpgpu_context::applyShard()
+{
+  int chunk = (n + nranks - 1) / nranks;
+  chunk = (chunk + PRICE_BLOCK - 1) / PRICE_BLOCK * PRICE_BLOCK;
+  shardChunk = chunk;
+  D.firstColumn = 0;
+  D.lastColumn = n;
+  D.priceFirst = std::min(rank * chunk, n);
+  D.priceLast = std::min((rank + 1) * chunk, n);
+}
+
+// launch errors (bad extents, missing code object) are sticky until read: surface them where the
+// launches were issued instead of at the next blocking call
+int clpgpu_context::checkLaunches(const char *where)
+{
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    setError("kernel launch failed in %s: %s", where, hipGetErrorString(e));
+    return -99;
+  }
+  return 0;
 }
 
 // Sliced-ELL copy of the priced column range (the coalescing-friendly layout of SURVEY.md 8f.2,
@@ -890,8 +999,12 @@ int clpgpu_context::factorize()
     int zero4[4] = { 0, 0, 0, 0 };
     rc |= h2d(dInfo, zero4, 4);
     size_t mat = (size_t)k * ld;
-    hipLaunchKernelGGL(k_zero, dim3(cdiv((int)mat, 256)), dim3(256), 0, stream, D.workW, (int)mat);
-    hipLaunchKernelGGL(k_zero, dim3(cdiv((int)mat, 256)), dim3(256), 0, stream, D.workX, (int)mat);
+    // (byte counts are size_t: k * ld passes 2^31 doubles' worth of bytes long before it passes INT_MAX entries)
+    if (hipMemsetAsync(D.workW, 0, mat * sizeof(double), stream) != hipSuccess ||
+        hipMemsetAsync(D.workX, 0, mat * sizeof(double), stream) != hipSuccess) {
+      setError("factorize: clearing the work matrices failed");
+      return -99;
+    }
     hipLaunchKernelGGL(k_gather_nucleus, dim3(k), dim3(64), 0, stream, D, dKcol, dLocalOfRow, k);
     hipLaunchKernelGGL(k_identity, dim3(cdiv(k, 256)), dim3(256), 0, stream, D, k);
     dim3 g2(cdiv(k, 256), k < 1024 ? k : 1024);
@@ -923,6 +1036,8 @@ int clpgpu_context::factorize()
       }
     }
     hipLaunchKernelGGL(k_gj_finish, g2, dim3(256), 0, stream, D, k);
+    if (checkLaunches("factorize"))
+      return -99;
     int info[4];
     rc |= d2h(info, dInfo, 4);
     if (rc)
@@ -1020,6 +1135,58 @@ int clpgpu_context::btranDevice(const double *cPos, double *yRow)
     hipLaunchKernelGGL(k_gemvT_final, dim3(cdiv(k, 256)), dim3(256), 0, stream, D, yRow, 0, 0);
   }
   return 0;
+}
+
+// two right-hand sides in one sweep (updateTwoColumnsFT, src/ClpFactorization.cpp:2889)
+int clpgpu_context::ftranDevice2(const double *v1Row, const double *v2Row, double *x1Pos, double *x2Pos)
+{
+  const int k = hCtrl->k;
+  if (k) {
+    hipLaunchKernelGGL(k_ftran_gather, dim3(cdiv(k, 256)), dim3(256), 0, stream, D, v1Row, v2Row, D.slotA, D.slotB, 0);
+    hipLaunchKernelGGL(k_gemv2, dim3(cdiv(k, 4)), dim3(256), 0, stream, D, (const double *)D.slotA, (const double *)D.slotB, D.slotC,
+                       D.slotD, 0);
+  }
+  hipLaunchKernelGGL(k_ftran_scatter, dim3(cdiv(m + k, 256)), dim3(256), 0, stream, D, v1Row, v2Row, (const double *)D.slotC,
+                     (const double *)D.slotD, x1Pos, x2Pos, 0);
+  return 0;
+}
+
+// plug-in level calls run single kernels of the iteration chain outside clpgpu_dual: the control block
+// must hold the scalars those kernels read (a context that never ran startup() has them at zero)
+void clpgpu_context::preparePlugin()
+{
+  Ctrl *h = hCtrl;
+  h->state = RUN;
+  h->stepLimit = -1;
+  h->pivotRule = pivotRule;
+  h->primalTolerance = primalTolerance;
+  h->dualTolerance = dualTolerance;
+  if (!h->zeroTolerance)
+    h->zeroTolerance = zeroTolerance;
+  h->dualBound = dualBound;
+  h->largeValue = largeValue;
+  h->largestPrimalError = largestPrimalError;
+  h->largestDualError = largestDualError;
+  h->maximumPivots = maximumPivots;
+  h->maximumIterations = 2147483647;
+  h->lastBadIteration = lastBadIteration;
+  h->acceptablePivotBase = acceptablePivot;
+  h->kcap = kcap;
+  if (!started) {
+    h->seed = seed;
+    h->logCapacity = 0;
+  }
+}
+
+// the plug-in calls take and return vectors in the caller's units; a context that scales internally
+// (option "scaling" / clpgpu_set_scales) holds a different matrix, so they are refused there rather
+// than answered in the wrong units (a Clp adapter passes its scaledMatrix_ as the problem instead)
+bool clpgpu_context::rejectScaled(const char *what)
+{
+  if (!scaled)
+    return false;
+  setError("%s: not available on a context that scales internally (plug-in calls work in the caller's units)", what);
+  return true;
 }
 
 // ClpSimplex::gutsOfSolution (src/ClpSimplex.cpp:574): computePrimals :914, computeDuals :1164 on
@@ -1336,6 +1503,15 @@ int clpgpu_context::saveWeights(int mode)
   if (mode == 2 || mode == 4) {
     hipLaunchKernelGGL(k_weights_from_seq, dim3(g), dim3(256), 0, stream, D, weightsInitialized ? 0 : 1);
     weightsInitialized = true;
+  } else if (mode == 5 || mode == 7) {
+    // strong branching entry (:786, :815-822): weights start again at 1.0 (the default steepest mode
+    // 3 does not compute full norms here, `mode_ != 1`), infeasibilities rebuilt below
+    hipLaunchKernelGGL(k_fill, dim3(g), dim3(256), 0, stream, D.weights, 1.0, m);
+    weightsInitialized = true;
+  } else if (mode == 6) {
+    // scale back the weights as the primal error grows (:937-957)
+    double allowed = largestPrimalError > 1.0e3 ? 10.0 : (largestPrimalError > 1.0e2 ? 50.0 : (largestPrimalError > 1.0e1 ? 100.0 : 1000.0));
+    hipLaunchKernelGGL(k_weights_scale_back, dim3(g), dim3(256), 0, stream, D, allowed);
   }
   // rebuild the list in ascending position order
   hCtrl->numberInfeasible = 0;
@@ -1422,6 +1598,11 @@ int clpgpu_context::startup()
   largestPrimalError = largestDualError = 0.0;
   objectiveValue = 0.0;
   dualTolerance = dualToleranceBase;
+  // a previous solve on this context may have left 5 x dualBound (changeBounds) or a relaxed
+  // acceptablePivot (the "no incoming" exit): every dual() starts from the caller's values, the
+  // effect of ClpDataSave around ClpSimplex::dual (src/ClpSimplex.cpp:5690-5697, :5918)
+  dualBound = optDualBound;
+  acceptablePivot = optAcceptablePivot;
   memset(&stats, 0, sizeof(stats));
   if (logCapacity < 65536) {
     logCapacity = 1 << 20;
@@ -1774,7 +1955,7 @@ int clpgpu_context::launchBatch()
     for (int b = 0; b < checkEvery; b++)
       launchIteration(b == 0, b & 1);
     joinUpdateBranch();
-    return 0;
+    return checkLaunches("launchIteration");
   }
   if (!graphExec || graphIterations != checkEvery) {
     dropGraph();
@@ -1798,7 +1979,7 @@ int clpgpu_context::launchBatch()
       for (int b = 0; b < checkEvery; b++)
         launchIteration(b == 0, b & 1);
       joinUpdateBranch();
-      return 0;
+      return checkLaunches("launchIteration");
     }
     graphIterations = checkEvery;
   }
@@ -2073,11 +2254,17 @@ int clpgpu_context::priceRow(int numberPi, const int *piIndex, const double *piV
   rc |= h2d(D.piNeg, piNeg.data(), m);
   rc |= h2d(D.status, st, N);
   rc |= h2d(D.dj, djv, N);
-  memset(hCtrl, 0, sizeof(Ctrl));
+  // only the scalars the pricing kernels read are set; the factorization state kept in the control
+  // block (k, kcap, pivots, zeroTolerance: a ClpGpuPackedMatrix and a CoinGpuFactorization adapter
+  // share one context) is left alone and the borrowed fields are put back afterwards
+  const int saveState = hCtrl->state;
+  const double saveDualTol = hCtrl->dualTolerance, saveZeroTol = hCtrl->zeroTolerance, saveAcc = hCtrl->acceptablePivot;
   hCtrl->state = RUN;
   hCtrl->dualTolerance = dualTol;
   hCtrl->zeroTolerance = zeroTol;
   hCtrl->acceptablePivot = accPivot;
+  hCtrl->numberCandidates = 0;
+  hCtrl->upperTheta = 1.0e31;
   rc |= pushCtrl();
   const int nbRows = cdiv(m, PRICE_BLOCK);
   const int nbCols = cdiv(D.lastColumn - D.firstColumn, PRICE_BLOCK);
@@ -2111,6 +2298,11 @@ int clpgpu_context::priceRow(int numberPi, const int *piIndex, const double *piV
   // leave the work vectors clean
   hipLaunchKernelGGL(k_zero, dim3(cdiv(m, 256)), dim3(256), 0, stream, D.rho, m);
   hipLaunchKernelGGL(k_zero, dim3(cdiv(m, 256)), dim3(256), 0, stream, D.piNeg, m);
+  hCtrl->state = saveState;
+  hCtrl->dualTolerance = saveDualTol;
+  hCtrl->zeroTolerance = saveZeroTol;
+  hCtrl->acceptablePivot = saveAcc;
+  rc |= pushCtrl();
   rc |= sync();
   return rc;
 }
@@ -2202,8 +2394,10 @@ int clpgpu_set_column_range(clpgpu_context *ctx, int firstColumn, int lastColumn
 
 int clpgpu_times(clpgpu_context *ctx, double scalar, const double *x, double *y)
 {
-  if (!ctx)
+  if (!ctx || !ctx->hCtrl)
     return -99;
+  if (ctx->rejectScaled("clpgpu_times"))
+    return -3;
   // needs the row copy in its load-time state or any partition: order inside a row does not matter
   int rc = 0;
   rc |= ctx->h2d(ctx->D.alphaCol, x, ctx->n);
@@ -2219,8 +2413,10 @@ int clpgpu_times(clpgpu_context *ctx, double scalar, const double *x, double *y)
 
 int clpgpu_transpose_times(clpgpu_context *ctx, double scalar, const double *x, double *y)
 {
-  if (!ctx)
+  if (!ctx || !ctx->hCtrl)
     return -99;
+  if (ctx->rejectScaled("clpgpu_transpose_times"))
+    return -3;
   int rc = 0;
   rc |= ctx->h2d(ctx->D.x3, x, ctx->m);
   rc |= ctx->h2d(ctx->D.alphaCol, y, ctx->n);
@@ -2238,16 +2434,20 @@ int clpgpu_price_row(clpgpu_context *ctx, int numberPi, const int *piIndex, cons
                      int *outIndex, double *outValue, int *numberCandidates, int *candIndex, double *candValue,
                      double *upperTheta)
 {
-  if (!ctx)
+  if (!ctx || !ctx->hCtrl)
     return -99;
+  if (ctx->rejectScaled("clpgpu_price_row"))
+    return -3;
   return ctx->priceRow(numberPi, piIndex, piValue, status, dj, zeroTolerance, dualTolerance, acceptablePivot, numberOut, outIndex,
                        outValue, numberCandidates, candIndex, candValue, upperTheta);
 }
 
 int clpgpu_factorize(clpgpu_context *ctx, const unsigned char *status, int *pivotVariable)
 {
-  if (!ctx)
+  if (!ctx || !ctx->hCtrl)
     return -99;
+  if (ctx->rejectScaled("clpgpu_factorize"))
+    return -3;
   ctx->status.assign(status, status + ctx->N);
   ctx->rebuildRowCopy = true;
   if (!ctx->hCtrl->zeroTolerance)
@@ -2267,8 +2467,10 @@ int clpgpu_factorize(clpgpu_context *ctx, const unsigned char *status, int *pivo
 
 int clpgpu_ftran(clpgpu_context *ctx, double *region)
 {
-  if (!ctx)
+  if (!ctx || !ctx->hCtrl)
     return -99;
+  if (ctx->rejectScaled("clpgpu_ftran"))
+    return -3;
   int rc = ctx->h2d(ctx->D.vecV2, region, ctx->m);
   ctx->ftranDevice(ctx->D.vecV2, ctx->D.x3);
   rc |= ctx->d2h(region, ctx->D.x3, ctx->m);
@@ -2280,8 +2482,10 @@ int clpgpu_ftran(clpgpu_context *ctx, double *region)
 
 int clpgpu_btran(clpgpu_context *ctx, double *region)
 {
-  if (!ctx)
+  if (!ctx || !ctx->hCtrl)
     return -99;
+  if (ctx->rejectScaled("clpgpu_btran"))
+    return -3;
   int rc = ctx->h2d(ctx->D.tau, region, ctx->m);
   ctx->btranDevice(ctx->D.tau, ctx->D.vecV2);
   rc |= ctx->d2h(region, ctx->D.vecV2, ctx->m);
@@ -2296,8 +2500,10 @@ int clpgpu_btran(clpgpu_context *ctx, double *region)
 // vectors it already holds; this standalone form keeps the C ABI to PODs).
 int clpgpu_replace_column(clpgpu_context *ctx, int pivotRow, int sequenceIn, double pivotCheck, double acceptablePivot)
 {
-  if (!ctx)
+  if (!ctx || !ctx->hCtrl)
     return -99;
+  if (ctx->rejectScaled("clpgpu_replace_column"))
+    return -3;
   (void)pivotCheck;
   (void)acceptablePivot;
   const int m = ctx->m, n = ctx->n;
@@ -2387,7 +2593,314 @@ int clpgpu_replace_column(clpgpu_context *ctx, int pivotRow, int sequenceIn, dou
   return rc ? rc : 0;
 }
 
-int clpgpu_pivots(const clpgpu_context *ctx) { return ctx ? ctx->hCtrl->pivots : 0; }
+int clpgpu_pivots(const clpgpu_context *ctx) { return (ctx && ctx->hCtrl) ? ctx->hCtrl->pivots : 0; }
+
+// ---- ClpFactorization::updateColumnFT / updateTwoColumnsFT (src/ClpFactorization.cpp:2723, :2889) ----
+// With the explicit nucleus inverse there is no Forrest-Tomlin stash to fill: the "FT" solve is the
+// plain FTRAN, and its result stays on the device (D.w) as the updated column the following
+// clpgpu_update_weights / clpgpu_replace_column refer to.  Returns the number of nonzeros like the
+// reference (a negative value there means "no room in the R area": never the case here).
+int clpgpu_ftran_ft(clpgpu_context *ctx, double *region)
+{
+  if (!ctx || !ctx->hCtrl)
+    return -99;
+  if (ctx->rejectScaled("clpgpu_ftran_ft"))
+    return -3;
+  const int m = ctx->m;
+  int rc = ctx->h2d(ctx->D.vecV2, region, m);
+  ctx->ftranDevice(ctx->D.vecV2, ctx->D.w);
+  rc |= ctx->d2h(region, ctx->D.w, m);
+  hipLaunchKernelGGL(k_zero, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, ctx->D.vecV2, m);
+  rc |= ctx->checkLaunches("clpgpu_ftran_ft");
+  rc |= ctx->sync();
+  if (rc)
+    return -99;
+  int count = 0;
+  for (int i = 0; i < m; i++)
+    count += region[i] != 0.0;
+  return count;
+}
+
+// both right-hand sides in one sweep over the nucleus inverse (k_gemv2 carries two vectors):
+// regionFT = the entering column (kept on the device as the updated column), region2 = the DSE vector
+int clpgpu_ftran_two_ft(clpgpu_context *ctx, double *regionFT, double *region2)
+{
+  if (!ctx || !ctx->hCtrl)
+    return -99;
+  if (ctx->rejectScaled("clpgpu_ftran_two_ft"))
+    return -3;
+  const int m = ctx->m;
+  int rc = ctx->h2d(ctx->D.vecV1, regionFT, m);
+  rc |= ctx->h2d(ctx->D.vecV2, region2, m);
+  ctx->ftranDevice2(ctx->D.vecV1, ctx->D.vecV2, ctx->D.w, ctx->D.tau);
+  rc |= ctx->d2h(regionFT, ctx->D.w, m);
+  rc |= ctx->d2h(region2, ctx->D.tau, m);
+  hipLaunchKernelGGL(k_zero, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, ctx->D.vecV1, m);
+  hipLaunchKernelGGL(k_zero, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, ctx->D.vecV2, m);
+  hipLaunchKernelGGL(k_zero, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, ctx->D.tau, m);
+  rc |= ctx->checkLaunches("clpgpu_ftran_two_ft");
+  rc |= ctx->sync();
+  if (rc)
+    return -99;
+  int count = 0;
+  for (int i = 0; i < m; i++)
+    count += regionFT[i] != 0.0;
+  return count;
+}
+
+// ---- ClpDualRowPivot surface (src/ClpDualRowPivot.hpp:30-76; ClpDualRowSteepest.cpp / ClpDualRowDantzig.cpp) ----
+// The rim arrays are Clp's (host); clpgpu_bind_rim copies the ones given into the engine's device
+// mirrors -- the "host mirrors synced at refactorization boundaries" contract of SURVEY 8b.
+int clpgpu_bind_rim(clpgpu_context *ctx, const double *cost, const double *lower, const double *upper, const double *dj,
+                    const double *solution, const unsigned char *status)
+{
+  if (!ctx || !ctx->hCtrl)
+    return -99;
+  const int N = ctx->N;
+  int rc = 0;
+  if (cost) {
+    ctx->cost.assign(cost, cost + N);
+    rc |= ctx->h2d(ctx->D.cost, cost, N);
+  }
+  if (lower) {
+    ctx->lower.assign(lower, lower + N);
+    rc |= ctx->h2d(ctx->D.lower, lower, N);
+  }
+  if (upper) {
+    ctx->upper.assign(upper, upper + N);
+    rc |= ctx->h2d(ctx->D.upper, upper, N);
+  }
+  if (dj) {
+    ctx->dj.assign(dj, dj + N);
+    rc |= ctx->h2d(ctx->D.dj, dj, N);
+  }
+  if (solution) {
+    ctx->sol.assign(solution, solution + N);
+    rc |= ctx->h2d(ctx->D.sol, solution, N);
+  }
+  if (status) {
+    ctx->status.assign(status, status + N);
+    rc |= ctx->h2d(ctx->D.status, status, N);
+  }
+  rc |= ctx->sync();
+  return rc;
+}
+
+// ClpDualRowPivot::pivotRow (ClpDualRowSteepest.cpp:179, ClpDualRowDantzig.cpp:56): the leaving row on
+// the current device state (bound rim, factorization's pivotVariable, weights and infeasibility list
+// from clpgpu_save_weights), or -1 when nothing is primal infeasible ("looks optimal").
+int clpgpu_pivot_row(clpgpu_context *ctx)
+{
+  if (!ctx || !ctx->hCtrl)
+    return -99;
+  ctx->preparePlugin();
+  Ctrl *h = ctx->hCtrl;
+  h->preDone = 0;
+  if (ctx->pushCtrl())
+    return -99;
+  Dev &D = ctx->D;
+  hipStream_t s = ctx->stream;
+  hipLaunchKernelGGL(k_chuzr_pre, dim3(1), dim3(64), 0, s, D);
+  hipLaunchKernelGGL(k_chuzr_scan, dim3(ctx->nChzBlocks), dim3(256), 0, s, D, -1);
+  hipLaunchKernelGGL(k_chuzr_final_btran, dim3(1), dim3(256), 0, s, D, ctx->nChzBlocks, 0);
+  // the final stage also stages the BTRAN unit vector of the engine's own loop: not wanted here
+  hipLaunchKernelGGL(k_zero, dim3(cdiv(ctx->m, 256)), dim3(256), 0, s, D.vecC, ctx->m);
+  if (ctx->checkLaunches("clpgpu_pivot_row") || ctx->pullCtrl())
+    return -99;
+  const int row = h->state == EXIT_NO_PIVOT_ROW ? -1 : h->pivotRow;
+  ctx->seed = h->seed;
+  h->state = RUN;
+  return row;
+}
+
+// ClpDualRowSteepest::updateWeights (:375-624): FTRAN of the entering column (the FT solve) and of pi
+// in one sweep, alpha = w[pivotRow], DSE weights updated on the support of w with the ratio test's
+// alpha (`model_->alpha()`, :509-516); old weights kept for clpgpu_unroll_weights.  updatedColumn (m
+// doubles, by basis position) receives w; the Dantzig rule only does the solve.
+int clpgpu_update_weights(clpgpu_context *ctx, int numberPi, const int *piIndex, const double *piValue, int pivotRow,
+                          int sequenceIn, double modelAlpha, double *updatedColumn, double *alphaOut)
+{
+  if (!ctx || !ctx->hCtrl || pivotRow < 0 || pivotRow >= ctx->m || sequenceIn < 0 || sequenceIn >= ctx->N)
+    return -99;
+  if (ctx->rejectScaled("clpgpu_update_weights"))
+    return -3;
+  ctx->preparePlugin();
+  const int m = ctx->m, n = ctx->n, g = cdiv(m, 256);
+  std::vector<double> pi(m, 0.0), col(m, 0.0);
+  for (int i = 0; i < numberPi; i++)
+    pi[piIndex[i]] = piValue[i];
+  if (sequenceIn >= n)
+    col[sequenceIn - n] = -1.0;
+  else
+    for (int p = ctx->colStart[sequenceIn]; p < ctx->colStart[sequenceIn + 1]; p++)
+      col[ctx->row[p]] = ctx->elem[p];
+  Dev &D = ctx->D;
+  hipStream_t s = ctx->stream;
+  int rc = ctx->h2d(D.vecV1, col.data(), m);
+  rc |= ctx->h2d(D.vecV2, pi.data(), m);
+  ctx->ftranDevice2(D.vecV1, D.vecV2, D.w, D.tau);
+  if (ctx->pivotRule) {
+    hipLaunchKernelGGL(k_plugin_norm, dim3(g), dim3(256), 0, s, D, (const double *)D.vecV2);
+    hipLaunchKernelGGL(k_plugin_weights, dim3(g), dim3(256), 0, s, D, pivotRow, modelAlpha, g);
+  }
+  hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, s, D.vecV1, m);
+  hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, s, D.vecV2, m);
+  hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, s, D.tau, m);
+  rc |= ctx->checkLaunches("clpgpu_update_weights");
+  std::vector<double> w(m);
+  rc |= ctx->d2h(w.data(), D.w, m);
+  if (rc)
+    return -99;
+  if (updatedColumn)
+    memcpy(updatedColumn, w.data(), sizeof(double) * (size_t)m);
+  if (alphaOut)
+    *alphaOut = w[pivotRow];
+  ctx->hCtrl->pivotRow = pivotRow;
+  return 0;
+}
+
+// ClpDualRowSteepest::updatePrimalSolution (:630-763): x_B -= theta * w over the support of the
+// updated column (the one clpgpu_update_weights / clpgpu_ftran_ft left on the device, or the one given),
+// squared infeasibilities refreshed, new entries appended to the list in position order; the row
+// given as pivotRow keeps a tiny entry (:705).  *changeInObjective += the objective change.
+int clpgpu_update_primal(clpgpu_context *ctx, const double *updatedColumn, int pivotRow, double theta, double *changeInObjective)
+{
+  if (!ctx || !ctx->hCtrl)
+    return -99;
+  ctx->preparePlugin();
+  const int m = ctx->m, g = cdiv(m, 256);
+  Dev &D = ctx->D;
+  hipStream_t s = ctx->stream;
+  Ctrl *h = ctx->hCtrl;
+  int rc = 0;
+  if (updatedColumn)
+    rc |= ctx->h2d(D.w, updatedColumn, m);
+  h->movement = theta;
+  h->numberFlips = 0;
+  h->pivotRow = pivotRow;
+  h->objectiveChange = 0.0;
+  h->numberAppend = 0;
+  rc |= ctx->pushCtrl();
+  hipLaunchKernelGGL(k_primal_update, dim3(g), dim3(256), 0, s, D, 0);
+  hipLaunchKernelGGL(k_append_scatter_abs, dim3(g), dim3(256), 0, s, D);
+  rc |= ctx->checkLaunches("clpgpu_update_primal");
+  rc |= ctx->pullCtrl();
+  if (rc)
+    return -99;
+  if (changeInObjective)
+    *changeInObjective += h->objectiveChange;
+  h->appendGo = 0;
+  h->numberAppend = 0;
+  return ctx->pushCtrl();
+}
+
+// ClpDualRowSteepest::saveWeights (:773-1014), modes 1-7
+int clpgpu_save_weights(clpgpu_context *ctx, int mode)
+{
+  if (!ctx || !ctx->hCtrl || mode < 1 || mode > 7)
+    return -99;
+  ctx->preparePlugin();
+  if (ctx->pushCtrl())
+    return -99;
+  int rc = ctx->saveWeights(mode);
+  rc |= ctx->checkLaunches("clpgpu_save_weights");
+  return rc;
+}
+
+// ClpDualRowSteepest::unrollWeights (:1022-1042): undo the last clpgpu_update_weights
+int clpgpu_unroll_weights(clpgpu_context *ctx)
+{
+  if (!ctx || !ctx->hCtrl)
+    return -99;
+  hipLaunchKernelGGL(k_unroll_weights, dim3(cdiv(ctx->m, 256)), dim3(256), 0, ctx->stream, ctx->D);
+  int rc = ctx->checkLaunches("clpgpu_unroll_weights");
+  rc |= ctx->sync();
+  return rc;
+}
+
+// ---- clone / external scales ------------------------------------------------------------------------
+// ClpMatrixBase::clone / ClpDualRowPivot::clone / CoinOtherFactorization::clone: Clp copies models and
+// their plug-ins freely (SURVEY 8b "copy/presolve caveat").  A clone is an independent context on the
+// same device holding the same problem, options, bounds/costs as changed so far and warm-start status;
+// the factorization is not copied (the first factorize / dual of the clone rebuilds it).
+clpgpu_context *clpgpu_clone(const clpgpu_context *src)
+{
+  if (!src)
+    return nullptr;
+  clpgpu_context *ctx = clpgpu_create(src->device);
+  if (!ctx)
+    return nullptr;
+  ctx->optPrimalTolerance = src->optPrimalTolerance;
+  ctx->optDualTolerance = src->optDualTolerance;
+  ctx->optZeroTolerance = src->optZeroTolerance;
+  ctx->optDualBound = src->optDualBound;
+  ctx->optAcceptablePivot = src->optAcceptablePivot;
+  ctx->largeValue = src->largeValue;
+  ctx->maximumIterations = src->maximumIterations;
+  ctx->pivotRule = src->pivotRule;
+  ctx->maximumPivots = src->maximumPivots;
+  ctx->logLevel = src->logLevel;
+  ctx->checkEvery = src->checkEvery;
+  ctx->seed = src->seed;
+  ctx->priceKernel = src->priceKernel;
+  ctx->useGraph = src->useGraph;
+  ctx->blockedRefactor = src->blockedRefactor;
+  ctx->registerPanel = src->registerPanel;
+  ctx->sellLanes = src->sellLanes;
+  ctx->scalingMode = src->scalingMode;
+  ctx->flipListCap = src->flipListCap;
+  ctx->haveExternalScales = src->haveExternalScales;
+  if (src->haveExternalScales) {
+    ctx->rowScale = src->rowScale;
+    ctx->colScale = src->colScale;
+  }
+  if (src->n > 0 && !src->colStart.empty()) {
+    int rc = ctx->loadProblem(src->m, src->n, src->colStart.data(), src->row.data(), src->origElem.data(), src->origColLower.data(),
+                              src->origColUpper.data(), src->origObj.data(), src->origRowLower.data(), src->origRowUpper.data());
+    if (rc) {
+      clpgpu_destroy(ctx);
+      return nullptr;
+    }
+    if (src->haveStatus) {
+      ctx->userStatus = src->userStatus;
+      ctx->haveStatus = true;
+    }
+  }
+  return ctx;
+}
+
+// ClpModel::rowScale_/columnScale_ handed over by the caller (SURVEY 8b clpgpu_set_scales): the engine
+// then keeps the LP in those units instead of computing factors itself (option "scaling").  NULL, NULL
+// drops them.  A loaded problem is rebuilt from the caller's original arrays.
+int clpgpu_set_scales(clpgpu_context *ctx, const double *rowScale, const double *columnScale)
+{
+  if (!ctx)
+    return -99;
+  if ((rowScale == nullptr) != (columnScale == nullptr))
+    return -1;
+  if (!rowScale) {
+    ctx->haveExternalScales = false;
+  } else {
+    if (ctx->n <= 0 || ctx->colStart.empty())
+      return -2;  // sizes come from the loaded problem: load first, then hand over the factors
+    for (int i = 0; i < ctx->m; i++)
+      if (!(rowScale[i] > 0.0))
+        return -1;
+    for (int j = 0; j < ctx->n; j++)
+      if (!(columnScale[j] > 0.0))
+        return -1;
+    ctx->rowScale.assign(rowScale, rowScale + ctx->m);
+    ctx->colScale.assign(columnScale, columnScale + ctx->n);
+    ctx->haveExternalScales = true;
+  }
+  if (ctx->n > 0 && !ctx->colStart.empty()) {
+    // (loadProblem copies its inputs before it releases anything, so passing the context's own arrays is fine)
+    int rc = ctx->loadProblem(ctx->m, ctx->n, ctx->colStart.data(), ctx->row.data(), ctx->origElem.data(), ctx->origColLower.data(),
+                              ctx->origColUpper.data(), ctx->origObj.data(), ctx->origRowLower.data(), ctx->origRowUpper.data());
+    return rc;
+  }
+  return 0;
+}
 
 // ---- multi-GPU: RCCL communicator for the column-sharded pricing exchange -------------------
 static void *rcclHandle()
@@ -2440,17 +2953,10 @@ int clpgpu_comm_init(clpgpu_context *ctx, int rank, int nranks, const void *id12
     ctx->comm = nullptr;
     return -1;
   }
-  // equal, 256-aligned shards so the in-place all-gather needs no displacements
-  int chunk = (ctx->n + nranks - 1) / nranks;
-  chunk = (chunk + PRICE_BLOCK - 1) / PRICE_BLOCK * PRICE_BLOCK;
   ctx->rank = rank;
   ctx->nranks = nranks;
   ctx->commActive = true;
-  ctx->shardChunk = chunk;
-  ctx->D.firstColumn = 0;
-  ctx->D.lastColumn = ctx->n;
-  ctx->D.priceFirst = std::min(rank * chunk, ctx->n);
-  ctx->D.priceLast = std::min((rank + 1) * chunk, ctx->n);
+  ctx->applyShard();
   ctx->useGraph = 0;  // collectives are enqueued between kernels; keep the eager chain
   rc = ctx->buildSell();
   return rc ? rc : ctx->buildSellX();
@@ -2478,9 +2984,11 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
       ctx->maximumPivots = f < 1000 ? f : 1000;
     }
   }
-  else if (!strcmp(name, "dual_bound")) ctx->dualBound = v;
-  else if (!strcmp(name, "primal_tolerance")) ctx->primalTolerance = v;
-  else if (!strcmp(name, "dual_tolerance")) ctx->dualTolerance = ctx->dualToleranceBase = v;
+  else if (!strcmp(name, "dual_bound")) ctx->dualBound = ctx->optDualBound = v;
+  else if (!strcmp(name, "primal_tolerance")) ctx->primalTolerance = ctx->optPrimalTolerance = v;
+  else if (!strcmp(name, "dual_tolerance")) ctx->dualTolerance = ctx->dualToleranceBase = ctx->optDualTolerance = v;
+  else if (!strcmp(name, "zero_tolerance")) ctx->zeroTolerance = ctx->optZeroTolerance = v;
+  else if (!strcmp(name, "acceptable_pivot")) ctx->acceptablePivot = ctx->optAcceptablePivot = v;
   else if (!strcmp(name, "random_seed")) ctx->seed = (unsigned int)v;
   else if (!strcmp(name, "log_level")) ctx->logLevel = (int)v;
   else if (!strcmp(name, "check_every")) {
@@ -2527,52 +3035,74 @@ int clpgpu_set_status(clpgpu_context *ctx, const unsigned char *status)
 // clpgpu_dual starts from these (and from the status given with clpgpu_set_status) -- the re-solve
 // pattern of branch and bound (ClpSimplex::dual with a warm basis).
 // (with option "scaling" the arrays arrive in the caller's units and are kept in scaled units)
+// the caller's arrays are kept (origRow*/origCol*); with scaling on, the pair is rebuilt the way the
+// load builds it (scaleBoundPair: infinities stay infinite, gaps below the primal tolerance close,
+// ClpSimplex::createRim src/ClpSimplex.cpp:3920-3980)
+static void rebuildRowBounds(clpgpu_context *ctx)
+{
+  for (int i = 0; i < ctx->m; i++) {
+    if (ctx->scaled)
+      scaleBoundPair(ctx->origRowLower[i], ctx->origRowUpper[i], ctx->rowScale[i], ctx->primalTolerance, ctx->rowLower[i], ctx->rowUpper[i]);
+    else {
+      ctx->rowLower[i] = ctx->origRowLower[i];
+      ctx->rowUpper[i] = ctx->origRowUpper[i];
+    }
+  }
+}
+static void rebuildColumnBounds(clpgpu_context *ctx)
+{
+  for (int j = 0; j < ctx->n; j++) {
+    if (ctx->scaled)
+      scaleBoundPair(ctx->origColLower[j], ctx->origColUpper[j], 1.0 / ctx->colScale[j], ctx->primalTolerance, ctx->colLower[j], ctx->colUpper[j]);
+    else {
+      ctx->colLower[j] = ctx->origColLower[j];
+      ctx->colUpper[j] = ctx->origColUpper[j];
+    }
+  }
+}
 int clpgpu_chg_row_lower(clpgpu_context *ctx, const double *rowLower)
 {
-  if (!ctx)
+  if (!ctx || !ctx->m)
     return -99;
-  for (int i = 0; i < ctx->m; i++) {
-    double v = rowLower ? rowLower[i] : -1.0e30;
-    ctx->rowLower[i] = (ctx->scaled && v > -1.0e20) ? v * ctx->rowScale[i] : v;
-  }
+  for (int i = 0; i < ctx->m; i++)
+    ctx->origRowLower[i] = rowLower ? rowLower[i] : -1.0e30;
+  rebuildRowBounds(ctx);
   return 0;
 }
 int clpgpu_chg_row_upper(clpgpu_context *ctx, const double *rowUpper)
 {
-  if (!ctx)
+  if (!ctx || !ctx->m)
     return -99;
-  for (int i = 0; i < ctx->m; i++) {
-    double v = rowUpper ? rowUpper[i] : 1.0e30;
-    ctx->rowUpper[i] = (ctx->scaled && v < 1.0e20) ? v * ctx->rowScale[i] : v;
-  }
+  for (int i = 0; i < ctx->m; i++)
+    ctx->origRowUpper[i] = rowUpper ? rowUpper[i] : 1.0e30;
+  rebuildRowBounds(ctx);
   return 0;
 }
 int clpgpu_chg_column_lower(clpgpu_context *ctx, const double *columnLower)
 {
-  if (!ctx)
+  if (!ctx || !ctx->n)
     return -99;
-  for (int j = 0; j < ctx->n; j++) {
-    double v = columnLower ? columnLower[j] : 0.0;
-    ctx->colLower[j] = (ctx->scaled && v > -1.0e20) ? v / ctx->colScale[j] : v;
-  }
+  for (int j = 0; j < ctx->n; j++)
+    ctx->origColLower[j] = columnLower ? columnLower[j] : 0.0;
+  rebuildColumnBounds(ctx);
   return 0;
 }
 int clpgpu_chg_column_upper(clpgpu_context *ctx, const double *columnUpper)
 {
-  if (!ctx)
+  if (!ctx || !ctx->n)
     return -99;
-  for (int j = 0; j < ctx->n; j++) {
-    double v = columnUpper ? columnUpper[j] : 1.0e30;
-    ctx->colUpper[j] = (ctx->scaled && v < 1.0e20) ? v / ctx->colScale[j] : v;
-  }
+  for (int j = 0; j < ctx->n; j++)
+    ctx->origColUpper[j] = columnUpper ? columnUpper[j] : 1.0e30;
+  rebuildColumnBounds(ctx);
   return 0;
 }
 int clpgpu_chg_obj_coefficients(clpgpu_context *ctx, const double *objIn)
 {
-  if (!ctx)
+  if (!ctx || !ctx->n)
     return -99;
   for (int j = 0; j < ctx->n; j++) {
     double v = objIn ? objIn[j] : 0.0;
+    ctx->origObj[j] = v;
     ctx->obj[j] = ctx->scaled ? v * ctx->colScale[j] : v;
   }
   return 0;
@@ -2586,7 +3116,7 @@ int clpgpu_scale_factors(int numberRows, int numberColumns, const int *columnSta
                          int mode, double primalTolerance, double *rowScale, double *columnScale)
 {
   if (numberRows <= 0 || numberColumns <= 0 || !columnStart || !rowIndex || !element || !rowScale || !columnScale || mode < 1 ||
-      mode > 4)
+      mode > 4 || !columnLower || !columnUpper || !rowLower || !rowUpper)
     return -1;
   double dualTolerance = 1.0e-7, zeroTolerance = 1.0e-13;
   std::fill(rowScale, rowScale + numberRows, 1.0);

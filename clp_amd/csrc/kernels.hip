@@ -1362,6 +1362,74 @@ __global__ void k_unroll_weights(Dev D)
     D.weights[p] = D.altWeights[p];
 }
 
+// ---- plug-in level ClpDualRowPivot calls (clpgpu_update_weights / clpgpu_update_primal): the same
+// arithmetic as the fused iteration kernels (k_rho_finish3's norm partials, k_ftran_scatter3's weight
+// update, k_fix_house's list appends), as stand-alone launches on host-supplied vectors
+// per-256-row partials of sum pi^2 (ClpDualRowSteepest::updateWeights :443-460)
+__global__ void __launch_bounds__(256) k_plugin_norm(Dev D, const double *piRow)
+{
+  __shared__ double sh[16];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double sq = 0.0;
+  if (i < D.m) {
+    double v = piRow[i];
+    sq = v * v;
+  }
+  double s = blockSum(sq, sh);
+  if (threadIdx.x == 0)
+    D.normPartial[blockIdx.x] = s;
+}
+// DSE weight update on the support of the updated column w (D.w, D.tau by basis position):
+// :516-538 with model alpha = the ratio test's alpha; old weights saved for unrollWeights (:1022)
+__global__ void __launch_bounds__(256) k_plugin_weights(Dev D, int pivotRow, double modelAlpha, int nbNorm)
+{
+  __shared__ double shd[16];
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < nbNorm; b += blockDim.x)
+    acc += D.normPartial[b];
+  acc = blockSum(acc, shd);
+  const double norm = acc / (modelAlpha * modelAlpha);
+  const double multiplier = 2.0 / modelAlpha;
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= D.m)
+    return;
+  const double x1 = D.w[p], x2 = D.tau[p];
+  if (x1 != 0.0) {
+    double devex = D.weights[p];
+    D.altWeights[p] = devex;
+    if (p == pivotRow) {
+      devex = (norm < DEVEX_TRY_NORM) ? DEVEX_TRY_NORM : norm;
+    } else {
+      devex += x1 * (x1 * norm + x2 * multiplier);
+      if (devex < DEVEX_TRY_NORM)
+        devex = DEVEX_TRY_NORM;
+    }
+    D.weights[p] = devex;
+  }
+}
+// new entries of the infeasibility list at the absolute offsets scanTailBody left
+__global__ void __launch_bounds__(256) k_append_scatter_abs(Dev D)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->numberAppend == 0)
+    return;
+  __shared__ int shi[17];
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  int flag = (p < D.m) ? D.appendFlag[p] : 0;
+  int total;
+  int rank = blockRank(flag, total, shi);
+  if (flag)
+    D.infIndex[D.blockOffset[blockIdx.x] + rank] = p;
+}
+// ClpDualRowSteepest::saveWeights mode 6 (:937-957): every weight becomes `allowed` (the reference
+// assigns the bound, not the clamped value)
+__global__ void k_weights_scale_back(Dev D, double allowed)
+{
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < D.m)
+    D.weights[p] = allowed;
+}
+
 // =============================================================================================
 // Primal update -- ClpDualRowSteepest::updatePrimalSolution (src/ClpDualRowSteepest.cpp:630-763)
 // x_B -= ratio * vec ; refresh squared infeasibilities ; new entries are appended to the list in

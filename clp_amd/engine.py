@@ -40,6 +40,8 @@ ABI_SYMBOLS = [
     "clpgpu_get_pivot_log", "clpgpu_get_row_weights", "clpgpu_get_stats",
     "clpgpu_chg_row_lower", "clpgpu_chg_row_upper", "clpgpu_chg_column_lower", "clpgpu_chg_column_upper",
     "clpgpu_chg_obj_coefficients", "clpgpu_scale_factors",
+    "clpgpu_clone", "clpgpu_set_scales", "clpgpu_ftran_ft", "clpgpu_ftran_two_ft", "clpgpu_bind_rim", "clpgpu_pivot_row",
+    "clpgpu_update_weights", "clpgpu_update_primal", "clpgpu_save_weights", "clpgpu_unroll_weights",
 ]
 
 
@@ -109,6 +111,17 @@ def lib():
         L.clpgpu_get_pivot_log.argtypes = [p, C.c_void_p, C.c_int]
         L.clpgpu_get_row_weights.argtypes = [p, dp, dp]
         L.clpgpu_get_stats.argtypes = [p, C.POINTER(Stats)]
+        L.clpgpu_clone.restype = p
+        L.clpgpu_clone.argtypes = [p]
+        L.clpgpu_set_scales.argtypes = [p, C.c_void_p, C.c_void_p]
+        L.clpgpu_ftran_ft.argtypes = [p, dp]
+        L.clpgpu_ftran_two_ft.argtypes = [p, dp, dp]
+        L.clpgpu_bind_rim.argtypes = [p] + [C.c_void_p] * 6
+        L.clpgpu_pivot_row.argtypes = [p]
+        L.clpgpu_update_weights.argtypes = [p, C.c_int, ip, dp, C.c_int, C.c_int, C.c_double, dp, C.POINTER(C.c_double)]
+        L.clpgpu_update_primal.argtypes = [p, C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_double)]
+        L.clpgpu_save_weights.argtypes = [p, C.c_int]
+        L.clpgpu_unroll_weights.argtypes = [p]
         _LIB = L
     return _LIB
 
@@ -298,3 +311,70 @@ class ClpGpuSimplex:
 
     def pivots(self):
         return lib().clpgpu_pivots(self._h)
+
+    def ftranFT(self, v):
+        v = np.array(v, dtype=np.float64)
+        rc = lib().clpgpu_ftran_ft(self._h, v)
+        if rc < 0:
+            self._check(rc, "clpgpu_ftran_ft")
+        return v
+
+    def ftranTwoFT(self, v_ft, v2):
+        a, b = np.array(v_ft, dtype=np.float64), np.array(v2, dtype=np.float64)
+        rc = lib().clpgpu_ftran_two_ft(self._h, a, b)
+        if rc < 0:
+            self._check(rc, "clpgpu_ftran_two_ft")
+        return a, b
+
+    # ---- ClpDualRowPivot surface ----------------------------------------------------------------
+    @staticmethod
+    def _opt(a, dtype):
+        if a is None:
+            return None, None
+        a = np.ascontiguousarray(a, dtype=dtype)
+        return a, a.ctypes.data_as(C.c_void_p)
+
+    def bindRim(self, cost=None, lower=None, upper=None, dj=None, solution=None, status=None):
+        keep, ptrs = [], []
+        for a, dt in ((cost, np.float64), (lower, np.float64), (upper, np.float64), (dj, np.float64),
+                      (solution, np.float64), (status, np.uint8)):
+            arr, ptr = self._opt(a, dt)
+            keep.append(arr)
+            ptrs.append(ptr)
+        self._check(lib().clpgpu_bind_rim(self._h, *ptrs), "clpgpu_bind_rim")
+
+    def pivotRow(self):
+        return lib().clpgpu_pivot_row(self._h)
+
+    def updateWeights(self, pi_index, pi_value, pivot_row, sequence_in, model_alpha):
+        w, alpha = np.zeros(self.m), C.c_double(0.0)
+        pi_index = np.ascontiguousarray(pi_index, dtype=np.int32)
+        self._check(lib().clpgpu_update_weights(self._h, len(pi_index), pi_index, np.ascontiguousarray(pi_value, dtype=np.float64),
+                                                int(pivot_row), int(sequence_in), float(model_alpha), w, C.byref(alpha)),
+                    "clpgpu_update_weights")
+        return alpha.value, w
+
+    def updatePrimalSolution(self, pivot_row, theta, updated_column=None):
+        change = C.c_double(0.0)
+        arr, ptr = self._opt(updated_column, np.float64)
+        self._check(lib().clpgpu_update_primal(self._h, ptr, int(pivot_row), float(theta), C.byref(change)), "clpgpu_update_primal")
+        return change.value
+
+    def saveWeights(self, mode):
+        self._check(lib().clpgpu_save_weights(self._h, int(mode)), "clpgpu_save_weights")
+
+    def unrollWeights(self):
+        self._check(lib().clpgpu_unroll_weights(self._h), "clpgpu_unroll_weights")
+
+    def clone(self):
+        other = object.__new__(ClpGpuSimplex)
+        other._h = lib().clpgpu_clone(self._h)
+        if not other._h:
+            raise RuntimeError("clpgpu_clone failed")
+        other.m, other.n = self.m, self.n
+        return other
+
+    def setScales(self, row_scale, column_scale):
+        ra, rp = self._opt(row_scale, np.float64)
+        ca, cp = self._opt(column_scale, np.float64)
+        self._check(lib().clpgpu_set_scales(self._h, rp, cp), "clpgpu_set_scales")

@@ -55,6 +55,12 @@ typedef struct {
  * there is no CPU fallback. */
 clpgpu_context *clpgpu_create(int device);
 void clpgpu_destroy(clpgpu_context *ctx);
+/* ClpMatrixBase::clone (src/ClpMatrixBase.hpp:96), ClpDualRowPivot::clone (src/ClpDualRowPivot.hpp:76),
+ * CoinOtherFactorization::clone: Clp copies models and their plug-ins freely (ClpModel.cpp:822, :885,
+ * ClpSimplex.cpp:2851).  An independent context on the same device with the same problem, options,
+ * changed bounds/costs and warm-start status; the factorization is rebuilt by the clone's first
+ * factorize / dual.  NULL on failure. */
+clpgpu_context *clpgpu_clone(const clpgpu_context *ctx);
 const char *clpgpu_last_error(const clpgpu_context *ctx);
 /* HIP stream (hipStream_t as void*) the engine launches on; for event timing by callers */
 void *clpgpu_stream(clpgpu_context *ctx);
@@ -79,6 +85,15 @@ int clpgpu_set_column_range(clpgpu_context *ctx, int firstColumn, int lastColumn
 int clpgpu_comm_unique_id(void *id128);
 int clpgpu_comm_init(clpgpu_context *ctx, int rank, int nranks, const void *id128);
 
+/* ClpModel::rowScale_ / columnScale_ supplied by the caller (what ClpPackedMatrix::scale left in the
+ * model, src/ClpPackedMatrix.cpp:4120, src/ClpSimplex.cpp:3701) instead of option "scaling": the engine
+ * keeps the LP in those units, getters return unscaled values.  Call after clpgpu_load_problem (the
+ * sizes come from it; the device copy is rebuilt).  NULL, NULL drops them.  0 OK, -1 bad factors,
+ * -2 nothing loaded. */
+int clpgpu_set_scales(clpgpu_context *ctx, const double *rowScale, const double *columnScale);
+
+/* The plug-in level calls below (times ... replace_column, ftran_ft, update_weights) work in the
+ * caller's units and return -3 on a context that scales internally. */
 /* ClpMatrixBase::times(scalar, x, y) (:275; ClpPackedMatrix.cpp:296): y += scalar*A*x */
 int clpgpu_times(clpgpu_context *ctx, double scalar, const double *x, double *y);
 /* ClpMatrixBase::transposeTimes(scalar, x, y) (:287; ClpPackedMatrix.cpp:362): y += scalar*A^T*x */
@@ -112,11 +127,46 @@ int clpgpu_btran(clpgpu_context *ctx, double *region);
 int clpgpu_replace_column(clpgpu_context *ctx, int pivotRow, int sequenceIn, double pivotCheck,
                           double acceptablePivot);
 int clpgpu_pivots(const clpgpu_context *ctx);
+/* ClpFactorization::updateColumnFT (src/ClpFactorization.cpp:2723; in-tree twin
+ * CoinAbcBaseFactorization3.cpp:2173): FTRAN of the entering column that also keeps what the basis
+ * update needs.  Here the result itself stays on the device as the "updated column" later calls refer
+ * to.  Returns the number of nonzeros (the reference: negative = no room, never here), -99 on error. */
+int clpgpu_ftran_ft(clpgpu_context *ctx, double *region);
+/* ClpFactorization::updateTwoColumnsFT (:2889; twin CoinAbcBaseFactorization3.cpp:1155): the FT solve of
+ * the entering column and the plain FTRAN of the DSE vector in one sweep.  Returns nonzeros of regionFT. */
+int clpgpu_ftran_two_ft(clpgpu_context *ctx, double *regionFT, double *region2);
+
+/* ---- ClpDualRowPivot surface (src/ClpDualRowPivot.hpp:30-76) ------------------------------ */
+/* Clp owns the rim arrays; the ones given (NULL = unchanged) are copied to the engine's mirrors,
+ * n+m entries each, [columns | rows] (src/ClpSimplex.hpp:1864-1922). */
+int clpgpu_bind_rim(clpgpu_context *ctx, const double *cost, const double *lower, const double *upper,
+                    const double *dj, const double *solution, const unsigned char *status);
+/* pivotRow() (:30; ClpDualRowSteepest.cpp:179, ClpDualRowDantzig.cpp:56): leaving row, or -1 when
+ * nothing is primal infeasible (the reference's "looks optimal" answer). */
+int clpgpu_pivot_row(clpgpu_context *ctx);
+/* updateWeights(input, spare, spare2, updatedColumn) (:33; ClpDualRowSteepest.cpp:375): input = packed
+ * pi; does the FT FTRAN of column sequenceIn and the FTRAN of pi, updates the DSE weights with
+ * modelAlpha = the ratio test's alpha (model_->alpha(), :509); updatedColumn[m] (by basis position)
+ * and *alpha (its pivotRow entry, the value the reference returns) are outputs. */
+int clpgpu_update_weights(clpgpu_context *ctx, int numberPi, const int *piIndex, const double *piValue,
+                          int pivotRow, int sequenceIn, double modelAlpha, double *updatedColumn,
+                          double *alpha);
+/* updatePrimalSolution(input, theta, changeInObjective) (:40; ClpDualRowSteepest.cpp:630): basic
+ * solution -= theta * updatedColumn (NULL = the column the last clpgpu_update_weights /
+ * clpgpu_ftran_ft produced), infeasibility list refreshed; read the result with clpgpu_get_solution. */
+int clpgpu_update_primal(clpgpu_context *ctx, const double *updatedColumn, int pivotRow, double theta,
+                         double *changeInObjective);
+/* saveWeights(model, mode) (:53; ClpDualRowSteepest.cpp:773): 1 before a factorization, 2 / 4 after,
+ * 3 redo the infeasibilities only, 5 / 7 strong-branching initialisation, 6 scale back. */
+int clpgpu_save_weights(clpgpu_context *ctx, int mode);
+/* unrollWeights() (:60; ClpDualRowSteepest.cpp:1022): undo the last clpgpu_update_weights */
+int clpgpu_unroll_weights(clpgpu_context *ctx);
 
 /* ---- whole-engine mode (precedent: ClpSimplex::dealWithAbc, src/ClpSolve.cpp:555-833) ---- */
 /* options by name (ClpSimplex setters): "pivot_rule" 0 Dantzig (ClpDualRowDantzig) / 1 steepest
  * (ClpDualRowSteepest); "max_iterations" (setMaximumIterations); "max_pivots"
- * (factorization maximumPivots); "dual_bound"; "primal_tolerance"; "dual_tolerance";
+ * (factorization maximumPivots); "dual_bound"; "primal_tolerance"; "dual_tolerance"; "zero_tolerance";
+ * "acceptable_pivot";
  * "random_seed"; "log_level"; "check_every" (host polls the device control block every N
  * iterations).  Engine tuning / test knobs (no counterpart in the reference): "timing" (HIP events
  * around every pricing launch), "price_kernel" (inner-loop variant of the pricing kernel, default
