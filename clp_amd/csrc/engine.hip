@@ -3218,7 +3218,7 @@ int clpgpu_get_row_weights(clpgpu_context *ctx, double *weights, double *infeasi
 }
 int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
 {
-  if (!ctx || !stats)
+  if (!ctx || !stats || !ctx->hCtrl)
     return -99;
   if (ctx->pullCtrl())
     return -99;
@@ -3234,6 +3234,8 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
   stats->total_ms = ctx->seconds * 1.0e3;
   stats->iterations = ctx->numberIterations;
   stats->refactorizations = ctx->numberRefactorizations;
+  stats->nucleus = ctx->hCtrl->k;
+  stats->nucleus_capacity = ctx->kcap;
   return 0;
 }
 

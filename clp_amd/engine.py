@@ -27,7 +27,8 @@ PIVOT_DTYPE = np.dtype([("iteration", "i4"), ("sequenceIn", "i4"), ("sequenceOut
 
 class Stats(C.Structure):
     _fields_ = [("price_ms", C.c_double), ("price_launches", C.c_long), ("price_bytes", C.c_double),
-                ("total_ms", C.c_double), ("iterations", C.c_long), ("refactorizations", C.c_long)]
+                ("total_ms", C.c_double), ("iterations", C.c_long), ("refactorizations", C.c_long),
+                ("nucleus", C.c_long), ("nucleus_capacity", C.c_long)]
 
 
 # every symbol include/clpgpu.h declares (tests/test_abi.py checks the library exports all of them)

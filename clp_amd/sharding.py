@@ -14,14 +14,11 @@ PRICE_BLOCK = 256  # the pricing kernel's workgroup covers 256 columns; keep sha
 
 
 def column_ranges(n: int, nranks: int):
+    """The engine's shard of every rank (clpgpu_context::applyShard): equal chunks rounded up to the
+    pricing workgroup's 256 columns, clipped at n -- trailing ranks of a small LP may be empty."""
     chunk = (n + nranks - 1) // nranks
-    chunk = ((chunk + PRICE_BLOCK - 1) // PRICE_BLOCK) * PRICE_BLOCK if n >= PRICE_BLOCK * nranks else chunk
-    out = []
-    for r in range(nranks):
-        a = min(r * chunk, n)
-        b = min((r + 1) * chunk, n) if r < nranks - 1 else n
-        out.append((a, max(a, b)))
-    return out
+    chunk = ((chunk + PRICE_BLOCK - 1) // PRICE_BLOCK) * PRICE_BLOCK
+    return [(min(r * chunk, n), min((r + 1) * chunk, n)) for r in range(nranks)]
 
 
 def merge_candidates(parts):

@@ -48,6 +48,8 @@ typedef struct {
   double total_ms;      /* whole clpgpu_dual wall time */
   long iterations;
   long refactorizations;
+  long nucleus;         /* k: basic structurals = order of the nucleus inverse right now */
+  long nucleus_capacity; /* rows allocated for it (3 k x k f64 matrices) */
 } clpgpu_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------- */
