@@ -32,6 +32,16 @@ using namespace clpgpu;
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// launch on the iteration chain; with option "timing" = 2 (eager launches) an event mark follows every
+// launch on the main stream, so the per-kernel times of exactly the pivots being benchmarked can be read
+#define KL(name, kernel, grid, block, lds, strm, ...)                                              \
+  do {                                                                                             \
+    hipLaunchKernelGGL(kernel, grid, block, lds, strm, __VA_ARGS__);                               \
+    if (ktOn && (strm) == stream)                                                                  \
+      ktMark(name);                                                                                \
+  } while (0)
+#define KT_MAX 32  // marks per pivot (the chain has 11-15 launches)
+
 struct clpgpu_context {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -120,6 +130,17 @@ struct clpgpu_context {
   std::vector<hipEvent_t> evStart, evStop;
   int evUsed = 0;
   double seconds = 0.0;
+  // per-kernel event marks (timing == 2)
+  bool ktOn = false;
+  int ktPivot = 0;
+  std::vector<hipEvent_t> ktEvents;        // [checkEvery * KT_MAX]
+  std::vector<int> ktSlotOfMark, ktMarks;  // slot of every mark; marks recorded per pivot of the batch
+  std::vector<const char *> ktNames;
+  std::vector<double> ktMs;
+  std::vector<long> ktCount;
+  void ktBegin(int pivotInBatch);
+  void ktMark(const char *name);
+  void ktCollect(int livePivots);
 
   void setError(const char *fmt, ...)
   {
@@ -1836,8 +1857,60 @@ void clpgpu_context::joinUpdateBranch()
   }
 }
 
+void clpgpu_context::ktBegin(int pivotInBatch)
+{
+  ktPivot = pivotInBatch;
+  if ((int)ktEvents.size() < checkEvery * KT_MAX) {
+    size_t old = ktEvents.size();
+    ktEvents.resize((size_t)checkEvery * KT_MAX);
+    for (size_t i = old; i < ktEvents.size(); i++)
+      (void)hipEventCreate(&ktEvents[i]);
+    ktSlotOfMark.assign((size_t)checkEvery * KT_MAX, -1);
+    ktMarks.assign(checkEvery, 0);
+  }
+  ktMarks[pivotInBatch] = 0;
+  ktMark(nullptr);  // start-of-pivot mark
+}
+void clpgpu_context::ktMark(const char *name)
+{
+  int &nm = ktMarks[ktPivot];
+  if (nm >= KT_MAX)
+    return;
+  int slot = -1;
+  if (name) {
+    for (size_t i = 0; i < ktNames.size(); i++)
+      if (ktNames[i] == name || !strcmp(ktNames[i], name))
+        slot = (int)i;
+    if (slot < 0) {
+      slot = (int)ktNames.size();
+      ktNames.push_back(name);
+      ktMs.push_back(0.0);
+      ktCount.push_back(0);
+    }
+  }
+  const size_t idx = (size_t)ktPivot * KT_MAX + nm;
+  ktSlotOfMark[idx] = slot;
+  (void)hipEventRecord(ktEvents[idx], stream);
+  nm++;
+}
+// after the batch has been synchronised: elapsed time between consecutive marks goes to the kernel
+// the later mark follows (kernel + the launch gap before it); only pivots the device really ran
+void clpgpu_context::ktCollect(int livePivots)
+{
+  for (int b = 0; b < livePivots && b < (int)ktMarks.size(); b++)
+    for (int i = 1; i < ktMarks[b]; i++) {
+      const size_t idx = (size_t)b * KT_MAX + i;
+      float ms = 0.0f;
+      if (ktSlotOfMark[idx] >= 0 && hipEventElapsedTime(&ms, ktEvents[idx - 1], ktEvents[idx]) == hipSuccess) {
+        ktMs[ktSlotOfMark[idx]] += ms;
+        ktCount[ktSlotOfMark[idx]]++;
+      }
+    }
+}
+
 int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
 {
+  ktOn = timing >= 2 && !capturing;
   const int nbRows = cdiv(m, PRICE_BLOCK);
   const int nbCols = cdiv(D.lastColumn - D.firstColumn, PRICE_BLOCK);
   const int nb = nbRows + nbCols;
@@ -1847,40 +1920,40 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   int selfScanSell = -1;
   // CHUZR (+ the analytic front end of the BTRAN)
   if (firstOfBatch)
-    hipLaunchKernelGGL(k_chuzr_pre, dim3(1), dim3(64), 0, stream, D);
+    KL("k_chuzr_pre", k_chuzr_pre, dim3(1), dim3(64), 0, stream, D);
   if (nChzBlocks <= 256) {
     // the last workgroup of the scan makes the final selection (no separate launch)
-    hipLaunchKernelGGL(k_chuzr_scan, dim3(nChzBlocks), dim3(256), 0, stream, D, wideRows ? 1 : 0);
+    KL("k_chuzr_scan", k_chuzr_scan, dim3(nChzBlocks), dim3(256), 0, stream, D, wideRows ? 1 : 0);
   } else {
-    hipLaunchKernelGGL(k_chuzr_scan, dim3(nChzBlocks), dim3(256), 0, stream, D, -1);
-    hipLaunchKernelGGL(k_chuzr_final_btran, dim3(1), dim3(256), 0, stream, D, nChzBlocks, wideRows ? 1 : 0);
+    KL("k_chuzr_scan", k_chuzr_scan, dim3(nChzBlocks), dim3(256), 0, stream, D, -1);
+    KL("k_chuzr_final_btran", k_chuzr_final_btran, dim3(1), dim3(256), 0, stream, D, nChzBlocks, wideRows ? 1 : 0);
   }
   // BTRAN (reads Minv: the previous pivot's basis-update branch must have finished)
   joinUpdateBranch();
   if (wideRows)
-    hipLaunchKernelGGL(k_gemvT_partial2, dim3(cdiv(kc, 256), cdiv(kc, 64)), dim3(256), 0, stream, D, (const double *)D.slotA, 1);
+    KL("k_gemvT_partial2", k_gemvT_partial2, dim3(cdiv(kc, 256), cdiv(kc, 64)), dim3(256), 0, stream, D, (const double *)D.slotA, 1);
   // (not column-sharded: the candidate counts come from this kernel and the pricing kernel, there
   // is no separate counting launch)
   const bool countInPrice = priceKernel >= 1 && !commActive && nb > 256;
   // experimental multi-lane pricing layout (needs the LDS bitmap: m <= 64 * SELL_BITS_MAX)
   const bool sellX = sellLanes > 1 && nSxBlocks > 0 && priceKernel >= 2 && !widePricing && m <= 64 * SELL_BITS_MAX;
-  hipLaunchKernelGGL(k_rho_finish3, dim3(gm), dim3(256), 0, stream, D, wideRows ? 1 : 0, countInPrice ? nbCols : -1);
+  KL("k_rho_finish3", k_rho_finish3, dim3(gm), dim3(256), 0, stream, D, wideRows ? 1 : 0, countInPrice ? nbCols : -1);
   // PRICE + first ratio pass
   if (ev)
     (void)hipEventRecord(evStart[evUsed], stream);
   if (priceKernel >= 1) {
     if (widePricing && priceKernel != 1)
-      hipLaunchKernelGGL(k_price_wide, dim3(nWideBlocks), dim3(256), 0, stream, D, denseColumns ? 1 : 0, countInPrice ? 1 : 0);
+      KL("k_price_wide", k_price_wide, dim3(nWideBlocks), dim3(256), 0, stream, D, denseColumns ? 1 : 0, countInPrice ? 1 : 0);
     else if (sellX) {
       const size_t lds = (size_t)((m + 63) / 64) * 8;
       if (sellLanes == 2)
-        hipLaunchKernelGGL((k_price_sellx<2>), dim3(nSxBlocks + nLongBlocks), dim3(256), lds, stream, D, countInPrice ? 1 : 0, nSxBlocks);
+        KL("k_price_sellx", (k_price_sellx<2>), dim3(nSxBlocks + nLongBlocks), dim3(256), lds, stream, D, countInPrice ? 1 : 0, nSxBlocks);
       else if (sellLanes == 4)
-        hipLaunchKernelGGL((k_price_sellx<4>), dim3(nSxBlocks + nLongBlocks), dim3(256), lds, stream, D, countInPrice ? 1 : 0, nSxBlocks);
+        KL("k_price_sellx", (k_price_sellx<4>), dim3(nSxBlocks + nLongBlocks), dim3(256), lds, stream, D, countInPrice ? 1 : 0, nSxBlocks);
       else
-        hipLaunchKernelGGL((k_price_sellx<8>), dim3(nSxBlocks + nLongBlocks), dim3(256), lds, stream, D, countInPrice ? 1 : 0, nSxBlocks);
+        KL("k_price_sellx", (k_price_sellx<8>), dim3(nSxBlocks + nLongBlocks), dim3(256), lds, stream, D, countInPrice ? 1 : 0, nSxBlocks);
     } else if (nSellBlocks + nLongBlocks > 0)
-      hipLaunchKernelGGL(k_price_sell, dim3(nSellBlocks + nLongBlocks), dim3(256), (m > 64 * SELL_BITS_MAX || priceKernel < 2) ? 0 : (size_t)((m + 63) / 64) * 8, stream, D, (m > 64 * SELL_BITS_MAX && priceKernel > 1) ? 1 : priceKernel,
+      KL("k_price_sell", k_price_sell, dim3(nSellBlocks + nLongBlocks), dim3(256), (m > 64 * SELL_BITS_MAX || priceKernel < 2) ? 0 : (size_t)((m + 63) / 64) * 8, stream, D, (m > 64 * SELL_BITS_MAX && priceKernel > 1) ? 1 : priceKernel,
                          countInPrice ? 1 : 0, nSellBlocks);
     if (ev)
       (void)hipEventRecord(evStop[evUsed++], stream);
@@ -1895,29 +1968,29 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
       const int nSell = (widePricing && priceKernel != 1) ? nWideBlocks : (sellX ? nSxBlocks : nSellBlocks) + nLongBlocks;
       const bool fuse = nb <= 256;  // small grids: the last workgroup scans the counts itself
       if (!countInPrice)
-        hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, commActive ? 1 : 0, fuse ? nSell : -1);
+        KL("k_cand_count", k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, commActive ? 1 : 0, fuse ? nSell : -1);
       selfScanSell = fuse ? -1 : nSell;  // large grids: k_cand_scatter scans for itself, no scan launch
     }
   } else {
-    hipLaunchKernelGGL(k_price, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
+    KL("k_price", k_price, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
     if (ev)
       (void)hipEventRecord(evStop[evUsed++], stream);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1, 0);
+    KL("k_scan_blocks", k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1, 0);
   }
-  hipLaunchKernelGGL(k_cand_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, selfScanSell);
+  KL("k_cand_scatter", k_cand_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, selfScanSell);
   // CHUZC (also unpacks the entering column)
-  hipLaunchKernelGGL(k_dual_column, dim3(1), dim3(DC_THREADS), 0, stream, D, nb);
+  KL("k_dual_column", k_dual_column, dim3(1), dim3(DC_THREADS), 0, stream, D, nb);
   // dual update + flip detection (needs only theta), flip list, flip right-hand side
-  hipLaunchKernelGGL(k_dj_flags, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, flipListCap);
-  hipLaunchKernelGGL(k_flip_apply2, dim3(1), dim3(1024), 0, stream, D, gm, denseColumns ? 1 : 0, flipListCap);
+  KL("k_dj_flags", k_dj_flags, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, flipListCap);
+  KL("k_flip_apply2", k_flip_apply2, dim3(1), dim3(1024), 0, stream, D, gm, denseColumns ? 1 : 0, flipListCap);
   if (denseColumns)
-    hipLaunchKernelGGL(k_flip_dense, dim3(gm), dim3(256), 0, stream, D);
+    KL("k_flip_dense", k_flip_dense, dim3(gm), dim3(256), 0, stream, D);
   // one FTRAN sweep for the entering column, rho (DSE) and the flip rhs; the back end also applies
   // the flip part of the primal update
-  hipLaunchKernelGGL(k_gemv3g, dim3(cdiv(kc, GEMV_RPB)), dim3(1024), 0, stream, D);
+  KL("k_gemv3g", k_gemv3g, dim3(cdiv(kc, GEMV_RPB)), dim3(1024), 0, stream, D);
   if (wideRows)
-    hipLaunchKernelGGL(k_slack_dots, dim3(cdiv(m, 4)), dim3(256), 0, stream, D);
-  hipLaunchKernelGGL(k_ftran_scatter3, dim3(cdiv(m + kc, 256)), dim3(256), 0, stream, D, gm, parity, wideRows ? 1 : 0);
+    KL("k_slack_dots", k_slack_dots, dim3(cdiv(m, 4)), dim3(256), 0, stream, D);
+  KL("k_ftran_scatter3", k_ftran_scatter3, dim3(cdiv(m + kc, 256)), dim3(256), 0, stream, D, gm, parity, wideRows ? 1 : 0);
   // basis update of the nucleus inverse: needs only what the FTRAN tail left (w and rho by slot, the
   // update scalars), nothing downstream needs Minv before the next BTRAN -> its own branch
   {
@@ -1925,14 +1998,14 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
     if (forkUpdate && stream2) {
       (void)hipEventRecord(evFork, stream);
       (void)hipStreamWaitEvent(stream2, evFork, 0);
-      hipLaunchKernelGGL(k_rank1, dim3(gx, gy), dim3(256), 0, stream2, D, parity);
-      hipLaunchKernelGGL(k_minv_fix, dim3(1), dim3(256), 0, stream2, D, parity);
+      KL("k_rank1", k_rank1, dim3(gx, gy), dim3(256), 0, stream2, D, parity);
+      KL("k_minv_fix", k_minv_fix, dim3(1), dim3(256), 0, stream2, D, parity);
       (void)hipEventRecord(evJoin, stream2);
       sidePending = true;
-      hipLaunchKernelGGL(k_primal_update, dim3(gm), dim3(256), 0, stream, D, 0);
+      KL("k_primal_update", k_primal_update, dim3(gm), dim3(256), 0, stream, D, 0);
     } else {
       // one launch: primal update with the entering column + rank-1 sweep of the nucleus inverse
-      hipLaunchKernelGGL(k_primal_rank1, dim3(gm + gx * gy), dim3(256), 0, stream, D, parity, gm, gx, gy);
+      KL("k_primal_rank1", k_primal_rank1, dim3(gm + gx * gy), dim3(256), 0, stream, D, parity, gm, gx, gy);
     }
   }
   // workgroup 0: fix-ups of the basis update, housekeeping, head of the next CHUZR; the others
@@ -1940,10 +2013,10 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   if (wideRows) {
     // long columns: the row-copy partition moves of the leaving and the entering column, one thread
     // per entry over the whole chip (workgroup 0 of k_fix_house then skips them)
-    hipLaunchKernelGGL(k_house_col, dim3(cdiv(maxColumnLength, 256)), dim3(256), 0, stream, D, 0);
-    hipLaunchKernelGGL(k_house_col, dim3(cdiv(maxColumnLength, 256)), dim3(256), 0, stream, D, 1);
+    KL("k_house_col", k_house_col, dim3(cdiv(maxColumnLength, 256)), dim3(256), 0, stream, D, 0);
+    KL("k_house_col", k_house_col, dim3(cdiv(maxColumnLength, 256)), dim3(256), 0, stream, D, 1);
   }
-  hipLaunchKernelGGL(k_fix_house, dim3(2 + gm), dim3(256), 0, stream, D, parity, (forkUpdate && stream2) ? 0 : 1, wideRows ? 1 : 0);
+  KL("k_fix_house", k_fix_house, dim3(2 + gm), dim3(256), 0, stream, D, parity, (forkUpdate && stream2) ? 0 : 1, wideRows ? 1 : 0);
   return 0;
 }
 
@@ -1952,8 +2025,11 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
 int clpgpu_context::launchBatch()
 {
   if (!useGraph || timing) {
-    for (int b = 0; b < checkEvery; b++)
+    for (int b = 0; b < checkEvery; b++) {
+      if (timing >= 2)
+        ktBegin(b);
       launchIteration(b == 0, b & 1);
+    }
     joinUpdateBranch();
     return checkLaunches("launchIteration");
   }
@@ -2038,6 +2114,8 @@ int clpgpu_context::whileIterating(int stepTarget)
           stats.price_launches++;
         }
       }
+      if (timing >= 2)
+        ktCollect((int)(hCtrl->statPriceLaunches - launchesBefore));
     }
     if (hCtrl->state != RUN)
       break;
@@ -2363,6 +2441,8 @@ void clpgpu_destroy(clpgpu_context *ctx)
   for (auto &e : ctx->evStart)
     (void)hipEventDestroy(e);
   for (auto &e : ctx->evStop)
+    (void)hipEventDestroy(e);
+  for (auto &e : ctx->ktEvents)
     (void)hipEventDestroy(e);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -2998,6 +3078,8 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
     for (auto &e : ctx->evStop) (void)hipEventDestroy(e);
     ctx->evStart.clear();
     ctx->evStop.clear();
+    for (auto &e : ctx->ktEvents) (void)hipEventDestroy(e);
+    ctx->ktEvents.clear();
   }
   else if (!strcmp(name, "timing")) { ctx->timing = (int)v; ctx->dropGraph(); }
   else if (!strcmp(name, "price_kernel")) { ctx->priceKernel = (int)v; ctx->dropGraph(); }
@@ -3215,6 +3297,21 @@ int clpgpu_get_row_weights(clpgpu_context *ctx, double *weights, double *infeasi
   if (infeasibility)
     rc |= ctx->d2h(infeasibility, ctx->D.infeas, ctx->m);
   return rc;
+}
+int clpgpu_get_kernel_times(clpgpu_context *ctx, int maxKernels, const char **names, double *milliseconds, long *launches)
+{
+  if (!ctx)
+    return -99;
+  int count = (int)ctx->ktNames.size();
+  for (int i = 0; i < count && i < maxKernels; i++) {
+    if (names)
+      names[i] = ctx->ktNames[i];
+    if (milliseconds)
+      milliseconds[i] = ctx->ktMs[i];
+    if (launches)
+      launches[i] = ctx->ktCount[i];
+  }
+  return count;
 }
 int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
 {

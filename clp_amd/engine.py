@@ -43,6 +43,7 @@ ABI_SYMBOLS = [
     "clpgpu_chg_obj_coefficients", "clpgpu_scale_factors",
     "clpgpu_clone", "clpgpu_set_scales", "clpgpu_ftran_ft", "clpgpu_ftran_two_ft", "clpgpu_bind_rim", "clpgpu_pivot_row",
     "clpgpu_update_weights", "clpgpu_update_primal", "clpgpu_save_weights", "clpgpu_unroll_weights",
+    "clpgpu_get_kernel_times",
 ]
 
 
@@ -123,6 +124,7 @@ def lib():
         L.clpgpu_update_primal.argtypes = [p, C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_double)]
         L.clpgpu_save_weights.argtypes = [p, C.c_int]
         L.clpgpu_unroll_weights.argtypes = [p]
+        L.clpgpu_get_kernel_times.argtypes = [p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_long)]
         _LIB = L
     return _LIB
 
@@ -260,6 +262,13 @@ class ClpGpuSimplex:
         s = Stats()
         self._check(lib().clpgpu_get_stats(self._h, C.byref(s)), "clpgpu_get_stats")
         return {f: getattr(s, f) for f, _ in Stats._fields_}
+
+    def kernelTimes(self):
+        """{kernel: (total ms, launches)} gathered with option timing = 2"""
+        cap = 64
+        names, ms, cnt = (C.c_char_p * cap)(), (C.c_double * cap)(), (C.c_long * cap)()
+        k = lib().clpgpu_get_kernel_times(self._h, cap, names, ms, cnt)
+        return {names[i].decode(): (ms[i], cnt[i]) for i in range(max(0, min(k, cap)))}
 
     def stream(self):
         return lib().clpgpu_stream(self._h)

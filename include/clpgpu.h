@@ -222,6 +222,11 @@ int clpgpu_get_pivot_log(clpgpu_context *ctx, clpgpu_pivot_record *out, int maxR
  * (ClpDualRowSteepest::weights_, infeasible_; src/ClpDualRowSteepest.hpp) -- diagnostics */
 int clpgpu_get_row_weights(clpgpu_context *ctx, double *weights, double *infeasibility);
 int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats);
+/* option "timing" = 2 (eager launches, a HIP event after every launch of the chain): accumulated time per
+ * kernel of the pivots run so far -- kernel plus the launch gap before it.  names[i] point at static
+ * strings.  Returns the number of kernels seen (fills at most maxKernels). */
+int clpgpu_get_kernel_times(clpgpu_context *ctx, int maxKernels, const char **names, double *milliseconds,
+                            long *launches);
 
 #ifdef __cplusplus
 }
