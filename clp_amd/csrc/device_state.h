@@ -63,7 +63,8 @@ struct Ctrl {
   double norm;
   double bestPossible;
   double scratchSum;
-  double statPriceBytes, statPriceLaunches;
+  double statPriceBytes, statPriceLaunches;  // by-column bytes; launches of either form
+  double statRowBytes, statRowLaunches;      // the by-row form's share
   // CHUZR hand-over between its three kernels
   double chuzrTolerance;
   int chuzrNumber, chuzrStart, chuzrLast, chuzrPad;
@@ -74,6 +75,7 @@ struct Ctrl {
   int ticket[8];        // "last workgroup done" counters (always 0 between launches)
   int ticketGroup[4][64];  // first level of the same: one counter per 32 workgroups (<= 2048 workgroups)
   int flipAppend, numberAppend1;
+  int lastPriceByRow, padRow;  // form the last pricing launch took (k_price_row_finish)
   int appendGo, flipDense;  // flipDense: this pivot's flip rhs is left to k_flip_dense
   int updGo[2], updK, updPad;  // basis-update branch: go flag per pivot parity, k at the time of the fork
   double tailAlpha, tailValueOut;  // w[pivotRow] / sol[sequenceOut] handed to the serial tail of k_ftran_scatter3  // this pivot's primal update completed: its list appends may be scattered  // unordered append count of k_dj_flags (ordered later by k_flip_apply2)
@@ -139,6 +141,10 @@ struct Dev {
   double *candAlpha;
   int *candTag;
   unsigned char *candLive;
+  double *candDj, *candRange;  // [N] dj and upper - lower of every candidate (snapshot taken by k_cand_scatter)
+  int *candBlk, *candRk;       // [N] compaction block of the candidate; its rank among classes <= 0 / 1 / 2 inside that block (10 bits each)
+  double *flipRecMv, *flipRecObj;   // [FLIP_LIST_CAP] per appended flip: movement, objective term
+  int *flipRecStart, *flipRecLen;   // [FLIP_LIST_CAP] its column extent (a row flip: length 1)
   int *blockCount, *blockOffset;
   int *classBlock;  // [3 * blocks] ratio-test breakpoint classes per compaction block
   double *blockMin, *blockSum;
@@ -157,10 +163,7 @@ struct Dev {
   const int *sellRow;
   const double *sellElem;
   int numSlices;
-  // optional SELL copy with L lanes per column (k_price_sellx; option "sell_lanes")
-  const int *sxStart, *sxCol, *sxLen, *sxRow;
-  const double *sxElem;
-  int sxSlices;
+  int *touchCol;  // [n] by-row pricing: contributors per column while a tableau row is assembled (zero otherwise)
   const int *longCol;  // [numLong] columns too long for a SELL lane (a wave strides each)
   int numLong;
   double *sellMin, *sellBytes;  // per pricing workgroup
@@ -172,7 +175,9 @@ struct Dev {
   int *perm;
   double *gjL;  // [kcap * 32] multipliers of the current block (blocked re-inversion)
   double *gjU;  // [32 * 2*ld]  pivot-row values of the current block
-  int *gjPiv;   // [32]
+  int *gjPiv;   // [64]
+  double *gjL2; // [kcap * 64]  multipliers of the current outer block (two-level re-inversion)
+  double *gjU2; // [64 * ld]    its pivot-row values
   Ctrl *ctrl;
   PivotRecord *log;
 };

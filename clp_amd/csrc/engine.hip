@@ -99,12 +99,16 @@ struct clpgpu_context {
   bool denseColumns = false;  // every column holds all m rows in ascending order
   bool wideRows = false;  // mean row length >= 256 (dense LPs): wave-per-row / split-k variants of the row-wise stages
   int blockedRefactor = 1;
+  // option "refactor_mode": -1 auto (two-level in-place re-inversion with the MFMA update from
+  // refactorMinK basic structurals on, the one-level exact form below), 1 one-level, 2 two-level with the
+  // vector update (same bits as 1), 3 two-level with the MFMA update
+  int refactorMode = -1, refactorMinK = 1024;
   int registerPanel = 1;  // option "register_panel": 0 forces the global-memory panel kernel (used for k > 4096)
   // basis update (rank-1 sweep + fix-ups of Minv) on a second stream beside primal update,
   // housekeeping and the next CHUZR; joined before the next BTRAN reads Minv
-  // option "sell_lanes" (1 default; 2/4/8 experimental): lanes per column of the pricing layout
-  int sellLanes = 1, nSxBlocks = 0;
-  int buildSellX();
+  // option "row_price_frac": row pricing goes BY ROW when nnz(pi) <= frac * m (the reference's switch,
+  // src/ClpPackedMatrix.cpp:727-754, with the crossover measured on the MI355X); 0 = always by column
+  double rowPriceFrac = 0.02;
   // option "scaling" (0 off, default; 1/2/3/4 as ClpModel::scaling): set BEFORE clpgpu_load_problem.  The
   // device then holds the scaled LP; solution getters return unscaled values, clpgpu_chg_* take unscaled ones.
   int scalingMode = 0;
@@ -585,6 +589,15 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   rc |= dalloc(D.candAlpha, N);
   rc |= dalloc(D.candTag, N);
   rc |= dalloc(D.candLive, N);
+  rc |= dalloc(D.touchCol, (size_t)n + 1);
+  rc |= dalloc(D.candDj, N);
+  rc |= dalloc(D.candRange, N);
+  rc |= dalloc(D.candBlk, N);
+  rc |= dalloc(D.candRk, N);
+  rc |= dalloc(D.flipRecMv, FLIP_LIST_CAP);
+  rc |= dalloc(D.flipRecObj, FLIP_LIST_CAP);
+  rc |= dalloc(D.flipRecStart, FLIP_LIST_CAP);
+  rc |= dalloc(D.flipRecLen, FLIP_LIST_CAP);
   int nb = cdiv(m, PRICE_BLOCK) + cdiv(n, PRICE_BLOCK) + 2;
   rc |= dalloc(D.blockCount, nb);
   rc |= dalloc(D.blockOffset, nb);
@@ -640,7 +653,6 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   if (commActive)
     applyShard();  // a reload keeps the communicator; the shard follows the new column count
   rc |= buildSell();
-  rc |= buildSellX();
   rc |= sync();
   started = false;
   return rc;
@@ -664,7 +676,7 @@ void clpgpu_context::releaseProblem()
   kcap = ld = 0;
   logCapacity = 0;
   dKcol = dLocalOfRow = dInfo = nullptr;
-  nLongBlocks = nSellBlocks = nChzBlocks = nSxBlocks = 0;
+  nLongBlocks = nSellBlocks = nChzBlocks = 0;
   weightsInitialized = false;
   haveStatus = false;
   userStatus.clear();
@@ -822,92 +834,6 @@ void clpgpu_context::dropGraph()
   graph = nullptr;
 }
 
-// SELL copy with `sellLanes` lanes per column for k_price_sellx (see the comment there).  Separate
-// from buildSell so that the default layout is untouched; long columns (> SELL_LONG) stay with
-// priceLongBody in both.
-int clpgpu_context::buildSellX()
-{
-  const int L = sellLanes;
-  nSxBlocks = 0;
-  D.sxSlices = 0;
-  if (L != 2 && L != 4 && L != 8)
-    return 0;
-  const int first = D.priceFirst, last = D.priceLast;
-  std::vector<int> order;
-  order.reserve(last - first);
-  for (int j = first; j < last; j++)
-    if (colStart[j + 1] - colStart[j] <= SELL_LONG)
-      order.push_back(j);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-    return (colStart[a + 1] - colStart[a]) > (colStart[b + 1] - colStart[b]);
-  });
-  const int count = (int)order.size(), cps = 64 / L;
-  const int numSlices = cdiv(count, cps);
-  std::vector<int> sxStart(numSlices + 1, 0), sxCol((size_t)numSlices * cps, -1), sxLen((size_t)numSlices * cps, 0);
-  for (int s = 0; s < numSlices; s++) {
-    int maxSteps = 0;
-    for (int cidx = 0; cidx < cps; cidx++) {
-      int i = s * cps + cidx;
-      if (i < count) {
-        int j = order[i];
-        sxCol[i] = j;
-        sxLen[i] = colStart[j + 1] - colStart[j];
-        maxSteps = std::max(maxSteps, cdiv(sxLen[i], L));
-      }
-    }
-    maxSteps = cdiv(maxSteps, SELL_U) * SELL_U;
-    sxStart[s + 1] = sxStart[s] + maxSteps * 64;
-  }
-  const size_t total = (size_t)sxStart[numSlices];
-  std::vector<int> sxRow(total ? total : 1, 0);
-  std::vector<double> sxElem(total ? total : 1, 0.0);
-  for (int s = 0; s < numSlices; s++)
-    for (int cidx = 0; cidx < cps; cidx++) {
-      int i = s * cps + cidx;
-      if (i >= count)
-        continue;
-      int j = order[i];
-      for (int p = colStart[j], en = 0; p < colStart[j + 1]; p++, en++) {
-        // entry en of the column: sub-lane en % L at step en / L
-        size_t at = (size_t)sxStart[s] + (size_t)(en / L) * 64 + (size_t)cidx * L + (size_t)(en % L);
-        sxRow[at] = row[p];
-        sxElem[at] = elem[p];
-      }
-    }
-  int *dStart, *dCol, *dLen, *dRow;
-  double *dElem;
-  int rc = 0;
-  rc |= dalloc(dStart, numSlices + 1);
-  rc |= dalloc(dCol, sxCol.size() + 1);
-  rc |= dalloc(dLen, sxLen.size() + 1);
-  rc |= dalloc(dRow, sxRow.size());
-  rc |= dalloc(dElem, sxElem.size());
-  if (rc)
-    return rc;
-  rc |= h2d(dStart, sxStart.data(), numSlices + 1);
-  if (!sxCol.empty()) {
-    rc |= h2d(dCol, sxCol.data(), sxCol.size());
-    rc |= h2d(dLen, sxLen.data(), sxLen.size());
-  }
-  rc |= h2d(dRow, sxRow.data(), sxRow.size());
-  rc |= h2d(dElem, sxElem.data(), sxElem.size());
-  rc |= sync();
-  D.sxStart = dStart;
-  D.sxCol = dCol;
-  D.sxLen = dLen;
-  D.sxRow = dRow;
-  D.sxElem = dElem;
-  D.sxSlices = numSlices;
-  nSxBlocks = cdiv(numSlices, 4);
-  // the per-workgroup outputs of the pricing launch are indexed by workgroup
-  int *dummy = nullptr;
-  (void)dummy;
-  rc |= dalloc(D.sellMin, std::max(std::max(nSellBlocks, nSxBlocks) + nLongBlocks, WIDE_BLOCKS));
-  rc |= dalloc(D.sellBytes, std::max(std::max(nSellBlocks, nSxBlocks) + nLongBlocks, WIDE_BLOCKS));
-  dropGraph();
-  return rc;
-}
-
 int clpgpu_context::allocNucleus(int kNeeded)
 {
   int want = kNeeded + maximumPivots + 16;
@@ -940,7 +866,9 @@ int clpgpu_context::allocNucleus(int kNeeded)
   rc |= dalloc(D.perm, kcap);
   rc |= dalloc(D.gjL, (size_t)kcap * GJ_B);
   rc |= dalloc(D.gjU, (size_t)GJ_B * 2 * ld);
-  rc |= dalloc(D.gjPiv, GJ_B);
+  rc |= dalloc(D.gjPiv, GJ_NB);
+  rc |= dalloc(D.gjL2, (size_t)kcap * GJ_NB);
+  rc |= dalloc(D.gjU2, (size_t)GJ_NB * ld);
   rc |= dalloc(dKcol, kcap);
   dropGraph();
   return rc;
@@ -1029,6 +957,51 @@ int clpgpu_context::factorize()
     hipLaunchKernelGGL(k_gather_nucleus, dim3(k), dim3(64), 0, stream, D, dKcol, dLocalOfRow, k);
     hipLaunchKernelGGL(k_identity, dim3(cdiv(k, 256)), dim3(256), 0, stream, D, k);
     dim3 g2(cdiv(k, 256), k < 1024 ? k : 1024);
+    int mode = refactorMode;
+    if (mode < 0)
+      mode = (blockedRefactor && k >= refactorMinK) ? 3 : 1;
+    if (mode >= 2 && (!blockedRefactor || k > 8192))
+      mode = 1;  // the register panels of the two-level form hold up to 8192 rows
+    if (mode >= 2) {
+      // two-level in-place form (see k_gj2_*): M = workW, identity side implicit
+      const int bIn = k <= 4096 ? 8 : 4;
+      for (int I0 = 0; I0 < k; I0 += GJ_NB) {
+        const int nb = std::min(GJ_NB, k - I0);
+        for (int j0 = 0; j0 < nb; j0 += bIn) {
+          const int i0 = I0 + j0, b = std::min(bIn, nb - j0);
+          GjOut out{ D.gjL2, GJ_NB, j0, j0 };
+          if (k <= 1024)
+            hipLaunchKernelGGL((k_gj_panel_reg<2, 8, 512>), dim3(1), dim3(512), 0, stream, D, i0, b, k, dInfo, out);
+          else if (k <= 2048)
+            hipLaunchKernelGGL((k_gj_panel_reg<4, 8, 512>), dim3(1), dim3(512), 0, stream, D, i0, b, k, dInfo, out);
+          else if (k <= 4096)
+            hipLaunchKernelGGL((k_gj_panel_reg<8, 8, 512>), dim3(1), dim3(512), 0, stream, D, i0, b, k, dInfo, out);
+          else
+            hipLaunchKernelGGL((k_gj_panel_reg<8, 4, 1024>), dim3(1), dim3(1024), 0, stream, D, i0, b, k, dInfo, out);
+          const int c0 = i0 + b, c1 = I0 + nb;
+          if (c1 > c0) {
+            // the rest of the outer panel: this inner panel's swaps, pivot-row values, rank-b update
+            hipLaunchKernelGGL(k_gj2_rowswaps, dim3(cdiv(c1 - c0, 64)), dim3(64), 0, stream, D, i0, b, dInfo, c0, c1, 0, 0, j0);
+            hipLaunchKernelGGL((k_gj2_upanel<8>), dim3(cdiv(c1 - c0, 64)), dim3(64), 0, stream, D, i0, b, dInfo, c0, c1,
+                               (const double *)D.gjL2, GJ_NB, j0, D.gjU, GJ_NB);
+            hipLaunchKernelGGL((k_gj2_trail_vec<8>), dim3(cdiv(c1 - c0, 64), cdiv(k, GJ_ROWS)), dim3(64), 0, stream, D, i0, b, k, dInfo,
+                               c0, c1, (const double *)D.gjL2, GJ_NB, j0, (const double *)D.gjU, GJ_NB);
+          }
+        }
+        // everything outside the outer panel, once per outer block
+        hipLaunchKernelGGL(k_gj2_rowswaps, dim3(cdiv(k, 256)), dim3(256), 0, stream, D, I0, nb, dInfo, 0, k, I0, I0 + nb, 0);
+        hipLaunchKernelGGL(k_gj2_unit, dim3(cdiv(k * nb, 256)), dim3(256), 0, stream, D, I0, nb, k, dInfo);
+        hipLaunchKernelGGL((k_gj2_upanel<GJ_NB>), dim3(cdiv(k, 256)), dim3(256), 0, stream, D, I0, nb, dInfo, 0, k, (const double *)D.gjL2,
+                           GJ_NB, 0, D.gjU2, ld);
+        if (mode == 3)
+          hipLaunchKernelGGL(k_gj2_trail_mfma, dim3(cdiv(k, 64), cdiv(k, 64)), dim3(256), 0, stream, D, I0, nb, k, dInfo,
+                             (const double *)D.gjL2, GJ_NB, (const double *)D.gjU2, ld);
+        else
+          hipLaunchKernelGGL((k_gj2_trail_vec<GJ_NB>), dim3(cdiv(k, 256), cdiv(k, GJ_ROWS)), dim3(256), 0, stream, D, I0, nb, k, dInfo, 0, k,
+                             (const double *)D.gjL2, GJ_NB, 0, (const double *)D.gjU2, ld);
+      }
+      hipLaunchKernelGGL(k_gj2_finish, g2, dim3(256), 0, stream, D, k);
+    } else {
     if (blockedRefactor) {
       // panel width: the register-resident panel kernel holds rows-per-thread x width doubles
       const int kp = registerPanel ? k : 1 << 30;  // which panel kernel (and width) this k gets
@@ -1057,6 +1030,7 @@ int clpgpu_context::factorize()
       }
     }
     hipLaunchKernelGGL(k_gj_finish, g2, dim3(256), 0, stream, D, k);
+    }
     if (checkLaunches("factorize"))
       return -99;
     int info[4];
@@ -1935,26 +1909,25 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   // (not column-sharded: the candidate counts come from this kernel and the pricing kernel, there
   // is no separate counting launch)
   const bool countInPrice = priceKernel >= 1 && !commActive && nb > 256;
-  // experimental multi-lane pricing layout (needs the LDS bitmap: m <= 64 * SELL_BITS_MAX)
-  const bool sellX = sellLanes > 1 && nSxBlocks > 0 && priceKernel >= 2 && !widePricing && m <= 64 * SELL_BITS_MAX;
-  KL("k_rho_finish3", k_rho_finish3, dim3(gm), dim3(256), 0, stream, D, wideRows ? 1 : 0, countInPrice ? nbCols : -1);
+  // by-row pricing for sparse pi (needs the bitmap and the count-in-price compaction scheme)
+  const int nSlots = nSellBlocks + nLongBlocks;
+  const int rowMax = (rowPriceFrac > 0.0 && countInPrice && !widePricing && priceKernel >= 2 && m <= 64 * SELL_BITS_MAX && nSlots > 0)
+                         ? std::max(1, (int)(rowPriceFrac * m))
+                         : 0;
+  KL("k_rho_finish3", k_rho_finish3, dim3(gm), dim3(256), 0, stream, D, wideRows ? 1 : 0, countInPrice ? nbCols : -1, rowMax > 0 ? nSlots : 0);
   // PRICE + first ratio pass
   if (ev)
     (void)hipEventRecord(evStart[evUsed], stream);
   if (priceKernel >= 1) {
     if (widePricing && priceKernel != 1)
       KL("k_price_wide", k_price_wide, dim3(nWideBlocks), dim3(256), 0, stream, D, denseColumns ? 1 : 0, countInPrice ? 1 : 0);
-    else if (sellX) {
-      const size_t lds = (size_t)((m + 63) / 64) * 8;
-      if (sellLanes == 2)
-        KL("k_price_sellx", (k_price_sellx<2>), dim3(nSxBlocks + nLongBlocks), dim3(256), lds, stream, D, countInPrice ? 1 : 0, nSxBlocks);
-      else if (sellLanes == 4)
-        KL("k_price_sellx", (k_price_sellx<4>), dim3(nSxBlocks + nLongBlocks), dim3(256), lds, stream, D, countInPrice ? 1 : 0, nSxBlocks);
-      else
-        KL("k_price_sellx", (k_price_sellx<8>), dim3(nSxBlocks + nLongBlocks), dim3(256), lds, stream, D, countInPrice ? 1 : 0, nSxBlocks);
-    } else if (nSellBlocks + nLongBlocks > 0)
-      KL("k_price_sell", k_price_sell, dim3(nSellBlocks + nLongBlocks), dim3(256), (m > 64 * SELL_BITS_MAX || priceKernel < 2) ? 0 : (size_t)((m + 63) / 64) * 8, stream, D, (m > 64 * SELL_BITS_MAX && priceKernel > 1) ? 1 : priceKernel,
-                         countInPrice ? 1 : 0, nSellBlocks);
+    else if (nSlots > 0) {
+      KL("k_price_sell", k_price_sell, dim3(nSlots + (rowMax > 0 ? gm : 0)), dim3(256),
+         (m > 64 * SELL_BITS_MAX || priceKernel < 2) ? 0 : (size_t)((m + 63) / 64) * 8, stream, D,
+         (m > 64 * SELL_BITS_MAX && priceKernel > 1) ? 1 : priceKernel, countInPrice ? 1 : 0, nSellBlocks, nSlots, rowMax);
+      if (rowMax > 0)
+        KL("k_price_row_finish", k_price_row_finish, dim3(nbCols), dim3(PRICE_BLOCK), 0, stream, D, nbRows, rowMax);
+    }
     if (ev)
       (void)hipEventRecord(evStop[evUsed++], stream);
     if (commActive) {
@@ -1965,7 +1938,7 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
       ncclAllGatherFn(D.candFlag + D.m + (size_t)rank * chunk, D.candFlag + D.m, chunk, 1 /* ncclUint8 */, comm, stream);
     }
     {
-      const int nSell = (widePricing && priceKernel != 1) ? nWideBlocks : (sellX ? nSxBlocks : nSellBlocks) + nLongBlocks;
+      const int nSell = (widePricing && priceKernel != 1) ? nWideBlocks : nSellBlocks + nLongBlocks;
       const bool fuse = nb <= 256;  // small grids: the last workgroup scans the counts itself
       if (!countInPrice)
         KL("k_cand_count", k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, commActive ? 1 : 0, fuse ? nSell : -1);
@@ -1981,7 +1954,8 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   // CHUZC (also unpacks the entering column)
   KL("k_dual_column", k_dual_column, dim3(1), dim3(DC_THREADS), 0, stream, D, nb);
   // dual update + flip detection (needs only theta), flip list, flip right-hand side
-  KL("k_dj_flags", k_dj_flags, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, flipListCap);
+  // (+ 1: the extra workgroup unpacks the entering column)
+  KL("k_dj_flags", k_dj_flags, dim3(nb + 1), dim3(PRICE_BLOCK), 0, stream, D, nbRows, flipListCap);
   KL("k_flip_apply2", k_flip_apply2, dim3(1), dim3(1024), 0, stream, D, gm, denseColumns ? 1 : 0, flipListCap);
   if (denseColumns)
     KL("k_flip_dense", k_flip_dense, dim3(gm), dim3(256), 0, stream, D);
@@ -2100,6 +2074,7 @@ int clpgpu_context::whileIterating(int stepTarget)
   while (!rc) {
     evUsed = 0;
     double launchesBefore = hCtrl->statPriceLaunches;
+    const int logBefore = hCtrl->logCount;
     rc |= launchBatch();
     rc |= pullCtrl();
     if (timing) {
@@ -2107,11 +2082,20 @@ int clpgpu_context::whileIterating(int stepTarget)
       int timed = (int)(hCtrl->statPriceLaunches - launchesBefore);
       if (timed > evUsed)
         timed = evUsed;
+      // which form each of those pivots priced with: bit 30 of its log record
+      std::vector<PivotRecord> recs(timed > 0 ? timed : 1);
+      const int firstRec = logBefore;
+      const bool haveRecs = timed > 0 && firstRec + timed <= logCapacity && !d2h(recs.data(), D.log + firstRec, timed);
       for (int i = 0; i < timed; i++) {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, evStart[i], evStop[i]) == hipSuccess) {
-          stats.price_ms += ms;
-          stats.price_launches++;
+          if (haveRecs && (recs[i].reserved >> 30) & 1) {
+            stats.row_ms += ms;
+            stats.row_launches++;
+          } else {
+            stats.price_ms += ms;
+            stats.price_launches++;
+          }
         }
       }
       if (timing >= 2)
@@ -2139,6 +2123,7 @@ int clpgpu_context::whileIterating(int stepTarget)
     hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, stream, D.flipRhs, m);
     hipLaunchKernelGGL(k_zero, dim3(cdiv(kcap, 256)), dim3(256), 0, stream, D.slotV1, kcap);
     hipLaunchKernelGGL(k_zero, dim3(cdiv(kcap, 256)), dim3(256), 0, stream, D.flipSlot, kcap);
+    hipLaunchKernelGGL(k_zero, dim3(cdiv(n, 256)), dim3(256), 0, stream, D.alphaCol, n);
   }
   switch (state) {
   case EXIT_STEP_LIMIT:
@@ -2348,15 +2333,26 @@ int clpgpu_context::priceRow(int numberPi, const int *piIndex, const double *piV
   const int nbCols = cdiv(D.lastColumn - D.firstColumn, PRICE_BLOCK);
   const int nb = nbRows + nbCols;
   hipLaunchKernelGGL(k_zero, dim3(cdiv(n, 256)), dim3(256), 0, stream, D.alphaCol, n);
-  if (priceKernel >= 1) {
-    if (nSellBlocks + nLongBlocks > 0)
-      hipLaunchKernelGGL(k_price_sell, dim3(nSellBlocks + nLongBlocks), dim3(256), 0, stream, D, 1, 0, nSellBlocks);
-    hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, 0, nSellBlocks + nLongBlocks);
+  const int nSlots = nSellBlocks + nLongBlocks;
+  // the reference's switch (src/ClpPackedMatrix.cpp:727-754) with this engine's crossover: option row_price_frac
+  const bool byRow = priceKernel >= 1 && rowPriceFrac > 0.0 && (double)numberPi <= rowPriceFrac * m && nSlots > 0 && !widePricing;
+  if (byRow) {
+    // by row: row part + bitmap + neutral per-block values, the two passes, then the self-scanning compaction
+    hipLaunchKernelGGL(k_price_row_init, dim3(nbRows), dim3(PRICE_BLOCK), 0, stream, D, nbCols, nSlots);
+    hipLaunchKernelGGL(k_price_sell, dim3(nSlots + nbRows), dim3(256), 0, stream, D, 1, 1, nSellBlocks, nSlots, m + 1, 1);
+    hipLaunchKernelGGL(k_price_row_finish, dim3(nbCols), dim3(PRICE_BLOCK), 0, stream, D, nbRows, m + 1);
+    hipLaunchKernelGGL(k_cand_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, nSlots);
+  } else if (priceKernel >= 1) {
+    if (nSlots > 0)
+      hipLaunchKernelGGL(k_price_sell, dim3(nSlots), dim3(256), 0, stream, D, 1, 0, nSellBlocks);
+    hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, 0, nSlots);
   } else {
     hipLaunchKernelGGL(k_price, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1, 0);
   }
-  hipLaunchKernelGGL(k_cand_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
+  if (!byRow)
+    hipLaunchKernelGGL(k_cand_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
+  rc |= checkLaunches("clpgpu_price_row");
   rc |= pullCtrl();
   std::vector<double> alpha(n);
   rc |= d2h(alpha.data(), D.alphaCol, n);
@@ -2469,7 +2465,7 @@ int clpgpu_set_column_range(clpgpu_context *ctx, int firstColumn, int lastColumn
   ctx->D.firstColumn = ctx->D.priceFirst = firstColumn;
   ctx->D.lastColumn = ctx->D.priceLast = lastColumn;
   int rc = ctx->buildSell();
-  return rc ? rc : ctx->buildSellX();
+  return rc;
 }
 
 int clpgpu_times(clpgpu_context *ctx, double scalar, const double *x, double *y)
@@ -2926,7 +2922,7 @@ clpgpu_context *clpgpu_clone(const clpgpu_context *src)
   ctx->useGraph = src->useGraph;
   ctx->blockedRefactor = src->blockedRefactor;
   ctx->registerPanel = src->registerPanel;
-  ctx->sellLanes = src->sellLanes;
+  ctx->rowPriceFrac = src->rowPriceFrac;
   ctx->scalingMode = src->scalingMode;
   ctx->flipListCap = src->flipListCap;
   ctx->haveExternalScales = src->haveExternalScales;
@@ -3039,7 +3035,7 @@ int clpgpu_comm_init(clpgpu_context *ctx, int rank, int nranks, const void *id12
   ctx->applyShard();
   ctx->useGraph = 0;  // collectives are enqueued between kernels; keep the eager chain
   rc = ctx->buildSell();
-  return rc ? rc : ctx->buildSellX();
+  return rc;
 }
 
 int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
@@ -3086,13 +3082,10 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "use_graph")) { ctx->useGraph = (int)v; ctx->dropGraph(); }
   else if (!strcmp(name, "blocked_refactor")) ctx->blockedRefactor = (int)v;
   else if (!strcmp(name, "register_panel")) ctx->registerPanel = (int)v;
+  else if (!strcmp(name, "refactor_mode")) ctx->refactorMode = (int)v;
+  else if (!strcmp(name, "refactor_min_k")) ctx->refactorMinK = (int)v;
   else if (!strcmp(name, "fork_update")) { ctx->forkUpdate = (int)v; ctx->dropGraph(); }
-  else if (!strcmp(name, "sell_lanes")) {
-    ctx->sellLanes = (int)v;
-    ctx->dropGraph();
-    if (ctx->n > 0 && ctx->D.colStart)  // already loaded: build (or drop) the extra copy now
-      return ctx->buildSellX();
-  }
+  else if (!strcmp(name, "row_price_frac")) { ctx->rowPriceFrac = v < 0.0 ? 0.0 : v; ctx->dropGraph(); }
   else if (!strcmp(name, "scaling")) {
     if (ctx->n > 0 && ctx->D.colStart)
       return -2;  // the matrix is already on the device in its current units: set before clpgpu_load_problem
@@ -3326,8 +3319,11 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
             g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9], g[10], g[11], g[12]);
   }
   stats->price_bytes = ctx->hCtrl->statPriceBytes;
-  if (!ctx->timing)
-    stats->price_launches = (long)ctx->hCtrl->statPriceLaunches;
+  stats->row_bytes = ctx->hCtrl->statRowBytes;
+  if (!ctx->timing) {
+    stats->row_launches = (long)ctx->hCtrl->statRowLaunches;
+    stats->price_launches = (long)(ctx->hCtrl->statPriceLaunches - ctx->hCtrl->statRowLaunches);
+  }
   stats->total_ms = ctx->seconds * 1.0e3;
   stats->iterations = ctx->numberIterations;
   stats->refactorizations = ctx->numberRefactorizations;

@@ -491,7 +491,13 @@ template <bool COHERENT> __device__ inline void scanBlocksBody(const Dev &D, int
       c->upperTheta = vmin;
       // algorithmic bytes of this pricing launch: per scanned column 12*len+4 (+20 per
       // emitted nonzero), plus status 1*n, pi 8*m, one extra colStart
-      c->statPriceBytes += bytes + (double)(D.lastColumn - D.firstColumn) + 8.0 * D.m + 4.0;
+      if (c->lastPriceByRow) {
+        // B_row: 12 B per visited row entry and per pi nonzero, 8 per touched column, 20 per emitted one
+        c->statRowBytes += bytes;
+        c->statRowLaunches += 1.0;
+      } else {
+        c->statPriceBytes += bytes + (double)(D.lastColumn - D.firstColumn) + 8.0 * D.m + 4.0;
+      }
       c->statPriceLaunches += 1.0;
     } else if (what == 1) {
       c->numberFlips = s_base;
@@ -591,7 +597,13 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_cand_scatter(Dev D, int nbRows,
           c->numberCandidates = all;
           c->upperTheta = upperTheta;
           // algorithmic bytes of this pricing launch, as in scanBlocksBody
-          c->statPriceBytes += bytes + (double)(D.lastColumn - D.firstColumn) + 8.0 * D.m + 4.0;
+          if (c->lastPriceByRow) {
+            // B_row: 12 B per visited row entry and per pi nonzero, 8 per touched column, 20 per emitted one
+            c->statRowBytes += bytes;
+            c->statRowLaunches += 1.0;
+          } else {
+            c->statPriceBytes += bytes + (double)(D.lastColumn - D.firstColumn) + 8.0 * D.m + 4.0;
+          }
           c->statPriceLaunches += 1.0;
         }
       }
@@ -601,26 +613,44 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_cand_scatter(Dev D, int nbRows,
     upperTheta = c->upperTheta;
   }
   int cls = 3;
+  int o = -1;
   if (flag) {
-    int o = offset + rank;
+    o = offset + rank;
     D.candSeq[o] = seq;
     D.candAlpha[o] = alpha;
     // breakpoint of the coarse ratio passes (ClpSimplexDual.cpp:4384 / :4412) against theta0
     const double tol = c->dualTolerance;
     const double djv = D.dj[seq];
+    const double range = D.upper[seq] - D.lower[seq];
     const double x = (alpha < 0.0) ? (djv - tol) / alpha : (djv + tol) / alpha;
     const double theta0 = fmax(10.0 * upperTheta, 1.0e-7);
     cls = (x <= theta0 * 8.0) ? 0 : ((x <= theta0 * 256.0) ? 1 : ((x <= theta0 * 16384.0) ? 2 : 3));
     D.candLive[o] = (unsigned char)cls;
+    // what the ratio test reads per candidate, gathered here by the whole chip instead of by its one workgroup
+    D.candDj[o] = djv;
+    D.candRange[o] = range;
   }
-  // per-class counts of this block (summed by the ratio test when it needs them)
+  // per-class counts of this block (summed by the ratio test when it needs them) and, per candidate,
+  // how many candidates of each class precede it inside the block: the ratio test's working set (all
+  // candidates of class <= J) is then placed by  prefix[block] + rank  with no serial pass
   __shared__ int shc[PRICE_BLOCK / 64][3];
+  int before[3];
+  const int lane = threadIdx.x & 63, wvi = threadIdx.x >> 6;
   for (int j = 0; j < 3; j++) {
     unsigned long long mk = __ballot(cls == j);
-    if ((threadIdx.x & 63) == 0)
-      shc[threadIdx.x >> 6][j] = (int)__popcll(mk);
+    before[j] = (int)__popcll(mk & ((1ull << lane) - 1ull));
+    if (lane == 0)
+      shc[wvi][j] = (int)__popcll(mk);
   }
   __syncthreads();
+  if (flag) {
+    for (int j = 0; j < 3; j++)
+      for (int w = 0; w < wvi; w++)
+        before[j] += shc[w][j];
+    const int r0 = before[0], r1 = r0 + before[1], r2 = r1 + before[2];
+    D.candRk[o] = r0 | (r1 << 10) | (r2 << 20);
+    D.candBlk[o] = (int)blockIdx.x;
+  }
   if (threadIdx.x < 3) {
     int s = 0;
     for (int w = 0; w < PRICE_BLOCK / 64; w++)
@@ -790,23 +820,29 @@ __device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nu
   };
   bool rl[R];
   if constexpr (CPT > 0) {
+    // alpha, dj and range of every candidate this thread owns, one round of loads (the snapshots
+    // k_cand_scatter left by candidate index; dj is not touched between there and here)
 #pragma unroll
     for (int q = 0; q < R; q++) {
-      int pos = tid + q * nthr;
-      rl[q] = false;
+      const int pos = tid + q * nthr;
+      rl[q] = pos < nc;
+      ri[q] = rl[q] ? (MAPPED ? map[pos] : pos) : 0;  // original candidate index: the list order for ties
+    }
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      ra[q] = D.candAlpha[ri[q]];
+      rd[q] = D.candDj[ri[q]];
+      rr[q] = D.candRange[ri[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < R; q++) {
       rt[q] = -1;
-      ri[q] = -1;
-      ra[q] = rd[q] = rr[q] = 0.0;
-      rq[q] = 1.0e50;
-      if (pos < nc) {
-        int i = MAPPED ? map[pos] : pos;  // original candidate index: the list order for ties
-        ri[q] = i;
-        int seq = D.candSeq[i];
-        ra[q] = D.candAlpha[i];
-        rd[q] = D.dj[seq];
-        rr[q] = D.upper[seq] - D.lower[seq];
+      if (rl[q]) {
         rq[q] = breakpoint(ra[q], rd[q]);
-        rl[q] = true;
+      } else {
+        ri[q] = -1;
+        ra[q] = rd[q] = rr[q] = 0.0;
+        rq[q] = 1.0e50;
       }
     }
   } else {
@@ -825,11 +861,10 @@ __device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nu
       }
     } else {
       for (int i = tid; i < nc; i += nthr) {
-        int seq = D.candSeq[i];
         bool live = D.candLive[i] != 0;
         int tag = D.candTag[i];
-        double alpha = D.candAlpha[i], djv = D.dj[seq];
-        body(i, alpha, djv, D.upper[seq] - D.lower[seq], breakpoint(alpha, djv), live, tag);
+        double alpha = D.candAlpha[i], djv = D.candDj[i];
+        body(i, alpha, djv, D.candRange[i], breakpoint(alpha, djv), live, tag);
         D.candLive[i] = live ? 1 : 0;
         D.candTag[i] = tag;
       }
@@ -1081,26 +1116,7 @@ __device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nu
     if (tid == 0)
       c->acceptablePivotBase = -c->acceptablePivotBase;
   }
-  // unpack the entering column (ClpSimplex::unpackPacked :3439-3495): by row, and by nucleus
-  // row-slot for the FTRAN sweep
-  if (sequenceIn >= D.n) {
-    if (tid == 0) {
-      const int r = sequenceIn - D.n;
-      D.vecV1[r] = -1.0;
-      const int sr = D.slotOfRow[r];
-      if (sr >= 0)
-        D.slotV1[sr] = -1.0;
-    }
-  } else if (sequenceIn >= 0) {
-    for (int p = D.colStart[sequenceIn] + tid; p < D.colStart[sequenceIn + 1]; p += nthr) {
-      const int r = D.row[p];
-      const double e = D.elem[p];
-      D.vecV1[r] = e;
-      const int sr = D.slotOfRow[r];
-      if (sr >= 0)
-        D.slotV1[sr] = e;
-    }
-  }
+  // (the entering column is unpacked by an extra workgroup of k_dj_flags, off this kernel's critical path)
   if (tid == 0) {
     c->dbg[ONEWAVE ? 0 : 1]++;
     c->dbg[2] += dbgPasses;
@@ -1156,6 +1172,8 @@ __device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nu
 #define DC_THREADS 512
 #define DC_SMALL (8 * 64)
 #define DC_WS_CAP (DC_CPT * DC_THREADS)
+#define DC_NB_PER 8                          // compaction blocks per thread of the class-prefix scan
+#define DC_NB_MAX (DC_NB_PER * DC_THREADS)   // beyond this many blocks (N > 1M) the working set is not used
 // One launch, 512 threads (256 VGPRs per lane available: no spills).
 //  * typical sparse tableau row (<= 512 candidates): wave 0 alone, candidates in registers,
 //    reductions are register butterflies -- no LDS, no barrier;
@@ -1194,75 +1212,111 @@ __global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass)
   __shared__ int shw[17];
   __shared__ int s_done;
   __shared__ int shCls[DC_THREADS / 64][3];
-  int cum[3] = { 0, 0, 0 };
-  for (int b = tid; b < nbClass; b += blockDim.x) {
-    cum[0] += D.classBlock[3 * b];
-    cum[1] += D.classBlock[3 * b + 1];
-    cum[2] += D.classBlock[3 * b + 2];
-  }
-  for (int j = 0; j < 3; j++) {
-    for (int o = 32; o > 0; o >>= 1)
-      cum[j] += __shfl_xor(cum[j], o);
-    if ((tid & 63) == 0)
-      shCls[tid >> 6][j] = cum[j];
-  }
-  __syncthreads();
-  for (int j = 0; j < 3; j++) {
-    cum[j] = 0;
-    for (int w = 0; w < DC_THREADS / 64; w++)
-      cum[j] += shCls[w][j];
-  }
-  cum[1] += cum[0];
-  cum[2] += cum[1];
-  int J = -1;
-  for (int j = 0; j < 3; j++)
-    if (cum[j] <= DC_WS_CAP && cum[j] < nc)
-      J = j;
-  if (J >= 0 && cum[J] > 0) {
-    const int ws = cum[J];
-    const double theta0 = fmax(10.0 * c->upperTheta, 1.0e-7);
-    const double tau = theta0 * (J == 0 ? 8.0 : (J == 1 ? 256.0 : 16384.0));
-    // ordered compaction of the working set (thread t owns a contiguous slice of the list)
-    const int per = (nc + (int)blockDim.x - 1) / (int)blockDim.x;
-    const int lo = min(nc, tid * per), hi = min(nc, lo + per);
-    int cnt = 0;
-    for (int i = lo; i < hi; i++)
-      cnt += (D.candLive[i] <= J);
+  __shared__ int s_pre[DC_NB_MAX];
+  if (nbClass <= DC_NB_MAX) {
+    // class totals, and -- once the class prefix J is chosen -- the exclusive prefix over the compaction
+    // blocks of their (class <= J) counts.  Thread t owns DC_NB_PER consecutive blocks; all their counts
+    // are requested together.
     const int lane = tid & 63, wv = tid >> 6;
-    int v = cnt;
-    for (int o = 1; o < 64; o <<= 1) {
-      int t = __shfl_up(v, o);
-      if (lane >= o)
-        v += t;
+    int c0[DC_NB_PER], c1[DC_NB_PER], c2[DC_NB_PER];
+    int cum[3] = { 0, 0, 0 };
+#pragma unroll
+    for (int u = 0; u < DC_NB_PER; u++) {
+      const int bb = tid * DC_NB_PER + u;
+      c0[u] = bb < nbClass ? D.classBlock[3 * bb] : 0;
+      c1[u] = bb < nbClass ? D.classBlock[3 * bb + 1] : 0;
+      c2[u] = bb < nbClass ? D.classBlock[3 * bb + 2] : 0;
     }
-    if (lane == 63)
-      shw[wv] = v;
+#pragma unroll
+    for (int u = 0; u < DC_NB_PER; u++) {
+      cum[0] += c0[u];
+      cum[1] += c1[u];
+      cum[2] += c2[u];
+    }
+    for (int j = 0; j < 3; j++) {
+      for (int o = 32; o > 0; o >>= 1)
+        cum[j] += __shfl_xor(cum[j], o);
+      if (lane == 0)
+        shCls[wv][j] = cum[j];
+    }
     __syncthreads();
-    int base = 0;
-    for (int i = 0; i < wv; i++)
-      base += shw[i];
-    int o = base + v - cnt;
-    for (int i = lo; i < hi; i++)
-      if (D.candLive[i] <= J)
-        wsIdx[o++] = i;
-    if (tid == 0)
-      s_done = 0;
-    __syncthreads();
-    bool ok;
-    if (ws <= DC_SMALL) {
-      if (tid < 64) {
-        ok = dualColumnImpl<8, true, true>(D, wsIdx, ws, tau);
-        if (tid == 0)
-          s_done = ok ? 1 : 0;
+    for (int j = 0; j < 3; j++) {
+      cum[j] = 0;
+      for (int w = 0; w < DC_THREADS / 64; w++)
+        cum[j] += shCls[w][j];
+    }
+    cum[1] += cum[0];
+    cum[2] += cum[1];
+    int J = -1;
+    for (int j = 0; j < 3; j++)
+      if (cum[j] <= DC_WS_CAP && cum[j] < nc)
+        J = j;
+    if (J >= 0 && cum[J] > 0) {
+      const int ws = cum[J];
+      const double theta0 = fmax(10.0 * c->upperTheta, 1.0e-7);
+      const double tau = theta0 * (J == 0 ? 8.0 : (J == 1 ? 256.0 : 16384.0));
+      // exclusive scan of the per-block working-set counts
+      int mine = 0;
+#pragma unroll
+      for (int u = 0; u < DC_NB_PER; u++)
+        mine += c0[u] + (J >= 1 ? c1[u] : 0) + (J >= 2 ? c2[u] : 0);
+      int v = mine;
+      for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(v, o);
+        if (lane >= o)
+          v += t;
+      }
+      if (lane == 63)
+        shw[wv] = v;
+      __syncthreads();
+      int base = 0;
+      for (int i = 0; i < wv; i++)
+        base += shw[i];
+      int run = base + v - mine;
+#pragma unroll
+      for (int u = 0; u < DC_NB_PER; u++) {
+        const int bb = tid * DC_NB_PER + u;
+        if (bb < nbClass)
+          s_pre[bb] = run;
+        run += c0[u] + (J >= 1 ? c1[u] : 0) + (J >= 2 ? c2[u] : 0);
+      }
+      if (tid == 0)
+        s_done = 0;
+      __syncthreads();
+      // every candidate of class <= J drops its index at prefix[its block] + its rank inside the block
+      // (both recorded by k_cand_scatter): ordered, and four independent loads in flight per thread
+      const int shift = 10 * J;
+      for (int i0 = 0; i0 < nc; i0 += 4 * DC_THREADS) {
+        int cl[4], bk[4], rk[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = i0 + u * DC_THREADS + tid;
+          cl[u] = i < nc ? (int)D.candLive[i] : 9;
+          bk[u] = i < nc ? D.candBlk[i] : 0;
+          rk[u] = i < nc ? D.candRk[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (cl[u] <= J)
+            wsIdx[s_pre[bk[u]] + ((rk[u] >> shift) & 1023)] = i0 + u * DC_THREADS + tid;
       }
       __syncthreads();
-      ok = s_done != 0;
-    } else {
-      ok = dualColumnImpl<DC_CPT, false, true>(D, wsIdx, ws, tau);
+      bool ok;
+      if (ws <= DC_SMALL) {
+        if (tid < 64) {
+          ok = dualColumnImpl<8, true, true>(D, wsIdx, ws, tau);
+          if (tid == 0)
+            s_done = ok ? 1 : 0;
+        }
+        __syncthreads();
+        ok = s_done != 0;
+      } else {
+        ok = dualColumnImpl<DC_CPT, false, true>(D, wsIdx, ws, tau);
+      }
+      if (ok)
+        return;
+      __syncthreads();
     }
-    if (ok)
-      return;
-    __syncthreads();
   }
   if (nc <= DC_CPT * (int)blockDim.x) {
     dualColumnImpl<DC_CPT, false>(D);
@@ -1824,7 +1878,8 @@ __device__ void houseBody(Dev D, int skipColumns = 0)
     r->sequenceOut = seqOut;
     r->pivotRow = pivotRow;
     r->numberFlipped = c->numberFlips;
-    r->reserved = c->numberCandidates;  // length of the ratio-test candidate list (diagnostics)
+    // length of the ratio-test candidate list; bit 30: the tableau row was priced by row (diagnostics)
+    r->reserved = c->numberCandidates | (c->lastPriceByRow << 30);
     r->theta = c->theta;
     r->alpha = c->alpha;
     r->dualOut = dualOut;
@@ -1928,7 +1983,7 @@ __global__ void k_chuzr_pre(Dev D)
   chuzrPreBody(D);
 }
 
-#define CHZ_ITEMS 4
+#define CHZ_ITEMS 2
 template <bool COHERENT> __device__ inline void chuzrFinalBody(const Dev &D, int nblocks, int wide);
 // fuseFinal >= 0: the last workgroup to finish also makes the final selection and builds the BTRAN
 // t-vector (no separate launch); the value is the wide-row flag of that stage
@@ -1944,42 +1999,59 @@ __global__ void __launch_bounds__(256) k_chuzr_scan(Dev D, int fuseFinal = -1)
   double best = 0.0;
   int bestKey = -1, bestRow = -1;
   const int base = blockIdx.x * (256 * CHZ_ITEMS);
+  // the chain list entry -> row -> basic variable -> its value and bounds is three dependent loads
+  // deep: every level is requested for all of this thread's items before anything is used
+  int idx[CHZ_ITEMS], iRow[CHZ_ITEMS], iSeq[CHZ_ITEMS];
+  double value[CHZ_ITEMS], rawWeight[CHZ_ITEMS], sv[CHZ_ITEMS], up[CHZ_ITEMS], lo[CHZ_ITEMS];
+  unsigned char st[CHZ_ITEMS];
+  const bool steepest = c->pivotRule != 0;
 #pragma unroll
   for (int q = 0; q < CHZ_ITEMS; q++) {
-    int i = base + q * 256 + threadIdx.x;
-    if (i >= number)
+    idx[q] = base + q * 256 + threadIdx.x;
+    iRow[q] = idx[q] < number ? (steepest ? D.infIndex[idx[q]] : idx[q]) : -1;
+  }
+#pragma unroll
+  for (int q = 0; q < CHZ_ITEMS; q++) {
+    const int r = iRow[q] >= 0 ? iRow[q] : 0;
+    value[q] = steepest ? D.infeas[r] : 0.0;
+    rawWeight[q] = steepest ? D.weights[r] : 1.0;
+    iSeq[q] = D.pivotVariable[r];
+  }
+#pragma unroll
+  for (int q = 0; q < CHZ_ITEMS; q++) {
+    st[q] = D.status[iSeq[q]];
+    sv[q] = D.sol[iSeq[q]];
+    up[q] = D.upper[iSeq[q]];
+    lo[q] = D.lower[iSeq[q]];
+  }
+#pragma unroll
+  for (int q = 0; q < CHZ_ITEMS; q++) {
+    if (iRow[q] < 0)
       continue;
-    if (c->pivotRule) {
-      int iRow = D.infIndex[i];
-      // everything indexed by the row is requested together (one round trip, not three)
-      double value = D.infeas[iRow];
-      const double rawWeight = D.weights[iRow];
-      const int iSequence = D.pivotVariable[iRow];
-      if (value > tolerance) {
-        double weight = fmin(rawWeight, 1.0e50);
-        if (iRow == last)
-          value *= 1.0e-10;
-        const unsigned char st = D.status[iSequence];
-        const double s = D.sol[iSequence], up = D.upper[iSequence], lo = D.lower[iSequence];
-        if (!(st & FLAGGED_BIT)) {
-          if (s > up + tolerance || s < lo - tolerance) {
-            double ratio = value / weight;
+    const int i = idx[q];
+    if (steepest) {
+      double v = value[q];
+      if (v > tolerance) {
+        double weight = fmin(rawWeight[q], 1.0e50);
+        if (iRow[q] == last)
+          v *= 1.0e-10;
+        if (!(st[q] & FLAGGED_BIT)) {
+          if (sv[q] > up[q] + tolerance || sv[q] < lo[q] - tolerance) {
+            double ratio = v / weight;
             int rank = i - start;
             if (rank < 0)
               rank += number;
             if (ratio > best || (ratio == best && bestKey >= 0 && rank < bestKey)) {
               best = ratio;
               bestKey = rank;
-              bestRow = iRow;
+              bestRow = iRow[q];
             }
           }
         }
       }
     } else {
-      int iSequence = D.pivotVariable[i];
-      double value = D.sol[iSequence];
-      double infeas = fmax(value - D.upper[iSequence], D.lower[iSequence] - value);
-      if (infeas > tolerance && !(D.status[iSequence] & FLAGGED_BIT)) {
+      double infeas = fmax(sv[q] - up[q], lo[q] - sv[q]);
+      if (infeas > tolerance && !(st[q] & FLAGGED_BIT)) {
         if (infeas > best || (infeas == best && bestKey >= 0 && i < bestKey)) {
           best = infeas;
           bestKey = i;
@@ -2022,7 +2094,7 @@ __global__ void __launch_bounds__(256) k_chuzr_scan(Dev D, int fuseFinal = -1)
 
 // iteration BTRAN, back end: rho[i] = slack part or sum of the gemvT partials, flush tiny, piNeg,
 // rhoSlot (unpruned, for the nucleus update) and the per-block partial of sum rho^2 (DSE norm)
-__global__ void __launch_bounds__(256) k_rho_finish3(Dev D, int wide = 0, int nbCols = -1)
+__global__ void __launch_bounds__(256) k_rho_finish3(Dev D, int wide = 0, int nbCols = -1, int nSlots = 0)
 {
   const Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -2106,6 +2178,11 @@ __global__ void __launch_bounds__(256) k_rho_finish3(Dev D, int wide = 0, int nb
       D.blockCount[gridDim.x + g] = 0;
       D.blockMin[gridDim.x + g] = 1.0e31;
       D.blockSum[gridDim.x + g] = 0.0;
+    }
+    // the per-workgroup slots of the by-column kernels: the by-row form leaves them untouched
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < nSlots; g += gridDim.x * blockDim.x) {
+      D.sellMin[g] = 1.0e31;
+      D.sellBytes[g] = 0.0;
     }
   }
 }
@@ -2390,141 +2467,237 @@ __device__ inline void priceLongBody(const Dev &D, int blk, int countCols)
   }
 }
 
-// Experimental layout (option "sell_lanes" = 2, 4 or 8; not the default): L adjacent lanes share one
-// column, so a wave owns 64/L columns and a column of length len takes len/(8 L) trips instead of
-// len/8.  With one lane per column the 200 000 columns of config 4 are only 3 125 waves -- three per
-// SIMD, each doing ~10 dependent trips -- which leaves the kernel latency-bound at about a third of
-// the HBM rate; more lanes per column put more waves (and more loads) in flight.  Entry e of a column
-// sits in sub-lane e mod L at step e / L; each sub-lane adds its entries in order and the L partial
-// sums are combined by a fixed butterfly: deterministic, equal to the sequential sum to rounding
-// (NOT bit-identical to it, unlike the default layout).  Same conditional fetch, same fused ratio pass.
-template <int L> __global__ void __launch_bounds__(256) k_price_sellx(Dev D, int countCols, int nSellBlocks)
+// =============================================================================================
+// Row pricing BY ROW for sparse pi -- ClpPackedMatrix::transposeTimes' other branch
+// (src/ClpPackedMatrix.cpp:727-754 chooses it when nnz(pi) <= factor * m; transposeTimesByRow :1307,
+// gutsOfTransposeTimesByRowGE3 :5176-5225: accumulate pi_i * row_i into a dense scratch).
+// A by-column sweep streams every row index of the matrix (40 MB at config 4) however sparse pi is;
+// by row only the rows in supp(pi) are read: 12 B x sum of their lengths.
+// Bit-identical to the by-column result without floating-point atomics:
+//   pass 1 (k_price_sell's extra workgroups): a wave per nonzero row of pi walks the nonbasic part of
+//     that row in the row copy; every entry bumps an integer touch counter of its column (order
+//     independent) and the FIRST toucher stores its product pi_i * a_ij as the column's value;
+//   pass 2 (k_price_row_finish, one thread per column): touched once -> that product IS the
+//     by-column sum (the other terms are exact zeros); touched more than once -> the column's own dot
+//     product is recomputed by column, in CSC order, exactly as the by-column kernel does it.  Then the
+//     same fused first ratio pass, candidate flags and per-block counts as the by-column kernels.
+// Which branch runs is decided on the device from nnz(pi) (popcount of the bitmap) against rowMax;
+// every workgroup of both launches takes the same decision.
+// =============================================================================================
+__device__ inline int piPopcount256(const Dev &D)
 {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long bits[];
-  const Ctrl *c = D.ctrl;
-  if ((int)blockIdx.x >= nSellBlocks) {
-    if (c->state == RUN)
-      priceLongBody(D, (int)blockIdx.x - nSellBlocks, countCols);
-    return;
+  __shared__ int shPopRow[4];
+  const int nwords = (D.m + 63) >> 6;
+  int pop = 0;
+  for (int w = threadIdx.x; w < nwords; w += blockDim.x)
+    pop += __popcll(D.piBits[w]);
+  for (int o = 32; o > 0; o >>= 1)
+    pop += __shfl_xor(pop, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0)
+    shPopRow[threadIdx.x >> 6] = pop;
+  __syncthreads();
+  return shPopRow[0] + shPopRow[1] + shPopRow[2] + shPopRow[3];
+}
+// pass 1: workgroup blk (of cdiv(m, 256)) owns 256 rows = four bitmap words, a wave per word
+__device__ inline void priceRowScatterBody(const Dev &D, int blk, int fullRows)
+{
+  const int lane = threadIdx.x & 63;
+  const int w = blk * 4 + (threadIdx.x >> 6);
+  const int nwords = (D.m + 63) >> 6;
+  unsigned long long word = w < nwords ? D.piBits[w] : 0ull;
+  int entries = 0;
+  while (word) {
+    const int bit = __ffsll((long long)word) - 1;
+    word &= word - 1ull;
+    const int i = w * 64 + bit;
+    const double v = D.piNeg[i];
+    const int e = D.rowStart[i + 1];
+    // the nonbasic part of the row (the engine keeps the row copy partitioned [basic | nonbasic]; the
+    // plug-in call walks whole rows, its caller's status array decides); two strides of 64 entries in flight
+    for (int q0 = D.rowStart[i] + (fullRows ? 0 : D.basicCount[i]); q0 < e; q0 += 128) {
+      int jj[2];
+      double aa[2];
+      unsigned char st[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int q = q0 + 64 * u + lane;
+        jj[u] = q < e ? D.ccol[q] : -1;
+        aa[u] = q < e ? D.relem[q] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+        st[u] = jj[u] >= 0 ? D.status[jj[u]] : 1;
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        if (jj[u] >= D.priceFirst && jj[u] < D.priceLast && (st[u] & 3) != 1) {
+          if (atomicAdd(&D.touchCol[jj[u]], 1) == 0)
+            D.alphaCol[jj[u]] = v * aa[u];
+          entries++;
+        }
+      }
+    }
   }
+  // algorithmic bytes of this pass (B_row): 12 B per entry visited + 12 B per pi nonzero
+  __shared__ int shEnt[4];
+  for (int o = 32; o > 0; o >>= 1)
+    entries += __shfl_xor(entries, o);
+  if (lane == 0)
+    shEnt[threadIdx.x >> 6] = entries;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int pops = 0;
+    for (int u = 0; u < 4; u++)
+      if (blk * 4 + u < nwords)
+        pops += __popcll(D.piBits[blk * 4 + u]);
+    D.blockSum[blk] = 12.0 * (shEnt[0] + shEnt[1] + shEnt[2] + shEnt[3]) + 12.0 * pops;
+  }
+}
+// pass 2: one thread per column of this GPU's range, compaction-block aligned (the k_price scheme:
+// per-block count / min ratio / bytes stored directly, no atomics)
+__global__ void __launch_bounds__(PRICE_BLOCK) k_price_row_finish(Dev D, int nbRows, int rowMax)
+{
+  Ctrl *c = D.ctrl;
   if (c->state != RUN)
     return;
-  constexpr int CPS = 64 / L;  // columns per slice
+  const int pop = rowMax > 0 ? piPopcount256(D) : 0;
+  const bool byRow = rowMax > 0 && pop <= rowMax;
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    c->lastPriceByRow = byRow ? 1 : 0;
+  if (!byRow)
+    return;
   __shared__ double shd[16];
-  __shared__ int shPop[4];
+  __shared__ int shi[17];
   const double dualT = -c->dualTolerance;
   const double acceptablePivot = c->acceptablePivot;
   const double zeroTolerance = c->zeroTolerance;
-  const int lane = threadIdx.x & 63;
-  const int slice = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int nwords = (D.m + 63) >> 6;
-  int pop = 0;
-  for (int w = threadIdx.x; w < nwords; w += blockDim.x) {
-    unsigned long long word = D.piBits[w];
-    bits[w] = word;
-    pop += __popcll(word);
-  }
-  for (int o = 32; o > 0; o >>= 1)
-    pop += __shfl_xor(pop, o);
-  if (lane == 0)
-    shPop[threadIdx.x >> 6] = pop;
-  __syncthreads();
-  pop = shPop[0] + shPop[1] + shPop[2] + shPop[3];
-  const bool sparsePi = 12 * (long long)pop < (long long)D.m;
+  const int j = D.firstColumn + (int)blockIdx.x * PRICE_BLOCK + threadIdx.x;
+  int flag = 0;
   double ratio = 1.0e31, bytes = 0.0;
-  if (slice < D.sxSlices) {
-    const int col = lane / L, sub = lane % L;
-    const int idx = slice * CPS + col;
-    const int j = D.sxCol[idx];
-    int len = 0, wanted = 0;
-    if (j >= 0) {
-      wanted = (D.status[j] & 3) - 1;
-      if (wanted)
-        len = D.sxLen[idx];
-    }
-    int maxSteps = (len + L - 1) / L;
-    for (int o = 32; o > 0; o >>= 1)
-      maxSteps = max(maxSteps, __shfl_xor(maxSteps, o));
+  if (j < D.lastColumn) {
     double value = 0.0;
-    if (maxSteps > 0) {
-      const int start = D.sxStart[slice];
-      const int *rp = D.sxRow + start + lane;
-      const double *ep = D.sxElem + start + lane;
-      for (int t = 0; t < maxSteps; t += SELL_U) {
-        int r[SELL_U];
-        double e[SELL_U], pv[SELL_U];
-        bool hit[SELL_U];
-#pragma unroll
-        for (int u = 0; u < SELL_U; u++)
-          r[u] = rp[(t + u) * 64];
-#pragma unroll
-        for (int u = 0; u < SELL_U; u++) {
-          hit[u] = ((t + u) * L + sub < len) && (!sparsePi || ((bits[r[u] >> 6] >> (r[u] & 63)) & 1ull));
-          e[u] = 0.0;
-          pv[u] = 0.0;
-          if (hit[u]) {
-            e[u] = ep[(t + u) * 64];
-            pv[u] = D.piNeg[r[u]];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < SELL_U; u++)
-          if (hit[u])
-            value += pv[u] * e[u];
+    const int cnt = (j >= D.priceFirst && j < D.priceLast) ? D.touchCol[j] : 0;
+    if (cnt) {
+      D.touchCol[j] = 0;
+      if (cnt == 1) {
+        value = D.alphaCol[j];
+      } else {
+        for (int p = D.colStart[j]; p < D.colStart[j + 1]; p++)
+          value += D.piNeg[D.row[p]] * D.elem[p];
       }
-    }
-    // the L partial sums of a column (adjacent lanes), fixed butterfly: every sub-lane gets the total
-#pragma unroll
-    for (int o = 1; o < L; o <<= 1)
-      value += __shfl_xor(value, o);
-    if (j >= 0 && sub == 0) {
-      int flag = 0;
-      if (wanted) {
-        bytes = 12.0 * len + 4.0;
-        if (fabs(value) > zeroTolerance) {
-          bytes += 20.0;
-          if (wanted > 0) {
-            double mult = (wanted == 1) ? -1.0 : 1.0;
-            double alpha = value * mult;
-            if (alpha > 0.0) {
-              double oldValue = D.dj[j] * mult;
-              double v2 = oldValue - 1.0e15 * alpha;
-              if (v2 < dualT) {
-                flag = 1;
-                if (alpha >= acceptablePivot)
-                  ratio = (oldValue - dualT) / alpha;
-              }
+      bytes = 8.0;  // the touched scratch entry
+      const int wanted = (D.status[j] & 3) - 1;
+      if (fabs(value) > zeroTolerance) {
+        bytes += 20.0;
+        if (wanted > 0) {
+          double mult = (wanted == 1) ? -1.0 : 1.0;
+          double alpha = value * mult;
+          if (alpha > 0.0) {
+            double oldValue = D.dj[j] * mult;
+            double v2 = oldValue - 1.0e15 * alpha;
+            if (v2 < dualT) {
+              flag = 1;
+              if (alpha >= acceptablePivot)
+                ratio = (oldValue - dualT) / alpha;
             }
           }
-        } else {
-          value = 0.0;
         }
+      } else {
+        value = 0.0;
       }
-      D.alphaCol[j] = value;
-      D.candFlag[D.m + j] = (unsigned char)flag;
-      if (flag && countCols)
-        atomicAdd(&D.blockCount[((D.m + PRICE_BLOCK - 1) / PRICE_BLOCK) + ((j - D.firstColumn) / PRICE_BLOCK)], 1);
     }
+    D.alphaCol[j] = value;
+    D.candFlag[D.m + j] = (unsigned char)flag;
   }
+  int total;
+  blockRank(flag, total, shi);
   double bmin = blockMin(ratio, shd);
   double bsum = blockSum(bytes, shd);
   if (threadIdx.x == 0) {
-    D.sellMin[blockIdx.x] = bmin;
-    D.sellBytes[blockIdx.x] = bsum;
+    D.blockCount[nbRows + blockIdx.x] = total;
+    D.blockMin[nbRows + blockIdx.x] = bmin;
+    D.blockSum[nbRows + blockIdx.x] = bsum;
+  }
+}
+// plug-in form (clpgpu_price_row): what k_rho_finish3 leaves for the pricing launches -- the first
+// ratio pass of the row (slack) part with its per-block counts, neutral values in the column blocks
+// and in the per-workgroup slots of the by-column kernel
+__global__ void __launch_bounds__(PRICE_BLOCK) k_price_row_init(Dev D, int nbCols, int nSlots)
+{
+  const Ctrl *c = D.ctrl;
+  __shared__ double sh[16];
+  __shared__ int shi[17];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int flag = 0;
+  double ratio = 1.0e31;
+  if (i < D.m) {
+    const double dualT = -c->dualTolerance;
+    const double value = D.rho[i];
+    if (value != 0.0) {
+      int iStatus = (D.status[D.n + i] & 3) - 1;
+      if (iStatus > 0) {
+        double mult = (iStatus == 1) ? -1.0 : 1.0;
+        double alpha = value * mult;
+        if (alpha > 0.0) {
+          double oldValue = D.dj[D.n + i] * mult;
+          double v2 = oldValue - 1.0e15 * alpha;
+          if (v2 < dualT) {
+            flag = 1;
+            if (alpha >= c->acceptablePivot)
+              ratio = (oldValue - dualT) / alpha;
+          }
+        }
+      }
+    }
+    D.candFlag[i] = (unsigned char)flag;
+  }
+  unsigned long long mask = __ballot(i < D.m && D.rho[i < D.m ? i : 0] != 0.0);
+  if ((threadIdx.x & 63) == 0 && i < D.m + 63)
+    D.piBits[i >> 6] = mask;
+  int total;
+  blockRank(flag, total, shi);
+  double bmin = blockMin(ratio, sh);
+  if (threadIdx.x == 0) {
+    D.blockCount[blockIdx.x] = total;
+    D.blockMin[blockIdx.x] = bmin;
+    D.blockSum[blockIdx.x] = 0.0;
+  }
+  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < nbCols; g += gridDim.x * blockDim.x) {
+    D.blockCount[gridDim.x + g] = 0;
+    D.blockMin[gridDim.x + g] = 1.0e31;
+    D.blockSum[gridDim.x + g] = 0.0;
+  }
+  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < nSlots; g += gridDim.x * blockDim.x) {
+    D.sellMin[g] = 1.0e31;
+    D.sellBytes[g] = 0.0;
   }
 }
 
-// workgroups [0, nSellBlocks) sweep the SELL slices, the rest the long columns
-__global__ void __launch_bounds__(256) k_price_sell(Dev D, int variant, int countCols = 0, int nSellBlocks = 1 << 30)
+// workgroups [0, nSellBlocks) sweep the SELL slices, the next numLong the long columns; the last
+// nRowBlocks (= cdiv(m, 256), only when rowMax > 0) are pass 1 of the by-row form.  rowMax > 0: nnz(pi)
+// <= rowMax sends the launch by row (the by-column workgroups return), otherwise by column.
+__global__ void __launch_bounds__(256) k_price_sell(Dev D, int variant, int countCols = 0, int nSellBlocks = 1 << 30, int nColBlocks = 1 << 30,
+                                                    int rowMax = 0, int fullRows = 0)
 {
+  if (D.ctrl->state != RUN)
+    return;
+  bool byRow = false;
+  if (rowMax > 0) {
+    const int pop = piPopcount256(D);
+    byRow = pop <= rowMax;
+  }
+  if ((int)blockIdx.x >= nColBlocks) {
+    if (byRow)
+      priceRowScatterBody(D, (int)blockIdx.x - nColBlocks, fullRows);
+    return;
+  }
+  if (byRow)
+    return;
   if ((int)blockIdx.x >= nSellBlocks) {
-    if (D.ctrl->state == RUN)
-      priceLongBody(D, (int)blockIdx.x - nSellBlocks, countCols);
+    priceLongBody(D, (int)blockIdx.x - nSellBlocks, countCols);
     return;
   }
   extern __shared__ __attribute__((aligned(16))) unsigned long long sellBits[];  // (m+63)/64 words for variants >= 2
-  if (D.ctrl->state != RUN)
-    return;
   switch (variant) {
   case 2:
     priceSellBody<false, false, true>(D, sellBits, countCols);
@@ -3078,7 +3251,32 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_dj_flags(Dev D, int nbRows, int
   const double theta = c->theta;
   const double tolerance = c->dualTolerance + fmin(1.0e-2, c->largestDualError);
   const int seqIn = c->sequenceIn;
-  int flag = 0, key = -1;
+  if (blockIdx.x == gridDim.x - 1) {
+    // the extra workgroup: unpack the entering column (ClpSimplex::unpackPacked :3439-3495), by row
+    // and by nucleus row-slot for the FTRAN sweep -- beside the dual update instead of inside the
+    // single-workgroup ratio test
+    if (seqIn >= D.n) {
+      if (threadIdx.x == 0) {
+        const int r = seqIn - D.n;
+        D.vecV1[r] = -1.0;
+        const int sr = D.slotOfRow[r];
+        if (sr >= 0)
+          D.slotV1[sr] = -1.0;
+      }
+    } else if (seqIn >= 0) {
+      for (int p = D.colStart[seqIn] + threadIdx.x; p < D.colStart[seqIn + 1]; p += blockDim.x) {
+        const int r = D.row[p];
+        const double e = D.elem[p];
+        D.vecV1[r] = e;
+        const int sr = D.slotOfRow[r];
+        if (sr >= 0)
+          D.slotV1[sr] = e;
+      }
+    }
+    return;
+  }
+  int flag = 0, key = -1, seqF = -1;
+  unsigned char stF = 0;
   if ((int)blockIdx.x < nbRows) {
     int i = blockIdx.x * PRICE_BLOCK + threadIdx.x;
     if (i < D.m) {
@@ -3093,10 +3291,12 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_dj_flags(Dev D, int nbRows, int
           value *= mult;
           if (value < -tolerance)
             flag = 1;
+          stF = D.status[seq];
         }
       }
       D.candFlag[i] = (unsigned char)flag;
       key = i;
+      seqF = seq;
     }
   } else {
     int j = D.firstColumn + ((int)blockIdx.x - nbRows) * PRICE_BLOCK + threadIdx.x;
@@ -3111,10 +3311,12 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_dj_flags(Dev D, int nbRows, int
           value *= mult;
           if (value < -tolerance && iStatus > 0)
             flag = 1;
+          stF = D.status[j];
         }
       }
       D.candFlag[D.m + j] = (unsigned char)flag;
       key = D.m + j;
+      seqF = j;
     }
   }
   // flips are few: append them in arrival order (one atomic per wave that has any); k_flip_apply2
@@ -3128,8 +3330,29 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_dj_flags(Dev D, int nbRows, int
     base = __shfl(base, 0);
     if (flag) {
       int o = base + __popcll(mk & ((1ull << lane) - 1ull));
-      if (o < listCap)
+      if (o < listCap) {
         D.flipKey[o] = key;
+        // the flip's movement, objective term and column extent travel with it (matrix_->add per
+        // flipped column, ClpSimplexDual.cpp:2586 / ClpPackedMatrix.cpp:4874): k_flip_apply2 then starts
+        // from complete records instead of three more rounds of dependent loads
+        const int iStatus = (stF & 3) - 1;
+        const double mult = (iStatus == 1) ? -1.0 : 1.0;
+        double mv, ob;
+        int start = 0, len = 1;
+        if (seqF >= D.n) {
+          mv = mult * (D.lower[seqF] - D.upper[seqF]);
+          ob = 0.0 - mv * D.cost[seqF];
+        } else {
+          mv = mult * (D.upper[seqF] - D.lower[seqF]);
+          ob = mv * D.cost[seqF];
+          start = D.colStart[seqF];
+          len = D.colStart[seqF + 1] - start;
+        }
+        D.flipRecMv[o] = mv;
+        D.flipRecObj[o] = ob;
+        D.flipRecStart[o] = start;
+        D.flipRecLen[o] = len;
+      }
     }
   }
 }
@@ -3220,15 +3443,21 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos, int dens
   // counters of k_ftran_scatter3's appends (position blocks) are reset here, flips or not
   for (int b = tid; b < nbPos; b += blockDim.x)
     D.blockCount[b] = 0;
-  const int key0 = D.flipKey[tid];  // requested together with the count (stale beyond it)
+  // the first record of every thread is requested together with the count (stale beyond it)
+  const int key0 = D.flipKey[tid];
+  const double mv0 = D.flipRecMv[tid], ob0 = D.flipRecObj[tid];
+  const int st0 = D.flipRecStart[tid], len0 = D.flipRecLen[tid];
   const int nraw = c->flipAppend;
   if (nraw == 0)
     return;  // numberFlips was zeroed by CHUZR
   // ---- the flip list in reference order (rows first, then columns ascending)
   __shared__ int s_seq[FLIP_LIST_CAP];
   __shared__ int shw[17];
+  __shared__ double s_mv[FLIP_MAX_FLIPS], s_ob[FLIP_MAX_FLIPS];
+  __shared__ int s_start[FLIP_MAX_FLIPS + 1], s_cs[FLIP_MAX_FLIPS];
   int nf;
-  if (nraw <= listCap) {
+  const bool haveRecords = nraw <= listCap;
+  if (haveRecords) {
     if (tid < nraw)
       s_seq[tid] = key0;
     for (int i = tid + blockDim.x; i < nraw; i += blockDim.x)
@@ -3255,6 +3484,14 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos, int dens
         int seq = myKey[q] < D.m ? D.n + myKey[q] : myKey[q] - D.m;
         s_seq[myRank[q]] = seq;
         D.flipSeq[myRank[q]] = seq;
+        // the record k_dj_flags wrote for this flip moves to its place in list order
+        if (myRank[q] < FLIP_MAX_FLIPS && nraw <= FLIP_MAX_FLIPS) {
+          const int i = tid + q * 1024;
+          s_mv[myRank[q]] = q == 0 ? mv0 : D.flipRecMv[i];
+          s_ob[myRank[q]] = q == 0 ? ob0 : D.flipRecObj[i];
+          s_cs[myRank[q]] = q == 0 ? st0 : D.flipRecStart[i];
+          s_start[myRank[q] + 1] = q == 0 ? len0 : D.flipRecLen[i];
+        }
       }
     }
     nf = nraw;
@@ -3297,11 +3534,9 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos, int dens
     c->dbg[10] += nf;
   }
   __syncthreads();
-  __shared__ double s_mv[FLIP_MAX_FLIPS];
   __shared__ int s_hash[1 << FLIP_HASH_BITS];  // 0 empty, else (row + 1) | MULTI
   for (int i = tid; i < (1 << FLIP_HASH_BITS); i += blockDim.x)
     s_hash[i] = 0;
-  __shared__ int s_start[FLIP_MAX_FLIPS + 1];
   __shared__ int s_cRow[FLIP_MAX_COLLIDE], s_cFlip[FLIP_MAX_COLLIDE], s_cSorted[FLIP_MAX_COLLIDE];
   __shared__ double s_cVal[FLIP_MAX_COLLIDE];
   __shared__ int s_nCollide, s_total;
@@ -3309,24 +3544,30 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos, int dens
   bool fallback = nf > FLIP_MAX_FLIPS;
   double changeObj = 0.0;
   if (!fallback) {
-    // per-flip scalars
+    // per-flip scalars: already in LDS when k_dj_flags' records were used, otherwise (flip-list overflow) from the rim
     for (int f = tid; f < nf; f += blockDim.x) {
-      int seq = s_seq[f];
-      int iStatus = (D.status[seq] & 3) - 1;
-      double mult = (iStatus == 1) ? -1.0 : 1.0;
-      double mv;
-      int len;
-      if (seq >= D.n) {
-        mv = mult * (D.lower[seq] - D.upper[seq]);
-        changeObj -= mv * D.cost[seq];
-        len = 1;
+      if (haveRecords) {
+        changeObj += s_ob[f];
       } else {
-        mv = mult * (D.upper[seq] - D.lower[seq]);
-        changeObj += mv * D.cost[seq];
-        len = D.colStart[seq + 1] - D.colStart[seq];
+        int seq = s_seq[f];
+        int iStatus = (D.status[seq] & 3) - 1;
+        double mult = (iStatus == 1) ? -1.0 : 1.0;
+        double mv;
+        int len;
+        if (seq >= D.n) {
+          mv = mult * (D.lower[seq] - D.upper[seq]);
+          changeObj -= mv * D.cost[seq];
+          len = 1;
+          s_cs[f] = 0;
+        } else {
+          mv = mult * (D.upper[seq] - D.lower[seq]);
+          changeObj += mv * D.cost[seq];
+          len = D.colStart[seq + 1] - D.colStart[seq];
+          s_cs[f] = D.colStart[seq];
+        }
+        s_mv[f] = mv;
+        s_start[f + 1] = len;
       }
-      s_mv[f] = mv;
-      s_start[f + 1] = len;
     }
     if (tid == 0) {
       s_start[0] = 0;
@@ -3391,7 +3632,7 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos, int dens
         r = seq - D.n;
         v = s_mv[f];
       } else {
-        int p = D.colStart[seq] + (e - s_start[f]);
+        int p = s_cs[f] + (e - s_start[f]);
         r = D.row[p];
         v = s_mv[f] * D.elem[p];
       }
@@ -3941,6 +4182,7 @@ __global__ void __launch_bounds__(1024) k_gj_panel(Dev D, int i0, int b, int k, 
 // position differs are permuted once at the end.  Same arithmetic, same pivots as k_gj_panel.  The
 // panel's own columns are dead after the block (only L, the pivots and the trailing columns are
 // used), so nothing is written back to W.
+#define GJ_NB 64  // outer block of the two-level form (inner panels of 4 / 8 columns)
 struct GjShared {
   double shv[16];
   int shk[16];
@@ -3948,13 +4190,20 @@ struct GjShared {
   int nMoved;
   double prow[GJ_B];
   int movedPos[2 * GJ_B];
-  double movedL[2 * GJ_B][GJ_B];
+  double movedL[2 * GJ_B][GJ_NB];
+};
+// where a panel leaves its multipliers and pivots: L[r * ldL + lcol0 + s], gjPiv[pcol0 + s].  The
+// one-level form uses (gjL, GJ_B, 0, 0); the two-level form writes inner panel j of an outer block at
+// column / pivot offset j * b of the outer block's L (gjL2, GJ_NB)
+struct GjOut {
+  double *L;
+  int ldL, lcol0, pcol0;
 };
 // one elimination step with the step index a compile-time constant (keeps v[][] in registers);
 // returns false when the panel turned out singular.  Two barriers per step.
 template <int S, int GJ_RPT, int BB, int NT>
 __device__ __forceinline__ bool gjPanelStep(const Dev &D, double (&v)[GJ_RPT][BB], int (&pos)[GJ_RPT], GjShared &sh, int i0, int k,
-                                            int *info, double zeroTolerance)
+                                            int *info, double zeroTolerance, const GjOut &out)
 {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = i0 + S;
@@ -3999,7 +4248,7 @@ __device__ __forceinline__ bool gjPanelStep(const Dev &D, double (&v)[GJ_RPT][BB
   if (tid == 0) {
     if (iRow < 0)
       info[0] = 1 + i;
-    D.gjPiv[S] = iRow;
+    D.gjPiv[out.pcol0 + S] = iRow;
   }
   if (iRow < 0)
     return false;
@@ -4024,10 +4273,10 @@ __device__ __forceinline__ bool gjPanelStep(const Dev &D, double (&v)[GJ_RPT][BB
     const int r = tid + q * NT;
     if (r < k) {
       if (pos[q] == i) {
-        D.gjL[(size_t)r * GJ_B + S] = 0.0;
+        out.L[(size_t)r * out.ldL + out.lcol0 + S] = 0.0;
       } else {
         double l = v[q][S] * inv;
-        D.gjL[(size_t)r * GJ_B + S] = l;
+        out.L[(size_t)r * out.ldL + out.lcol0 + S] = l;
         if (l != 0.0) {
 #pragma unroll
           for (int t = S + 1; t < BB; t++)
@@ -4041,29 +4290,32 @@ __device__ __forceinline__ bool gjPanelStep(const Dev &D, double (&v)[GJ_RPT][BB
 }
 template <int S, int GJ_RPT, int BB, int NT> struct GjPanelRun {
   static __device__ __forceinline__ bool run(const Dev &D, double (&v)[GJ_RPT][BB], int (&pos)[GJ_RPT], GjShared &sh, int i0, int b,
-                                             int k, int *info, double zeroTolerance)
+                                             int k, int *info, double zeroTolerance, const GjOut &out)
   {
     if (S >= b)
       return true;
-    if (!gjPanelStep<S, GJ_RPT, BB, NT>(D, v, pos, sh, i0, k, info, zeroTolerance))
+    if (!gjPanelStep<S, GJ_RPT, BB, NT>(D, v, pos, sh, i0, k, info, zeroTolerance, out))
       return false;
-    return GjPanelRun<S + 1, GJ_RPT, BB, NT>::run(D, v, pos, sh, i0, b, k, info, zeroTolerance);
+    return GjPanelRun<S + 1, GJ_RPT, BB, NT>::run(D, v, pos, sh, i0, b, k, info, zeroTolerance, out);
   }
 };
 template <int GJ_RPT, int BB, int NT> struct GjPanelRun<BB, GJ_RPT, BB, NT> {
   static __device__ __forceinline__ bool run(const Dev &, double (&)[GJ_RPT][BB], int (&)[GJ_RPT], GjShared &, int, int, int, int *,
-                                             double)
+                                             double, const GjOut &)
   {
     return true;
   }
 };
 // NT threads own GJ_RPT rows each (k <= NT * GJ_RPT); fewer, fatter waves keep the per-step control
 // overhead (which is what bounds this single-workgroup kernel) low
-template <int GJ_RPT, int BB, int NT> __global__ void __launch_bounds__(NT) k_gj_panel_reg(Dev D, int i0, int b, int k, int *info)
+template <int GJ_RPT, int BB, int NT>
+__global__ void __launch_bounds__(NT) k_gj_panel_reg(Dev D, int i0, int b, int k, int *info, GjOut out = GjOut{ nullptr, GJ_B, 0, 0 })
 {
   __shared__ GjShared sh;
   if (info[0])
     return;
+  if (!out.L)
+    out.L = D.gjL;
   const int tid = threadIdx.x;
   double v[GJ_RPT][BB];
   int pos[GJ_RPT], permOld[GJ_RPT];
@@ -4078,26 +4330,29 @@ template <int GJ_RPT, int BB, int NT> __global__ void __launch_bounds__(NT) k_gj
   }
   if (tid == 0)
     sh.nMoved = 0;
-  if (!GjPanelRun<0, GJ_RPT, BB, NT>::run(D, v, pos, sh, i0, b, k, info, D.ctrl->zeroTolerance))
+  if (!GjPanelRun<0, GJ_RPT, BB, NT>::run(D, v, pos, sh, i0, b, k, info, D.ctrl->zeroTolerance, out))
     return;
   __syncthreads();
-  // rows that ended at another position: move their multipliers and their perm entry there
+  // rows that ended at another position: move their multipliers -- this panel's and, in the two-level
+  // form, those of the outer block's earlier inner panels (columns [0, lcol0): L follows its physical
+  // row) -- and their perm entry there
+  const int ncL = out.lcol0 + b;
 #pragma unroll
   for (int q = 0; q < GJ_RPT; q++) {
     int r = tid + q * NT;
     if (r < k && pos[q] != r) {
       int slot = atomicAdd(&sh.nMoved, 1);
       sh.movedPos[slot] = pos[q];
-      for (int t = 0; t < b; t++)
-        sh.movedL[slot][t] = D.gjL[(size_t)r * GJ_B + t];
+      for (int t = 0; t < ncL; t++)
+        sh.movedL[slot][t] = out.L[(size_t)r * out.ldL + t];
       D.perm[pos[q]] = permOld[q];
     }
   }
   __syncthreads();
   const int nMoved = sh.nMoved;
-  for (int e = tid; e < nMoved * b; e += NT) {
-    int slot = e / b, t = e - slot * b;
-    D.gjL[(size_t)sh.movedPos[slot] * GJ_B + t] = sh.movedL[slot][t];
+  for (int e = tid; e < nMoved * ncL; e += NT) {
+    int slot = e / ncL, t = e - slot * ncL;
+    out.L[(size_t)sh.movedPos[slot] * out.ldL + t] = sh.movedL[slot][t];
   }
 }
 // the block's row swaps applied to everything outside the panel: W columns >= i0+b and all of X
@@ -4209,6 +4464,197 @@ __global__ void __launch_bounds__(256) k_gj_trail(Dev D, int i0, int b, int k, i
     }
     if (changed)
       base[(size_t)r * D.ld + c] = a;
+  }
+}
+
+// =============================================================================================
+// Two-level, in-place form of the same Gauss-Jordan re-inversion, for nuclei that are genuinely
+// large and dense (k >= option refactor_min_k; the wantToGoDense tail of
+// CoinAbcBaseFactorization1.cpp:2409-2462 factored by CoinAbcDgetrf, AbcSimplexParallel.cpp:2491,
+// with CoinAbcDgemm, CoinAbcHelperFunctions.cpp:1658, as the trailing update).
+//   * in place: M = workW is k x k.  Column s of the identity side only comes alive when row s
+//     becomes a pivot row, and the W column it eliminates dies at the same moment, so the new X column
+//     takes the dead W column's place (columns [0, I0) finished X columns, [I0, I0+nb) the outer panel,
+//     [I0+nb, k) live W columns): half the columns of the augmented form, k live columns at all times.
+//     The X columns come out in pivot order; k_gj2_finish puts column s at perm[s].
+//   * two levels: an outer block of nb <= GJ_NB = 64 pivots is factored as inner register-resident
+//     panels of 8 (k <= 4096) or 4 columns; each inner panel's swaps / U rows / rank-b update are
+//     applied to the remaining columns of the outer panel only (L2-resident), and the k x k rest of the
+//     matrix is read and written once per outer block by a rank-nb update
+//         M[:, rest] -= L[:, 0:nb] * U[0:nb, rest]
+//     on the matrix cores: v_mfma_f64_16x16x4_f64, 64 x 64 tile per workgroup, one 16 x 64 strip per wave.
+// The vector form of the outer update (k_gj2_trail_vec, option refactor_mode 2) performs the
+// one-level kernels' operations in the same order and reproduces their bits; the MFMA form fuses the
+// four products of a k-step, so it equals them to rounding only -- it is used where the reference itself
+// switches to its dense LAPACK-style kernels.
+// =============================================================================================
+typedef double gj_v4d __attribute__((ext_vector_type(4)));
+
+// row interchanges of steps [0, b) of a panel at i0, columns [c0, c1) except [skip0, skip1)
+__global__ void k_gj2_rowswaps(Dev D, int i0, int b, int *info, int c0, int c1, int skip0, int skip1, int pcol0)
+{
+  if (info[0])
+    return;
+  int c = c0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= c1 || (c >= skip0 && c < skip1))
+    return;
+  double *M = D.workW;
+  for (int s = 0; s < b; s++) {
+    int i = i0 + s, iRow = D.gjPiv[pcol0 + s];
+    if (iRow != i) {
+      size_t a = (size_t)i * D.ld + c, a2 = (size_t)iRow * D.ld + c;
+      double v = M[a];
+      M[a] = M[a2];
+      M[a2] = v;
+    }
+  }
+}
+// the outer panel's own columns become the X columns its pivots create: after the interchanges pivot
+// row s sits at position I0 + s, so column I0 + s starts as that unit vector
+__global__ void k_gj2_unit(Dev D, int I0, int nb, int k, int *info)
+{
+  if (info[0])
+    return;
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= k * nb)
+    return;
+  int r = e / nb, s = e - r * nb;
+  D.workW[(size_t)r * D.ld + I0 + s] = (r == I0 + s) ? 1.0 : 0.0;
+}
+// U[s][c - c0]: value of pivot row i0+s in column c at the time of step s (columns [c0, c1))
+template <int MAXB>
+__global__ void __launch_bounds__(256) k_gj2_upanel(Dev D, int i0, int b, int *info, int c0, int c1, const double *L, int ldL, int lcol0,
+                                                     double *U, int ldU)
+{
+  if (info[0])
+    return;
+  __shared__ double sLp[MAXB][MAXB + 1];  // multipliers of the pivot rows among themselves
+  for (int e = threadIdx.x; e < b * b; e += blockDim.x) {
+    int s = e / b, s2 = e - s * b;
+    sLp[s][s2] = L[(size_t)(i0 + s) * ldL + lcol0 + s2];
+  }
+  __syncthreads();
+  int c = c0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= c1)
+    return;
+  const double *M = D.workW;
+  double u[MAXB];
+#pragma unroll
+  for (int s = 0; s < MAXB; s++) {
+    u[s] = 0.0;
+    if (s < b) {
+      double a = M[(size_t)(i0 + s) * D.ld + c];
+#pragma unroll
+      for (int s2 = 0; s2 < s; s2++) {
+        double l = sLp[s][s2];
+        if (l != 0.0)
+          a -= u[s2] * l;
+      }
+      u[s] = a;
+      U[(size_t)s * ldU + (c - c0)] = a;
+    }
+  }
+}
+// vector form of the rank-b update, columns [c0, c1), all rows: a -= U[s][c] * L[r][s] for s = 0..b-1 in
+// order (multiply, then subtract: the arithmetic of k_gj_trail), 32 rows per workgroup
+template <int MAXB>
+__global__ void __launch_bounds__(256) k_gj2_trail_vec(Dev D, int i0, int b, int k, int *info, int c0, int c1, const double *L, int ldL,
+                                                        int lcol0, const double *U, int ldU)
+{
+  if (info[0])
+    return;
+  __shared__ double sL[GJ_ROWS][MAXB];
+  const int r0 = blockIdx.y * GJ_ROWS;
+  for (int e = threadIdx.x; e < GJ_ROWS * MAXB; e += blockDim.x) {
+    int rr = e / MAXB, s = e % MAXB;
+    sL[rr][s] = (r0 + rr < k && s < b) ? L[(size_t)(r0 + rr) * ldL + lcol0 + s] : 0.0;
+  }
+  __syncthreads();
+  int c = c0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= c1)
+    return;
+  double *M = D.workW;
+  double u[MAXB];
+#pragma unroll
+  for (int s = 0; s < MAXB; s++)
+    u[s] = (s < b) ? U[(size_t)s * ldU + (c - c0)] : 0.0;
+  const int rEnd = min(GJ_ROWS, k - r0);
+  for (int rr = 0; rr < rEnd; rr++) {
+    const int r = r0 + rr;
+    double a = M[(size_t)r * D.ld + c];
+    bool changed = false;
+#pragma unroll
+    for (int s = 0; s < MAXB; s++) {
+      double l = sL[rr][s];
+      if (l != 0.0 && r != i0 + s) {
+        a -= u[s] * l;
+        changed = true;
+      }
+    }
+    if (changed)
+      M[(size_t)r * D.ld + c] = a;
+  }
+}
+// matrix-core form of the outer update over all k columns: M -= L[:, 0:nb] * U[0:nb, :].
+// v_mfma_f64_16x16x4_f64: lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15] (one f64 each) and four
+// results D[(l >> 4) + 4 v][l & 15], v = 0..3.  A = -L so that D = A B + C is the update.  A pivot
+// row's own step is excluded by its zero multiplier (the panel stores L[I0 + s][s] = 0).
+__global__ void __launch_bounds__(256) k_gj2_trail_mfma(Dev D, int I0, int nb, int k, int *info, const double *L, int ldL, const double *U,
+                                                        int ldU)
+{
+  if (info[0])
+    return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int rowA = blockIdx.y * 64 + wv * 16 + (lane & 15);   // A operand: this lane's row of L
+  const int kq = lane >> 4;                                     // its k index inside a 4-step
+  const int colB = blockIdx.x * 64 + (lane & 15);              // B / C / D: this lane's column in sub-tile 0
+  const int rowC = blockIdx.y * 64 + wv * 16 + (lane >> 4);    // C / D: row of result v is rowC + 4 v
+  double *M = D.workW;
+  gj_v4d acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int c = colB + 16 * j;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const int r = rowC + 4 * v;
+      acc[j][v] = (r < k && c < k) ? M[(size_t)r * D.ld + c] : 0.0;
+    }
+  }
+  const double *Lrow = L + (size_t)(rowA < k ? rowA : 0) * ldL;
+  const bool rowOk = rowA < k;
+  for (int k0 = 0; k0 < nb; k0 += 4) {
+    const int kk = k0 + kq;
+    const bool kOk = kk < nb;
+    const double a = (rowOk && kOk) ? -Lrow[kk] : 0.0;
+    double bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int c = colB + 16 * j;
+      bv[j] = (kOk && c < k) ? U[(size_t)kk * ldU + c] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[j], acc[j], 0, 0, 0);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int c = colB + 16 * j;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const int r = rowC + 4 * v;
+      if (r < k && c < k)
+        M[(size_t)r * D.ld + c] = acc[j][v];
+    }
+  }
+}
+// Minv = D^-1 X with the X columns put back from pivot order: column s belongs to the row that was
+// pivot s, whose original (local) index is perm[s]
+__global__ void __launch_bounds__(256) k_gj2_finish(Dev D, int k)
+{
+  for (int r = blockIdx.y; r < k; r += gridDim.y) {
+    double inv = D.slotB[r];
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < k; j += gridDim.x * blockDim.x)
+      D.Minv[(size_t)r * D.ld + D.perm[j]] = D.workW[(size_t)r * D.ld + j] * inv;
   }
 }
 

@@ -48,6 +48,9 @@ typedef struct {
   double total_ms;      /* whole clpgpu_dual wall time */
   long iterations;
   long refactorizations;
+  double row_ms;        /* the same three for pricing launches that went BY ROW (sparse pi) */
+  long row_launches;
+  double row_bytes;     /* B_row of SURVEY 8d: 12 B per visited row entry and pi nonzero, 8 per touched column, 20 per emitted one */
   long nucleus;         /* k: basic structurals = order of the nucleus inverse right now */
   long nucleus_capacity; /* rows allocated for it (3 k x k f64 matrices) */
 } clpgpu_stats;
@@ -176,10 +179,11 @@ int clpgpu_unroll_weights(clpgpu_context *ctx);
  * update on a second stream),
  * "flip_list_cap" (size of the bound-flip append buffer; small values force its overflow path),
  * "scaling" (0 off; 1/2/3/4 = ClpModel::scaling modes; must be set BEFORE clpgpu_load_problem: the
- * device then holds the scaled LP, getters return unscaled values; engine-side plumbing written at the
- * end of round 1 and not yet run on hardware -- the factor computation is CPU-tested against the
- * oracle), "sell_lanes" (1; 2/4/8 = experimental pricing layout with several lanes per column, written at
- * the end of round 1 and not yet run on hardware). */
+ * device then holds the scaled LP, getters return unscaled values),
+ * "row_price_frac" (row pricing goes by row when nnz(pi) <= frac * m, ClpPackedMatrix.cpp:727-754; 0 = always
+ * by column; also selects the form of clpgpu_price_row), "refactor_mode" (-1 auto / 1 one-level / 2
+ * two-level vector / 3 two-level MFMA re-inversion), "refactor_min_k" (auto: two-level MFMA from this
+ * many basic structurals on, default 1024). */
 int clpgpu_set_option(clpgpu_context *ctx, const char *name, double value);
 /* Whole-array replacement of bounds / costs with the matrix left resident
  * (ClpModel::chgRowLower ... chgObjCoefficients, src/ClpModel.hpp:254-262, src/ClpModel.cpp:2669-2770;

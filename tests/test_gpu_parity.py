@@ -743,3 +743,142 @@ def test_dual_row_pivot_plugin_calls_reproduce_a_pivot(gpu_cls):
     assert rel(g.rowWeights()[0], wnew) < 1e-15
     g.saveWeights(5)
     assert np.all(g.rowWeights()[0] == 1.0)
+
+
+# ---------------------------------------------------------------- re-inversion forms -------------
+@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("maker,args", [("sparse_lp", (300, 1200, 8, 11)), ("dense_lp", (300, 400, 5))])
+def test_two_level_reinversion_solves_match(gpu_cls, mode, maker, args):
+    """The two-level in-place re-inversion (option refactor_mode: 2 = vector outer update, 3 = MFMA
+    outer update) forced on small LPs with a refactorization every 20 pivots, against the one-level
+    form and the oracle.  Mode 2 performs the one-level form's operations in the same order: identical
+    pivots AND identical solution bits.  Mode 3 fuses the products of a k-step on the matrix cores:
+    identical pivots and pivotVariable (same partial-pivoting choices), solution to 1e-9."""
+    lp = getattr(P, maker)(*args)
+    a, b = gpu_cls().loadProblem(lp), gpu_cls().loadProblem(lp)
+    for g in (a, b):
+        g.set_option("max_pivots", 20)
+    b.set_option("refactor_mode", mode)
+    o = oracle(lp, 1, max_pivots=20)
+    assert a.dual() == b.dual() == o.dual() == 0
+    la, lb, lo = a.pivotLog(), b.pivotLog(), o.pivot_log()
+    assert len(la) == len(lb) == len(lo)
+    assert np.array_equal(la["sequenceIn"], lb["sequenceIn"]) and np.array_equal(la["sequenceOut"], lb["sequenceOut"])
+    assert np.array_equal(lb["sequenceIn"], lo["sequenceIn"])
+    assert np.array_equal(a.pivotVariable(), b.pivotVariable())
+    if mode == 2:
+        assert np.array_equal(a.solution(), b.solution())
+    else:
+        assert rel(b.solution(), a.solution()) < 1e-9
+    assert rel(b.solution(), o.solution()) < RTOL
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("k", [100, 333, 600])
+def test_two_level_reinversion_factor_matches_oracle(gpu_cls, mode, k):
+    """clpgpu_factorize through the two-level form on dense nuclei spanning several outer blocks of 64:
+    the oracle's pivot positions, FTRAN / BTRAN against the oracle's LU."""
+    lp = P.dense_lp(700, 800, 12)
+    g, o = gpu_cls().loadProblem(lp), oracle(lp)
+    g.set_option("refactor_mode", mode)
+    rng = np.random.default_rng(5)
+    m, n = lp.m, lp.n
+    status = np.full(n + m, 3, np.uint8)
+    status[n:] = 1
+    status[rng.choice(n, k, replace=False)] = 1
+    status[n + rng.choice(m, k, replace=False)] = 3
+    (rg, pg), (ro, po) = g.factorize(status), o.factorize(status)
+    assert rg == ro == 0 and np.array_equal(pg, po)
+    for t in range(3):
+        v = rng.standard_normal(m)
+        assert rel(g.ftran(v), o.ftran(v)) < 1e-9 and rel(g.btran(v), o.btran(v)) < 1e-9
+
+
+def test_two_level_reinversion_large_nucleus(gpu_cls):
+    """k = 4300 > 4096: the 4-column register panel on 1024 threads, 68 outer blocks, MFMA update.
+    No oracle at this size (its dense LU is O(k^3) on one core): B^-1 B = I on basic columns, and the
+    pivot positions of the one-level form."""
+    lp = P.dense_lp(4500, 4600, 3)
+    rng = np.random.default_rng(9)
+    m, n, k = lp.m, lp.n, 4300
+    status = np.full(n + m, 3, np.uint8)
+    status[n:] = 1
+    cols = rng.choice(n, k, replace=False)
+    status[cols] = 1
+    status[n + rng.choice(m, k, replace=False)] = 3
+    g = gpu_cls().loadProblem(lp)
+    g.set_option("refactor_mode", 3)
+    rc, pv = g.factorize(status)
+    assert rc == 0
+    for pos in rng.choice(m, 6, replace=False):
+        seq = int(pv[pos])
+        col = np.zeros(m)
+        if seq >= n:
+            col[seq - n] = -1.0
+        else:
+            col[lp.row[lp.col_start[seq]:lp.col_start[seq + 1]]] = lp.elem[lp.col_start[seq]:lp.col_start[seq + 1]]
+        e = np.zeros(m)
+        e[pos] = 1.0
+        assert np.allclose(g.ftran(col), e, atol=1e-6)
+    h = gpu_cls().loadProblem(lp)
+    h.set_option("refactor_mode", 1)
+    rc1, pv1 = h.factorize(status)
+    assert rc1 == 0 and np.array_equal(pv, pv1)
+    v = rng.standard_normal(m)
+    assert rel(g.ftran(v), h.ftran(v)) < 1e-7
+
+
+def test_full_size_sparse_1500_pivots_mfma_refactor(gpu_cls):
+    """Config 4 through pivot 1500: the refactorizations at pivots 950 and 1425 find k >= 1024 basic
+    structurals and take the two-level MFMA re-inversion (the default from refactor_min_k = 1024 on).
+    Pivot sequence against the oracle (its LU is the exact one-level arithmetic), theta / alpha 1e-7."""
+    lp = P.sparse_lp()
+    g, o = _pivot_window(gpu_cls, lp, 1, 1500, max_pivots=0)
+    _assert_same_window(g, o)
+    assert rel(g.solution(), o.solution()) < 1e-7
+
+
+# ---------------------------------------------------------------- pricing by row -----------------
+@pytest.mark.parametrize("maker,args", [("sparse_lp", (300, 1200, 8, 11)), ("sparse_lp", (2000, 9000, 12, 13)),
+                                        ("netlib_shaped_lp", (2000, 6000, 70000, 21))])
+@pytest.mark.parametrize("density", [0.005, 0.05, 0.5])
+def test_price_row_by_row_bit_identical(gpu_cls, maker, args, density):
+    """ClpPackedMatrix::transposeTimes' by-row branch (:727-754, :1307, GE3 :5176) on the GPU: the
+    tableau row, candidate list (by-column order) and upperTheta of the by-row form are bit-identical
+    to the by-column form and to the oracle, for sparse and for dense pi, with columns touched by
+    several pi rows and with long columns."""
+    lp = getattr(P, maker)(*args)
+    by_row, by_col, o = gpu_cls().loadProblem(lp), gpu_cls().loadProblem(lp), oracle(lp)
+    by_row.set_option("row_price_frac", 1.0)  # nnz(pi) <= m: always by row
+    by_col.set_option("row_price_frac", 0.0)
+    rng = np.random.default_rng(23)
+    m, n = lp.m, lp.n
+    k = max(1, int(density * m))
+    status = rng.choice([1, 2, 3, 5], size=n + m, p=[0.2, 0.3, 0.45, 0.05]).astype(np.uint8)
+    dj = np.where((status & 3) == 2, -1.0, 1.0) * rng.uniform(0, 2, n + m)
+    for trial in range(2):  # twice on the same context: the touch counters must come back to zero
+        idx = np.sort(rng.choice(m, k, replace=False)).astype(np.int32)
+        val = rng.standard_normal(k)
+        a, b, c = by_row.priceRow(idx, val, status, dj), by_col.priceRow(idx, val, status, dj), o.price_row_fused(idx, val, status, dj)
+        for x, y, z in zip(a[:4], b[:4], c[:4]):
+            assert np.array_equal(x, z) and np.array_equal(y, z)
+        assert a[4] == b[4] == c[4]
+
+
+def test_full_size_by_row_and_by_column_give_the_same_solve(gpu_cls):
+    """Config 4, first 400 pivots: pi has at most a few hundred nonzeros there, so the default engine
+    prices every one of them by row (stats.row_launches); with row_price_frac = 0 it sweeps by column.
+    Same pivots, same solution bits."""
+    lp = P.sparse_lp()
+    a, b = gpu_cls().loadProblem(lp), gpu_cls().loadProblem(lp)
+    for g in (a, b):
+        g.set_option("max_pivots", 0)
+    b.set_option("row_price_frac", 0.0)
+    assert a.dual_steps(400) == -1 and b.dual_steps(400) == -1
+    la, lb = a.pivotLog(), b.pivotLog()
+    for key in ("sequenceIn", "sequenceOut", "pivotRow", "numberFlipped"):
+        assert np.array_equal(la[key], lb[key])
+    assert np.array_equal(a.solution(), b.solution()) and np.array_equal(a.reducedCosts(), b.reducedCosts())
+    sa, sb = a.stats(), b.stats()
+    assert sa["row_launches"] >= 390 and sb["row_launches"] == 0
+    assert np.all((la["reserved"] >> 30) & 1 == 1) and np.all((lb["reserved"] >> 30) == 0)
