@@ -1,0 +1,51 @@
+// clpGpuDual -- the whole dual simplex on the device, installed the way ClpSimplex::dealWithAbc installs
+// the Abc engine (src/ClpSolve.cpp:555-833): copy the model in, solve, move status and solution back,
+// let Clp re-derive what it wants (:777-811).  Call next to dealWithAbc in ClpSimplex::initialSolve (:1935).
+#include <vector>
+
+#include "ClpPackedMatrix.hpp"
+#include "ClpSimplex.hpp"
+#include "CoinHelperFunctions.hpp"
+#include "CoinPackedMatrix.hpp"
+#include "clpgpu.h"
+
+int clpGpuDual(ClpSimplex &model, int device, bool scaling)
+{
+  ClpPackedMatrix *clpMatrix = dynamic_cast< ClpPackedMatrix * >(model.clpMatrix());
+  if (!clpMatrix || clpMatrix->getNumElements() == 0)
+    return model.dual(); // other matrix types stay on the CPU path
+  const CoinPackedMatrix *A = clpMatrix->getPackedMatrix(); // column ordered, no gaps
+  clpgpu_context *ctx = clpgpu_create(device);
+  if (!ctx)
+    return model.dual(); // no MI355X: the caller keeps the reference path
+  const int numberRows = model.numberRows(), numberColumns = model.numberColumns();
+  if (scaling)
+    clpgpu_set_option(ctx, "scaling", model.scalingFlag() > 0 ? model.scalingFlag() : 0); // before the load
+  clpgpu_load_problem(ctx, numberRows, numberColumns, A->getVectorStarts(), A->getIndices(), A->getElements(),
+    model.columnLower(), model.columnUpper(), model.objective(), model.rowLower(), model.rowUpper());
+  clpgpu_set_option(ctx, "pivot_rule", model.dualRowPivot()->type() == 2 ? 1 : 0);
+  clpgpu_set_option(ctx, "max_iterations", model.maximumIterations());
+  clpgpu_set_option(ctx, "max_pivots", model.factorization()->maximumPivots());
+  clpgpu_set_option(ctx, "dual_bound", model.dualBound());
+  clpgpu_set_option(ctx, "primal_tolerance", model.primalTolerance());
+  clpgpu_set_option(ctx, "dual_tolerance", model.dualTolerance());
+  if (model.statusArray())
+    clpgpu_set_status(ctx, model.statusArray()); // warm start
+  int problemStatus = clpgpu_dual(ctx);          // ClpSimplex::dual()
+  model.setProblemStatus(problemStatus);
+  model.setNumberIterations(model.numberIterations() + clpgpu_number_iterations(ctx));
+  std::vector< double > solution(numberRows + numberColumns), dj(numberRows + numberColumns);
+  clpgpu_get_status(ctx, model.statusArray());
+  clpgpu_get_solution(ctx, solution.data());
+  clpgpu_get_reduced_costs(ctx, dj.data());
+  CoinMemcpyN(solution.data(), numberColumns, model.primalColumnSolution());
+  CoinMemcpyN(solution.data() + numberColumns, numberRows, model.primalRowSolution());
+  CoinMemcpyN(dj.data(), numberColumns, model.dualColumnSolution());
+  for (int i = 0; i < numberRows; i++)
+    model.dualRowSolution()[i] = dj[numberColumns + i]; // row dj == dual (src/ClpSimplex.cpp:1381-1386)
+  model.setObjectiveValue(clpgpu_objective_value(ctx));
+  clpgpu_destroy(ctx);
+  if (problemStatus == 10) // "needs primal clean-up", src/ClpSimplex.cpp:5808
+    return model.primal(1);
+  return problemStatus;
+}
