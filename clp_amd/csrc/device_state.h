@@ -164,6 +164,8 @@ struct Dev {
   const double *sellElem;
   int numSlices;
   int *touchCol;  // [n] by-row pricing: contributors per column while a tableau row is assembled (zero otherwise)
+  int *touchRow;  // [n * 8] their rows ...
+  double *touchVal;  // [n * 8] ... and products, in ticket order
   const int *longCol;  // [numLong] columns too long for a SELL lane (a wave strides each)
   int numLong;
   double *sellMin, *sellBytes;  // per pricing workgroup

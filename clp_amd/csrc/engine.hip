@@ -85,6 +85,13 @@ struct clpgpu_context {
   int lastCleaned = 0, factorType = 0;
   bool started = false, needStatus = true, weightsInitialized = false;
   bool rebuildRowCopy = true;  // the device keeps the [basic|nonbasic] row partition current between refactorizations
+  // basis / solution at the last good refactorization (ClpSimplex::saveStatus_, savedSolution_): what a
+  // singular refactorization falls back to (ClpSimplexDual.cpp:5060-5125)
+  std::vector<unsigned char> saveStatus;
+  std::vector<double> savedSolution;
+  bool haveSnapshot = false;
+  int numberThrownOut = 0;  // structurals replaced by slacks by the singular-basis repair, whole solve
+  void resetFakeBounds();
   int pivots = 0, kNucleus = 0;
   // ---- device
   Dev D;
@@ -215,7 +222,9 @@ struct clpgpu_context {
   int pushRim();
   int pullRim(bool all);
   int startup();
-  int factorize();
+  int factorize(bool repair = false);
+  int factorizeOnce();
+  int lastSingularColumn = -1, lastSingularRow = -1;
   int ftranDevice(const double *vRow, double *xPos);
   int ftranDevice2(const double *v1Row, const double *v2Row, double *x1Pos, double *x2Pos);
   void preparePlugin();
@@ -590,6 +599,8 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   rc |= dalloc(D.candTag, N);
   rc |= dalloc(D.candLive, N);
   rc |= dalloc(D.touchCol, (size_t)n + 1);
+  rc |= dalloc(D.touchRow, (size_t)n * ROW_SLOTS + 1);
+  rc |= dalloc(D.touchVal, (size_t)n * ROW_SLOTS + 1);
   rc |= dalloc(D.candDj, N);
   rc |= dalloc(D.candRange, N);
   rc |= dalloc(D.candBlk, N);
@@ -908,11 +919,54 @@ int clpgpu_context::pullRim(bool all)
   return rc;
 }
 
+static inline int getFake(unsigned char s) { return (s >> 3) & 3; }
+static inline unsigned char withFake(unsigned char s, int f) { return (unsigned char)((s & ~24) | (f << 3)); }
+static inline unsigned char withStatus(unsigned char s, int st) { return (unsigned char)((s & ~7) | st); }
+
 // ---------------------------------------------------------------------------------------------
 // Refactorization: ClpFactorization::factorize (src/ClpFactorization.cpp:1649) -- collect basic
 // rows then columns, nucleus inversion on the device, pivotVariable from the pivot order.
 // ---------------------------------------------------------------------------------------------
-int clpgpu_context::factorize()
+// repair = true: a dependent basic structural is replaced by the slack of a row no step pivoted on and
+// the factorization is repeated (the loop of ClpFactorization::factorize, src/ClpFactorization.cpp:2382-2532:
+// "take out" at the nearer bound, "put in slack"); returns the number of structurals thrown out (>= 0).
+// repair = false: -1 on a singular basis, as CoinOtherFactorization::factor reports it.
+int clpgpu_context::factorize(bool repair)
+{
+  int thrownOut = 0;
+  for (;;) {
+    int rcOnce = factorizeOnce();
+    if (rcOnce != -1 || !repair)
+      return rcOnce < 0 ? rcOnce : thrownOut;
+    // singular at step s: column s of the nucleus (structural lastSingularColumn) depends on the columns
+    // before it; lastSingularRow was never a pivot row
+    const int seq = lastSingularColumn, iRow = lastSingularRow;
+    if (seq < 0 || iRow < 0 || thrownOut > m)
+      return -1;
+    const double lo = lower[seq], up = upper[seq], value = sol[seq];
+    if (lo > -largeValue || up < largeValue) {
+      if (fabs(value - lo) < fabs(value - up)) {
+        status[seq] = withStatus(status[seq], ST_LOWER);
+        sol[seq] = lo;
+      } else {
+        status[seq] = withStatus(status[seq], ST_UPPER);
+        sol[seq] = up;
+      }
+    } else {
+      status[seq] = withStatus(status[seq], ST_UPPER);  // free: fake bounds follow in changeBounds (see startup)
+    }
+    if (lo == up)
+      status[seq] = withStatus(status[seq], ST_FIXED);
+    status[n + iRow] = withStatus(withFake(status[n + iRow], FAKE_NONE), ST_BASIC);
+    thrownOut++;
+    numberThrownOut++;
+    rebuildRowCopy = true;
+    if (logLevel > 0)
+      fprintf(stderr, "clpgpu: singular basis: structural %d out, slack of row %d in\n", seq, iRow);
+  }
+}
+
+int clpgpu_context::factorizeOnce()
 {
   std::vector<int> kcol, rrows, localOfRow(m, -1);
   int numberBasic = 0;
@@ -1039,6 +1093,8 @@ int clpgpu_context::factorize()
       return rc;
     if (info[0]) {
       setError("factorize: singular nucleus at step %d of %d", info[0] - 1, k);
+      lastSingularColumn = kcol[info[0] - 1];
+      lastSingularRow = (info[2] >= 0 && info[2] < k) ? rrows[info[2]] : -1;
       return -1;
     }
     rc |= d2h(perm.data(), D.perm, k);
@@ -1292,9 +1348,6 @@ void clpgpu_context::checkDualSolution()
   }
 }
 
-static inline int getFake(unsigned char s) { return (s >> 3) & 3; }
-static inline unsigned char withFake(unsigned char s, int f) { return (unsigned char)((s & ~24) | (f << 3)); }
-static inline unsigned char withStatus(unsigned char s, int st) { return (unsigned char)((s & ~7) | st); }
 
 // ClpSimplexDual::changeBounds (src/ClpSimplexDual.cpp:3148-3512) on the host mirrors
 int clpgpu_context::changeBounds(int initialize, double &changeCost)
@@ -1421,6 +1474,43 @@ int clpgpu_context::changeBounds(int initialize, double &changeCost)
     }
   }
   return 1;
+}
+
+// ClpSimplexDual::resetFakeBounds(1) (src/ClpSimplexDual.cpp:8505-8596): working bounds rebuilt from the
+// original ones and the fake-bound flags of the status bytes
+void clpgpu_context::resetFakeBounds()
+{
+  lower = origLower;
+  upper = origUpper;
+  numberFake = 0;
+  for (int i = 0; i < N; i++) {
+    const int fake = getFake(status[i]);
+    if (fake == FAKE_NONE)
+      continue;
+    const int st = status[i] & 7;
+    if (st == ST_BASIC || st == ST_FIXED) {
+      status[i] = withFake(status[i], FAKE_NONE);
+      continue;
+    }
+    const double lowerValue = lower[i], upperValue = upper[i], value = sol[i];
+    numberFake++;
+    if (fake == FAKE_UPPER) {
+      upper[i] = lowerValue + dualBound;
+      sol[i] = (st == ST_LOWER) ? lowerValue : upper[i];
+    } else if (fake == FAKE_LOWER) {
+      lower[i] = upperValue - dualBound;
+      sol[i] = (st == ST_LOWER) ? lower[i] : upperValue;
+    } else if (st == ST_LOWER) {
+      lower[i] = value;
+      upper[i] = value + dualBound;
+    } else if (st == ST_UPPER) {
+      upper[i] = value;
+      lower[i] = value - dualBound;
+    } else {
+      lower[i] = value - 0.5 * dualBound;
+      upper[i] = value + 0.5 * dualBound;
+    }
+  }
 }
 
 int clpgpu_context::numberAtFakeBound() const
@@ -1627,7 +1717,13 @@ int clpgpu_context::startup()
   hCtrl->largeValue = largeValue;
   rebuildRowCopy = true;
   int rc = pushCtrl();
-  rc |= factorize();
+  haveSnapshot = false;
+  numberThrownOut = 0;
+  {
+    int frc = factorize(true);  // a singular starting basis is repaired (ClpSimplex::internalFactorize)
+    if (frc < 0)
+      rc |= frc;
+  }
   if (rc) {
     problemStatus = 4;
     return rc;
@@ -1658,9 +1754,37 @@ int clpgpu_context::statusOfProblemInDual(int type)
     weightsSaved = true;
     if (type) {
       rc |= pullRim(true);
-      int frc = factorize();
+      int frc = factorize(false);
+      if (frc == -1) {
+        // singular (ClpSimplexDual.cpp:5060-5125): back to the basis of the last good factorization with
+        // the leaving variable flagged and a refactorization forced after every pivot; if that basis is
+        // singular too, the repaired basis (dependent structurals out, slacks in)
+        if (haveSnapshot) {
+          for (int i = 0; i < N; i++)
+            if (status[i] & FLAGGED_BIT)
+              saveStatus[i] |= FLAGGED_BIT;
+          status = saveStatus;
+          sol = savedSolution;
+          resetFakeBounds();
+          if (hCtrl->sequenceOut >= 0 && hCtrl->sequenceOut < N)
+            status[hCtrl->sequenceOut] |= FLAGGED_BIT;
+          forceFactorization = 1;
+          rebuildRowCopy = true;
+          frc = factorize(false);
+        }
+        if (frc == -1) {
+          frc = factorize(true);
+          if (frc >= 0)
+            resetFakeBounds();
+        }
+        if (frc >= 0) {
+          frc = 0;
+          type = 2;
+          rc |= pushRim();
+        }
+      }
       if (frc) {
-        problemStatus = 4;  // singular: the reference restores the previous basis and flags (:5064-5125)
+        problemStatus = 4;
         return frc;
       }
     }
@@ -1808,6 +1932,10 @@ int clpgpu_context::statusOfProblemInDual(int type)
     }
     if (dirty)
       rc |= pushRim();
+    // the basis just factorized is the one to come back to (saveStatus_ / savedSolution_, :6212-6222)
+    saveStatus = status;
+    savedSolution = sol;
+    haveSnapshot = true;
     if (weightsSaved) {
       if (tentativeStatus > -3)
         rc |= saveWeights((type < 2) ? 2 : 4);

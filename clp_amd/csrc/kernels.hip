@@ -2475,15 +2475,18 @@ __device__ inline void priceLongBody(const Dev &D, int blk, int countCols)
 // by row only the rows in supp(pi) are read: 12 B x sum of their lengths.
 // Bit-identical to the by-column result without floating-point atomics:
 //   pass 1 (k_price_sell's extra workgroups): a wave per nonzero row of pi walks the nonbasic part of
-//     that row in the row copy; every entry bumps an integer touch counter of its column (order
-//     independent) and the FIRST toucher stores its product pi_i * a_ij as the column's value;
-//   pass 2 (k_price_row_finish, one thread per column): touched once -> that product IS the
-//     by-column sum (the other terms are exact zeros); touched more than once -> the column's own dot
-//     product is recomputed by column, in CSC order, exactly as the by-column kernel does it.  Then the
-//     same fused first ratio pass, candidate flags and per-block counts as the by-column kernels.
+//     that row in the row copy; every entry draws an integer ticket from its column's touch counter
+//     (order independent) and, for the first ROW_SLOTS tickets, leaves (row, pi_i * a_ij) in the
+//     column's slot of that number;
+//   pass 2 (k_price_row_finish, one thread per column): the column's <= ROW_SLOTS contributions are put
+//     in ascending row order and added -- the by-column loop's sum with its exact-zero terms left out;
+//     a column with more contributors (dense pi) recomputes its own dot product by column, in CSC
+//     order.  Then the same fused first ratio pass, candidate flags and per-block counts as the
+//     by-column kernels.
 // Which branch runs is decided on the device from nnz(pi) (popcount of the bitmap) against rowMax;
 // every workgroup of both launches takes the same decision.
 // =============================================================================================
+#define ROW_SLOTS 8  // contributors a column keeps individually in by-row pricing
 __device__ inline int piPopcount256(const Dev &D)
 {
   __shared__ int shPopRow[4];
@@ -2531,8 +2534,14 @@ __device__ inline void priceRowScatterBody(const Dev &D, int blk, int fullRows)
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         if (jj[u] >= D.priceFirst && jj[u] < D.priceLast && (st[u] & 3) != 1) {
-          if (atomicAdd(&D.touchCol[jj[u]], 1) == 0)
-            D.alphaCol[jj[u]] = v * aa[u];
+          // the ticket is order independent; the first ROW_SLOTS contributors leave (row, product) in
+          // the column's slots, pass 2 puts them in row order
+          const int old = atomicAdd(&D.touchCol[jj[u]], 1);
+          if (old < ROW_SLOTS) {
+            const size_t at = (size_t)jj[u] * ROW_SLOTS + old;
+            D.touchRow[at] = i;
+            D.touchVal[at] = v * aa[u];
+          }
           entries++;
         }
       }
@@ -2579,11 +2588,55 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_price_row_finish(Dev D, int nbR
     const int cnt = (j >= D.priceFirst && j < D.priceLast) ? D.touchCol[j] : 0;
     if (cnt) {
       D.touchCol[j] = 0;
-      if (cnt == 1) {
-        value = D.alphaCol[j];
+      if (cnt <= ROW_SLOTS) {
+        // the contributors' products, added in ascending row order: the by-column loop's sum with its
+        // exact-zero terms left out (0.0 + x == x, x + 0.0 == x)
+        int rr[ROW_SLOTS];
+        double vv[ROW_SLOTS];
+        const size_t at = (size_t)j * ROW_SLOTS;
+#pragma unroll
+        for (int u = 0; u < ROW_SLOTS; u++) {
+          rr[u] = u < cnt ? D.touchRow[at + u] : 0x7fffffff;
+          vv[u] = u < cnt ? D.touchVal[at + u] : 0.0;
+        }
+        // odd-even transposition sort on the row index (ROW_SLOTS rounds, registers only)
+#pragma unroll
+        for (int round = 0; round < ROW_SLOTS; round++) {
+#pragma unroll
+          for (int u = round & 1; u + 1 < ROW_SLOTS; u += 2) {
+            if (rr[u + 1] < rr[u]) {
+              int tr = rr[u];
+              rr[u] = rr[u + 1];
+              rr[u + 1] = tr;
+              double tv = vv[u];
+              vv[u] = vv[u + 1];
+              vv[u + 1] = tv;
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < ROW_SLOTS; u++)
+          if (u < cnt)
+            value += vv[u];
       } else {
-        for (int p = D.colStart[j]; p < D.colStart[j + 1]; p++)
-          value += D.piNeg[D.row[p]] * D.elem[p];
+        // more contributors than slots (dense pi): the column's own dot product, eight entries per trip
+        const int pe = D.colStart[j + 1];
+        for (int p0 = D.colStart[j]; p0 < pe; p0 += 8) {
+          int r8[8];
+          double e8[8], p8[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            r8[u] = p0 + u < pe ? D.row[p0 + u] : 0;
+            e8[u] = p0 + u < pe ? D.elem[p0 + u] : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++)
+            p8[u] = D.piNeg[r8[u]];
+#pragma unroll
+          for (int u = 0; u < 8; u++)
+            if (p0 + u < pe)
+              value += p8[u] * e8[u];
+        }
       }
       bytes = 8.0;  // the touched scratch entry
       const int wanted = (D.status[j] & 3) - 1;
@@ -4036,8 +4089,10 @@ __global__ void __launch_bounds__(1024) k_gj_step(Dev D, int i, int k, int *info
   }
   blockArgMax(best, key, shv, shk);
   if (threadIdx.x == 0) {
-    if (key < 0)
+    if (key < 0) {
       info[0] = 1 + i;
+      info[2] = D.perm[i];  // a row no step has pivoted on: its slack can replace the dependent column
+    }
     info[1] = key;
     s_row = key;
   }
@@ -4124,8 +4179,10 @@ __global__ void __launch_bounds__(1024) k_gj_panel(Dev D, int i0, int b, int k, 
     blockArgMax(best, key, shv, shk);
     if (tid == 0) {
       s_row = key;
-      if (key < 0)
+      if (key < 0) {
         info[0] = 1 + i;
+        info[2] = D.perm[i];
+      }
       D.gjPiv[s] = key;
     }
     __syncthreads();
@@ -4246,8 +4303,10 @@ __device__ __forceinline__ bool gjPanelStep(const Dev &D, double (&v)[GJ_RPT][BB
   combine(xchgD<3>(best), xchgI<3>(key));
   const int iRow = key;
   if (tid == 0) {
-    if (iRow < 0)
+    if (iRow < 0) {
       info[0] = 1 + i;
+      sh.row = i;
+    }
     D.gjPiv[out.pcol0 + S] = iRow;
   }
   if (iRow < 0)
@@ -4330,8 +4389,17 @@ __global__ void __launch_bounds__(NT) k_gj_panel_reg(Dev D, int i0, int b, int k
   }
   if (tid == 0)
     sh.nMoved = 0;
-  if (!GjPanelRun<0, GJ_RPT, BB, NT>::run(D, v, pos, sh, i0, b, k, info, D.ctrl->zeroTolerance, out))
+  if (!GjPanelRun<0, GJ_RPT, BB, NT>::run(D, v, pos, sh, i0, b, k, info, D.ctrl->zeroTolerance, out)) {
+    // singular: the row now at the failing position has never been a pivot row; its original index is
+    // what the host needs to put that row's slack into the basis (ClpFactorization.cpp:2382-2532)
+    __syncthreads();
+    const int iFail = sh.row;
+#pragma unroll
+    for (int q = 0; q < GJ_RPT; q++)
+      if (pos[q] == iFail)
+        info[2] = permOld[q];
     return;
+  }
   __syncthreads();
   // rows that ended at another position: move their multipliers -- this panel's and, in the two-level
   // form, those of the outer block's earlier inner panels (columns [0, lcol0): L follows its physical

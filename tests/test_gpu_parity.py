@@ -882,3 +882,26 @@ def test_full_size_by_row_and_by_column_give_the_same_solve(gpu_cls):
     sa, sb = a.stats(), b.stats()
     assert sa["row_launches"] >= 390 and sb["row_launches"] == 0
     assert np.all((la["reserved"] >> 30) & 1 == 1) and np.all((lb["reserved"] >> 30) == 0)
+
+
+# ---------------------------------------------------------------- failure paths -----------------
+def test_singular_starting_basis_is_repaired(gpu_cls):
+    """A warm start whose basis is structurally singular (40 random structurals against 40 random rows of
+    a sparse LP): ClpFactorization::factorize (src/ClpFactorization.cpp:2382-2532) takes the dependent
+    structurals out at their nearer bound, puts the slacks of the unpivoted rows in and repeats; the
+    engine does the same and then solves to the optimum the slack start reaches."""
+    lp = P.sparse_lp(300, 1200, 8, seed=11)
+    rng = np.random.default_rng(5)
+    status = np.full(lp.n + lp.m, 3, np.uint8)
+    status[lp.n:] = 1
+    status[rng.choice(lp.n, 40, replace=False)] = 1
+    status[lp.n + rng.choice(lp.m, 40, replace=False)] = 3
+    g = gpu_cls().loadProblem(lp)
+    assert g.factorize(status)[0] == -1  # the plug-in call reports it (ClpFactorization.hpp:53) ...
+    g2 = gpu_cls().loadProblem(lp)
+    g2.setStatusArray(status)
+    assert g2.dual() == 0  # ... the engine repairs it and carries on
+    o = oracle(lp, 1)
+    assert o.dual() == 0
+    assert abs(g2.objectiveValue() - o.objective) <= RTOL * (1 + abs(o.objective))
+    kkt(lp, g2)
