@@ -1701,6 +1701,8 @@ int clpgpu_context::startup()
   hCtrl->state = EXIT_REFACTOR;
   hCtrl->pivotRow = -1;
   hCtrl->sequenceIn = hCtrl->sequenceOut = -1;
+  for (int i = 0; i < 12; i++)  // progress_.startCheck() (ClpSimplexDual.cpp:452)
+    hCtrl->cycIn[i] = hCtrl->cycOut[i] = -1;
   hCtrl->maximumPivots = maximumPivots;
   hCtrl->maximumIterations = maximumIterations;
   hCtrl->forceFactorization = -1;

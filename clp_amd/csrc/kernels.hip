@@ -1891,6 +1891,63 @@ __device__ void houseBody(Dev D, int skipColumns = 0)
     c->state = EXIT_MAX_ITERATIONS;
     return;
   }
+  // ---- small cycles (ClpSimplex.cpp:2397-2431; ClpSimplexProgress::cycle, ClpSolve.cpp:4726-4825): the last 12
+  // (in, out, way) triples; a repeat of the oldest with everything after it repeating too is a cycle of
+  // that length, two irregular repeats count as 100
+  {
+    int matched = 0;
+    for (int i = 1; i < 12; i++)
+      if (seqIn == c->cycOut[i]) {
+        matched = -1;
+        break;
+      }
+    if (matched && c->cycIn[0] >= 0) {
+      matched = 0;
+      int nMatched = 0;
+      const int way0 = c->cycWay[0], in0 = c->cycIn[0], out0 = c->cycOut[0];
+      for (int kk = 1; kk < 12 - 4; kk++) {
+        if (in0 == c->cycIn[kk] && out0 == c->cycOut[kk] && way0 == c->cycWay[kk]) {
+          nMatched++;
+          const int end = 12 - kk;
+          int j;
+          for (j = 1; j < end; j++)
+            if (c->cycIn[j + kk] != c->cycIn[j] || c->cycOut[j + kk] != c->cycOut[j] || c->cycWay[j + kk] != c->cycWay[j])
+              break;
+          if (j == end) {
+            matched = kk;
+            break;
+          }
+        }
+      }
+      if (matched <= 0 && nMatched > 1)
+        matched = 100;
+    }
+    for (int i = 0; i < 11; i++) {
+      c->cycIn[i] = c->cycIn[i + 1];
+      c->cycOut[i] = c->cycOut[i + 1];
+      c->cycWay[i] = c->cycWay[i + 1];
+    }
+    c->cycIn[11] = seqIn;
+    c->cycOut[11] = seqOut;
+    c->cycWay[11] = 1 - c->directionIn + 4 * (1 - c->directionOut);
+    if (matched > 0) {
+      for (int i = 0; i < 12; i++) {
+        c->cycIn[i] = c->cycOut[i] = -1;
+        c->cycWay[i] = 0;
+      }
+      const double random = randomDouble(c);
+      const int extra = (int)(9.999 * random);
+      const int off[10] = { 1, 1, 1, 1, 2, 2, 2, 3, 3, 4 };
+      if (c->pivots > matched) {
+        c->forceFactorization = max(1, matched - off[extra]);
+      } else {
+        // "need to reject something": the leaving variable is flagged (:2418-2428)
+        D.status[seqOut] = (unsigned char)(D.status[seqOut] | FLAGGED_BIT);
+      }
+      c->state = EXIT_REFACTOR;
+      return;
+    }
+  }
   int numberPivots = c->pivots;
   if (numberPivots == c->maximumPivots || c->maximumPivots < 2) {
     c->state = EXIT_REFACTOR;

@@ -56,6 +56,7 @@ typedef struct {
   long etaCap;
 } Factor;
 
+#define ORC_CYCLE 12 /* CLP_CYCLE, src/ClpSolve.hpp:435 */
 struct OrcModel {
   int m, n;
   int *colStart, *row;
@@ -88,6 +89,8 @@ struct OrcModel {
   int numberPrimalInfeasibilities, numberDualInfeasibilities;
   int numberFake, numberChanged, numberTimesOptimal, forceFactorization, lastBadIteration;
   unsigned int seed;
+  int cycIn[ORC_CYCLE], cycOut[ORC_CYCLE]; /* ClpSimplexProgress in_ / out_ / way_ */
+  char cycWay[ORC_CYCLE];
   int scalingMode;            /* ClpModel::scaling(): 0 off (default here), 1 equilibrium, 2 geometric, 3/4 auto */
   int scalingApplied;         /* last orc_dual really scaled (scale() returned 0) */
   double *rowScale, *colScale; /* [m], [n] of the last scaled solve */
@@ -2013,7 +2016,50 @@ static void logPivot(OrcModel *M, int numberFlipped)
   }
 }
 
-/* ClpSimplex::housekeeping :2065-2489 (no cycle check).  Returns 0 carry on, 1 refactorize,
+/* ClpSimplexProgress::cycle (ClpSolve.cpp:4726-4825): the last ORC_CYCLE (in, out, way) triples; a repeat
+ * of the oldest one with everything after it repeating too is a cycle of that length, two irregular
+ * repeats count as 100 */
+static int progressCycle(OrcModel *M, int in, int out, int wayIn, int wayOut)
+{
+  int matched = 0;
+  for (int i = 1; i < ORC_CYCLE; i++)
+    if (in == M->cycOut[i]) {
+      matched = -1;
+      break;
+    }
+  if (matched && M->cycIn[0] >= 0) {
+    matched = 0;
+    int nMatched = 0;
+    const char way0 = M->cycWay[0];
+    const int in0 = M->cycIn[0], out0 = M->cycOut[0];
+    for (int k = 1; k < ORC_CYCLE - 4; k++) {
+      if (in0 == M->cycIn[k] && out0 == M->cycOut[k] && way0 == M->cycWay[k]) {
+        nMatched++;
+        int end = ORC_CYCLE - k, j;
+        for (j = 1; j < end; j++)
+          if (M->cycIn[j + k] != M->cycIn[j] || M->cycOut[j + k] != M->cycOut[j] || M->cycWay[j + k] != M->cycWay[j])
+            break;
+        if (j == end) {
+          matched = k;
+          break;
+        }
+      }
+    }
+    if (matched <= 0 && nMatched > 1)
+      matched = 100;
+  }
+  for (int i = 0; i < ORC_CYCLE - 1; i++) {
+    M->cycIn[i] = M->cycIn[i + 1];
+    M->cycOut[i] = M->cycOut[i + 1];
+    M->cycWay[i] = M->cycWay[i + 1];
+  }
+  M->cycIn[ORC_CYCLE - 1] = in;
+  M->cycOut[ORC_CYCLE - 1] = out;
+  M->cycWay[ORC_CYCLE - 1] = (char)(1 - wayIn + 4 * (1 - wayOut));
+  return matched;
+}
+
+/* ClpSimplex::housekeeping :2065-2489.  Returns 0 carry on, 1 refactorize,
  * 2 iteration limit. */
 static int housekeeping(OrcModel *M, double objectiveChange, int numberFlipped)
 {
@@ -2042,6 +2088,25 @@ static int housekeeping(OrcModel *M, double objectiveChange, int numberFlipped)
   logPivot(M, numberFlipped);
   if (M->numberIterations >= M->maximumIterations)
     return 2;
+  /* small cycles (:2397-2431, ClpSimplexProgress::cycle ClpSolve.cpp:4726-4825) */
+  {
+    int cycle = progressCycle(M, M->sequenceIn, M->sequenceOut, M->directionIn, M->directionOut);
+    if (cycle > 0) {
+      static const int off[] = { 1, 1, 1, 1, 2, 2, 2, 3, 3, 4 };
+      for (int i = 0; i < ORC_CYCLE; i++) {
+        M->cycIn[i] = M->cycOut[i] = -1;
+        M->cycWay[i] = 0;
+      }
+      double random = randomDouble(M);
+      int extra = (int)(9.999 * random);
+      if (M->fac.nEta > cycle) {
+        M->forceFactorization = cycle - off[extra] > 1 ? cycle - off[extra] : 1;
+      } else {
+        M->status[M->sequenceOut] |= 64; /* setFlagged(sequenceOut_) */
+      }
+      return 1;
+    }
+  }
   int numberPivots = M->fac.nEta;
   if (numberPivots == M->maximumPivots || M->maximumPivots < 2) {
     return 1;
@@ -2546,6 +2611,10 @@ static int dualOnRim(OrcModel *M)
   M->numberFake = 0;
   M->numberChanged = 0;
   M->numberTimesOptimal = 0;
+  for (int i = 0; i < ORC_CYCLE; i++) { /* progress_.startCheck(), ClpSimplexDual.cpp:452 */
+    M->cycIn[i] = M->cycOut[i] = -1;
+    M->cycWay[i] = 0;
+  }
   M->pivotRow = -1;
   M->numberInfeasible = 0;
   M->haveSavedWeights = 0;
