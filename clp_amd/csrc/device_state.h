@@ -25,7 +25,8 @@ enum : int {
   EXIT_MAX_ITERATIONS = 104,
   EXIT_BACKWARDS = 105,     // objective going backwards (:1574)
   EXIT_BAD_UPDATE = 106,    // replaceColumn says singular (:1618)
-  EXIT_STEP_LIMIT = 107     // bench stepping: requested number of pivots done
+  EXIT_STEP_LIMIT = 107,    // bench stepping: requested number of pivots done
+  EXIT_SHARD_OVERFLOW = 108 // column-sharded run: a rank's candidate / flip records exceed the exchange buffer
 };
 
 struct Ctrl {
@@ -75,7 +76,7 @@ struct Ctrl {
   int ticket[8];        // "last workgroup done" counters (always 0 between launches)
   int ticketGroup[4][64];  // first level of the same: one counter per 32 workgroups (<= 2048 workgroups)
   int flipAppend, numberAppend1;
-  int lastPriceByRow, padRow;
+  int lastPriceByRow, shardRowCands;  // row candidates ahead of the column candidates in the local list (sharded runs)
   int cycIn[12], cycOut[12], cycWay[12];  // ClpSimplexProgress in_ / out_ / way_ (CLP_CYCLE = 12, src/ClpSolve.hpp:435)  // form the last pricing launch took (k_price_row_finish)
   int appendGo, flipDense;  // flipDense: this pivot's flip rhs is left to k_flip_dense
   int updGo[2], updK, updPad;  // basis-update branch: go flag per pivot parity, k at the time of the fork

@@ -129,6 +129,14 @@ struct clpgpu_context {
   // ---- multi-GPU (RCCL resolved at run time; a single-GPU build has no link dependency on it)
   int rank = 0, nranks = 1, shardChunk = 0;
   bool commActive = false;
+  // commMode 2 (default): every rank handles only its own column range and the ranks all-gather the
+  // per-rank candidate lists and flip records (k_shard_*); 1: the round-1 form (dense tableau-row
+  // slices all-gathered, everything downstream replicated) -- also what a run falls back to when a
+  // rank's records outgrow the exchange buffer
+  int commMode = 2;
+  int shardCandCap = 2048, shardFlipCap = 512;  // options "shard_cand_cap", "shard_flip_cap"
+  double *dCandSend = nullptr, *dCandRecv = nullptr, *dFlipSend = nullptr, *dFlipRecv = nullptr;
+  int allocShardBuffers();
   void *comm = nullptr;
   int (*ncclAllGatherFn)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
   int (*ncclCommDestroyFn)(void *) = nullptr;
@@ -661,8 +669,10 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   }
   memset(hCtrl, 0, sizeof(Ctrl));
   hCtrl->pivotRow = hCtrl->sequenceIn = hCtrl->sequenceOut = -1;  // model_->pivotRow() before the first pivot
-  if (commActive)
+  if (commActive) {
     applyShard();  // a reload keeps the communicator; the shard follows the new column count
+    rc |= allocShardBuffers();
+  }
   rc |= buildSell();
   rc |= sync();
   started = false;
@@ -687,6 +697,7 @@ void clpgpu_context::releaseProblem()
   kcap = ld = 0;
   logCapacity = 0;
   dKcol = dLocalOfRow = dInfo = nullptr;
+  dCandSend = dCandRecv = dFlipSend = dFlipRecv = nullptr;
   nLongBlocks = nSellBlocks = nChzBlocks = 0;
   weightsInitialized = false;
   haveStatus = false;
@@ -713,10 +724,26 @@ void clpgpu_context::applyShard()
   int chunk = (n + nranks - 1) / nranks;
   chunk = (chunk + PRICE_BLOCK - 1) / PRICE_BLOCK * PRICE_BLOCK;
   shardChunk = chunk;
-  D.firstColumn = 0;
-  D.lastColumn = n;
   D.priceFirst = std::min(rank * chunk, n);
   D.priceLast = std::min((rank + 1) * chunk, n);
+  if (commMode == 2) {
+    D.firstColumn = D.priceFirst;  // candidates, dual update and flip test on the own range only
+    D.lastColumn = D.priceLast;
+  } else {
+    D.firstColumn = 0;
+    D.lastColumn = n;
+  }
+}
+
+int clpgpu_context::allocShardBuffers()
+{
+  const size_t candRec = SHARD_HDR + 4 * (size_t)shardCandCap, flipRec = SHARD_HDR + 5 * (size_t)shardFlipCap;
+  int rc = 0;
+  rc |= dalloc(dCandSend, candRec);
+  rc |= dalloc(dCandRecv, candRec * (size_t)nranks);
+  rc |= dalloc(dFlipSend, flipRec);
+  rc |= dalloc(dFlipRecv, flipRec * (size_t)nranks);
+  return rc;
 }
 
 // launch errors (bad extents, missing code object) are sticky until read: surface them where the
@@ -2038,7 +2065,9 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
     KL("k_gemvT_partial2", k_gemvT_partial2, dim3(cdiv(kc, 256), cdiv(kc, 64)), dim3(256), 0, stream, D, (const double *)D.slotA, 1);
   // (not column-sharded: the candidate counts come from this kernel and the pricing kernel, there
   // is no separate counting launch)
-  const bool countInPrice = priceKernel >= 1 && !commActive && nb > 256;
+  const bool gatherRows = commActive && commMode == 1;  // round-1 exchange: dense row slices, candidates recomputed from them
+  const bool shardLists = commActive && commMode == 2;  // candidate / flip lists exchanged, reduced costs owned by the shard
+  const bool countInPrice = priceKernel >= 1 && !gatherRows && nb > 256;
   // by-row pricing for sparse pi (needs the bitmap and the count-in-price compaction scheme)
   const int nSlots = nSellBlocks + nLongBlocks;
   const int rowMax = (rowPriceFrac > 0.0 && countInPrice && !widePricing && priceKernel >= 2 && m <= 64 * SELL_BITS_MAX && nSlots > 0)
@@ -2060,8 +2089,8 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
     }
     if (ev)
       (void)hipEventRecord(evStop[evUsed++], stream);
-    if (commActive) {
-      // exchange step of the column-sharded pricing: every rank contributes its slice of
+    if (gatherRows) {
+      // round-1 exchange (also the fallback of the list exchange): every rank contributes its slice of
       // the tableau row and of the first-pass flags, in place; everything after is replicated
       const size_t chunk = (size_t)shardChunk;
       ncclAllGatherFn(D.alphaCol + (size_t)rank * chunk, D.alphaCol, chunk, 8 /* ncclFloat64 */, comm, stream);
@@ -2071,7 +2100,7 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
       const int nSell = (widePricing && priceKernel != 1) ? nWideBlocks : nSellBlocks + nLongBlocks;
       const bool fuse = nb <= 256;  // small grids: the last workgroup scans the counts itself
       if (!countInPrice)
-        KL("k_cand_count", k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, commActive ? 1 : 0, fuse ? nSell : -1);
+        KL("k_cand_count", k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, gatherRows ? 1 : 0, fuse ? nSell : -1);
       selfScanSell = fuse ? -1 : nSell;  // large grids: k_cand_scatter scans for itself, no scan launch
     }
   } else {
@@ -2081,11 +2110,25 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
     KL("k_scan_blocks", k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1, 0);
   }
   KL("k_cand_scatter", k_cand_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, selfScanSell);
-  // CHUZC (also unpacks the entering column)
-  KL("k_dual_column", k_dual_column, dim3(1), dim3(DC_THREADS), 0, stream, D, nb);
+  if (shardLists) {
+    // the local list is [row candidates (replicated) | this rank's column candidates]: the column part
+    // of every rank, gathered in rank order behind the rows, is the single-GPU list
+    KL("k_shard_pack_cands", k_shard_pack_cands, dim3(1), dim3(256), 0, stream, D, nbRows, dCandSend, shardCandCap);
+    ncclAllGatherFn(dCandSend, dCandRecv, SHARD_HDR + 4 * (size_t)shardCandCap, 8 /* ncclFloat64 */, comm, stream);
+    KL("k_shard_merge_cands", k_shard_merge_cands, dim3(cdiv(shardCandCap, 256), nranks), dim3(256), 0, stream, D, (const double *)dCandRecv,
+       nranks, shardCandCap);
+  }
+  // CHUZC (the working-set shortcut needs per-block class counts of the whole list: not in sharded runs)
+  KL("k_dual_column", k_dual_column, dim3(1), dim3(DC_THREADS), 0, stream, D, shardLists ? DC_NB_MAX + 1 : nb);
   // dual update + flip detection (needs only theta), flip list, flip right-hand side
   // (+ 1: the extra workgroup unpacks the entering column)
   KL("k_dj_flags", k_dj_flags, dim3(nb + 1), dim3(PRICE_BLOCK), 0, stream, D, nbRows, flipListCap);
+  if (shardLists) {
+    KL("k_shard_pack_flips", k_shard_pack_flips, dim3(1), dim3(256), 0, stream, D, dFlipSend, shardFlipCap, flipListCap);
+    ncclAllGatherFn(dFlipSend, dFlipRecv, SHARD_HDR + 5 * (size_t)shardFlipCap, 8 /* ncclFloat64 */, comm, stream);
+    KL("k_shard_merge_flips", k_shard_merge_flips, dim3(1), dim3(256), 0, stream, D, (const double *)dFlipRecv, rank, nranks, shardFlipCap,
+       flipListCap);
+  }
   KL("k_flip_apply2", k_flip_apply2, dim3(1), dim3(1024), 0, stream, D, gm, denseColumns ? 1 : 0, flipListCap);
   if (denseColumns)
     KL("k_flip_dense", k_flip_dense, dim3(gm), dim3(256), 0, stream, D);
@@ -2283,6 +2326,19 @@ int clpgpu_context::whileIterating(int stepTarget)
   }
   case EXIT_BACKWARDS:
     hipLaunchKernelGGL(k_unroll_weights, dim3(g), dim3(256), 0, stream, D);
+    problemStatus = -2;
+    break;
+  case EXIT_SHARD_OVERFLOW:
+    // a rank's candidate or flip records outgrew the exchange buffer (every rank sees the same headers,
+    // so all of them arrive here at the same pivot): the pivot is abandoned, the run continues with the
+    // dense row-slice exchange, and the refactorization + resync that follows recomputes every reduced
+    // cost (the non-owned ones were stale) and the basic solution
+    commMode = 1;
+    D.firstColumn = 0;
+    D.lastColumn = n;
+    dropGraph();
+    if (logLevel > 0)
+      fprintf(stderr, "clpgpu: rank %d: exchange buffer overflow at iteration %d, falling back to the dense row exchange\n", rank, numberIterations);
     problemStatus = -2;
     break;
   case EXIT_BAD_UPDATE: {
@@ -3162,7 +3218,12 @@ int clpgpu_comm_init(clpgpu_context *ctx, int rank, int nranks, const void *id12
   ctx->rank = rank;
   ctx->nranks = nranks;
   ctx->commActive = true;
+  ctx->commMode = getenv("CLPGPU_COMM_MODE") ? atoi(getenv("CLPGPU_COMM_MODE")) : ctx->commMode;
+  if (ctx->commMode != 1)
+    ctx->commMode = 2;
   ctx->applyShard();
+  if (ctx->allocShardBuffers())
+    return -99;
   ctx->useGraph = 0;  // collectives are enqueued between kernels; keep the eager chain
   rc = ctx->buildSell();
   return rc;
@@ -3213,6 +3274,21 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "blocked_refactor")) ctx->blockedRefactor = (int)v;
   else if (!strcmp(name, "register_panel")) ctx->registerPanel = (int)v;
   else if (!strcmp(name, "refactor_mode")) ctx->refactorMode = (int)v;
+  else if (!strcmp(name, "shard_cand_cap")) {
+    if (ctx->commActive)
+      return -2;  // sizes the exchange buffers: before clpgpu_comm_init
+    ctx->shardCandCap = std::max(1, (int)v);
+  }
+  else if (!strcmp(name, "shard_flip_cap")) {
+    if (ctx->commActive)
+      return -2;
+    ctx->shardFlipCap = std::max(1, (int)v);
+  }
+  else if (!strcmp(name, "comm_mode")) {
+    if (ctx->commActive)
+      return -2;
+    ctx->commMode = (int)v == 1 ? 1 : 2;
+  }
   else if (!strcmp(name, "refactor_min_k")) ctx->refactorMinK = (int)v;
   else if (!strcmp(name, "fork_update")) { ctx->forkUpdate = (int)v; ctx->dropGraph(); }
   else if (!strcmp(name, "row_price_frac")) { ctx->rowPriceFrac = v < 0.0 ? 0.0 : v; ctx->dropGraph(); }

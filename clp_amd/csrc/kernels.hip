@@ -2966,6 +2966,167 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_cand_count(Dev D, int nbRows, i
 
 
 // =============================================================================================
+// Column-sharded engine (one process per GPU): every rank prices, compacts, updates and
+// flip-tests only its own contiguous column range (plus the rows, which are replicated) and the ranks
+// exchange what the replicated part of the pivot needs -- the reduce of ABOCA_LITE's chunks
+// (src/ClpPackedMatrix.cpp:1848-1854: min upperTheta, counts summed, lists concatenated in chunk order)
+// and of Abc's blocked ratio test (src/AbcSimplexDual.cpp:1623-1634), done as ONE all-gather of the
+// per-rank candidate lists {sequence, alpha, dj, range} with a {count, min ratio} header: the merged
+// list in rank order IS the single-GPU list, so the replicated ratio test takes bit-identical
+// decisions.  (A literal all-reduce of the {theta, thru, increase, best pivot} struct per ratio-test
+// pass would put ~11 dependent collectives of ~10 us each into a 150 us pivot.)  After the ratio test
+// the bound flips each rank found in its range travel the same way.  Reduced costs are owned by the
+// rank that owns the column; nothing between two refactorizations reads a non-owned one.
+// Record layouts in doubles (integers are exact): candidates [count, minRatio | seq, alpha, dj, range]*,
+// flips [count, 0 | key, movement, objective term, column start, column length]*.
+// =============================================================================================
+#define SHARD_HDR 2
+// own-column part of the local candidate list -> send buffer (one workgroup)
+__global__ void __launch_bounds__(256) k_shard_pack_cands(Dev D, int nbRows, double *send, int cap)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ int shi[17];
+  int local = 0;
+  for (int b = threadIdx.x; b < nbRows; b += blockDim.x)
+    local += D.blockCount[b];
+  const int nRow = blockSumInt(local, shi);
+  const int cnt = c->numberCandidates - nRow;
+  if (threadIdx.x == 0) {
+    send[0] = (double)cnt;
+    send[1] = c->upperTheta;
+    c->shardRowCands = nRow;
+  }
+  for (int i = threadIdx.x; i < cnt && i < cap; i += blockDim.x) {
+    double *r = send + SHARD_HDR + 4 * (size_t)i;
+    r[0] = (double)D.candSeq[nRow + i];
+    r[1] = D.candAlpha[nRow + i];
+    r[2] = D.candDj[nRow + i];
+    r[3] = D.candRange[nRow + i];
+  }
+}
+// every rank's list behind the (replicated) row candidates, in rank order; totals and the global min ratio
+__global__ void __launch_bounds__(256) k_shard_merge_cands(Dev D, const double *recv, int nranks, int cap)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  const size_t stride = SHARD_HDR + 4 * (size_t)cap;
+  const int nRow = c->shardRowCands;
+  int base = nRow, total = nRow;
+  bool overflow = false;
+  double vmin = 1.0e31;
+  const int me = blockIdx.y;  // the rank whose records this workgroup row copies
+  for (int r = 0; r < nranks; r++) {
+    const int cnt = (int)recv[r * stride];
+    if (cnt > cap)
+      overflow = true;
+    if (r < me)
+      base += cnt;
+    total += cnt;
+    vmin = fmin(vmin, recv[r * stride + 1]);
+  }
+  if (overflow) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+      c->state = EXIT_SHARD_OVERFLOW;
+    return;
+  }
+  const int cnt = (int)recv[me * stride];
+  const double *src = recv + me * stride + SHARD_HDR;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
+    const int seq = (int)src[4 * (size_t)i];
+    D.candSeq[base + i] = seq;
+    D.candAlpha[base + i] = src[4 * (size_t)i + 1];
+    D.candDj[base + i] = src[4 * (size_t)i + 2];
+    D.candRange[base + i] = src[4 * (size_t)i + 3];
+    // the ratio test reads and shifts the reduced costs of candidates: this rank's copy of a column it
+    // does not own is brought up to date here (the owner's value, bit for bit)
+    D.dj[seq] = src[4 * (size_t)i + 2];
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    c->numberCandidates = total;
+    c->upperTheta = vmin;
+  }
+}
+// this rank's flip records -> send buffer (one workgroup)
+__global__ void __launch_bounds__(256) k_shard_pack_flips(Dev D, double *send, int cap, int listCap)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  const int cnt = c->flipAppend;
+  if (threadIdx.x == 0) {
+    // (more flips than the append buffer holds have no records at all: reported as overflow)
+    send[0] = (double)(cnt > listCap ? cap + 1 : cnt);
+    send[1] = 0.0;
+  }
+  for (int i = threadIdx.x; i < cnt && i < cap && i < listCap; i += blockDim.x) {
+    double *r = send + SHARD_HDR + 5 * (size_t)i;
+    r[0] = (double)D.flipKey[i];
+    r[1] = D.flipRecMv[i];
+    r[2] = D.flipRecObj[i];
+    r[3] = (double)D.flipRecStart[i];
+    r[4] = (double)D.flipRecLen[i];
+  }
+}
+// merged flip list: the row flips (every rank found the same ones) from this rank's own records, the
+// column flips of every rank in rank order (one workgroup; k_flip_apply2 orders by key afterwards)
+__global__ void __launch_bounds__(256) k_shard_merge_flips(Dev D, const double *recv, int rank, int nranks, int cap, int listCap)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ int shi[17];
+  __shared__ int s_out;
+  const size_t stride = SHARD_HDR + 5 * (size_t)cap;
+  bool overflow = false;
+  for (int r = 0; r < nranks; r++)
+    if ((int)recv[r * stride] > cap)
+      overflow = true;
+  if (threadIdx.x == 0)
+    s_out = 0;
+  __syncthreads();
+  if (!overflow) {
+    for (int pass = 0; pass <= nranks; pass++) {
+      // pass 0: own row flips; pass 1 + r: column flips of rank r
+      const int r = pass == 0 ? rank : pass - 1;
+      const int cnt = (int)recv[r * stride];
+      const double *src = recv + r * stride + SHARD_HDR;
+      for (int i0 = 0; i0 < cnt; i0 += blockDim.x) {
+        const int i = i0 + threadIdx.x;
+        int key = -1;
+        if (i < cnt)
+          key = (int)src[5 * (size_t)i];
+        const int take = key >= 0 && ((pass == 0) == (key < D.m));
+        int tot;
+        const int rk = blockRank(take, tot, shi);
+        const int o = s_out + rk;
+        if (take && o < listCap) {
+          D.flipKey[o] = key;
+          D.flipRecMv[o] = src[5 * (size_t)i + 1];
+          D.flipRecObj[o] = src[5 * (size_t)i + 2];
+          D.flipRecStart[o] = (int)src[5 * (size_t)i + 3];
+          D.flipRecLen[o] = (int)src[5 * (size_t)i + 4];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+          s_out += tot;
+        __syncthreads();
+      }
+    }
+    if (s_out > listCap)
+      overflow = true;
+  }
+  if (threadIdx.x == 0) {
+    if (overflow)
+      c->state = EXIT_SHARD_OVERFLOW;
+    else
+      c->flipAppend = s_out;
+  }
+}
+
+// =============================================================================================
 // Fused stages: fewer grid-wide dependencies per pivot (each launch costs ~4 us on 256 CUs)
 // =============================================================================================
 

@@ -2,11 +2,14 @@
 the engine for the per-pivot exchange.
 
 Protocol: structural columns are split into `world` contiguous,
-256-aligned ranges; each rank prices its range, the slices of the tableau row and of the first-pass
-candidate flags are all-gathered in place (RCCL over xGMI, ~9 bytes per column per pivot), and
-everything downstream (ratio test, solves, updates) runs replicated and deterministic, so the ranks
-stay in lock step without any further message.  The ncclUniqueId is created by rank 0 inside the
-engine and broadcast here through torch.distributed (any backend; gloo on CPU for the tests).
+256-aligned ranges.  Each rank prices, compacts, dual-updates and flip-tests only its own range (the
+rows are replicated); per pivot the ranks all-gather (RCCL over xGMI) their candidate lists
+{sequence, alpha, dj, range} + {count, min ratio} before the ratio test and their bound-flip records
+after it -- a few tens of KB -- and everything else (CHUZR, solves, ratio test on the merged list,
+basis update) runs replicated and deterministic, so the ranks stay in lock step.  Rank-major
+concatenation of the lists is the single-GPU order, so the pivot sequence is the single-GPU one.  The
+ncclUniqueId is created by rank 0 inside the engine and broadcast here through torch.distributed (any
+backend; gloo on CPU for the tests).
 """
 from __future__ import annotations
 

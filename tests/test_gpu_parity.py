@@ -552,6 +552,43 @@ def test_forced_communicator_one_rank_matches_unsharded(gpu_cls, monkeypatch):
     assert np.array_equal(ref.solution(), g.solution())
 
 
+def test_forced_communicator_exchange_overflow_falls_back(gpu_cls, monkeypatch):
+    """A candidate list longer than the exchange buffer (shard_cand_cap = 4) abandons that pivot on every
+    rank, switches to the dense row-slice exchange after a full resync and still reaches the optimum."""
+    from clp_amd.multigpu import attach_communicator
+
+    lp = P.sparse_lp(1500, 6000, 10, 31)
+    ref = gpu_cls().loadProblem(lp)
+    assert ref.dual() == 0
+    monkeypatch.setenv("CLPGPU_FORCE_COMM", "1")
+    g = gpu_cls().loadProblem(lp)
+    g.set_option("shard_cand_cap", 4)
+    attach_communicator(g, 0, 1)
+    assert g.dual() == 0
+    assert abs(g.objectiveValue() - ref.objectiveValue()) <= RTOL * (1 + abs(ref.objectiveValue()))
+    kkt(lp, g)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_forced_communicator_modes_match_unsharded(gpu_cls, monkeypatch, mode):
+    """both exchange forms (comm_mode 1: dense row slices; 2: candidate / flip lists, the default) with a
+    one-rank communicator on a larger LP whose pricing also goes by row"""
+    from clp_amd.multigpu import attach_communicator
+
+    lp = P.sparse_lp(20000, 70000, 12, 7)
+    ref = gpu_cls().loadProblem(lp)
+    assert ref.dual_steps(600) == -1
+    monkeypatch.setenv("CLPGPU_FORCE_COMM", "1")
+    g = gpu_cls().loadProblem(lp)
+    g.set_option("comm_mode", mode)
+    attach_communicator(g, 0, 1)
+    assert g.dual_steps(600) == -1
+    la, lb = ref.pivotLog(), g.pivotLog()
+    for key in ("sequenceIn", "sequenceOut", "pivotRow", "numberFlipped"):
+        assert np.array_equal(la[key], lb[key])
+    assert np.array_equal(ref.solution(), g.solution())
+
+
 def _two_rank_worker(rank, world, port, out):
     import torch
     import torch.distributed as dist
