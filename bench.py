@@ -154,7 +154,7 @@ def main():
     ap.add_argument("--check-every", type=int, default=16)
     ap.add_argument("--workload", default="sparse", choices=["sparse", "dense", "netlib"],
                     help="sparse = BASELINE configs[3] (default, the quoted metric); dense = configs[2]; netlib = power-law variant")
-    ap.add_argument("--tto-budget", type=float, default=40.0, help="seconds allowed for the time-to-optimal leg (0 skips it)")
+    ap.add_argument("--tto-budget", type=float, default=20.0, help="seconds allowed for the time-to-optimal leg (0 skips it)")
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"], help="live PMC traffic of the pricing kernel via rocprofv3 child runs")
     ap.add_argument("--pmc-timeout", type=float, default=150.0)
     ap.add_argument("--clp-timeout", type=float, default=600.0)

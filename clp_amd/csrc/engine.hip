@@ -737,6 +737,8 @@ void clpgpu_context::applyShard()
 
 int clpgpu_context::allocShardBuffers()
 {
+  if (dalloc(D.classBlock, 3 * (size_t)(cdiv(m, PRICE_BLOCK) + cdiv(n, PRICE_BLOCK) + cdiv(nranks * shardCandCap, PRICE_BLOCK) + 4)))
+    return -99;
   const size_t candRec = SHARD_HDR + 4 * (size_t)shardCandCap, flipRec = SHARD_HDR + 5 * (size_t)shardFlipCap;
   int rc = 0;
   rc |= dalloc(dCandSend, candRec);
@@ -1041,11 +1043,11 @@ int clpgpu_context::factorizeOnce()
     int mode = refactorMode;
     if (mode < 0)
       mode = (blockedRefactor && k >= refactorMinK) ? 3 : 1;
-    if (mode >= 2 && (!blockedRefactor || k > 8192))
-      mode = 1;  // the register panels of the two-level form hold up to 8192 rows
+    if (mode >= 2 && (!blockedRefactor || k > 16384))
+      mode = 1;  // the register panels of the two-level form hold up to 16384 rows
     if (mode >= 2) {
       // two-level in-place form (see k_gj2_*): M = workW, identity side implicit
-      const int bIn = k <= 4096 ? 8 : 4;
+      const int bIn = k <= 4096 ? 8 : (k <= 8192 ? 4 : 2);
       for (int I0 = 0; I0 < k; I0 += GJ_NB) {
         const int nb = std::min(GJ_NB, k - I0);
         for (int j0 = 0; j0 < nb; j0 += bIn) {
@@ -1057,8 +1059,10 @@ int clpgpu_context::factorizeOnce()
             hipLaunchKernelGGL((k_gj_panel_reg<4, 8, 512>), dim3(1), dim3(512), 0, stream, D, i0, b, k, dInfo, out);
           else if (k <= 4096)
             hipLaunchKernelGGL((k_gj_panel_reg<8, 8, 512>), dim3(1), dim3(512), 0, stream, D, i0, b, k, dInfo, out);
-          else
+          else if (k <= 8192)
             hipLaunchKernelGGL((k_gj_panel_reg<8, 4, 1024>), dim3(1), dim3(1024), 0, stream, D, i0, b, k, dInfo, out);
+          else
+            hipLaunchKernelGGL((k_gj_panel_reg<16, 2, 1024>), dim3(1), dim3(1024), 0, stream, D, i0, b, k, dInfo, out);
           const int c0 = i0 + b, c1 = I0 + nb;
           if (c1 > c0) {
             // the rest of the outer panel: this inner panel's swaps, pivot-row values, rank-b update
@@ -2118,8 +2122,13 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
     KL("k_shard_merge_cands", k_shard_merge_cands, dim3(cdiv(shardCandCap, 256), nranks), dim3(256), 0, stream, D, (const double *)dCandRecv,
        nranks, shardCandCap);
   }
-  // CHUZC (the working-set shortcut needs per-block class counts of the whole list: not in sharded runs)
-  KL("k_dual_column", k_dual_column, dim3(1), dim3(DC_THREADS), 0, stream, D, shardLists ? DC_NB_MAX + 1 : nb);
+  // CHUZC; in sharded runs the classes of the working-set shortcut are those of the merged list
+  int nbClass = nb;
+  if (shardLists) {
+    nbClass = cdiv(m + nranks * shardCandCap, PRICE_BLOCK);
+    KL("k_shard_classes", k_shard_classes, dim3(nbClass), dim3(PRICE_BLOCK), 0, stream, D);
+  }
+  KL("k_dual_column", k_dual_column, dim3(1), dim3(DC_THREADS), 0, stream, D, nbClass);
   // dual update + flip detection (needs only theta), flip list, flip right-hand side
   // (+ 1: the extra workgroup unpacks the entering column)
   KL("k_dj_flags", k_dj_flags, dim3(nb + 1), dim3(PRICE_BLOCK), 0, stream, D, nbRows, flipListCap);

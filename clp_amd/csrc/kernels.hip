@@ -3049,6 +3049,49 @@ __global__ void __launch_bounds__(256) k_shard_merge_cands(Dev D, const double *
     c->upperTheta = vmin;
   }
 }
+// classes / ranks of the merged list for the ratio test's working-set shortcut, exactly as k_cand_scatter
+// leaves them on one GPU (there the "blocks" are 256 keys; any partition of the list in list order gives the
+// same working set): 256 merged candidates per workgroup
+__global__ void __launch_bounds__(PRICE_BLOCK) k_shard_classes(Dev D)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  const int i = blockIdx.x * PRICE_BLOCK + threadIdx.x;
+  const bool have = i < c->numberCandidates;
+  int cls = 3;
+  if (have) {
+    const double tol = c->dualTolerance, alpha = D.candAlpha[i], djv = D.candDj[i];
+    const double x = (alpha < 0.0) ? (djv - tol) / alpha : (djv + tol) / alpha;
+    const double theta0 = fmax(10.0 * c->upperTheta, 1.0e-7);
+    cls = (x <= theta0 * 8.0) ? 0 : ((x <= theta0 * 256.0) ? 1 : ((x <= theta0 * 16384.0) ? 2 : 3));
+    D.candLive[i] = (unsigned char)cls;
+  }
+  __shared__ int shc[PRICE_BLOCK / 64][3];
+  int before[3];
+  const int lane = threadIdx.x & 63, wvi = threadIdx.x >> 6;
+  for (int j = 0; j < 3; j++) {
+    unsigned long long mk = __ballot(cls == j);
+    before[j] = (int)__popcll(mk & ((1ull << lane) - 1ull));
+    if (lane == 0)
+      shc[wvi][j] = (int)__popcll(mk);
+  }
+  __syncthreads();
+  if (have) {
+    for (int j = 0; j < 3; j++)
+      for (int w = 0; w < wvi; w++)
+        before[j] += shc[w][j];
+    const int r0 = before[0], r1 = r0 + before[1], r2 = r1 + before[2];
+    D.candRk[i] = r0 | (r1 << 10) | (r2 << 20);
+    D.candBlk[i] = (int)blockIdx.x;
+  }
+  if (threadIdx.x < 3) {
+    int s = 0;
+    for (int w = 0; w < PRICE_BLOCK / 64; w++)
+      s += shc[w][threadIdx.x];
+    D.classBlock[3 * blockIdx.x + threadIdx.x] = s;
+  }
+}
 // this rank's flip records -> send buffer (one workgroup)
 __global__ void __launch_bounds__(256) k_shard_pack_flips(Dev D, double *send, int cap, int listCap)
 {
@@ -4465,6 +4508,7 @@ struct GjShared {
   int nMoved;
   double prow[GJ_B];
   int movedPos[2 * GJ_B];
+  int movedPerm[2 * GJ_B];
   double movedL[2 * GJ_B][GJ_NB];
 };
 // where a panel leaves its multipliers and pivots: L[r * ldL + lcol0 + s], gjPiv[pcol0 + s].  The
@@ -4595,12 +4639,11 @@ __global__ void __launch_bounds__(NT) k_gj_panel_reg(Dev D, int i0, int b, int k
     out.L = D.gjL;
   const int tid = threadIdx.x;
   double v[GJ_RPT][BB];
-  int pos[GJ_RPT], permOld[GJ_RPT];
+  int pos[GJ_RPT];
 #pragma unroll
   for (int q = 0; q < GJ_RPT; q++) {
     int r = tid + q * NT;
     pos[q] = r < k ? r : -1;
-    permOld[q] = r < k ? D.perm[r] : 0;
 #pragma unroll
     for (int t = 0; t < BB; t++)
       v[q][t] = (r < k && t < b) ? D.workW[(size_t)r * D.ld + i0 + t] : 0.0;
@@ -4615,7 +4658,7 @@ __global__ void __launch_bounds__(NT) k_gj_panel_reg(Dev D, int i0, int b, int k
 #pragma unroll
     for (int q = 0; q < GJ_RPT; q++)
       if (pos[q] == iFail)
-        info[2] = permOld[q];
+        info[2] = D.perm[tid + q * NT];  // (perm is only rewritten at the end of a successful panel)
     return;
   }
   __syncthreads();
@@ -4629,13 +4672,15 @@ __global__ void __launch_bounds__(NT) k_gj_panel_reg(Dev D, int i0, int b, int k
     if (r < k && pos[q] != r) {
       int slot = atomicAdd(&sh.nMoved, 1);
       sh.movedPos[slot] = pos[q];
+      sh.movedPerm[slot] = D.perm[r];
       for (int t = 0; t < ncL; t++)
         sh.movedL[slot][t] = out.L[(size_t)r * out.ldL + t];
-      D.perm[pos[q]] = permOld[q];
     }
   }
   __syncthreads();
   const int nMoved = sh.nMoved;
+  for (int e = tid; e < nMoved; e += NT)
+    D.perm[sh.movedPos[e]] = sh.movedPerm[e];
   for (int e = tid; e < nMoved * ncL; e += NT) {
     int slot = e / ncL, t = e - slot * ncL;
     out.L[(size_t)sh.movedPos[slot] * out.ldL + t] = sh.movedL[slot][t];

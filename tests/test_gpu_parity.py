@@ -952,3 +952,27 @@ def test_singular_starting_basis_is_repaired(gpu_cls):
     assert o.dual() == 0
     assert abs(g2.objectiveValue() - o.objective) <= RTOL * (1 + abs(o.objective))
     kkt(lp, g2)
+
+
+def test_two_level_reinversion_beyond_8192(gpu_cls):
+    """k = 8300: the 2-column register panel on 1024 threads (16 rows per thread), 130 outer blocks.  B^-1 B = I."""
+    lp = P.dense_lp(8500, 8600, 4)
+    rng = np.random.default_rng(11)
+    m, n, k = lp.m, lp.n, 8300
+    status = np.full(n + m, 3, np.uint8)
+    status[n:] = 1
+    status[rng.choice(n, k, replace=False)] = 1
+    status[n + rng.choice(m, k, replace=False)] = 3
+    g = gpu_cls().loadProblem(lp)
+    rc, pv = g.factorize(status)
+    assert rc == 0
+    for pos in rng.choice(m, 4, replace=False):
+        seq = int(pv[pos])
+        col = np.zeros(m)
+        if seq >= n:
+            col[seq - n] = -1.0
+        else:
+            col[lp.row[lp.col_start[seq]:lp.col_start[seq + 1]]] = lp.elem[lp.col_start[seq]:lp.col_start[seq + 1]]
+        e = np.zeros(m)
+        e[pos] = 1.0
+        assert np.allclose(g.ftran(col), e, atol=1e-5)
