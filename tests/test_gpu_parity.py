@@ -544,6 +544,11 @@ def test_forced_communicator_one_rank_matches_unsharded(gpu_cls, monkeypatch):
     assert ref.dual() == 0
     monkeypatch.setenv("CLPGPU_FORCE_COMM", "1")
     g = gpu_cls().loadProblem(lp)
+    # (an exchange buffer that holds any candidate list of this LP: with the default 2048 a late, dense
+    # tableau row overflows it and the run continues, correctly but with an extra resync, in the
+    # dense-exchange form -- test_forced_communicator_exchange_overflow_falls_back)
+    g.set_option("shard_cand_cap", 8192)
+    g.set_option("shard_flip_cap", 4096)
     first, last = attach_communicator(g, 0, 1)
     assert (first, last) == (0, lp.n)
     assert g.dual() == 0
