@@ -101,6 +101,7 @@ struct Dev {
   // partition maintainable in O(column length) per pivot (cf. ClpPackedMatrix3::swapOne)
   const int *rowStart;
   int *ccol;
+  int *cslot;  // [nnz] col-slot of the entry's column while it is in the basic part of its row
   double *relem;
   int *csrToCsc;
   int *cscToCsr;

@@ -552,6 +552,7 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   rc |= dalloc(dElem, nnz);
   rc |= dalloc(dRowStart, m + 1);
   rc |= dalloc(D.ccol, nnz);
+  rc |= dalloc(D.cslot, nnz);
   rc |= dalloc(D.relem, nnz);
   rc |= dalloc(D.csrToCsc, nnz);
   rc |= dalloc(D.cscToCsr, nnz);
@@ -1184,6 +1185,8 @@ int clpgpu_context::factorizeOnce()
   
   rebuildRowCopy = false;
   }
+  // the slots were renumbered: the basic entries of the row copy carry their column's slot
+  hipLaunchKernelGGL(k_cslot_rebuild, dim3(cdiv(m, 256)), dim3(256), 0, stream, D);
   kNucleus = k;
   pivots = 0;
   hCtrl->k = k;

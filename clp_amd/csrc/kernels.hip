@@ -1389,7 +1389,7 @@ __global__ void k_ftran_scatter(Dev D, const double *v1, const double *v2, const
       double a1 = 0.0, a2 = 0.0;
       int s = D.rowStart[t], e = s + D.basicCount[t];
       for (int q = s; q < e; q++) {
-        int sc = D.slotOfCol[D.ccol[q]];
+        int sc = D.cslot[q];  // col-slot of the basic entry, kept with it in the row copy
         double a = D.relem[q];
         a1 += a * xk1[sc];
         if (v2)
@@ -1690,14 +1690,23 @@ __device__ inline void rowCopySwap(const Dev &D, int e, int b)
   int ce = D.ccol[e], cb = D.ccol[b];
   double ve = D.relem[e], vb = D.relem[b];
   int pe = D.csrToCsc[e], pb = D.csrToCsc[b];
+  int se = D.cslot[e], sb = D.cslot[b];
   D.ccol[e] = cb;
   D.relem[e] = vb;
   D.csrToCsc[e] = pb;
   D.cscToCsr[pb] = e;
+  D.cslot[e] = sb;
   D.ccol[b] = ce;
   D.relem[b] = ve;
   D.csrToCsc[b] = pe;
   D.cscToCsr[pe] = b;
+  D.cslot[b] = se;
+}
+// col-slot the entering structural is about to get (houseBody's bookkeeping: case 0 takes the leaving
+// column's slot, case 1 the new last slot)
+__device__ inline int enteringSlot(const Ctrl *c)
+{
+  return c->updateCase == 0 ? c->slotColOut : c->k;
 }
 
 // wide mode: one of the two column moves of houseBody, one thread per entry (distinct rows)
@@ -1721,6 +1730,7 @@ __global__ void __launch_bounds__(256) k_house_col(Dev D, int which)
   } else {
     const int b = D.rowStart[r] + D.basicCount[r];
     rowCopySwap(D, e, b);
+    D.cslot[b] = enteringSlot(c);
     D.basicCount[r] += 1;
   }
 }
@@ -1749,8 +1759,16 @@ __device__ void houseBody(Dev D, int skipColumns = 0)
       int e = D.cscToCsr[p];
       int b = D.rowStart[r] + D.basicCount[r];
       rowCopySwap(D, e, b);
+      D.cslot[b] = enteringSlot(c);
       D.basicCount[r] += 1;
     }
+  }
+  // ---- a structural leaves and the last col-slot moves into its place (case 2): the entries of that
+  // column carry their column's slot in the row copy
+  if (c->updateCase == 2 && c->slotColOut != c->k - 1) {
+    const int colLast = D.slotCol[c->k - 1], a = c->slotColOut;
+    for (int p = D.colStart[colLast] + tid; p < D.colStart[colLast + 1]; p += blockDim.x)
+      D.cslot[D.cscToCsr[p]] = a;
   }
   // ---- clear the sparse work vectors of this iteration
   if (seqIn < n) {
@@ -3286,7 +3304,7 @@ template <bool COHERENT> __device__ inline void chuzrFinalBody(const Dev &D, int
       const double y = dir * -1.0;
       const int s = D.rowStart[rOut], cnt = D.basicCount[rOut];
       for (int q = threadIdx.x; q < cnt; q += blockDim.x)
-        D.slotA[D.slotOfCol[D.ccol[s + q]]] = 0.0 - y * D.relem[s + q];
+        D.slotA[D.cslot[s + q]] = 0.0 - y * D.relem[s + q];
     }
     if (threadIdx.x == 0)
       c->tCount = -1;
@@ -3304,10 +3322,10 @@ template <bool COHERENT> __device__ inline void chuzrFinalBody(const Dev &D, int
     const int s = D.rowStart[rOut], cnt = D.basicCount[rOut];
     // ascending col-slot order so the later sum matches the dense form; rows are short
     for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
-      int sc = D.slotOfCol[D.ccol[s + q]];
+      int sc = D.cslot[s + q];
       int rank = 0;
       for (int q2 = 0; q2 < cnt; q2++) {
-        int sc2 = D.slotOfCol[D.ccol[s + q2]];
+        int sc2 = D.cslot[s + q2];
         rank += (sc2 < sc);
       }
       D.tIndex[rank] = sc;
@@ -4116,12 +4134,10 @@ __global__ void __launch_bounds__(256) k_slack_dots(Dev D)
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int q = q0 + 64 * u;
-      cc[u] = q < e ? D.ccol[q] : -1;
+      cc[u] = q < e ? 0 : -1;
+      sc[u] = q < e ? D.cslot[q] : 0;  // the entry's col-slot travels with it: no column -> slot lookup
       a[u] = q < e ? D.relem[q] : 0.0;
     }
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-      sc[u] = cc[u] >= 0 ? D.slotOfCol[cc[u]] : 0;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       c1[u] = D.slotC[sc[u]];
@@ -4179,12 +4195,10 @@ __global__ void __launch_bounds__(256) k_ftran_scatter3(Dev D, int nbNorm, int p
         double a[4], c1[4], c2[4], c3[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          cc[u] = (q + u < e) ? D.ccol[q + u] : -1;
+          cc[u] = (q + u < e) ? 0 : -1;
+          sc[u] = (q + u < e) ? D.cslot[q + u] : 0;  // col-slot kept with the entry (rowCopySwap, houseBody)
           a[u] = (q + u < e) ? D.relem[q + u] : 0.0;
         }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-          sc[u] = cc[u] >= 0 ? D.slotOfCol[cc[u]] : 0;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           c1[u] = D.slotC[sc[u]];
@@ -4987,6 +5001,17 @@ __global__ void __launch_bounds__(256) k_gj2_finish(Dev D, int k)
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < k; j += gridDim.x * blockDim.x)
       D.Minv[(size_t)r * D.ld + D.perm[j]] = D.workW[(size_t)r * D.ld + j] * inv;
   }
+}
+
+// col-slots of the basic entries of the row copy, rebuilt after a refactorization renumbered the slots
+__global__ void k_cslot_rebuild(Dev D)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= D.m)
+    return;
+  const int s = D.rowStart[i], e = s + D.basicCount[i];
+  for (int q = s; q < e; q++)
+    D.cslot[q] = D.slotOfCol[D.ccol[q]];
 }
 
 // Minv = D^-1 X
