@@ -77,7 +77,7 @@ struct Ctrl {
   int ticketGroup[4][64];  // first level of the same: one counter per 32 workgroups (<= 2048 workgroups)
   int flipAppend, numberAppend1;
   int lastPriceByRow, shardRowCands;  // row candidates ahead of the column candidates in the local list (sharded runs)
-  int cycIn[12], cycOut[12], cycWay[12];  // ClpSimplexProgress in_ / out_ / way_ (CLP_CYCLE = 12, src/ClpSolve.hpp:435)  // form the last pricing launch took (k_price_row_finish)
+  int cycIn[12], cycOut[12], cycWay[12], cycHead;  // ClpSimplexProgress in_ / out_ / way_ (CLP_CYCLE = 12, src/ClpSolve.hpp:435)  // form the last pricing launch took (k_price_row_finish)
   int appendGo, flipDense;  // flipDense: this pivot's flip rhs is left to k_flip_dense
   int updGo[2], updK, updPad;  // basis-update branch: go flag per pivot parity, k at the time of the fork
   double tailAlpha, tailValueOut;  // w[pivotRow] / sol[sequenceOut] handed to the serial tail of k_ftran_scatter3  // this pivot's primal update completed: its list appends may be scattered  // unordered append count of k_dj_flags (ordered later by k_flip_apply2)

@@ -110,6 +110,7 @@ struct clpgpu_context {
   // refactorMinK basic structurals on, the one-level exact form below), 1 one-level, 2 two-level with the
   // vector update (same bits as 1), 3 two-level with the MFMA update
   int refactorMode = -1, refactorMinK = 1024;
+  int dcVariant = 0;  // option "dc_variant": lane layout of the ratio test for <= 512 candidates (0: one wave, 4 / 8 per lane; 1: 2 per lane / eight waves with one per lane)
   int registerPanel = 1;  // option "register_panel": 0 forces the global-memory panel kernel (used for k > 4096)
   // basis update (rank-1 sweep + fix-ups of Minv) on a second stream beside primal update,
   // housekeeping and the next CHUZR; joined before the next BTRAN reads Minv
@@ -1737,6 +1738,7 @@ int clpgpu_context::startup()
   hCtrl->sequenceIn = hCtrl->sequenceOut = -1;
   for (int i = 0; i < 12; i++)  // progress_.startCheck() (ClpSimplexDual.cpp:452)
     hCtrl->cycIn[i] = hCtrl->cycOut[i] = -1;
+  hCtrl->cycHead = 0;
   hCtrl->maximumPivots = maximumPivots;
   hCtrl->maximumIterations = maximumIterations;
   hCtrl->forceFactorization = -1;
@@ -2131,7 +2133,7 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
     nbClass = cdiv(m + nranks * shardCandCap, PRICE_BLOCK);
     KL("k_shard_classes", k_shard_classes, dim3(nbClass), dim3(PRICE_BLOCK), 0, stream, D);
   }
-  KL("k_dual_column", k_dual_column, dim3(1), dim3(DC_THREADS), 0, stream, D, nbClass);
+  KL("k_dual_column", k_dual_column, dim3(1), dim3(DC_THREADS), 0, stream, D, nbClass, dcVariant);
   // dual update + flip detection (needs only theta), flip list, flip right-hand side
   // (+ 1: the extra workgroup unpacks the entering column)
   KL("k_dj_flags", k_dj_flags, dim3(nb + 1), dim3(PRICE_BLOCK), 0, stream, D, nbRows, flipListCap);
@@ -3285,6 +3287,7 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "use_graph")) { ctx->useGraph = (int)v; ctx->dropGraph(); }
   else if (!strcmp(name, "blocked_refactor")) ctx->blockedRefactor = (int)v;
   else if (!strcmp(name, "register_panel")) ctx->registerPanel = (int)v;
+  else if (!strcmp(name, "dc_variant")) { ctx->dcVariant = (int)v; ctx->dropGraph(); }
   else if (!strcmp(name, "refactor_mode")) ctx->refactorMode = (int)v;
   else if (!strcmp(name, "shard_cand_cap")) {
     if (ctx->commActive)

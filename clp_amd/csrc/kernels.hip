@@ -1183,7 +1183,7 @@ __device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nu
 //    the largest class prefix that fits in registers becomes the working set, the test runs on it,
 //    and is repeated on the full list only if theta ever reaches the class threshold (exact either
 //    way).
-__global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass)
+__global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass, int variant = 0)
 {
   Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -1200,6 +1200,17 @@ __global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass)
     return;
   }
   if (nc <= DC_SMALL) {
+    if (variant == 1) {
+      // fewer candidates per lane: a pass is then mostly its reduction.  Up to 128 candidates one wave
+      // with two per lane; up to 512 all eight waves with one per lane and one LDS exchange per reduction
+      if (nc <= 2 * 64) {
+        if (tid < 64)
+          dualColumnImpl<2, true>(D);
+      } else {
+        dualColumnImpl<1, false>(D);
+      }
+      return;
+    }
     if (tid < 64) {
       if (nc <= 4 * 64)
         dualColumnImpl<4, true>(D);
@@ -1911,25 +1922,32 @@ __device__ void houseBody(Dev D, int skipColumns = 0)
   }
   // ---- small cycles (ClpSimplex.cpp:2397-2431; ClpSimplexProgress::cycle, ClpSolve.cpp:4726-4825): the last 12
   // (in, out, way) triples; a repeat of the oldest with everything after it repeating too is a cycle of
-  // that length, two irregular repeats count as 100
+  // that length, two irregular repeats count as 100.  Kept as a ring (entry i of the reference's arrays is
+  // ring slot (head + i) % 12) so that a pivot costs 11 loads and 3 stores instead of shifting the arrays.
   {
+    const int head = c->cycHead;
+#define CYC(i) (((head) + (i)) % 12)
     int matched = 0;
+    int outs[12];
+#pragma unroll
     for (int i = 1; i < 12; i++)
-      if (seqIn == c->cycOut[i]) {
+      outs[i] = c->cycOut[CYC(i)];
+#pragma unroll
+    for (int i = 1; i < 12; i++)
+      if (seqIn == outs[i] && !matched)
         matched = -1;
-        break;
-      }
-    if (matched && c->cycIn[0] >= 0) {
+    if (matched && c->cycIn[CYC(0)] >= 0) {
       matched = 0;
       int nMatched = 0;
-      const int way0 = c->cycWay[0], in0 = c->cycIn[0], out0 = c->cycOut[0];
+      const int way0 = c->cycWay[CYC(0)], in0 = c->cycIn[CYC(0)], out0 = c->cycOut[CYC(0)];
       for (int kk = 1; kk < 12 - 4; kk++) {
-        if (in0 == c->cycIn[kk] && out0 == c->cycOut[kk] && way0 == c->cycWay[kk]) {
+        if (in0 == c->cycIn[CYC(kk)] && out0 == c->cycOut[CYC(kk)] && way0 == c->cycWay[CYC(kk)]) {
           nMatched++;
           const int end = 12 - kk;
           int j;
           for (j = 1; j < end; j++)
-            if (c->cycIn[j + kk] != c->cycIn[j] || c->cycOut[j + kk] != c->cycOut[j] || c->cycWay[j + kk] != c->cycWay[j])
+            if (c->cycIn[CYC(j + kk)] != c->cycIn[CYC(j)] || c->cycOut[CYC(j + kk)] != c->cycOut[CYC(j)] ||
+                c->cycWay[CYC(j + kk)] != c->cycWay[CYC(j)])
               break;
           if (j == end) {
             matched = kk;
@@ -1940,19 +1958,18 @@ __device__ void houseBody(Dev D, int skipColumns = 0)
       if (matched <= 0 && nMatched > 1)
         matched = 100;
     }
-    for (int i = 0; i < 11; i++) {
-      c->cycIn[i] = c->cycIn[i + 1];
-      c->cycOut[i] = c->cycOut[i + 1];
-      c->cycWay[i] = c->cycWay[i + 1];
-    }
-    c->cycIn[11] = seqIn;
-    c->cycOut[11] = seqOut;
-    c->cycWay[11] = 1 - c->directionIn + 4 * (1 - c->directionOut);
+    // drop the oldest, append this pivot: the oldest slot becomes the newest, the head moves on
+    c->cycIn[head] = seqIn;
+    c->cycOut[head] = seqOut;
+    c->cycWay[head] = 1 - c->directionIn + 4 * (1 - c->directionOut);
+    c->cycHead = (head + 1) % 12;
+#undef CYC
     if (matched > 0) {
       for (int i = 0; i < 12; i++) {
         c->cycIn[i] = c->cycOut[i] = -1;
         c->cycWay[i] = 0;
       }
+      c->cycHead = 0;
       const double random = randomDouble(c);
       const int extra = (int)(9.999 * random);
       const int off[10] = { 1, 1, 1, 1, 2, 2, 2, 3, 3, 4 };
