@@ -157,7 +157,10 @@ struct Dev {
   int *flipKey;  // [FLIP_LIST_CAP] flagged bound flips in arrival order, as compaction keys
   int *appendFlag;  // [m]
   int *appendFlag1, *blockOffset1;  // the same for the flip part of the primal update (scattered together later)
-  int *touchCount;  // [m] contributors per row while the flip rhs is assembled (zero otherwise)
+  int *touchCount;  // [m] (unused since round 2)
+  int *flipTouch;   // [m] contributors per row while the flip rhs is assembled (zero otherwise)
+  int *flipRowKey;  // [m * 8] their flip keys ...
+  double *flipRowVal;  // [m * 8] ... and movement * element, in ticket order
   // sliced-ELL copy of the priced column range: slice = 64 columns (one wave), entry t of the
   // slice's lane l at sellStart[slice] + t*64 + l; columns sorted by length so padding is ~1%
   const int *sellStart;  // [numSlices+1]

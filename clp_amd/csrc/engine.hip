@@ -110,7 +110,6 @@ struct clpgpu_context {
   // refactorMinK basic structurals on, the one-level exact form below), 1 one-level, 2 two-level with the
   // vector update (same bits as 1), 3 two-level with the MFMA update
   int refactorMode = -1, refactorMinK = 1024;
-  int dcVariant = 0;  // option "dc_variant": lane layout of the ratio test for <= 512 candidates (0: one wave, 4 / 8 per lane; 1: 2 per lane / eight waves with one per lane)
   int registerPanel = 1;  // option "register_panel": 0 forces the global-memory panel kernel (used for k > 4096)
   // basis update (rank-1 sweep + fix-ups of Minv) on a second stream beside primal update,
   // housekeeping and the next CHUZR; joined before the next BTRAN reads Minv
@@ -633,6 +632,9 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   rc |= dalloc(D.appendFlag1, m);
   rc |= dalloc(D.blockOffset1, cdiv(m, 256) + 2);
   rc |= dalloc(D.touchCount, m);
+  rc |= dalloc(D.flipTouch, m);
+  rc |= dalloc(D.flipRowKey, (size_t)m * FLIP_SLOTS);
+  rc |= dalloc(D.flipRowVal, (size_t)m * FLIP_SLOTS);
   rc |= dalloc(D.ctrl, 1);
   nChzBlocks = cdiv(m, 256 * CHZ_ITEMS);
   rc |= dalloc(D.chzBest, nChzBlocks);
@@ -2133,17 +2135,21 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
     nbClass = cdiv(m + nranks * shardCandCap, PRICE_BLOCK);
     KL("k_shard_classes", k_shard_classes, dim3(nbClass), dim3(PRICE_BLOCK), 0, stream, D);
   }
-  KL("k_dual_column", k_dual_column, dim3(1), dim3(DC_THREADS), 0, stream, D, nbClass, dcVariant);
+  KL("k_dual_column", k_dual_column, dim3(1), dim3(DC_THREADS), 0, stream, D, nbClass);
   // dual update + flip detection (needs only theta), flip list, flip right-hand side
   // (+ 1: the extra workgroup unpacks the entering column)
-  KL("k_dj_flags", k_dj_flags, dim3(nb + 1), dim3(PRICE_BLOCK), 0, stream, D, nbRows, flipListCap);
+  // sparse LPs, columns owned by this GPU or replicated: the waves that find a flip scatter its column
+  // (the flip right-hand side then needs no single-workgroup pass over the flipped columns' entries)
+  const int scatterFlips = (!wideRows && !denseColumns && !shardLists) ? 1 : 0;
+  KL("k_dj_flags", k_dj_flags, dim3(nb + 1), dim3(PRICE_BLOCK), 0, stream, D, nbRows, flipListCap, scatterFlips);
   if (shardLists) {
     KL("k_shard_pack_flips", k_shard_pack_flips, dim3(1), dim3(256), 0, stream, D, dFlipSend, shardFlipCap, flipListCap);
     ncclAllGatherFn(dFlipSend, dFlipRecv, SHARD_HDR + 5 * (size_t)shardFlipCap, 8 /* ncclFloat64 */, comm, stream);
     KL("k_shard_merge_flips", k_shard_merge_flips, dim3(1), dim3(256), 0, stream, D, (const double *)dFlipRecv, rank, nranks, shardFlipCap,
        flipListCap);
   }
-  KL("k_flip_apply2", k_flip_apply2, dim3(1), dim3(1024), 0, stream, D, gm, denseColumns ? 1 : 0, flipListCap);
+  KL("k_flip_apply2", k_flip_apply2, dim3(1 + (scatterFlips ? cdiv(m, 1024) : 0)), dim3(1024), 0, stream, D, gm, denseColumns ? 1 : 0, flipListCap,
+     scatterFlips);
   if (denseColumns)
     KL("k_flip_dense", k_flip_dense, dim3(gm), dim3(256), 0, stream, D);
   // one FTRAN sweep for the entering column, rho (DSE) and the flip rhs; the back end also applies
@@ -3287,7 +3293,6 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "use_graph")) { ctx->useGraph = (int)v; ctx->dropGraph(); }
   else if (!strcmp(name, "blocked_refactor")) ctx->blockedRefactor = (int)v;
   else if (!strcmp(name, "register_panel")) ctx->registerPanel = (int)v;
-  else if (!strcmp(name, "dc_variant")) { ctx->dcVariant = (int)v; ctx->dropGraph(); }
   else if (!strcmp(name, "refactor_mode")) ctx->refactorMode = (int)v;
   else if (!strcmp(name, "shard_cand_cap")) {
     if (ctx->commActive)

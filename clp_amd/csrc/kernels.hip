@@ -1183,7 +1183,7 @@ __device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nu
 //    the largest class prefix that fits in registers becomes the working set, the test runs on it,
 //    and is repeated on the full list only if theta ever reaches the class threshold (exact either
 //    way).
-__global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass, int variant = 0)
+__global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass)
 {
   Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -1200,17 +1200,6 @@ __global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass, 
     return;
   }
   if (nc <= DC_SMALL) {
-    if (variant == 1) {
-      // fewer candidates per lane: a pass is then mostly its reduction.  Up to 128 candidates one wave
-      // with two per lane; up to 512 all eight waves with one per lane and one LDS exchange per reduction
-      if (nc <= 2 * 64) {
-        if (tid < 64)
-          dualColumnImpl<2, true>(D);
-      } else {
-        dualColumnImpl<1, false>(D);
-      }
-      return;
-    }
     if (tid < 64) {
       if (nc <= 4 * 64)
         dualColumnImpl<4, true>(D);
@@ -3592,7 +3581,8 @@ __global__ void __launch_bounds__(256) k_fix_house(Dev D, int parity, int doFix,
 
 // dual update + flip detection only (the weights need the FTRAN and come later)
 #define FLIP_LIST_CAP 4096
-__global__ void __launch_bounds__(PRICE_BLOCK) k_dj_flags(Dev D, int nbRows, int listCap = FLIP_LIST_CAP)
+#define FLIP_SLOTS 8  // contributions a row keeps individually while the flip right-hand side is assembled
+__global__ void __launch_bounds__(PRICE_BLOCK) k_dj_flags(Dev D, int nbRows, int listCap = FLIP_LIST_CAP, int scatterFlips = 0)
 {
   Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -3673,6 +3663,23 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_dj_flags(Dev D, int nbRows, int
   unsigned long long mk = __ballot(flag);
   if (mk) {
     const int lane = threadIdx.x & 63;
+    // the flip's movement, objective term and column extent (matrix_->add per flipped column,
+    // ClpSimplexDual.cpp:2586 / ClpPackedMatrix.cpp:4874)
+    double mv = 0.0, ob = 0.0;
+    int start = 0, len = 1;
+    if (flag) {
+      const int iStatus = (stF & 3) - 1;
+      const double mult = (iStatus == 1) ? -1.0 : 1.0;
+      if (seqF >= D.n) {
+        mv = mult * (D.lower[seqF] - D.upper[seqF]);
+        ob = 0.0 - mv * D.cost[seqF];
+      } else {
+        mv = mult * (D.upper[seqF] - D.lower[seqF]);
+        ob = mv * D.cost[seqF];
+        start = D.colStart[seqF];
+        len = D.colStart[seqF + 1] - start;
+      }
+    }
     int base = 0;
     if (lane == 0)
       base = atomicAdd(&c->flipAppend, (int)__popcll(mk));
@@ -3680,27 +3687,44 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_dj_flags(Dev D, int nbRows, int
     if (flag) {
       int o = base + __popcll(mk & ((1ull << lane) - 1ull));
       if (o < listCap) {
+        // complete records: k_flip_apply2 starts from them instead of three more rounds of dependent loads
         D.flipKey[o] = key;
-        // the flip's movement, objective term and column extent travel with it (matrix_->add per
-        // flipped column, ClpSimplexDual.cpp:2586 / ClpPackedMatrix.cpp:4874): k_flip_apply2 then starts
-        // from complete records instead of three more rounds of dependent loads
-        const int iStatus = (stF & 3) - 1;
-        const double mult = (iStatus == 1) ? -1.0 : 1.0;
-        double mv, ob;
-        int start = 0, len = 1;
-        if (seqF >= D.n) {
-          mv = mult * (D.lower[seqF] - D.upper[seqF]);
-          ob = 0.0 - mv * D.cost[seqF];
-        } else {
-          mv = mult * (D.upper[seqF] - D.lower[seqF]);
-          ob = mv * D.cost[seqF];
-          start = D.colStart[seqF];
-          len = D.colStart[seqF + 1] - start;
-        }
         D.flipRecMv[o] = mv;
         D.flipRecObj[o] = ob;
         D.flipRecStart[o] = start;
         D.flipRecLen[o] = len;
+      }
+    }
+    if (scatterFlips) {
+      // the flip right-hand side is assembled here, by the wave that found the flip: every entry of the
+      // flipped column draws a ticket from its row's counter (integer, order independent) and leaves
+      // (flip key, movement * element) in that slot; k_flip_apply2's row workgroups add a row's
+      // contributions in key order = flip order, the sum of the reference's sequential loop
+      unsigned long long rem = mk;
+      while (rem) {
+        const int b = __ffsll((long long)rem) - 1;
+        rem &= rem - 1ull;
+        const int keyB = __shfl(key, b), stB = __shfl(start, b), lnB = __shfl(len, b);
+        const double mvB = __shfl(mv, b);
+        if (keyB < D.m) {
+          if (lane == 0) {
+            const int t = atomicAdd(&D.flipTouch[keyB], 1);
+            if (t < FLIP_SLOTS) {
+              D.flipRowKey[(size_t)keyB * FLIP_SLOTS + t] = keyB;
+              D.flipRowVal[(size_t)keyB * FLIP_SLOTS + t] = mvB;
+            }
+          }
+        } else {
+          for (int p = stB + lane; p < stB + lnB; p += 64) {
+            const int r = D.row[p];
+            const double v = mvB * D.elem[p];
+            const int t = atomicAdd(&D.flipTouch[r], 1);
+            if (t < FLIP_SLOTS) {
+              D.flipRowKey[(size_t)r * FLIP_SLOTS + t] = keyB;
+              D.flipRowVal[(size_t)r * FLIP_SLOTS + t] = v;
+            }
+          }
+        }
       }
     }
   }
@@ -3783,12 +3807,105 @@ __global__ void __launch_bounds__(256) k_flip_dense(Dev D)
     D.flipSlot[sr] = acc;
 }
 
-__global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos, int denseColumns = 0, int listCap = FLIP_LIST_CAP)
+// rows whose flip contributions k_dj_flags scattered (option scattered): a row's <= FLIP_SLOTS (key, value)
+// pairs are put in key order -- the flip order: rows first, then columns ascending -- and added, exactly
+// the adds of the reference's loop over the flipped columns (matrix_->add, ClpPackedMatrix.cpp:4874)
+__device__ inline void flipRowsBody(const Dev &D, int blk, int nraw, bool useScatter)
+{
+  const int r = blk * (int)blockDim.x + threadIdx.x;
+  if (r >= D.m)
+    return;
+  const int cnt = D.flipTouch[r];
+  if (!cnt)
+    return;
+  D.flipTouch[r] = 0;
+  if (!useScatter)
+    return;  // (more flips than the record buffer orders: workgroup 0 takes the sequential form)
+  double acc = 0.0;
+  if (cnt <= FLIP_SLOTS) {
+    int kk[FLIP_SLOTS];
+    double vv[FLIP_SLOTS];
+    const size_t at = (size_t)r * FLIP_SLOTS;
+#pragma unroll
+    for (int u = 0; u < FLIP_SLOTS; u++) {
+      kk[u] = u < cnt ? D.flipRowKey[at + u] : 0x7fffffff;
+      vv[u] = u < cnt ? D.flipRowVal[at + u] : 0.0;
+    }
+#pragma unroll
+    for (int round = 0; round < FLIP_SLOTS; round++) {
+#pragma unroll
+      for (int u = round & 1; u + 1 < FLIP_SLOTS; u += 2) {
+        if (kk[u + 1] < kk[u]) {
+          int tk = kk[u];
+          kk[u] = kk[u + 1];
+          kk[u + 1] = tk;
+          double tv = vv[u];
+          vv[u] = vv[u + 1];
+          vv[u + 1] = tv;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < FLIP_SLOTS; u++)
+      if (u < cnt)
+        acc += vv[u];
+  } else {
+    // more contributors than slots (a row many flipped columns share): take them from the flip
+    // records in ascending key order, one selection pass per contributor (rare; nraw <= FLIP_MAX_FLIPS)
+    int lastKey = -1;
+    for (int done = 0; done < cnt; done++) {
+      int bestKey = 0x7fffffff;
+      double bestVal = 0.0;
+      for (int f = 0; f < nraw; f++) {
+        const int key = D.flipKey[f];
+        if (key <= lastKey || key >= bestKey)
+          continue;
+        if (key < D.m) {
+          if (key == r) {
+            bestKey = key;
+            bestVal = D.flipRecMv[f];
+          }
+        } else {
+          int lo = D.flipRecStart[f], hi = lo + D.flipRecLen[f] - 1;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (D.row[mid] < r)
+              lo = mid + 1;
+            else
+              hi = mid;
+          }
+          if (lo == hi && D.row[lo] == r) {
+            bestKey = key;
+            bestVal = D.flipRecMv[f] * D.elem[lo];
+          }
+        }
+      }
+      if (bestKey == 0x7fffffff)
+        break;
+      acc += bestVal;
+      lastKey = bestKey;
+    }
+  }
+  D.flipRhs[r] = acc;
+  const int sr = D.slotOfRow[r];
+  if (sr >= 0)
+    D.flipSlot[sr] = acc;
+}
+
+// workgroup 0: the flip list in order, its scalars and -- unless k_dj_flags scattered the columns --
+// the flip right-hand side; workgroups 1.. (scattered form only): the rows' contributions
+__global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos, int denseColumns = 0, int listCap = FLIP_LIST_CAP, int scattered = 0)
 {
   Ctrl *c = D.ctrl;
   if (c->state != RUN)
     return;
   const int tid = threadIdx.x;
+  if (blockIdx.x > 0) {
+    const int nrawRows = c->flipAppend;
+    if (nrawRows)
+      flipRowsBody(D, (int)blockIdx.x - 1, nrawRows, nrawRows <= listCap && nrawRows <= FLIP_MAX_FLIPS);
+    return;
+  }
   // counters of k_ftran_scatter3's appends (position blocks) are reset here, flips or not
   for (int b = tid; b < nbPos; b += blockDim.x)
     D.blockCount[b] = 0;
@@ -3799,6 +3916,7 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos, int dens
   const int nraw = c->flipAppend;
   if (nraw == 0)
     return;  // numberFlips was zeroed by CHUZR
+  const bool rowsDoRhs = scattered && nraw <= listCap && nraw <= FLIP_MAX_FLIPS;
   // ---- the flip list in reference order (rows first, then columns ascending)
   __shared__ int s_seq[FLIP_LIST_CAP];
   __shared__ int shw[17];
@@ -3917,6 +4035,13 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos, int dens
         s_mv[f] = mv;
         s_start[f + 1] = len;
       }
+    }
+    if (rowsDoRhs) {
+      // the right-hand side is the row workgroups' job: only the objective term is left
+      double s = blockSum(changeObj, shd);
+      if (tid == 0)
+        c->objectiveChange += s;
+      return;
     }
     if (tid == 0) {
       s_start[0] = 0;
