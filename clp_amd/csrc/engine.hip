@@ -116,6 +116,9 @@ struct clpgpu_context {
   // option "row_price_frac": row pricing goes BY ROW when nnz(pi) <= frac * m (the reference's switch,
   // src/ClpPackedMatrix.cpp:727-754, with the crossover measured on the MI355X); 0 = always by column
   double rowPriceFrac = 0.02;
+  // option "flip_scatter": the waves that detect a bound flip scatter its column into per-row slots
+  // (sparse LPs only); 0 = the single-workgroup assembly from the flip records
+  int flipScatter = 1;
   // option "scaling" (0 off, default; 1/2/3/4 as ClpModel::scaling): set BEFORE clpgpu_load_problem.  The
   // device then holds the scaled LP; solution getters return unscaled values, clpgpu_chg_* take unscaled ones.
   int scalingMode = 0;
@@ -2140,7 +2143,7 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   // (+ 1: the extra workgroup unpacks the entering column)
   // sparse LPs, columns owned by this GPU or replicated: the waves that find a flip scatter its column
   // (the flip right-hand side then needs no single-workgroup pass over the flipped columns' entries)
-  const int scatterFlips = (!wideRows && !denseColumns && !shardLists) ? 1 : 0;
+  const int scatterFlips = (flipScatter && !wideRows && !denseColumns && !shardLists) ? 1 : 0;
   KL("k_dj_flags", k_dj_flags, dim3(nb + 1), dim3(PRICE_BLOCK), 0, stream, D, nbRows, flipListCap, scatterFlips);
   if (shardLists) {
     KL("k_shard_pack_flips", k_shard_pack_flips, dim3(1), dim3(256), 0, stream, D, dFlipSend, shardFlipCap, flipListCap);
@@ -3129,6 +3132,7 @@ clpgpu_context *clpgpu_clone(const clpgpu_context *src)
   ctx->blockedRefactor = src->blockedRefactor;
   ctx->registerPanel = src->registerPanel;
   ctx->rowPriceFrac = src->rowPriceFrac;
+  ctx->flipScatter = src->flipScatter;
   ctx->scalingMode = src->scalingMode;
   ctx->flipListCap = src->flipListCap;
   ctx->haveExternalScales = src->haveExternalScales;
@@ -3311,6 +3315,7 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   }
   else if (!strcmp(name, "refactor_min_k")) ctx->refactorMinK = (int)v;
   else if (!strcmp(name, "fork_update")) { ctx->forkUpdate = (int)v; ctx->dropGraph(); }
+  else if (!strcmp(name, "flip_scatter")) { ctx->flipScatter = v != 0.0; ctx->dropGraph(); }
   else if (!strcmp(name, "row_price_frac")) { ctx->rowPriceFrac = v < 0.0 ? 0.0 : v; ctx->dropGraph(); }
   else if (!strcmp(name, "scaling")) {
     if (ctx->n > 0 && ctx->D.colStart)
