@@ -104,6 +104,9 @@ struct clpgpu_context {
   bool widePricing = false;
   int maxColumnLength = 1;
   bool denseColumns = false;  // every column holds all m rows in ascending order
+  // no row holds more than n/256 entries: a row then collects more than FLIP_SLOTS flip contributions only
+  // in freak pivots (the scatter form of the flip right-hand side is kept for such LPs)
+  bool lightRows = false;
   bool wideRows = false;  // mean row length >= 256 (dense LPs): wave-per-row / split-k variants of the row-wise stages
   int blockedRefactor = 1;
   // option "refactor_mode": -1 auto (two-level in-place re-inversion with the MFMA update from
@@ -117,8 +120,10 @@ struct clpgpu_context {
   // src/ClpPackedMatrix.cpp:727-754, with the crossover measured on the MI355X); 0 = always by column
   double rowPriceFrac = 0.02;
   // option "flip_scatter": the waves that detect a bound flip scatter its column into per-row slots
-  // (sparse LPs only); 0 = the single-workgroup assembly from the flip records
+  // (1: sparse LPs with light rows only; 2: any sparse LP -- tests); 0 = the single-workgroup assembly
+  // from the flip records
   int flipScatter = 1;
+  int flipSlotCap = FLIP_SLOTS;  // option "flip_slot_cap" (test knob: small values force the many-contributors path)
   // option "scaling" (0 off, default; 1/2/3/4 as ClpModel::scaling): set BEFORE clpgpu_load_problem.  The
   // device then holds the scaled LP; solution getters return unscaled values, clpgpu_chg_* take unscaled ones.
   int scalingMode = 0;
@@ -839,6 +844,15 @@ int clpgpu_context::buildSell()
   maxColumnLength = 1;
   for (int j = 0; j < n; j++)
     maxColumnLength = std::max(maxColumnLength, colStart[j + 1] - colStart[j]);
+  {
+    std::vector<int> rowCount(m, 0);
+    for (int p = 0; p < colStart[n]; p++)
+      rowCount[row[p]]++;
+    int maxRow = 0;
+    for (int i = 0; i < m; i++)
+      maxRow = std::max(maxRow, rowCount[i]);
+    lightRows = (long long)maxRow * 256 <= (long long)n;
+  }
   denseColumns = wideRows && (size_t)colStart[n] == (size_t)m * (size_t)n;
   for (int j = 0; j < n && denseColumns; j++)
     for (int p = colStart[j], i = 0; p < colStart[j + 1]; p++, i++)
@@ -2143,8 +2157,8 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   // (+ 1: the extra workgroup unpacks the entering column)
   // sparse LPs, columns owned by this GPU or replicated: the waves that find a flip scatter its column
   // (the flip right-hand side then needs no single-workgroup pass over the flipped columns' entries)
-  const int scatterFlips = (flipScatter && !wideRows && !denseColumns && !shardLists) ? 1 : 0;
-  KL("k_dj_flags", k_dj_flags, dim3(nb + 1), dim3(PRICE_BLOCK), 0, stream, D, nbRows, flipListCap, scatterFlips);
+  const int scatterFlips = ((flipScatter == 2 || (flipScatter == 1 && lightRows)) && !wideRows && !denseColumns && !shardLists) ? 1 : 0;
+  KL("k_dj_flags", k_dj_flags, dim3(nb + 1), dim3(PRICE_BLOCK), 0, stream, D, nbRows, flipListCap, scatterFlips, flipSlotCap);
   if (shardLists) {
     KL("k_shard_pack_flips", k_shard_pack_flips, dim3(1), dim3(256), 0, stream, D, dFlipSend, shardFlipCap, flipListCap);
     ncclAllGatherFn(dFlipSend, dFlipRecv, SHARD_HDR + 5 * (size_t)shardFlipCap, 8 /* ncclFloat64 */, comm, stream);
@@ -2152,7 +2166,7 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
        flipListCap);
   }
   KL("k_flip_apply2", k_flip_apply2, dim3(1 + (scatterFlips ? cdiv(m, 1024) : 0)), dim3(1024), 0, stream, D, gm, denseColumns ? 1 : 0, flipListCap,
-     scatterFlips);
+     scatterFlips, flipSlotCap);
   if (denseColumns)
     KL("k_flip_dense", k_flip_dense, dim3(gm), dim3(256), 0, stream, D);
   // one FTRAN sweep for the entering column, rho (DSE) and the flip rhs; the back end also applies
@@ -3133,6 +3147,7 @@ clpgpu_context *clpgpu_clone(const clpgpu_context *src)
   ctx->registerPanel = src->registerPanel;
   ctx->rowPriceFrac = src->rowPriceFrac;
   ctx->flipScatter = src->flipScatter;
+  ctx->flipSlotCap = src->flipSlotCap;
   ctx->scalingMode = src->scalingMode;
   ctx->flipListCap = src->flipListCap;
   ctx->haveExternalScales = src->haveExternalScales;
@@ -3315,7 +3330,8 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   }
   else if (!strcmp(name, "refactor_min_k")) ctx->refactorMinK = (int)v;
   else if (!strcmp(name, "fork_update")) { ctx->forkUpdate = (int)v; ctx->dropGraph(); }
-  else if (!strcmp(name, "flip_scatter")) { ctx->flipScatter = v != 0.0; ctx->dropGraph(); }
+  else if (!strcmp(name, "flip_slot_cap")) { ctx->flipSlotCap = std::max(1, std::min((int)v, (int)FLIP_SLOTS)); ctx->dropGraph(); }
+  else if (!strcmp(name, "flip_scatter")) { ctx->flipScatter = v >= 2.0 ? 2 : (v != 0.0 ? 1 : 0); ctx->dropGraph(); }
   else if (!strcmp(name, "row_price_frac")) { ctx->rowPriceFrac = v < 0.0 ? 0.0 : v; ctx->dropGraph(); }
   else if (!strcmp(name, "scaling")) {
     if (ctx->n > 0 && ctx->D.colStart)

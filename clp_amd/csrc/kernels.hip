@@ -3581,8 +3581,8 @@ __global__ void __launch_bounds__(256) k_fix_house(Dev D, int parity, int doFix,
 
 // dual update + flip detection only (the weights need the FTRAN and come later)
 #define FLIP_LIST_CAP 4096
-#define FLIP_SLOTS 8  // contributions a row keeps individually while the flip right-hand side is assembled
-__global__ void __launch_bounds__(PRICE_BLOCK) k_dj_flags(Dev D, int nbRows, int listCap = FLIP_LIST_CAP, int scatterFlips = 0)
+#define FLIP_SLOTS 16  // contributions a row keeps individually while the flip right-hand side is assembled
+__global__ void __launch_bounds__(PRICE_BLOCK) k_dj_flags(Dev D, int nbRows, int listCap = FLIP_LIST_CAP, int scatterFlips = 0, int slotCap = FLIP_SLOTS)
 {
   Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -3709,7 +3709,7 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_dj_flags(Dev D, int nbRows, int
         if (keyB < D.m) {
           if (lane == 0) {
             const int t = atomicAdd(&D.flipTouch[keyB], 1);
-            if (t < FLIP_SLOTS) {
+            if (t < slotCap) {
               D.flipRowKey[(size_t)keyB * FLIP_SLOTS + t] = keyB;
               D.flipRowVal[(size_t)keyB * FLIP_SLOTS + t] = mvB;
             }
@@ -3719,7 +3719,7 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_dj_flags(Dev D, int nbRows, int
             const int r = D.row[p];
             const double v = mvB * D.elem[p];
             const int t = atomicAdd(&D.flipTouch[r], 1);
-            if (t < FLIP_SLOTS) {
+            if (t < slotCap) {
               D.flipRowKey[(size_t)r * FLIP_SLOTS + t] = keyB;
               D.flipRowVal[(size_t)r * FLIP_SLOTS + t] = v;
             }
@@ -3807,10 +3807,84 @@ __global__ void __launch_bounds__(256) k_flip_dense(Dev D)
     D.flipSlot[sr] = acc;
 }
 
+// sum of cnt <= W (key, value) pairs in ascending key order, from 0.0 (odd-even transposition network in registers)
+template <int W>
+__device__ inline double flipOrderedSum(const int *keys, const double *vals, int cnt)
+{
+  int kk[W];
+  double vv[W];
+#pragma unroll
+  for (int u = 0; u < W; u++) {
+    kk[u] = u < cnt ? keys[u] : 0x7fffffff;
+    vv[u] = u < cnt ? vals[u] : 0.0;
+  }
+#pragma unroll
+  for (int round = 0; round < W; round++) {
+#pragma unroll
+    for (int u = round & 1; u + 1 < W; u += 2) {
+      if (kk[u + 1] < kk[u]) {
+        int tk = kk[u];
+        kk[u] = kk[u + 1];
+        kk[u + 1] = tk;
+        double tv = vv[u];
+        vv[u] = vv[u + 1];
+        vv[u + 1] = tv;
+      }
+    }
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int u = 0; u < W; u++)
+    if (u < cnt)
+      acc += vv[u];
+  return acc;
+}
+
+// more contributors than slots (a row many flipped columns share): they are taken from the flip records in
+// ascending key order, one selection pass per contributor (rare; nraw <= FLIP_MAX_FLIPS)
+__device__ inline double flipSelectSum(const Dev &D, int r, int cnt, int nraw)
+{
+  double acc = 0.0;
+  int lastKey = -1;
+  for (int done = 0; done < cnt; done++) {
+    int bestKey = 0x7fffffff;
+    double bestVal = 0.0;
+    for (int f = 0; f < nraw; f++) {
+      const int key = D.flipKey[f];
+      if (key <= lastKey || key >= bestKey)
+        continue;
+      if (key < D.m) {
+        if (key == r) {
+          bestKey = key;
+          bestVal = D.flipRecMv[f];
+        }
+      } else {
+        int lo = D.flipRecStart[f], hi = lo + D.flipRecLen[f] - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (D.row[mid] < r)
+            lo = mid + 1;
+          else
+            hi = mid;
+        }
+        if (lo == hi && D.row[lo] == r) {
+          bestKey = key;
+          bestVal = D.flipRecMv[f] * D.elem[lo];
+        }
+      }
+    }
+    if (bestKey == 0x7fffffff)
+      break;
+    acc += bestVal;
+    lastKey = bestKey;
+  }
+  return acc;
+}
+
 // rows whose flip contributions k_dj_flags scattered (option scattered): a row's <= FLIP_SLOTS (key, value)
 // pairs are put in key order -- the flip order: rows first, then columns ascending -- and added, exactly
 // the adds of the reference's loop over the flipped columns (matrix_->add, ClpPackedMatrix.cpp:4874)
-__device__ inline void flipRowsBody(const Dev &D, int blk, int nraw, bool useScatter)
+__device__ inline void flipRowsBody(const Dev &D, int blk, int nraw, bool useScatter, int slotCap)
 {
   const int r = blk * (int)blockDim.x + threadIdx.x;
   if (r >= D.m)
@@ -3822,69 +3896,15 @@ __device__ inline void flipRowsBody(const Dev &D, int blk, int nraw, bool useSca
   if (!useScatter)
     return;  // (more flips than the record buffer orders: workgroup 0 takes the sequential form)
   double acc = 0.0;
-  if (cnt <= FLIP_SLOTS) {
-    int kk[FLIP_SLOTS];
-    double vv[FLIP_SLOTS];
-    const size_t at = (size_t)r * FLIP_SLOTS;
-#pragma unroll
-    for (int u = 0; u < FLIP_SLOTS; u++) {
-      kk[u] = u < cnt ? D.flipRowKey[at + u] : 0x7fffffff;
-      vv[u] = u < cnt ? D.flipRowVal[at + u] : 0.0;
-    }
-#pragma unroll
-    for (int round = 0; round < FLIP_SLOTS; round++) {
-#pragma unroll
-      for (int u = round & 1; u + 1 < FLIP_SLOTS; u += 2) {
-        if (kk[u + 1] < kk[u]) {
-          int tk = kk[u];
-          kk[u] = kk[u + 1];
-          kk[u + 1] = tk;
-          double tv = vv[u];
-          vv[u] = vv[u + 1];
-          vv[u + 1] = tv;
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < FLIP_SLOTS; u++)
-      if (u < cnt)
-        acc += vv[u];
-  } else {
-    // more contributors than slots (a row many flipped columns share): take them from the flip
-    // records in ascending key order, one selection pass per contributor (rare; nraw <= FLIP_MAX_FLIPS)
-    int lastKey = -1;
-    for (int done = 0; done < cnt; done++) {
-      int bestKey = 0x7fffffff;
-      double bestVal = 0.0;
-      for (int f = 0; f < nraw; f++) {
-        const int key = D.flipKey[f];
-        if (key <= lastKey || key >= bestKey)
-          continue;
-        if (key < D.m) {
-          if (key == r) {
-            bestKey = key;
-            bestVal = D.flipRecMv[f];
-          }
-        } else {
-          int lo = D.flipRecStart[f], hi = lo + D.flipRecLen[f] - 1;
-          while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (D.row[mid] < r)
-              lo = mid + 1;
-            else
-              hi = mid;
-          }
-          if (lo == hi && D.row[lo] == r) {
-            bestKey = key;
-            bestVal = D.flipRecMv[f] * D.elem[lo];
-          }
-        }
-      }
-      if (bestKey == 0x7fffffff)
-        break;
-      acc += bestVal;
-      lastKey = bestKey;
-    }
+  const size_t at = (size_t)r * FLIP_SLOTS;
+  if (cnt > slotCap) {
+    acc = flipSelectSum(D, r, cnt, nraw);
+  } else if (cnt == 1) {
+    acc += D.flipRowVal[at];
+  } else if (cnt <= 8) {
+    acc = flipOrderedSum<8>(D.flipRowKey + at, D.flipRowVal + at, cnt);
+  } else if (cnt <= FLIP_SLOTS) {
+    acc = flipOrderedSum<FLIP_SLOTS>(D.flipRowKey + at, D.flipRowVal + at, cnt);
   }
   D.flipRhs[r] = acc;
   const int sr = D.slotOfRow[r];
@@ -3894,7 +3914,7 @@ __device__ inline void flipRowsBody(const Dev &D, int blk, int nraw, bool useSca
 
 // workgroup 0: the flip list in order, its scalars and -- unless k_dj_flags scattered the columns --
 // the flip right-hand side; workgroups 1.. (scattered form only): the rows' contributions
-__global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos, int denseColumns = 0, int listCap = FLIP_LIST_CAP, int scattered = 0)
+__global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos, int denseColumns = 0, int listCap = FLIP_LIST_CAP, int scattered = 0, int slotCap = FLIP_SLOTS)
 {
   Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -3903,7 +3923,7 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos, int dens
   if (blockIdx.x > 0) {
     const int nrawRows = c->flipAppend;
     if (nrawRows)
-      flipRowsBody(D, (int)blockIdx.x - 1, nrawRows, nrawRows <= listCap && nrawRows <= FLIP_MAX_FLIPS);
+      flipRowsBody(D, (int)blockIdx.x - 1, nrawRows, nrawRows <= listCap && nrawRows <= FLIP_MAX_FLIPS, slotCap);
     return;
   }
   // counters of k_ftran_scatter3's appends (position blocks) are reset here, flips or not

@@ -179,7 +179,9 @@ int clpgpu_unroll_weights(clpgpu_context *ctx);
  * update on a second stream),
  * "flip_list_cap" (size of the bound-flip append buffer; small values force its overflow path),
  * "flip_scatter" (1 default: the waves that detect a bound flip scatter its column into per-row slots,
- * sparse LPs; 0: the flip right-hand side is assembled by one workgroup from the flip records),
+ * sparse LPs whose heaviest row holds <= n/256 entries; 2: any sparse LP; 0: the flip right-hand side is
+ * assembled by one workgroup from the flip records), "flip_slot_cap" (contributions a row keeps
+ * individually, <= 16; small values force the many-contributors path),
  * "scaling" (0 off; 1/2/3/4 = ClpModel::scaling modes; must be set BEFORE clpgpu_load_problem: the
  * device then holds the scaled LP, getters return unscaled values),
  * "row_price_frac" (row pricing goes by row when nnz(pi) <= frac * m, ClpPackedMatrix.cpp:727-754; 0 = always

@@ -317,6 +317,31 @@ def test_flip_list_overflow_path_matches(gpu_cls):
     assert np.array_equal(a.solution(), b.solution())
 
 
+@pytest.mark.parametrize("slot_cap", [16, 1])
+def test_flip_scatter_matches_record_assembly(gpu_cls, slot_cap):
+    """Flip right-hand side assembled by the waves that detect the flips (column scatter with integer
+    row tickets, contributions added in flip-key order) against the single-workgroup assembly from the
+    flip records: same pivots, same flips, bit-identical solution, and both equal to the oracle's
+    pivots.  slot_cap 1 sends every row shared by two flipped columns down the many-contributors path."""
+    from oracle.oracle import OracleSimplex
+
+    lp = P.sparse_lp(1500, 6000, 10, 31)
+    a = gpu_cls().loadProblem(lp)
+    b = gpu_cls().loadProblem(lp)
+    a.set_option("flip_scatter", 0)
+    b.set_option("flip_scatter", 2)
+    b.set_option("flip_slot_cap", slot_cap)
+    o = OracleSimplex(lp)
+    assert a.dual() == b.dual() == o.dual() == 0
+    la, lb, lo = a.pivotLog(), b.pivotLog(), o.pivot_log()
+    assert int(la["numberFlipped"].max()) > 4, "instance no longer exercises multi-flip pivots"
+    for key in ("sequenceIn", "sequenceOut", "numberFlipped"):
+        assert np.array_equal(la[key], lb[key])
+        assert np.array_equal(la[key], lo[key])
+    assert np.array_equal(a.solution(), b.solution())
+    assert a.objectiveValue() == b.objectiveValue()
+
+
 @pytest.mark.parametrize("n", [10, 50])
 def test_infeasible(gpu_cls, n):
     g, sg, o, so = solve_both(gpu_cls, P.infeasible(n), 1)
