@@ -29,6 +29,7 @@ enum : int {
   EXIT_SHARD_OVERFLOW = 108 // column-sharded run: a rank's candidate / flip records exceed the exchange buffer
 };
 
+#define FLIP_HOT_CAP 1024
 struct Ctrl {
   int state;
   int numberIterations;
@@ -76,6 +77,7 @@ struct Ctrl {
   int ticket[8];        // "last workgroup done" counters (always 0 between launches)
   int ticketGroup[4][64];  // first level of the same: one counter per 32 workgroups (<= 2048 workgroups)
   int flipAppend, numberAppend1;
+  int flipHotCount;  // rows with more flip contributions than slots this pivot (k_dj_flags appends, CHUZR resets)
   int lastPriceByRow, shardRowCands;  // row candidates ahead of the column candidates in the local list (sharded runs)
   int cycIn[12], cycOut[12], cycWay[12], cycHead;  // ClpSimplexProgress in_ / out_ / way_ (CLP_CYCLE = 12, src/ClpSolve.hpp:435)  // form the last pricing launch took (k_price_row_finish)
   int appendGo, flipDense;  // flipDense: this pivot's flip rhs is left to k_flip_dense
@@ -158,6 +160,7 @@ struct Dev {
   int *appendFlag;  // [m]
   int *appendFlag1, *blockOffset1;  // the same for the flip part of the primal update (scattered together later)
   int *touchCount;  // [m] (unused since round 2)
+  int *flipHot;     // [FLIP_HOT_CAP] those rows
   int *flipTouch;   // [m] contributors per row while the flip rhs is assembled (zero otherwise)
   int *flipRowKey;  // [m * 8] their flip keys ...
   double *flipRowVal;  // [m * 8] ... and movement * element, in ticket order

@@ -641,6 +641,7 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   rc |= dalloc(D.blockOffset1, cdiv(m, 256) + 2);
   rc |= dalloc(D.touchCount, m);
   rc |= dalloc(D.flipTouch, m);
+  rc |= dalloc(D.flipHot, FLIP_HOT_CAP);
   rc |= dalloc(D.flipRowKey, (size_t)m * FLIP_SLOTS);
   rc |= dalloc(D.flipRowVal, (size_t)m * FLIP_SLOTS);
   rc |= dalloc(D.ctrl, 1);
@@ -2157,7 +2158,7 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   // (+ 1: the extra workgroup unpacks the entering column)
   // sparse LPs, columns owned by this GPU or replicated: the waves that find a flip scatter its column
   // (the flip right-hand side then needs no single-workgroup pass over the flipped columns' entries)
-  const int scatterFlips = ((flipScatter == 2 || (flipScatter == 1 && lightRows)) && !wideRows && !denseColumns && !shardLists) ? 1 : 0;
+  const int scatterFlips = ((flipScatter == 2 || (flipScatter == 1 && lightRows)) && !wideRows && !denseColumns && !shardLists && !gatherRows) ? 1 : 0;
   KL("k_dj_flags", k_dj_flags, dim3(nb + 1), dim3(PRICE_BLOCK), 0, stream, D, nbRows, flipListCap, scatterFlips, flipSlotCap);
   if (shardLists) {
     KL("k_shard_pack_flips", k_shard_pack_flips, dim3(1), dim3(256), 0, stream, D, dFlipSend, shardFlipCap, flipListCap);
@@ -3562,8 +3563,8 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
   *stats = ctx->stats;
   if (getenv("CLPGPU_DEBUG_STATS")) {
     const long long *g = ctx->hCtrl->dbg;
-    fprintf(stderr, "clpgpu dbg: dc small %lld big %lld passes %lld tries %lld sumNc %lld mapped %lld full %lld ticksSmall %lld ticksBig %lld | flip iters %lld flips %lld entries %lld sequential %lld\n",
-            g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9], g[10], g[11], g[12]);
+    fprintf(stderr, "clpgpu dbg: dc small %lld big %lld passes %lld tries %lld sumNc %lld mapped %lld full %lld ticksSmall %lld ticksBig %lld | flip iters %lld flips %lld entries %lld sequential %lld | scattered %lld select rows %lld hot rows %lld row ticks %lld\n",
+            g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9], g[10], g[11], g[12], g[14], g[13], g[15], ctx->hCtrl->dbg2[6]);
   }
   stats->price_bytes = ctx->hCtrl->statPriceBytes;
   stats->row_bytes = ctx->hCtrl->statRowBytes;

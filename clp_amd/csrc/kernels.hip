@@ -3283,6 +3283,7 @@ template <bool COHERENT> __device__ inline void chuzrFinalBody(const Dev &D, int
       c->sequenceIn = -1;
       c->numberFlips = 0;
       c->flipAppend = 0;
+      c->flipHotCount = 0;
       c->flipDense = 0;
       c->appendGo = 0;
       c->objectiveChange = 0.0;
@@ -3712,6 +3713,10 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_dj_flags(Dev D, int nbRows, int
             if (t < slotCap) {
               D.flipRowKey[(size_t)keyB * FLIP_SLOTS + t] = keyB;
               D.flipRowVal[(size_t)keyB * FLIP_SLOTS + t] = mvB;
+            } else if (t == slotCap) {
+              const int h = atomicAdd(&c->flipHotCount, 1);
+              if (h < FLIP_HOT_CAP)
+                D.flipHot[h] = keyB;
             }
           }
         } else {
@@ -3722,6 +3727,12 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_dj_flags(Dev D, int nbRows, int
             if (t < slotCap) {
               D.flipRowKey[(size_t)r * FLIP_SLOTS + t] = keyB;
               D.flipRowVal[(size_t)r * FLIP_SLOTS + t] = v;
+            } else if (t == slotCap) {
+              // a row most flipped columns share (the pivot row's neighbourhood: the candidates all meet
+              // supp(rho)): k_flip_apply2's first workgroup sums it from the ordered records
+              const int h = atomicAdd(&c->flipHotCount, 1);
+              if (h < FLIP_HOT_CAP)
+                D.flipHot[h] = r;
             }
           }
         }
@@ -3898,6 +3909,9 @@ __device__ inline void flipRowsBody(const Dev &D, int blk, int nraw, bool useSca
   double acc = 0.0;
   const size_t at = (size_t)r * FLIP_SLOTS;
   if (cnt > slotCap) {
+    if (D.ctrl->flipHotCount <= FLIP_HOT_CAP)
+      return;  // workgroup 0 sums this row from the ordered records
+    atomicAdd((unsigned long long *)&D.ctrl->dbg[13], 1ull);
     acc = flipSelectSum(D, r, cnt, nraw);
   } else if (cnt == 1) {
     acc += D.flipRowVal[at];
@@ -3922,8 +3936,12 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos, int dens
   const int tid = threadIdx.x;
   if (blockIdx.x > 0) {
     const int nrawRows = c->flipAppend;
+    const long long t0 = wall_clock64();
     if (nrawRows)
       flipRowsBody(D, (int)blockIdx.x - 1, nrawRows, nrawRows <= listCap && nrawRows <= FLIP_MAX_FLIPS, slotCap);
+    __syncthreads();
+    if (blockIdx.x == 1 && tid == 0 && nrawRows)
+      c->dbg2[6] += wall_clock64() - t0;
     return;
   }
   // counters of k_ftran_scatter3's appends (position blocks) are reset here, flips or not
@@ -4059,8 +4077,54 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos, int dens
     if (rowsDoRhs) {
       // the right-hand side is the row workgroups' job: only the objective term is left
       double s = blockSum(changeObj, shd);
-      if (tid == 0)
+      if (tid == 0) {
         c->objectiveChange += s;
+        c->dbg[14]++;
+      }
+      // ... and the rows more flipped columns share than a row has slots: one wave per such row; the
+      // lanes look the row up in 64 flipped columns at a time (flip order) and the wave adds the 64
+      // values in lane order (absent ones are + 0.0, which leaves every partial sum as it is)
+      const int nHot = c->flipHotCount;
+      if (nHot > 0 && nHot <= FLIP_HOT_CAP) {
+        const int lane = tid & 63, wv = tid >> 6, nWaves = (int)blockDim.x >> 6;
+        for (int h = wv; h < nHot; h += nWaves) {
+          const int r = D.flipHot[h];
+          double acc = 0.0;
+          for (int base = 0; base < nf; base += 64) {
+            const int f = base + lane;
+            double v = 0.0;
+            if (f < nf) {
+              const int seq = s_seq[f];
+              if (seq >= D.n) {
+                if (seq - D.n == r)
+                  v = s_mv[f];
+              } else {
+                int lo = s_cs[f], hi = lo + s_start[f + 1] - 1;
+                while (lo < hi) {
+                  const int mid = (lo + hi) >> 1;
+                  if (D.row[mid] < r)
+                    lo = mid + 1;
+                  else
+                    hi = mid;
+                }
+                if (lo == hi && D.row[lo] == r)
+                  v = s_mv[f] * D.elem[lo];
+              }
+            }
+            const int lim = min(64, nf - base);
+            for (int i = 0; i < lim; i++)
+              acc += __shfl(v, i);
+          }
+          if (lane == 0) {
+            D.flipRhs[r] = acc;
+            const int sr = D.slotOfRow[r];
+            if (sr >= 0)
+              D.flipSlot[sr] = acc;
+          }
+        }
+        if (tid == 0)
+          c->dbg[15] += nHot;
+      }
       return;
     }
     if (tid == 0) {
