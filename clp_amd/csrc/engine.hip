@@ -259,6 +259,12 @@ struct clpgpu_context {
   int launchBatch();
   bool capturing = false;
   int whileIterating(int stepTarget);
+  // ClpSimplexDual::fastDual (src/ClpSimplexDual.cpp:7227): 0 = run() as clpgpu_dual does; 1 = in fastDual with
+  // alwaysFinish, 2 = in fastDual without (stop at the first exit of the iteration loop that asks for a
+  // refactorization: "can't say anything interesting - might as well return", :7422-7431)
+  int fastDualMode = 0;
+  int lastReturnCode = -1;  // whileIterating's return code in the reference's numbering (:7352-7358)
+  int fastDual(bool alwaysFinish);
   int run(int maxSteps);
   void finish();
   int priceRow(int numberPi, const int *piIndex, const double *piValue, const unsigned char *st, const double *djv,
@@ -2336,6 +2342,7 @@ int clpgpu_context::whileIterating(int stepTarget)
     hipLaunchKernelGGL(k_zero, dim3(cdiv(kcap, 256)), dim3(256), 0, stream, D.flipSlot, kcap);
     hipLaunchKernelGGL(k_zero, dim3(cdiv(n, 256)), dim3(256), 0, stream, D.alphaCol, n);
   }
+  lastReturnCode = -1;
   switch (state) {
   case EXIT_STEP_LIMIT:
     return 1;
@@ -2344,6 +2351,7 @@ int clpgpu_context::whileIterating(int stepTarget)
     break;
   case EXIT_MAX_ITERATIONS:
     problemStatus = 3;
+    lastReturnCode = 3;
     break;
   case EXIT_ALPHA_CHECK: {
     // :1451-1500
@@ -2414,10 +2422,12 @@ int clpgpu_context::whileIterating(int stepTarget)
     if (pivots < 5 && acceptablePivot > 1.0e-8)
       acceptablePivot = 1.0e-8;
     hCtrl->acceptablePivotBase = acceptablePivot;
+    lastReturnCode = problemStatus == 1 ? 1 : -2;
     break;
   }
   case EXIT_NO_PIVOT_ROW: {
     // no pivot row (:2080-2331)
+    lastReturnCode = pivots ? -2 : 0;
     if (!pivots) {
       rc |= pullRim(true);
       problemStatus = -1;
@@ -2513,6 +2523,10 @@ int clpgpu_context::run(int maxSteps)
     }
     if (rc) {
       problemStatus = 4;
+      break;
+    }
+    if (fastDualMode && problemStatus < 0 && ((fastDualMode == 2 && lastReturnCode < 0) || lastReturnCode == 3)) {
+      problemStatus = 3;  // :7422-7431
       break;
     }
     needStatus = true;
@@ -3473,6 +3487,148 @@ int clpgpu_dual_steps(clpgpu_context *ctx, int iterations)
   return ctx->run(iterations);
 }
 
+// ClpSimplexDual::fastDual (src/ClpSimplexDual.cpp:7227-7480): the dual from the basis at hand with the
+// iteration count restarted, as strong branching and the node loops of branch and bound call it.  Returns 0
+// when the run came to a conclusion (optimal / infeasible: problem status as clpgpu_dual), 1 when it was
+// stopped (iteration limit, or -- without alwaysFinish -- the first time the iteration loop asks for a
+// refactorization); the problem status is then 3.
+int clpgpu_context::fastDual(bool alwaysFinish)
+{
+  fastDualMode = alwaysFinish ? 1 : 2;
+  started = false;
+  seconds = 0.0;
+  run(-1);
+  fastDualMode = 0;
+  if (problemStatus == 10)
+    problemStatus = 3;
+  return problemStatus == 3 ? 1 : 0;
+}
+
+int clpgpu_fast_dual(clpgpu_context *ctx, int alwaysFinish)
+{
+  if (!ctx || !ctx->m)
+    return -99;
+  (void)hipSetDevice(ctx->device);
+  int rc = ctx->fastDual(alwaysFinish != 0);
+  return ctx->problemStatus == 4 ? -99 : rc;
+}
+
+// ClpSimplexDual::strongBranching (src/ClpSimplexDual.cpp:6965-7226).  For every listed column: "down" (upper
+// bound newUpper[i]) then "up" (lower bound newLower[i]), each a fastDual from the basis the context holds
+// (the finished solve's), everything put back afterwards.  On return newUpper[i] / newLower[i] hold the
+// change in objective of the down / up branch (1e100 = infeasible), outputStatus[2i], [2i+1] the branch
+// status (0 finished, 1 infeasible, 2 unfinished), outputIterations the iteration counts and -- when
+// outputSolution is given -- outputSolution[2i], [2i+1] the column solutions.  Return code 0 nothing
+// interesting, 1 one branch of some column infeasible, -1 both branches of a column infeasible, -2 error.
+// The reference keeps a copy of the factorization and puts it back per branch; here every branch starts
+// with a re-inversion of the saved basis (same numbers up to rounding).
+int clpgpu_strong_branching(clpgpu_context *ctx, int numberVariables, const int *variables, double *newLower, double *newUpper,
+                            double **outputSolution, int *outputStatus, int *outputIterations, int stopOnFirstInfeasible,
+                            int alwaysFinish)
+{
+  if (!ctx || !ctx->m || numberVariables < 0 || (numberVariables && (!variables || !newLower || !newUpper || !outputStatus || !outputIterations)))
+    return -99;
+  (void)hipSetDevice(ctx->device);
+  if (!ctx->started) {
+    ctx->setError("clpgpu_strong_branching: no solve to branch from (call clpgpu_dual first)");
+    return -2;
+  }
+  const int n = ctx->n, N = ctx->N;
+  for (int i = 0; i < numberVariables; i++)
+    if (variables[i] < 0 || variables[i] >= n)
+      return -99;
+  const double saveObjectiveValue = ctx->objectiveValue;
+  const int saveIterations = ctx->numberIterations, saveProblemStatus = ctx->problemStatus;
+  std::vector<unsigned char> saveStatus(N);
+  if (ctx->d2h(saveStatus.data(), ctx->D.status, N))
+    return -2;
+  for (int i = 0; i < N; i++)
+    saveStatus[i] &= 7;
+  const bool hadStatus = ctx->haveStatus;
+  const std::vector<unsigned char> saveUserStatus = ctx->userStatus;
+  int returnCode = 0;
+  bool failed = false;
+  auto branch = [&](int iColumn, bool down, double bound, double &objectiveChange, int slot) {
+    double &external = down ? ctx->origColUpper[iColumn] : ctx->origColLower[iColumn];
+    const double saveBound = external;
+    external = bound;
+    rebuildColumnBounds(ctx);
+    ctx->userStatus = saveStatus;
+    ctx->haveStatus = true;
+    int status = ctx->fastDual(alwaysFinish != 0);
+    if (ctx->problemStatus == 4)
+      failed = true;
+    // make sure plausible (:7060)
+    const double obj = std::max(ctx->objectiveValue, saveObjectiveValue);
+    if (status && ctx->problemStatus != 3) {
+      // not finished - might be optimal (:7061-7070; no dual objective limit in the engine)
+      if (!ctx->numberPrimalInfeasibilities)
+        ctx->problemStatus = 0;
+      status = ctx->problemStatus;
+    }
+    if (ctx->problemStatus == 3)
+      status = 2;
+    if (status || ctx->problemStatus == 0) {
+      objectiveChange = obj - saveObjectiveValue;
+    } else {
+      objectiveChange = 1.0e100;
+      status = 1;
+    }
+    if (outputSolution && outputSolution[slot]) {
+      std::vector<double> all(N);
+      if (clpgpu_get_solution(ctx, all.data()))
+        failed = true;
+      std::copy(all.begin(), all.begin() + n, outputSolution[slot]);
+    }
+    outputStatus[slot] = status;
+    outputIterations[slot] = ctx->numberIterations;
+    external = saveBound;
+  };
+  int iSolution = 0;
+  for (int i = 0; i < numberVariables && !failed; i++) {
+    const int iColumn = variables[i];
+    double down, up;
+    branch(iColumn, true, newUpper[i], down, iSolution++);
+    if (failed)
+      break;
+    branch(iColumn, false, newLower[i], up, iSolution++);
+    newUpper[i] = down;
+    newLower[i] = up;
+    // both sides feasible: nothing; one side: 1 (and stop if asked); neither: -1 and stop (:7177-7205)
+    if (down < 1.0e100) {
+      if (up >= 1.0e100) {
+        returnCode = 1;
+        if (stopOnFirstInfeasible)
+          break;
+      }
+    } else {
+      if (up < 1.0e100) {
+        returnCode = 1;
+        if (stopOnFirstInfeasible)
+          break;
+      } else {
+        returnCode = -1;
+        break;
+      }
+    }
+  }
+  // everything back: bounds, basis, the factorization and solution of the saved basis, the objective
+  rebuildColumnBounds(ctx);
+  ctx->userStatus = saveStatus;
+  ctx->haveStatus = true;
+  ctx->started = false;
+  ctx->run(0);
+  if (ctx->problemStatus == 4)
+    failed = true;
+  ctx->userStatus = hadStatus ? saveUserStatus : saveStatus;
+  ctx->objectiveValue = saveObjectiveValue;
+  ctx->numberIterations = saveIterations;
+  if (!failed)
+    ctx->problemStatus = saveProblemStatus;
+  return failed ? -2 : returnCode;
+}
+
+int clpgpu_problem_status(const clpgpu_context *ctx) { return ctx ? ctx->problemStatus : -99; }
 int clpgpu_number_iterations(const clpgpu_context *ctx) { return ctx ? ctx->numberIterations : 0; }
 double clpgpu_objective_value(const clpgpu_context *ctx) { return ctx ? ctx->objectiveValue : 0.0; }
 

@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "clpgpu_create", "clpgpu_destroy", "clpgpu_last_error", "clpgpu_stream", "clpgpu_load_problem",
     "clpgpu_set_column_range", "clpgpu_comm_unique_id", "clpgpu_comm_init", "clpgpu_times", "clpgpu_transpose_times", "clpgpu_price_row", "clpgpu_factorize",
     "clpgpu_ftran", "clpgpu_btran", "clpgpu_replace_column", "clpgpu_pivots", "clpgpu_set_option",
-    "clpgpu_set_status", "clpgpu_dual", "clpgpu_dual_steps", "clpgpu_number_iterations", "clpgpu_objective_value",
+    "clpgpu_set_status", "clpgpu_dual", "clpgpu_dual_steps", "clpgpu_fast_dual", "clpgpu_strong_branching", "clpgpu_problem_status", "clpgpu_number_iterations", "clpgpu_objective_value",
     "clpgpu_get_solution", "clpgpu_get_reduced_costs", "clpgpu_get_status", "clpgpu_get_pivot_variable",
     "clpgpu_get_pivot_log", "clpgpu_get_row_weights", "clpgpu_get_stats",
     "clpgpu_chg_row_lower", "clpgpu_chg_row_upper", "clpgpu_chg_column_lower", "clpgpu_chg_column_upper",
@@ -104,6 +104,9 @@ def lib():
             getattr(L, "clpgpu_chg_" + name).argtypes = [p, dp]
         L.clpgpu_dual.argtypes = [p]
         L.clpgpu_dual_steps.argtypes = [p, C.c_int]
+        L.clpgpu_fast_dual.argtypes = [p, C.c_int]
+        L.clpgpu_strong_branching.argtypes = [p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                              C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int]
         L.clpgpu_number_iterations.argtypes = [p]
         L.clpgpu_objective_value.argtypes = [p]
         L.clpgpu_objective_value.restype = C.c_double
@@ -211,6 +214,33 @@ class ClpGpuSimplex:
 
     def dual_steps(self, iterations):
         return lib().clpgpu_dual_steps(self._h, int(iterations))
+
+    def problemStatus(self):
+        return lib().clpgpu_problem_status(self._h)
+
+    def fastDual(self, alwaysFinish=False):
+        """ClpSimplexDual::fastDual: 0 finished, 1 stopped"""
+        rc = lib().clpgpu_fast_dual(self._h, int(bool(alwaysFinish)))
+        if rc < 0:
+            self._check(rc, "clpgpu_fast_dual")
+        return rc
+
+    def strongBranching(self, variables, newLower, newUpper, stopOnFirstInfeasible=True, alwaysFinish=False, solutions=True):
+        """ClpSimplexDual::strongBranching.  Returns (returnCode, downChange, upChange, status[2k], iterations[2k],
+        solutions[2k, n] or None); status / iterations / solutions: even = down, odd = up."""
+        k = len(variables)
+        var = (C.c_int * k)(*[int(v) for v in variables])
+        lo = (C.c_double * k)(*[float(v) for v in newLower])
+        up = (C.c_double * k)(*[float(v) for v in newUpper])
+        st, it = (C.c_int * (2 * k))(), (C.c_int * (2 * k))()
+        sol = np.zeros((2 * k, self.n)) if solutions else None
+        ptrs = None
+        if solutions:
+            ptrs = (C.POINTER(C.c_double) * (2 * k))(*[sol[i].ctypes.data_as(C.POINTER(C.c_double)) for i in range(2 * k)])
+        rc = lib().clpgpu_strong_branching(self._h, k, var, lo, up, ptrs, st, it, int(bool(stopOnFirstInfeasible)), int(bool(alwaysFinish)))
+        if rc in (-2, -99):
+            self._check(rc, "clpgpu_strong_branching")
+        return rc, np.array(up[:]), np.array(lo[:]), np.array(st[:]), np.array(it[:]), sol
 
     def numberIterations(self):
         return lib().clpgpu_number_iterations(self._h)

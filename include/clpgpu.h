@@ -216,7 +216,29 @@ int clpgpu_dual(clpgpu_context *ctx);
 /* Run at most `iterations` further pivots from the current device state (bench stepping);
  * the first call performs startup.  Returns problemStatus, or -1 if still iterating. */
 int clpgpu_dual_steps(clpgpu_context *ctx, int iterations);
+/* ClpSimplexDual::fastDual (src/ClpSimplexDual.hpp:276, src/ClpSimplexDual.cpp:7227-7480): the dual from the
+ * basis at hand (clpgpu_set_status, or the one the last solve ended with when none is given), iteration count
+ * restarted, bounds / costs as last changed with clpgpu_chg_*.  Returns 0 when the run came to a conclusion
+ * (clpgpu_problem_status then says which: 0 optimal, 1 infeasible, 2 unbounded), 1 when it was stopped
+ * (problem status 3): iteration limit (option "max_iterations"), or -- alwaysFinish == 0 -- the first time the
+ * iteration loop asks for a refactorization (:7422-7431).  -99 on errors. */
+int clpgpu_fast_dual(clpgpu_context *ctx, int alwaysFinish);
+/* ClpSimplexDual::strongBranching (src/ClpSimplexDual.hpp:125-131, src/ClpSimplexDual.cpp:6965-7226), same
+ * arguments and meaning: for variables[i] the "down" branch (column upper bound newUpper[i]) and the "up"
+ * branch (column lower bound newLower[i]) are each solved with fastDual from the basis of the finished solve
+ * the context holds; on return newUpper[i] / newLower[i] hold the change in objective of the down / up branch
+ * (1e100 = infeasible), outputStatus[2i], [2i+1] = 0 finished / 1 infeasible / 2 unfinished,
+ * outputIterations[2i], [2i+1] the iteration counts, outputSolution[2i], [2i+1] (each numberColumns long;
+ * the array or single entries may be NULL) the column solutions -- even down, odd up.  The context is put
+ * back (bounds, basis, solution, objective) before returning.  Return 0 nothing interesting, 1 some column
+ * infeasible one way, -1 a column infeasible both ways, -2 error.  (startFinishOptions of the reference has
+ * no meaning here: the matrix and rim live on the device throughout.) */
+int clpgpu_strong_branching(clpgpu_context *ctx, int numberVariables, const int *variables, double *newLower,
+                            double *newUpper, double **outputSolution, int *outputStatus, int *outputIterations,
+                            int stopOnFirstInfeasible, int alwaysFinish);
 
+/* ClpModel::problemStatus (src/ClpModel.hpp:441): -1 not finished, else as clpgpu_dual returns it */
+int clpgpu_problem_status(const clpgpu_context *ctx);
 int clpgpu_number_iterations(const clpgpu_context *ctx);
 double clpgpu_objective_value(const clpgpu_context *ctx);
 /* n+m doubles each, [columns | rows] */

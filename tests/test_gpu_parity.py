@@ -225,8 +225,8 @@ def test_random_lp_identical_pivot_sequence(gpu_cls, maker, args, rule):
     kkt(lp, g)
 
 
-@pytest.mark.parametrize("case", [("nqueens", (8,), -8.0), ("nqueens", (20,), -20.0), ("tsp_mtz", (20, 42), 172.283333),
-                                  ("ufl", (10, 30, 99), 560.0), ("ufl", (20, 60, 77), 770.5)])
+@pytest.mark.parametrize("case", [("nqueens", (8,), -8.0), ("nqueens", (20,), -20.0), ("nqueens", (50,), -50.0),
+                                  ("tsp_mtz", (20, 42), 172.283333), ("ufl", (10, 30, 99), 560.0), ("ufl", (20, 60, 77), 770.5)])
 @pytest.mark.parametrize("rule", [0, 1])
 def test_degenerate_reference_instances(gpu_cls, case, rule):
     """Generated instances of test/test_racing_lp.cpp with the bounds of test/test_racing_reference.txt.
@@ -281,6 +281,80 @@ def test_warm_resolve_after_bound_change(gpu_cls):
     assert abs(g.objectiveValue() - o.objective) <= RTOL * (1 + abs(o.objective))
     assert np.all(g.solution()[:lp.n][branch] <= new_upper[branch] + 1e-7)
     kkt(lp2, g)
+
+
+def test_strong_branching_matches_oracle_warm_solves(gpu_cls):
+    """ClpSimplexDual::strongBranching at the C ABI (src/ClpSimplexDual.cpp:6965): for five columns, the down
+    branch (upper bound floor(x/2)) and the up branch (lower bound ceil(x/2)+1 ... a bound the optimum violates)
+    are solved by the engine's fastDual from the optimal basis.  Each branch must agree with the oracle solving
+    the modified LP from the same basis: status and objective change (1e-8 relative), and the branch solutions
+    respect the new bound.  Afterwards the context is as before the call: objective, solution, basis, and a
+    further dual() needs no pivot.  With alwaysFinish = 0 a branch is either finished with the same result or
+    reported unfinished (status 2) with an objective change no larger than the finished one."""
+    lp = P.sparse_lp(300, 1200, 8, 11)
+    g = gpu_cls().loadProblem(lp)
+    assert g.dual() == 0
+    obj0, sol0, status0 = g.objectiveValue(), g.solution(), g.statusArray().copy()
+    its0 = g.numberIterations()
+    branch = np.argsort(-sol0[:lp.n], kind="stable")[:5]
+    assert np.all(sol0[branch] > 2.0)
+    new_upper = np.floor(sol0[branch] * 0.5)
+    new_lower = np.minimum(np.ceil(sol0[branch]) + 1.0, lp.col_upper[branch])
+    rc, down, up, st, it, sols = g.strongBranching(branch, new_lower, new_upper, stopOnFirstInfeasible=False, alwaysFinish=True)
+    assert rc in (0, 1)
+    for i, j in enumerate(branch):
+        for way, (bound, change) in enumerate(((new_upper[i], down[i]), (new_lower[i], up[i]))):
+            lp2 = type(lp)(lp)
+            if way == 0:
+                lp2.col_upper = lp.col_upper.copy()
+                lp2.col_upper[j] = bound
+            else:
+                lp2.col_lower = lp.col_lower.copy()
+                lp2.col_lower[j] = bound
+            o = oracle(lp2, 1)
+            o.set_status(status0 & 7)
+            so = o.dual()
+            slot = 2 * i + way
+            if so == 0:
+                assert st[slot] == 0
+                assert abs((obj0 + change) - o.objective) <= RTOL * (1 + abs(o.objective))
+                assert it[slot] > 0
+                x = sols[slot][j]
+                assert (x <= bound + 1e-7) if way == 0 else (x >= bound - 1e-7)
+            else:
+                assert so == 1 and st[slot] == 1 and change >= 1.0e100
+    # the context is back where it was
+    assert g.objectiveValue() == obj0 and g.numberIterations() == its0
+    assert rel(g.solution(), sol0) < RTOL
+    assert np.array_equal((g.statusArray() & 7) == 1, (status0 & 7) == 1)  # same basic set
+    assert g.dual() == 0 and g.numberIterations() == 0
+    assert abs(g.objectiveValue() - obj0) <= RTOL * (1 + abs(obj0))
+    # without alwaysFinish: stop at the first refactorization request
+    g.set_option("max_pivots", 5)
+    rc2, down2, up2, st2, it2, _ = g.strongBranching(branch, new_lower, new_upper, stopOnFirstInfeasible=False, alwaysFinish=False, solutions=False)
+    assert set(st2.tolist()) <= {0, 1, 2} and np.any(st2 == 2), "no branch stopped early: instance no longer exercises the early stop"
+    full = np.stack([down, up], axis=1).ravel()
+    part = np.stack([down2, up2], axis=1).ravel()
+    for slot in range(len(st2)):
+        if st2[slot] == 2:
+            assert it2[slot] <= 6 and part[slot] <= full[slot] + 1e-7 * (1 + abs(full[slot]))
+        elif st[slot] == 0:
+            assert st2[slot] == 0 and abs(part[slot] - full[slot]) <= 1e-7 * (1 + abs(full[slot]))
+
+
+def test_fast_dual_iteration_limit(gpu_cls):
+    """fastDual (src/ClpSimplexDual.cpp:7227) returns 1 with problem status 3 at the iteration limit and 0 once
+    it is allowed to finish; the iteration count restarts with every call."""
+    lp = P.sparse_lp(300, 1200, 8, 11)
+    g = gpu_cls().loadProblem(lp)
+    g.set_option("max_iterations", 50)
+    assert g.fastDual(alwaysFinish=True) == 1 and g.problemStatus() == 3 and g.numberIterations() == 50
+    g.set_option("max_iterations", 1 << 30)
+    assert g.fastDual(alwaysFinish=True) == 0 and g.problemStatus() == 0
+    o = oracle(lp, 1)
+    assert o.dual() == 0
+    assert abs(g.objectiveValue() - o.objective) <= RTOL * (1 + abs(o.objective))
+    assert g.numberIterations() == o.iterations
 
 
 @pytest.mark.parametrize("option", ["blocked_refactor", "register_panel"])
