@@ -296,10 +296,11 @@ def test_strong_branching_matches_oracle_warm_solves(gpu_cls):
     assert g.dual() == 0
     obj0, sol0, status0 = g.objectiveValue(), g.solution(), g.statusArray().copy()
     its0 = g.numberIterations()
-    branch = np.argsort(-sol0[:lp.n], kind="stable")[:5]
-    assert np.all(sol0[branch] > 2.0)
+    basic = np.nonzero(((status0[:lp.n] & 7) == 1) & (sol0[:lp.n] > 2.0) & (sol0[:lp.n] < lp.col_upper - 2.0))[0]
+    branch = basic[np.argsort(-sol0[basic], kind="stable")[:5]]
+    assert len(branch) == 5
     new_upper = np.floor(sol0[branch] * 0.5)
-    new_lower = np.minimum(np.ceil(sol0[branch]) + 1.0, lp.col_upper[branch])
+    new_lower = np.ceil(sol0[branch]) + 1.0
     rc, down, up, st, it, sols = g.strongBranching(branch, new_lower, new_upper, stopOnFirstInfeasible=False, alwaysFinish=True)
     assert rc in (0, 1)
     for i, j in enumerate(branch):
