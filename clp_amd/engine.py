@@ -105,6 +105,7 @@ def lib():
         L.clpgpu_dual.argtypes = [p]
         L.clpgpu_dual_steps.argtypes = [p, C.c_int]
         L.clpgpu_fast_dual.argtypes = [p, C.c_int]
+        L.clpgpu_problem_status.argtypes = [p]
         L.clpgpu_strong_branching.argtypes = [p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                               C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int]
         L.clpgpu_number_iterations.argtypes = [p]
