@@ -90,6 +90,17 @@ struct clpgpu_context {
   std::vector<unsigned char> saveStatus;
   std::vector<double> savedSolution;
   bool haveSnapshot = false;
+  // Verified refresh (large nuclei): at a scheduled refactorization the explicit inverse, kept current by the
+  // rank-1 / bordering updates, is KEPT when the solutions recomputed with it leave residuals below
+  // refreshTolerance (max |A x - s|, max |dj| over the basics: the reference's own measures of a factorization,
+  // largestPrimalError_ / largestDualError_); otherwise -- and every refreshMax-th time anyway -- the nucleus is
+  // re-inverted.  The reference re-factorizes because its eta file grows and errors accumulate; with an explicit
+  // inverse only the second reason is left, and it is measured.  Options "refresh_min_k" (nuclei of at least
+  // this order, default 6144; 0 = never), "refresh_max", "refresh_tolerance".
+  int refreshMinK = 6144, refreshMax = 15, consecutiveRefreshes = 0, numberRefreshes = 0, numberRefreshesRejected = 0;
+  double refreshTolerance = 1.0e-8;
+  bool refreshEligible();
+  int refreshFactor();
   int numberThrownOut = 0;  // structurals replaced by slacks by the singular-basis repair, whole solve
   void resetFakeBounds();
   int pivots = 0, kNucleus = 0;
@@ -1735,6 +1746,7 @@ int clpgpu_context::startup()
   problemStatus = -1;
   numberIterations = 0;
   numberRefactorizations = 0;
+  numberRefreshes = numberRefreshesRejected = consecutiveRefreshes = 0;
   numberFake = numberChanged = numberTimesOptimal = 0;
   forceFactorization = -1;
   lastBadIteration = -999999;
@@ -1806,19 +1818,59 @@ int clpgpu_context::startup()
 // device (factorize, gutsOfSolution).  Restates the branches that can be reached without
 // perturbation, values pass, Cbc options or primal fall-back.
 // ---------------------------------------------------------------------------------------------
+// see the members: keep the inverse at a scheduled refactorization?
+bool clpgpu_context::refreshEligible()
+{
+  if (refreshMinK <= 0 || !blockedRefactor || rebuildRowCopy || forceFactorization == 1 || !hCtrl)
+    return false;
+  const int k = hCtrl->k;
+  if (k < refreshMinK || consecutiveRefreshes >= refreshMax)
+    return false;
+  return k + maximumPivots + 16 <= kcap;  // room for the growth until the next one
+}
+int clpgpu_context::refreshFactor()
+{
+  // what factorizeOnce leaves behind, minus the re-inversion: the slot arrays, the row-copy partition and
+  // pivotVariable are current on the device (houseBody keeps them); the host mirror of pivotVariable follows
+  int rc = d2h(pivotVariable.data(), D.pivotVariable, m);
+  kNucleus = hCtrl->k;
+  pivots = 0;
+  hCtrl->pivots = 0;
+  consecutiveRefreshes++;
+  numberRefreshes++;
+  return rc;
+}
+
 int clpgpu_context::statusOfProblemInDual(int type)
 {
   int rc = 0;
   int numberPivots = pivots;
   int tentativeStatus = problemStatus;
   bool weightsSaved = false;
+  bool gutsDone = false;  // a verified refresh has already recomputed the solutions
   double changeCost = 0.0;
   if (problemStatus > -3 || numberPivots > 0) {
     rc |= saveWeights(1);
     weightsSaved = true;
-    if (type) {
+    if (type && refreshEligible()) {
+      rc |= pullRim(true);
+      rc |= refreshFactor();
+      rc |= gutsOfSolution();
+      if (largestPrimalError <= refreshTolerance && largestDualError <= refreshTolerance) {
+        gutsDone = true;
+      } else {
+        // the inverse has drifted: re-invert below
+        numberRefreshes--;
+        numberRefreshesRejected++;
+        consecutiveRefreshes = refreshMax;
+        if (logLevel > 0)
+          fprintf(stderr, "clpgpu: refresh rejected at iteration %d (errors %g %g), re-inverting\n", numberIterations, largestPrimalError, largestDualError);
+      }
+    }
+    if (type && !gutsDone) {
       rc |= pullRim(true);
       int frc = factorize(false);
+      consecutiveRefreshes = 0;
       if (frc == -1) {
         // singular (ClpSimplexDual.cpp:5060-5125): back to the basis of the last good factorization with
         // the leaving variable flagged and a refactorization forced after every pivot; if that basis is
@@ -1855,7 +1907,7 @@ int clpgpu_context::statusOfProblemInDual(int type)
     if (problemStatus != -4 || numberPivots > 10)
       problemStatus = -3;
   }
-  if (type)
+  if (type && !gutsDone)
     rc |= gutsOfSolution();
   int situationChanged = 0;
   bool needCleanFake = false, dirty = false;
@@ -3163,6 +3215,9 @@ clpgpu_context *clpgpu_clone(const clpgpu_context *src)
   ctx->rowPriceFrac = src->rowPriceFrac;
   ctx->flipScatter = src->flipScatter;
   ctx->flipSlotCap = src->flipSlotCap;
+  ctx->refreshMinK = src->refreshMinK;
+  ctx->refreshMax = src->refreshMax;
+  ctx->refreshTolerance = src->refreshTolerance;
   ctx->scalingMode = src->scalingMode;
   ctx->flipListCap = src->flipListCap;
   ctx->haveExternalScales = src->haveExternalScales;
@@ -3345,6 +3400,9 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   }
   else if (!strcmp(name, "refactor_min_k")) ctx->refactorMinK = (int)v;
   else if (!strcmp(name, "fork_update")) { ctx->forkUpdate = (int)v; ctx->dropGraph(); }
+  else if (!strcmp(name, "refresh_min_k")) ctx->refreshMinK = (int)v;
+  else if (!strcmp(name, "refresh_max")) ctx->refreshMax = std::max(0, (int)v);
+  else if (!strcmp(name, "refresh_tolerance")) ctx->refreshTolerance = v;
   else if (!strcmp(name, "flip_slot_cap")) { ctx->flipSlotCap = std::max(1, std::min((int)v, (int)FLIP_SLOTS)); ctx->dropGraph(); }
   else if (!strcmp(name, "flip_scatter")) { ctx->flipScatter = v >= 2.0 ? 2 : (v != 0.0 ? 1 : 0); ctx->dropGraph(); }
   else if (!strcmp(name, "row_price_frac")) { ctx->rowPriceFrac = v < 0.0 ? 0.0 : v; ctx->dropGraph(); }
@@ -3733,6 +3791,8 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
   stats->refactorizations = ctx->numberRefactorizations;
   stats->nucleus = ctx->hCtrl->k;
   stats->nucleus_capacity = ctx->kcap;
+  stats->refreshes = ctx->numberRefreshes;
+  stats->refreshes_rejected = ctx->numberRefreshesRejected;
   return 0;
 }
 

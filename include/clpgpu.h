@@ -53,6 +53,8 @@ typedef struct {
   double row_bytes;     /* B_row of SURVEY 8d: 12 B per visited row entry and pi nonzero, 8 per touched column, 20 per emitted one */
   long nucleus;         /* k: basic structurals = order of the nucleus inverse right now */
   long nucleus_capacity; /* rows allocated for it (3 k x k f64 matrices) */
+  long refreshes;        /* scheduled refactorizations at which the inverse was kept (verified refresh, option refresh_min_k) */
+  long refreshes_rejected; /* ... and those where the residual check sent it to a re-inversion after all */
 } clpgpu_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------- */
@@ -187,7 +189,10 @@ int clpgpu_unroll_weights(clpgpu_context *ctx);
  * "row_price_frac" (row pricing goes by row when nnz(pi) <= frac * m, ClpPackedMatrix.cpp:727-754; 0 = always
  * by column; also selects the form of clpgpu_price_row), "refactor_mode" (-1 auto / 1 one-level / 2
  * two-level vector / 3 two-level MFMA re-inversion), "refactor_min_k" (auto: two-level MFMA from this
- * many basic structurals on, default 1024). */
+ * many basic structurals on, default 1024), "refresh_min_k" / "refresh_max" / "refresh_tolerance" (verified
+ * refresh: from this nucleus order on -- default 6144, 0 = never -- a scheduled refactorization keeps the explicit
+ * inverse when the recomputed solutions leave max |A x - s| and max basic |dj| below the tolerance, default 1e-8,
+ * and re-inverts otherwise and every refresh_max-th time, default 15). */
 int clpgpu_set_option(clpgpu_context *ctx, const char *name, double value);
 /* Whole-array replacement of bounds / costs with the matrix left resident
  * (ClpModel::chgRowLower ... chgObjCoefficients, src/ClpModel.hpp:254-262, src/ClpModel.cpp:2669-2770;

@@ -358,6 +358,39 @@ def test_fast_dual_iteration_limit(gpu_cls):
     assert g.numberIterations() == o.iterations
 
 
+def test_verified_refresh_of_the_inverse(gpu_cls):
+    """Large nuclei keep the explicit inverse at a scheduled refactorization when the recomputed solutions leave
+    small residuals (options refresh_min_k / refresh_max / refresh_tolerance).  Forced on for
+    a small LP: the solve must end at the oracle's optimum (objective 1e-8 relative, KKT) with refreshes taken
+    and a re-inversion every refresh_max-th time; with tolerance 0 every refresh is rejected and re-inverted,
+    which must reproduce the pivots and solution bits of the engine with the feature off."""
+    lp = P.sparse_lp(1500, 6000, 10, 31)
+    o = oracle(lp, 1)
+    assert o.dual() == 0
+    off = gpu_cls().loadProblem(lp)
+    off.set_option("refresh_min_k", 0)
+    on = gpu_cls().loadProblem(lp)
+    on.set_option("refresh_min_k", 50)
+    on.set_option("refresh_max", 3)
+    rej = gpu_cls().loadProblem(lp)
+    rej.set_option("refresh_min_k", 50)
+    rej.set_option("refresh_tolerance", 0.0)
+    for g in (off, on, rej):
+        g.set_option("max_pivots", 40)  # many refactorization points
+        assert g.dual() == 0
+        assert abs(g.objectiveValue() - o.objective) <= RTOL * (1 + abs(o.objective))
+        kkt(lp, g)
+    s_on, s_rej, s_off = on.stats(), rej.stats(), off.stats()
+    assert s_off["refreshes"] == 0 and s_off["refreshes_rejected"] == 0
+    assert s_on["refreshes"] > 10 and s_on["refactorizations"] >= s_on["refreshes"] // 3
+    assert s_on["refactorizations"] < s_off["refactorizations"]
+    assert s_rej["refreshes"] == 0 and s_rej["refreshes_rejected"] > 10
+    assert rel(on.solution(), o.solution()) < 1e-7
+    la, lb = off.pivotLog(), rej.pivotLog()
+    assert np.array_equal(la["sequenceIn"], lb["sequenceIn"]) and np.array_equal(la["sequenceOut"], lb["sequenceOut"])
+    assert np.array_equal(off.solution(), rej.solution())
+
+
 @pytest.mark.parametrize("option", ["blocked_refactor", "register_panel"])
 def test_reinversion_variants_agree(gpu_cls, option):
     """Re-inversion of the nucleus: the unblocked form, the blocked form with the global-memory panel

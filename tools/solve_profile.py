@@ -52,13 +52,14 @@ def main():
         it = g.numberIterations()
         print(json.dumps({"iterations": it, "elapsed_s": round(now - t0, 3), "chunk_it_per_s": round((it - last_it) / max(now - last_t, 1e-9), 1),
                           "nucleus": st["nucleus"], "capacity": st["nucleus_capacity"], "refactorizations": st["refactorizations"],
-                          "objective": g.objectiveValue(), "status": status}), flush=True)
+                          "refreshes": st["refreshes"], "refreshes_rejected": st["refreshes_rejected"], "objective": g.objectiveValue(), "status": status}), flush=True)
         last_t, last_it = now, it
     total = time.perf_counter() - t0
     print(json.dumps({"summary": True, "workload": args.workload, "rows": int(lp.m), "cols": int(lp.n), "status": status,
                       "iterations": g.numberIterations(), "seconds": round(total, 3),
                       "time_to_optimal_s": round(total, 3) if status == 0 else None, "objective": g.objectiveValue(),
-                      "nucleus": g.stats()["nucleus"]}), flush=True)
+                      "nucleus": g.stats()["nucleus"], "refactorizations": g.stats()["refactorizations"],
+                      "refreshes": g.stats()["refreshes"], "refreshes_rejected": g.stats()["refreshes_rejected"]}), flush=True)
 
 
 if __name__ == "__main__":
