@@ -96,11 +96,20 @@ struct clpgpu_context {
   // largestPrimalError_ / largestDualError_); otherwise -- and every refreshMax-th time anyway -- the nucleus is
   // re-inverted.  The reference re-factorizes because its eta file grows and errors accumulate; with an explicit
   // inverse only the second reason is left, and it is measured.  Options "refresh_min_k" (nuclei of at least
-  // this order, default 6144; 0 = never), "refresh_max", "refresh_tolerance".
-  int refreshMinK = 6144, refreshMax = 15, consecutiveRefreshes = 0, numberRefreshes = 0, numberRefreshesRejected = 0;
+  // this order; default 0 = never: on the bench LP the inverse drifts to residuals of 1e-7..1e-5 within the
+  // ~475 pivots between refactorizations, 10-100x what a re-inversion leaves, so every refresh is rejected at
+  // the default tolerance -- profiles/r02_refresh_errors.txt), "refresh_max", "refresh_tolerance".
+  int refreshMinK = 0, refreshMax = 15, consecutiveRefreshes = 0, numberRefreshes = 0, numberRefreshesRejected = 0;
   double refreshTolerance = 1.0e-8;
   bool refreshEligible();
   int refreshFactor();
+  // option "refresh_refine" (default 1): before the check, one Newton-Schulz step X += X (I - C X) on the kept
+  // inverse -- a sparse residual kernel and one k^3 f64 GEMM (rocBLAS, loaded on first use) instead of the
+  // latency-bound elimination; refreshResidualMax: no step (re-invert) when max |I - C X| exceeds it
+  int refreshRefine = 1, numberRefines = 0;
+  double refreshResidualMax = 1.0e-2, lastResidual = 0.0;
+  void *blasHandle = nullptr;
+  int refineInverse();
   int numberThrownOut = 0;  // structurals replaced by slacks by the singular-basis repair, whole solve
   void resetFakeBounds();
   int pivots = 0, kNucleus = 0;
@@ -1828,6 +1837,60 @@ bool clpgpu_context::refreshEligible()
     return false;
   return k + maximumPivots + 16 <= kcap;  // room for the growth until the next one
 }
+// rocBLAS, loaded when a nucleus first asks for the GEMM of the Newton-Schulz step
+static void *rocblasLibrary()
+{
+  static void *h = nullptr;
+  if (!h)
+    h = dlopen("librocblas.so.5", RTLD_NOW | RTLD_LOCAL);
+  if (!h)
+    h = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
+  return h;
+}
+int clpgpu_context::refineInverse()
+{
+  typedef int (*create_t)(void **);
+  typedef int (*stream_t)(void *, hipStream_t);
+  typedef int (*dgemm_t)(void *, int, int, int, int, int, const double *, const double *, int, const double *, int, const double *, double *, int);
+  void *lib = rocblasLibrary();
+  if (!lib)
+    return 1;
+  static create_t createFn = (create_t)dlsym(lib, "rocblas_create_handle");
+  static stream_t streamFn = (stream_t)dlsym(lib, "rocblas_set_stream");
+  static dgemm_t dgemmFn = (dgemm_t)dlsym(lib, "rocblas_dgemm");
+  if (!createFn || !streamFn || !dgemmFn)
+    return 1;
+  if (!blasHandle) {
+    if (createFn(&blasHandle) != 0 || streamFn(blasHandle, stream) != 0) {
+      blasHandle = nullptr;
+      return 1;
+    }
+  }
+  const int k = hCtrl->k;
+  const size_t mat = (size_t)k * ld * sizeof(double);
+  unsigned long long *dMax = (unsigned long long *)D.normPartial;
+  if (hipMemsetAsync(dMax, 0, sizeof(unsigned long long), stream) != hipSuccess)
+    return 1;
+  hipLaunchKernelGGL(k_refine_residual, dim3(k), dim3(256), 0, stream, D, k, D.workX, dMax);
+  unsigned long long bits = 0;
+  if (d2h(&bits, dMax, 1))
+    return 1;
+  memcpy(&lastResidual, &bits, sizeof(double));
+  if (!(lastResidual <= refreshResidualMax))
+    return 2;  // too far for one step: re-invert
+  // workW = X; workW += X R  (row-major X R = column-major R^T X^T: A = R, B = X in rocBLAS terms)
+  if (hipMemcpyAsync(D.workW, D.Minv, mat, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+    return 1;
+  const double one = 1.0;
+  const int none = 111;  // rocblas_operation_none
+  if (dgemmFn(blasHandle, none, none, k, k, k, &one, D.workX, ld, D.Minv, ld, &one, D.workW, ld) != 0)
+    return 1;
+  if (hipMemcpyAsync(D.Minv, D.workW, mat, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+    return 1;
+  numberRefines++;
+  return 0;
+}
+
 int clpgpu_context::refreshFactor()
 {
   // what factorizeOnce leaves behind, minus the re-inversion: the slot arrays, the row-copy partition and
@@ -1852,10 +1915,13 @@ int clpgpu_context::statusOfProblemInDual(int type)
   if (problemStatus > -3 || numberPivots > 0) {
     rc |= saveWeights(1);
     weightsSaved = true;
-    if (type && refreshEligible()) {
+    if (type && refreshEligible() && (!refreshRefine || refineInverse() == 0)) {
       rc |= pullRim(true);
       rc |= refreshFactor();
       rc |= gutsOfSolution();
+      if (logLevel > 1)
+        fprintf(stderr, "clpgpu: iteration %d, nucleus %d kept%s (max |I - C X| before %g): errors %g %g\n", numberIterations, kNucleus,
+                refreshRefine ? " + Newton step" : "", lastResidual, largestPrimalError, largestDualError);
       if (largestPrimalError <= refreshTolerance && largestDualError <= refreshTolerance) {
         gutsDone = true;
       } else {
@@ -1907,8 +1973,11 @@ int clpgpu_context::statusOfProblemInDual(int type)
     if (problemStatus != -4 || numberPivots > 10)
       problemStatus = -3;
   }
-  if (type && !gutsDone)
+  if (type && !gutsDone) {
     rc |= gutsOfSolution();
+    if (logLevel > 1)
+      fprintf(stderr, "clpgpu: iteration %d, nucleus %d re-inverted: errors %g %g\n", numberIterations, kNucleus, largestPrimalError, largestDualError);
+  }
   int situationChanged = 0;
   bool needCleanFake = false, dirty = false;
   double saveDualBound = dualBound;
@@ -2720,6 +2789,13 @@ void clpgpu_destroy(clpgpu_context *ctx)
     (void)hipEventDestroy(ctx->evJoin);
   if (ctx->comm && ctx->ncclCommDestroyFn)
     ctx->ncclCommDestroyFn(ctx->comm);
+  if (ctx->blasHandle) {
+    typedef int (*destroy_t)(void *);
+    void *lib = rocblasLibrary();
+    destroy_t destroyFn = lib ? (destroy_t)dlsym(lib, "rocblas_destroy_handle") : nullptr;
+    if (destroyFn)
+      destroyFn(ctx->blasHandle);
+  }
   for (void *p : ctx->allocations)
     (void)hipFree(p);
   if (ctx->hCtrl)
@@ -3218,6 +3294,8 @@ clpgpu_context *clpgpu_clone(const clpgpu_context *src)
   ctx->refreshMinK = src->refreshMinK;
   ctx->refreshMax = src->refreshMax;
   ctx->refreshTolerance = src->refreshTolerance;
+  ctx->refreshRefine = src->refreshRefine;
+  ctx->refreshResidualMax = src->refreshResidualMax;
   ctx->scalingMode = src->scalingMode;
   ctx->flipListCap = src->flipListCap;
   ctx->haveExternalScales = src->haveExternalScales;
@@ -3403,6 +3481,8 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "refresh_min_k")) ctx->refreshMinK = (int)v;
   else if (!strcmp(name, "refresh_max")) ctx->refreshMax = std::max(0, (int)v);
   else if (!strcmp(name, "refresh_tolerance")) ctx->refreshTolerance = v;
+  else if (!strcmp(name, "refresh_refine")) ctx->refreshRefine = v != 0.0;
+  else if (!strcmp(name, "refresh_residual_max")) ctx->refreshResidualMax = v;
   else if (!strcmp(name, "flip_slot_cap")) { ctx->flipSlotCap = std::max(1, std::min((int)v, (int)FLIP_SLOTS)); ctx->dropGraph(); }
   else if (!strcmp(name, "flip_scatter")) { ctx->flipScatter = v >= 2.0 ? 2 : (v != 0.0 ? 1 : 0); ctx->dropGraph(); }
   else if (!strcmp(name, "row_price_frac")) { ctx->rowPriceFrac = v < 0.0 ? 0.0 : v; ctx->dropGraph(); }

@@ -4545,6 +4545,53 @@ __global__ void k_zero(double *p, int n)
     p[i] = 0.0;
 }
 // =============================================================================================
+// Newton-Schulz step on the explicit inverse (large nuclei, see clpgpu_context::refineInverse):
+// R = I - C X with C = A[R,K] read from the basic part of the row copy (entries carry their column's slot),
+// one workgroup per row slot; X += X R is a plain f64 GEMM (rocBLAS).  out[0] = max |R| (bit pattern).
+// =============================================================================================
+__global__ void __launch_bounds__(256) k_refine_residual(Dev D, int k, double *R, unsigned long long *out)
+{
+  __shared__ int s_slot[256];
+  __shared__ double s_elem[256];
+  __shared__ double s_max[4];
+  const int sr = blockIdx.x;
+  if (sr >= k)
+    return;
+  const int r = D.slotRow[sr];
+  const int start = D.rowStart[r], nb = D.basicCount[r];
+  double best = 0.0;
+  for (int c0 = 0; c0 < k; c0 += 256) {
+    const int col = c0 + threadIdx.x;
+    double acc = (col == sr) ? 1.0 : 0.0;
+    for (int e0 = 0; e0 < nb; e0 += 256) {
+      __syncthreads();
+      if (e0 + (int)threadIdx.x < nb) {
+        s_slot[threadIdx.x] = D.cslot[start + e0 + threadIdx.x];
+        s_elem[threadIdx.x] = D.relem[start + e0 + threadIdx.x];
+      }
+      __syncthreads();
+      const int cnt = min(256, nb - e0);
+      if (col < k)
+        for (int e = 0; e < cnt; e++)
+          acc -= s_elem[e] * D.Minv[(size_t)s_slot[e] * D.ld + col];
+    }
+    if (col < k) {
+      R[(size_t)sr * D.ld + col] = acc;
+      best = fmax(best, fabs(acc));
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1)
+    best = fmax(best, __shfl_xor(best, o));
+  if ((threadIdx.x & 63) == 0)
+    s_max[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    best = fmax(fmax(s_max[0], s_max[1]), fmax(s_max[2], s_max[3]));
+    atomicMax(out, (unsigned long long)__double_as_longlong(best));
+  }
+}
+
+// =============================================================================================
 // Refactorization of the nucleus: gather C = A[R,K], Gauss-Jordan with partial pivoting whose
 // arithmetic on the not-yet-pivoted rows is exactly the right-looking LU of
 // CoinAbcDenseFactorization::factor (src/CoinAbcDenseFactorization.cpp:262-313): multiplier

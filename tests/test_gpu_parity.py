@@ -361,7 +361,8 @@ def test_fast_dual_iteration_limit(gpu_cls):
 def test_verified_refresh_of_the_inverse(gpu_cls):
     """Large nuclei keep the explicit inverse at a scheduled refactorization when the recomputed solutions leave
     small residuals (options refresh_min_k / refresh_max / refresh_tolerance).  Forced on for
-    a small LP: the solve must end at the oracle's optimum (objective 1e-8 relative, KKT) with refreshes taken
+    a small LP, with and without the Newton-Schulz step on the kept inverse (residual kernel + rocBLAS dgemm):
+    the solve must end at the oracle's optimum (objective 1e-8 relative, KKT) with refreshes taken
     and a re-inversion every refresh_max-th time; with tolerance 0 every refresh is rejected and re-inverted,
     which must reproduce the pivots and solution bits of the engine with the feature off."""
     lp = P.sparse_lp(1500, 6000, 10, 31)
@@ -372,10 +373,14 @@ def test_verified_refresh_of_the_inverse(gpu_cls):
     on = gpu_cls().loadProblem(lp)
     on.set_option("refresh_min_k", 50)
     on.set_option("refresh_max", 3)
+    plain = gpu_cls().loadProblem(lp)  # the inverse kept as it is, no Newton-Schulz step before the check
+    plain.set_option("refresh_min_k", 50)
+    plain.set_option("refresh_max", 3)
+    plain.set_option("refresh_refine", 0)
     rej = gpu_cls().loadProblem(lp)
     rej.set_option("refresh_min_k", 50)
     rej.set_option("refresh_tolerance", 0.0)
-    for g in (off, on, rej):
+    for g in (off, on, plain, rej):
         g.set_option("max_pivots", 40)  # many refactorization points
         assert g.dual() == 0
         assert abs(g.objectiveValue() - o.objective) <= RTOL * (1 + abs(o.objective))
@@ -383,6 +388,7 @@ def test_verified_refresh_of_the_inverse(gpu_cls):
     s_on, s_rej, s_off = on.stats(), rej.stats(), off.stats()
     assert s_off["refreshes"] == 0 and s_off["refreshes_rejected"] == 0
     assert s_on["refreshes"] > 10 and s_on["refactorizations"] >= s_on["refreshes"] // 3
+    assert plain.stats()["refreshes"] > 10 and rel(plain.solution(), o.solution()) < 1e-7
     assert s_on["refactorizations"] < s_off["refactorizations"]
     assert s_rej["refreshes"] == 0 and s_rej["refreshes_rejected"] > 10
     assert rel(on.solution(), o.solution()) < 1e-7
