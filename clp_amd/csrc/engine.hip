@@ -95,12 +95,14 @@ struct clpgpu_context {
   // refreshTolerance (max |A x - s|, max |dj| over the basics: the reference's own measures of a factorization,
   // largestPrimalError_ / largestDualError_); otherwise -- and every refreshMax-th time anyway -- the nucleus is
   // re-inverted.  The reference re-factorizes because its eta file grows and errors accumulate; with an explicit
-  // inverse only the second reason is left, and it is measured.  Options "refresh_min_k" (nuclei of at least
-  // this order; default 0 = never: on the bench LP the inverse drifts to residuals of 1e-7..1e-5 within the
-  // ~475 pivots between refactorizations, 10-100x what a re-inversion leaves, so every refresh is rejected at
-  // the default tolerance -- profiles/r02_refresh_errors.txt), "refresh_max", "refresh_tolerance".
-  int refreshMinK = 0, refreshMax = 15, consecutiveRefreshes = 0, numberRefreshes = 0, numberRefreshesRejected = 0;
-  double refreshTolerance = 1.0e-8;
+  // inverse only the second reason is left, and it is measured.  Kept as it is, the inverse of the bench LP
+  // drifts to residuals of 1e-7..1e-5 within the ~475 pivots between refactorizations (10-100x what a
+  // re-inversion leaves, profiles/r02_refresh_errors.txt); with one Newton-Schulz step first (refineInverse) it
+  // comes out at 1e-9..4e-8, below the re-inversion's own 4e-9..6e-7, at a fifth of the cost
+  // (profiles/r02_refresh_newton.txt).  Options "refresh_min_k" (nuclei of at least this order, default 6144;
+  // 0 = never), "refresh_max", "refresh_tolerance", "refresh_refine".
+  int refreshMinK = 6144, refreshMax = 15, consecutiveRefreshes = 0, numberRefreshes = 0, numberRefreshesRejected = 0;
+  double refreshTolerance = 1.0e-6;
   bool refreshEligible();
   int refreshFactor();
   // option "refresh_refine" (default 1): before the check, one Newton-Schulz step X += X (I - C X) on the kept

@@ -189,10 +189,12 @@ int clpgpu_unroll_weights(clpgpu_context *ctx);
  * "row_price_frac" (row pricing goes by row when nnz(pi) <= frac * m, ClpPackedMatrix.cpp:727-754; 0 = always
  * by column; also selects the form of clpgpu_price_row), "refactor_mode" (-1 auto / 1 one-level / 2
  * two-level vector / 3 two-level MFMA re-inversion), "refactor_min_k" (auto: two-level MFMA from this
- * many basic structurals on, default 1024), "refresh_min_k" / "refresh_max" / "refresh_tolerance" (verified
- * refresh: from this nucleus order on -- default 0 = never -- a scheduled refactorization keeps the explicit
- * inverse when the recomputed solutions leave max |A x - s| and max basic |dj| below the tolerance, default 1e-8,
- * and re-inverts otherwise and every refresh_max-th time, default 15). */
+ * many basic structurals on, default 1024), "refresh_min_k" / "refresh_max" / "refresh_tolerance" /
+ * "refresh_refine" (verified refresh: from this nucleus order on -- default 6144, 0 = never -- a scheduled
+ * refactorization keeps the explicit inverse, improved by one Newton-Schulz step X += X (I - C X) unless
+ * refresh_refine is 0 (a sparse residual kernel + one f64 GEMM from rocBLAS), when the solutions recomputed with
+ * it leave max |A x - s| and max basic |dj| below the tolerance, default 1e-6; it re-inverts otherwise and every
+ * refresh_max-th time, default 15). */
 int clpgpu_set_option(clpgpu_context *ctx, const char *name, double value);
 /* Whole-array replacement of bounds / costs with the matrix left resident
  * (ClpModel::chgRowLower ... chgObjCoefficients, src/ClpModel.hpp:254-262, src/ClpModel.cpp:2669-2770;
