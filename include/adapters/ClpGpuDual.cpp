@@ -49,3 +49,17 @@ int clpGpuDual(ClpSimplex &model, int device, bool scaling)
     return model.primal(1);
   return problemStatus;
 }
+
+// ClpSimplexDual::strongBranching (src/ClpSimplexDual.hpp:125-131, src/ClpSimplexDual.cpp:6965) for a node LP
+// that was solved on the device: same arguments, same outputs (newLower / newUpper come back as the objective
+// changes, outputStatus 0 / 1 / 2, even = down, odd = up).  `ctx` is the context of that solve -- a caller that
+// wants strong branching keeps it alive instead of destroying it at the end of clpGpuDual -- so the matrix and
+// the optimal basis are already resident; every branch is a fastDual (src/ClpSimplexDual.cpp:7227) on the device.
+int clpGpuStrongBranching(ClpSimplex &model, clpgpu_context *ctx, int numberVariables, const int *variables,
+  double *newLower, double *newUpper, double **outputSolution, int *outputStatus, int *outputIterations,
+  bool stopOnFirstInfeasible, bool alwaysFinish)
+{
+  clpgpu_set_option(ctx, "max_iterations", model.maximumIterations()); // Cbc sets a small limit for this call
+  return clpgpu_strong_branching(ctx, numberVariables, variables, newLower, newUpper, outputSolution, outputStatus,
+    outputIterations, stopOnFirstInfeasible ? 1 : 0, alwaysFinish ? 1 : 0);
+}
