@@ -173,6 +173,13 @@ struct clpgpu_context {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graphExec = nullptr;
   int graphIterations = 0;
+  // shorter batches (1, 2, 4, ... pivots) for the tail of a stepped run (clpgpu_dual_steps): a batch of
+  // check_every pivots whose step limit falls inside it replays every kernel of the remaining pivots as a no-op
+  // (~20 us per pivot); captured the first time a tail of that size is asked for
+  static const int TAIL_SIZES = 8;
+  hipGraph_t tailGraph[TAIL_SIZES] = {};
+  hipGraphExec_t tailExec[TAIL_SIZES] = {};
+  int captureBatch(int count, hipGraph_t &g, hipGraphExec_t &exec);
   int logCapacity = 0;
   // ---- stats
   clpgpu_stats stats;
@@ -278,7 +285,7 @@ struct clpgpu_context {
   int statusOfProblemInDual(int type);
   int launchIteration(bool firstOfBatch, int parity);
   void joinUpdateBranch();
-  int launchBatch();
+  int launchBatch(int count = -1);
   bool capturing = false;
   int whileIterating(int stepTarget);
   // ClpSimplexDual::fastDual (src/ClpSimplexDual.cpp:7227): 0 = run() as clpgpu_dual does; 1 = in fastDual with
@@ -922,6 +929,14 @@ void clpgpu_context::dropGraph()
     (void)hipGraphDestroy(graph);
   graphExec = nullptr;
   graph = nullptr;
+  for (int i = 0; i < TAIL_SIZES; i++) {
+    if (tailExec[i])
+      (void)hipGraphExecDestroy(tailExec[i]);
+    if (tailGraph[i])
+      (void)hipGraphDestroy(tailGraph[i]);
+    tailExec[i] = nullptr;
+    tailGraph[i] = nullptr;
+  }
 }
 
 int clpgpu_context::allocNucleus(int kNeeded)
@@ -2336,10 +2351,39 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
 
 // `checkEvery` pivots as one hipGraph (the chain has no host-visible decisions), replayed until
 // the device control block leaves RUN.  Re-captured whenever a captured pointer or extent changes.
-int clpgpu_context::launchBatch()
+// capture `count` pivots of the chain into a graph; 0 on success (exec valid), 1 when capture / instantiation failed
+int clpgpu_context::captureBatch(int count, hipGraph_t &g, hipGraphExec_t &exec)
 {
+  capturing = true;
+  evUsed = 0;
+  hipError_t e = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal);
+  if (e == hipSuccess) {
+    for (int b = 0; b < count; b++)
+      launchIteration(b == 0, b & 1);
+    joinUpdateBranch();  // every forked branch rejoins the origin stream before the capture ends
+    e = hipStreamEndCapture(stream, &g);
+  }
+  capturing = false;
+  if (e == hipSuccess)
+    e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    if (g)
+      (void)hipGraphDestroy(g);
+    g = nullptr;
+    exec = nullptr;
+    return 1;
+  }
+  return 0;
+}
+
+// one batch of pivots: check_every of them, or -- count in 1 .. check_every-1, a power of two -- a tail batch
+int clpgpu_context::launchBatch(int count)
+{
+  if (count < 0 || count > checkEvery)
+    count = checkEvery;
   if (!useGraph || timing) {
-    for (int b = 0; b < checkEvery; b++) {
+    for (int b = 0; b < count; b++) {
       if (timing >= 2)
         ktBegin(b);
       launchIteration(b == 0, b & 1);
@@ -2348,43 +2392,49 @@ int clpgpu_context::launchBatch()
     return checkLaunches("launchIteration");
   }
   if (!graphExec || graphIterations != checkEvery) {
+    // (the full-size graph is always built first, also when a tail batch is what runs now: a stepped run
+    // that warms up with a few pivots must not pay for its instantiation later)
     dropGraph();
-    capturing = true;
-    evUsed = 0;
-    hipError_t e = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal);
-    if (e == hipSuccess) {
-      for (int b = 0; b < checkEvery; b++)
-        launchIteration(b == 0, b & 1);
-      joinUpdateBranch();  // every forked branch rejoins the origin stream before the capture ends
-      e = hipStreamEndCapture(stream, &graph);
-    }
-    capturing = false;
-    if (e == hipSuccess)
-      e = hipGraphInstantiate(&graphExec, graph, nullptr, nullptr, 0);
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
+    if (captureBatch(checkEvery, graph, graphExec)) {
       dropGraph();
       useGraph = 0;  // fall back to eager launches of the same chain
       sidePending = false;
-      for (int b = 0; b < checkEvery; b++)
+      for (int b = 0; b < count; b++)
         launchIteration(b == 0, b & 1);
       joinUpdateBranch();
       return checkLaunches("launchIteration");
     }
     graphIterations = checkEvery;
   }
-  hipError_t e = hipGraphLaunch(graphExec, stream);
+  hipGraphExec_t exec = graphExec;
+  if (count < checkEvery) {
+    int slot = 0;
+    while ((1 << slot) < count)
+      slot++;
+    if ((1 << slot) != count || slot >= TAIL_SIZES) {
+      setError("launchBatch: tail batch of %d pivots", count);
+      return -99;
+    }
+    if (!tailExec[slot] && captureBatch(count, tailGraph[slot], tailExec[slot])) {
+      // no graph for this size: the same pivots eagerly
+      sidePending = false;
+      for (int b = 0; b < count; b++)
+        launchIteration(b == 0, b & 1);
+      joinUpdateBranch();
+      return checkLaunches("launchIteration");
+    }
+    exec = tailExec[slot];
+  }
+  hipError_t e = hipGraphLaunch(exec, stream);
   if (e != hipSuccess) {
     setError("hipGraphLaunch failed: %s", hipGetErrorString(e));
     return -99;
   }
   if (timing)
-    evUsed = checkEvery;  // the event-record nodes of every captured pivot were replayed
+    evUsed = count;  // the event-record nodes of every captured pivot were replayed
   return 0;
 }
 
-// ClpSimplexDual::whileIterating (:973-2384): the loop body runs on the device; this is the exit
-// handling.  Returns 0 when the caller should go to statusOfProblemInDual, 1 on step limit.
 int clpgpu_context::whileIterating(int stepTarget)
 {
   // push the scalars the device needs for this run of iterations
@@ -2415,8 +2465,25 @@ int clpgpu_context::whileIterating(int stepTarget)
     evUsed = 0;
     double launchesBefore = hCtrl->statPriceLaunches;
     const int logBefore = hCtrl->logCount;
-    rc |= launchBatch();
+    // a stepped run (clpgpu_dual_steps) ends on the pivot asked for: the last batches are 8, 4, 2, 1 pivots
+    // long instead of a full batch that idles through the pivots behind the limit
+    int count = checkEvery;
+    if (stepTarget >= 0) {
+      const int remaining = stepTarget - hCtrl->numberIterations;
+      if (remaining <= 0) {
+        hCtrl->state = EXIT_STEP_LIMIT;
+        break;
+      }
+      if (remaining < checkEvery) {
+        count = 1;
+        while (count * 2 <= remaining && count * 2 < (1 << clpgpu_context::TAIL_SIZES))
+          count *= 2;
+      }
+    }
+    rc |= launchBatch(count);
     rc |= pullCtrl();
+    if (!rc && hCtrl->state == RUN && stepTarget >= 0 && hCtrl->numberIterations >= stepTarget)
+      hCtrl->state = EXIT_STEP_LIMIT;  // the batch ended exactly on the limit: the device never saw a pivot beyond it
     if (timing) {
       // the device counts a pricing launch only while the loop is live; those are the first ones
       int timed = (int)(hCtrl->statPriceLaunches - launchesBefore);
