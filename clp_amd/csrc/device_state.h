@@ -159,7 +159,6 @@ struct Dev {
   int *flipKey;  // [FLIP_LIST_CAP] flagged bound flips in arrival order, as compaction keys
   int *appendFlag;  // [m]
   int *appendFlag1, *blockOffset1;  // the same for the flip part of the primal update (scattered together later)
-  int *touchCount;  // [m] (unused since round 2)
   int *flipHot;     // [FLIP_HOT_CAP] those rows
   int *flipTouch;   // [m] contributors per row while the flip rhs is assembled (zero otherwise)
   int *flipRowKey;  // [m * 8] their flip keys ...

@@ -674,7 +674,6 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   rc |= dalloc(D.appendFlag, m);
   rc |= dalloc(D.appendFlag1, m);
   rc |= dalloc(D.blockOffset1, cdiv(m, 256) + 2);
-  rc |= dalloc(D.touchCount, m);
   rc |= dalloc(D.flipTouch, m);
   rc |= dalloc(D.flipHot, FLIP_HOT_CAP);
   rc |= dalloc(D.flipRowKey, (size_t)m * FLIP_SLOTS);
@@ -3926,8 +3925,8 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
   *stats = ctx->stats;
   if (getenv("CLPGPU_DEBUG_STATS")) {
     const long long *g = ctx->hCtrl->dbg;
-    fprintf(stderr, "clpgpu dbg: dc small %lld big %lld passes %lld tries %lld sumNc %lld mapped %lld full %lld ticksSmall %lld ticksBig %lld | flip iters %lld flips %lld entries %lld sequential %lld | scattered %lld select rows %lld hot rows %lld row ticks %lld\n",
-            g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9], g[10], g[11], g[12], g[14], g[13], g[15], ctx->hCtrl->dbg2[6]);
+    fprintf(stderr, "clpgpu dbg: dc small %lld big %lld passes %lld tries %lld sumNc %lld mapped %lld full %lld ticksSmall %lld ticksBig %lld | flip iters %lld flips %lld entries %lld sequential %lld | scattered %lld select rows %lld hot rows %lld\n",
+            g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9], g[10], g[11], g[12], g[14], g[13], g[15]);
   }
   stats->price_bytes = ctx->hCtrl->statPriceBytes;
   stats->row_bytes = ctx->hCtrl->statRowBytes;

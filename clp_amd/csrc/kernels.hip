@@ -3936,12 +3936,8 @@ __global__ void __launch_bounds__(1024) k_flip_apply2(Dev D, int nbPos, int dens
   const int tid = threadIdx.x;
   if (blockIdx.x > 0) {
     const int nrawRows = c->flipAppend;
-    const long long t0 = wall_clock64();
     if (nrawRows)
       flipRowsBody(D, (int)blockIdx.x - 1, nrawRows, nrawRows <= listCap && nrawRows <= FLIP_MAX_FLIPS, slotCap);
-    __syncthreads();
-    if (blockIdx.x == 1 && tid == 0 && nrawRows)
-      c->dbg2[6] += wall_clock64() - t0;
     return;
   }
   // counters of k_ftran_scatter3's appends (position blocks) are reset here, flips or not
