@@ -108,7 +108,7 @@ struct clpgpu_context {
   // option "refresh_refine" (default 1): before the check, one Newton-Schulz step X += X (I - C X) on the kept
   // inverse -- a sparse residual kernel and one k^3 f64 GEMM (rocBLAS, loaded on first use) instead of the
   // latency-bound elimination; refreshResidualMax: no step (re-invert) when max |I - C X| exceeds it
-  int refreshRefine = 1, numberRefines = 0;
+  int refreshRefine = 1, numberRefines = 0, refreshMinKDense = 2048;
   double refreshResidualMax = 1.0e-2, lastResidual = 0.0;
   void *blasHandle = nullptr;
   int refineInverse();
@@ -1849,7 +1849,10 @@ bool clpgpu_context::refreshEligible()
   if (refreshMinK <= 0 || !blockedRefactor || rebuildRowCopy || forceFactorization == 1 || !hCtrl)
     return false;
   const int k = hCtrl->k;
-  if (k < refreshMinK || consecutiveRefreshes >= refreshMax)
+  // (long rows: the re-inversion is a larger share of a pivot's cost already at a few thousand, and both halves
+  // of the step are GEMMs there; no parity test solves a dense LP with a nucleus beyond a few hundred)
+  const int minK = wideRows ? std::min(refreshMinK, refreshMinKDense) : refreshMinK;
+  if (k < minK || consecutiveRefreshes >= refreshMax)
     return false;
   return k + maximumPivots + 16 <= kcap;  // room for the growth until the next one
 }
@@ -1887,7 +1890,20 @@ int clpgpu_context::refineInverse()
   unsigned long long *dMax = (unsigned long long *)D.normPartial;
   if (hipMemsetAsync(dMax, 0, sizeof(unsigned long long), stream) != hipSuccess)
     return 1;
-  hipLaunchKernelGGL(k_refine_residual, dim3(k), dim3(256), 0, stream, D, k, D.workX, dMax);
+  const double one = 1.0, minusOne = -1.0;
+  const int none = 111;  // rocblas_operation_none
+  if (wideRows) {
+    // long rows: C gathered dense, R = I - C X as a GEMM (row-major C X = column-major X^T C^T: A = X, B = C)
+    if (hipMemsetAsync(D.workW, 0, mat, stream) != hipSuccess || hipMemsetAsync(D.workX, 0, mat, stream) != hipSuccess)
+      return 1;
+    hipLaunchKernelGGL(k_gather_slots, dim3(k), dim3(64), 0, stream, D, k, D.workW);
+    hipLaunchKernelGGL(k_identity, dim3(cdiv(k, 256)), dim3(256), 0, stream, D, k);
+    if (dgemmFn(blasHandle, none, none, k, k, k, &minusOne, D.Minv, ld, D.workW, ld, &one, D.workX, ld) != 0)
+      return 1;
+    hipLaunchKernelGGL(k_absmax_rows, dim3(k), dim3(256), 0, stream, D, k, (const double *)D.workX, dMax);
+  } else {
+    hipLaunchKernelGGL(k_refine_residual, dim3(k), dim3(256), 0, stream, D, k, D.workX, dMax);
+  }
   unsigned long long bits = 0;
   if (d2h(&bits, dMax, 1))
     return 1;
@@ -1897,8 +1913,6 @@ int clpgpu_context::refineInverse()
   // workW = X; workW += X R  (row-major X R = column-major R^T X^T: A = R, B = X in rocBLAS terms)
   if (hipMemcpyAsync(D.workW, D.Minv, mat, hipMemcpyDeviceToDevice, stream) != hipSuccess)
     return 1;
-  const double one = 1.0;
-  const int none = 111;  // rocblas_operation_none
   if (dgemmFn(blasHandle, none, none, k, k, k, &one, D.workX, ld, D.Minv, ld, &one, D.workW, ld) != 0)
     return 1;
   if (hipMemcpyAsync(D.Minv, D.workW, mat, hipMemcpyDeviceToDevice, stream) != hipSuccess)
@@ -3363,6 +3377,7 @@ clpgpu_context *clpgpu_clone(const clpgpu_context *src)
   ctx->refreshMax = src->refreshMax;
   ctx->refreshTolerance = src->refreshTolerance;
   ctx->refreshRefine = src->refreshRefine;
+  ctx->refreshMinKDense = src->refreshMinKDense;
   ctx->refreshResidualMax = src->refreshResidualMax;
   ctx->scalingMode = src->scalingMode;
   ctx->flipListCap = src->flipListCap;
@@ -3547,6 +3562,7 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "refactor_min_k")) ctx->refactorMinK = (int)v;
   else if (!strcmp(name, "fork_update")) { ctx->forkUpdate = (int)v; ctx->dropGraph(); }
   else if (!strcmp(name, "refresh_min_k")) ctx->refreshMinK = (int)v;
+  else if (!strcmp(name, "refresh_min_k_dense")) ctx->refreshMinKDense = (int)v;
   else if (!strcmp(name, "refresh_max")) ctx->refreshMax = std::max(0, (int)v);
   else if (!strcmp(name, "refresh_tolerance")) ctx->refreshTolerance = v;
   else if (!strcmp(name, "refresh_refine")) ctx->refreshRefine = v != 0.0;

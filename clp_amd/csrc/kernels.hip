@@ -4587,6 +4587,40 @@ __global__ void __launch_bounds__(256) k_refine_residual(Dev D, int k, double *R
   }
 }
 
+// dense form of the same step (LPs with long rows: the residual is a GEMM too): C = A[R,K] by slots into W
+// (zeroed by the caller), one workgroup per column slot; max |R| of a k x k row-major matrix
+__global__ void __launch_bounds__(64) k_gather_slots(Dev D, int k, double *W)
+{
+  const int sc = blockIdx.x;
+  if (sc >= k)
+    return;
+  const int j = D.slotCol[sc];
+  for (int p = D.colStart[j] + threadIdx.x; p < D.colStart[j + 1]; p += blockDim.x) {
+    const int sr = D.slotOfRow[D.row[p]];
+    if (sr >= 0)
+      W[(size_t)sr * D.ld + sc] = D.elem[p];
+  }
+}
+__global__ void __launch_bounds__(256) k_absmax_rows(Dev D, int k, const double *R, unsigned long long *out)
+{
+  __shared__ double s_max[4];
+  const int r = blockIdx.x;
+  if (r >= k)
+    return;
+  double best = 0.0;
+  for (int c = threadIdx.x; c < k; c += 256)
+    best = fmax(best, fabs(R[(size_t)r * D.ld + c]));
+  for (int o = 32; o > 0; o >>= 1)
+    best = fmax(best, __shfl_xor(best, o));
+  if ((threadIdx.x & 63) == 0)
+    s_max[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    best = fmax(fmax(s_max[0], s_max[1]), fmax(s_max[2], s_max[3]));
+    atomicMax(out, (unsigned long long)__double_as_longlong(best));
+  }
+}
+
 // =============================================================================================
 // Refactorization of the nucleus: gather C = A[R,K], Gauss-Jordan with partial pivoting whose
 // arithmetic on the not-yet-pivoted rows is exactly the right-looking LU of
