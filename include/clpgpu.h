@@ -190,7 +190,7 @@ int clpgpu_unroll_weights(clpgpu_context *ctx);
  * by column; also selects the form of clpgpu_price_row), "refactor_mode" (-1 auto / 1 one-level / 2
  * two-level vector / 3 two-level MFMA re-inversion), "refactor_min_k" (auto: two-level MFMA from this
  * many basic structurals on, default 1024), "refresh_min_k" / "refresh_max" / "refresh_tolerance" /
- * "refresh_refine" (verified refresh: from this nucleus order on -- default 6144, 0 = never -- a scheduled
+ * "refresh_refine" (verified refresh: from this nucleus order on -- default 6144, LPs with long rows "refresh_min_k_dense" = 2048; 0 = never -- a scheduled
  * refactorization keeps the explicit inverse, improved by one Newton-Schulz step X += X (I - C X) unless
  * refresh_refine is 0 (a sparse residual kernel + one f64 GEMM from rocBLAS), when the solutions recomputed with
  * it leave max |A x - s| and max basic |dj| below the tolerance, default 1e-6; it re-inverts otherwise and every
