@@ -397,6 +397,26 @@ def test_verified_refresh_of_the_inverse(gpu_cls):
     assert np.array_equal(off.solution(), rej.solution())
 
 
+def test_verified_refresh_dense_form(gpu_cls):
+    """The same refresh on an LP with long rows (config-3 shape): the nucleus is gathered dense by slots and both
+    halves of the Newton-Schulz step are GEMMs.  Forced on from nucleus order 20: oracle's optimum (1e-8), KKT,
+    refreshes taken, none rejected at the default tolerance."""
+    lp = P.dense_lp(300, 400, 5)
+    o = oracle(lp, 1)
+    assert o.dual() == 0
+    g = gpu_cls().loadProblem(lp)
+    g.set_option("refresh_min_k", 20)
+    g.set_option("refresh_min_k_dense", 20)
+    g.set_option("refresh_max", 3)
+    g.set_option("max_pivots", 25)
+    assert g.dual() == 0
+    assert abs(g.objectiveValue() - o.objective) <= RTOL * (1 + abs(o.objective))
+    assert rel(g.solution(), o.solution()) < 1e-7
+    kkt(lp, g)
+    st = g.stats()
+    assert st["refreshes"] > 5 and st["refreshes_rejected"] == 0
+
+
 @pytest.mark.parametrize("option", ["blocked_refactor", "register_panel"])
 def test_reinversion_variants_agree(gpu_cls, option):
     """Re-inversion of the nucleus: the unblocked form, the blocked form with the global-memory panel
