@@ -83,3 +83,37 @@ def test_merge_candidates_equals_unsharded(built):
     for k in range(4):
         assert np.array_equal(merged[k], full[k])
     assert merged[4] == full[4]
+
+
+def test_newton_schulz_refresh_model():
+    """The algebra behind the engine's verified refresh, in numpy: a drifted inverse X of a
+    sparse, moderately conditioned C -- what a few hundred rank-1 updates leave -- comes back to the accuracy of a
+    fresh inverse with ONE step X += X (I - C X); and the GEMM argument order the engine hands to a column-major
+    BLAS for its row-major arrays (A = R, B = X for X R; A = X, B = C for C X) computes those products."""
+    rng = np.random.default_rng(7)
+    k, ld = 200, 208
+    C = sp.random(k, k, density=0.05, random_state=3, format="csr").toarray() + np.diag(rng.uniform(1.0, 2.0, k))
+    exact = np.linalg.inv(C)
+    X = exact * (1.0 + 1.0e-8 * rng.standard_normal((k, k)))  # relative drift 1e-8 (max |I - C X| ~ 1e-7, the size measured on the GPU)
+    before = np.abs(np.eye(k) - C @ X).max()
+    R = np.eye(k) - C @ X
+    X1 = X + X @ R
+    after = np.abs(np.eye(k) - C @ X1).max()
+    fresh = np.abs(np.eye(k) - C @ exact).max()
+    # quadratic: the residual after the step is the square of the one before, down to the rounding floor of a fresh inverse
+    assert before > 5.0e-8 and after <= 10.0 * k * before * before + 50.0 * fresh and after < 1.0e-4 * before
+
+    # row-major buffers with a leading dimension, as the engine holds them
+    def rowmajor(M):
+        buf = np.zeros((k, ld))
+        buf[:, :k] = M
+        return buf
+
+    def colmajor_gemm(a_buf, b_buf):
+        # what a column-major BLAS computes from two row-major buffers passed with lda = ldb = ld and m = n = k:
+        # it sees A = a_buf^T, B = b_buf^T and returns (A B) stored column-major = (A B)^T stored row-major
+        A, B = a_buf[:, :k].T, b_buf[:, :k].T
+        return (A @ B).T
+
+    assert np.allclose(colmajor_gemm(rowmajor(R), rowmajor(X)), X @ R, rtol=0, atol=1e-13)
+    assert np.allclose(colmajor_gemm(rowmajor(X), rowmajor(C)), C @ X, rtol=0, atol=1e-12)
