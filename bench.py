@@ -333,6 +333,23 @@ def main():
                   "netlib": "Netlib-shaped variant of BASELINE.json configs[3]"}[args.workload]
     if (args.rows, args.cols) != {"dense": (5000, 5000)}.get(args.workload, (50000, 200000)):
         config_ref += ", non-default size"
+    # the kernel that takes the most time per pivot is not the one that moves the bytes: say which, and what bounds it
+    kernel_bound = {
+        "k_dual_column": ("latency", "bound-flipping ratio test: one workgroup, candidates in registers (28 B each), about 11 dependent "
+                                     "wave-wide reductions per pivot -- no byte or flop roofline applies (DESIGN section 5)"),
+        "k_price_sell": ("hbm", "row pricing; by column this is the HBM sweep the roofline object is quoted for"),
+        "k_ftran_scatter3": ("latency", "scatter of three FTRAN results + DSE weights, 16-40 B x rows"),
+        "k_fix_house": ("latency", "inverse fix-up + housekeeping, serial tail"),
+        "k_chuzr_scan": ("latency", "CHUZR scan over the infeasibility list"),
+        "k_primal_rank1": ("hbm", "rank-1 update of the nucleus inverse: 16 k^2 bytes"),
+        "k_gemv3g": ("hbm", "three FTRAN right-hand sides through the nucleus inverse: 8 k^2 bytes"),
+    }
+    dominant_by_time = None
+    if per_kernel_us:
+        top = max(per_kernel_us, key=per_kernel_us.get)
+        dominant_by_time = {"kernel": top, "us_per_pivot": per_kernel_us[top],
+                            "share_of_kernel_time": round(per_kernel_us[top] / max(sum(per_kernel_us.values()), 1e-9), 3),
+                            "bound": kernel_bound.get(top, ("latency", ""))[0], "note": kernel_bound.get(top, ("latency", "latency-bound small kernel"))[1]}
     if rank == 0:
         out = {
             "metric": "dual-simplex iterations/sec",
@@ -365,6 +382,7 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_source,
                          "moved": moved, "moved_frac": (moved / HBM_PEAK_GBS) if moved else None,
                          "per_kernel_us": per_kernel_us,
+                         "dominant_by_time": dominant_by_time,
                          "per_kernel_note": "per pivot, eager launches: kernel + the launch gap before it; hipGraph replay (the headline) has smaller gaps"},
             "cpu_baseline": cpu,
             "time_to_optimal": tto,
