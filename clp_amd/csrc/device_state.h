@@ -90,6 +90,45 @@ struct PivotRecord {  // == clpgpu_pivot_record
   double theta, alpha, dualOut, objective;
 };
 
+
+// ---- LU factorization mode (lu_kernels.hip): frozen B0 = [slack singletons | Markowitz front | dense tail]
+// plus a product-form eta file.  One gather-form level schedule per triangular sweep.
+struct LuTri {
+  int nLevels, nItems;
+  const int *levelStart;  // [nLevels+1] into the items
+  const int *tgt, *src;   // [nItems] out[tgt] = (srcv[src] - sum val * vec[idx]) / div
+  const int *entStart;    // [nItems+1]
+  const int *entIdx;
+  const double *entVal;
+  const double *div;      // [nItems]
+};
+struct LuDev {
+  int k, nF, k2, ns;   // nucleus order, front pivots, tail order, rows whose slack was basic at the refactorization
+  int kpad, tcap;      // stride of the per-right-hand-side work vectors; capacity of the eta file
+  LuTri Lf, Ub, Utf, UtT, Ltb;
+  const int *rowOfLocal;  // [k] local nucleus row -> row
+  const int *posOfCol;    // [k] local nucleus column -> basis position
+  const int *tailRow, *tailCol;  // [k2] tail slot -> local nucleus row / column
+  // U rows of the slack singletons: row i, entries (local nucleus column, value); and the same by column
+  const int *sRowIndex, *sRowStart, *sRowCol;
+  const double *sRowVal;
+  const int *sColStart, *sColRow;  // sColRow holds ROW INDICES (positions of the slacks)
+  const double *sColVal;
+  // work
+  double *wr, *xc;     // [3 * kpad] by local nucleus row / column
+  double *tcv;         // [kpad]
+  double *x0;          // [3 * m] B0 solves by position
+  double *cp;          // [m] c' of the BTRAN (zero between solves)
+  double *y;           // [m] BTRAN result by row (chain)
+  // eta file
+  double *H;           // [tcap * m] eta j at H + j*m, by position
+  double *G;           // [tcap * tcap] (I + N)^-1, row-major, lower triangular
+  int *P;              // [tcap] position of eta j
+  int *prevSame, *nextSame;  // [tcap] etas on the same position
+  int *lastOfPos;      // [m]
+  double *s, *g, *d;   // [3 * tcap], [tcap], [tcap]
+};
+
 // All device pointers of one context.  Passed by value to kernels.
 struct Dev {
   int m, n, N;
@@ -188,6 +227,8 @@ struct Dev {
   int *gjPiv;   // [64]
   double *gjL2; // [kcap * 64]  multipliers of the current outer block (two-level re-inversion)
   double *gjU2; // [64 * ld]    its pivot-row values
+  int luMode;       // 1: the factorization on the device is the LU form (lu_kernels.hip)
+  const LuDev *lu;  // its descriptor, in device memory
   Ctrl *ctrl;
   PivotRecord *log;
 };

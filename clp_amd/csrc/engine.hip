@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/clpgpu.h"
+#include "lu_front.h"
 
 using namespace clpgpu;
 
@@ -41,6 +42,22 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
       ktMark(name);                                                                                \
   } while (0)
 #define KT_MAX 32  // marks per pivot (the chain has 11-15 launches)
+
+struct clpgpu_context;
+struct LuTriHost;
+// growable device buffer of the LU factorization (sizes change from one refactorization to the next)
+struct DBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int need(clpgpu_context *ctx, size_t bytes, void *&out);
+  template <typename T> int put(clpgpu_context *ctx, const std::vector<T> &v, T *&out);
+};
+enum {
+  LB_SROW, LB_SCOL, LB_SVAL, LB_ROWOFLOCAL, LB_POSOFCOL, LB_TAILROW, LB_TAILCOL, LB_SROWINDEX, LB_SROWSTART, LB_SROWCOL, LB_SROWVAL,
+  LB_SCOLSTART, LB_SCOLROW, LB_SCOLVAL, LB_WR, LB_XC, LB_TCV, LB_X0, LB_CP, LB_Y, LB_H, LB_G, LB_P, LB_PREV, LB_NEXT, LB_S, LB_GV, LB_DV,
+  LB_LASTOFPOS, LB_TRI, LB_COUNT = LB_TRI + 35
+};
+#define LU_TCAP_MAX 2048
 
 struct clpgpu_context {
   int device = 0;
@@ -115,6 +132,25 @@ struct clpgpu_context {
   int numberThrownOut = 0;  // structurals replaced by slacks by the singular-basis repair, whole solve
   void resetFakeBounds();
   int pivots = 0, kNucleus = 0;
+  // ---- LU factorization mode (lu_front.h, lu_host.hip, lu_kernels.hip): the nucleus as a sparse
+  // Markowitz front (host, at the refactorization) + a dense tail inverted on the matrix cores, with a
+  // product-form eta file between refactorizations.  Option "factor_mode": 0 = explicit inverse of the whole
+  // nucleus (rank-1 updated), 1 = LU, -1 (default) = LU from "lu_min_k" basic structurals on (sparse LPs, one GPU).
+  int factorMode = -1, luMinK = 3072, luMaxPivots = 1000, luMinTail = 16;
+  double luStopDensity = 0.012, luThreshold = 0.1;
+  bool luActive = false, luSlotsCleared = false;
+  LuFront luF;
+  LuDev hLu = {};
+  LuDev *dLu = nullptr;
+  DBuf luBuf[LB_COUNT];
+  double luFrontSeconds = 0.0, luInvertSeconds = 0.0, luBuildSeconds = 0.0;
+  long luFactorizations = 0;
+  int luLastFront = 0, luLastTail = 0;
+  int luUploadTri(const LuTriHost &h, LuTri &d, int slot);
+  int luFtran(const double *v0, const double *v1, double *o0, double *o1);
+  int luBtran(const double *cPos, double *yRow);
+  void luLaunchBtran();
+  void luLaunchFtran(int gm, int parity);
   // ---- device
   Dev D;
   Ctrl *hCtrl = nullptr;  // pinned
@@ -269,6 +305,10 @@ struct clpgpu_context {
   int startup();
   int factorize(bool repair = false);
   int factorizeOnce();
+  int rebuildRowCopyIfNeeded();
+  int prepareWork(int k);
+  int invertWork(int k, std::vector<int> &perm, int info[4]);
+  int factorizeLu(const std::vector<int> &kcol, const std::vector<int> &rrows, const std::vector<int> &localOfRow);
   int lastSingularColumn = -1, lastSingularRow = -1;
   int ftranDevice(const double *vRow, double *xPos);
   int ftranDevice2(const double *v1Row, const double *v2Row, double *x1Pos, double *x2Pos);
@@ -300,6 +340,39 @@ struct clpgpu_context {
                double zeroTol, double dualTol, double accPivot, int *numberOut, int *outIndex, double *outValue,
                int *numberCand, int *candIndex, double *candValue, double *upperTheta);
 };
+
+int DBuf::need(clpgpu_context *ctx, size_t bytes, void *&out)
+{
+  if (bytes > cap || !p) {
+    if (p) {
+      (void)hipStreamSynchronize(ctx->stream);
+      (void)hipFree(p);
+      p = nullptr;
+    }
+    const size_t want = bytes + bytes / 4 + 256;
+    if (hipMalloc(&p, want) != hipSuccess) {
+      p = nullptr;
+      cap = 0;
+      ctx->setError("hipMalloc(%zu) failed (LU factorization)", want);
+      return -99;
+    }
+    cap = want;
+    (void)hipMemsetAsync(p, 0, want, ctx->stream);
+  }
+  out = p;
+  return 0;
+}
+template <typename T> int DBuf::put(clpgpu_context *ctx, const std::vector<T> &v, T *&out)
+{
+  void *q = nullptr;
+  int rc = need(ctx, sizeof(T) * (v.size() ? v.size() : 1), q);
+  out = (T *)q;
+  if (!rc && !v.empty())
+    rc = ctx->h2d(out, v.data(), v.size());
+  return rc;
+}
+
+#include "lu_host.hip"
 
 // ---------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------
@@ -737,6 +810,15 @@ void clpgpu_context::releaseProblem()
   for (void *p : allocations)
     (void)hipFree(p);
   allocations.clear();
+  for (DBuf &b : luBuf) {
+    if (b.p)
+      (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  dLu = nullptr;  // (was in `allocations`)
+  hLu = LuDev();
+  luActive = luSlotsCleared = false;
   if (hCtrl)
     (void)hipHostFree(hCtrl);
   hCtrl = nullptr;
@@ -1059,49 +1141,66 @@ int clpgpu_context::factorize(bool repair)
   }
 }
 
-int clpgpu_context::factorizeOnce()
+// row copy partition [basic | nonbasic]: rebuilt on the host (refactorization boundary only)
+int clpgpu_context::rebuildRowCopyIfNeeded()
 {
-  std::vector<int> kcol, rrows, localOfRow(m, -1);
-  int numberBasic = 0;
-  for (int i = 0; i < m; i++) {
-    if ((status[n + i] & 7) == ST_BASIC)
-      numberBasic++;
-    else {
-      localOfRow[i] = (int)rrows.size();
-      rrows.push_back(i);
+  int rc = 0;
+  if (rebuildRowCopy) {
+  // row copy partition [basic | nonbasic]: rebuilt on the host (refactorization boundary only)
+    {
+      std::vector<int> ccol(nnz), csrToCsc(nnz), cscToCsr(nnz), basicCount(m, 0);
+      std::vector<double> relem(nnz);
+      std::vector<int> head(rowStart.begin(), rowStart.end() - 1), tail(rowStart.begin() + 1, rowStart.end());
+      for (int j = 0; j < n; j++) {
+        bool basic = (status[j] & 7) == ST_BASIC;
+        for (int p = colStart[j]; p < colStart[j + 1]; p++) {
+          int i = row[p];
+          int q = basic ? head[i]++ : --tail[i];
+          ccol[q] = j;
+          relem[q] = elem[p];
+          csrToCsc[q] = p;
+          cscToCsr[p] = q;
+          if (basic)
+            basicCount[i]++;
+        }
+      }
+      rc |= h2d(D.ccol, ccol.data(), nnz);
+      rc |= h2d(D.relem, relem.data(), nnz);
+      rc |= h2d(D.csrToCsc, csrToCsc.data(), nnz);
+      rc |= h2d(D.cscToCsr, cscToCsr.data(), nnz);
+      rc |= h2d(D.basicCount, basicCount.data(), m);
+      rc |= sync();
     }
+  
+  rebuildRowCopy = false;
   }
-  for (int j = 0; j < n; j++)
-    if ((status[j] & 7) == ST_BASIC) {
-      kcol.push_back(j);
-      numberBasic++;
-    }
-  if (numberBasic != m || kcol.size() != rrows.size()) {
-    setError("factorize: %d basic variables for %d rows", numberBasic, m);
-    return -2;
+  return rc;
+}
+
+// the dense inversion shared by the two factorization forms: D.workW (k x k, filled by the caller after
+// prepareWork) -> D.Minv, the pivot row of every column in perm; info[0] != 0: singular at step info[0]-1
+int clpgpu_context::prepareWork(int k)
+{
+  int rc = 0;
+  std::vector<int> ident(k);
+  for (int i = 0; i < k; i++)
+    ident[i] = i;
+  rc |= h2d(D.perm, ident.data(), k);
+  int zero4[4] = { 0, 0, 0, 0 };
+  rc |= h2d(dInfo, zero4, 4);
+  size_t mat = (size_t)k * ld;
+  // (byte counts are size_t: k * ld passes 2^31 doubles' worth of bytes long before it passes INT_MAX entries)
+  if (hipMemsetAsync(D.workW, 0, mat * sizeof(double), stream) != hipSuccess ||
+      hipMemsetAsync(D.workX, 0, mat * sizeof(double), stream) != hipSuccess) {
+    setError("factorize: clearing the work matrices failed");
+    return -99;
   }
-  const int k = (int)kcol.size();
-  int rc = allocNucleus(k);
-  if (rc)
-    return rc;
-  numberRefactorizations++;
-  std::vector<int> perm(k);
-  if (k) {
-    rc |= h2d(dKcol, kcol.data(), k);
-    rc |= h2d(dLocalOfRow, localOfRow.data(), m);
-    for (int i = 0; i < k; i++)
-      perm[i] = i;
-    rc |= h2d(D.perm, perm.data(), k);
-    int zero4[4] = { 0, 0, 0, 0 };
-    rc |= h2d(dInfo, zero4, 4);
-    size_t mat = (size_t)k * ld;
-    // (byte counts are size_t: k * ld passes 2^31 doubles' worth of bytes long before it passes INT_MAX entries)
-    if (hipMemsetAsync(D.workW, 0, mat * sizeof(double), stream) != hipSuccess ||
-        hipMemsetAsync(D.workX, 0, mat * sizeof(double), stream) != hipSuccess) {
-      setError("factorize: clearing the work matrices failed");
-      return -99;
-    }
-    hipLaunchKernelGGL(k_gather_nucleus, dim3(k), dim3(64), 0, stream, D, dKcol, dLocalOfRow, k);
+  return rc;
+}
+int clpgpu_context::invertWork(int k, std::vector<int> &perm, int info[4])
+{
+  int rc = 0;
+  {
     hipLaunchKernelGGL(k_identity, dim3(cdiv(k, 256)), dim3(256), 0, stream, D, k);
     dim3 g2(cdiv(k, 256), k < 1024 ? k : 1024);
     int mode = refactorMode;
@@ -1182,8 +1281,59 @@ int clpgpu_context::factorizeOnce()
     }
     if (checkLaunches("factorize"))
       return -99;
-    int info[4];
     rc |= d2h(info, dInfo, 4);
+    if (rc)
+      return rc;
+    if (!info[0])
+      rc |= d2h(perm.data(), D.perm, k);
+  }
+  return rc;
+}
+
+int clpgpu_context::factorizeOnce()
+{
+  std::vector<int> kcol, rrows, localOfRow(m, -1);
+  int numberBasic = 0;
+  for (int i = 0; i < m; i++) {
+    if ((status[n + i] & 7) == ST_BASIC)
+      numberBasic++;
+    else {
+      localOfRow[i] = (int)rrows.size();
+      rrows.push_back(i);
+    }
+  }
+  for (int j = 0; j < n; j++)
+    if ((status[j] & 7) == ST_BASIC) {
+      kcol.push_back(j);
+      numberBasic++;
+    }
+  if (numberBasic != m || kcol.size() != rrows.size()) {
+    setError("factorize: %d basic variables for %d rows", numberBasic, m);
+    return -2;
+  }
+  const int k = (int)kcol.size();
+  numberRefactorizations++;
+  const bool wantLu = k > 0 && (factorMode == 1 || (factorMode < 0 && !wideRows && !commActive && k >= luMinK));
+  if (wantLu != luActive)
+    dropGraph();  // the chain of a pivot differs between the two forms
+  if (wantLu)
+    return factorizeLu(kcol, rrows, localOfRow);
+  luActive = false;
+  D.luMode = 0;
+  luSlotsCleared = false;
+  int rc = allocNucleus(k);
+  if (rc)
+    return rc;
+  std::vector<int> perm(k);
+  if (k) {
+    rc |= h2d(dKcol, kcol.data(), k);
+    rc |= h2d(dLocalOfRow, localOfRow.data(), m);
+    int info[4];
+    rc |= prepareWork(k);
+    if (rc)
+      return rc;
+    hipLaunchKernelGGL(k_gather_nucleus, dim3(k), dim3(64), 0, stream, D, dKcol, dLocalOfRow, k);
+    rc = invertWork(k, perm, info);
     if (rc)
       return rc;
     if (info[0]) {
@@ -1192,7 +1342,6 @@ int clpgpu_context::factorizeOnce()
       lastSingularRow = (info[2] >= 0 && info[2] < k) ? rrows[info[2]] : -1;
       return -1;
     }
-    rc |= d2h(perm.data(), D.perm, k);
   }
   // bookkeeping arrays
   std::vector<int> posOfSlack(m, -1), slotOfRow(m, -1), slotOfCol(n, -1), slotRow(k), slotCol(k), slotPos(k);
@@ -1219,35 +1368,7 @@ int clpgpu_context::factorizeOnce()
     rc |= h2d(D.slotPos, slotPos.data(), k);
   }
   rc |= h2d(D.pivotVariable, pivotVariable.data(), m);
-  if (rebuildRowCopy) {
-  // row copy partition [basic | nonbasic]: rebuilt on the host (refactorization boundary only)
-    {
-      std::vector<int> ccol(nnz), csrToCsc(nnz), cscToCsr(nnz), basicCount(m, 0);
-      std::vector<double> relem(nnz);
-      std::vector<int> head(rowStart.begin(), rowStart.end() - 1), tail(rowStart.begin() + 1, rowStart.end());
-      for (int j = 0; j < n; j++) {
-        bool basic = slotOfCol[j] >= 0;
-        for (int p = colStart[j]; p < colStart[j + 1]; p++) {
-          int i = row[p];
-          int q = basic ? head[i]++ : --tail[i];
-          ccol[q] = j;
-          relem[q] = elem[p];
-          csrToCsc[q] = p;
-          cscToCsr[p] = q;
-          if (basic)
-            basicCount[i]++;
-        }
-      }
-      rc |= h2d(D.ccol, ccol.data(), nnz);
-      rc |= h2d(D.relem, relem.data(), nnz);
-      rc |= h2d(D.csrToCsc, csrToCsc.data(), nnz);
-      rc |= h2d(D.cscToCsr, cscToCsr.data(), nnz);
-      rc |= h2d(D.basicCount, basicCount.data(), m);
-      rc |= sync();
-    }
-  
-  rebuildRowCopy = false;
-  }
+  rc |= rebuildRowCopyIfNeeded();
   // the slots were renumbered: the basic entries of the row copy carry their column's slot
   hipLaunchKernelGGL(k_cslot_rebuild, dim3(cdiv(m, 256)), dim3(256), 0, stream, D);
   kNucleus = k;
@@ -1261,6 +1382,8 @@ int clpgpu_context::factorizeOnce()
 // generic dense solves (used at refactorization boundaries and by the C-ABI plug-in calls)
 int clpgpu_context::ftranDevice(const double *vRow, double *xPos)
 {
+  if (luActive)
+    return luFtran(vRow, nullptr, xPos, nullptr);
   const int k = hCtrl->k;
   if (k) {
     hipLaunchKernelGGL(k_ftran_gather, dim3(cdiv(k, 256)), dim3(256), 0, stream, D, vRow, (const double *)nullptr, D.slotA,
@@ -1274,6 +1397,8 @@ int clpgpu_context::ftranDevice(const double *vRow, double *xPos)
 }
 int clpgpu_context::btranDevice(const double *cPos, double *yRow)
 {
+  if (luActive)
+    return luBtran(cPos, yRow);
   const int k = hCtrl->k;
   hipLaunchKernelGGL(k_btran_slack, dim3(cdiv(m, 256)), dim3(256), 0, stream, D, cPos, yRow, 0);
   if (k) {
@@ -1288,6 +1413,8 @@ int clpgpu_context::btranDevice(const double *cPos, double *yRow)
 // two right-hand sides in one sweep (updateTwoColumnsFT, src/ClpFactorization.cpp:2889)
 int clpgpu_context::ftranDevice2(const double *v1Row, const double *v2Row, double *x1Pos, double *x2Pos)
 {
+  if (luActive)
+    return luFtran(v1Row, v2Row, x1Pos, x2Pos);
   const int k = hCtrl->k;
   if (k) {
     hipLaunchKernelGGL(k_ftran_gather, dim3(cdiv(k, 256)), dim3(256), 0, stream, D, v1Row, v2Row, D.slotA, D.slotB, 0);
@@ -1846,7 +1973,7 @@ int clpgpu_context::startup()
 // see the members: keep the inverse at a scheduled refactorization?
 bool clpgpu_context::refreshEligible()
 {
-  if (refreshMinK <= 0 || !blockedRefactor || rebuildRowCopy || forceFactorization == 1 || !hCtrl)
+  if (refreshMinK <= 0 || !blockedRefactor || rebuildRowCopy || forceFactorization == 1 || !hCtrl || luActive)
     return false;
   const int k = hCtrl->k;
   // (long rows: the re-inversion is a larger share of a pivot's cost already at a few thousand, and both halves
@@ -2247,6 +2374,8 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   }
   // BTRAN (reads Minv: the previous pivot's basis-update branch must have finished)
   joinUpdateBranch();
+  if (luActive)
+    luLaunchBtran();
   if (wideRows)
     KL("k_gemvT_partial2", k_gemvT_partial2, dim3(cdiv(kc, 256), cdiv(kc, 64)), dim3(256), 0, stream, D, (const double *)D.slotA, 1);
   // (not column-sharded: the candidate counts come from this kernel and the pricing kernel, there
@@ -2329,15 +2458,23 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
     KL("k_flip_dense", k_flip_dense, dim3(gm), dim3(256), 0, stream, D);
   // one FTRAN sweep for the entering column, rho (DSE) and the flip rhs; the back end also applies
   // the flip part of the primal update
-  KL("k_gemv3g", k_gemv3g, dim3(cdiv(kc, GEMV_RPB)), dim3(1024), 0, stream, D);
-  if (wideRows)
-    KL("k_slack_dots", k_slack_dots, dim3(cdiv(m, 4)), dim3(256), 0, stream, D);
-  KL("k_ftran_scatter3", k_ftran_scatter3, dim3(cdiv(m + kc, 256)), dim3(256), 0, stream, D, gm, parity, wideRows ? 1 : 0);
+  if (luActive) {
+    luLaunchFtran(gm, parity);
+  } else {
+    KL("k_gemv3g", k_gemv3g, dim3(cdiv(kc, GEMV_RPB)), dim3(1024), 0, stream, D);
+    if (wideRows)
+      KL("k_slack_dots", k_slack_dots, dim3(cdiv(m, 4)), dim3(256), 0, stream, D);
+    KL("k_ftran_scatter3", k_ftran_scatter3, dim3(cdiv(m + kc, 256)), dim3(256), 0, stream, D, gm, parity, wideRows ? 1 : 0);
+  }
   // basis update of the nucleus inverse: needs only what the FTRAN tail left (w and rho by slot, the
   // update scalars), nothing downstream needs Minv before the next BTRAN -> its own branch
   {
     const int gx = cdiv(kc, 256), gy = kc < 512 ? kc : 512;
-    if (forkUpdate && stream2) {
+    if (luActive) {
+      // primal update as usual; the basis update is one more eta (column of H, row of G)
+      KL("k_primal_update", k_primal_update, dim3(gm), dim3(256), 0, stream, D, 0);
+      KL("k_lu_pf_append", k_lu_pf_append, dim3(gm + cdiv(hLu.tcap, 64)), dim3(256), 0, stream, D, 1, gm);
+    } else if (forkUpdate && stream2) {
       (void)hipEventRecord(evFork, stream);
       (void)hipStreamWaitEvent(stream2, evFork, 0);
       KL("k_rank1", k_rank1, dim3(gx, gy), dim3(256), 0, stream2, D, parity);
@@ -2358,7 +2495,7 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
     KL("k_house_col", k_house_col, dim3(cdiv(maxColumnLength, 256)), dim3(256), 0, stream, D, 0);
     KL("k_house_col", k_house_col, dim3(cdiv(maxColumnLength, 256)), dim3(256), 0, stream, D, 1);
   }
-  KL("k_fix_house", k_fix_house, dim3(2 + gm), dim3(256), 0, stream, D, parity, (forkUpdate && stream2) ? 0 : 1, wideRows ? 1 : 0);
+  KL("k_fix_house", k_fix_house, dim3(2 + gm), dim3(256), 0, stream, D, parity, ((forkUpdate && stream2) || luActive) ? 0 : 1, wideRows ? 1 : 0);
   return 0;
 }
 
@@ -2463,7 +2600,7 @@ int clpgpu_context::whileIterating(int stepTarget)
   hCtrl->forceFactorization = forceFactorization;
   hCtrl->numberChanged = numberChanged;
   hCtrl->lastBadIteration = lastBadIteration;
-  hCtrl->maximumPivots = maximumPivots;
+  hCtrl->maximumPivots = luActive ? std::min(luMaxPivots, hLu.tcap - 1) : maximumPivots;
   hCtrl->maximumIterations = maximumIterations;
   int rc = pushCtrl();
   if (timing && evStart.empty()) {
@@ -3032,8 +3169,57 @@ int clpgpu_replace_column(clpgpu_context *ctx, int pivotRow, int sequenceIn, dou
   (void)acceptablePivot;
   const int m = ctx->m, n = ctx->n;
   Ctrl *h = ctx->hCtrl;
-  if (h->pivots >= ctx->maximumPivots)
+  if (h->pivots >= (ctx->luActive ? std::min(ctx->luMaxPivots, ctx->hLu.tcap - 1) : ctx->maximumPivots))
     return 5;
+  if (ctx->luActive) {
+    // LU mode: w = B^-1 a_q through the factorization and the eta file, then one more eta
+    std::vector<double> v(m, 0.0);
+    if (sequenceIn >= n)
+      v[sequenceIn - n] = -1.0;
+    else
+      for (int p = ctx->colStart[sequenceIn]; p < ctx->colStart[sequenceIn + 1]; p++)
+        v[ctx->row[p]] = ctx->elem[p];
+    Dev &D = ctx->D;
+    hipStream_t s = ctx->stream;
+    const int gm = cdiv(m, 256);
+    int rc = ctx->h2d(D.vecV1, v.data(), m);
+    ctx->luFtran(D.vecV1, nullptr, D.w, nullptr);
+    double alpha = 0.0;
+    rc |= ctx->d2h(&alpha, D.w + pivotRow, 1);
+    if (rc)
+      return rc;
+    if (fabs(alpha) < ctx->zeroTolerance) {
+      hipLaunchKernelGGL(k_zero, dim3(gm), dim3(256), 0, s, D.vecV1, m);
+      ctx->sync();
+      return 2;
+    }
+    rc |= ctx->pullCtrl();
+    h->state = RUN;
+    h->pivotRow = pivotRow;
+    h->sequenceIn = sequenceIn;
+    h->sequenceOut = ctx->pivotVariable[pivotRow];
+    h->directionOut = 1;
+    h->alpha = alpha;
+    h->theta = 0.0;
+    h->dualOut = 0.0;
+    h->directionIn = 1;
+    h->lowerIn = h->upperIn = h->valueIn = 0.0;
+    h->lowerOut = h->upperOut = 0.0;
+    h->objectiveChange = 0.0;
+    h->maximumIterations = 2147483647;
+    h->maximumPivots = LU_TCAP_MAX;
+    h->logCapacity = 0;
+    rc |= ctx->pushCtrl();
+    hipLaunchKernelGGL(k_lu_pf_append, dim3(gm + cdiv(ctx->hLu.tcap, 64)), dim3(256), 0, s, D, 0, gm);
+    hipLaunchKernelGGL(k_house, dim3(1), dim3(256), 0, s, D);
+    rc |= ctx->pullCtrl();
+    rc |= ctx->d2h(ctx->pivotVariable.data(), D.pivotVariable, m);
+    hipLaunchKernelGGL(k_zero, dim3(gm), dim3(256), 0, s, D.w, m);
+    rc |= ctx->checkLaunches("clpgpu_replace_column");
+    rc |= ctx->sync();
+    ctx->pivots = h->pivots;
+    return rc ? rc : 0;
+  }
   if (h->k + 2 >= ctx->kcap)
     return 3;
   // stage the two solves through the same kernels the iteration uses
@@ -3374,6 +3560,12 @@ clpgpu_context *clpgpu_clone(const clpgpu_context *src)
   ctx->flipScatter = src->flipScatter;
   ctx->flipSlotCap = src->flipSlotCap;
   ctx->refreshMinK = src->refreshMinK;
+  ctx->factorMode = src->factorMode;
+  ctx->luMinK = src->luMinK;
+  ctx->luMaxPivots = src->luMaxPivots;
+  ctx->luStopDensity = src->luStopDensity;
+  ctx->luMinTail = src->luMinTail;
+  ctx->luThreshold = src->luThreshold;
   ctx->refreshMax = src->refreshMax;
   ctx->refreshTolerance = src->refreshTolerance;
   ctx->refreshRefine = src->refreshRefine;
@@ -3560,6 +3752,12 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
     ctx->commMode = (int)v == 1 ? 1 : 2;
   }
   else if (!strcmp(name, "refactor_min_k")) ctx->refactorMinK = (int)v;
+  else if (!strcmp(name, "factor_mode")) ctx->factorMode = (int)v;
+  else if (!strcmp(name, "lu_min_k")) ctx->luMinK = (int)v;
+  else if (!strcmp(name, "lu_max_pivots")) ctx->luMaxPivots = std::max(1, std::min((int)v, LU_TCAP_MAX - 1));
+  else if (!strcmp(name, "lu_stop_density")) ctx->luStopDensity = v;
+  else if (!strcmp(name, "lu_min_tail")) ctx->luMinTail = std::max(0, (int)v);
+  else if (!strcmp(name, "lu_threshold")) ctx->luThreshold = v;
   else if (!strcmp(name, "fork_update")) { ctx->forkUpdate = (int)v; ctx->dropGraph(); }
   else if (!strcmp(name, "refresh_min_k")) ctx->refreshMinK = (int)v;
   else if (!strcmp(name, "refresh_min_k_dense")) ctx->refreshMinKDense = (int)v;
@@ -3953,7 +4151,15 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
   stats->total_ms = ctx->seconds * 1.0e3;
   stats->iterations = ctx->numberIterations;
   stats->refactorizations = ctx->numberRefactorizations;
-  stats->nucleus = ctx->hCtrl->k;
+  stats->nucleus = ctx->luActive ? ctx->hLu.k : ctx->hCtrl->k;
+  stats->lu_active = ctx->luActive ? 1 : 0;
+  stats->lu_front = ctx->luActive ? ctx->hLu.nF : 0;
+  stats->lu_tail = ctx->luActive ? ctx->hLu.k2 : 0;
+  stats->lu_factorizations = ctx->luFactorizations;
+  stats->lu_front_ms = ctx->luFrontSeconds * 1.0e3;
+  stats->lu_invert_ms = ctx->luInvertSeconds * 1.0e3;
+  stats->lu_build_ms = ctx->luBuildSeconds * 1.0e3;
+  stats->eta_count = ctx->hCtrl->pivots;
   stats->nucleus_capacity = ctx->kcap;
   stats->refreshes = ctx->numberRefreshes;
   stats->refreshes_rejected = ctx->numberRefreshesRejected;

@@ -1730,7 +1730,7 @@ __global__ void __launch_bounds__(256) k_house_col(Dev D, int which)
   } else {
     const int b = D.rowStart[r] + D.basicCount[r];
     rowCopySwap(D, e, b);
-    D.cslot[b] = enteringSlot(c);
+    D.cslot[b] = D.luMode ? -1 : enteringSlot(c);
     D.basicCount[r] += 1;
   }
 }
@@ -1759,13 +1759,13 @@ __device__ void houseBody(Dev D, int skipColumns = 0)
       int e = D.cscToCsr[p];
       int b = D.rowStart[r] + D.basicCount[r];
       rowCopySwap(D, e, b);
-      D.cslot[b] = enteringSlot(c);
+      D.cslot[b] = D.luMode ? -1 : enteringSlot(c);
       D.basicCount[r] += 1;
     }
   }
   // ---- a structural leaves and the last col-slot moves into its place (case 2): the entries of that
   // column carry their column's slot in the row copy
-  if (c->updateCase == 2 && c->slotColOut != c->k - 1) {
+  if (!D.luMode && c->updateCase == 2 && c->slotColOut != c->k - 1) {
     const int colLast = D.slotCol[c->k - 1], a = c->slotColOut;
     for (int p = D.colStart[colLast] + tid; p < D.colStart[colLast + 1]; p += blockDim.x)
       D.cslot[D.cscToCsr[p]] = a;
@@ -1783,8 +1783,10 @@ __device__ void houseBody(Dev D, int skipColumns = 0)
   D.vecC[pivotRow] = 0.0;
   // ---- nucleus bookkeeping
   int k = c->k;
-  const int ucase = c->updateCase;
-  if (ucase == 0) {
+  const int ucase = D.luMode ? -1 : c->updateCase;
+  if (ucase < 0) {
+    // LU mode: the factorization's maps are frozen until the next refactorization
+  } else if (ucase == 0) {
     int a = c->slotColOut;
     D.slotOfCol[seqOut] = -1;
     D.slotOfCol[seqIn] = a;
@@ -1988,7 +1990,7 @@ __device__ void houseBody(Dev D, int skipColumns = 0)
     if (numberPivots >= random * maxNumber)
       c->state = EXIT_REFACTOR;
   }
-  if (c->state == RUN && c->k + 2 >= c->kcap)
+  if (c->state == RUN && !D.luMode && c->k + 2 >= c->kcap)
     c->state = EXIT_REFACTOR;  // nucleus storage nearly full: host regrows it at the refactorization
 }
 
@@ -2185,8 +2187,10 @@ __global__ void __launch_bounds__(256) k_rho_finish3(Dev D, int wide = 0, int nb
   double sq = 0.0;
   if (i < D.m) {
     double v;
-    int sr = D.slotOfRow[i];
-    if (sr >= 0) {
+    int sr = D.luMode ? -2 : D.slotOfRow[i];
+    if (sr == -2) {
+      v = D.lu->y[i];  // LU mode: the BTRAN result by row (k_lu_bt_gather / k_lu_bt_back)
+    } else if (sr >= 0) {
       // y_R = Minv^T t with t given as a short list: read only those rows of Minv
       const int tc = c->tCount;
       v = 0.0;
@@ -3290,8 +3294,8 @@ template <bool COHERENT> __device__ inline void chuzrFinalBody(const Dev &D, int
     }
   }
   __syncthreads();
-  if (!s_ok)
-    return;
+  if (!s_ok || D.luMode)
+    return;  // (LU mode: the BTRAN is the k_lu_* chain)
   // BTRAN t-vector for dir*e_p (t = c_K - A_SK^T y_S with c = dir*e_p, y_S = -c_S), kept as a short list: t has one nonzero when a
   // structural leaves, and one per basic entry of the leaving slack's row otherwise
   const double dir = (double)c->directionOut;
@@ -3463,6 +3467,8 @@ __device__ inline void scanTailBody(const Dev &D, int nbCount, int nbSum, int wh
     }
     if (c->theta < 0.0)
       c->theta = 0.0;
+    if (D.luMode)
+      return;  // (the eta file needs only w, alpha and the pivot row)
     int seqIn = c->sequenceIn, seqOut = c->sequenceOut;
     int inStruct = seqIn < D.n, outStruct = seqOut < D.n;
     c->updateCase = outStruct ? (inStruct ? 0 : 2) : (inStruct ? 1 : 3);
@@ -4386,74 +4392,11 @@ __global__ void __launch_bounds__(256) k_slack_dots(Dev D)
   }
 }
 
-__global__ void __launch_bounds__(256) k_ftran_scatter3(Dev D, int nbNorm, int parity, int wide = 0)
+// back end shared by the two forms of the FTRAN scatter: DSE weights, flip part of the primal update,
+// hand-over to the serial tail
+__device__ inline void ftranScatterTail(const Dev &D, const Ctrl *c, int p, double x1, double x2, double x3, bool doFlip, double tolerance,
+                                        int nbNorm, int parity, double *shd)
 {
-  const Ctrl *c = D.ctrl;
-  if (c->state != RUN)
-    return;
-  __shared__ double shd[16];
-  const int k = c->k;
-  const bool doFlip = c->numberFlips != 0;
-  const double tolerance = c->primalTolerance;
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  int p = -1;
-  double x1 = 0.0, x2 = 0.0, x3 = 0.0;
-  if (t < D.m) {
-    p = D.posOfSlack[t];
-    if (p >= 0) {
-      double a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      int s = D.rowStart[t], e = s + D.basicCount[t];
-      const double v1t = D.vecV1[t], rhot = D.rho[t], flipt = doFlip ? D.flipRhs[t] : 0.0;
-      // four entries per trip: column, then slot, then the three slot values are each requested
-      // together (the chain is three dependent loads deep); the adds stay in entry order
-      if (wide) {
-        a1 = D.rowDot[3 * (size_t)t];
-        a2 = D.rowDot[3 * (size_t)t + 1];
-        a3 = D.rowDot[3 * (size_t)t + 2];
-        e = s;
-      }
-      for (int q = s; q < e; q += 4) {
-        int cc[4], sc[4];
-        double a[4], c1[4], c2[4], c3[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          cc[u] = (q + u < e) ? 0 : -1;
-          sc[u] = (q + u < e) ? D.cslot[q + u] : 0;  // col-slot kept with the entry (rowCopySwap, houseBody)
-          a[u] = (q + u < e) ? D.relem[q + u] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          c1[u] = D.slotC[sc[u]];
-          c2[u] = D.slotD[sc[u]];
-          c3[u] = doFlip ? D.slotE[sc[u]] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          if (cc[u] >= 0) {
-            a1 += a[u] * c1[u];
-            a2 += a[u] * c2[u];
-            if (doFlip)
-              a3 += a[u] * c3[u];
-          }
-        }
-      }
-      x1 = a1 - v1t;
-      x2 = a2 - rhot;
-      if (doFlip)
-        x3 = a3 - flipt;
-    }
-    if (doFlip)
-      D.flipRhs[t] = 0.0;  // consumed (nucleus rows were read by k_gemv3g)
-  } else if (t < D.m + k) {
-    int sc = t - D.m;
-    p = D.slotPos[sc];
-    x1 = D.slotC[sc];
-    x2 = D.slotD[sc];
-    x3 = D.slotE[sc];
-    D.slotV1[sc] = 0.0;  // right-hand sides by slot: consumed by k_gemv3g
-    if (doFlip)
-      D.flipSlot[sc] = 0.0;
-  }
   // DSE norm for the weight update (ClpDualRowSteepest::updateWeights :516-538): sum of the
   // per-block partials of sum rho^2; alpha is still the ratio-test alpha here
   double norm = 0.0, multiplier = 0.0;
@@ -4532,6 +4475,78 @@ __global__ void __launch_bounds__(256) k_ftran_scatter3(Dev D, int nbNorm, int p
   // alpha test and the scalar set-up of the basis update
   if (lastBlockDone(D.ctrl, 1))
     scanTailBody(D, nbNorm, gridDim.x, 1, 1, parity);
+}
+
+
+__global__ void __launch_bounds__(256) k_ftran_scatter3(Dev D, int nbNorm, int parity, int wide = 0)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  __shared__ double shd[16];
+  const int k = c->k;
+  const bool doFlip = c->numberFlips != 0;
+  const double tolerance = c->primalTolerance;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int p = -1;
+  double x1 = 0.0, x2 = 0.0, x3 = 0.0;
+  if (t < D.m) {
+    p = D.posOfSlack[t];
+    if (p >= 0) {
+      double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      int s = D.rowStart[t], e = s + D.basicCount[t];
+      const double v1t = D.vecV1[t], rhot = D.rho[t], flipt = doFlip ? D.flipRhs[t] : 0.0;
+      // four entries per trip: column, then slot, then the three slot values are each requested
+      // together (the chain is three dependent loads deep); the adds stay in entry order
+      if (wide) {
+        a1 = D.rowDot[3 * (size_t)t];
+        a2 = D.rowDot[3 * (size_t)t + 1];
+        a3 = D.rowDot[3 * (size_t)t + 2];
+        e = s;
+      }
+      for (int q = s; q < e; q += 4) {
+        int cc[4], sc[4];
+        double a[4], c1[4], c2[4], c3[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          cc[u] = (q + u < e) ? 0 : -1;
+          sc[u] = (q + u < e) ? D.cslot[q + u] : 0;  // col-slot kept with the entry (rowCopySwap, houseBody)
+          a[u] = (q + u < e) ? D.relem[q + u] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          c1[u] = D.slotC[sc[u]];
+          c2[u] = D.slotD[sc[u]];
+          c3[u] = doFlip ? D.slotE[sc[u]] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (cc[u] >= 0) {
+            a1 += a[u] * c1[u];
+            a2 += a[u] * c2[u];
+            if (doFlip)
+              a3 += a[u] * c3[u];
+          }
+        }
+      }
+      x1 = a1 - v1t;
+      x2 = a2 - rhot;
+      if (doFlip)
+        x3 = a3 - flipt;
+    }
+    if (doFlip)
+      D.flipRhs[t] = 0.0;  // consumed (nucleus rows were read by k_gemv3g)
+  } else if (t < D.m + k) {
+    int sc = t - D.m;
+    p = D.slotPos[sc];
+    x1 = D.slotC[sc];
+    x2 = D.slotD[sc];
+    x3 = D.slotE[sc];
+    D.slotV1[sc] = 0.0;  // right-hand sides by slot: consumed by k_gemv3g
+    if (doFlip)
+      D.flipSlot[sc] = 0.0;
+  }
+  ftranScatterTail(D, c, p, x1, x2, x3, doFlip, tolerance, nbNorm, parity, shd);
 }
 
 __global__ void k_zero(double *p, int n)
@@ -5516,3 +5531,4 @@ __global__ void k_infeas_finish(Dev D)
   D.ctrl->numberAppend = 0;
 }
 }  // namespace clpgpu
+#include "lu_kernels.hip"

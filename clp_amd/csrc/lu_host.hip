@@ -1,0 +1,505 @@
+// lu_host.hip -- host side of the LU factorization mode (included by engine.hip after clpgpu_context):
+// builds B0 = [slack singletons | Markowitz front | dense tail] at a refactorization boundary and drives the
+// generic (non-chain) solves.  See lu_front.h (host Markowitz) and lu_kernels.hip (device sweeps, eta file).
+//
+// ClpFactorization::factorize (src/ClpFactorization.cpp:1649) -> CoinAbcBaseFactorization::factor
+// (src/CoinAbcBaseFactorization1.cpp:372: preProcess, factorSparse, factorDense, cleanup/permute).
+
+// one gather-form level schedule, flattened for the device
+struct LuTriHost {
+  std::vector<int> levelStart, tgt, src, entStart, entIdx;
+  std::vector<double> entVal, div;
+  // items given unordered: item i has level lev[i], entries [es[i], es[i+1]) of (idx, val)
+  void build(int nItems, const std::vector<int> &lev, const std::vector<int> &tg, const std::vector<int> &sr, const std::vector<double> &dv,
+             const std::vector<int> &es, const std::vector<int> &ei, const std::vector<double> &ev)
+  {
+    int nLev = 0;
+    for (int i = 0; i < nItems; i++)
+      nLev = std::max(nLev, lev[i] + 1);
+    levelStart.assign(nLev + 1, 0);
+    for (int i = 0; i < nItems; i++)
+      levelStart[lev[i] + 1]++;
+    for (int l = 0; l < nLev; l++)
+      levelStart[l + 1] += levelStart[l];
+    std::vector<int> at(levelStart.begin(), levelStart.end() - 1), order(nItems);
+    for (int i = 0; i < nItems; i++)
+      order[at[lev[i]]++] = i;
+    tgt.resize(nItems);
+    src.resize(nItems);
+    div.resize(nItems);
+    entStart.assign(nItems + 1, 0);
+    entIdx.clear();
+    entVal.clear();
+    entIdx.reserve(ei.size());
+    entVal.reserve(ev.size());
+    for (int o = 0; o < nItems; o++) {
+      const int i = order[o];
+      tgt[o] = tg[i];
+      src[o] = sr[i];
+      div[o] = dv[i];
+      for (int e = es[i]; e < es[i + 1]; e++) {
+        entIdx.push_back(ei[e]);
+        entVal.push_back(ev[e]);
+      }
+      entStart[o + 1] = (int)entIdx.size();
+    }
+  }
+};
+
+int clpgpu_context::luUploadTri(const LuTriHost &h, LuTri &d, int slot)
+{
+  const int nItems = (int)h.tgt.size();
+  int rc = 0;
+  d.nLevels = (int)h.levelStart.size() - 1;
+  d.nItems = nItems;
+  int *ip = nullptr;
+  double *dp = nullptr;
+  rc |= luBuf[slot + 0].put(this, h.levelStart, ip);
+  d.levelStart = ip;
+  rc |= luBuf[slot + 1].put(this, h.tgt, ip);
+  d.tgt = ip;
+  rc |= luBuf[slot + 2].put(this, h.src, ip);
+  d.src = ip;
+  rc |= luBuf[slot + 3].put(this, h.entStart, ip);
+  d.entStart = ip;
+  rc |= luBuf[slot + 4].put(this, h.entIdx, ip);
+  d.entIdx = ip;
+  rc |= luBuf[slot + 5].put(this, h.entVal, dp);
+  d.entVal = dp;
+  rc |= luBuf[slot + 6].put(this, h.div, dp);
+  d.div = dp;
+  return rc;
+}
+
+int clpgpu_context::factorizeLu(const std::vector<int> &kcol, const std::vector<int> &rrows, const std::vector<int> &localOfRow)
+{
+  const int k = (int)kcol.size();
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = 0;
+  // ---- the nucleus C = A[R, K] by columns, local rows
+  std::vector<int> cStart(k + 1, 0), cRow;
+  std::vector<double> cVal;
+  // ... and the frozen slack part: entries of the basic structurals in rows whose slack is basic
+  std::vector<int> sColStart(k + 1, 0), sColRow;
+  std::vector<double> sColVal;
+  for (int c = 0; c < k; c++) {
+    const int j = kcol[c];
+    for (int p = colStart[j]; p < colStart[j + 1]; p++) {
+      const int lr = localOfRow[row[p]];
+      if (lr >= 0) {
+        cRow.push_back(lr);
+        cVal.push_back(elem[p]);
+      } else {
+        sColRow.push_back(row[p]);
+        sColVal.push_back(elem[p]);
+      }
+    }
+    cStart[c + 1] = (int)cRow.size();
+    sColStart[c + 1] = (int)sColRow.size();
+  }
+  // ---- Markowitz front on the host (skipped outright when the nucleus is dense already)
+  LuFront &F = luF;
+  const double nnzC = (double)cRow.size();
+  if (luStopDensity > 0.0 && nnzC <= luStopDensity * (double)k * (double)k) {
+    luFrontFactor(k, cStart.data(), cRow.data(), cVal.data(), luStopDensity, luMinTail, luThreshold, 1.0e-11, F);
+  } else {
+    F = LuFront();
+    F.k = k;
+    F.k2 = k;
+    F.lStart.assign(1, 0);
+    F.uStart.assign(1, 0);
+    F.tailRow.resize(k);
+    F.tailCol.resize(k);
+    for (int i = 0; i < k; i++)
+      F.tailRow[i] = F.tailCol[i] = i;
+    for (int c = 0; c < k; c++)
+      for (int p = cStart[c]; p < cStart[c + 1]; p++) {
+        F.sRow.push_back(cRow[p]);
+        F.sCol.push_back(c);
+        F.sVal.push_back(cVal[p]);
+      }
+  }
+  const int nF = F.nF, k2 = F.k2;
+  const auto t1 = std::chrono::steady_clock::now();
+  // ---- dense tail: S -> S^-1 on the device (MFMA re-inversion)
+  rc = allocNucleus(k2);
+  if (rc)
+    return rc;
+  std::vector<int> perm(k2);
+  if (k2) {
+    int info[4];
+    rc |= prepareWork(k2);
+    int *dSRow = nullptr, *dSCol = nullptr;
+    double *dSVal = nullptr;
+    rc |= luBuf[LB_SROW].put(this, F.sRow, dSRow);
+    rc |= luBuf[LB_SCOL].put(this, F.sCol, dSCol);
+    rc |= luBuf[LB_SVAL].put(this, F.sVal, dSVal);
+    if (rc)
+      return rc;
+    const int snz = (int)F.sVal.size();
+    if (snz)
+      hipLaunchKernelGGL(k_lu_scatter_tail, dim3(cdiv(snz, 256)), dim3(256), 0, stream, D, (const int *)dSRow, (const int *)dSCol,
+                         (const double *)dSVal, snz);
+    rc = invertWork(k2, perm, info);
+    if (rc)
+      return rc;
+    if (info[0]) {
+      setError("factorize: singular tail at step %d of %d (nucleus %d, front %d)", info[0] - 1, k2, k, nF);
+      lastSingularColumn = kcol[F.tailCol[info[0] - 1]];
+      lastSingularRow = (info[2] >= 0 && info[2] < k2) ? rrows[F.tailRow[info[2]]] : -1;
+      return -1;
+    }
+  }
+  const auto t2 = std::chrono::steady_clock::now();
+  // ---- positions: front pivot f puts column fcol[f] at the position of row frow[f]; the tail as the
+  // dense pivoting decided
+  std::vector<int> posOfCol(k), rowOfLocal(rrows);
+  for (int f = 0; f < nF; f++)
+    posOfCol[F.fcol[f]] = rrows[F.frow[f]];
+  for (int tc = 0; tc < k2; tc++)
+    posOfCol[F.tailCol[tc]] = rrows[F.tailRow[perm[tc]]];
+  for (int i = 0; i < m; i++)
+    if (localOfRow[i] < 0)
+      pivotVariable[i] = n + i;
+  for (int c = 0; c < k; c++)
+    pivotVariable[posOfCol[c]] = kcol[c];
+  // ---- the four triangular sweeps in gather form, with level sets
+  std::vector<int> pivOfRow(k, -1), pivOfCol(k, -1);
+  for (int f = 0; f < nF; f++) {
+    pivOfRow[F.frow[f]] = f;
+    pivOfCol[F.fcol[f]] = f;
+  }
+  LuTriHost Lf, Ub, Utf, UtT, Ltb;
+  {
+    // L forward: row lr gathers the multipliers the earlier pivots left on it
+    std::vector<int> cnt(k + 1, 0);
+    for (int e = 0; e < (int)F.lRow.size(); e++)
+      cnt[F.lRow[e] + 1]++;
+    for (int i = 0; i < k; i++)
+      cnt[i + 1] += cnt[i];
+    std::vector<int> ei(F.lRow.size()), at(cnt.begin(), cnt.end() - 1), lev(k, 0);
+    std::vector<double> ev(F.lRow.size());
+    for (int f = 0; f < nF; f++) {
+      const int lvf = lev[F.frow[f]];  // final: every entry of the pivot row comes from an earlier pivot
+      for (int e = F.lStart[f]; e < F.lStart[f + 1]; e++) {
+        const int lr = F.lRow[e];
+        ei[at[lr]] = F.frow[f];
+        ev[at[lr]] = F.lVal[e];
+        at[lr]++;
+        lev[lr] = std::max(lev[lr], lvf + 1);
+      }
+    }
+    std::vector<int> items, il, es(1, 0), ci;
+    std::vector<double> cv, dv;
+    for (int lr = 0; lr < k; lr++)
+      if (cnt[lr + 1] > cnt[lr]) {
+        items.push_back(lr);
+        il.push_back(lev[lr] - 1);
+        for (int e = cnt[lr]; e < cnt[lr + 1]; e++) {
+          ci.push_back(ei[e]);
+          cv.push_back(ev[e]);
+        }
+        es.push_back((int)ci.size());
+        dv.push_back(1.0);
+      }
+    Lf.build((int)items.size(), il, items, items, dv, es, ci, cv);
+  }
+  {
+    // U backward: pivot f gathers its row (columns pivoted later or in the tail)
+    std::vector<int> lev(nF, 0), tg(nF), sr(nF);
+    std::vector<double> dv(nF);
+    for (int f = nF - 1; f >= 0; f--) {
+      int l = 0;
+      for (int e = F.uStart[f]; e < F.uStart[f + 1]; e++) {
+        const int f2 = pivOfCol[F.uCol[e]];
+        if (f2 >= 0)
+          l = std::max(l, lev[f2] + 1);
+      }
+      lev[f] = l;
+      tg[f] = F.fcol[f];
+      sr[f] = F.frow[f];
+      dv[f] = F.fpiv[f];
+    }
+    Ub.build(nF, lev, tg, sr, dv, F.uStart, F.uCol, F.uVal);
+  }
+  {
+    // U^T forward: column of pivot f2 gathers from the earlier pivot rows that hold an entry in it;
+    // tail columns likewise, in one final level
+    std::vector<int> cntF(nF + 1, 0), cntT(k2 + 1, 0), tailSlotOfCol(k, -1);
+    for (int tc = 0; tc < k2; tc++)
+      tailSlotOfCol[F.tailCol[tc]] = tc;
+    for (int f = 0; f < nF; f++)
+      for (int e = F.uStart[f]; e < F.uStart[f + 1]; e++) {
+        const int f2 = pivOfCol[F.uCol[e]];
+        if (f2 >= 0)
+          cntF[f2 + 1]++;
+        else
+          cntT[tailSlotOfCol[F.uCol[e]] + 1]++;
+      }
+    for (int i = 0; i < nF; i++)
+      cntF[i + 1] += cntF[i];
+    for (int i = 0; i < k2; i++)
+      cntT[i + 1] += cntT[i];
+    std::vector<int> eiF(cntF[nF]), eiT(cntT[k2]), atF(cntF.begin(), cntF.end() - 1), atT(cntT.begin(), cntT.end() - 1), lev(nF, 0);
+    std::vector<double> evF(cntF[nF]), evT(cntT[k2]);
+    for (int f = 0; f < nF; f++) {
+      const int lvf = lev[f];  // final: its column entries come from earlier pivots only
+      for (int e = F.uStart[f]; e < F.uStart[f + 1]; e++) {
+        const int f2 = pivOfCol[F.uCol[e]];
+        if (f2 >= 0) {
+          eiF[atF[f2]] = F.frow[f];
+          evF[atF[f2]] = F.uVal[e];
+          atF[f2]++;
+          lev[f2] = std::max(lev[f2], lvf + 1);
+        } else {
+          const int tc = tailSlotOfCol[F.uCol[e]];
+          eiT[atT[tc]] = F.frow[f];
+          evT[atT[tc]] = F.uVal[e];
+          atT[tc]++;
+        }
+      }
+    }
+    std::vector<int> tg(nF), sr(nF);
+    std::vector<double> dv(nF);
+    for (int f = 0; f < nF; f++) {
+      tg[f] = F.frow[f];
+      sr[f] = F.fcol[f];
+      dv[f] = F.fpiv[f];
+    }
+    Utf.build(nF, lev, tg, sr, dv, cntF, eiF, evF);
+    std::vector<int> levT(k2, 0), tgT(k2), srT(k2);
+    std::vector<double> dvT(k2, 1.0);
+    for (int tc = 0; tc < k2; tc++) {
+      tgT[tc] = tc;
+      srT[tc] = F.tailCol[tc];
+    }
+    UtT.build(k2, levT, tgT, srT, dvT, cntT, eiT, evT);
+  }
+  {
+    // L^T backward: pivot f gathers its column of multipliers (rows pivoted later or in the tail)
+    std::vector<int> lev(nF, 0), items, il, es(1, 0), ci;
+    std::vector<double> cv, dv;
+    for (int f = nF - 1; f >= 0; f--) {
+      int l = 0;
+      for (int e = F.lStart[f]; e < F.lStart[f + 1]; e++) {
+        const int f2 = pivOfRow[F.lRow[e]];
+        if (f2 >= 0)
+          l = std::max(l, lev[f2] + 1);
+      }
+      lev[f] = l;
+    }
+    // (a pivot without multipliers is not an item, but pivots depending on it see level 0 + 1: harmless)
+    for (int f = 0; f < nF; f++)
+      if (F.lStart[f + 1] > F.lStart[f]) {
+        items.push_back(F.frow[f]);
+        il.push_back(lev[f]);
+        for (int e = F.lStart[f]; e < F.lStart[f + 1]; e++) {
+          ci.push_back(F.lRow[e]);
+          cv.push_back(F.lVal[e]);
+        }
+        es.push_back((int)ci.size());
+        dv.push_back(1.0);
+      }
+    Ltb.build((int)items.size(), il, items, items, dv, es, ci, cv);
+  }
+  // ---- frozen slack rows (their U rows) by row
+  std::vector<int> sRowIndex, sRowOf(m, -1);
+  for (int i = 0; i < m; i++)
+    if (localOfRow[i] < 0) {
+      sRowOf[i] = (int)sRowIndex.size();
+      sRowIndex.push_back(i);
+    }
+  const int ns = (int)sRowIndex.size();
+  std::vector<int> sRowStart(ns + 1, 0);
+  for (int e = 0; e < (int)sColRow.size(); e++)
+    sRowStart[sRowOf[sColRow[e]] + 1]++;
+  for (int s = 0; s < ns; s++)
+    sRowStart[s + 1] += sRowStart[s];
+  std::vector<int> sRowCol(sColRow.size()), at(sRowStart.begin(), sRowStart.end() - 1);
+  std::vector<double> sRowVal(sColRow.size());
+  for (int c = 0; c < k; c++)
+    for (int e = sColStart[c]; e < sColStart[c + 1]; e++) {
+      const int s = sRowOf[sColRow[e]];
+      sRowCol[at[s]] = c;
+      sRowVal[at[s]] = sColVal[e];
+      at[s]++;
+    }
+  // ---- upload
+  LuDev &L = hLu;
+  L.k = k;
+  L.nF = nF;
+  L.k2 = k2;
+  L.ns = ns;
+  L.kpad = (k + 63) & ~63;
+  int tcapWant = std::min(luMaxPivots, LU_TCAP_MAX - 1) + 1;
+  rc |= luUploadTri(Lf, L.Lf, LB_TRI + 0);
+  rc |= luUploadTri(Ub, L.Ub, LB_TRI + 7);
+  rc |= luUploadTri(Utf, L.Utf, LB_TRI + 14);
+  rc |= luUploadTri(UtT, L.UtT, LB_TRI + 21);
+  rc |= luUploadTri(Ltb, L.Ltb, LB_TRI + 28);
+  int *ip = nullptr;
+  double *dp = nullptr;
+  rc |= luBuf[LB_ROWOFLOCAL].put(this, rowOfLocal, ip);
+  L.rowOfLocal = ip;
+  rc |= luBuf[LB_POSOFCOL].put(this, posOfCol, ip);
+  L.posOfCol = ip;
+  rc |= luBuf[LB_TAILROW].put(this, F.tailRow, ip);
+  L.tailRow = ip;
+  rc |= luBuf[LB_TAILCOL].put(this, F.tailCol, ip);
+  L.tailCol = ip;
+  rc |= luBuf[LB_SROWINDEX].put(this, sRowIndex, ip);
+  L.sRowIndex = ip;
+  rc |= luBuf[LB_SROWSTART].put(this, sRowStart, ip);
+  L.sRowStart = ip;
+  rc |= luBuf[LB_SROWCOL].put(this, sRowCol, ip);
+  L.sRowCol = ip;
+  rc |= luBuf[LB_SROWVAL].put(this, sRowVal, dp);
+  L.sRowVal = dp;
+  rc |= luBuf[LB_SCOLSTART].put(this, sColStart, ip);
+  L.sColStart = ip;
+  rc |= luBuf[LB_SCOLROW].put(this, sColRow, ip);
+  L.sColRow = ip;
+  rc |= luBuf[LB_SCOLVAL].put(this, sColVal, dp);
+  L.sColVal = dp;
+  // work vectors and the eta file (sized once per problem / capacity)
+  void *vp = nullptr;
+  rc |= luBuf[LB_WR].need(this, sizeof(double) * 3 * (size_t)L.kpad, vp);
+  L.wr = (double *)vp;
+  rc |= luBuf[LB_XC].need(this, sizeof(double) * 3 * (size_t)L.kpad, vp);
+  L.xc = (double *)vp;
+  rc |= luBuf[LB_TCV].need(this, sizeof(double) * (size_t)L.kpad, vp);
+  L.tcv = (double *)vp;
+  rc |= luBuf[LB_X0].need(this, sizeof(double) * 3 * (size_t)m, vp);
+  L.x0 = (double *)vp;
+  rc |= luBuf[LB_CP].need(this, sizeof(double) * (size_t)m, vp);
+  L.cp = (double *)vp;
+  rc |= luBuf[LB_Y].need(this, sizeof(double) * (size_t)m, vp);
+  L.y = (double *)vp;
+  if (tcapWant > L.tcap || !luBuf[LB_H].p) {
+    L.tcap = tcapWant;
+    dropGraph();  // launch extents of the eta-file kernels follow the capacity
+    rc |= luBuf[LB_H].need(this, sizeof(double) * (size_t)L.tcap * (size_t)m, vp);
+    rc |= luBuf[LB_G].need(this, sizeof(double) * (size_t)L.tcap * (size_t)L.tcap, vp);
+    rc |= luBuf[LB_P].need(this, sizeof(int) * (size_t)L.tcap, vp);
+    rc |= luBuf[LB_PREV].need(this, sizeof(int) * (size_t)L.tcap, vp);
+    rc |= luBuf[LB_NEXT].need(this, sizeof(int) * (size_t)L.tcap, vp);
+    rc |= luBuf[LB_S].need(this, sizeof(double) * 3 * (size_t)L.tcap, vp);
+    rc |= luBuf[LB_GV].need(this, sizeof(double) * (size_t)L.tcap, vp);
+    rc |= luBuf[LB_DV].need(this, sizeof(double) * (size_t)L.tcap, vp);
+  }
+  L.H = (double *)luBuf[LB_H].p;
+  L.G = (double *)luBuf[LB_G].p;
+  L.P = (int *)luBuf[LB_P].p;
+  L.prevSame = (int *)luBuf[LB_PREV].p;
+  L.nextSame = (int *)luBuf[LB_NEXT].p;
+  L.s = (double *)luBuf[LB_S].p;
+  L.g = (double *)luBuf[LB_GV].p;
+  L.d = (double *)luBuf[LB_DV].p;
+  rc |= luBuf[LB_LASTOFPOS].need(this, sizeof(int) * (size_t)m, vp);
+  L.lastOfPos = (int *)vp;
+  if (rc)
+    return rc;
+  // the descriptor itself sits in device memory at a fixed address: captured launch graphs stay valid
+  if (!dLu) {
+    rc |= dalloc(dLu, 1);
+    dropGraph();
+  }
+  rc |= h2d(dLu, &hLu, 1);
+  D.lu = dLu;
+  D.luMode = 1;
+  hipLaunchKernelGGL(k_lu_reset, dim3(cdiv(m, 256)), dim3(256), 0, stream, D);
+  // ---- the explicit-inverse bookkeeping is switched off: no row or column has a slot
+  if (!luSlotsCleared) {
+    std::vector<int> minusM(m, -1), minusN(n, -1);
+    rc |= h2d(D.slotOfRow, minusM.data(), m);
+    rc |= h2d(D.slotOfCol, minusN.data(), n);
+    rc |= h2d(D.posOfSlack, minusM.data(), m);
+    luSlotsCleared = true;
+  }
+  rc |= h2d(D.pivotVariable, pivotVariable.data(), m);
+  rc |= rebuildRowCopyIfNeeded();
+  luActive = true;
+  kNucleus = k;
+  pivots = 0;
+  hCtrl->k = k2;
+  hCtrl->pivots = 0;
+  hCtrl->kcap = kcap;
+  rc |= checkLaunches("factorizeLu");
+  const auto t3 = std::chrono::steady_clock::now();
+  luFrontSeconds += std::chrono::duration<double>(t1 - t0).count();
+  luInvertSeconds += std::chrono::duration<double>(t2 - t1).count();
+  luBuildSeconds += std::chrono::duration<double>(t3 - t2).count();
+  luFactorizations++;
+  luLastFront = nF;
+  luLastTail = k2;
+  if (logLevel > 1)
+    fprintf(stderr, "clpgpu: LU factorization: nucleus %d = front %d (L %zu, U %zu nz; levels %d/%d/%d/%d) + dense tail %d (S %zu nz); host %.1f ms, "
+                    "inversion %.1f ms, build+upload %.1f ms\n",
+            k, nF, F.lRow.size(), F.uCol.size(), hLu.Lf.nLevels, hLu.Ub.nLevels, hLu.Utf.nLevels, hLu.Ltb.nLevels, k2, F.sVal.size(),
+            1e3 * std::chrono::duration<double>(t1 - t0).count(), 1e3 * std::chrono::duration<double>(t2 - t1).count(),
+            1e3 * std::chrono::duration<double>(t3 - t2).count());
+  return rc;
+}
+
+// generic solves in LU mode (refactorization boundaries, plug-in calls): one or two right-hand sides by row in,
+// results by basis position out
+int clpgpu_context::luFtran(const double *v0, const double *v1, double *o0, double *o1)
+{
+  const int k2 = hLu.k2, ns = hLu.ns;
+  const int nrhs = v1 ? 2 : 1;
+  hipLaunchKernelGGL(k_lu_fwd, dim3(nrhs), dim3(1024), 0, stream, D, 0, v0, v1, (const double *)nullptr, D.slotA, v1 ? D.slotB : (double *)nullptr,
+                     (double *)nullptr);
+  if (k2)
+    hipLaunchKernelGGL(k_gemv2, dim3(cdiv(k2, 4)), dim3(256), 0, stream, D, (const double *)D.slotA, v1 ? (const double *)D.slotB : (const double *)nullptr,
+                       D.slotC, v1 ? D.slotD : (double *)nullptr, 0);
+  hipLaunchKernelGGL(k_lu_bwd, dim3(nrhs), dim3(1024), 0, stream, D, 0, (const double *)D.slotC, (const double *)D.slotD, (const double *)nullptr, 1,
+                     v1 ? 1 : 0, 0);
+  if (ns)
+    hipLaunchKernelGGL(k_lu_slack, dim3(cdiv(ns, 256), nrhs), dim3(256), 0, stream, D, 0, v0, v1, (const double *)nullptr, 1, v1 ? 1 : 0, 0);
+  hipLaunchKernelGGL(k_lu_pf_s, dim3(64), dim3(256), 0, stream, D, 0, 1, v1 ? 1 : 0, 0);
+  hipLaunchKernelGGL(k_lu_pf_apply, dim3(cdiv(m, 256)), dim3(256), sizeof(double) * 3 * (size_t)hLu.tcap, stream, D, o0, o1, (double *)nullptr);
+  return 0;
+}
+
+int clpgpu_context::luBtran(const double *cPos, double *yRow)
+{
+  const int k = hLu.k, k2 = hLu.k2, ns = hLu.ns, tcap = hLu.tcap;
+  hipLaunchKernelGGL(k_lu_pf_gdot, dim3(64), dim3(256), 0, stream, D, cPos);
+  hipLaunchKernelGGL(k_lu_pf_d, dim3(cdiv(tcap, 64)), dim3(256), 0, stream, D, 0);
+  hipLaunchKernelGGL(k_lu_cprime, dim3(1), dim3(1024), 0, stream, D, 0, cPos);
+  hipLaunchKernelGGL(k_lu_bt_gather, dim3(cdiv(k + ns, 256)), dim3(256), 0, stream, D, 0, yRow);
+  hipLaunchKernelGGL(k_lu_bt_front, dim3(1), dim3(1024), 0, stream, D, 0, D.slotA);
+  if (k2) {
+    hipLaunchKernelGGL(k_gemvT_partial, dim3(cdiv(k2, 256), cdiv(k2, 64)), dim3(256), 0, stream, D, (const double *)D.slotA, 0);
+    hipLaunchKernelGGL(k_lu_gemvT_final, dim3(cdiv(k2, 256)), dim3(256), 0, stream, D, 0);
+  }
+  hipLaunchKernelGGL(k_lu_bt_back, dim3(1), dim3(1024), 0, stream, D, 0, yRow);
+  return 0;
+}
+
+// the LU-mode stretch of one pivot's chain: BTRAN (after CHUZR) ...
+void clpgpu_context::luLaunchBtran()
+{
+  const int k = hLu.k, ns = hLu.ns, tcap = hLu.tcap, kc = kcap;
+  KL("k_lu_pf_d", k_lu_pf_d, dim3(cdiv(tcap, 64)), dim3(256), 0, stream, D, 1);
+  KL("k_lu_cprime", k_lu_cprime, dim3(1), dim3(1024), 0, stream, D, 1, (const double *)nullptr);
+  KL("k_lu_bt_gather", k_lu_bt_gather, dim3(cdiv(k + ns, 256)), dim3(256), 0, stream, D, 1, hLu.y);
+  KL("k_lu_bt_front", k_lu_bt_front, dim3(1), dim3(1024), 0, stream, D, 1, D.slotA);
+  KL("k_gemvT_partial", k_gemvT_partial, dim3(cdiv(kc, 256), cdiv(kc, 64)), dim3(256), 0, stream, D, (const double *)D.slotA, 1);
+  KL("k_lu_gemvT_final", k_lu_gemvT_final, dim3(cdiv(kc, 256)), dim3(256), 0, stream, D, 1);
+  KL("k_lu_bt_back", k_lu_bt_back, dim3(1), dim3(1024), 0, stream, D, 1, hLu.y);
+}
+// ... and the three FTRANs (entering column, rho, flip rhs) up to the scatter with the eta file applied
+void clpgpu_context::luLaunchFtran(int gm, int parity)
+{
+  const int ns = hLu.ns, kc = kcap;
+  KL("k_lu_fwd", k_lu_fwd, dim3(3), dim3(1024), 0, stream, D, 1, (const double *)D.vecV1, (const double *)D.rho, (const double *)D.flipRhs, D.slotV1,
+     D.rhoSlotF, D.flipSlot);
+  KL("k_gemv3g", k_gemv3g, dim3(cdiv(kc, GEMV_RPB)), dim3(1024), 0, stream, D);
+  KL("k_lu_bwd", k_lu_bwd, dim3(3), dim3(1024), 0, stream, D, 1, (const double *)D.slotC, (const double *)D.slotD, (const double *)D.slotE, 1, 1, 1);
+  if (ns)
+    KL("k_lu_slack", k_lu_slack, dim3(cdiv(ns, 256), 3), dim3(256), 0, stream, D, 1, (const double *)D.vecV1, (const double *)D.rho,
+       (const double *)D.flipRhs, 1, 1, 1);
+  KL("k_lu_pf_s", k_lu_pf_s, dim3(64), dim3(256), 0, stream, D, 1, 1, 1, 1);
+  KL("k_ftran_scatter3_lu", k_ftran_scatter3_lu, dim3(gm), dim3(256), 0, stream, D, gm, parity);
+}

@@ -29,7 +29,9 @@ class Stats(C.Structure):
     _fields_ = [("price_ms", C.c_double), ("price_launches", C.c_long), ("price_bytes", C.c_double),
                 ("total_ms", C.c_double), ("iterations", C.c_long), ("refactorizations", C.c_long),
                 ("row_ms", C.c_double), ("row_launches", C.c_long), ("row_bytes", C.c_double),
-                ("nucleus", C.c_long), ("nucleus_capacity", C.c_long), ("refreshes", C.c_long), ("refreshes_rejected", C.c_long)]
+                ("nucleus", C.c_long), ("nucleus_capacity", C.c_long), ("refreshes", C.c_long), ("refreshes_rejected", C.c_long),
+                ("lu_active", C.c_long), ("lu_front", C.c_long), ("lu_tail", C.c_long), ("lu_factorizations", C.c_long),
+                ("lu_front_ms", C.c_double), ("lu_invert_ms", C.c_double), ("lu_build_ms", C.c_double), ("eta_count", C.c_long)]
 
 
 # every symbol include/clpgpu.h declares (tests/test_abi.py checks the library exports all of them)

@@ -55,6 +55,15 @@ typedef struct {
   long nucleus_capacity; /* rows allocated for it (3 k x k f64 matrices) */
   long refreshes;        /* scheduled refactorizations at which the inverse was kept (verified refresh, option refresh_min_k) */
   long refreshes_rejected; /* ... and those where the residual check sent it to a re-inversion after all */
+  /* LU factorization mode (option factor_mode): sparse Markowitz front + dense tail + product-form eta file */
+  long lu_active;          /* 1 when the factorization now on the device is the LU form */
+  long lu_front;           /* pivots of the sparse front */
+  long lu_tail;            /* order of the dense tail (inverted on the matrix cores) */
+  long lu_factorizations;  /* LU factorizations so far */
+  double lu_front_ms;      /* host time spent in the Markowitz front, all factorizations */
+  double lu_invert_ms;     /* time of the tail inversions (device, measured on the host clock) */
+  double lu_build_ms;      /* level schedules + uploads */
+  long eta_count;          /* basis updates since the last factorization (length of the eta file in LU mode) */
 } clpgpu_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------- */

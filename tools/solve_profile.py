@@ -52,7 +52,8 @@ def main():
         it = g.numberIterations()
         print(json.dumps({"iterations": it, "elapsed_s": round(now - t0, 3), "chunk_it_per_s": round((it - last_it) / max(now - last_t, 1e-9), 1),
                           "nucleus": st["nucleus"], "capacity": st["nucleus_capacity"], "refactorizations": st["refactorizations"],
-                          "refreshes": st["refreshes"], "refreshes_rejected": st["refreshes_rejected"], "objective": g.objectiveValue(), "status": status}), flush=True)
+                          "refreshes": st["refreshes"], "refreshes_rejected": st["refreshes_rejected"], "lu": [st["lu_active"], st["lu_front"], st["lu_tail"], st["lu_factorizations"], round(st["lu_front_ms"]), round(st["lu_invert_ms"]), round(st["lu_build_ms"])],
+                          "objective": g.objectiveValue(), "status": status}), flush=True)
         last_t, last_it = now, it
     total = time.perf_counter() - t0
     print(json.dumps({"summary": True, "workload": args.workload, "rows": int(lp.m), "cols": int(lp.n), "status": status,
