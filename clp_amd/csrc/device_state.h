@@ -105,7 +105,7 @@ struct LuTri {
 struct LuDev {
   int k, nF, k2, ns;   // nucleus order, front pivots, tail order, rows whose slack was basic at the refactorization
   int kpad, tcap;      // stride of the per-right-hand-side work vectors; capacity of the eta file
-  LuTri Lf, Ub, Utf, UtT, Ltb;
+  LuTri Lf, Ub, Utf, Ltb;  // L^-1 rows; U11^-1 [I | -U12] rows; its transpose (front pivots, then tail columns); L^-T
   const int *rowOfLocal;  // [k] local nucleus row -> row
   const int *posOfCol;    // [k] local nucleus column -> basis position
   const int *tailRow, *tailCol;  // [k2] tail slot -> local nucleus row / column
@@ -123,6 +123,7 @@ struct LuDev {
   // eta file
   double *H;           // [tcap * m] eta j at H + j*m, by position
   double *G;           // [tcap * tcap] (I + N)^-1, row-major, lower triangular
+  double *GT;          // [tcap * tcap] its transpose (column sweeps read it row-wise)
   int *P;              // [tcap] position of eta j
   int *prevSame, *nextSame;  // [tcap] etas on the same position
   int *lastOfPos;      // [m]

@@ -54,10 +54,9 @@ struct DBuf {
 };
 enum {
   LB_SROW, LB_SCOL, LB_SVAL, LB_ROWOFLOCAL, LB_POSOFCOL, LB_TAILROW, LB_TAILCOL, LB_SROWINDEX, LB_SROWSTART, LB_SROWCOL, LB_SROWVAL,
-  LB_SCOLSTART, LB_SCOLROW, LB_SCOLVAL, LB_WR, LB_XC, LB_TCV, LB_X0, LB_CP, LB_Y, LB_H, LB_G, LB_P, LB_PREV, LB_NEXT, LB_S, LB_GV, LB_DV,
+  LB_SCOLSTART, LB_SCOLROW, LB_SCOLVAL, LB_WR, LB_XC, LB_TCV, LB_X0, LB_CP, LB_Y, LB_H, LB_G, LB_GT, LB_P, LB_PREV, LB_NEXT, LB_S, LB_GV, LB_DV,
   LB_LASTOFPOS, LB_TRI, LB_COUNT = LB_TRI + 35
 };
-#define LU_TCAP_MAX 2048
 
 struct clpgpu_context {
   int device = 0;
@@ -128,10 +127,18 @@ struct clpgpu_context {
   int refreshRefine = 1, numberRefines = 0, refreshMinKDense = 2048;
   double refreshResidualMax = 1.0e-2, lastResidual = 0.0;
   void *blasHandle = nullptr;
-  int refineInverse();
+  // tailFromS: the matrix is the LU mode's dense tail (its entries are still on the device as triplets);
+  // goodBelow: return 3 without a step when max |I - C X| is already below it
+  int refineInverse(bool tailFromS = false, double goodBelow = 0.0);
+  int luPolish = 2, numberPolishSteps = 0;
+  double luPolishTolerance = 1.0e-11, luLastResidual = 0.0;
   int numberThrownOut = 0;  // structurals replaced by slacks by the singular-basis repair, whole solve
   void resetFakeBounds();
   int pivots = 0, kNucleus = 0;
+  // option "solution_refinements": refinement passes of the primal / dual solves at a refactorization, taken
+  // only while the residual exceeds "refine_above" (ClpSimplex::numberRefinements_, src/ClpSimplex.hpp)
+  int solutionRefinements = 2, numberPrimalRefinements = 0, numberDualRefinements = 0;
+  double refineAbove = 1.0e-9;
   // ---- LU factorization mode (lu_front.h, lu_host.hip, lu_kernels.hip): the nucleus as a sparse
   // Markowitz front (host, at the refactorization) + a dense tail inverted on the matrix cores, with a
   // product-form eta file between refactorizations.  Option "factor_mode": 0 = explicit inverse of the whole
@@ -146,6 +153,8 @@ struct clpgpu_context {
   double luFrontSeconds = 0.0, luInvertSeconds = 0.0, luBuildSeconds = 0.0;
   long luFactorizations = 0;
   int luLastFront = 0, luLastTail = 0;
+  long luLastInverseFill = 0;
+  double luInverseFillCap = 6.0e6;  // option "lu_inverse_fill_cap"
   int luUploadTri(const LuTriHost &h, LuTri &d, int slot);
   int luFtran(const double *v0, const double *v1, double *o0, double *o1);
   int luBtran(const double *cPos, double *yRow);
@@ -1316,8 +1325,13 @@ int clpgpu_context::factorizeOnce()
   const bool wantLu = k > 0 && (factorMode == 1 || (factorMode < 0 && !wideRows && !commActive && k >= luMinK));
   if (wantLu != luActive)
     dropGraph();  // the chain of a pivot differs between the two forms
-  if (wantLu)
-    return factorizeLu(kcol, rrows, localOfRow);
+  if (wantLu) {
+    const int lrc = factorizeLu(kcol, rrows, localOfRow);
+    if (lrc != -7)
+      return lrc;
+    if (luActive)
+      dropGraph();
+  }
   luActive = false;
   D.luMode = 0;
   luSlotsCleared = false;
@@ -1470,42 +1484,79 @@ int clpgpu_context::gutsOfSolution()
 {
   int rc = pushCtrl();
   const int g = cdiv(m, 256);
+  const int gr = wideRows ? cdiv(m, 4) : g;
+  // NaN-propagating maximum: a non-finite residual must read as "bad", not as zero
+  auto worst = [](double a, double b) { return !(b <= a) ? b : a; };
+  auto primalError = [&](double &largest) {
+    // largestPrimalError: max |(A x - s)_i| over all rows, reduced per block on the device
+    hipLaunchKernelGGL(k_primal_residual, dim3(gr), dim3(256), 0, stream, D, wideRows ? 1 : 0);
+    std::vector<double> part(gr);
+    int r = d2h(part.data(), D.normPartial, gr);
+    largest = 0.0;
+    for (int b = 0; b < gr; b++)
+      largest = worst(largest, part[b]);
+    return r;
+  };
   hipLaunchKernelGGL(k_zero_basic, dim3(g), dim3(256), 0, stream, D);
-  hipLaunchKernelGGL(k_primal_rhs, dim3(wideRows ? cdiv(m, 4) : g), dim3(256), 0, stream, D, D.vecV2, wideRows ? 1 : 0);
+  hipLaunchKernelGGL(k_primal_rhs, dim3(gr), dim3(256), 0, stream, D, D.vecV2, wideRows ? 1 : 0);
   ftranDevice(D.vecV2, D.x3);
   hipLaunchKernelGGL(k_store_basic, dim3(g), dim3(256), 0, stream, D, (const double *)D.x3);
+  rc |= primalError(largestPrimalError);
+  // iterative refinement (ClpSimplex::computePrimals :1040-1130 does the same under numberRefinements_): with the
+  // basics in place, s - A x is the residual of B x_B = rhs; one more FTRAN of it is the correction.  Only when the
+  // factorization left a residual that matters (ill-conditioned bases); never in the parity tests' regime.
+  for (int pass = 0; pass < solutionRefinements && largestPrimalError > refineAbove; pass++) {
+    hipLaunchKernelGGL(k_primal_rhs, dim3(gr), dim3(256), 0, stream, D, D.vecV2, wideRows ? 1 : 0);
+    ftranDevice(D.vecV2, D.x3);
+    hipLaunchKernelGGL(k_add_basic, dim3(g), dim3(256), 0, stream, D, (const double *)D.x3);
+    double after = 0.0;
+    rc |= primalError(after);
+    numberPrimalRefinements++;
+    if (!(after < largestPrimalError)) {
+      // no better: take the correction back
+      hipLaunchKernelGGL(k_sub_basic, dim3(g), dim3(256), 0, stream, D, (const double *)D.x3);
+      break;
+    }
+    largestPrimalError = after;
+  }
   hipLaunchKernelGGL(k_basic_costs, dim3(g), dim3(256), 0, stream, D, D.tau);
   btranDevice(D.tau, D.vecV2);
-  if (widePricing)
-    hipLaunchKernelGGL(k_djs, dim3(cdiv(n, 4) + cdiv(m, 256)), dim3(256), 0, stream, D, (const double *)D.vecV2, 1);
-  else
-    hipLaunchKernelGGL(k_djs, dim3(cdiv(N, 256)), dim3(256), 0, stream, D, (const double *)D.vecV2, 0);
-  // errors: residuals of the two solves (computed from the device results on the host mirrors)
-  std::vector<double> rhs(m), xB(m), y(m);
-  rc |= d2h(rhs.data(), D.vecV2, m);  // y (duals) now in vecV2
-  y = rhs;
+  auto djs = [&]() {
+    if (widePricing)
+      hipLaunchKernelGGL(k_djs, dim3(cdiv(n, 4) + cdiv(m, 256)), dim3(256), 0, stream, D, (const double *)D.vecV2, 1);
+    else
+      hipLaunchKernelGGL(k_djs, dim3(cdiv(N, 256)), dim3(256), 0, stream, D, (const double *)D.vecV2, 0);
+  };
+  djs();
   rc |= pullRim(false);
+  auto dualError = [&]() {
+    // largestDualError: max over basics of |dj| (should be zero)
+    double largest = 0.0;
+    for (int i = 0; i < m; i++)
+      largest = worst(largest, fabs(dj[pivotVariable[i]]));
+    return largest;
+  };
+  largestDualError = dualError();
+  for (int pass = 0; pass < solutionRefinements && largestDualError > refineAbove; pass++) {
+    // the basic reduced costs are the residual of B^T y = c_B: y += B^-T (that residual)
+    hipLaunchKernelGGL(k_basic_djs, dim3(g), dim3(256), 0, stream, D, D.tau);
+    btranDevice(D.tau, D.x3);
+    hipLaunchKernelGGL(k_axpy, dim3(g), dim3(256), 0, stream, D.vecV2, (const double *)D.x3, 1.0, m);
+    djs();
+    rc |= pullRim(false);
+    const double after = dualError();
+    numberDualRefinements++;
+    if (!(after < largestDualError)) {
+      hipLaunchKernelGGL(k_axpy, dim3(g), dim3(256), 0, stream, D.vecV2, (const double *)D.x3, -1.0, m);
+      djs();
+      rc |= pullRim(false);
+      break;
+    }
+    largestDualError = after;
+  }
   hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, stream, D.vecV2, m);
   hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, stream, D.tau, m);
   hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, stream, D.x3, m);
-  // largestPrimalError: max |(A x - s)_i| over all rows, reduced per block on the device
-  {
-    const int gr = wideRows ? cdiv(m, 4) : g;
-    hipLaunchKernelGGL(k_primal_residual, dim3(gr), dim3(256), 0, stream, D, wideRows ? 1 : 0);
-    std::vector<double> part(gr);
-    rc |= d2h(part.data(), D.normPartial, gr);
-    double largest = 0.0;
-    for (int b = 0; b < gr; b++)
-      largest = fmax(largest, part[b]);
-    largestPrimalError = largest;
-  }
-  // largestDualError: max over basics of |dj| (should be zero)
-  {
-    double largest = 0.0;
-    for (int i = 0; i < m; i++)
-      largest = fmax(largest, fabs(dj[pivotVariable[i]]));
-    largestDualError = largest;
-  }
   checkPrimalSolution();
   checkDualSolution();
   return rc;
@@ -1993,7 +2044,7 @@ static void *rocblasLibrary()
     h = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
   return h;
 }
-int clpgpu_context::refineInverse()
+int clpgpu_context::refineInverse(bool tailFromS, double goodBelow)
 {
   typedef int (*create_t)(void **);
   typedef int (*stream_t)(void *, hipStream_t);
@@ -2012,19 +2063,28 @@ int clpgpu_context::refineInverse()
       return 1;
     }
   }
-  const int k = hCtrl->k;
+  const int k = tailFromS ? hLu.k2 : hCtrl->k;
   const size_t mat = (size_t)k * ld * sizeof(double);
   unsigned long long *dMax = (unsigned long long *)D.normPartial;
   if (hipMemsetAsync(dMax, 0, sizeof(unsigned long long), stream) != hipSuccess)
     return 1;
   const double one = 1.0, minusOne = -1.0;
   const int none = 111;  // rocblas_operation_none
-  if (wideRows) {
+  if (wideRows || tailFromS) {
     // long rows: C gathered dense, R = I - C X as a GEMM (row-major C X = column-major X^T C^T: A = X, B = C)
     if (hipMemsetAsync(D.workW, 0, mat, stream) != hipSuccess || hipMemsetAsync(D.workX, 0, mat, stream) != hipSuccess)
       return 1;
-    hipLaunchKernelGGL(k_gather_slots, dim3(k), dim3(64), 0, stream, D, k, D.workW);
+    if (tailFromS) {
+      const int snz = (int)luF.sVal.size();
+      if (snz)
+        hipLaunchKernelGGL(k_lu_scatter_tail, dim3(cdiv(snz, 256)), dim3(256), 0, stream, D, (const int *)luBuf[LB_SROW].p,
+                           (const int *)luBuf[LB_SCOL].p, (const double *)luBuf[LB_SVAL].p, snz);
+    } else {
+      hipLaunchKernelGGL(k_gather_slots, dim3(k), dim3(64), 0, stream, D, k, D.workW);
+    }
     hipLaunchKernelGGL(k_identity, dim3(cdiv(k, 256)), dim3(256), 0, stream, D, k);
+    if (checkLaunches("refineInverse (gather)"))
+      return 1;
     if (dgemmFn(blasHandle, none, none, k, k, k, &minusOne, D.Minv, ld, D.workW, ld, &one, D.workX, ld) != 0)
       return 1;
     hipLaunchKernelGGL(k_absmax_rows, dim3(k), dim3(256), 0, stream, D, k, (const double *)D.workX, dMax);
@@ -2035,8 +2095,10 @@ int clpgpu_context::refineInverse()
   if (d2h(&bits, dMax, 1))
     return 1;
   memcpy(&lastResidual, &bits, sizeof(double));
-  if (!(lastResidual <= refreshResidualMax))
-    return 2;  // too far for one step: re-invert
+  if (!(lastResidual <= (tailFromS ? 0.5 : refreshResidualMax)))
+    return 2;  // too far for one step (or not finite): re-invert
+  if (lastResidual < goodBelow)
+    return 3;  // nothing to gain
   // workW = X; workW += X R  (row-major X R = column-major R^T X^T: A = R, B = X in rocBLAS terms)
   if (hipMemcpyAsync(D.workW, D.Minv, mat, hipMemcpyDeviceToDevice, stream) != hipSuccess)
     return 1;
@@ -2473,7 +2535,7 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
     if (luActive) {
       // primal update as usual; the basis update is one more eta (column of H, row of G)
       KL("k_primal_update", k_primal_update, dim3(gm), dim3(256), 0, stream, D, 0);
-      KL("k_lu_pf_append", k_lu_pf_append, dim3(gm + cdiv(hLu.tcap, 64)), dim3(256), 0, stream, D, 1, gm);
+      KL("k_lu_pf_append", k_lu_pf_append, dim3(gm + cdiv(hLu.tcap, 4)), dim3(256), 0, stream, D, 1, gm);
     } else if (forkUpdate && stream2) {
       (void)hipEventRecord(evFork, stream);
       (void)hipStreamWaitEvent(stream2, evFork, 0);
@@ -3210,7 +3272,7 @@ int clpgpu_replace_column(clpgpu_context *ctx, int pivotRow, int sequenceIn, dou
     h->maximumPivots = LU_TCAP_MAX;
     h->logCapacity = 0;
     rc |= ctx->pushCtrl();
-    hipLaunchKernelGGL(k_lu_pf_append, dim3(gm + cdiv(ctx->hLu.tcap, 64)), dim3(256), 0, s, D, 0, gm);
+    hipLaunchKernelGGL(k_lu_pf_append, dim3(gm + cdiv(ctx->hLu.tcap, 4)), dim3(256), 0, s, D, 0, gm);
     hipLaunchKernelGGL(k_house, dim3(1), dim3(256), 0, s, D);
     rc |= ctx->pullCtrl();
     rc |= ctx->d2h(ctx->pivotVariable.data(), D.pivotVariable, m);
@@ -3752,12 +3814,17 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
     ctx->commMode = (int)v == 1 ? 1 : 2;
   }
   else if (!strcmp(name, "refactor_min_k")) ctx->refactorMinK = (int)v;
+  else if (!strcmp(name, "solution_refinements")) ctx->solutionRefinements = std::max(0, (int)v);
+  else if (!strcmp(name, "refine_above")) ctx->refineAbove = v;
+  else if (!strcmp(name, "lu_polish")) ctx->luPolish = std::max(0, (int)v);
+  else if (!strcmp(name, "lu_polish_tolerance")) ctx->luPolishTolerance = v;
   else if (!strcmp(name, "factor_mode")) ctx->factorMode = (int)v;
   else if (!strcmp(name, "lu_min_k")) ctx->luMinK = (int)v;
   else if (!strcmp(name, "lu_max_pivots")) ctx->luMaxPivots = std::max(1, std::min((int)v, LU_TCAP_MAX - 1));
   else if (!strcmp(name, "lu_stop_density")) ctx->luStopDensity = v;
   else if (!strcmp(name, "lu_min_tail")) ctx->luMinTail = std::max(0, (int)v);
   else if (!strcmp(name, "lu_threshold")) ctx->luThreshold = v;
+  else if (!strcmp(name, "lu_inverse_fill_cap")) ctx->luInverseFillCap = v;
   else if (!strcmp(name, "fork_update")) { ctx->forkUpdate = (int)v; ctx->dropGraph(); }
   else if (!strcmp(name, "refresh_min_k")) ctx->refreshMinK = (int)v;
   else if (!strcmp(name, "refresh_min_k_dense")) ctx->refreshMinKDense = (int)v;

@@ -17,6 +17,11 @@ constexpr double DEVEX_TRY_NORM = 1.0e-4; // src/ClpSimplex.hpp:2056
 // ---------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------
+// maximum that keeps a NaN (fmax drops it): residual checks must see a poisoned factorization
+__device__ inline double nanMax(double a, double b)
+{
+  return !(b <= a) ? b : a;
+}
 __device__ inline double waveSum(double v)
 {
   for (int o = 32; o > 0; o >>= 1)
@@ -4588,16 +4593,18 @@ __global__ void __launch_bounds__(256) k_refine_residual(Dev D, int k, double *R
     }
     if (col < k) {
       R[(size_t)sr * D.ld + col] = acc;
-      best = fmax(best, fabs(acc));
+      best = nanMax(best, fabs(acc));
     }
   }
   for (int o = 32; o > 0; o >>= 1)
-    best = fmax(best, __shfl_xor(best, o));
+    best = nanMax(best, __shfl_xor(best, o));
   if ((threadIdx.x & 63) == 0)
     s_max[threadIdx.x >> 6] = best;
   __syncthreads();
   if (threadIdx.x == 0) {
-    best = fmax(fmax(s_max[0], s_max[1]), fmax(s_max[2], s_max[3]));
+    best = nanMax(nanMax(s_max[0], s_max[1]), nanMax(s_max[2], s_max[3]));
+    if (!(best == best))
+      best = __longlong_as_double(0x7ff0000000000000LL);  // NaN -> +inf (largest under the integer max)
     atomicMax(out, (unsigned long long)__double_as_longlong(best));
   }
 }
@@ -4624,14 +4631,16 @@ __global__ void __launch_bounds__(256) k_absmax_rows(Dev D, int k, const double 
     return;
   double best = 0.0;
   for (int c = threadIdx.x; c < k; c += 256)
-    best = fmax(best, fabs(R[(size_t)r * D.ld + c]));
+    best = nanMax(best, fabs(R[(size_t)r * D.ld + c]));
   for (int o = 32; o > 0; o >>= 1)
-    best = fmax(best, __shfl_xor(best, o));
+    best = nanMax(best, __shfl_xor(best, o));
   if ((threadIdx.x & 63) == 0)
     s_max[threadIdx.x >> 6] = best;
   __syncthreads();
   if (threadIdx.x == 0) {
-    best = fmax(fmax(s_max[0], s_max[1]), fmax(s_max[2], s_max[3]));
+    best = nanMax(nanMax(s_max[0], s_max[1]), nanMax(s_max[2], s_max[3]));
+    if (!(best == best))
+      best = __longlong_as_double(0x7ff0000000000000LL);  // NaN -> +inf: ordered as the largest by the integer max
     atomicMax(out, (unsigned long long)__double_as_longlong(best));
   }
 }
@@ -5421,7 +5430,9 @@ __global__ void __launch_bounds__(256) k_primal_residual(Dev D, int wide = 0)
       acc += D.relem[q] * D.sol[D.ccol[q]];
     r = fabs(acc - D.sol[D.n + i]);
   }
-  // max via min of negatives
+  // max via min of negatives (a NaN residual is reported as +inf: comparisons would drop it)
+  if (!(r == r))
+    r = __longlong_as_double(0x7ff0000000000000LL);
   double mx = -blockMin(-r, sh);
   if (threadIdx.x == 0)
     D.normPartial[blockIdx.x] = mx;
@@ -5431,6 +5442,31 @@ __global__ void k_store_basic(Dev D, const double *x)
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < D.m)
     D.sol[D.pivotVariable[p]] = x[p];
+}
+// iterative refinement of the resync solves: x_B += dx, x_B -= dx, basic reduced costs by position, y += a x
+__global__ void k_add_basic(Dev D, const double *x)
+{
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < D.m)
+    D.sol[D.pivotVariable[p]] += x[p];
+}
+__global__ void k_sub_basic(Dev D, const double *x)
+{
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < D.m)
+    D.sol[D.pivotVariable[p]] -= x[p];
+}
+__global__ void k_basic_djs(Dev D, double *out)
+{
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < D.m)
+    out[p] = D.dj[D.pivotVariable[p]];
+}
+__global__ void k_axpy(double *y, const double *x, double a, int n)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    y[i] += a * x[i];
 }
 // computeDuals helpers (src/ClpSimplex.cpp:1164)
 __global__ void k_basic_costs(Dev D, double *cB)

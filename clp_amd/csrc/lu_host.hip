@@ -150,6 +150,23 @@ int clpgpu_context::factorizeLu(const std::vector<int> &kcol, const std::vector<
       return -1;
     }
   }
+  // ---- polish: the explicit inverse of an ill-conditioned tail carries a residual of cond(S) * eps; Newton-Schulz
+  // steps X += X (I - S X) square it (the bases of the bench LP pass through condition numbers of 1e10 and more)
+  hLu.k2 = k2;  // (refineInverse sizes its work from the descriptor)
+  for (int step = 0; k2 && step < luPolish; step++) {
+    const int prc = refineInverse(true, luPolishTolerance);
+    luLastResidual = lastResidual;
+    if (prc != 0)
+      break;  // good enough already (3), no GEMM library / not finite / too far (1, 2): keep what we have
+    numberPolishSteps++;
+  }
+  // (the GEMM library probes pointers with runtime calls whose failures stay behind as the thread's "last error":
+  // the engine's own launches up to here were checked by invertWork)
+  {
+    hipError_t pending = hipGetLastError();
+    if (pending != hipSuccess && logLevel > 0)
+      fprintf(stderr, "clpgpu: (cleared after the tail polish: %s)\n", hipGetErrorString(pending));
+  }
   const auto t2 = std::chrono::steady_clock::now();
   // ---- positions: front pivot f puts column fcol[f] at the position of row frow[f]; the tail as the
   // dense pivoting decided
@@ -163,145 +180,216 @@ int clpgpu_context::factorizeLu(const std::vector<int> &kcol, const std::vector<
       pivotVariable[i] = n + i;
   for (int c = 0; c < k; c++)
     pivotVariable[posOfCol[c]] = kcol[c];
-  // ---- the four triangular sweeps in gather form, with level sets
-  std::vector<int> pivOfRow(k, -1), pivOfCol(k, -1);
+  // ---- the front's triangular factors as EXPLICIT sparse inverses, each applied in one gather pass:
+  //   L^-1  (rows; unit diagonal)            y = L^-1 v          -> front rows y_F, tail rows the GEMV's input
+  //   X = U11^-1 [ I | -U12 ]  (rows)        x_F = X [y_F ; x_T]
+  // and their transposes for the BTRAN.  On the bench LP they hold < 2x the entries of L and U (measured:
+  // nucleus 11 000: L 44 k -> L^-1 75 k; U 46 k -> X 91 k); a front whose inverses fill in beyond
+  // luInverseFillCap falls back to the explicit inverse of the whole nucleus for this refactorization.
+  std::vector<int> pivOfRow(k, -1), pivOfCol(k, -1), tailSlotOfRow(k, -1), tailSlotOfCol(k, -1);
   for (int f = 0; f < nF; f++) {
     pivOfRow[F.frow[f]] = f;
     pivOfCol[F.fcol[f]] = f;
   }
-  LuTriHost Lf, Ub, Utf, UtT, Ltb;
-  {
-    // L forward: row lr gathers the multipliers the earlier pivots left on it
-    std::vector<int> cnt(k + 1, 0);
-    for (int e = 0; e < (int)F.lRow.size(); e++)
-      cnt[F.lRow[e] + 1]++;
-    for (int i = 0; i < k; i++)
-      cnt[i + 1] += cnt[i];
-    std::vector<int> ei(F.lRow.size()), at(cnt.begin(), cnt.end() - 1), lev(k, 0);
-    std::vector<double> ev(F.lRow.size());
-    for (int f = 0; f < nF; f++) {
-      const int lvf = lev[F.frow[f]];  // final: every entry of the pivot row comes from an earlier pivot
-      for (int e = F.lStart[f]; e < F.lStart[f + 1]; e++) {
-        const int lr = F.lRow[e];
-        ei[at[lr]] = F.frow[f];
-        ev[at[lr]] = F.lVal[e];
-        at[lr]++;
-        lev[lr] = std::max(lev[lr], lvf + 1);
+  for (int ts = 0; ts < k2; ts++) {
+    tailSlotOfRow[F.tailRow[ts]] = ts;
+    tailSlotOfCol[F.tailCol[ts]] = ts;
+  }
+  const size_t fillCap = (size_t)luInverseFillCap;
+  // L by row (entries in pivot order)
+  std::vector<int> lcnt(k + 1, 0);
+  for (size_t e = 0; e < F.lRow.size(); e++)
+    lcnt[F.lRow[e] + 1]++;
+  for (int i = 0; i < k; i++)
+    lcnt[i + 1] += lcnt[i];
+  std::vector<int> lrp(F.lRow.size()), lat(lcnt.begin(), lcnt.end() - 1);
+  std::vector<double> lrv(F.lRow.size());
+  for (int f = 0; f < nF; f++)
+    for (int e = F.lStart[f]; e < F.lStart[f + 1]; e++) {
+      const int lr = F.lRow[e];
+      lrp[lat[lr]] = F.frow[f];
+      lrv[lat[lr]] = F.lVal[e];
+      lat[lr]++;
+    }
+  // sparse accumulator
+  std::vector<double> spa(k + k2, 0.0);
+  std::vector<int> spaMark(k + k2, 0), spaList;
+  auto spaAdd = [&](int j, double v) {
+    if (!spaMark[j]) {
+      spaMark[j] = 1;
+      spaList.push_back(j);
+    }
+    spa[j] += v;
+  };
+  // rows of L^-1 - I: y_r = v_r + sum_j linv[r][j] v_j
+  std::vector<std::vector<std::pair<int, double>>> linv(k);
+  size_t fill = 0;
+  bool tooMuch = false;
+  auto lrow = [&](int r) {
+    if (lcnt[r + 1] == lcnt[r])
+      return;
+    for (int e = lcnt[r]; e < lcnt[r + 1]; e++) {
+      const int p = lrp[e];
+      const double mult = lrv[e];
+      spaAdd(p, -mult);
+      for (const auto &pr : linv[p])
+        spaAdd(pr.first, -mult * pr.second);
+    }
+    std::sort(spaList.begin(), spaList.end());
+    linv[r].reserve(spaList.size());
+    for (int j : spaList) {
+      if (spa[j] != 0.0)
+        linv[r].push_back({ j, spa[j] });
+      spa[j] = 0.0;
+      spaMark[j] = 0;
+    }
+    spaList.clear();
+    fill += linv[r].size();
+  };
+  for (int f = 0; f < nF && fill <= fillCap; f++)
+    lrow(F.frow[f]);
+  for (int ts = 0; ts < k2 && fill <= fillCap; ts++)
+    lrow(F.tailRow[ts]);
+  // rows of X: x_f = sum xinv[f][j] * (j < k ? y[local row j] : x_T[j - k])
+  std::vector<std::vector<std::pair<int, double>>> xinv(nF);
+  for (int f = nF - 1; f >= 0 && fill <= fillCap; f--) {
+    const double ip = 1.0 / F.fpiv[f];
+    spaAdd(F.frow[f], ip);
+    for (int e = F.uStart[f]; e < F.uStart[f + 1]; e++) {
+      const int cc = F.uCol[e];
+      const double u = F.uVal[e] * ip;
+      const int f2 = pivOfCol[cc];
+      if (f2 >= 0) {
+        for (const auto &pr : xinv[f2])
+          spaAdd(pr.first, -u * pr.second);
+      } else {
+        spaAdd(k + tailSlotOfCol[cc], -u);
       }
     }
-    std::vector<int> items, il, es(1, 0), ci;
-    std::vector<double> cv, dv;
-    for (int lr = 0; lr < k; lr++)
-      if (cnt[lr + 1] > cnt[lr]) {
-        items.push_back(lr);
-        il.push_back(lev[lr] - 1);
-        for (int e = cnt[lr]; e < cnt[lr + 1]; e++) {
-          ci.push_back(ei[e]);
-          cv.push_back(ev[e]);
-        }
-        es.push_back((int)ci.size());
-        dv.push_back(1.0);
+    std::sort(spaList.begin(), spaList.end());
+    xinv[f].reserve(spaList.size());
+    for (int j : spaList) {
+      if (spa[j] != 0.0)
+        xinv[f].push_back({ j, spa[j] });
+      spa[j] = 0.0;
+      spaMark[j] = 0;
+    }
+    spaList.clear();
+    fill += xinv[f].size();
+  }
+  tooMuch = fill > fillCap;
+  if (tooMuch) {
+    if (logLevel > 0)
+      fprintf(stderr, "clpgpu: LU front of %d pivots: explicit inverses exceed %zu entries, explicit nucleus inverse instead\n", nF, fillCap);
+    return -7;  // factorizeOnce falls back to the explicit inverse of the whole nucleus
+  }
+  LuTriHost Lf, Ub, Utf, Ltb;
+  auto flat = [&](LuTriHost &h, int nItems, const std::vector<int> &tg, const std::vector<int> &sr, const std::vector<double> &dv,
+                  const std::vector<int> &es, const std::vector<int> &ei, const std::vector<double> &ev) {
+    h.levelStart.assign(2, 0);
+    h.levelStart[1] = nItems;
+    h.tgt = tg;
+    h.src = sr;
+    h.div = dv;
+    h.entStart = es;
+    h.entIdx = ei;
+    h.entVal = ev;
+  };
+  {
+    // forward: item = local row r; source vectors are given BY ROW (global row indices)
+    std::vector<int> tg(k), sr(k), es(k + 1, 0), ei;
+    std::vector<double> dv(k, 1.0), ev;
+    for (int r = 0; r < k; r++) {
+      tg[r] = tailSlotOfRow[r] >= 0 ? k + tailSlotOfRow[r] : r;
+      sr[r] = rrows[r];
+      for (const auto &pr : linv[r]) {
+        ei.push_back(rrows[pr.first]);
+        ev.push_back(-pr.second);
       }
-    Lf.build((int)items.size(), il, items, items, dv, es, ci, cv);
+      es[r + 1] = (int)ei.size();
+    }
+    flat(Lf, k, tg, sr, dv, es, ei, ev);
   }
   {
-    // U backward: pivot f gathers its row (columns pivoted later or in the tail)
-    std::vector<int> lev(nF, 0), tg(nF), sr(nF);
-    std::vector<double> dv(nF);
-    for (int f = nF - 1; f >= 0; f--) {
-      int l = 0;
-      for (int e = F.uStart[f]; e < F.uStart[f + 1]; e++) {
-        const int f2 = pivOfCol[F.uCol[e]];
-        if (f2 >= 0)
-          l = std::max(l, lev[f2] + 1);
-      }
-      lev[f] = l;
+    // backward: item = front pivot f; out = (y[frow f] - sum val * src[idx]) / piv with val = -piv * xinv (off-diagonal)
+    std::vector<int> tg(nF), sr(nF), es(nF + 1, 0), ei;
+    std::vector<double> dv(nF), ev;
+    for (int f = 0; f < nF; f++) {
       tg[f] = F.fcol[f];
       sr[f] = F.frow[f];
-      dv[f] = F.fpiv[f];
+      double diag = 0.0;
+      for (const auto &pr : xinv[f])
+        if (pr.first == F.frow[f])
+          diag = pr.second;
+      dv[f] = 1.0 / diag;
+      for (const auto &pr : xinv[f])
+        if (pr.first != F.frow[f]) {
+          ei.push_back(pr.first);
+          ev.push_back(-pr.second / diag);
+        }
+      es[f + 1] = (int)ei.size();
     }
-    Ub.build(nF, lev, tg, sr, dv, F.uStart, F.uCol, F.uVal);
+    flat(Ub, nF, tg, sr, dv, es, ei, ev);
   }
   {
-    // U^T forward: column of pivot f2 gathers from the earlier pivot rows that hold an entry in it;
-    // tail columns likewise, in one final level
-    std::vector<int> cntF(nF + 1, 0), cntT(k2 + 1, 0), tailSlotOfCol(k, -1);
-    for (int tc = 0; tc < k2; tc++)
-      tailSlotOfCol[F.tailCol[tc]] = tc;
+    // BTRAN front: z_f = sum_f' xinv[f'][frow f] t[fcol f'] ; tail: zt[tc] = t[tailCol tc] + sum_f' xinv[f'][k + tc] t[fcol f']
+    // (transposes of the rows above; item order: front pivots, then tail column slots)
+    const int nI = nF + k2;
+    std::vector<int> cnt(nI + 1, 0);
+    auto itemOf = [&](int j) { return j < k ? pivOfRow[j] : nF + (j - k); };
     for (int f = 0; f < nF; f++)
-      for (int e = F.uStart[f]; e < F.uStart[f + 1]; e++) {
-        const int f2 = pivOfCol[F.uCol[e]];
-        if (f2 >= 0)
-          cntF[f2 + 1]++;
-        else
-          cntT[tailSlotOfCol[F.uCol[e]] + 1]++;
-      }
-    for (int i = 0; i < nF; i++)
-      cntF[i + 1] += cntF[i];
-    for (int i = 0; i < k2; i++)
-      cntT[i + 1] += cntT[i];
-    std::vector<int> eiF(cntF[nF]), eiT(cntT[k2]), atF(cntF.begin(), cntF.end() - 1), atT(cntT.begin(), cntT.end() - 1), lev(nF, 0);
-    std::vector<double> evF(cntF[nF]), evT(cntT[k2]);
+      for (const auto &pr : xinv[f])
+        if (pr.first != F.frow[f])
+          cnt[itemOf(pr.first) + 1]++;
+    for (int i = 0; i < nI; i++)
+      cnt[i + 1] += cnt[i];
+    std::vector<int> ei(cnt[nI]), at(cnt.begin(), cnt.end() - 1), tg(nI), sr(nI);
+    std::vector<double> ev(cnt[nI]), dv(nI, 1.0);
     for (int f = 0; f < nF; f++) {
-      const int lvf = lev[f];  // final: its column entries come from earlier pivots only
-      for (int e = F.uStart[f]; e < F.uStart[f + 1]; e++) {
-        const int f2 = pivOfCol[F.uCol[e]];
-        if (f2 >= 0) {
-          eiF[atF[f2]] = F.frow[f];
-          evF[atF[f2]] = F.uVal[e];
-          atF[f2]++;
-          lev[f2] = std::max(lev[f2], lvf + 1);
-        } else {
-          const int tc = tailSlotOfCol[F.uCol[e]];
-          eiT[atT[tc]] = F.frow[f];
-          evT[atT[tc]] = F.uVal[e];
-          atT[tc]++;
-        }
-      }
-    }
-    std::vector<int> tg(nF), sr(nF);
-    std::vector<double> dv(nF);
-    for (int f = 0; f < nF; f++) {
+      double diag = 0.0;
+      for (const auto &pr : xinv[f])
+        if (pr.first == F.frow[f])
+          diag = pr.second;
       tg[f] = F.frow[f];
       sr[f] = F.fcol[f];
-      dv[f] = F.fpiv[f];
+      dv[f] = 1.0 / diag;
     }
-    Utf.build(nF, lev, tg, sr, dv, cntF, eiF, evF);
-    std::vector<int> levT(k2, 0), tgT(k2), srT(k2);
-    std::vector<double> dvT(k2, 1.0);
     for (int tc = 0; tc < k2; tc++) {
-      tgT[tc] = tc;
-      srT[tc] = F.tailCol[tc];
+      tg[nF + tc] = k + tc;
+      sr[nF + tc] = F.tailCol[tc];
     }
-    UtT.build(k2, levT, tgT, srT, dvT, cntT, eiT, evT);
+    for (int f = 0; f < nF; f++)
+      for (const auto &pr : xinv[f])
+        if (pr.first != F.frow[f]) {
+          const int it = itemOf(pr.first);
+          ei[at[it]] = F.fcol[f];
+          // out = (t[src] - sum val t[idx]) / div  must equal  diag_it * t[src] + sum xinv * t[idx]
+          ev[at[it]] = -pr.second * dv[it];
+          at[it]++;
+        }
+    flat(Utf, nI, tg, sr, dv, cnt, ei, ev);
   }
   {
-    // L^T backward: pivot f gathers its column of multipliers (rows pivoted later or in the tail)
-    std::vector<int> lev(nF, 0), items, il, es(1, 0), ci;
-    std::vector<double> cv, dv;
-    for (int f = nF - 1; f >= 0; f--) {
-      int l = 0;
-      for (int e = F.lStart[f]; e < F.lStart[f + 1]; e++) {
-        const int f2 = pivOfRow[F.lRow[e]];
-        if (f2 >= 0)
-          l = std::max(l, lev[f2] + 1);
+    // BTRAN back: y_r = z_r + sum_r' linv[r'][r] z_r'   (transposed rows of L^-1 - I); item = local row r
+    std::vector<int> cnt(k + 1, 0);
+    for (int r2 = 0; r2 < k; r2++)
+      for (const auto &pr : linv[r2])
+        cnt[pr.first + 1]++;
+    for (int i = 0; i < k; i++)
+      cnt[i + 1] += cnt[i];
+    std::vector<int> ei(cnt[k]), at(cnt.begin(), cnt.end() - 1), tg(k), sr(k);
+    std::vector<double> ev(cnt[k]), dv(k, 1.0);
+    for (int r = 0; r < k; r++)
+      tg[r] = sr[r] = r;
+    for (int r2 = 0; r2 < k; r2++)
+      for (const auto &pr : linv[r2]) {
+        ei[at[pr.first]] = r2;
+        ev[at[pr.first]] = -pr.second;
+        at[pr.first]++;
       }
-      lev[f] = l;
-    }
-    // (a pivot without multipliers is not an item, but pivots depending on it see level 0 + 1: harmless)
-    for (int f = 0; f < nF; f++)
-      if (F.lStart[f + 1] > F.lStart[f]) {
-        items.push_back(F.frow[f]);
-        il.push_back(lev[f]);
-        for (int e = F.lStart[f]; e < F.lStart[f + 1]; e++) {
-          ci.push_back(F.lRow[e]);
-          cv.push_back(F.lVal[e]);
-        }
-        es.push_back((int)ci.size());
-        dv.push_back(1.0);
-      }
-    Ltb.build((int)items.size(), il, items, items, dv, es, ci, cv);
+    flat(Ltb, k, tg, sr, dv, cnt, ei, ev);
   }
+  luLastInverseFill = (long)fill;
   // ---- frozen slack rows (their U rows) by row
   std::vector<int> sRowIndex, sRowOf(m, -1);
   for (int i = 0; i < m; i++)
@@ -335,7 +423,6 @@ int clpgpu_context::factorizeLu(const std::vector<int> &kcol, const std::vector<
   rc |= luUploadTri(Lf, L.Lf, LB_TRI + 0);
   rc |= luUploadTri(Ub, L.Ub, LB_TRI + 7);
   rc |= luUploadTri(Utf, L.Utf, LB_TRI + 14);
-  rc |= luUploadTri(UtT, L.UtT, LB_TRI + 21);
   rc |= luUploadTri(Ltb, L.Ltb, LB_TRI + 28);
   int *ip = nullptr;
   double *dp = nullptr;
@@ -380,6 +467,7 @@ int clpgpu_context::factorizeLu(const std::vector<int> &kcol, const std::vector<
     dropGraph();  // launch extents of the eta-file kernels follow the capacity
     rc |= luBuf[LB_H].need(this, sizeof(double) * (size_t)L.tcap * (size_t)m, vp);
     rc |= luBuf[LB_G].need(this, sizeof(double) * (size_t)L.tcap * (size_t)L.tcap, vp);
+    rc |= luBuf[LB_GT].need(this, sizeof(double) * (size_t)L.tcap * (size_t)L.tcap, vp);
     rc |= luBuf[LB_P].need(this, sizeof(int) * (size_t)L.tcap, vp);
     rc |= luBuf[LB_PREV].need(this, sizeof(int) * (size_t)L.tcap, vp);
     rc |= luBuf[LB_NEXT].need(this, sizeof(int) * (size_t)L.tcap, vp);
@@ -389,6 +477,7 @@ int clpgpu_context::factorizeLu(const std::vector<int> &kcol, const std::vector<
   }
   L.H = (double *)luBuf[LB_H].p;
   L.G = (double *)luBuf[LB_G].p;
+  L.GT = (double *)luBuf[LB_GT].p;
   L.P = (int *)luBuf[LB_P].p;
   L.prevSame = (int *)luBuf[LB_PREV].p;
   L.nextSame = (int *)luBuf[LB_NEXT].p;
@@ -399,6 +488,8 @@ int clpgpu_context::factorizeLu(const std::vector<int> &kcol, const std::vector<
   L.lastOfPos = (int *)vp;
   if (rc)
     return rc;
+  if (checkLaunches("factorizeLu (uploads)"))
+    return -99;
   // the descriptor itself sits in device memory at a fixed address: captured launch graphs stay valid
   if (!dLu) {
     rc |= dalloc(dLu, 1);
@@ -408,6 +499,8 @@ int clpgpu_context::factorizeLu(const std::vector<int> &kcol, const std::vector<
   D.lu = dLu;
   D.luMode = 1;
   hipLaunchKernelGGL(k_lu_reset, dim3(cdiv(m, 256)), dim3(256), 0, stream, D);
+  if (checkLaunches("factorizeLu (reset)"))
+    return -99;
   // ---- the explicit-inverse bookkeeping is switched off: no row or column has a slot
   if (!luSlotsCleared) {
     std::vector<int> minusM(m, -1), minusN(n, -1);
@@ -433,10 +526,10 @@ int clpgpu_context::factorizeLu(const std::vector<int> &kcol, const std::vector<
   luLastFront = nF;
   luLastTail = k2;
   if (logLevel > 1)
-    fprintf(stderr, "clpgpu: LU factorization: nucleus %d = front %d (L %zu, U %zu nz; levels %d/%d/%d/%d) + dense tail %d (S %zu nz); host %.1f ms, "
-                    "inversion %.1f ms, build+upload %.1f ms\n",
-            k, nF, F.lRow.size(), F.uCol.size(), hLu.Lf.nLevels, hLu.Ub.nLevels, hLu.Utf.nLevels, hLu.Ltb.nLevels, k2, F.sVal.size(),
-            1e3 * std::chrono::duration<double>(t1 - t0).count(), 1e3 * std::chrono::duration<double>(t2 - t1).count(),
+    fprintf(stderr, "clpgpu: LU factorization: nucleus %d = front %d (L %zu, U %zu nz; explicit inverses %ld nz) + dense tail %d (S %zu nz); host %.1f ms, "
+                    "inversion %.1f ms (max |I - S X| %.2g), build+upload %.1f ms\n",
+            k, nF, F.lRow.size(), F.uCol.size(), luLastInverseFill, k2, F.sVal.size(),
+            1e3 * std::chrono::duration<double>(t1 - t0).count(), 1e3 * std::chrono::duration<double>(t2 - t1).count(), luLastResidual,
             1e3 * std::chrono::duration<double>(t3 - t2).count());
   return rc;
 }
@@ -447,15 +540,16 @@ int clpgpu_context::luFtran(const double *v0, const double *v1, double *o0, doub
 {
   const int k2 = hLu.k2, ns = hLu.ns;
   const int nrhs = v1 ? 2 : 1;
-  hipLaunchKernelGGL(k_lu_fwd, dim3(nrhs), dim3(1024), 0, stream, D, 0, v0, v1, (const double *)nullptr, D.slotA, v1 ? D.slotB : (double *)nullptr,
+  const int gm = cdiv(m, 256);
+  hipLaunchKernelGGL(k_lu_fwd, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 0, v0, v1, (const double *)nullptr, D.slotA, v1 ? D.slotB : (double *)nullptr,
                      (double *)nullptr);
   if (k2)
     hipLaunchKernelGGL(k_gemv2, dim3(cdiv(k2, 4)), dim3(256), 0, stream, D, (const double *)D.slotA, v1 ? (const double *)D.slotB : (const double *)nullptr,
                        D.slotC, v1 ? D.slotD : (double *)nullptr, 0);
-  hipLaunchKernelGGL(k_lu_bwd, dim3(nrhs), dim3(1024), 0, stream, D, 0, (const double *)D.slotC, (const double *)D.slotD, (const double *)nullptr, 1,
+  hipLaunchKernelGGL(k_lu_bwd, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 0, (const double *)D.slotC, (const double *)D.slotD, (const double *)nullptr, 1,
                      v1 ? 1 : 0, 0);
   if (ns)
-    hipLaunchKernelGGL(k_lu_slack, dim3(cdiv(ns, 256), nrhs), dim3(256), 0, stream, D, 0, v0, v1, (const double *)nullptr, 1, v1 ? 1 : 0, 0);
+    hipLaunchKernelGGL(k_lu_slack, dim3(cdiv(m, 256), nrhs), dim3(256), 0, stream, D, 0, v0, v1, (const double *)nullptr, 1, v1 ? 1 : 0, 0);
   hipLaunchKernelGGL(k_lu_pf_s, dim3(64), dim3(256), 0, stream, D, 0, 1, v1 ? 1 : 0, 0);
   hipLaunchKernelGGL(k_lu_pf_apply, dim3(cdiv(m, 256)), dim3(256), sizeof(double) * 3 * (size_t)hLu.tcap, stream, D, o0, o1, (double *)nullptr);
   return 0;
@@ -465,15 +559,15 @@ int clpgpu_context::luBtran(const double *cPos, double *yRow)
 {
   const int k = hLu.k, k2 = hLu.k2, ns = hLu.ns, tcap = hLu.tcap;
   hipLaunchKernelGGL(k_lu_pf_gdot, dim3(64), dim3(256), 0, stream, D, cPos);
-  hipLaunchKernelGGL(k_lu_pf_d, dim3(cdiv(tcap, 64)), dim3(256), 0, stream, D, 0);
+  hipLaunchKernelGGL(k_lu_pf_d, dim3(cdiv(tcap, 4)), dim3(256), 0, stream, D, 0);
   hipLaunchKernelGGL(k_lu_cprime, dim3(1), dim3(1024), 0, stream, D, 0, cPos);
-  hipLaunchKernelGGL(k_lu_bt_gather, dim3(cdiv(k + ns, 256)), dim3(256), 0, stream, D, 0, yRow);
-  hipLaunchKernelGGL(k_lu_bt_front, dim3(1), dim3(1024), 0, stream, D, 0, D.slotA);
+  hipLaunchKernelGGL(k_lu_bt_gather, dim3(cdiv(m, 32)), dim3(256), 0, stream, D, 0, yRow);
+  hipLaunchKernelGGL(k_lu_bt_front, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 0, D.slotA);
   if (k2) {
     hipLaunchKernelGGL(k_gemvT_partial, dim3(cdiv(k2, 256), cdiv(k2, 64)), dim3(256), 0, stream, D, (const double *)D.slotA, 0);
     hipLaunchKernelGGL(k_lu_gemvT_final, dim3(cdiv(k2, 256)), dim3(256), 0, stream, D, 0);
   }
-  hipLaunchKernelGGL(k_lu_bt_back, dim3(1), dim3(1024), 0, stream, D, 0, yRow);
+  hipLaunchKernelGGL(k_lu_bt_back, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 0, yRow);
   return 0;
 }
 
@@ -481,24 +575,23 @@ int clpgpu_context::luBtran(const double *cPos, double *yRow)
 void clpgpu_context::luLaunchBtran()
 {
   const int k = hLu.k, ns = hLu.ns, tcap = hLu.tcap, kc = kcap;
-  KL("k_lu_pf_d", k_lu_pf_d, dim3(cdiv(tcap, 64)), dim3(256), 0, stream, D, 1);
+  KL("k_lu_pf_d", k_lu_pf_d, dim3(cdiv(tcap, 4)), dim3(256), 0, stream, D, 1);
   KL("k_lu_cprime", k_lu_cprime, dim3(1), dim3(1024), 0, stream, D, 1, (const double *)nullptr);
-  KL("k_lu_bt_gather", k_lu_bt_gather, dim3(cdiv(k + ns, 256)), dim3(256), 0, stream, D, 1, hLu.y);
-  KL("k_lu_bt_front", k_lu_bt_front, dim3(1), dim3(1024), 0, stream, D, 1, D.slotA);
+  KL("k_lu_bt_gather", k_lu_bt_gather, dim3(cdiv(m, 32)), dim3(256), 0, stream, D, 1, (double *)nullptr);
+  KL("k_lu_bt_front", k_lu_bt_front, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, D.slotA);
   KL("k_gemvT_partial", k_gemvT_partial, dim3(cdiv(kc, 256), cdiv(kc, 64)), dim3(256), 0, stream, D, (const double *)D.slotA, 1);
   KL("k_lu_gemvT_final", k_lu_gemvT_final, dim3(cdiv(kc, 256)), dim3(256), 0, stream, D, 1);
-  KL("k_lu_bt_back", k_lu_bt_back, dim3(1), dim3(1024), 0, stream, D, 1, hLu.y);
+  KL("k_lu_bt_back", k_lu_bt_back, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, (double *)nullptr);
 }
 // ... and the three FTRANs (entering column, rho, flip rhs) up to the scatter with the eta file applied
 void clpgpu_context::luLaunchFtran(int gm, int parity)
 {
   const int ns = hLu.ns, kc = kcap;
-  KL("k_lu_fwd", k_lu_fwd, dim3(3), dim3(1024), 0, stream, D, 1, (const double *)D.vecV1, (const double *)D.rho, (const double *)D.flipRhs, D.slotV1,
+  KL("k_lu_fwd", k_lu_fwd, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, (const double *)D.vecV1, (const double *)D.rho, (const double *)D.flipRhs, D.slotV1,
      D.rhoSlotF, D.flipSlot);
   KL("k_gemv3g", k_gemv3g, dim3(cdiv(kc, GEMV_RPB)), dim3(1024), 0, stream, D);
-  KL("k_lu_bwd", k_lu_bwd, dim3(3), dim3(1024), 0, stream, D, 1, (const double *)D.slotC, (const double *)D.slotD, (const double *)D.slotE, 1, 1, 1);
-  if (ns)
-    KL("k_lu_slack", k_lu_slack, dim3(cdiv(ns, 256), 3), dim3(256), 0, stream, D, 1, (const double *)D.vecV1, (const double *)D.rho,
+  KL("k_lu_bwd", k_lu_bwd, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, (const double *)D.slotC, (const double *)D.slotD, (const double *)D.slotE, 1, 1, 1);
+  KL("k_lu_slack", k_lu_slack, dim3(cdiv(m, 256), 3), dim3(256), 0, stream, D, 1, (const double *)D.vecV1, (const double *)D.rho,
        (const double *)D.flipRhs, 1, 1, 1);
   KL("k_lu_pf_s", k_lu_pf_s, dim3(64), dim3(256), 0, stream, D, 1, 1, 1, 1);
   KL("k_ftran_scatter3_lu", k_ftran_scatter3_lu, dim3(gm), dim3(256), 0, stream, D, gm, parity);

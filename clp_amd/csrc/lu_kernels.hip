@@ -30,82 +30,146 @@ namespace clpgpu {
 // the factorization's descriptor lives in device memory (its sizes and pointers change at every refactorization
 // while the captured launch graphs stay valid)
 #define LUD (*D.lu)
+#define LU_TCAP_MAX 2048  // capacity of the eta file (rows of G, LDS staging of its vectors)
 
-__device__ inline void luSweep(const LuTri T, double *out, const double *srcv, const double *vec)
+// One sparse operator application in gather form: out[tgt] = (srcv[src] - sum val * vec[idx]) / div, every item
+// independent of the others.  The triangular factors of the front are applied through their EXPLICIT sparse
+// inverses (lu_host.hip builds them: on these LPs L^-1 and U11^-1 [I | -U12] hold < 2x the entries of L and U),
+// so a solve with the front is one such pass over the whole chip instead of a level-by-level dependency chain.
+// ---- FTRAN, front half: [y_F ; tail rhs] = L^-1 v for the three right-hand sides (given by row).
+// item = local nucleus row; target < k: a front row (work vector), >= k: tail slot target - k (the GEMV's input)
+__global__ void __launch_bounds__(256) k_lu_fwd(Dev D, int chain, const double *v0, const double *v1, const double *v2, double *t0,
+                                                double *t1, double *t2)
 {
-  for (int l = 0; l < T.nLevels; l++) {
-    const int a = T.levelStart[l], b = T.levelStart[l + 1];
-    for (int it = a + threadIdx.x; it < b; it += blockDim.x) {
-      double acc = srcv[T.src[it]];
-      const int e0 = T.entStart[it], e1 = T.entStart[it + 1];
-      for (int e = e0; e < e1; e++)
-        acc -= T.entVal[e] * vec[T.entIdx[e]];
-      out[T.tgt[it]] = acc / T.div[it];
+  const Ctrl *c = D.ctrl;
+  if (chain && c->state != RUN)
+    return;
+  const LuTri T = LUD.Lf;
+  // one wave per item: rows of the explicit inverses run from one entry to thousands
+  const int it = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (it >= T.nItems)
+    return;
+  bool l0 = v0 != nullptr, l1 = v1 != nullptr, l2 = v2 != nullptr;
+  if (chain) {
+    l1 = c->pivotRule != 0;
+    l2 = c->numberFlips != 0;
+  }
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  const int e0 = T.entStart[it], e1 = T.entStart[it + 1];
+  for (int e = e0 + lane; e < e1; e += 64) {
+    const int idx = T.entIdx[e];
+    const double val = T.entVal[e];
+    if (l0)
+      a0 -= val * v0[idx];
+    if (l1)
+      a1 -= val * v1[idx];
+    if (l2)
+      a2 -= val * v2[idx];
+  }
+  if (e1 - e0 > 1) {
+    a0 = waveSum(a0);
+    a1 = waveSum(a1);
+    a2 = waveSum(a2);
+  }
+  if (lane != 0)
+    return;
+  const int src = T.src[it];
+  a0 = l0 ? v0[src] + a0 : 0.0;
+  a1 = l1 ? v1[src] + a1 : 0.0;
+  a2 = l2 ? v2[src] + a2 : 0.0;
+  const int tgt = T.tgt[it], k = LUD.k, kpad = LUD.kpad;
+  if (tgt < k) {
+    LUD.wr[tgt] = a0;
+    LUD.wr[kpad + tgt] = a1;
+    LUD.wr[2 * kpad + tgt] = a2;
+  } else {
+    t0[tgt - k] = a0;
+    if (t1)
+      t1[tgt - k] = a1;
+    if (t2)
+      t2[tgt - k] = a2;
+  }
+}
+
+// ---- FTRAN, back half: x_F = U11^-1 (y_F - U12 x_T) as one pass (entries index y by local row, or x_T by
+// k + tail column slot); the tail columns copy x_T; both scatter by basis position and by local column
+__global__ void __launch_bounds__(256) k_lu_bwd(Dev D, int chain, const double *x0, const double *x1, const double *x2, int live0,
+                                                int live1, int live2)
+{
+  const Ctrl *c = D.ctrl;
+  if (chain && c->state != RUN)
+    return;
+  const LuTri T = LUD.Ub;
+  const int it = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int k = LUD.k, k2 = LUD.k2, kpad = LUD.kpad;
+  bool l0 = live0 != 0, l1 = live1 != 0, l2 = live2 != 0;
+  if (chain) {
+    l0 = true;
+    l1 = c->pivotRule != 0;
+    l2 = c->numberFlips != 0;
+  }
+  int col;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  if (it < T.nItems) {
+    const double *w0 = LUD.wr, *w1 = LUD.wr + kpad, *w2 = LUD.wr + 2 * kpad;
+    const int e0 = T.entStart[it], e1 = T.entStart[it + 1];
+    for (int e = e0 + lane; e < e1; e += 64) {
+      const int idx = T.entIdx[e];
+      const double val = T.entVal[e];
+      if (idx < k) {
+        if (l0)
+          a0 -= val * w0[idx];
+        if (l1)
+          a1 -= val * w1[idx];
+        if (l2)
+          a2 -= val * w2[idx];
+      } else {
+        if (l0)
+          a0 -= val * x0[idx - k];
+        if (l1)
+          a1 -= val * x1[idx - k];
+        if (l2)
+          a2 -= val * x2[idx - k];
+      }
     }
-    __syncthreads();
-  }
-}
-
-// ---- FTRAN, front half: gather the right-hand sides by nucleus row, L forward, hand the tail part to the GEMV.
-// One workgroup per right-hand side.  chain = 1: the three vectors of the pivot (entering column, pruned rho,
-// flip rhs) with the skip rules of k_gemv3g; chain = 0: the vectors given.
-__global__ void __launch_bounds__(1024) k_lu_fwd(Dev D, int chain, const double *v0, const double *v1, const double *v2, double *t0,
-                                                 double *t1, double *t2)
-{
-  const Ctrl *c = D.ctrl;
-  if (chain && c->state != RUN)
-    return;
-  const int r = blockIdx.x;
-  const double *v = r == 0 ? v0 : (r == 1 ? v1 : v2);
-  double *tout = r == 0 ? t0 : (r == 1 ? t1 : t2);
-  if (!tout)
-    return;
-  const int k = LUD.k, k2 = LUD.k2;
-  bool live = v != nullptr;
-  if (chain && r == 1)
-    live = c->pivotRule != 0;
-  if (chain && r == 2)
-    live = c->numberFlips != 0;
-  if (!live) {
-    for (int ts = threadIdx.x; ts < k2; ts += blockDim.x)
-      tout[ts] = 0.0;
+    if (e1 - e0 > 1) {
+      a0 = waveSum(a0);
+      a1 = waveSum(a1);
+      a2 = waveSum(a2);
+    }
+    if (lane != 0)
+      return;
+    const int src = T.src[it];
+    const double dv = T.div[it];
+    a0 = l0 ? (w0[src] + a0) / dv : 0.0;
+    a1 = l1 ? (w1[src] + a1) / dv : 0.0;
+    a2 = l2 ? (w2[src] + a2) / dv : 0.0;
+    col = T.tgt[it];
+  } else if (it < T.nItems + k2) {
+    if (lane != 0)
+      return;
+    const int tc = it - T.nItems;
+    col = LUD.tailCol[tc];
+    a0 = l0 ? x0[tc] : 0.0;
+    a1 = l1 ? x1[tc] : 0.0;
+    a2 = l2 ? x2[tc] : 0.0;
+  } else {
     return;
   }
-  double *wr = LUD.wr + (size_t)r * LUD.kpad;
-  for (int lr = threadIdx.x; lr < k; lr += blockDim.x)
-    wr[lr] = v[LUD.rowOfLocal[lr]];
-  __syncthreads();
-  luSweep(LUD.Lf, wr, wr, wr);
-  for (int ts = threadIdx.x; ts < k2; ts += blockDim.x)
-    tout[ts] = wr[LUD.tailRow[ts]];
-}
-
-// ---- FTRAN, back half: tail solution in, U backward, scatter by basis position
-__global__ void __launch_bounds__(1024) k_lu_bwd(Dev D, int chain, const double *x0, const double *x1, const double *x2, int live0,
-                                                 int live1, int live2)
-{
-  const Ctrl *c = D.ctrl;
-  if (chain && c->state != RUN)
-    return;
-  const int r = blockIdx.x;
-  const double *xt = r == 0 ? x0 : (r == 1 ? x1 : x2);
-  bool live = (r == 0 ? live0 : (r == 1 ? live1 : live2)) != 0;
-  if (chain && r == 1)
-    live = c->pivotRule != 0;
-  if (chain && r == 2)
-    live = c->numberFlips != 0;
-  if (!live)
-    return;
-  const int k = LUD.k, k2 = LUD.k2;
-  double *wr = LUD.wr + (size_t)r * LUD.kpad;
-  double *xc = LUD.xc + (size_t)r * LUD.kpad;
-  for (int tc = threadIdx.x; tc < k2; tc += blockDim.x)
-    xc[LUD.tailCol[tc]] = xt[tc];
-  __syncthreads();
-  luSweep(LUD.Ub, xc, wr, xc);
-  double *x0pos = LUD.x0 + (size_t)r * D.m;
-  for (int cc = threadIdx.x; cc < k; cc += blockDim.x)
-    x0pos[LUD.posOfCol[cc]] = xc[cc];
+  const int pos = LUD.posOfCol[col];
+  const size_t m = (size_t)D.m;
+  if (l0) {
+    LUD.xc[col] = a0;
+    LUD.x0[pos] = a0;
+  }
+  if (l1) {
+    LUD.xc[kpad + col] = a1;
+    LUD.x0[m + pos] = a1;
+  }
+  if (l2) {
+    LUD.xc[2 * kpad + col] = a2;
+    LUD.x0[2 * m + pos] = a2;
+  }
 }
 
 // ---- FTRAN, slack positions: x0[i] = A[i, K0] x_K0 - v[i] over the rows whose slack was basic at the
@@ -182,20 +246,19 @@ __device__ inline void luPfApply(const Dev &D, int t, int p, const double *s0, c
   const double *Hp = LUD.H + p;
   const size_t m = (size_t)D.m;
   int j = 0;
-  for (; j + 4 <= t; j += 4) {
-    const double h0 = Hp[(size_t)j * m], h1 = Hp[(size_t)(j + 1) * m], h2 = Hp[(size_t)(j + 2) * m], h3 = Hp[(size_t)(j + 3) * m];
-    x1 -= h0 * s0[j];
-    x2 -= h0 * s1[j];
-    x3 -= h0 * s2[j];
-    x1 -= h1 * s0[j + 1];
-    x2 -= h1 * s1[j + 1];
-    x3 -= h1 * s2[j + 1];
-    x1 -= h2 * s0[j + 2];
-    x2 -= h2 * s1[j + 2];
-    x3 -= h2 * s2[j + 2];
-    x1 -= h3 * s0[j + 3];
-    x2 -= h3 * s1[j + 3];
-    x3 -= h3 * s2[j + 3];
+  // eight independent loads per trip: one thread per position leaves few waves per CU, so the HBM stream
+  // needs its parallelism from within the thread
+  for (; j + 8 <= t; j += 8) {
+    double h[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      h[u] = Hp[(size_t)(j + u) * m];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      x1 -= h[u] * s0[j + u];
+      x2 -= h[u] * s1[j + u];
+      x3 -= h[u] * s2[j + u];
+    }
   }
   for (; j < t; j++) {
     const double h = Hp[(size_t)j * m];
@@ -246,31 +309,28 @@ __global__ void __launch_bounds__(256) k_lu_pf_gdot(Dev D, const double *cvec)
   }
 }
 
-// d = G^T g: workgroup b owns columns [64 b, 64 b + 64); its four waves take the rows j = w (mod 4), the four
-// partial sums are added in wave order
+// d = G^T g: one wave per column i of G = row i of the transposed copy GT (contiguous), lanes over the etas j >= i;
+// chain form: g_j = dir * eta_j[r], a scattered load per eta that every wave issues alongside its GT loads
 __global__ void __launch_bounds__(256) k_lu_pf_d(Dev D, int chain)
 {
   const Ctrl *c = D.ctrl;
   if (chain && c->state != RUN)
     return;
   const int t = c->pivots;
-  __shared__ double part[4][64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + lane;
-  if (blockIdx.x * 64 >= t)
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= t)
     return;
   const double dir = (double)c->directionOut;
   const int r = c->pivotRow;
+  const double *GTrow = LUD.GT + (size_t)i * LUD.tcap;
   double acc = 0.0;
-  for (int j = blockIdx.x * 64 + wv; j < t; j += 4) {
+  for (int j = i + lane; j < t; j += 64) {
     const double gj = chain ? dir * LUD.H[(size_t)j * D.m + r] : LUD.g[j];
-    if (i <= j)
-      acc += LUD.G[(size_t)j * LUD.tcap + i] * gj;
+    acc += GTrow[j] * gj;
   }
-  part[wv][lane] = acc;
-  __syncthreads();
-  if (wv == 0 && i < t)
-    LUD.d[i] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+  acc = waveSum(acc);
+  if (lane == 0)
+    LUD.d[i] = acc;
 }
 
 // c' = c - P d as a dense vector by position (luCp).  Etas that replaced the same position form a chain
@@ -316,26 +376,50 @@ __global__ void __launch_bounds__(256) k_lu_bt_gather(Dev D, int chain, double *
   const Ctrl *c = D.ctrl;
   if (chain && c->state != RUN)
     return;
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  // 8 lanes per nucleus column (a column holds a few dozen entries in slack rows); fixed 8-way tree
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int id = g >> 3, sub = g & 7;
   if (id < LUD.k) {
-    double acc = LUD.cp[LUD.posOfCol[id]];
-    for (int e = LUD.sColStart[id]; e < LUD.sColStart[id + 1]; e++)
+    double acc = 0.0;
+    for (int e = LUD.sColStart[id] + sub; e < LUD.sColStart[id + 1]; e += 8)
       acc += LUD.sColVal[e] * LUD.cp[LUD.sColRow[e]];
-    LUD.tcv[id] = acc;
-  } else if (id < LUD.k + LUD.ns) {
-    const int i = LUD.sRowIndex[id - LUD.k];
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    acc += __shfl_xor(acc, 4);
+    if (sub == 0)
+      LUD.tcv[id] = LUD.cp[LUD.posOfCol[id]] + acc;
+  }
+  if (g < LUD.ns) {
+    const int i = LUD.sRowIndex[g];
     (chain ? LUD.y : y)[i] = 0.0 - LUD.cp[i];
   }
 }
 
-// U^T forward over the front, then the tail's right-hand side (by tail column slot) for the GEMV^T
-__global__ void __launch_bounds__(1024) k_lu_bt_front(Dev D, int chain, double *zt)
+// z_F = U11^-T t_F and the tail's right-hand side t_T - U12^T z_F, one pass over the transposed explicit inverse
+// (every entry indexes t by local column).  target < k: local row of a front pivot (work vector), >= k: tail column slot
+__global__ void __launch_bounds__(256) k_lu_bt_front(Dev D, int chain, double *zt)
 {
   if (chain && D.ctrl->state != RUN)
     return;
-  double *wr = LUD.wr;
-  luSweep(LUD.Utf, wr, LUD.tcv, wr);
-  luSweep(LUD.UtT, zt, LUD.tcv, wr);
+  const LuTri T = LUD.Utf;
+  const int it = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (it >= T.nItems)
+    return;
+  const double *tcv = LUD.tcv;
+  double acc = 0.0;
+  const int e0 = T.entStart[it], e1 = T.entStart[it + 1];
+  for (int e = e0 + lane; e < e1; e += 64)
+    acc -= T.entVal[e] * tcv[T.entIdx[e]];
+  if (e1 - e0 > 1)
+    acc = waveSum(acc);
+  if (lane != 0)
+    return;
+  acc = (tcv[T.src[it]] + acc) / T.div[it];
+  const int tgt = T.tgt[it], k = LUD.k;
+  if (tgt < k)
+    LUD.wr[tgt] = acc;
+  else
+    zt[tgt - k] = acc;
 }
 
 // y_T = Minv^T z_T from the per-chunk partials of k_gemvT_partial, left by tail row slot in the work vector
@@ -354,33 +438,42 @@ __global__ void __launch_bounds__(256) k_lu_gemvT_final(Dev D, int chain)
   LUD.wr[LUD.tailRow[sr]] = acc;
 }
 
-// L^T backward, result by row; the sparse c' is cleared again
-__global__ void __launch_bounds__(1024) k_lu_bt_back(Dev D, int chain, double *y)
+// y = L^-T z (z_F by front row and y_T by tail row in the work vector), result by row; c' is cleared again
+__global__ void __launch_bounds__(256) k_lu_bt_back(Dev D, int chain, double *y)
 {
   const Ctrl *c = D.ctrl;
   if (chain && c->state != RUN)
     return;
-  double *wr = LUD.wr;
-  luSweep(LUD.Ltb, wr, wr, wr);
-  const int k = LUD.k;
+  const LuTri T = LUD.Ltb;
+  const int it = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   double *yout = chain ? LUD.y : y;
-  for (int lr = threadIdx.x; lr < k; lr += blockDim.x)
-    yout[LUD.rowOfLocal[lr]] = wr[lr];
-  if (chain) {
-    const int t = c->pivots;
-    if (threadIdx.x == 0)
-      LUD.cp[c->pivotRow] = 0.0;
-    __syncthreads();
-    for (int j = threadIdx.x; j < t; j += blockDim.x)
-      LUD.cp[LUD.P[j]] = 0.0;
-  } else {
-    for (int p = threadIdx.x; p < D.m; p += blockDim.x)
-      LUD.cp[p] = 0.0;
+  // c' back to zero (nothing below reads it): chain form at the pivot row and the eta positions, generic form everywhere
+  {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (chain) {
+      if (g == 0)
+        LUD.cp[c->pivotRow] = 0.0;
+      if (g < c->pivots)
+        LUD.cp[LUD.P[g]] = 0.0;
+    } else if (g < D.m) {
+      LUD.cp[g] = 0.0;
+    }
   }
+  if (it >= T.nItems)
+    return;
+  const double *wr = LUD.wr;
+  double acc = 0.0;
+  const int e0 = T.entStart[it], e1 = T.entStart[it + 1];
+  for (int e = e0 + lane; e < e1; e += 64)
+    acc -= T.entVal[e] * wr[T.entIdx[e]];
+  if (e1 - e0 > 1)
+    acc = waveSum(acc);
+  if (lane == 0)
+    yout[LUD.rowOfLocal[T.tgt[it]]] = wr[T.src[it]] + acc;
 }
 
 // ---- the update: a new eta (column t of H), its position, and row t of G.
-// Workgroups [0, gm): eta = (w - e_r) / alpha over the m positions; the rest: 64 columns of the new row of G each.
+// Workgroups [0, gm): eta = (w - e_r) / alpha over the m positions; the rest: a wave per column of the new row of G.
 // n_t[j] = eta_j[r] (j < t); G[t][i] = -sum_{j >= i} n_t[j] G[j][i]; G[t][t] = 1.
 __global__ void __launch_bounds__(256) k_lu_pf_append(Dev D, int chain, int gm)
 {
@@ -409,29 +502,26 @@ __global__ void __launch_bounds__(256) k_lu_pf_append(Dev D, int chain, int gm)
         LUD.nextSame[prev] = t;
       LUD.lastOfPos[r] = t;
       LUD.G[(size_t)t * LUD.tcap + t] = 1.0;
+      LUD.GT[(size_t)t * LUD.tcap + t] = 1.0;
     }
     return;
   }
-  const int b = blockIdx.x - gm;
-  if (b * 64 >= t)
+  // row t of G (and column t of GT): one wave per column i < t
+  const int i = (blockIdx.x - gm) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= t)
     return;
-  __shared__ double part[4][64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int i = b * 64 + lane;
+  const double *GTrow = LUD.GT + (size_t)i * LUD.tcap;
   double acc = 0.0;
-  for (int j = b * 64 + wv; j < t; j += 4) {
-    const double nj = LUD.H[(size_t)j * D.m + r];
-    if (i <= j)
-      acc += nj * LUD.G[(size_t)j * LUD.tcap + i];
+  for (int j = i + lane; j < t; j += 64)
+    acc += LUD.H[(size_t)j * D.m + r] * GTrow[j];
+  acc = waveSum(acc);
+  if (lane == 0) {
+    LUD.G[(size_t)t * LUD.tcap + i] = 0.0 - acc;
+    LUD.GT[(size_t)i * LUD.tcap + t] = 0.0 - acc;
   }
-  part[wv][lane] = acc;
-  __syncthreads();
-  if (wv == 0 && i < t)
-    LUD.G[(size_t)t * LUD.tcap + i] = 0.0 - (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]);
 }
 
 // LU mode: x = x0 - H s per basis position (x0 from the k_lu_* sweeps, s from k_lu_pf_s), then the same back end
-#define LU_TCAP_MAX 2048
 __global__ void __launch_bounds__(256) k_ftran_scatter3_lu(Dev D, int nbNorm, int parity)
 {
   const Ctrl *c = D.ctrl;

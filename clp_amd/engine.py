@@ -170,6 +170,9 @@ class ClpGpuSimplex:
             raise RuntimeError(f"{what} failed ({rc}): {lib().clpgpu_last_error(self._h).decode()}")
 
     # ---- ClpModel / ClpSimplex surface --------------------------------------------------------
+    def lastError(self):
+        return lib().clpgpu_last_error(self._h).decode()
+
     def loadProblem(self, lp):
         c = np.ascontiguousarray
         self.m, self.n = int(lp.m), int(lp.n)

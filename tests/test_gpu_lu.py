@@ -43,6 +43,11 @@ def rel(a, b):
     return float(np.max(np.abs(a - b) / (1.0 + np.abs(b)))) if len(a) else 0.0
 
 
+def nrel(a, b):
+    """normwise relative error of a solve vector (the measure a backward-stable solver is held to)"""
+    return float(np.max(np.abs(a - b)) / (1.0 + np.max(np.abs(b)))) if len(a) else 0.0
+
+
 def basis_matrix(lp, pv):
     """B by basis position: column p is the column of variable pv[p] in [A | -I]."""
     m, n = lp.m, lp.n
@@ -89,7 +94,7 @@ def test_lu_solves_and_eta_file(gpu_cls, args, npiv, density):
     g.set_option("lu_min_tail", 4)
     rng = np.random.default_rng(5)
     rc, pv = g.factorize(status)
-    assert rc == 0
+    assert rc == 0, g.lastError()
     assert sorted(int(s) for s in pv) == sorted(int(i) for i in np.nonzero(status == 1)[0])
     st = g.stats()
     assert st["lu_active"] == 1 and st["lu_front"] + st["lu_tail"] == k
@@ -106,17 +111,17 @@ def test_lu_solves_and_eta_file(gpu_cls, args, npiv, density):
         for _ in range(3):
             v = rng.standard_normal(m) * (rng.random(m) < 0.6)
             x, y = g.ftran(v), g.btran(v)
-            assert rel(x, lu.solve(v)) < tol
-            assert rel(y, lu.solve(v, trans="T")) < tol
+            assert nrel(x, lu.solve(v)) < tol
+            assert nrel(y, lu.solve(v, trans="T")) < tol
             if o is not None:
                 # by variable: x[pos] belongs to pv[pos] here and to po[pos] in the oracle
                 xo = o.ftran(v)
                 byseq = np.zeros(n + m)
                 byseq[po_now] = xo
-                assert rel(x, byseq[pv]) < tol
+                assert nrel(x, byseq[pv]) < tol
                 cseq = np.zeros(n + m)
                 cseq[pv] = v
-                assert rel(y, o.btran(cseq[po_now])) < tol
+                assert nrel(y, o.btran(cseq[po_now])) < tol
 
     po_now = po.copy() if o is not None else None
     pv = pv.copy()
@@ -170,7 +175,7 @@ def test_lu_engine_solves_match_oracle(gpu_cls, args, rule):
         g.set_option("lu_min_tail", 4)
         assert g.dual() == 0
         assert g.stats()["lu_factorizations"] > 0
-        assert abs(g.objectiveValue() - o.objectiveValue()) <= 1e-8 * (1.0 + abs(o.objectiveValue()))
+        assert abs(g.objectiveValue() - o.objective) <= 1e-8 * (1.0 + abs(o.objective))
         assert rel(g.solution(), o.solution()) < 1e-7
         assert rel(g.solution(), base.solution()) < 1e-7
         # same pivots as the explicit-inverse engine as long as no tie is broken by basis position
