@@ -114,6 +114,7 @@ struct LuDev {
   const double *sRowVal;
   const int *sColStart, *sColRow;  // sColRow holds ROW INDICES (positions of the slacks)
   const double *sColVal;
+  const double *MinvT;  // [k2 x ld] transpose of the tail inverse (the BTRAN's contiguous rows)
   // work
   double *wr, *xc;     // [3 * kpad] by local nucleus row / column
   double *tcv;         // [kpad]

@@ -2370,6 +2370,7 @@ __device__ inline void priceSellBody(Dev D, unsigned long long *bits, int countC
     const int idx = slice * 64 + lane;
     const int j = D.sellCol[idx];
     int len = 0, wanted = 0;
+    int hits = -1;  // elements really fetched (conditional form); -1: all of them
     if (j >= 0) {
       wanted = (D.status[j] & 3) - 1;
       if (wanted)
@@ -2420,6 +2421,7 @@ __device__ inline void priceSellBody(Dev D, unsigned long long *bits, int countC
       } else if (COND && sparsePi) {
         // pi is sparse: stream the row indices, fetch element and pi only where the row's bit is
         // set.  Skipped products are exact zeros in the unconditional loop, so the sum is the same.
+        hits = 0;
         for (int t = 0; t < maxLen; t += SELL_U) {
           int r[SELL_U];
           double e[SELL_U], pv[SELL_U];
@@ -2439,8 +2441,10 @@ __device__ inline void priceSellBody(Dev D, unsigned long long *bits, int countC
           }
 #pragma unroll
           for (int u = 0; u < SELL_U; u++)
-            if (hit[u])
+            if (hit[u]) {
               value += pv[u] * e[u];
+              hits++;
+            }
         }
       } else {
         for (int t = 0; t < maxLen; t += SELL_U) {
@@ -2464,7 +2468,9 @@ __device__ inline void priceSellBody(Dev D, unsigned long long *bits, int countC
     if (j >= 0) {
       int flag = 0;
       if (wanted) {
-        bytes = 12.0 * len + 4.0;
+        // bytes this column really streams: every row index (4 B), the element (8 B) only where it is fetched --
+        // all of them in the unconditional forms, those under a set bit of pi in the conditional one
+        bytes = 4.0 * len + 8.0 * (hits < 0 ? len : hits) + 4.0;
         if (fabs(value) > zeroTolerance) {
           bytes += 20.0;
           if (wanted > 0) {

@@ -167,6 +167,9 @@ int clpgpu_context::factorizeLu(const std::vector<int> &kcol, const std::vector<
     if (pending != hipSuccess && logLevel > 0)
       fprintf(stderr, "clpgpu: (cleared after the tail polish: %s)\n", hipGetErrorString(pending));
   }
+  if (k2)
+    hipLaunchKernelGGL(k_lu_transpose_tail, dim3(cdiv(k2, 32), cdiv(k2, 32)), dim3(256), 0, stream, D, k2, D.workX);
+  hLu.MinvT = D.workX;  // (free until the next refactorization; allocNucleus drops the graphs when it moves)
   const auto t2 = std::chrono::steady_clock::now();
   // ---- positions: front pivot f puts column fcol[f] at the position of row frow[f]; the tail as the
   // dense pivoting decided
@@ -563,10 +566,8 @@ int clpgpu_context::luBtran(const double *cPos, double *yRow)
   hipLaunchKernelGGL(k_lu_cprime, dim3(1), dim3(1024), 0, stream, D, 0, cPos);
   hipLaunchKernelGGL(k_lu_bt_gather, dim3(cdiv(m, 32)), dim3(256), 0, stream, D, 0, yRow);
   hipLaunchKernelGGL(k_lu_bt_front, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 0, D.slotA);
-  if (k2) {
-    hipLaunchKernelGGL(k_gemvT_partial, dim3(cdiv(k2, 256), cdiv(k2, 64)), dim3(256), 0, stream, D, (const double *)D.slotA, 0);
-    hipLaunchKernelGGL(k_lu_gemvT_final, dim3(cdiv(k2, 256)), dim3(256), 0, stream, D, 0);
-  }
+  if (k2)
+    hipLaunchKernelGGL(k_lu_gemvT, dim3(cdiv(k2, 4)), dim3(256), 0, stream, D, 0, (const double *)D.slotA);
   hipLaunchKernelGGL(k_lu_bt_back, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 0, yRow);
   return 0;
 }
@@ -579,8 +580,7 @@ void clpgpu_context::luLaunchBtran()
   KL("k_lu_cprime", k_lu_cprime, dim3(1), dim3(1024), 0, stream, D, 1, (const double *)nullptr);
   KL("k_lu_bt_gather", k_lu_bt_gather, dim3(cdiv(m, 32)), dim3(256), 0, stream, D, 1, (double *)nullptr);
   KL("k_lu_bt_front", k_lu_bt_front, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, D.slotA);
-  KL("k_gemvT_partial", k_gemvT_partial, dim3(cdiv(kc, 256), cdiv(kc, 64)), dim3(256), 0, stream, D, (const double *)D.slotA, 1);
-  KL("k_lu_gemvT_final", k_lu_gemvT_final, dim3(cdiv(kc, 256)), dim3(256), 0, stream, D, 1);
+  KL("k_lu_gemvT", k_lu_gemvT, dim3(cdiv(kc, 4)), dim3(256), 0, stream, D, 1, (const double *)D.slotA);
   KL("k_lu_bt_back", k_lu_bt_back, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, (double *)nullptr);
 }
 // ... and the three FTRANs (entering column, rho, flip rhs) up to the scatter with the eta file applied

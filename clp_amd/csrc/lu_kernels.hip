@@ -422,20 +422,46 @@ __global__ void __launch_bounds__(256) k_lu_bt_front(Dev D, int chain, double *z
     zt[tgt - k] = acc;
 }
 
-// y_T = Minv^T z_T from the per-chunk partials of k_gemvT_partial, left by tail row slot in the work vector
-__global__ void __launch_bounds__(256) k_lu_gemvT_final(Dev D, int chain)
+// y_T = S^-T z_T: the tail inverse is frozen between refactorizations, so its transpose is kept as well
+// (k_lu_transpose_tail, once per refactorization) and the BTRAN streams contiguous rows like the FTRAN does:
+// one wave per tail row slot, result straight into the work vector by local row
+__global__ void __launch_bounds__(256) k_lu_gemvT(Dev D, int chain, const double *zt)
 {
   if (chain && D.ctrl->state != RUN)
     return;
   const int k2 = LUD.k2;
-  const int sr = blockIdx.x * blockDim.x + threadIdx.x;
-  if (sr >= k2)
-    return;
-  const int nchunk = (k2 + 63) >> 6;
-  double acc = 0.0;
-  for (int ch = 0; ch < nchunk; ch++)
-    acc += D.partial[(size_t)ch * D.ld + sr];
-  LUD.wr[LUD.tailRow[sr]] = acc;
+  const int lane = threadIdx.x & 63;
+  for (int ts = blockIdx.x * 4 + (threadIdx.x >> 6); ts < k2; ts += gridDim.x * 4) {
+    const double *row = LUD.MinvT + (size_t)ts * D.ld;
+    double a0 = 0.0, a1 = 0.0;
+    int i = lane;
+    for (; i + 64 < k2; i += 128) {
+      a0 += row[i] * zt[i];
+      a1 += row[i + 64] * zt[i + 64];
+    }
+    if (i < k2)
+      a0 += row[i] * zt[i];
+    const double acc = waveSum(a0 + a1);
+    if (lane == 0)
+      LUD.wr[LUD.tailRow[ts]] = acc;
+  }
+}
+// MinvT[ts][tc] = Minv[tc][ts], 32 x 32 tiles through LDS
+__global__ void __launch_bounds__(256) k_lu_transpose_tail(Dev D, int k2, double *out)
+{
+  __shared__ double tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int row = by + r, col = bx + tx;
+    tile[r][tx] = (row < k2 && col < k2) ? D.Minv[(size_t)row * D.ld + col] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int row = bx + r, col = by + tx;
+    if (row < k2 && col < k2)
+      out[(size_t)row * D.ld + col] = tile[tx][r];
+  }
 }
 
 // y = L^-T z (z_F by front row and y_T by tail row in the work vector), result by row; c' is cleared again
