@@ -143,7 +143,7 @@ struct clpgpu_context {
   // Markowitz front (host, at the refactorization) + a dense tail inverted on the matrix cores, with a
   // product-form eta file between refactorizations.  Option "factor_mode": 0 = explicit inverse of the whole
   // nucleus (rank-1 updated), 1 = LU, -1 (default) = LU from "lu_min_k" basic structurals on (sparse LPs, one GPU).
-  int factorMode = -1, luMinK = 3072, luMaxPivots = 1000, luMinTail = 16;
+  int factorMode = -1, luMinK = 3072, luMaxPivots = 2000, luMinTail = 16;
   double luStopDensity = 0.012, luThreshold = 0.1;
   bool luActive = false, luSlotsCleared = false;
   LuFront luF;

@@ -213,3 +213,25 @@ def test_lu_full_size_matches_inverse_mode(gpu_cls):
     if same == 2500:
         assert abs(runs[1].objectiveValue() - runs[0].objectiveValue()) <= 1e-9 * abs(runs[0].objectiveValue())
         assert rel(runs[1].solution(), runs[0].solution()) < 1e-7
+
+
+def test_lu_solve_matches_independent_solver(gpu_cls):
+    """End to end against an INDEPENDENT solver: HiGHS' dual simplex (scipy) on a config-4-shaped LP small enough
+    for it to finish; the engine runs in LU mode from a nucleus of 256 on.  Objective to 1e-8 relative."""
+    from scipy.optimize import linprog
+
+    lp = P.sparse_lp(3000, 12000, 12, seed=23)
+    m, n = lp.m, lp.n
+    A = sp.csc_matrix((lp.elem, lp.row, lp.col_start), shape=(m, n))
+    Aeq = sp.hstack([A, -sp.identity(m, format="csc")]).tocsr()
+    bounds = np.column_stack([np.concatenate([lp.col_lower, lp.row_lower]), np.concatenate([lp.col_upper, lp.row_upper])])
+    r = linprog(np.concatenate([lp.obj, np.zeros(m)]), A_eq=Aeq, b_eq=np.zeros(m), bounds=bounds, method="highs-ds")
+    assert r.status == 0
+    g = gpu_cls().loadProblem(lp)
+    g.set_option("pivot_rule", 1)
+    g.set_option("check_every", 16)
+    g.set_option("max_pivots", 0)
+    g.set_option("lu_min_k", 256)
+    assert g.dual() == 0
+    assert g.stats()["lu_factorizations"] > 0
+    assert abs(g.objectiveValue() - r.fun) <= 1e-8 * abs(r.fun)
