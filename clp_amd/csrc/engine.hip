@@ -119,6 +119,7 @@ struct clpgpu_context {
   // 0 = never), "refresh_max", "refresh_tolerance", "refresh_refine".
   int refreshMinK = 6144, refreshMax = 15, consecutiveRefreshes = 0, numberRefreshes = 0, numberRefreshesRejected = 0;
   double refreshTolerance = 1.0e-6;
+  int lastExitState = EXIT_REFACTOR;  // why the iteration loop last stopped (whileIterating)
   bool refreshEligible();
   int refreshFactor();
   // option "refresh_refine" (default 1): before the check, one Newton-Schulz step X += X (I - C X) on the kept
@@ -130,6 +131,10 @@ struct clpgpu_context {
   // tailFromS: the matrix is the LU mode's dense tail (its entries are still on the device as triplets);
   // goodBelow: return 3 without a step when max |I - C X| is already below it
   int refineInverse(bool tailFromS = false, double goodBelow = 0.0);
+  // option "gemm_backend": 0 = the engine's own MFMA f64 GEMM (gemm_kernel.hip, default), 1 = rocBLAS dgemm loaded at
+  // run time (kept as the comparison point SURVEY section 7 allows)
+  int gemmBackend = 0;
+  int dgemmDevice(int nn, double alpha, const double *A, const double *B, double beta, double *C);
   int luPolish = 2, numberPolishSteps = 0;
   double luPolishTolerance = 1.0e-11, luLastResidual = 0.0;
   int numberThrownOut = 0;  // structurals replaced by slacks by the singular-basis repair, whole solve
@@ -154,6 +159,9 @@ struct clpgpu_context {
   long luFactorizations = 0;
   int luLastFront = 0, luLastTail = 0;
   long luLastInverseFill = 0;
+  // option "lu_adaptive" (default 1): the eta file's length follows the measured refactorization time
+  int luAdaptive = 1, luMinPivots = 200, luEtaLimit = 1000;
+  double luRefactorSeconds = 0.0;
   double luInverseFillCap = 6.0e6;  // option "lu_inverse_fill_cap"
   int luUploadTri(const LuTriHost &h, LuTri &d, int slot);
   int luFtran(const double *v0, const double *v1, double *o0, double *o1);
@@ -2026,6 +2034,12 @@ bool clpgpu_context::refreshEligible()
 {
   if (refreshMinK <= 0 || !blockedRefactor || rebuildRowCopy || forceFactorization == 1 || !hCtrl || luActive)
     return false;
+  // only a SCHEDULED refactorization may keep the inverse: an exit raised by the numerics (alpha mismatch, bad
+  // update, objective going backwards, no pivot row / no entering column) asks for a clean factorization, as
+  // the reference gives it (ClpSimplexDual.cpp:1451-1500, :1574, :1618); nor in column-sharded runs, where every
+  // rank would have to take the same accept / reject decision
+  if (lastExitState != EXIT_REFACTOR || commActive)
+    return false;
   const int k = hCtrl->k;
   // (long rows: the re-inversion is a larger share of a pivot's cost already at a few thousand, and both halves
   // of the step are GEMMs there; no parity test solves a dense LP with a nucleus beyond a few hundred)
@@ -2044,8 +2058,56 @@ static void *rocblasLibrary()
     h = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
   return h;
 }
+// C = beta C + alpha A B (n x n, row-major, leading dimension ld) on the engine's own MFMA kernel
+int clpgpu_context::dgemmDevice(int nn, double alpha, const double *A, const double *B, double beta, double *C)
+{
+  hipLaunchKernelGGL(k_dgemm, dim3(cdiv(nn, DG_T), cdiv(nn, DG_T)), dim3(256), 0, stream, nn, nn, nn, alpha, A, ld, B, ld, beta, C, ld);
+  return 0;
+}
+
 int clpgpu_context::refineInverse(bool tailFromS, double goodBelow)
 {
+  if (!gemmBackend) {
+    // the engine's own GEMM (default): no library involved
+    const int k = tailFromS ? hLu.k2 : hCtrl->k;
+    const size_t mat = (size_t)k * ld * sizeof(double);
+    unsigned long long *dMax = (unsigned long long *)D.normPartial;
+    if (hipMemsetAsync(dMax, 0, sizeof(unsigned long long), stream) != hipSuccess)
+      return 1;
+    if (wideRows || tailFromS) {
+      if (hipMemsetAsync(D.workW, 0, mat, stream) != hipSuccess || hipMemsetAsync(D.workX, 0, mat, stream) != hipSuccess)
+        return 1;
+      if (tailFromS) {
+        const int snz = (int)luF.sVal.size();
+        if (snz)
+          hipLaunchKernelGGL(k_lu_scatter_tail, dim3(cdiv(snz, 256)), dim3(256), 0, stream, D, (const int *)luBuf[LB_SROW].p,
+                             (const int *)luBuf[LB_SCOL].p, (const double *)luBuf[LB_SVAL].p, snz);
+      } else {
+        hipLaunchKernelGGL(k_gather_slots, dim3(k), dim3(64), 0, stream, D, k, D.workW);
+      }
+      hipLaunchKernelGGL(k_identity, dim3(cdiv(k, 256)), dim3(256), 0, stream, D, k);
+      dgemmDevice(k, -1.0, D.workW, D.Minv, 1.0, D.workX);  // R = I - C X
+      hipLaunchKernelGGL(k_absmax_rows, dim3(k), dim3(256), 0, stream, D, k, (const double *)D.workX, dMax);
+    } else {
+      hipLaunchKernelGGL(k_refine_residual, dim3(k), dim3(256), 0, stream, D, k, D.workX, dMax);
+    }
+    unsigned long long bits = 0;
+    if (checkLaunches("refineInverse") || d2h(&bits, dMax, 1))
+      return 1;
+    memcpy(&lastResidual, &bits, sizeof(double));
+    if (!(lastResidual <= (tailFromS ? 0.5 : refreshResidualMax)))
+      return 2;  // too far for one step (or not finite): re-invert
+    if (lastResidual < goodBelow)
+      return 3;  // nothing to gain
+    // X <- X + X R  (into workW, then back)
+    if (hipMemcpyAsync(D.workW, D.Minv, mat, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+      return 1;
+    dgemmDevice(k, 1.0, D.Minv, D.workX, 1.0, D.workW);
+    if (hipMemcpyAsync(D.Minv, D.workW, mat, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+      return 1;
+    numberRefines++;
+    return checkLaunches("refineInverse (step)") ? 1 : 0;
+  }
   typedef int (*create_t)(void **);
   typedef int (*stream_t)(void *, hipStream_t);
   typedef int (*dgemm_t)(void *, int, int, int, int, int, const double *, const double *, int, const double *, int, const double *, double *, int);
@@ -2662,7 +2724,7 @@ int clpgpu_context::whileIterating(int stepTarget)
   hCtrl->forceFactorization = forceFactorization;
   hCtrl->numberChanged = numberChanged;
   hCtrl->lastBadIteration = lastBadIteration;
-  hCtrl->maximumPivots = luActive ? std::min(luMaxPivots, hLu.tcap - 1) : maximumPivots;
+  hCtrl->maximumPivots = luActive ? luEtaLimit : maximumPivots;
   hCtrl->maximumIterations = maximumIterations;
   int rc = pushCtrl();
   if (timing && evStart.empty()) {
@@ -2734,6 +2796,7 @@ int clpgpu_context::whileIterating(int stepTarget)
   acceptablePivot = hCtrl->acceptablePivotBase;
   seed = hCtrl->seed;
   const int state = hCtrl->state;
+  lastExitState = state;
   const int g = cdiv(m, 256);
   if (state != EXIT_REFACTOR && state != EXIT_STEP_LIMIT && state != EXIT_MAX_ITERATIONS) {
     // the pivot was abandoned part-way: k_house did not clear the sparse work vectors
@@ -3231,7 +3294,7 @@ int clpgpu_replace_column(clpgpu_context *ctx, int pivotRow, int sequenceIn, dou
   (void)acceptablePivot;
   const int m = ctx->m, n = ctx->n;
   Ctrl *h = ctx->hCtrl;
-  if (h->pivots >= (ctx->luActive ? std::min(ctx->luMaxPivots, ctx->hLu.tcap - 1) : ctx->maximumPivots))
+  if (h->pivots >= (ctx->luActive ? ctx->luEtaLimit : ctx->maximumPivots))
     return 5;
   if (ctx->luActive) {
     // LU mode: w = B^-1 a_q through the factorization and the eta file, then one more eta
@@ -3366,6 +3429,33 @@ int clpgpu_replace_column(clpgpu_context *ctx, int pivotRow, int sequenceIn, dou
 }
 
 int clpgpu_pivots(const clpgpu_context *ctx) { return (ctx && ctx->hCtrl) ? ctx->hCtrl->pivots : 0; }
+
+// the engine's own f64 MFMA GEMM on host arrays (row-major n x n): c = beta c + alpha a b.  A parity hook for the
+// kernel behind the Newton-Schulz steps (CoinAbcDgemm's role, src/CoinAbcHelperFunctions.cpp:1658).
+int clpgpu_dgemm(clpgpu_context *ctx, int nn, double alpha, const double *a, const double *b, double beta, double *c)
+{
+  if (!ctx || nn <= 0)
+    return -99;
+  double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  const size_t bytes = sizeof(double) * (size_t)nn * nn;
+  if (hipMalloc((void **)&dA, bytes) != hipSuccess || hipMalloc((void **)&dB, bytes) != hipSuccess || hipMalloc((void **)&dC, bytes) != hipSuccess) {
+    if (dA) (void)hipFree(dA);
+    if (dB) (void)hipFree(dB);
+    ctx->setError("clpgpu_dgemm: hipMalloc failed");
+    return -99;
+  }
+  int rc = ctx->h2d(dA, a, (size_t)nn * nn);
+  rc |= ctx->h2d(dB, b, (size_t)nn * nn);
+  rc |= ctx->h2d(dC, c, (size_t)nn * nn);
+  hipLaunchKernelGGL(k_dgemm, dim3(cdiv(nn, DG_T), cdiv(nn, DG_T)), dim3(256), 0, ctx->stream, nn, nn, nn, alpha, (const double *)dA, nn,
+                     (const double *)dB, nn, beta, dC, nn);
+  rc |= ctx->checkLaunches("clpgpu_dgemm");
+  rc |= ctx->d2h(c, dC, (size_t)nn * nn);
+  (void)hipFree(dA);
+  (void)hipFree(dB);
+  (void)hipFree(dC);
+  return rc;
+}
 
 // ---- ClpFactorization::updateColumnFT / updateTwoColumnsFT (src/ClpFactorization.cpp:2723, :2889) ----
 // With the explicit nucleus inverse there is no Forrest-Tomlin stash to fill: the "FT" solve is the
@@ -3816,6 +3906,7 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "refactor_min_k")) ctx->refactorMinK = (int)v;
   else if (!strcmp(name, "solution_refinements")) ctx->solutionRefinements = std::max(0, (int)v);
   else if (!strcmp(name, "refine_above")) ctx->refineAbove = v;
+  else if (!strcmp(name, "gemm_backend")) ctx->gemmBackend = (int)v;
   else if (!strcmp(name, "lu_polish")) ctx->luPolish = std::max(0, (int)v);
   else if (!strcmp(name, "lu_polish_tolerance")) ctx->luPolishTolerance = v;
   else if (!strcmp(name, "factor_mode")) ctx->factorMode = (int)v;
@@ -3824,6 +3915,8 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "lu_stop_density")) ctx->luStopDensity = v;
   else if (!strcmp(name, "lu_min_tail")) ctx->luMinTail = std::max(0, (int)v);
   else if (!strcmp(name, "lu_threshold")) ctx->luThreshold = v;
+  else if (!strcmp(name, "lu_adaptive")) ctx->luAdaptive = (int)v;
+  else if (!strcmp(name, "lu_min_pivots")) ctx->luMinPivots = std::max(1, (int)v);
   else if (!strcmp(name, "lu_inverse_fill_cap")) ctx->luInverseFillCap = v;
   else if (!strcmp(name, "fork_update")) { ctx->forkUpdate = (int)v; ctx->dropGraph(); }
   else if (!strcmp(name, "refresh_min_k")) ctx->refreshMinK = (int)v;

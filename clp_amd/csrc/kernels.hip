@@ -5573,4 +5573,5 @@ __global__ void k_infeas_finish(Dev D)
   D.ctrl->numberAppend = 0;
 }
 }  // namespace clpgpu
+#include "gemm_kernel.hip"
 #include "lu_kernels.hip"

@@ -526,6 +526,17 @@ int clpgpu_context::factorizeLu(const std::vector<int> &kcol, const std::vector<
   luInvertSeconds += std::chrono::duration<double>(t2 - t1).count();
   luBuildSeconds += std::chrono::duration<double>(t3 - t2).count();
   luFactorizations++;
+  // length of the eta file until the next scheduled refactorization: a pivot with t etas streams 8 m t bytes of H,
+  // a refactorization costs R seconds -> the cost per pivot R / T + a T / 2 is least at T = sqrt(2 R / a)
+  // (a = seconds per eta and pivot at the rate the eta kernel reaches); option "lu_max_pivots" caps it
+  {
+    const double R = std::chrono::duration<double>(t3 - t0).count();
+    luRefactorSeconds = luRefactorSeconds > 0.0 ? 0.5 * (luRefactorSeconds + R) : R;
+    const double a = 8.0 * (double)m / 3.0e12;
+    int T = (int)sqrt(2.0 * luRefactorSeconds / a);
+    T = std::min(std::max(T, luMinPivots), std::min(luMaxPivots, hLu.tcap - 1));
+    luEtaLimit = luAdaptive ? T : std::min(luMaxPivots, hLu.tcap - 1);
+  }
   luLastFront = nF;
   luLastTail = k2;
   if (logLevel > 1)
@@ -553,7 +564,7 @@ int clpgpu_context::luFtran(const double *v0, const double *v1, double *o0, doub
                      v1 ? 1 : 0, 0);
   if (ns)
     hipLaunchKernelGGL(k_lu_slack, dim3(cdiv(m, 256), nrhs), dim3(256), 0, stream, D, 0, v0, v1, (const double *)nullptr, 1, v1 ? 1 : 0, 0);
-  hipLaunchKernelGGL(k_lu_pf_s, dim3(64), dim3(256), 0, stream, D, 0, 1, v1 ? 1 : 0, 0);
+  hipLaunchKernelGGL(k_lu_pf_s, dim3(128), dim3(256), 0, stream, D, 0, 1, v1 ? 1 : 0, 0);
   hipLaunchKernelGGL(k_lu_pf_apply, dim3(cdiv(m, 256)), dim3(256), sizeof(double) * 3 * (size_t)hLu.tcap, stream, D, o0, o1, (double *)nullptr);
   return 0;
 }
@@ -593,6 +604,6 @@ void clpgpu_context::luLaunchFtran(int gm, int parity)
   KL("k_lu_bwd", k_lu_bwd, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, (const double *)D.slotC, (const double *)D.slotD, (const double *)D.slotE, 1, 1, 1);
   KL("k_lu_slack", k_lu_slack, dim3(cdiv(m, 256), 3), dim3(256), 0, stream, D, 1, (const double *)D.vecV1, (const double *)D.rho,
        (const double *)D.flipRhs, 1, 1, 1);
-  KL("k_lu_pf_s", k_lu_pf_s, dim3(64), dim3(256), 0, stream, D, 1, 1, 1, 1);
+  KL("k_lu_pf_s", k_lu_pf_s, dim3(128), dim3(256), 0, stream, D, 1, 1, 1, 1);
   KL("k_ftran_scatter3_lu", k_ftran_scatter3_lu, dim3(gm), dim3(256), 0, stream, D, gm, parity);
 }

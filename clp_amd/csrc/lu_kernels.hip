@@ -200,33 +200,42 @@ __global__ void __launch_bounds__(256) k_lu_slack(Dev D, int chain, const double
   LUD.x0[(size_t)r * D.m + i] = acc - v[i];
 }
 
-// ---- product form, FTRAN side: s = G x0[P] for the three right-hand sides; one wave per row of G
+// ---- product form, FTRAN side: s = G x0[P] for the three right-hand sides; one wave per row of G.
+// x0[P] (a scattered gather) is staged once per workgroup in LDS; the rows of G then stream against it.
 __global__ void __launch_bounds__(256) k_lu_pf_s(Dev D, int chain, int live0, int live1, int live2)
 {
   const Ctrl *c = D.ctrl;
   if (chain && c->state != RUN)
     return;
   const int t = c->pivots;
+  if ((int)blockIdx.x * 4 >= t)
+    return;
   bool l0 = live0 != 0, l1 = live1 != 0, l2 = live2 != 0;
   if (chain) {
     l0 = true;
     l1 = c->pivotRule != 0;
     l2 = c->numberFlips != 0;
   }
+  __shared__ double xp[3 * LU_TCAP_MAX];
+  {
+    const double *x0 = LUD.x0, *x1 = LUD.x0 + D.m, *x2 = LUD.x0 + 2 * (size_t)D.m;
+    for (int i = threadIdx.x; i < t; i += blockDim.x) {
+      const int p = LUD.P[i];
+      xp[i] = l0 ? x0[p] : 0.0;
+      xp[LU_TCAP_MAX + i] = l1 ? x1[p] : 0.0;
+      xp[2 * LU_TCAP_MAX + i] = l2 ? x2[p] : 0.0;
+    }
+  }
+  __syncthreads();
   const int lane = threadIdx.x & 63;
-  const double *x0 = LUD.x0, *x1 = LUD.x0 + D.m, *x2 = LUD.x0 + 2 * (size_t)D.m;
   for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < t; j += gridDim.x * 4) {
     const double *Grow = LUD.G + (size_t)j * LUD.tcap;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     for (int i = lane; i <= j; i += 64) {
       const double g = Grow[i];
-      const int p = LUD.P[i];
-      if (l0)
-        a0 += g * x0[p];
-      if (l1)
-        a1 += g * x1[p];
-      if (l2)
-        a2 += g * x2[p];
+      a0 += g * xp[i];
+      a1 += g * xp[LU_TCAP_MAX + i];
+      a2 += g * xp[2 * LU_TCAP_MAX + i];
     }
     a0 = waveSum(a0);
     a1 = waveSum(a1);

@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "clpgpu_chg_obj_coefficients", "clpgpu_scale_factors",
     "clpgpu_clone", "clpgpu_set_scales", "clpgpu_ftran_ft", "clpgpu_ftran_two_ft", "clpgpu_bind_rim", "clpgpu_pivot_row",
     "clpgpu_update_weights", "clpgpu_update_primal", "clpgpu_save_weights", "clpgpu_unroll_weights",
-    "clpgpu_get_kernel_times",
+    "clpgpu_get_kernel_times", "clpgpu_dgemm",
 ]
 
 
@@ -355,6 +355,17 @@ class ClpGpuSimplex:
 
     def replaceColumn(self, pivot_row, sequence_in):
         return lib().clpgpu_replace_column(self._h, int(pivot_row), int(sequence_in), 0.0, 1e-8)
+
+    def dgemm(self, alpha, a, b, beta, c):
+        """c = beta c + alpha a b on the engine's own MFMA f64 GEMM (square row-major arrays)"""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        c = np.array(c, dtype=np.float64, order="C")
+        dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+        f = lib().clpgpu_dgemm
+        f.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, dp, C.c_double, dp]
+        self._check(f(self._h, int(a.shape[0]), float(alpha), a, b, float(beta), c), "clpgpu_dgemm")
+        return c
 
     def pivots(self):
         return lib().clpgpu_pivots(self._h)

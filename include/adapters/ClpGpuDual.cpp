@@ -21,8 +21,15 @@ int clpGpuDual(ClpSimplex &model, int device, bool scaling)
   const int numberRows = model.numberRows(), numberColumns = model.numberColumns();
   if (scaling)
     clpgpu_set_option(ctx, "scaling", model.scalingFlag() > 0 ? model.scalingFlag() : 0); // before the load
+  // the engine minimises: a maximisation model (optimizationDirection -1) is loaded with its costs negated, as
+  // ClpSimplex::createRim does (src/ClpSimplex.cpp:3754: cost_ = direction * objective), and the duals come back
+  // multiplied by the direction again (ClpSimplex::finish -> deleteRim, src/ClpSimplex.cpp:4590ff)
+  const double direction = model.optimizationDirection() == 0.0 ? 1.0 : model.optimizationDirection();
+  std::vector< double > cost(model.objective(), model.objective() + numberColumns);
+  for (int j = 0; j < numberColumns; j++)
+    cost[j] *= direction;
   clpgpu_load_problem(ctx, numberRows, numberColumns, A->getVectorStarts(), A->getIndices(), A->getElements(),
-    model.columnLower(), model.columnUpper(), model.objective(), model.rowLower(), model.rowUpper());
+    model.columnLower(), model.columnUpper(), cost.data(), model.rowLower(), model.rowUpper());
   clpgpu_set_option(ctx, "pivot_rule", model.dualRowPivot()->type() == 2 ? 1 : 0);
   clpgpu_set_option(ctx, "max_iterations", model.maximumIterations());
   clpgpu_set_option(ctx, "max_pivots", model.factorization()->maximumPivots());
@@ -40,10 +47,13 @@ int clpGpuDual(ClpSimplex &model, int device, bool scaling)
   clpgpu_get_reduced_costs(ctx, dj.data());
   CoinMemcpyN(solution.data(), numberColumns, model.primalColumnSolution());
   CoinMemcpyN(solution.data() + numberColumns, numberRows, model.primalRowSolution());
-  CoinMemcpyN(dj.data(), numberColumns, model.dualColumnSolution());
+  for (int j = 0; j < numberColumns; j++)
+    model.dualColumnSolution()[j] = direction * dj[j];
   for (int i = 0; i < numberRows; i++)
-    model.dualRowSolution()[i] = dj[numberColumns + i]; // row dj == dual (src/ClpSimplex.cpp:1381-1386)
-  model.setObjectiveValue(clpgpu_objective_value(ctx));
+    model.dualRowSolution()[i] = direction * dj[numberColumns + i]; // row dj == dual (src/ClpSimplex.cpp:1381-1386)
+  // ClpModel::setObjectiveValue takes the value in the user's sense and applies offset and direction itself
+  // (src/ClpModel.hpp:862-865); the device minimised direction * c x
+  model.setObjectiveValue(direction * clpgpu_objective_value(ctx) - model.objectiveOffset());
   clpgpu_destroy(ctx);
   if (problemStatus == 10) // "needs primal clean-up", src/ClpSimplex.cpp:5808
     return model.primal(1);

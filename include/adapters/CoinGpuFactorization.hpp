@@ -69,11 +69,16 @@ public:
   }
   virtual int updateTwoColumnsFT(CoinIndexedVector *, CoinIndexedVector *regionSparse2, CoinIndexedVector *regionSparse3, bool) override
   {
+    // the callers hand packed vectors in and read them back packed (ClpSimplexDual::whileIterating unpacks the
+    // entering column with unpackPacked, src/ClpSimplexDual.cpp:1435; ClpDualRowSteepest::updateWeights reads
+    // work[i] / which[i]); the reference's dense factorization honours packedMode the same way
+    // (src/CoinAbcDenseFactorization.cpp:412, :439)
+    const bool packed2 = regionSparse2->packedMode(), packed3 = regionSparse3->packedMode();
     regionSparse2->expand();
     regionSparse3->expand();
     int rc = clpgpu_ftran_two_ft(ctx_.get(), regionSparse2->denseVector(), regionSparse3->denseVector());
-    regionSparse2->scan();
-    regionSparse3->scan();
+    repack(regionSparse2, packed2);
+    repack(regionSparse3, packed3);
     return rc;
   }
   virtual int updateColumnTranspose(CoinIndexedVector *, CoinIndexedVector *regionSparse2) const override
@@ -95,10 +100,19 @@ public:
 private:
   int solve(CoinIndexedVector *region, int (*fn)(clpgpu_context *, double *)) const
   {
+    const bool packed = region->packedMode();
     region->expand();
     int rc = fn(ctx_.get(), region->denseVector());
-    region->scan();
+    repack(region, packed);
     return rc < 0 ? rc : region->getNumElements();
+  }
+  // expand() leaves the vector dense and clears packedMode_; a vector that came in packed goes back packed
+  static void repack(CoinIndexedVector *region, bool wasPacked)
+  {
+    if (wasPacked)
+      region->scanAndPack();
+    else
+      region->scan();
   }
   std::shared_ptr< clpgpu_context > ctx_;
   const ClpSimplex *model_;

@@ -267,6 +267,10 @@ int clpgpu_get_pivot_log(clpgpu_context *ctx, clpgpu_pivot_record *out, int maxR
 /* dual steepest-edge reference weights and squared infeasibilities by basis position
  * (ClpDualRowSteepest::weights_, infeasible_; src/ClpDualRowSteepest.hpp) -- diagnostics */
 int clpgpu_get_row_weights(clpgpu_context *ctx, double *weights, double *infeasibility);
+/* CoinAbcDgemm (src/CoinAbcHelperFunctions.cpp:1658; used by CoinAbcDgetrf, src/AbcSimplexParallel.cpp:2491-2534):
+ * the engine's own f64 GEMM on the matrix cores, c = beta c + alpha a b for row-major n x n host arrays.  The
+ * kernel behind the Newton-Schulz steps on the explicit (tail) inverse; exposed so that tests hold it to numpy. */
+int clpgpu_dgemm(clpgpu_context *ctx, int n, double alpha, const double *a, const double *b, double beta, double *c);
 int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats);
 /* option "timing" = 2 (eager launches, a HIP event after every launch of the chain): accumulated time per
  * kernel of the pivots run so far -- kernel plus the launch gap before it.  names[i] point at static

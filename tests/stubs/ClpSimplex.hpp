@@ -31,6 +31,8 @@ public:
   inline int scalingFlag() const;
   inline ClpMatrixBase *clpMatrix() const;
   inline void setObjectiveValue(double value);
+  inline double optimizationDirection() const;
+  inline double objectiveOffset() const;
   inline unsigned char *statusArray() const;
 };
 class ClpSimplex : public ClpModel {

@@ -13,6 +13,7 @@ public:
   void setPackedMode(bool yesNo);
   void expand();
   int scan();
+  int scanAndPack();
   void clear();
 };
 #endif

@@ -220,7 +220,7 @@ def test_lu_solve_matches_independent_solver(gpu_cls):
     for it to finish; the engine runs in LU mode from a nucleus of 256 on.  Objective to 1e-8 relative."""
     from scipy.optimize import linprog
 
-    lp = P.sparse_lp(3000, 12000, 12, seed=23)
+    lp = P.sparse_lp(1500, 6000, 10, seed=23)
     m, n = lp.m, lp.n
     A = sp.csc_matrix((lp.elem, lp.row, lp.col_start), shape=(m, n))
     Aeq = sp.hstack([A, -sp.identity(m, format="csc")]).tocsr()
@@ -235,3 +235,17 @@ def test_lu_solve_matches_independent_solver(gpu_cls):
     assert g.dual() == 0
     assert g.stats()["lu_factorizations"] > 0
     assert abs(g.objectiveValue() - r.fun) <= 1e-8 * abs(r.fun)
+
+
+@pytest.mark.parametrize("n", [37, 128, 300, 1111])
+def test_own_mfma_gemm_matches_numpy(gpu_cls, n):
+    """The engine's f64 GEMM on the matrix cores (the kernel behind the Newton-Schulz steps) against numpy:
+    c = beta c + alpha a b, sizes that are not multiples of the 128 x 128 x 16 tiling."""
+    lp = P.sparse_lp(300, 1200, 8, seed=11)
+    g = gpu_cls().loadProblem(lp)
+    rng = np.random.default_rng(n)
+    a, b, c = rng.standard_normal((n, n)), rng.standard_normal((n, n)), rng.standard_normal((n, n))
+    for alpha, beta in ((1.0, 0.0), (-1.0, 1.0), (0.5, -2.0)):
+        out = g.dgemm(alpha, a, b, beta, c)
+        ref = beta * c + alpha * (a @ b)
+        assert np.max(np.abs(out - ref)) <= 1e-12 * n * (1.0 + np.max(np.abs(ref)))
