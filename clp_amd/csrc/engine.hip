@@ -6,6 +6,8 @@
 #include "kernels.hip"
 
 #include <dlfcn.h>
+#include <pthread.h>
+#include <time.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -45,6 +47,47 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 struct clpgpu_context;
 struct LuTriHost;
+// Loopback "communicator": N contexts of ONE process on one GPU, each driven by its own host thread and stream,
+// exchange what the RCCL all-gathers would carry through device-to-device copies (clpgpu_virtual_*).  It exists so
+// that the column-sharded code path -- rank offsets in k_shard_pack_* / k_shard_merge_*, owned reduced costs, the
+// overflow fallback agreeing across ranks -- runs with 2 / 4 / 8 ranks on a one-GPU box.
+struct clpgpu_virtual_group {
+  int nranks = 0;
+  clpgpu_context *ctx[8] = {};
+  const void *sendPtr[8] = {};
+  pthread_mutex_t mutex = PTHREAD_MUTEX_INITIALIZER;
+  pthread_cond_t cond = PTHREAD_COND_INITIALIZER;
+  int waiting = 0, generation = 0;
+  bool failed = false;
+  // barrier with a time limit: a rank that never arrives (diverged control flow) must not hang the box
+  bool barrier()
+  {
+    pthread_mutex_lock(&mutex);
+    if (failed) {
+      pthread_mutex_unlock(&mutex);
+      return false;
+    }
+    const int gen = generation;
+    if (++waiting == nranks) {
+      waiting = 0;
+      generation++;
+      pthread_cond_broadcast(&cond);
+    } else {
+      struct timespec ts;
+      clock_gettime(CLOCK_REALTIME, &ts);
+      ts.tv_sec += 20;
+      while (gen == generation && !failed)
+        if (pthread_cond_timedwait(&cond, &mutex, &ts) != 0) {
+          failed = true;
+          pthread_cond_broadcast(&cond);
+          break;
+        }
+    }
+    const bool ok = !failed;
+    pthread_mutex_unlock(&mutex);
+    return ok;
+  }
+};
 // growable device buffer of the LU factorization (sizes change from one refactorization to the next)
 struct DBuf {
   void *p = nullptr;
@@ -222,6 +265,10 @@ struct clpgpu_context {
   int allocShardBuffers();
   void *comm = nullptr;
   int (*ncclAllGatherFn)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  clpgpu_virtual_group *virtualGroup = nullptr;  // loopback exchange instead of RCCL (clpgpu_virtual_attach)
+  bool commFailed = false;
+  // every rank contributes `count` elements; recv holds them in rank order (send may alias its slice of recv)
+  void allGather(const void *send, void *recv, size_t count, int dtype);
   int (*ncclCommDestroyFn)(void *) = nullptr;
   hipGraph_t graph = nullptr;
   hipGraphExec_t graphExec = nullptr;
@@ -2476,6 +2523,34 @@ void clpgpu_context::ktCollect(int livePivots)
     }
 }
 
+void clpgpu_context::allGather(const void *send, void *recv, size_t count, int dtype)
+{
+  if (!virtualGroup) {
+    ncclAllGatherFn(send, recv, count, dtype, comm, stream);
+    return;
+  }
+  // loopback: my contribution is complete once my stream has drained; then every rank copies every slice
+  clpgpu_virtual_group *g = virtualGroup;
+  const size_t bytes = count * (dtype == 1 ? 1 : 8);
+  if (commFailed || hipStreamSynchronize(stream) != hipSuccess) {
+    commFailed = true;
+    return;
+  }
+  g->sendPtr[rank] = send;
+  if (!g->barrier()) {
+    commFailed = true;
+    return;
+  }
+  for (int r = 0; r < nranks; r++) {
+    char *dst = (char *)recv + (size_t)r * bytes;
+    if (g->sendPtr[r] != (const void *)dst)
+      (void)hipMemcpyAsync(dst, g->sendPtr[r], bytes, hipMemcpyDeviceToDevice, stream);
+  }
+  // nobody may overwrite its send buffer before every copy out of it has executed
+  if (hipStreamSynchronize(stream) != hipSuccess || !g->barrier())
+    commFailed = true;
+}
+
 int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
 {
   ktOn = timing >= 2 && !capturing;
@@ -2532,8 +2607,8 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
       // round-1 exchange (also the fallback of the list exchange): every rank contributes its slice of
       // the tableau row and of the first-pass flags, in place; everything after is replicated
       const size_t chunk = (size_t)shardChunk;
-      ncclAllGatherFn(D.alphaCol + (size_t)rank * chunk, D.alphaCol, chunk, 8 /* ncclFloat64 */, comm, stream);
-      ncclAllGatherFn(D.candFlag + D.m + (size_t)rank * chunk, D.candFlag + D.m, chunk, 1 /* ncclUint8 */, comm, stream);
+      allGather(D.alphaCol + (size_t)rank * chunk, D.alphaCol, chunk, 8 /* ncclFloat64 */);
+      allGather(D.candFlag + D.m + (size_t)rank * chunk, D.candFlag + D.m, chunk, 1 /* ncclUint8 */);
     }
     {
       const int nSell = (widePricing && priceKernel != 1) ? nWideBlocks : nSellBlocks + nLongBlocks;
@@ -2553,7 +2628,7 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
     // the local list is [row candidates (replicated) | this rank's column candidates]: the column part
     // of every rank, gathered in rank order behind the rows, is the single-GPU list
     KL("k_shard_pack_cands", k_shard_pack_cands, dim3(1), dim3(256), 0, stream, D, nbRows, dCandSend, shardCandCap);
-    ncclAllGatherFn(dCandSend, dCandRecv, SHARD_HDR + 4 * (size_t)shardCandCap, 8 /* ncclFloat64 */, comm, stream);
+    allGather(dCandSend, dCandRecv, SHARD_HDR + 4 * (size_t)shardCandCap, 8 /* ncclFloat64 */);
     KL("k_shard_merge_cands", k_shard_merge_cands, dim3(cdiv(shardCandCap, 256), nranks), dim3(256), 0, stream, D, (const double *)dCandRecv,
        nranks, shardCandCap);
   }
@@ -2572,7 +2647,7 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   KL("k_dj_flags", k_dj_flags, dim3(nb + 1), dim3(PRICE_BLOCK), 0, stream, D, nbRows, flipListCap, scatterFlips, flipSlotCap);
   if (shardLists) {
     KL("k_shard_pack_flips", k_shard_pack_flips, dim3(1), dim3(256), 0, stream, D, dFlipSend, shardFlipCap, flipListCap);
-    ncclAllGatherFn(dFlipSend, dFlipRecv, SHARD_HDR + 5 * (size_t)shardFlipCap, 8 /* ncclFloat64 */, comm, stream);
+    allGather(dFlipSend, dFlipRecv, SHARD_HDR + 5 * (size_t)shardFlipCap, 8 /* ncclFloat64 */);
     KL("k_shard_merge_flips", k_shard_merge_flips, dim3(1), dim3(256), 0, stream, D, (const double *)dFlipRecv, rank, nranks, shardFlipCap,
        flipListCap);
   }
@@ -3840,6 +3915,72 @@ int clpgpu_comm_init(clpgpu_context *ctx, int rank, int nranks, const void *id12
     return -99;
   ctx->useGraph = 0;  // collectives are enqueued between kernels; keep the eager chain
   rc = ctx->buildSell();
+  return rc;
+}
+
+// ---- loopback ranks (see clpgpu_virtual_group) ----
+clpgpu_virtual_group *clpgpu_virtual_group_create(int nranks)
+{
+  if (nranks < 1 || nranks > 8)
+    return nullptr;
+  clpgpu_virtual_group *g = new clpgpu_virtual_group();
+  g->nranks = nranks;
+  return g;
+}
+void clpgpu_virtual_group_destroy(clpgpu_virtual_group *g) { delete g; }
+
+int clpgpu_virtual_attach(clpgpu_context *ctx, clpgpu_virtual_group *g, int rank)
+{
+  if (!ctx || !g || rank < 0 || rank >= g->nranks)
+    return -1;
+  g->ctx[rank] = ctx;
+  ctx->virtualGroup = g;
+  ctx->rank = rank;
+  ctx->nranks = g->nranks;
+  ctx->commActive = true;
+  ctx->commMode = getenv("CLPGPU_COMM_MODE") ? atoi(getenv("CLPGPU_COMM_MODE")) : ctx->commMode;
+  if (ctx->commMode != 1)
+    ctx->commMode = 2;
+  ctx->applyShard();
+  if (ctx->allocShardBuffers())
+    return -99;
+  ctx->useGraph = 0;
+  return ctx->buildSell();
+}
+
+// clpgpu_dual_steps on every rank of the group at once, one host thread per rank (the ranks meet at the exchanges)
+int clpgpu_virtual_dual_steps(clpgpu_virtual_group *g, int iterations, int *statusOut)
+{
+  if (!g)
+    return -99;
+  struct Arg {
+    clpgpu_context *ctx;
+    int iterations, status;
+  } args[8];
+  pthread_t th[8];
+  for (int r = 0; r < g->nranks; r++) {
+    if (!g->ctx[r])
+      return -1;
+    args[r] = { g->ctx[r], iterations, 0 };
+  }
+  auto body = [](void *p) -> void * {
+    Arg *a = (Arg *)p;
+    (void)hipSetDevice(a->ctx->device);
+    a->status = a->ctx->run(a->iterations);
+    return nullptr;
+  };
+  for (int r = 0; r < g->nranks; r++)
+    pthread_create(&th[r], nullptr, body, &args[r]);
+  int rc = 0;
+  for (int r = 0; r < g->nranks; r++) {
+    pthread_join(th[r], nullptr);
+    if (statusOut)
+      statusOut[r] = args[r].status;
+    if (g->ctx[r]->commFailed)
+      rc = -2;
+  }
+  if (g->failed)
+    rc = -2;
   return rc;
 }
 

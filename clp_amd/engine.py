@@ -47,6 +47,7 @@ ABI_SYMBOLS = [
     "clpgpu_clone", "clpgpu_set_scales", "clpgpu_ftran_ft", "clpgpu_ftran_two_ft", "clpgpu_bind_rim", "clpgpu_pivot_row",
     "clpgpu_update_weights", "clpgpu_update_primal", "clpgpu_save_weights", "clpgpu_unroll_weights",
     "clpgpu_get_kernel_times", "clpgpu_dgemm",
+    "clpgpu_virtual_group_create", "clpgpu_virtual_group_destroy", "clpgpu_virtual_attach", "clpgpu_virtual_dual_steps",
 ]
 
 
@@ -436,3 +437,44 @@ class ClpGpuSimplex:
         ra, rp = self._opt(row_scale, np.float64)
         ca, cp = self._opt(column_scale, np.float64)
         self._check(lib().clpgpu_set_scales(self._h, rp, cp), "clpgpu_set_scales")
+
+
+class VirtualRanks:
+    """N loopback ranks on one GPU (include/clpgpu.h, clpgpu_virtual_*): the column-sharded engine with real rank
+    offsets, the exchanges done by device-to-device copies.  `engines[r]` is rank r's ClpGpuSimplex."""
+
+    def __init__(self, lp, nranks, configure=None, device=0):
+        L = lib()
+        L.clpgpu_virtual_group_create.restype = C.c_void_p
+        L.clpgpu_virtual_group_create.argtypes = [C.c_int]
+        L.clpgpu_virtual_group_destroy.argtypes = [C.c_void_p]
+        L.clpgpu_virtual_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.clpgpu_virtual_dual_steps.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        self._g = L.clpgpu_virtual_group_create(nranks)
+        if not self._g:
+            raise RuntimeError("clpgpu_virtual_group_create failed")
+        self.engines = []
+        for r in range(nranks):
+            e = ClpGpuSimplex(device).loadProblem(lp)
+            if configure:
+                configure(e)
+            rc = L.clpgpu_virtual_attach(e._h, self._g, r)
+            if rc:
+                raise RuntimeError(f"clpgpu_virtual_attach failed ({rc}): {e.lastError()}")
+            self.engines.append(e)
+
+    def dual_steps(self, iterations=-1):
+        st = (C.c_int * len(self.engines))()
+        rc = lib().clpgpu_virtual_dual_steps(self._g, int(iterations), st)
+        if rc:
+            raise RuntimeError(f"clpgpu_virtual_dual_steps failed ({rc}): the ranks lost step")
+        return list(st)
+
+    def __del__(self):
+        self.engines = []
+        if getattr(self, "_g", None) and lib is not None:
+            try:
+                lib().clpgpu_virtual_group_destroy(self._g)
+            except Exception:  # noqa: BLE001 -- interpreter shutdown
+                pass
+            self._g = None

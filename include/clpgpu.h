@@ -267,6 +267,19 @@ int clpgpu_get_pivot_log(clpgpu_context *ctx, clpgpu_pivot_record *out, int maxR
 /* dual steepest-edge reference weights and squared infeasibilities by basis position
  * (ClpDualRowSteepest::weights_, infeasible_; src/ClpDualRowSteepest.hpp) -- diagnostics */
 int clpgpu_get_row_weights(clpgpu_context *ctx, double *weights, double *infeasibility);
+/* ---- loopback ranks: the column-sharded path (AbcSimplexDual.cpp:1623-1634, ClpPackedMatrix.cpp:1823-1854)
+ * with 2 / 4 / 8 ranks on ONE GPU.  N contexts of one process, one host thread and stream each; what the RCCL
+ * all-gathers carry between GPUs travels by device-to-device copies.  For tests of the sharded code path on a
+ * one-GPU box: rank offsets of the pack / merge kernels, owned reduced costs, the overflow fallback. */
+typedef struct clpgpu_virtual_group clpgpu_virtual_group;
+clpgpu_virtual_group *clpgpu_virtual_group_create(int nranks);
+void clpgpu_virtual_group_destroy(clpgpu_virtual_group *group);
+/* after clpgpu_load_problem and the options, instead of clpgpu_comm_init */
+int clpgpu_virtual_attach(clpgpu_context *ctx, clpgpu_virtual_group *group, int rank);
+/* clpgpu_dual_steps (iterations < 0: clpgpu_dual) on every rank at once; status[r] = what rank r returned.
+ * 0, or -2 when the ranks lost step (an exchange timed out). */
+int clpgpu_virtual_dual_steps(clpgpu_virtual_group *group, int iterations, int *status);
+
 /* CoinAbcDgemm (src/CoinAbcHelperFunctions.cpp:1658; used by CoinAbcDgetrf, src/AbcSimplexParallel.cpp:2491-2534):
  * the engine's own f64 GEMM on the matrix cores, c = beta c + alpha a b for row-major n x n host arrays.  The
  * kernel behind the Newton-Schulz steps on the explicit (tail) inverse; exposed so that tests hold it to numpy. */

@@ -1,0 +1,87 @@
+"""Column-sharded engine with MORE THAN ONE RANK on a one-GPU box: N loopback ranks -- N contexts
+of this process, one host thread and stream each -- run the sharded chain with real rank offsets
+(k_shard_pack_cands / k_shard_merge_cands / k_shard_pack_flips / k_shard_merge_flips, reduced costs owned by the
+rank that owns the column); what RCCL's all-gathers carry between GPUs travels by device-to-device copies
+(include/clpgpu.h, clpgpu_virtual_*).  The sharded runs must reproduce the unsharded run: same pivots on every
+rank, same solution.  Reference shape: AbcSimplexDual.cpp:1450-1528 (dualColumn2First per chunk), :1623-1634
+(combine), ClpPackedMatrix.cpp:1823-1854 (ABOCA_LITE column chunks)."""
+import numpy as np
+import pytest
+
+from clp_amd import problems as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(built):
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from clp_amd import engine
+
+    return engine
+
+
+def configure(e, **opts):
+    e.set_option("pivot_rule", 1)
+    e.set_option("max_pivots", 0)
+    e.set_option("factor_mode", 0)
+    for k, v in opts.items():
+        e.set_option(k, v)
+
+
+def same_pivots(a, b, n):
+    return np.array_equal(a["sequenceIn"][:n], b["sequenceIn"][:n]) and np.array_equal(a["sequenceOut"][:n], b["sequenceOut"][:n]) \
+        and np.array_equal(a["pivotRow"][:n], b["pivotRow"][:n])
+
+
+@pytest.mark.parametrize("nranks", [2, 4, 8])
+@pytest.mark.parametrize("mode", [2, 1])
+def test_virtual_ranks_match_unsharded(gpu, nranks, mode):
+    lp = P.sparse_lp(2000, 9000, 12, seed=13)
+    base = gpu.ClpGpuSimplex(0).loadProblem(lp)
+    configure(base)
+    assert base.dual() == 0
+    # (exchange buffers large enough for this LP's candidate lists -- 4000 and more per pivot: an overflow would send
+    # the run to the dense row exchange after an extra resync, a different refactorization schedule; that path has
+    # its own test below)
+    vr = gpu.VirtualRanks(lp, nranks, configure=lambda e: configure(e, comm_mode=mode, shard_cand_cap=16384, shard_flip_cap=4096))
+    assert vr.dual_steps(-1) == [0] * nranks
+    ref = base.pivotLog()
+    for r, e in enumerate(vr.engines):
+        log = e.pivotLog()
+        assert len(log) == len(ref), f"rank {r}"
+        assert same_pivots(log, ref, len(ref)), f"rank {r}"
+        assert e.objectiveValue() == base.objectiveValue()
+        assert np.array_equal(e.solution(), base.solution())
+
+
+def test_virtual_ranks_overflow_fallback_agrees(gpu):
+    """exchange buffers far too small: every rank sees the overflow at the same pivot, all fall back to the dense
+    row-slice exchange together and reach the unsharded optimum"""
+    lp = P.sparse_lp(2000, 9000, 12, seed=13)
+    base = gpu.ClpGpuSimplex(0).loadProblem(lp)
+    configure(base)
+    assert base.dual() == 0
+    vr = gpu.VirtualRanks(lp, 4, configure=lambda e: configure(e, shard_cand_cap=4, shard_flip_cap=2))
+    assert vr.dual_steps(-1) == [0, 0, 0, 0]
+    its = {e.numberIterations() for e in vr.engines}
+    assert len(its) == 1
+    for e in vr.engines:
+        assert abs(e.objectiveValue() - base.objectiveValue()) <= 1e-9 * abs(base.objectiveValue())
+
+
+def test_virtual_ranks_full_size(gpu):
+    """config 5 in miniature: the 50 000 x 200 000 LP of config 4, columns sharded over 8 loopback ranks, first 300
+    pivots against the unsharded engine"""
+    lp = P.sparse_lp()
+    base = gpu.ClpGpuSimplex(0).loadProblem(lp)
+    configure(base)
+    base.dual_steps(300)
+    vr = gpu.VirtualRanks(lp, 8, configure=lambda e: configure(e, shard_cand_cap=8192, shard_flip_cap=2048))
+    assert vr.dual_steps(300) == [-1] * 8
+    ref = base.pivotLog()
+    for r, e in enumerate(vr.engines):
+        assert same_pivots(e.pivotLog(), ref, 300), f"rank {r}"
+        assert np.array_equal(e.solution(), base.solution())
