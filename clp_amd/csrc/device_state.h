@@ -82,6 +82,7 @@ struct Ctrl {
   int cycIn[12], cycOut[12], cycWay[12], cycHead;  // ClpSimplexProgress in_ / out_ / way_ (CLP_CYCLE = 12, src/ClpSolve.hpp:435)  // form the last pricing launch took (k_price_row_finish)
   int appendGo, flipDense;  // flipDense: this pivot's flip rhs is left to k_flip_dense
   int updGo[2], updK, updPad;  // basis-update branch: go flag per pivot parity, k at the time of the fork
+  long long dbgDc[4];  // ratio test, working-set path: calls, ticks of the whole kernel, ticks before the passes start, max ticks of one call
   double tailAlpha, tailValueOut;  // w[pivotRow] / sol[sequenceOut] handed to the serial tail of k_ftran_scatter3  // this pivot's primal update completed: its list appends may be scattered  // unordered append count of k_dj_flags (ordered later by k_flip_apply2)
 };
 

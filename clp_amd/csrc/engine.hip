@@ -4442,6 +4442,9 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
     const long long *g = ctx->hCtrl->dbg;
     fprintf(stderr, "clpgpu dbg: dc small %lld big %lld passes %lld tries %lld sumNc %lld mapped %lld full %lld ticksSmall %lld ticksBig %lld | flip iters %lld flips %lld entries %lld sequential %lld | scattered %lld select rows %lld hot rows %lld\n",
             g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9], g[10], g[11], g[12], g[14], g[13], g[15]);
+    const long long *q = ctx->hCtrl->dbgDc;
+    fprintf(stderr, "clpgpu dbg: ratio test working-set path: calls %lld, ticks/call %.0f, before the passes %.0f, max %lld\n", q[0],
+            q[0] ? (double)q[1] / q[0] : 0.0, q[0] ? (double)q[2] / q[0] : 0.0, q[3]);
   }
   stats->price_bytes = ctx->hCtrl->statPriceBytes;
   stats->row_bytes = ctx->hCtrl->statRowBytes;

@@ -1193,6 +1193,7 @@ __global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass)
   Ctrl *c = D.ctrl;
   if (c->state != RUN)
     return;
+  const long long dcT0 = wall_clock64();
   const int nc = c->numberCandidates;
   const int tid = threadIdx.x;
   if (!nc) {
@@ -1307,6 +1308,7 @@ __global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass)
       }
       __syncthreads();
       bool ok;
+      const long long dcT1 = wall_clock64();
       if (ws <= DC_SMALL) {
         if (tid < 64) {
           ok = dualColumnImpl<8, true, true>(D, wsIdx, ws, tau);
@@ -1318,8 +1320,17 @@ __global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass)
       } else {
         ok = dualColumnImpl<DC_CPT, false, true>(D, wsIdx, ws, tau);
       }
-      if (ok)
+      if (ok) {
+        if (tid == 0) {
+          const long long dt = wall_clock64() - dcT0;
+          c->dbgDc[0]++;
+          c->dbgDc[1] += dt;
+          c->dbgDc[2] += dcT1 - dcT0;
+          if (dt > c->dbgDc[3])
+            c->dbgDc[3] = dt;
+        }
         return;
+      }
       __syncthreads();
     }
   }

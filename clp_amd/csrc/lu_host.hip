@@ -563,7 +563,7 @@ int clpgpu_context::luFtran(const double *v0, const double *v1, double *o0, doub
   hipLaunchKernelGGL(k_lu_bwd, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 0, (const double *)D.slotC, (const double *)D.slotD, (const double *)nullptr, 1,
                      v1 ? 1 : 0, 0);
   if (ns)
-    hipLaunchKernelGGL(k_lu_slack, dim3(cdiv(m, 256), nrhs), dim3(256), 0, stream, D, 0, v0, v1, (const double *)nullptr, 1, v1 ? 1 : 0, 0);
+    hipLaunchKernelGGL(k_lu_slack, dim3(cdiv(m, 32), nrhs), dim3(256), 0, stream, D, 0, v0, v1, (const double *)nullptr, 1, v1 ? 1 : 0, 0);
   hipLaunchKernelGGL(k_lu_pf_s, dim3(128), dim3(256), 0, stream, D, 0, 1, v1 ? 1 : 0, 0);
   hipLaunchKernelGGL(k_lu_pf_apply, dim3(cdiv(m, 256)), dim3(256), sizeof(double) * 3 * (size_t)hLu.tcap, stream, D, o0, o1, (double *)nullptr);
   return 0;
@@ -575,7 +575,7 @@ int clpgpu_context::luBtran(const double *cPos, double *yRow)
   hipLaunchKernelGGL(k_lu_pf_gdot, dim3(64), dim3(256), 0, stream, D, cPos);
   hipLaunchKernelGGL(k_lu_pf_d, dim3(cdiv(tcap, 4)), dim3(256), 0, stream, D, 0);
   hipLaunchKernelGGL(k_lu_cprime, dim3(1), dim3(1024), 0, stream, D, 0, cPos);
-  hipLaunchKernelGGL(k_lu_bt_gather, dim3(cdiv(m, 32)), dim3(256), 0, stream, D, 0, yRow);
+  hipLaunchKernelGGL(k_lu_bt_gather, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 0, yRow);
   hipLaunchKernelGGL(k_lu_bt_front, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 0, D.slotA);
   if (k2)
     hipLaunchKernelGGL(k_lu_gemvT, dim3(cdiv(k2, 4)), dim3(256), 0, stream, D, 0, (const double *)D.slotA);
@@ -589,7 +589,7 @@ void clpgpu_context::luLaunchBtran()
   const int k = hLu.k, ns = hLu.ns, tcap = hLu.tcap, kc = kcap;
   KL("k_lu_pf_d", k_lu_pf_d, dim3(cdiv(tcap, 4)), dim3(256), 0, stream, D, 1);
   KL("k_lu_cprime", k_lu_cprime, dim3(1), dim3(1024), 0, stream, D, 1, (const double *)nullptr);
-  KL("k_lu_bt_gather", k_lu_bt_gather, dim3(cdiv(m, 32)), dim3(256), 0, stream, D, 1, (double *)nullptr);
+  KL("k_lu_bt_gather", k_lu_bt_gather, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, (double *)nullptr);
   KL("k_lu_bt_front", k_lu_bt_front, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, D.slotA);
   KL("k_lu_gemvT", k_lu_gemvT, dim3(cdiv(kc, 4)), dim3(256), 0, stream, D, 1, (const double *)D.slotA);
   KL("k_lu_bt_back", k_lu_bt_back, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, (double *)nullptr);
@@ -602,7 +602,7 @@ void clpgpu_context::luLaunchFtran(int gm, int parity)
      D.rhoSlotF, D.flipSlot);
   KL("k_gemv3g", k_gemv3g, dim3(cdiv(kc, GEMV_RPB)), dim3(1024), 0, stream, D);
   KL("k_lu_bwd", k_lu_bwd, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, (const double *)D.slotC, (const double *)D.slotD, (const double *)D.slotE, 1, 1, 1);
-  KL("k_lu_slack", k_lu_slack, dim3(cdiv(m, 256), 3), dim3(256), 0, stream, D, 1, (const double *)D.vecV1, (const double *)D.rho,
+  KL("k_lu_slack", k_lu_slack, dim3(cdiv(m, 32), 3), dim3(256), 0, stream, D, 1, (const double *)D.vecV1, (const double *)D.rho,
        (const double *)D.flipRhs, 1, 1, 1);
   KL("k_lu_pf_s", k_lu_pf_s, dim3(128), dim3(256), 0, stream, D, 1, 1, 1, 1);
   KL("k_ftran_scatter3_lu", k_ftran_scatter3_lu, dim3(gm), dim3(256), 0, stream, D, gm, parity);

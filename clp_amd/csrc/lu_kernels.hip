@@ -189,15 +189,22 @@ __global__ void __launch_bounds__(256) k_lu_slack(Dev D, int chain, const double
     live = c->numberFlips != 0;
   if (!live)
     return;
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= LUD.ns)
-    return;
-  const double *xc = LUD.xc + (size_t)r * LUD.kpad;
-  const int i = LUD.sRowIndex[s];
+  // 8 lanes per row (fixed 8-way tree): rows are short on the uniform LPs, long on the power-law ones
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = g >> 3, sub = g & 7;
   double acc = 0.0;
-  for (int e = LUD.sRowStart[s]; e < LUD.sRowStart[s + 1]; e++)
-    acc += LUD.sRowVal[e] * xc[LUD.sRowCol[e]];
-  LUD.x0[(size_t)r * D.m + i] = acc - v[i];
+  if (s < LUD.ns) {
+    const double *xc = LUD.xc + (size_t)r * LUD.kpad;
+    for (int e = LUD.sRowStart[s] + sub; e < LUD.sRowStart[s + 1]; e += 8)
+      acc += LUD.sRowVal[e] * xc[LUD.sRowCol[e]];
+  }
+  acc += __shfl_xor(acc, 1);
+  acc += __shfl_xor(acc, 2);
+  acc += __shfl_xor(acc, 4);
+  if (s < LUD.ns && sub == 0) {
+    const int i = LUD.sRowIndex[s];
+    LUD.x0[(size_t)r * D.m + i] = acc - v[i];
+  }
 }
 
 // ---- product form, FTRAN side: s = G x0[P] for the three right-hand sides; one wave per row of G.
@@ -385,19 +392,24 @@ __global__ void __launch_bounds__(256) k_lu_bt_gather(Dev D, int chain, double *
   const Ctrl *c = D.ctrl;
   if (chain && c->state != RUN)
     return;
-  // 8 lanes per nucleus column (a column holds a few dozen entries in slack rows); fixed 8-way tree
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  const int id = g >> 3, sub = g & 7;
+  // one wave per nucleus column: a column holds a few dozen entries in slack rows on the uniform LPs, thousands
+  // on the power-law (Netlib-shaped) ones; fixed 64-way tree
+  const int id = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (id < LUD.k) {
-    double acc = 0.0;
-    for (int e = LUD.sColStart[id] + sub; e < LUD.sColStart[id + 1]; e += 8)
-      acc += LUD.sColVal[e] * LUD.cp[LUD.sColRow[e]];
-    acc += __shfl_xor(acc, 1);
-    acc += __shfl_xor(acc, 2);
-    acc += __shfl_xor(acc, 4);
-    if (sub == 0)
+    double a0 = 0.0, a1 = 0.0;
+    const int e1 = LUD.sColStart[id + 1];
+    int e = LUD.sColStart[id] + lane;
+    for (; e + 64 < e1; e += 128) {
+      a0 += LUD.sColVal[e] * LUD.cp[LUD.sColRow[e]];
+      a1 += LUD.sColVal[e + 64] * LUD.cp[LUD.sColRow[e + 64]];
+    }
+    if (e < e1)
+      a0 += LUD.sColVal[e] * LUD.cp[LUD.sColRow[e]];
+    const double acc = waveSum(a0 + a1);
+    if (lane == 0)
       LUD.tcv[id] = LUD.cp[LUD.posOfCol[id]] + acc;
   }
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g < LUD.ns) {
     const int i = LUD.sRowIndex[g];
     (chain ? LUD.y : y)[i] = 0.0 - LUD.cp[i];

@@ -54,7 +54,8 @@ ABI_SYMBOLS = [
 def build(force: bool = False) -> str:
     """Compile libclpgpu.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("engine.hip", "kernels.hip", "device_state.h")]
+    srcs = [os.path.join(src_dir, f) for f in ("engine.hip", "kernels.hip", "lu_kernels.hip", "lu_host.hip", "lu_front.h", "gemm_kernel.hip",
+                                               "device_state.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "clpgpu.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:

@@ -205,6 +205,24 @@ def test_afiro_identical_pivot_sequence(gpu_cls, afiro, rule):
     kkt(afiro, g)
 
 
+@pytest.mark.parametrize("rule", [0, 1])
+def test_hello_plumbing_case_on_the_engine(gpu_cls, rule):
+    """BASELINE config 1: the reference's examples/hello.mps (21 x 53; parsed arrays committed by
+    tests/golden/make_golden.py) through the engine: same status, objective, pivots and basis as the CPU oracle."""
+    from clp_amd.mps import LpData
+
+    d = np.load(os.path.join(HERE, "golden", "hello_lp.npz"))
+    lp = LpData({k: (int(d[k]) if k in ("m", "n") else d[k]) for k in d.files if k != "optimum"})
+    lp["name"] = "hello"
+    g, sg, o, so = solve_both(gpu_cls, lp, rule)
+    assert sg == so == 0
+    assert abs(g.objectiveValue() - float(d["optimum"])) < 1e-9
+    assert g.numberIterations() == o.iterations
+    assert np.array_equal(g.statusArray() & 7, o.status() & 7)
+    assert rel(g.solution(), o.solution()) < RTOL
+    kkt(lp, g)
+
+
 # dense 300x400: mean row and column length >= 256 -> the wide-row / wide-column / dense-column kernel
 # variants; sparse 60x30000: long rows with short columns (wide-row variants alone)
 @pytest.mark.parametrize("maker,args", [("dense_lp", (120, 150, 12)), ("sparse_lp", (300, 1200, 8, 11)),
