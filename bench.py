@@ -390,6 +390,7 @@ def main():
             model = {  # algorithmic bytes per launch of the kernels that stream a matrix in this regime
                 "k_gemv3g": (8.0 * kd * kd, "hbm", "three FTRAN right-hand sides through the dense " + ("tail inverse" if lu else "nucleus inverse") + ": 8 k^2 B"),
                 "k_lu_gemvT": (8.0 * kd * kd, "hbm", "BTRAN through the transposed tail inverse: 8 k^2 B"),
+                "k_lu_gemv3": (8.0 * kd * kd, "hbm", "three FTRAN right-hand sides through the dense tail inverse in one sweep: 8 k^2 B"),
                 "k_ftran_scatter3_lu": (8.0 * lp.m * eta + 3 * 8.0 * lp.m, "hbm", "eta file: x = x0 - H s over the m positions, 8 m t B (t = etas since the factorization)"),
                 "k_primal_rank1": (16.0 * kd * kd, "hbm", "rank-1 update of the explicit nucleus inverse: 16 k^2 B"),
                 "k_price_sell": (price_b, "hbm", "row pricing by column: bytes the kernel streams (4 B per row index, 8 B per element fetched, lists)"),

@@ -467,6 +467,50 @@ __global__ void __launch_bounds__(256) k_lu_gemvT(Dev D, int chain, const double
       LUD.wr[LUD.tailRow[ts]] = acc;
   }
 }
+// x_T = S^-1 v_T for the three FTRAN right-hand sides in one sweep of the tail inverse: one wave per row, the three
+// vectors (slotV1 / rhoSlotF / flipSlot, k2 doubles each) come from L2; skip rules as in k_gemv3g
+__global__ void __launch_bounds__(256) k_lu_gemv3(Dev D)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  const int k2 = LUD.k2;
+  const bool doTau = c->pivotRule != 0, doFlip = c->numberFlips != 0;
+  const int lane = threadIdx.x & 63;
+  const double *v1 = D.slotV1, *v2 = D.rhoSlotF, *v3 = D.flipSlot;
+  for (int sc = blockIdx.x * 4 + (threadIdx.x >> 6); sc < k2; sc += gridDim.x * 4) {
+    const double *row = D.Minv + (size_t)sc * D.ld;
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+    int i = lane;
+    for (; i + 64 < k2; i += 128) {
+      const double m0 = row[i], m1 = row[i + 64];
+      a1 += m0 * v1[i];
+      b1 += m1 * v1[i + 64];
+      if (doTau) {
+        a2 += m0 * v2[i];
+        b2 += m1 * v2[i + 64];
+      }
+      if (doFlip) {
+        a3 += m0 * v3[i];
+        b3 += m1 * v3[i + 64];
+      }
+    }
+    if (i < k2) {
+      const double m0 = row[i];
+      a1 += m0 * v1[i];
+      if (doTau)
+        a2 += m0 * v2[i];
+      if (doFlip)
+        a3 += m0 * v3[i];
+    }
+    const double r1 = waveSum(a1 + b1), r2 = waveSum(a2 + b2), r3 = waveSum(a3 + b3);
+    if (lane == 0) {
+      D.slotC[sc] = r1;
+      D.slotD[sc] = r2;
+      D.slotE[sc] = r3;
+    }
+  }
+}
 // MinvT[ts][tc] = Minv[tc][ts], 32 x 32 tiles through LDS
 __global__ void __launch_bounds__(256) k_lu_transpose_tail(Dev D, int k2, double *out)
 {
