@@ -600,7 +600,7 @@ void clpgpu_context::luLaunchFtran(int gm, int parity)
   const int ns = hLu.ns, kc = kcap;
   KL("k_lu_fwd", k_lu_fwd, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, (const double *)D.vecV1, (const double *)D.rho, (const double *)D.flipRhs, D.slotV1,
      D.rhoSlotF, D.flipSlot);
-  KL("k_lu_gemv3", k_lu_gemv3, dim3(cdiv(kc, 4)), dim3(256), 0, stream, D);
+  KL("k_lu_gemv3", k_lu_gemv3, dim3(cdiv(kc, 16)), dim3(256), 0, stream, D);
   KL("k_lu_bwd", k_lu_bwd, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, (const double *)D.slotC, (const double *)D.slotD, (const double *)D.slotE, 1, 1, 1);
   KL("k_lu_slack", k_lu_slack, dim3(cdiv(m, 32), 3), dim3(256), 0, stream, D, 1, (const double *)D.vecV1, (const double *)D.rho,
        (const double *)D.flipRhs, 1, 1, 1);

@@ -467,8 +467,10 @@ __global__ void __launch_bounds__(256) k_lu_gemvT(Dev D, int chain, const double
       LUD.wr[LUD.tailRow[ts]] = acc;
   }
 }
-// x_T = S^-1 v_T for the three FTRAN right-hand sides in one sweep of the tail inverse: one wave per row, the three
-// vectors (slotV1 / rhoSlotF / flipSlot, k2 doubles each) come from L2; skip rules as in k_gemv3g
+// x_T = S^-1 v_T for the three FTRAN right-hand sides in one sweep of the tail inverse.  One wave per FOUR rows:
+// the three vectors (slotV1 / rhoSlotF / flipSlot, from L2) are loaded once per column and used against four
+// matrix rows, so the kernel issues 7 loads per 12 multiply-adds instead of 4 per 3; skip rules as in k_gemv3g
+#define LUG_ROWS 4
 __global__ void __launch_bounds__(256) k_lu_gemv3(Dev D)
 {
   const Ctrl *c = D.ctrl;
@@ -478,36 +480,35 @@ __global__ void __launch_bounds__(256) k_lu_gemv3(Dev D)
   const bool doTau = c->pivotRule != 0, doFlip = c->numberFlips != 0;
   const int lane = threadIdx.x & 63;
   const double *v1 = D.slotV1, *v2 = D.rhoSlotF, *v3 = D.flipSlot;
-  for (int sc = blockIdx.x * 4 + (threadIdx.x >> 6); sc < k2; sc += gridDim.x * 4) {
-    const double *row = D.Minv + (size_t)sc * D.ld;
-    double a1 = 0.0, a2 = 0.0, a3 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
-    int i = lane;
-    for (; i + 64 < k2; i += 128) {
-      const double m0 = row[i], m1 = row[i + 64];
-      a1 += m0 * v1[i];
-      b1 += m1 * v1[i + 64];
-      if (doTau) {
-        a2 += m0 * v2[i];
-        b2 += m1 * v2[i + 64];
-      }
-      if (doFlip) {
-        a3 += m0 * v3[i];
-        b3 += m1 * v3[i + 64];
+  for (int sc0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LUG_ROWS; sc0 < k2; sc0 += gridDim.x * 4 * LUG_ROWS) {
+    double a1[LUG_ROWS], a2[LUG_ROWS], a3[LUG_ROWS];
+    const double *row[LUG_ROWS];
+#pragma unroll
+    for (int r = 0; r < LUG_ROWS; r++) {
+      a1[r] = a2[r] = a3[r] = 0.0;
+      row[r] = D.Minv + (size_t)min(sc0 + r, k2 - 1) * D.ld;
+    }
+    for (int i = lane; i < k2; i += 64) {
+      const double x1 = v1[i], x2 = doTau ? v2[i] : 0.0, x3 = doFlip ? v3[i] : 0.0;
+      double mv[LUG_ROWS];
+#pragma unroll
+      for (int r = 0; r < LUG_ROWS; r++)
+        mv[r] = row[r][i];
+#pragma unroll
+      for (int r = 0; r < LUG_ROWS; r++) {
+        a1[r] += mv[r] * x1;
+        a2[r] += mv[r] * x2;
+        a3[r] += mv[r] * x3;
       }
     }
-    if (i < k2) {
-      const double m0 = row[i];
-      a1 += m0 * v1[i];
-      if (doTau)
-        a2 += m0 * v2[i];
-      if (doFlip)
-        a3 += m0 * v3[i];
-    }
-    const double r1 = waveSum(a1 + b1), r2 = waveSum(a2 + b2), r3 = waveSum(a3 + b3);
-    if (lane == 0) {
-      D.slotC[sc] = r1;
-      D.slotD[sc] = r2;
-      D.slotE[sc] = r3;
+#pragma unroll
+    for (int r = 0; r < LUG_ROWS; r++) {
+      const double r1 = waveSum(a1[r]), r2 = waveSum(a2[r]), r3 = waveSum(a3[r]);
+      if (lane == 0 && sc0 + r < k2) {
+        D.slotC[sc0 + r] = r1;
+        D.slotD[sc0 + r] = r2;
+        D.slotE[sc0 + r] = r3;
+      }
     }
   }
 }
