@@ -179,7 +179,7 @@ struct clpgpu_context {
   int gemmBackend = 0;
   int dgemmDevice(int nn, double alpha, const double *A, const double *B, double beta, double *C);
   int luPolish = 2, numberPolishSteps = 0;
-  double luPolishTolerance = 1.0e-11, luLastResidual = 0.0;
+  double luPolishTolerance = 1.0e-9, luLastResidual = 0.0;
   int numberThrownOut = 0;  // structurals replaced by slacks by the singular-basis repair, whole solve
   void resetFakeBounds();
   int pivots = 0, kNucleus = 0;

@@ -153,12 +153,19 @@ int clpgpu_context::factorizeLu(const std::vector<int> &kcol, const std::vector<
   // ---- polish: the explicit inverse of an ill-conditioned tail carries a residual of cond(S) * eps; Newton-Schulz
   // steps X += X (I - S X) square it (the bases of the bench LP pass through condition numbers of 1e10 and more)
   hLu.k2 = k2;  // (refineInverse sizes its work from the descriptor)
+  // One GEMM measures max |I - S X|; below the tolerance nothing else happens.  A Newton-Schulz step (one more
+  // GEMM) squares the residual, so after a step from r the next measurement is only taken when r^2 is still
+  // above the tolerance.
   for (int step = 0; k2 && step < luPolish; step++) {
     const int prc = refineInverse(true, luPolishTolerance);
     luLastResidual = lastResidual;
     if (prc != 0)
-      break;  // good enough already (3), no GEMM library / not finite / too far (1, 2): keep what we have
+      break;  // good enough already (3), not finite / too far (1, 2): keep what we have
     numberPolishSteps++;
+    if (lastResidual * lastResidual < luPolishTolerance) {
+      luLastResidual = lastResidual * lastResidual;  // (estimate: the step squares it)
+      break;
+    }
   }
   // (the GEMM library probes pointers with runtime calls whose failures stay behind as the thread's "last error":
   // the engine's own launches up to here were checked by invertWork)
@@ -541,9 +548,9 @@ int clpgpu_context::factorizeLu(const std::vector<int> &kcol, const std::vector<
   luLastTail = k2;
   if (logLevel > 1)
     fprintf(stderr, "clpgpu: LU factorization: nucleus %d = front %d (L %zu, U %zu nz; explicit inverses %ld nz) + dense tail %d (S %zu nz); host %.1f ms, "
-                    "inversion %.1f ms (max |I - S X| %.2g), build+upload %.1f ms\n",
+                    "inversion %.1f ms (max |I - S X| %.2g after %d Newton-Schulz steps so far), build+upload %.1f ms\n",
             k, nF, F.lRow.size(), F.uCol.size(), luLastInverseFill, k2, F.sVal.size(),
-            1e3 * std::chrono::duration<double>(t1 - t0).count(), 1e3 * std::chrono::duration<double>(t2 - t1).count(), luLastResidual,
+            1e3 * std::chrono::duration<double>(t1 - t0).count(), 1e3 * std::chrono::duration<double>(t2 - t1).count(), luLastResidual, numberPolishSteps,
             1e3 * std::chrono::duration<double>(t3 - t2).count());
   return rc;
 }
