@@ -117,3 +117,50 @@ def test_newton_schulz_refresh_model():
 
     assert np.allclose(colmajor_gemm(rowmajor(R), rowmajor(X)), X @ R, rtol=0, atol=1e-13)
     assert np.allclose(colmajor_gemm(rowmajor(X), rowmajor(C)), C @ X, rtol=0, atol=1e-12)
+
+
+def test_product_form_algebra():
+    """The eta file of the LU mode (clp_amd/csrc/lu_kernels.hip) in numpy: with eta_j = (w_j - e_pj) / alpha_j, H = [eta_j],
+    N[j][i] = eta_i[p_j] (i < j) and G = (I + N)^-1 grown one row per update (G[t] = -n_t^T G),
+        B_t^-1 v = x0 - H (G x0[P]),   B_t^-T c = B0^-T (c - P (G^T (H^T c)))     with x0 = B0^-1 v,
+    including positions replaced more than once.  This is the algebra the kernels implement without a t-step chain."""
+    rng = np.random.default_rng(0)
+    m = 40
+    B = rng.standard_normal((m, m)) + 5 * np.eye(m)
+    B0inv = np.linalg.inv(B)
+    H, P, G = [], [], np.zeros((0, 0))
+    for j in range(25):
+        a = rng.standard_normal(m)
+        p = int(rng.integers(0, m)) if (j % 3 or not P) else P[-1]  # every third update hits the previous position again
+
+        def ftran(v):
+            x0 = B0inv @ v
+            return x0 if not H else x0 - np.array(H).T @ (G @ x0[P])
+
+        def btran(c):
+            cp = c.copy()
+            if H:
+                d = G.T @ (np.array(H) @ c)
+                for jj, pp in enumerate(P):
+                    cp[pp] -= d[jj]
+            return B0inv.T @ cp
+
+        w = ftran(a)
+        assert np.allclose(w, np.linalg.solve(B, a))
+        c = rng.standard_normal(m)
+        assert np.allclose(btran(c), np.linalg.solve(B.T, c))
+        e = np.zeros(m)
+        e[p] = 1.0
+        assert np.allclose(btran(e), np.linalg.solve(B.T, e))
+        eta = (w - e) / w[p]
+        t = len(H)
+        n = np.array([H[i][p] for i in range(t)])
+        Gn = np.zeros((t + 1, t + 1))
+        Gn[:t, :t] = G
+        if t:
+            Gn[t, :t] = -(n @ G)
+        Gn[t, t] = 1.0
+        G = Gn
+        H.append(eta)
+        P.append(p)
+        B[:, p] = a
