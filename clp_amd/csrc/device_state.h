@@ -82,7 +82,8 @@ struct Ctrl {
   int cycIn[12], cycOut[12], cycWay[12], cycHead;  // ClpSimplexProgress in_ / out_ / way_ (CLP_CYCLE = 12, src/ClpSolve.hpp:435)  // form the last pricing launch took (k_price_row_finish)
   int appendGo, flipDense;  // flipDense: this pivot's flip rhs is left to k_flip_dense
   int updGo[2], updK, updPad;  // basis-update branch: go flag per pivot parity, k at the time of the fork
-  long long dbgDc[4];  // ratio test, working-set path: calls, ticks of the whole kernel, ticks before the passes start, max ticks of one call
+  long long dbgDc[8];
+  int wsJ, wsCount;  // ratio test: breakpoint class prefix of the working set k_dc_working_set compacted, and its size (wsJ < 0: none)  // ratio test, working-set path: calls, ticks of the whole kernel, ticks before the passes start, max ticks of one call
   double tailAlpha, tailValueOut;  // w[pivotRow] / sol[sequenceOut] handed to the serial tail of k_ftran_scatter3  // this pivot's primal update completed: its list appends may be scattered  // unordered append count of k_dj_flags (ordered later by k_flip_apply2)
 };
 
@@ -189,6 +190,7 @@ struct Dev {
   int *candTag;
   unsigned char *candLive;
   double *candDj, *candRange;  // [N] dj and upper - lower of every candidate (snapshot taken by k_cand_scatter)
+  int *wsIdxG;                 // [DC_WS_CAP] working set of the ratio test (candidate indices, list order)
   int *candBlk, *candRk;       // [N] compaction block of the candidate; its rank among classes <= 0 / 1 / 2 inside that block (10 bits each)
   double *flipRecMv, *flipRecObj;   // [FLIP_LIST_CAP] per appended flip: movement, objective term
   int *flipRecStart, *flipRecLen;   // [FLIP_LIST_CAP] its column extent (a row flip: length 1)

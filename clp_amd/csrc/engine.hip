@@ -794,6 +794,7 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   rc |= dalloc(D.candRange, N);
   rc |= dalloc(D.candBlk, N);
   rc |= dalloc(D.candRk, N);
+  rc |= dalloc(D.wsIdxG, DC_WS_CAP);
   rc |= dalloc(D.flipRecMv, FLIP_LIST_CAP);
   rc |= dalloc(D.flipRecObj, FLIP_LIST_CAP);
   rc |= dalloc(D.flipRecStart, FLIP_LIST_CAP);
@@ -2638,6 +2639,7 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
     nbClass = cdiv(m + nranks * shardCandCap, PRICE_BLOCK);
     KL("k_shard_classes", k_shard_classes, dim3(nbClass), dim3(PRICE_BLOCK), 0, stream, D);
   }
+  KL("k_dc_working_set", k_dc_working_set, dim3(128), dim3(WS_THREADS), 0, stream, D, nbClass);
   KL("k_dual_column", k_dual_column, dim3(1), dim3(DC_THREADS), 0, stream, D, nbClass);
   // dual update + flip detection (needs only theta), flip list, flip right-hand side
   // (+ 1: the extra workgroup unpacks the entering column)
@@ -4443,8 +4445,9 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
     fprintf(stderr, "clpgpu dbg: dc small %lld big %lld passes %lld tries %lld sumNc %lld mapped %lld full %lld ticksSmall %lld ticksBig %lld | flip iters %lld flips %lld entries %lld sequential %lld | scattered %lld select rows %lld hot rows %lld\n",
             g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9], g[10], g[11], g[12], g[14], g[13], g[15]);
     const long long *q = ctx->hCtrl->dbgDc;
-    fprintf(stderr, "clpgpu dbg: ratio test working-set path: calls %lld, ticks/call %.0f, before the passes %.0f, max %lld\n", q[0],
-            q[0] ? (double)q[1] / q[0] : 0.0, q[0] ? (double)q[2] / q[0] : 0.0, q[3]);
+    fprintf(stderr, "clpgpu dbg: ratio test working-set path: calls %lld, ticks/call %.0f, before the passes %.0f (class loads %.0f, totals %.0f, "
+                    "prefix %.0f, compaction %.0f: in k_dc_working_set since round 3), max %lld\n", q[0], q[0] ? (double)q[1] / q[0] : 0.0, q[0] ? (double)q[2] / q[0] : 0.0,
+            q[0] ? (double)q[4] / q[0] : 0.0, q[0] ? (double)q[5] / q[0] : 0.0, q[0] ? (double)q[6] / q[0] : 0.0, q[0] ? (double)q[7] / q[0] : 0.0, q[3]);
   }
   stats->price_bytes = ctx->hCtrl->statPriceBytes;
   stats->row_bytes = ctx->hCtrl->statRowBytes;

@@ -1188,6 +1188,97 @@ __device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nu
 //    the largest class prefix that fits in registers becomes the working set, the test runs on it,
 //    and is repeated on the full list only if theta ever reaches the class threshold (exact either
 //    way).
+// The working set of the ratio test, built over the whole chip (round 3).  With a dense pi the candidate list holds
+// every nonbasic column of the right sign -- 10^5 entries -- and the single-workgroup ratio test spent 62 of its 112 us
+// walking that list once just to pick out the few thousand candidates whose breakpoints are near theta0.  Here every
+// workgroup repeats the cheap part (class totals over the compaction blocks -> the class prefix J that fits the
+// working set; exclusive prefix of the per-block counts, both from k_cand_scatter's classBlock) and then places its
+// share of the candidates at  prefix[block] + rank-in-block  in D.wsIdxG -- the same positions, hence the same
+// order, the ratio test used to compute for itself.  c->wsJ / c->wsCount tell k_dual_column what it got.
+#define WS_THREADS 256
+__global__ void __launch_bounds__(WS_THREADS) k_dc_working_set(Dev D, int nbClass)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  const int nc = c->numberCandidates;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (nc <= DC_SMALL || nbClass > DC_NB_MAX) {
+    if (blockIdx.x == 0 && tid == 0) {
+      c->wsJ = -1;
+      c->wsCount = 0;
+    }
+    return;
+  }
+  __shared__ int s_pre[DC_NB_MAX];
+  __shared__ int shCls[WS_THREADS / 64][3];
+  __shared__ int shw[WS_THREADS / 64];
+  // class totals
+  int cum[3] = { 0, 0, 0 };
+  for (int bb = tid; bb < nbClass; bb += WS_THREADS) {
+    cum[0] += D.classBlock[3 * bb];
+    cum[1] += D.classBlock[3 * bb + 1];
+    cum[2] += D.classBlock[3 * bb + 2];
+  }
+  for (int j = 0; j < 3; j++) {
+    for (int o = 32; o > 0; o >>= 1)
+      cum[j] += __shfl_xor(cum[j], o);
+    if (lane == 0)
+      shCls[wv][j] = cum[j];
+  }
+  __syncthreads();
+  for (int j = 0; j < 3; j++) {
+    cum[j] = 0;
+    for (int w = 0; w < WS_THREADS / 64; w++)
+      cum[j] += shCls[w][j];
+  }
+  cum[1] += cum[0];
+  cum[2] += cum[1];
+  int J = -1;
+  for (int j = 0; j < 3; j++)
+    if (cum[j] <= DC_WS_CAP && cum[j] < nc)
+      J = j;
+  if (J < 0 || cum[J] <= 0) {
+    if (blockIdx.x == 0 && tid == 0) {
+      c->wsJ = -1;
+      c->wsCount = 0;
+    }
+    return;
+  }
+  // exclusive prefix over the blocks of their (class <= J) counts: thread t owns a contiguous run of blocks
+  const int per = (nbClass + WS_THREADS - 1) / WS_THREADS;
+  const int b0 = tid * per, b1 = min(b0 + per, nbClass);
+  int mine = 0;
+  for (int bb = b0; bb < b1; bb++)
+    mine += D.classBlock[3 * bb] + (J >= 1 ? D.classBlock[3 * bb + 1] : 0) + (J >= 2 ? D.classBlock[3 * bb + 2] : 0);
+  int v = mine;
+  for (int o = 1; o < 64; o <<= 1) {
+    int u = __shfl_up(v, o);
+    if (lane >= o)
+      v += u;
+  }
+  if (lane == 63)
+    shw[wv] = v;
+  __syncthreads();
+  int run = v - mine;
+  for (int i = 0; i < wv; i++)
+    run += shw[i];
+  for (int bb = b0; bb < b1; bb++) {
+    s_pre[bb] = run;
+    run += D.classBlock[3 * bb] + (J >= 1 ? D.classBlock[3 * bb + 1] : 0) + (J >= 2 ? D.classBlock[3 * bb + 2] : 0);
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && tid == 0) {
+    c->wsJ = J;
+    c->wsCount = cum[J];
+  }
+  const int shift = 10 * J;
+  for (int i = blockIdx.x * WS_THREADS + tid; i < nc; i += gridDim.x * WS_THREADS) {
+    if ((int)D.candLive[i] <= J)
+      D.wsIdxG[s_pre[D.candBlk[i]] + ((D.candRk[i] >> shift) & 1023)] = i;
+  }
+}
+
 __global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass)
 {
   Ctrl *c = D.ctrl;
@@ -1215,97 +1306,19 @@ __global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass)
     return;
   }
   __shared__ int wsIdx[DC_WS_CAP];
-  __shared__ int shw[17];
   __shared__ int s_done;
-  __shared__ int shCls[DC_THREADS / 64][3];
-  __shared__ int s_pre[DC_NB_MAX];
   if (nbClass <= DC_NB_MAX) {
-    // class totals, and -- once the class prefix J is chosen -- the exclusive prefix over the compaction
-    // blocks of their (class <= J) counts.  Thread t owns DC_NB_PER consecutive blocks; all their counts
-    // are requested together.
-    const int lane = tid & 63, wv = tid >> 6;
-    int c0[DC_NB_PER], c1[DC_NB_PER], c2[DC_NB_PER];
-    int cum[3] = { 0, 0, 0 };
-#pragma unroll
-    for (int u = 0; u < DC_NB_PER; u++) {
-      const int bb = tid * DC_NB_PER + u;
-      c0[u] = bb < nbClass ? D.classBlock[3 * bb] : 0;
-      c1[u] = bb < nbClass ? D.classBlock[3 * bb + 1] : 0;
-      c2[u] = bb < nbClass ? D.classBlock[3 * bb + 2] : 0;
-    }
-#pragma unroll
-    for (int u = 0; u < DC_NB_PER; u++) {
-      cum[0] += c0[u];
-      cum[1] += c1[u];
-      cum[2] += c2[u];
-    }
-    for (int j = 0; j < 3; j++) {
-      for (int o = 32; o > 0; o >>= 1)
-        cum[j] += __shfl_xor(cum[j], o);
-      if (lane == 0)
-        shCls[wv][j] = cum[j];
-    }
-    __syncthreads();
-    for (int j = 0; j < 3; j++) {
-      cum[j] = 0;
-      for (int w = 0; w < DC_THREADS / 64; w++)
-        cum[j] += shCls[w][j];
-    }
-    cum[1] += cum[0];
-    cum[2] += cum[1];
-    int J = -1;
-    for (int j = 0; j < 3; j++)
-      if (cum[j] <= DC_WS_CAP && cum[j] < nc)
-        J = j;
-    if (J >= 0 && cum[J] > 0) {
-      const int ws = cum[J];
+    // the working set (candidates of breakpoint class <= J, in list order) was compacted over the whole chip by
+    // k_dc_working_set; only its indices are read here
+    const int J = c->wsJ;
+    if (J >= 0 && c->wsCount > 0) {
+      const int ws = c->wsCount;
       const double theta0 = fmax(10.0 * c->upperTheta, 1.0e-7);
       const double tau = theta0 * (J == 0 ? 8.0 : (J == 1 ? 256.0 : 16384.0));
-      // exclusive scan of the per-block working-set counts
-      int mine = 0;
-#pragma unroll
-      for (int u = 0; u < DC_NB_PER; u++)
-        mine += c0[u] + (J >= 1 ? c1[u] : 0) + (J >= 2 ? c2[u] : 0);
-      int v = mine;
-      for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(v, o);
-        if (lane >= o)
-          v += t;
-      }
-      if (lane == 63)
-        shw[wv] = v;
-      __syncthreads();
-      int base = 0;
-      for (int i = 0; i < wv; i++)
-        base += shw[i];
-      int run = base + v - mine;
-#pragma unroll
-      for (int u = 0; u < DC_NB_PER; u++) {
-        const int bb = tid * DC_NB_PER + u;
-        if (bb < nbClass)
-          s_pre[bb] = run;
-        run += c0[u] + (J >= 1 ? c1[u] : 0) + (J >= 2 ? c2[u] : 0);
-      }
+      for (int i = tid; i < ws; i += DC_THREADS)
+        wsIdx[i] = D.wsIdxG[i];
       if (tid == 0)
         s_done = 0;
-      __syncthreads();
-      // every candidate of class <= J drops its index at prefix[its block] + its rank inside the block
-      // (both recorded by k_cand_scatter): ordered, and four independent loads in flight per thread
-      const int shift = 10 * J;
-      for (int i0 = 0; i0 < nc; i0 += 4 * DC_THREADS) {
-        int cl[4], bk[4], rk[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int i = i0 + u * DC_THREADS + tid;
-          cl[u] = i < nc ? (int)D.candLive[i] : 9;
-          bk[u] = i < nc ? D.candBlk[i] : 0;
-          rk[u] = i < nc ? D.candRk[i] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-          if (cl[u] <= J)
-            wsIdx[s_pre[bk[u]] + ((rk[u] >> shift) & 1023)] = i0 + u * DC_THREADS + tid;
-      }
       __syncthreads();
       bool ok;
       const long long dcT1 = wall_clock64();
