@@ -3507,6 +3507,33 @@ int clpgpu_replace_column(clpgpu_context *ctx, int pivotRow, int sequenceIn, dou
 
 int clpgpu_pivots(const clpgpu_context *ctx) { return (ctx && ctx->hCtrl) ? ctx->hCtrl->pivots : 0; }
 
+// parity hook for the cycle detector of the device housekeeping (ClpSimplexProgress::cycle, src/ClpSolve.cpp:4726-4825):
+// the sequence of pivots given goes through cycleStep on a scratch control block; matched[i] = its verdict at pivot i
+int clpgpu_test_cycle(clpgpu_context *ctx, int count, const int *in, const int *out, const int *wayIn, const int *wayOut, int *matched)
+{
+  if (!ctx || count <= 0)
+    return -99;
+  Ctrl *scratch = nullptr;
+  int *d = nullptr;
+  if (hipMalloc((void **)&scratch, sizeof(Ctrl)) != hipSuccess || hipMalloc((void **)&d, sizeof(int) * 5 * (size_t)count) != hipSuccess) {
+    if (scratch)
+      (void)hipFree(scratch);
+    return -99;
+  }
+  int rc = 0;
+  rc |= ctx->h2d(d, in, count);
+  rc |= ctx->h2d(d + count, out, count);
+  rc |= ctx->h2d(d + 2 * count, wayIn, count);
+  rc |= ctx->h2d(d + 3 * count, wayOut, count);
+  hipLaunchKernelGGL(k_test_cycle, dim3(1), dim3(64), 0, ctx->stream, scratch, count, (const int *)d, (const int *)(d + count),
+                     (const int *)(d + 2 * count), (const int *)(d + 3 * count), d + 4 * count);
+  rc |= ctx->checkLaunches("clpgpu_test_cycle");
+  rc |= ctx->d2h(matched, d + 4 * count, count);
+  (void)hipFree(scratch);
+  (void)hipFree(d);
+  return rc;
+}
+
 // the engine's own f64 MFMA GEMM on host arrays (row-major n x n): c = beta c + alpha a b.  A parity hook for the
 // kernel behind the Newton-Schulz steps (CoinAbcDgemm's role, src/CoinAbcHelperFunctions.cpp:1658).
 int clpgpu_dgemm(clpgpu_context *ctx, int nn, double alpha, const double *a, const double *b, double beta, double *c)

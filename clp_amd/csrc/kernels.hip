@@ -1764,6 +1764,52 @@ __global__ void __launch_bounds__(256) k_house_col(Dev D, int which)
   }
 }
 
+// ClpSimplexProgress::cycle (src/ClpSolve.cpp:4726-4825) on the control block's ring of the last 12 (in, out, way)
+// triples: > 0 = a cycle of that length (100: irregular repeats), 0 = none; the triple of this pivot is appended.
+__device__ inline int cycleStep(Ctrl *c, int seqIn, int seqOut, int directionIn, int directionOut)
+{
+  const int head = c->cycHead;
+#define CYC(i) (((head) + (i)) % 12)
+    int matched = 0;
+    int outs[12];
+#pragma unroll
+    for (int i = 1; i < 12; i++)
+      outs[i] = c->cycOut[CYC(i)];
+#pragma unroll
+    for (int i = 1; i < 12; i++)
+      if (seqIn == outs[i] && !matched)
+        matched = -1;
+    if (matched && c->cycIn[CYC(0)] >= 0) {
+      matched = 0;
+      int nMatched = 0;
+      const int way0 = c->cycWay[CYC(0)], in0 = c->cycIn[CYC(0)], out0 = c->cycOut[CYC(0)];
+      for (int kk = 1; kk < 12 - 4; kk++) {
+        if (in0 == c->cycIn[CYC(kk)] && out0 == c->cycOut[CYC(kk)] && way0 == c->cycWay[CYC(kk)]) {
+          nMatched++;
+          const int end = 12 - kk;
+          int j;
+          for (j = 1; j < end; j++)
+            if (c->cycIn[CYC(j + kk)] != c->cycIn[CYC(j)] || c->cycOut[CYC(j + kk)] != c->cycOut[CYC(j)] ||
+                c->cycWay[CYC(j + kk)] != c->cycWay[CYC(j)])
+              break;
+          if (j == end) {
+            matched = kk;
+            break;
+          }
+        }
+      }
+      if (matched <= 0 && nMatched > 1)
+        matched = 100;
+    }
+    // drop the oldest, append this pivot: the oldest slot becomes the newest, the head moves on
+    c->cycIn[head] = seqIn;
+    c->cycOut[head] = seqOut;
+    c->cycWay[head] = 1 - directionIn + 4 * (1 - directionOut);
+    c->cycHead = (head + 1) % 12;
+#undef CYC
+  return matched;
+}
+
 __device__ void houseBody(Dev D, int skipColumns = 0)
 {
   Ctrl *c = D.ctrl;
@@ -1945,45 +1991,7 @@ __device__ void houseBody(Dev D, int skipColumns = 0)
   // that length, two irregular repeats count as 100.  Kept as a ring (entry i of the reference's arrays is
   // ring slot (head + i) % 12) so that a pivot costs 11 loads and 3 stores instead of shifting the arrays.
   {
-    const int head = c->cycHead;
-#define CYC(i) (((head) + (i)) % 12)
-    int matched = 0;
-    int outs[12];
-#pragma unroll
-    for (int i = 1; i < 12; i++)
-      outs[i] = c->cycOut[CYC(i)];
-#pragma unroll
-    for (int i = 1; i < 12; i++)
-      if (seqIn == outs[i] && !matched)
-        matched = -1;
-    if (matched && c->cycIn[CYC(0)] >= 0) {
-      matched = 0;
-      int nMatched = 0;
-      const int way0 = c->cycWay[CYC(0)], in0 = c->cycIn[CYC(0)], out0 = c->cycOut[CYC(0)];
-      for (int kk = 1; kk < 12 - 4; kk++) {
-        if (in0 == c->cycIn[CYC(kk)] && out0 == c->cycOut[CYC(kk)] && way0 == c->cycWay[CYC(kk)]) {
-          nMatched++;
-          const int end = 12 - kk;
-          int j;
-          for (j = 1; j < end; j++)
-            if (c->cycIn[CYC(j + kk)] != c->cycIn[CYC(j)] || c->cycOut[CYC(j + kk)] != c->cycOut[CYC(j)] ||
-                c->cycWay[CYC(j + kk)] != c->cycWay[CYC(j)])
-              break;
-          if (j == end) {
-            matched = kk;
-            break;
-          }
-        }
-      }
-      if (matched <= 0 && nMatched > 1)
-        matched = 100;
-    }
-    // drop the oldest, append this pivot: the oldest slot becomes the newest, the head moves on
-    c->cycIn[head] = seqIn;
-    c->cycOut[head] = seqOut;
-    c->cycWay[head] = 1 - c->directionIn + 4 * (1 - c->directionOut);
-    c->cycHead = (head + 1) % 12;
-#undef CYC
+    const int matched = cycleStep(c, seqIn, seqOut, c->directionIn, c->directionOut);
     if (matched > 0) {
       for (int i = 0; i < 12; i++) {
         c->cycIn[i] = c->cycOut[i] = -1;
@@ -5595,6 +5603,19 @@ __global__ void k_infeas_finish(Dev D)
 {
   D.ctrl->numberInfeasible = D.ctrl->numberAppend;
   D.ctrl->numberAppend = 0;
+}
+// parity hook for the cycle detector: feeds a sequence of pivots through cycleStep on a scratch control block
+__global__ void k_test_cycle(Ctrl *scratch, int n, const int *in, const int *out, const int *wayIn, const int *wayOut, int *matched)
+{
+  if (threadIdx.x || blockIdx.x)
+    return;
+  for (int i = 0; i < 12; i++) {
+    scratch->cycIn[i] = scratch->cycOut[i] = -1;
+    scratch->cycWay[i] = 0;
+  }
+  scratch->cycHead = 0;
+  for (int i = 0; i < n; i++)
+    matched[i] = cycleStep(scratch, in[i], out[i], wayIn[i], wayOut[i]);
 }
 }  // namespace clpgpu
 #include "gemm_kernel.hip"

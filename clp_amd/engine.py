@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "clpgpu_chg_obj_coefficients", "clpgpu_scale_factors",
     "clpgpu_clone", "clpgpu_set_scales", "clpgpu_ftran_ft", "clpgpu_ftran_two_ft", "clpgpu_bind_rim", "clpgpu_pivot_row",
     "clpgpu_update_weights", "clpgpu_update_primal", "clpgpu_save_weights", "clpgpu_unroll_weights",
-    "clpgpu_get_kernel_times", "clpgpu_dgemm",
+    "clpgpu_get_kernel_times", "clpgpu_dgemm", "clpgpu_test_cycle",
     "clpgpu_virtual_group_create", "clpgpu_virtual_group_destroy", "clpgpu_virtual_attach", "clpgpu_virtual_dual_steps",
 ]
 
@@ -357,6 +357,16 @@ class ClpGpuSimplex:
 
     def replaceColumn(self, pivot_row, sequence_in):
         return lib().clpgpu_replace_column(self._h, int(pivot_row), int(sequence_in), 0.0, 1e-8)
+
+    def testCycle(self, seq_in, seq_out, way_in, way_out):
+        """the device cycle detector over a sequence of pivots (see clpgpu_test_cycle)"""
+        arr = [np.ascontiguousarray(a, dtype=np.int32) for a in (seq_in, seq_out, way_in, way_out)]
+        out = np.zeros(len(arr[0]), np.int32)
+        ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+        f = lib().clpgpu_test_cycle
+        f.argtypes = [C.c_void_p, C.c_int, ip, ip, ip, ip, ip]
+        self._check(f(self._h, len(out), *arr, out), "clpgpu_test_cycle")
+        return out
 
     def dgemm(self, alpha, a, b, beta, c):
         """c = beta c + alpha a b on the engine's own MFMA f64 GEMM (square row-major arrays)"""

@@ -280,6 +280,12 @@ int clpgpu_virtual_attach(clpgpu_context *ctx, clpgpu_virtual_group *group, int 
  * 0, or -2 when the ranks lost step (an exchange timed out). */
 int clpgpu_virtual_dual_steps(clpgpu_virtual_group *group, int iterations, int *status);
 
+/* ClpSimplexProgress::cycle (src/ClpSolve.cpp:4726-4825; called from ClpSimplex::housekeeping, src/ClpSimplex.cpp:2397-2431):
+ * the device housekeeping's cycle detector fed with a sequence of pivots (entering, leaving, their directions), from
+ * empty history; matched[i] = its verdict at pivot i (0 none, k a cycle of length k, 100 irregular repeats).  A parity hook:
+ * no LP here runs into a cycle on its own. */
+int clpgpu_test_cycle(clpgpu_context *ctx, int count, const int *in, const int *out, const int *wayIn, const int *wayOut, int *matched);
+
 /* CoinAbcDgemm (src/CoinAbcHelperFunctions.cpp:1658; used by CoinAbcDgetrf, src/AbcSimplexParallel.cpp:2491-2534):
  * the engine's own f64 GEMM on the matrix cores, c = beta c + alpha a b for row-major n x n host arrays.  The
  * kernel behind the Newton-Schulz steps on the explicit (tail) inverse; exposed so that tests hold it to numpy. */

@@ -2059,6 +2059,20 @@ static int progressCycle(OrcModel *M, int in, int out, int wayIn, int wayOut)
   return matched;
 }
 
+/* parity hook: a sequence of pivots through progressCycle on a scratch model (tests compare it with the device's
+ * ring-buffer form and with a Python restatement of ClpSolve.cpp:4726-4825) */
+void orc_test_cycle(int n, const int *in, const int *out, const int *wayIn, const int *wayOut, int *matched)
+{
+  OrcModel *M = (OrcModel *)calloc(1, sizeof(OrcModel));
+  for (int i = 0; i < ORC_CYCLE; i++) {
+    M->cycIn[i] = M->cycOut[i] = -1;
+    M->cycWay[i] = 0;
+  }
+  for (int i = 0; i < n; i++)
+    matched[i] = progressCycle(M, in[i], out[i], wayIn[i], wayOut[i]);
+  free(M);
+}
+
 /* ClpSimplex::housekeeping :2065-2489.  Returns 0 carry on, 1 refactorize,
  * 2 iteration limit. */
 static int housekeeping(OrcModel *M, double objectiveChange, int numberFlipped)

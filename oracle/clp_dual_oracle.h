@@ -104,6 +104,8 @@ int orc_price_row_fused(const OrcModel *model, int numberPi, const int *piIndex,
                         int *numberCandidates, int *candIndex, double *candValue, double *upperTheta);
 
 /* factorization of the basis given by status (basic==1): returns 0 or -1 singular; fills pivotVariable */
+/* ClpSimplexProgress::cycle (src/ClpSolve.cpp:4726-4825) over a sequence of pivots, from empty history */
+void orc_test_cycle(int n, const int *in, const int *out, const int *wayIn, const int *wayOut, int *matched);
 int orc_factorize(OrcModel *model, const unsigned char *status, int *pivotVariable);
 /* in-place dense (length m) solves with the current factorization (+ eta file) */
 void orc_ftran(OrcModel *model, double *region);

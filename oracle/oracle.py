@@ -200,3 +200,15 @@ class OracleSimplex:
 
     def replace_column(self, w, pivot_row, alpha):
         return lib().orc_replace_column(self._h, np.ascontiguousarray(w, dtype=np.float64), int(pivot_row), float(alpha))
+
+
+def test_cycle(seq_in, seq_out, way_in, way_out):
+    """ClpSimplexProgress::cycle of the oracle over a sequence of pivots (orc_test_cycle)"""
+    arr = [np.ascontiguousarray(a, dtype=np.int32) for a in (seq_in, seq_out, way_in, way_out)]
+    out = np.zeros(len(arr[0]), np.int32)
+    ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    f = lib().orc_test_cycle
+    f.restype = None
+    f.argtypes = [C.c_int, ip, ip, ip, ip, ip]
+    f(len(out), *arr, out)
+    return out
