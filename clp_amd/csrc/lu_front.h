@@ -46,6 +46,13 @@ struct LuFront {
   double seconds = 0.0;
 };
 
+// progress print of the elimination (environment LUDBG=1), read once
+static inline bool luFrontDebug()
+{
+  static const bool on = getenv("LUDBG") != nullptr;
+  return on;
+}
+
 // C given by columns: column c holds rows cRow[cStart[c] .. cStart[c+1]) (local nucleus rows 0..k-1).
 // stopDensity: stop when nnz(active) > stopDensity * nActive^2; minTail: never look for pivots once the
 // active block is this small; threshold u: |pivot| >= u * max|row|.
@@ -164,7 +171,15 @@ static inline void luFrontFactor(int k, const int *cStart, const int *cRow, cons
           trials++;
       }
     }
-    if (getenv("LUDBG") && (F.nF % 250 == 0)) { static double tl = 0; struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); double tn = ts.tv_sec + 1e-9 * ts.tv_nsec; fprintf(stderr, "step %d nAct %d actNnz %ld bestCost %.0f minCount %d us/step %.1f\n", F.nF, nAct, actNnz, bestCost, minCount, (tn - tl) * 1e6 / 250); tl = tn; }
+    if (luFrontDebug() && (F.nF % 250 == 0)) {
+      static double tl = 0;
+      struct timespec ts;
+      clock_gettime(CLOCK_MONOTONIC, &ts);
+      const double tn = ts.tv_sec + 1e-9 * ts.tv_nsec;
+      fprintf(stderr, "step %d nAct %d actNnz %ld bestCost %.0f minCount %d us/step %.1f\n", F.nF, nAct, actNnz, bestCost, minCount,
+              (tn - tl) * 1e6 / 250);
+      tl = tn;
+    }
     if (bi < 0)
       break;  // nothing acceptable among the sparse candidates: the rest goes to the dense tail
     // ---- eliminate with pivot (bi, bj)
@@ -284,37 +299,6 @@ static inline void luFrontFactor(int k, const int *cStart, const int *cRow, cons
         F.sCol.push_back(slotOfCol[rIdx[i][q]]);
         F.sVal.push_back(rVal[i][q]);
       }
-}
-
-// Device-side form of the front: four gather-form sparse triangular structures with level sets
-// (the dependency DAGs of a Markowitz front on these LPs are 6-8 levels deep), indexed by local
-// nucleus row (work vector "wr") and local nucleus column ("xc").
-struct LuLevels {
-  // items of each level, then per item its entries
-  std::vector<int> levelStart;  // [nLevels+1] into item
-  std::vector<int> item;        // the row / pivot / column the item computes
-  std::vector<int> itemStart;   // [nItems+1] into ent
-  std::vector<int> entIdx;
-  std::vector<double> entVal;
-  std::vector<double> itemDiv;  // pivot value (1.0 where none)
-  std::vector<int> itemAux;     // second index of the item (meaning depends on the structure)
-};
-
-// order the items by level; dependencies: level(item) = 1 + max(level(dep)) ; deps given through lvOf[]
-static inline void luBuildLevels(int nItems, const std::vector<int> &itemLevel, LuLevels &out, std::vector<int> &order)
-{
-  int nLev = 0;
-  for (int i = 0; i < nItems; i++)
-    nLev = std::max(nLev, itemLevel[i] + 1);
-  out.levelStart.assign(nLev + 1, 0);
-  for (int i = 0; i < nItems; i++)
-    out.levelStart[itemLevel[i] + 1]++;
-  for (int l = 0; l < nLev; l++)
-    out.levelStart[l + 1] += out.levelStart[l];
-  order.assign(nItems, 0);
-  std::vector<int> fillPos(out.levelStart.begin(), out.levelStart.end() - 1);
-  for (int i = 0; i < nItems; i++)
-    order[fillPos[itemLevel[i]]++] = i;
 }
 
 }  // namespace clpgpu
