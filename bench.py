@@ -393,7 +393,8 @@ def main():
                 "k_lu_gemv3": (8.0 * kd * kd, "hbm", "three FTRAN right-hand sides through the dense tail inverse in one sweep: 8 k^2 B"),
                 "k_ftran_scatter3_lu": (8.0 * lp.m * eta + 3 * 8.0 * lp.m, "hbm", "eta file: x = x0 - H s over the m positions, 8 m t B (t = etas since the factorization)"),
                 "k_primal_rank1": (16.0 * kd * kd, "hbm", "rank-1 update of the explicit nucleus inverse: 16 k^2 B"),
-                "k_price_sell": (price_b, "hbm", "row pricing by column: bytes the kernel streams (4 B per row index, 8 B per element fetched, lists)"),
+                "k_price_sell": (None if "k_price_tiled" in kern else price_b, "hbm", "row pricing by column: bytes the kernel streams (4 B per row index, 8 B per element fetched, lists)"),
+                "k_price_tiled": (price_b, "hbm", "row pricing by column with pi tiles in LDS: 2-byte row index + 8-byte element per entry of the nonbasic columns (padding of the tile segments not counted); k_price_sell then only runs the fused first ratio pass on the result"),
             }
             rl = []
             for name, (us, cnt) in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1]):

@@ -215,6 +215,14 @@ struct Dev {
   const int *sellRow;
   const double *sellElem;
   int numSlices;
+  // the same slices stored tile by tile for the dense-pi form (k_price_tiled): numTiles row tiles of tileRows;
+  // segment (tile, slice) at tsStart[tile * numSlices + slice], entry t of lane l at + 64 t + l
+  int numTiles, tileRows;
+  const int *tsStart;            // [numTiles * numSlices]
+  const unsigned char *tsLen;    // [numTiles * numSlices * 64] entries of the lane's column in the tile
+  const unsigned short *tsRow;   // row index local to the tile
+  const double *tsElem;
+  double *priceAcc;              // [numSlices * 64] dot products left by k_price_tiled
   int *touchCol;  // [n] by-row pricing: contributors per column while a tableau row is assembled (zero otherwise)
   int *touchRow;  // [n * 8] their rows ...
   double *touchVal;  // [n * 8] ... and products, in ticket order

@@ -237,6 +237,10 @@ struct clpgpu_context {
   // option "row_price_frac": row pricing goes BY ROW when nnz(pi) <= frac * m (the reference's switch,
   // src/ClpPackedMatrix.cpp:727-754, with the crossover measured on the MI355X); 0 = always by column
   double rowPriceFrac = 0.02;
+  // option "price_tiles" (default 1; before the load): keep a second, row-tiled SELL copy and price dense tableau rows
+  // with pi in LDS (k_price_tiled)
+  int priceTiles = 1;
+  size_t priceTileLds = 0;
   // option "flip_scatter": the waves that detect a bound flip scatter its column into per-row slots
   // (1: sparse LPs with light rows only; 2: any sparse LP -- tests); 0 = the single-workgroup assembly
   // from the flip records
@@ -965,8 +969,45 @@ int clpgpu_context::buildSell()
   std::vector<int> order(count);
   for (int i = 0; i < count; i++)
     order[i] = first + i;
+  // Row tiles of the dense-pi pricing form (k_price_tiled): pi tile <= 133 KB of LDS, 2-byte local row indices.
+  // Needs the rows of every column in ascending order (tile after tile is then the column's own entry order).
+  int numTiles = 0, tileRows = 0;
+  if (priceTiles && count >= 64 * 64 && m >= 4096) {
+    numTiles = (int)(((size_t)m * 8 + 135999) / 136000);
+    tileRows = ((m + numTiles - 1) / numTiles + 7) & ~7;
+    bool sorted = tileRows <= 65535 && numTiles <= 8;
+    for (int j = first; j < last && sorted; j++)
+      for (int p = colStart[j] + 1; p < colStart[j + 1]; p++)
+        if (row[p] <= row[p - 1]) {
+          sorted = false;
+          break;
+        }
+    if (!sorted)
+      numTiles = 0;
+  }
+  std::vector<unsigned char> tileCount;  // [count][numTiles] entries of a column per tile (columns of <= SELL_LONG entries)
+  if (numTiles) {
+    tileCount.assign((size_t)count * numTiles, 0);
+    for (int i = 0; i < count; i++) {
+      const int j = first + i;
+      if (colStart[j + 1] - colStart[j] <= SELL_LONG)
+        for (int p = colStart[j]; p < colStart[j + 1]; p++)
+          tileCount[(size_t)i * numTiles + row[p] / tileRows]++;
+    }
+  }
+  // columns by decreasing length; with tiles, columns of equal length by their entries per tile, so that the 64
+  // columns of a slice have similar tile profiles and the per-tile segments pad by ~10 % instead of ~50 %
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-    return (colStart[a + 1] - colStart[a]) > (colStart[b + 1] - colStart[b]);
+    const int la = colStart[a + 1] - colStart[a], lb = colStart[b + 1] - colStart[b];
+    if (la != lb)
+      return la > lb;
+    if (numTiles) {
+      const unsigned char *ca = &tileCount[(size_t)(a - first) * numTiles], *cb = &tileCount[(size_t)(b - first) * numTiles];
+      for (int q = 0; q + 1 < numTiles; q++)
+        if (ca[q] != cb[q])
+          return ca[q] > cb[q];
+    }
+    return false;
   });
   // columns longer than SELL_LONG entries would keep one lane busy for len/8 dependent trips while
   // the rest of the chip waits (power-law column counts): they leave the SELL copy and are priced by
@@ -1009,6 +1050,56 @@ int clpgpu_context::buildSell()
         sellElem[base + (size_t)t * 64] = elem[p];
       }
     }
+  if (numSlices > PT_MAXS * 256 * (PT_THREADS / 64))
+    numTiles = 0;  // more slices than the persistent grid's waves can carry in registers
+  std::vector<int> tsStart;
+  std::vector<unsigned char> tsLen;
+  std::vector<unsigned short> tsRow;
+  std::vector<double> tsElem;
+  if (numTiles) {
+    tsStart.assign((size_t)numTiles * numSlices, 0);
+    tsLen.assign((size_t)numTiles * numSlices * 64, 0);
+    size_t totalT = 0;
+    for (int q = 0; q < numTiles; q++)
+      for (int s = 0; s < numSlices; s++) {
+        int maxLen = 0;
+        for (int l = 0; l < 64; l++) {
+          const int i = s * 64 + l;
+          if (i < count) {
+            const unsigned char cnt = tileCount[(size_t)(order[i] - first) * numTiles + q];
+            tsLen[((size_t)q * numSlices + s) * 64 + l] = cnt;
+            maxLen = std::max(maxLen, (int)cnt);
+          }
+        }
+        maxLen = (maxLen + 1) & ~1;
+        if (totalT + (size_t)maxLen * 64 > 2000000000u) {
+          numTiles = 0;
+          break;
+        }
+        tsStart[(size_t)q * numSlices + s] = (int)totalT;
+        totalT += (size_t)maxLen * 64;
+      }
+    if (numTiles) {
+      tsRow.assign(totalT ? totalT : 1, 0);
+      tsElem.assign(totalT ? totalT : 1, 0.0);
+      for (int s = 0; s < numSlices; s++)
+        for (int l = 0; l < 64; l++) {
+          const int i = s * 64 + l;
+          if (i >= count)
+            continue;
+          const int j = order[i];
+          int p = colStart[j];
+          for (int q = 0; q < numTiles; q++) {
+            const size_t base = (size_t)tsStart[(size_t)q * numSlices + s] + l;
+            const int cnt = tsLen[((size_t)q * numSlices + s) * 64 + l];
+            for (int u = 0; u < cnt; u++, p++) {
+              tsRow[base + (size_t)u * 64] = (unsigned short)(row[p] - q * tileRows);
+              tsElem[base + (size_t)u * 64] = elem[p];
+            }
+          }
+        }
+    }
+  }
   int *dStart, *dCol, *dLen, *dRow, *dLong;
   double *dElem;
   int rc = 0;
@@ -1063,6 +1154,38 @@ int clpgpu_context::buildSell()
   D.numSlices = numSlices;
   D.longCol = dLong;
   D.numLong = nLong;
+  D.numTiles = 0;
+  if (numTiles && !rc) {
+    int *dTs;
+    unsigned char *dTl;
+    unsigned short *dTr;
+    double *dTe, *dAcc;
+    rc |= dalloc(dTs, tsStart.size());
+    rc |= dalloc(dTl, tsLen.size());
+    rc |= dalloc(dTr, tsRow.size());
+    rc |= dalloc(dTe, tsElem.size());
+    rc |= dalloc(dAcc, (size_t)numSlices * 64);
+    if (!rc) {
+      rc |= h2d(dTs, tsStart.data(), tsStart.size());
+      rc |= h2d(dTl, tsLen.data(), tsLen.size());
+      rc |= h2d(dTr, tsRow.data(), tsRow.size());
+      rc |= h2d(dTe, tsElem.data(), tsElem.size());
+      rc |= sync();
+      // the pi tile needs more dynamic LDS than the default limit allows
+      priceTileLds = (size_t)tileRows * sizeof(double);
+      if (hipFuncSetAttribute((const void *)k_price_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, (int)priceTileLds) == hipSuccess) {
+        D.tsStart = dTs;
+        D.tsLen = dTl;
+        D.tsRow = dTr;
+        D.tsElem = dTe;
+        D.priceAcc = dAcc;
+        D.tileRows = tileRows;
+        D.numTiles = numTiles;
+      } else {
+        (void)hipGetLastError();
+      }
+    }
+  }
   dropGraph();
   return rc;
 }
@@ -2596,6 +2719,8 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
     if (widePricing && priceKernel != 1)
       KL("k_price_wide", k_price_wide, dim3(nWideBlocks), dim3(256), 0, stream, D, denseColumns ? 1 : 0, countInPrice ? 1 : 0);
     else if (nSlots > 0) {
+      if (D.numTiles > 0 && priceKernel == 6)
+        KL("k_price_tiled", k_price_tiled, dim3(256), dim3(PT_THREADS), priceTileLds, stream, D);
       KL("k_price_sell", k_price_sell, dim3(nSlots + (rowMax > 0 ? gm : 0)), dim3(256),
          (m > 64 * SELL_BITS_MAX || priceKernel < 2) ? 0 : (size_t)((m + 63) / 64) * 8, stream, D,
          (m > 64 * SELL_BITS_MAX && priceKernel > 1) ? 1 : priceKernel, countInPrice ? 1 : 0, nSellBlocks, nSlots, rowMax);
@@ -3123,8 +3248,20 @@ int clpgpu_context::priceRow(int numberPi, const int *piIndex, const double *piV
     hipLaunchKernelGGL(k_price_row_finish, dim3(nbCols), dim3(PRICE_BLOCK), 0, stream, D, nbRows, m + 1);
     hipLaunchKernelGGL(k_cand_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, nSlots);
   } else if (priceKernel >= 1) {
-    if (nSlots > 0)
-      hipLaunchKernelGGL(k_price_sell, dim3(nSlots), dim3(256), 0, stream, D, 1, 0, nSellBlocks);
+    if (nSlots > 0) {
+      if (D.numTiles > 0 && priceKernel == 6 && 12LL * numberPi >= (long long)m && m <= 64 * SELL_BITS_MAX) {
+        // dense pi: the tiled form (pi tiles in LDS), as the iteration chain takes it; the bitmap of pi's rows first
+        std::vector<unsigned long long> bitsHost((size_t)((m + 63) / 64) + 4, 0ull);
+        for (int i = 0; i < numberPi; i++)
+          if (piValue[i] != 0.0)
+            bitsHost[piIndex[i] >> 6] |= 1ull << (piIndex[i] & 63);
+        rc |= h2d(D.piBits, bitsHost.data(), bitsHost.size());
+        hipLaunchKernelGGL(k_price_tiled, dim3(256), dim3(PT_THREADS), priceTileLds, stream, D);
+        hipLaunchKernelGGL(k_price_sell, dim3(nSlots), dim3(256), (size_t)((m + 63) / 64) * 8, stream, D, 6, 0, nSellBlocks);
+      } else {
+        hipLaunchKernelGGL(k_price_sell, dim3(nSlots), dim3(256), 0, stream, D, 1, 0, nSellBlocks);
+      }
+    }
     hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, 0, nSlots);
   } else {
     hipLaunchKernelGGL(k_price, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
@@ -4098,6 +4235,11 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "flip_slot_cap")) { ctx->flipSlotCap = std::max(1, std::min((int)v, (int)FLIP_SLOTS)); ctx->dropGraph(); }
   else if (!strcmp(name, "flip_scatter")) { ctx->flipScatter = v >= 2.0 ? 2 : (v != 0.0 ? 1 : 0); ctx->dropGraph(); }
   else if (!strcmp(name, "row_price_frac")) { ctx->rowPriceFrac = v < 0.0 ? 0.0 : v; ctx->dropGraph(); }
+  else if (!strcmp(name, "price_tiles")) {
+    if (ctx->n > 0 && ctx->D.colStart)
+      return -2;  // decides what buildSell lays out: set before clpgpu_load_problem
+    ctx->priceTiles = (int)v;
+  }
   else if (!strcmp(name, "scaling")) {
     if (ctx->n > 0 && ctx->D.colStart)
       return -2;  // the matrix is already on the device in its current units: set before clpgpu_load_problem

@@ -2478,6 +2478,10 @@ __device__ inline void priceSellBody(Dev D, unsigned long long *bits, int countC
               hits++;
             }
         }
+      } else if (COND && D.numTiles > 0) {
+        // dense pi: k_price_tiled has left every column's dot product (pi tiles in LDS, same summation order)
+        value = (len > 0) ? D.priceAcc[idx] : 0.0;
+        hits = -2;
       } else {
         for (int t = 0; t < maxLen; t += SELL_U) {
           int r[SELL_U];
@@ -2502,7 +2506,8 @@ __device__ inline void priceSellBody(Dev D, unsigned long long *bits, int countC
       if (wanted) {
         // bytes this column really streams: every row index (4 B), the element (8 B) only where it is fetched --
         // all of them in the unconditional forms, those under a set bit of pi in the conditional one
-        bytes = 4.0 * len + 8.0 * (hits < 0 ? len : hits) + 4.0;
+        bytes = hits == -2 ? 10.0 * len + 12.0  // tiled form: 2-byte row index + element per entry, accumulator, column index
+                           : 4.0 * len + 8.0 * (hits < 0 ? len : hits) + 4.0;
         if (fabs(value) > zeroTolerance) {
           bytes += 20.0;
           if (wanted > 0) {
@@ -2857,6 +2862,102 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_price_row_init(Dev D, int nbCol
 // workgroups [0, nSellBlocks) sweep the SELL slices, the next numLong the long columns; the last
 // nRowBlocks (= cdiv(m, 256), only when rowMax > 0) are pass 1 of the by-row form.  rowMax > 0: nnz(pi)
 // <= rowMax sends the launch by row (the by-column workgroups return), otherwise by column.
+// Row pricing by column with pi in LDS (round 3; the dense-pi regime).  The gather of pi -- 8 bytes out of a 64-byte
+// line, one per matrix entry, 10^7 per launch -- saturates the L2 request path at a fifth of the HBM rate when pi is a
+// plain global array.  Here the rows are cut into D.numTiles tiles of D.tileRows (pi tile <= 133 KB of LDS), the SELL
+// copy is stored tile by tile (same 64-column slices, columns ordered by (length, entries per tile) so that a slice
+// pads by ~10 %; 2-byte row index local to the tile + 8-byte element), and a persistent grid of one 1024-thread
+// workgroup per CU walks the tiles in order: every wave owns one slice (up to PT_MAXS), loads nothing but its streams,
+// gathers pi from LDS, and keeps each column's partial sum in a register from tile to tile -- rows ascend within a
+// column, so the sum is the reference's sequential sum, bit for bit (ClpPackedMatrix.cpp:1799-1993).  The result goes
+// to D.priceAcc by SELL position; k_price_sell then does its fused first ratio pass on it without touching the matrix.
+// Sparse pi (12 nnz < m, the rule of priceSellBody) leaves the launch at once: those pivots price by row or by the
+// conditional-fetch form.
+#define PT_THREADS 1024
+#define PT_MAXS 4
+__global__ void __launch_bounds__(PT_THREADS) k_price_tiled(Dev D)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  extern __shared__ double piTile[];
+  __shared__ int shPop[PT_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  {
+    int pop = 0;
+    const int nwords = (D.m + 63) >> 6;
+    for (int w = tid; w < nwords; w += PT_THREADS)
+      pop += __popcll(D.piBits[w]);
+    for (int o = 32; o > 0; o >>= 1)
+      pop += __shfl_xor(pop, o);
+    if (lane == 0)
+      shPop[wv] = pop;
+    __syncthreads();
+    pop = 0;
+    for (int w = 0; w < PT_THREADS / 64; w++)
+      pop += shPop[w];
+    if (12 * (long long)pop < (long long)D.m)
+      return;
+  }
+  const int numSlices = D.numSlices, wavesTotal = gridDim.x * (PT_THREADS / 64);
+  const int gw = blockIdx.x * (PT_THREADS / 64) + wv;
+  double acc[PT_MAXS];
+  bool want[PT_MAXS];
+#pragma unroll
+  for (int q = 0; q < PT_MAXS; q++) {
+    acc[q] = 0.0;
+    const int s = gw + q * wavesTotal;
+    want[q] = false;
+    if (s < numSlices) {
+      const int j = D.sellCol[s * 64 + lane];
+      want[q] = j >= 0 && ((D.status[j] & 3) - 1) != 0;  // basic columns are not priced
+    }
+  }
+  for (int tau = 0; tau < D.numTiles; tau++) {
+    __syncthreads();
+    const int r0 = tau * D.tileRows, rn = min(D.tileRows, D.m - r0);
+    for (int i = tid; i < rn; i += PT_THREADS)
+      piTile[i] = D.piNeg[r0 + i];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PT_MAXS; q++) {
+      const int s = gw + q * wavesTotal;
+      if (s >= numSlices)
+        continue;
+      const size_t seg = (size_t)tau * numSlices + s;
+      const int len = want[q] ? (int)D.tsLen[seg * 64 + lane] : 0;
+      int maxLen = len;
+      for (int o = 32; o > 0; o >>= 1)
+        maxLen = max(maxLen, __shfl_xor(maxLen, o));
+      const unsigned short *rp = D.tsRow + D.tsStart[seg] + lane;
+      const double *ep = D.tsElem + D.tsStart[seg] + lane;
+      double a = acc[q];
+      // (segments are padded to an even number of steps; four steps in flight)
+      for (int t = 0; t < maxLen; t += 4) {
+        unsigned short r[4];
+        double e[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const bool in = t + u < maxLen;
+          r[u] = in ? rp[(size_t)(t + u) * 64] : (unsigned short)0;
+          e[u] = in ? ep[(size_t)(t + u) * 64] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (t + u < len)
+            a += piTile[r[u]] * e[u];
+      }
+      acc[q] = a;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < PT_MAXS; q++) {
+    const int s = gw + q * wavesTotal;
+    if (s < numSlices)
+      D.priceAcc[s * 64 + lane] = acc[q];
+  }
+}
+
 __global__ void __launch_bounds__(256) k_price_sell(Dev D, int variant, int countCols = 0, int nSellBlocks = 1 << 30, int nColBlocks = 1 << 30,
                                                     int rowMax = 0, int fullRows = 0)
 {

@@ -249,3 +249,44 @@ def test_own_mfma_gemm_matches_numpy(gpu_cls, n):
         out = g.dgemm(alpha, a, b, beta, c)
         ref = beta * c + alpha * (a @ b)
         assert np.max(np.abs(out - ref)) <= 1e-12 * n * (1.0 + np.max(np.abs(ref)))
+
+
+# ---------------------------------------------------------------- row pricing with pi in LDS ----------------
+@pytest.mark.parametrize("args", [(20000, 40000, 8, 29), (50000, 200000, 50, 20260926)])
+def test_tiled_pricing_bit_identical_to_oracle(gpu_cls, args):
+    """Dense tableau rows are priced by k_price_tiled (row tiles of pi in LDS, tile-by-tile SELL copy): the tableau row,
+    the candidate list and upperTheta must be the oracle's bit for bit, on a two-tile LP and on config 4 (three tiles)."""
+    lp = P.sparse_lp(*args)
+    g, o = gpu_cls().loadProblem(lp), oracle(lp)
+    rng = np.random.default_rng(17)
+    m, n = lp.m, lp.n
+    for density in (0.5, 0.12):
+        k = int(density * m)
+        idx = np.sort(rng.choice(m, k, replace=False)).astype(np.int32)
+        val = rng.standard_normal(k)
+        status = rng.choice([1, 2, 3, 5], size=n + m, p=[0.2, 0.3, 0.45, 0.05]).astype(np.uint8)
+        dj = np.where((status & 3) == 2, -1.0, 1.0) * rng.uniform(0, 2, n + m)
+        a, b = g.priceRow(idx, val, status, dj), o.price_row_fused(idx, val, status, dj)
+        for x, y in zip(a[:4], b[:4]):
+            assert np.array_equal(x, y)
+        assert a[4] == b[4]
+
+
+def test_tiled_pricing_engine_runs_match_untiled(gpu_cls):
+    """The same solve stretch with and without the tiled form (option price_tiles): identical pivots and solution bits,
+    far enough into the solve for pi to be dense on most pivots."""
+    lp = P.sparse_lp(20000, 40000, 8, seed=29)
+    runs = []
+    for tiles in (1, 0):
+        g = gpu_cls()
+        g.set_option("price_tiles", tiles)
+        g.loadProblem(lp)
+        g.set_option("pivot_rule", 1)
+        g.set_option("check_every", 16)
+        g.set_option("max_pivots", 0)
+        g.set_option("factor_mode", 0)
+        g.dual_steps(6000)
+        runs.append(g)
+    a, b = runs[0].pivotLog(), runs[1].pivotLog()
+    assert len(a) == len(b) and np.array_equal(a["sequenceIn"], b["sequenceIn"]) and np.array_equal(a["sequenceOut"], b["sequenceOut"])
+    assert np.array_equal(runs[0].solution(), runs[1].solution())
