@@ -237,9 +237,12 @@ struct clpgpu_context {
   // option "row_price_frac": row pricing goes BY ROW when nnz(pi) <= frac * m (the reference's switch,
   // src/ClpPackedMatrix.cpp:727-754, with the crossover measured on the MI355X); 0 = always by column
   double rowPriceFrac = 0.02;
-  // option "price_tiles" (default 1; before the load): keep a second, row-tiled SELL copy and price dense tableau rows
-  // with pi in LDS (k_price_tiled)
-  int priceTiles = 1;
+  // option "price_tiles" (default 0; before the load): keep a second, row-tiled SELL copy and price dense tableau rows
+  // with pi in LDS (k_price_tiled).  Bit-identical to the plain form (tests) but measured SLOWER on the MI355X: the
+  // matrix sweep of k_price_sell already runs at ~0.58 of the HBM peak (26 us for 120 MB; the other 41 us of that kernel
+  // are the fused first ratio pass and the candidate bookkeeping over 10^5 candidates), while the tiled sweep -- one
+  // slice per wave, three barrier-separated phases, one workgroup per CU -- takes 50 us (profiles/r03_tiled_pricing.txt)
+  int priceTiles = 0;
   size_t priceTileLds = 0;
   // option "flip_scatter": the waves that detect a bound flip scatter its column into per-row slots
   // (1: sparse LPs with light rows only; 2: any sparse LP -- tests); 0 = the single-workgroup assembly
@@ -3950,6 +3953,7 @@ clpgpu_context *clpgpu_clone(const clpgpu_context *src)
   ctx->blockedRefactor = src->blockedRefactor;
   ctx->registerPanel = src->registerPanel;
   ctx->rowPriceFrac = src->rowPriceFrac;
+  ctx->priceTiles = src->priceTiles;
   ctx->flipScatter = src->flipScatter;
   ctx->flipSlotCap = src->flipSlotCap;
   ctx->refreshMinK = src->refreshMinK;

@@ -257,7 +257,10 @@ def test_tiled_pricing_bit_identical_to_oracle(gpu_cls, args):
     """Dense tableau rows are priced by k_price_tiled (row tiles of pi in LDS, tile-by-tile SELL copy): the tableau row,
     the candidate list and upperTheta must be the oracle's bit for bit, on a two-tile LP and on config 4 (three tiles)."""
     lp = P.sparse_lp(*args)
-    g, o = gpu_cls().loadProblem(lp), oracle(lp)
+    g = gpu_cls()
+    g.set_option("price_tiles", 1)  # (off by default: measured slower than the plain sweep, DESIGN section 5)
+    g.loadProblem(lp)
+    o = oracle(lp)
     rng = np.random.default_rng(17)
     m, n = lp.m, lp.n
     for density in (0.5, 0.12):
