@@ -1504,7 +1504,8 @@ int clpgpu_context::factorizeOnce()
   }
   const int k = (int)kcol.size();
   numberRefactorizations++;
-  const bool wantLu = k > 0 && (factorMode == 1 || (factorMode < 0 && !wideRows && !commActive && k >= luMinK));
+  // (column-sharded runs keep the explicit inverse: the LU chain has not been run with an exchange in it)
+  const bool wantLu = k > 0 && !commActive && (factorMode == 1 || (factorMode < 0 && !wideRows && k >= luMinK));
   if (wantLu != luActive)
     dropGraph();  // the chain of a pivot differs between the two forms
   if (wantLu) {
