@@ -245,7 +245,7 @@ int clpgpu_context::factorizeLu(const std::vector<int> &kcol, const std::vector<
       for (const auto &pr : linv[p])
         spaAdd(pr.first, -mult * pr.second);
     }
-    std::sort(spaList.begin(), spaList.end());
+    // (entries stay in the order the recurrence produced them: deterministic, and the gather kernels do not care)
     linv[r].reserve(spaList.size());
     for (int j : spaList) {
       if (spa[j] != 0.0)
@@ -276,7 +276,7 @@ int clpgpu_context::factorizeLu(const std::vector<int> &kcol, const std::vector<
         spaAdd(k + tailSlotOfCol[cc], -u);
       }
     }
-    std::sort(spaList.begin(), spaList.end());
+    // (entries stay in the order the recurrence produced them: deterministic, and the gather kernels do not care)
     xinv[f].reserve(spaList.size());
     for (int j : spaList) {
       if (spa[j] != 0.0)
