@@ -14,9 +14,11 @@
 //     / updateColumnTranspose :634-700; the reference's sparse engine uses Forrest-Tomlin row etas
 //     (src/CoinAbcBaseFactorization4.cpp:1634-1900) for the same job
 //
-// The triangular parts are GATHER-form level schedules (every item is out[tgt] = (src[s] - sum val*vec[idx]) / div,
-// items of a level are independent): deterministic, no floating-point atomics.  On the bench LP (nucleus 11 000,
-// front 4 500 pivots, 6-8 levels) one 1024-thread workgroup per right-hand side runs a sweep in a few microseconds.
+// The triangular factors of the front are applied through their EXPLICIT sparse inverses (lu_host.hip builds L^-1 and
+// U11^-1 [I | -U12] and their transposes; on the bench LP they hold < 2x the entries of L and U), every one a gather-form
+// operator: out[tgt] = (src[s] - sum val * vec[idx]) / div with all items independent -- one pass over the whole chip per
+// solve, one wave per row, fixed reduction tree, no floating-point atomics.  (A first version walked level schedules of
+// the triangular factors in one workgroup per right-hand side: 16 levels, 760 us; profiles/r03_lu_v1_* -> r03_lu_v2_*.)
 //
 // Product form without a serial chain: with eta_j = (w_j - e_pj)/alpha_j, H = [eta_1 .. eta_t], P = [p_1 .. p_t] and
 // N[j][i] = eta_i[p_j] (i < j), the scalars s_j = (E_{j-1}..E_1 x0)[p_j] solve (I + N) s = x0[P]; the engine keeps
