@@ -361,7 +361,11 @@ def main():
             if chunks[-1] is not pick[-1]:
                 pick.append(chunks[-1])
             whole = (chunks[-1]["pivots"][1] - chunks[0]["pivots"][0] + 1) / max(sum(c["seconds"] for c in chunks), 1e-9)
+            objs = [c["objective"] for c in chunks]
             sustained = {"unit": "iterations/s", "windows": pick, "over_the_whole_leg": round(whole, 1),
+                         # the dual objective is a lower bound on the optimum and must not fall (cost shifting aside): checked per window
+                         "dual_objective_monotone": bool(all(b >= a - 1e-9 * abs(a) for a, b in zip(objs, objs[1:]))),
+                         "dual_objective_first_last": [objs[0], objs[-1]],
                          "mature": pick[-1]["iterations_per_s"],
                          "note": "wall clock around clpgpu_dual_steps(2000) on the live solve, refactorizations (host Markowitz front + dense tail "
                                  "inversion) included; `mature` = the last window reached within the budget"}
