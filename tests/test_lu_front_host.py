@@ -83,3 +83,34 @@ def test_front_factors_reproduce_the_matrix(harness, tmp_path, k, per_col, densi
         x = solve_with_factors(k, fac, b)
         ref = lu.solve(b)
         assert np.max(np.abs(x - ref)) <= 1e-9 * (1.0 + np.max(np.abs(ref)))
+
+
+def test_front_leaves_dependent_columns_to_the_tail(harness, tmp_path):
+    """A structurally singular nucleus (an empty column, two identical columns, an empty row): the front must not crash or
+    pivot on them; they stay in the active block, where the dense inversion reports the singularity (engine: repair path)."""
+    rng = np.random.default_rng(7)
+    k = 200
+    rows = np.concatenate([rng.choice(k, 4, replace=False) for _ in range(k)])
+    cols = np.repeat(np.arange(k), 4)
+    vals = rng.uniform(0.1, 1.0, len(rows))
+    C = (sp.csc_matrix((vals, (rows, cols)), shape=(k, k)) + sp.identity(k, format="csc") * 2.0).tolil()
+    C[:, 17] = 0.0  # empty column
+    C[:, 31] = C[:, 30]  # duplicate column
+    C[55, :] = 0.0  # empty row
+    C = C.tocsc()
+    C.eliminate_zeros()
+    C.sort_indices()
+    src, dst = str(tmp_path / "C.bin"), str(tmp_path / "F.bin")
+    with open(src, "wb") as o:
+        o.write(struct.pack("qq", k, C.nnz))
+        o.write(C.indptr.astype(np.int32).tobytes())
+        o.write(C.indices.astype(np.int32).tobytes())
+        o.write(C.data.tobytes())
+    out = subprocess.run([harness, src, "1.0", "0", dst], capture_output=True, text=True, check=True).stdout.split()
+    nF, k2 = int(out[0]), int(out[1])
+    assert nF + k2 == k and k2 >= 2
+    fac = read_vectors(dst, [np.int32, np.int32, np.float64, np.int32, np.int32, np.float64, np.int32, np.int32, np.float64, np.int32, np.int32,
+                             np.int32, np.int32, np.float64])
+    assert 17 in fac[10].tolist()  # the empty column was never a pivot column
+    assert 55 in fac[9].tolist()  # nor the empty row a pivot row
+    assert np.min(np.abs(fac[2])) > 1e-11
