@@ -6,6 +6,7 @@
 #include "kernels.hip"
 
 #include <dlfcn.h>
+#include <float.h>
 #include <pthread.h>
 #include <time.h>
 #include <math.h>
@@ -21,6 +22,7 @@
 
 #include "../../include/clpgpu.h"
 #include "lu_front.h"
+#include "perturb_host.h"
 
 using namespace clpgpu;
 
@@ -142,6 +144,11 @@ struct clpgpu_context {
   int numberPrimalInfeasibilities = 0, numberDualInfeasibilities = 0;
   int numberFake = 0, numberChanged = 0, numberTimesOptimal = 0, forceFactorization = -1, lastBadIteration = -999999;
   int lastCleaned = 0, factorType = 0;
+  // ClpSimplex::perturbation_: the value every solve is entered with (option "perturbation": 102 never, 100 only the
+  // kick after 2(m+n) iterations, 50 the clp command's default, 51-69 fixed fractions) and the running state
+  // (101 = the costs are perturbed now, 102 = no more perturbing in this solve)
+  int perturbationOption = 102, perturbation = 102, numberPerturbations = 0;
+  std::vector<double> perturbationArray;  // ClpSimplex::perturbationArray_: 2n uniform numbers, drawn once per problem
   bool started = false, needStatus = true, weightsInitialized = false;
   bool rebuildRowCopy = true;  // the device keeps the [basic|nonbasic] row partition current between refactorizations
   // basis / solution at the last good refactorization (ClpSimplex::saveStatus_, savedSolution_): what a
@@ -390,6 +397,8 @@ struct clpgpu_context {
   void checkPrimalSolution();
   void checkDualSolution();
   int changeBounds(int initialize, double &changeCost);
+  int perturb();
+  void restoreCosts();
   int numberAtFakeBound() const;
   int updateDualsFullRecompute();
   int saveWeights(int mode);
@@ -903,6 +912,7 @@ void clpgpu_context::releaseProblem()
   weightsInitialized = false;
   haveStatus = false;
   userStatus.clear();
+  perturbationArray.clear();
   started = false;
   needStatus = true;
   rebuildRowCopy = true;
@@ -1936,6 +1946,26 @@ int clpgpu_context::changeBounds(int initialize, double &changeCost)
 
 // ClpSimplexDual::resetFakeBounds(1) (src/ClpSimplexDual.cpp:8505-8596): working bounds rebuilt from the
 // original ones and the fake-bound flags of the status bytes
+// ClpSimplexDual::perturb (src/ClpSimplexDual.cpp:6533): the arithmetic is in perturb_host.h; the caller pushes the costs
+int clpgpu_context::perturb()
+{
+  PerturbRim rim{m, n, colStart.data(), elem.data(), lower.data(), upper.data(), status.data(), origObj.data(), dualTolerance, largeValue,
+                 numberIterations};
+  const int rc = perturbCosts(rim, perturbation, perturbationArray, seed, cost.data());
+  if (perturbation == 101)
+    numberPerturbations++;
+  return rc;
+}
+
+// ClpSimplex::createRim4(false) (src/ClpSimplex.cpp:4645): the costs of the problem back in the rim
+void clpgpu_context::restoreCosts()
+{
+  for (int j = 0; j < n; j++)
+    cost[j] = obj[j];
+  for (int i = 0; i < m; i++)
+    cost[n + i] = 0.0;
+}
+
 void clpgpu_context::resetFakeBounds()
 {
   lower = origLower;
@@ -2134,6 +2164,9 @@ int clpgpu_context::startup()
   numberRefactorizations = 0;
   numberRefreshes = numberRefreshesRejected = consecutiveRefreshes = 0;
   numberFake = numberChanged = numberTimesOptimal = 0;
+  // ClpDataSave: every dual() is entered with the caller's perturbation_; fastDual (:7260) does not perturb at all
+  perturbation = fastDualMode ? 102 : perturbationOption;
+  numberPerturbations = 0;
   forceFactorization = -1;
   lastBadIteration = -999999;
   lastCleaned = 0;
@@ -2194,6 +2227,15 @@ int clpgpu_context::startup()
   changeBounds(1, dummy);
   rc |= pushRim();
   rc |= gutsOfSolution();
+  if (perturbation < 100) {
+    // startupSolve :335-341.  perturb() == 1 ("safer to use primal": every cost is zero) is only a hint to
+    // callers that hold a primal; dual carries on unperturbed.
+    perturb();
+    rc |= h2d(D.cost, cost.data(), N);
+    rc |= gutsOfSolution();
+  }
+  if (!numberDualInfeasibilities && !numberPrimalInfeasibilities && perturbation < 101)
+    problemStatus = 0;  // ClpSimplexDual::dual :664-666: nothing to do
   started = true;
   needStatus = true;
   return rc;
@@ -2456,6 +2498,19 @@ int clpgpu_context::statusOfProblemInDual(int type)
         numberChangedBounds = (dualBound < 1.0e20) ? changeBounds(0, changeCost) : 0;
         dirty = true;
         if (numberChangedBounds <= 0 && !numberDualInfeasibilities) {
+          if (perturbation == 101) {
+            // looks optimal for the perturbed costs: the true costs back and look again (:5708-5733)
+            perturbation = 102;
+            cleanDuals = 1;
+            changeBounds(1, changeCost);  // make sure fake bounds are back
+            restoreCosts();
+            rc |= pushRim();
+            rc |= gutsOfSolution();  // computeDuals + checkDualSolution with the true costs
+            if (numberDualInfeasibilities) {
+              numberChanged = 1;  // force something to happen
+              lastCleaned = numberIterations - 1;
+            }
+          }
           if (lastCleaned < numberIterations && numberTimesOptimal < 4) {
             doOriginalTolerance = 2;
             numberTimesOptimal++;
@@ -2474,6 +2529,14 @@ int clpgpu_context::statusOfProblemInDual(int type)
               problemStatus = 2;
             else
               problemStatus = -3;
+            if (problemStatus == 2 && perturbation == 101) {
+              // unbounded only for the perturbed costs? (:5814-5820)
+              perturbation = 102;
+              cleanDuals = 1;
+              restoreCosts();
+              rc |= h2d(D.cost, cost.data(), N);
+              problemStatus = -1;
+            }
           } else {
             doOriginalTolerance = 2;
           }
@@ -2486,6 +2549,8 @@ int clpgpu_context::statusOfProblemInDual(int type)
         if ((numberChangedBounds <= 0 || dualBound > 1.0e20 || (largestPrimalError > 1.0 && dualBound > 1.0e17))
             && (numberPivots < 4 || sumPrimalInfeasibilities > 1.0e-6)) {
           problemStatus = 1;
+          if (perturbation == 101)
+            perturbation = 102;  // :5860
           if (!numberPrimalInfeasibilities) {
             problemStatus = -1;
             doOriginalTolerance = 2;
@@ -2504,10 +2569,8 @@ int clpgpu_context::statusOfProblemInDual(int type)
       if (doOriginalTolerance == 2) {
         lastCleaned = numberIterations;
         numberChanged = 0;
-        for (int j = 0; j < n; j++)
-          cost[j] = obj[j];
-        for (int i = 0; i < m; i++)
-          cost[n + i] = 0.0;
+        perturbation = 102;  // stop any perturbations (:5891)
+        restoreCosts();
         // computeDuals with the original costs, on the device
         rc |= pushRim();
         rc |= gutsOfSolution();
@@ -2929,6 +2992,7 @@ int clpgpu_context::whileIterating(int stepTarget)
   hCtrl->numberIterations = numberIterations;
   hCtrl->forceFactorization = forceFactorization;
   hCtrl->numberChanged = numberChanged;
+  hCtrl->seed = seed;  // perturb() draws from the same generator on the host
   hCtrl->lastBadIteration = lastBadIteration;
   hCtrl->maximumPivots = luActive ? luEtaLimit : maximumPivots;
   hCtrl->maximumIterations = maximumIterations;
@@ -3121,12 +3185,10 @@ int clpgpu_context::whileIterating(int stepTarget)
         sumPrimalInfeasibilities = 0.0;
         numberDualInfeasibilities = 0;
         sumDualInfeasibilities = 0.0;
-        if (numberChanged) {
+        if (perturbation == 101 || numberChanged) {
           numberChanged = 0;
-          for (int j = 0; j < n; j++)
-            cost[j] = obj[j];
-          for (int i = 0; i < m; i++)
-            cost[n + i] = 0.0;
+          perturbation = 102;  // :2222-2224
+          restoreCosts();
           rc |= pushRim();
           rc |= gutsOfSolution();
           if (numberDualInfeasibilities)
@@ -3152,7 +3214,7 @@ int clpgpu_context::whileIterating(int stepTarget)
 void clpgpu_context::finish()
 {
   pullRim(true);
-  if (problemStatus == 0 || problemStatus == 3) {
+  if (problemStatus == 0 || problemStatus == 3 || problemStatus == 10) {  // 10: the point a primal clean-up would start from
     double objective = 0.0;
     for (int j = 0; j < n; j++)
       objective += obj[j] * sol[j];
@@ -3172,6 +3234,19 @@ int clpgpu_context::run(int maxSteps)
   int stepTarget = (maxSteps < 0) ? -1 : numberIterations + maxSteps;
   int result = -1;
   while (problemStatus < 0) {
+    if (needStatus && perturbation < 101 && numberIterations > 2 * (m + n) && !fastDualMode) {
+      // "if getting nowhere - why not give it a kick" (gutsOfDual :488-492)
+      rc = pullRim(true);
+      perturb();
+      rc |= h2d(D.cost, cost.data(), N);
+      rc |= gutsOfSolution();
+      if (rc) {
+        problemStatus = 4;
+        break;
+      }
+      if (logLevel > 0)
+        fprintf(stderr, "clpgpu: iteration %d > 2(m+n): costs perturbed\n", numberIterations);
+    }
     if (needStatus) {
       rc = statusOfProblemInDual(factorType);
       factorType = 1;
@@ -3949,6 +4024,7 @@ clpgpu_context *clpgpu_clone(const clpgpu_context *src)
   ctx->logLevel = src->logLevel;
   ctx->checkEvery = src->checkEvery;
   ctx->seed = src->seed;
+  ctx->perturbationOption = src->perturbationOption;
   ctx->priceKernel = src->priceKernel;
   ctx->useGraph = src->useGraph;
   ctx->blockedRefactor = src->blockedRefactor;
@@ -4183,6 +4259,7 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "zero_tolerance")) ctx->zeroTolerance = ctx->optZeroTolerance = v;
   else if (!strcmp(name, "acceptable_pivot")) ctx->acceptablePivot = ctx->optAcceptablePivot = v;
   else if (!strcmp(name, "random_seed")) ctx->seed = (unsigned int)v;
+  else if (!strcmp(name, "perturbation")) ctx->perturbationOption = (int)v;
   else if (!strcmp(name, "log_level")) ctx->logLevel = (int)v;
   else if (!strcmp(name, "check_every")) {
     ctx->checkEvery = (int)v < 1 ? 1 : (int)v;
@@ -4641,6 +4718,7 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
   stats->lu_invert_ms = ctx->luInvertSeconds * 1.0e3;
   stats->lu_build_ms = ctx->luBuildSeconds * 1.0e3;
   stats->eta_count = ctx->hCtrl->pivots;
+  stats->perturbations = ctx->numberPerturbations;
   stats->nucleus_capacity = ctx->kcap;
   stats->refreshes = ctx->numberRefreshes;
   stats->refreshes_rejected = ctx->numberRefreshesRejected;

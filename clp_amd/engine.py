@@ -31,7 +31,8 @@ class Stats(C.Structure):
                 ("row_ms", C.c_double), ("row_launches", C.c_long), ("row_bytes", C.c_double),
                 ("nucleus", C.c_long), ("nucleus_capacity", C.c_long), ("refreshes", C.c_long), ("refreshes_rejected", C.c_long),
                 ("lu_active", C.c_long), ("lu_front", C.c_long), ("lu_tail", C.c_long), ("lu_factorizations", C.c_long),
-                ("lu_front_ms", C.c_double), ("lu_invert_ms", C.c_double), ("lu_build_ms", C.c_double), ("eta_count", C.c_long)]
+                ("lu_front_ms", C.c_double), ("lu_invert_ms", C.c_double), ("lu_build_ms", C.c_double), ("eta_count", C.c_long),
+                ("perturbations", C.c_long)]
 
 
 # every symbol include/clpgpu.h declares (tests/test_abi.py checks the library exports all of them)
@@ -54,7 +55,7 @@ ABI_SYMBOLS = [
 def build(force: bool = False) -> str:
     """Compile libclpgpu.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("engine.hip", "kernels.hip", "lu_kernels.hip", "lu_host.hip", "lu_front.h", "gemm_kernel.hip",
+    srcs = [os.path.join(src_dir, f) for f in ("engine.hip", "kernels.hip", "lu_kernels.hip", "lu_host.hip", "lu_front.h", "perturb_host.h", "gemm_kernel.hip",
                                                "device_state.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "clpgpu.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)

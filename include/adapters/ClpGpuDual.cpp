@@ -36,6 +36,10 @@ int clpGpuDual(ClpSimplex &model, int device, bool scaling)
   clpgpu_set_option(ctx, "dual_bound", model.dualBound());
   clpgpu_set_option(ctx, "primal_tolerance", model.primalTolerance());
   clpgpu_set_option(ctx, "dual_tolerance", model.dualTolerance());
+  // ClpSimplex::perturbation_ (100 from the constructor, 50 from the clp command): start-up perturbation and the kick of
+  // ClpSimplexDual.cpp:488 happen on the device side as they would in dual(); a solve that ends on perturbed costs with
+  // dual infeasibilities for the true ones comes back as status 10 and is finished by primal below, as in ClpSimplex::dual
+  clpgpu_set_option(ctx, "perturbation", model.perturbation());
   if (model.statusArray())
     clpgpu_set_status(ctx, model.statusArray()); // warm start
   int problemStatus = clpgpu_dual(ctx);          // ClpSimplex::dual()

@@ -64,6 +64,7 @@ typedef struct {
   double lu_invert_ms;     /* time of the tail inversions (device, measured on the host clock) */
   double lu_build_ms;      /* level schedules + uploads */
   long eta_count;          /* basis updates since the last factorization (length of the eta file in LU mode) */
+  long perturbations;      /* times ClpSimplexDual::perturb changed the costs in the last solve (option perturbation) */
 } clpgpu_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------- */
@@ -183,6 +184,12 @@ int clpgpu_unroll_weights(clpgpu_context *ctx);
  * (ClpDualRowSteepest); "max_iterations" (setMaximumIterations); "max_pivots"
  * (factorization maximumPivots); "dual_bound"; "primal_tolerance"; "dual_tolerance"; "zero_tolerance";
  * "acceptable_pivot";
+ * "perturbation" (ClpSimplex::setPerturbation, the value dual() is entered with: 102 = never, the default of a bare
+ * context because a perturbed solve can end as status 10 "needs primal clean-up" and the engine holds no primal;
+ * 100 = the ClpSimplex constructor's value: nothing at start-up, the kick after 2(m+n) iterations,
+ * src/ClpSimplexDual.cpp:488; 50 = the clp command's: perturb at start-up when at most a quarter of the |costs| are
+ * distinct; 51-69 fixed maximum fractions; < 50 = 10^value; ClpSimplexDual::perturb :6533; the clpGpuDual adapter
+ * passes the model's value and runs primal on status 10 as ClpSimplex::dual does);
  * "random_seed"; "log_level"; "check_every" (host polls the device control block every N
  * iterations).  Engine tuning / test knobs (no counterpart in the reference): "timing" (HIP events
  * around every pricing launch), "price_kernel" (inner-loop variant of the pricing kernel, default
@@ -203,7 +210,14 @@ int clpgpu_unroll_weights(clpgpu_context *ctx);
  * refactorization keeps the explicit inverse, improved by one Newton-Schulz step X += X (I - C X) unless
  * refresh_refine is 0 (a sparse residual kernel + one f64 GEMM from rocBLAS), when the solutions recomputed with
  * it leave max |A x - s| and max basic |dj| below the tolerance, default 1e-6; it re-inverts otherwise and every
- * refresh_max-th time, default 15). */
+ * refresh_max-th time, default 15),
+ * "factor_mode" (-1 auto: the LU form from "lu_min_k" = 3072 basic structurals on, for sparse LPs on one rank;
+ * 0 explicit inverse of the nucleus; 1 LU form: host Markowitz front + dense tail inverted on the matrix cores +
+ * product-form eta file) with "lu_stop_density", "lu_min_tail", "lu_threshold",
+ * "lu_inverse_fill_cap" (front / explicit-inverse controls), "lu_max_pivots", "lu_min_pivots", "lu_adaptive" (eta-file
+ * length), "lu_polish", "lu_polish_tolerance" (Newton-Schulz steps on the tail inverse),
+ * "gemm_backend" (0 the engine's own MFMA f64 GEMM, 1 rocBLAS), "solution_refinements" / "refine_above" (iterative
+ * refinement of the recomputed primal and dual solutions), "price_tiles" (1: pricing with pi tiles staged in LDS). */
 int clpgpu_set_option(clpgpu_context *ctx, const char *name, double value);
 /* Whole-array replacement of bounds / costs with the matrix left resident
  * (ClpModel::chgRowLower ... chgObjCoefficients, src/ClpModel.hpp:254-262, src/ClpModel.cpp:2669-2770;

@@ -2,8 +2,9 @@
  * clp_dual_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY; see clp_dual_oracle.h).
  *
  * Restates the revised dual simplex of coin-or/Clp for the fast branch "no free / superbasic
- * nonbasic variables" (moreSpecialOptions_&8, src/ClpSimplexDual.cpp:3685), scaling off,
- * perturbation off (perturbation_ 102).  Each function cites the reference lines it follows.
+ * nonbasic variables" (moreSpecialOptions_&8, src/ClpSimplexDual.cpp:3685); scaling (option "scaling") and
+ * cost perturbation (option "perturbation", ClpSimplexDual::perturb :6533) are off unless asked for.  Each
+ * function cites the reference lines it follows.
  * Variable order is Clp's: sequences [0,n) structurals, [n,n+m) row slacks, slack column = -e_i
  * (src/ClpSimplex.cpp:3442-3474).
  *
@@ -13,8 +14,7 @@
  *    remaining nucleus, product-form eta updates (replaceColumnPart3).  Because a slack column -e_i
  *    has a single entry, doing the slacks first leaves the other columns untouched, so this is
  *    arithmetically the dense factorization of the whole basis with the zero work skipped.
- *  - cycle detection (ClpSimplexProgress::cycle) and the "objective going backwards" restore logic
- *    of statusOfProblemInDual (:5331-5480) are not restated.
+ *  - the "objective going backwards" restore logic of statusOfProblemInDual (:5331-5480) is not restated.
  *  - nonbasic free columns are given "bothFake" bounds at start (the reference keeps them isFree and
  *    uses the general branch of dualColumn0).
  *  - CoinThreadRandom lives in CoinUtils (absent); the 32-bit LCG form is used [unverifiable here].
@@ -23,6 +23,7 @@
  */
 #include "clp_dual_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -89,6 +90,10 @@ struct OrcModel {
   int numberPrimalInfeasibilities, numberDualInfeasibilities;
   int numberFake, numberChanged, numberTimesOptimal, forceFactorization, lastBadIteration;
   unsigned int seed;
+  int perturbation, perturbationOption; /* ClpSimplex::perturbation_: 50 auto, 100 "only the kick", 101 perturbed, 102 never again */
+  double *perturbationArray;            /* ClpSimplex::perturbationArray_ [2n], filled on the first perturb() */
+  const double *objBeforeScaling;       /* objective() as the caller gave it (perturb() looks at that one, :6566) */
+  int numberPerturbations;              /* how many times perturb() changed costs in the last solve (test hook) */
   int cycIn[ORC_CYCLE], cycOut[ORC_CYCLE]; /* ClpSimplexProgress in_ / out_ / way_ */
   char cycWay[ORC_CYCLE];
   int scalingMode;            /* ClpModel::scaling(): 0 off (default here), 1 equilibrium, 2 geometric, 3/4 auto */
@@ -136,6 +141,7 @@ static inline void setFake(OrcModel *M, int i, int f) { M->status[i] = (unsigned
 static inline int flagged(const OrcModel *M, int i) { return (M->status[i] & FLAGGED_BIT) != 0; }
 static inline void setFlagged(OrcModel *M, int i) { M->status[i] |= FLAGGED_BIT; }
 static inline void clearFlagged(OrcModel *M, int i) { M->status[i] &= (unsigned char)~FLAGGED_BIT; }
+static void restoreCosts(OrcModel *M);
 static inline double dmin(double a, double b) { return a < b ? a : b; }
 static inline double dmax(double a, double b) { return a > b ? a : b; }
 
@@ -215,6 +221,7 @@ OrcModel *orc_create(int m, int n, const int *colStart, const int *row, const do
   M->pivotRule = 1;
   M->maximumPivots = 200; /* CoinAbcBaseFactorization1.cpp:142 default */
   M->seed = 1234567u;     /* src/ClpModel.cpp:149 */
+  M->perturbationOption = 102; /* off; the reference's constructor default is 100 (src/ClpSimplex.cpp:114), the clp CLI's 50 */
   M->forceFactorization = -1;
   M->lastBadIteration = -999999;
   M->fac.rowToK = IALLOC(m);
@@ -278,6 +285,7 @@ void orc_destroy(OrcModel *M)
   free(M->piIndex); free(M->piValue); free(M->colIndex); free(M->colValue); free(M->wIndex); free(M->wValue);
   for (int i = 0; i < 2; i++) { free(M->spareIndex[i]); free(M->spareValue[i]); }
   free(M->rowFlip); free(M->colFlip); free(M->log);
+  free(M->perturbationArray);
   free(M);
 }
 
@@ -306,6 +314,7 @@ int orc_set_option(OrcModel *M, const char *name, double v)
   else if (!strcmp(name, "random_seed")) M->seed = (unsigned int)v;
   else if (!strcmp(name, "price_by_row")) M->priceByRow = (int)v;
   else if (!strcmp(name, "scaling")) M->scalingMode = (int)v;
+  else if (!strcmp(name, "perturbation")) M->perturbationOption = (int)v;
   else return -1;
   return 0;
 }
@@ -2367,13 +2376,11 @@ static int whileIterating(OrcModel *M)
             M->sumPrimalInfeasibilities = 0.0;
             M->numberDualInfeasibilities = 0;
             M->sumDualInfeasibilities = 0.0;
-            if (M->numberChanged) {
-              /* costs were modified: restore (createRim4) and recheck (:2222-2236) */
+            if (M->perturbation == 101 || M->numberChanged) {
+              /* costs were perturbed or modified: restore (createRim4) and recheck (:2222-2236) */
               M->numberChanged = 0;
-              for (int j = 0; j < M->n; j++)
-                M->cost[j] = M->obj[j];
-              for (int i = 0; i < m; i++)
-                M->cost[M->n + i] = 0.0;
+              M->perturbation = 102; /* stop any perturbations */
+              restoreCosts(M);
               computeDuals(M);
               checkDualSolution(M);
               if (M->numberDualInfeasibilities)
@@ -2396,11 +2403,261 @@ static int whileIterating(OrcModel *M)
   return returnCode;
 }
 
-/* ClpSimplexDual::statusOfProblemInDual :4996-6343, the parts that matter without perturbation,
- * values pass, Cbc options or primal fallback. */
-static void statusOfProblemInDual(OrcModel *M, int *lastCleaned, int type)
+static int compareDoubles(const void *a, const void *b)
+{
+  double x = *(const double *)a, y = *(const double *)b;
+  return (x > y) - (x < y);
+}
+
+/* ClpSimplexDual::perturb :6533-6957 -- cost perturbation of the nonbasic, non-fixed structurals.
+ * Restated for the values dual() can be entered with here: 50 (the clp default: perturb at start-up when at
+ * most a quarter of the |costs| are distinct), 51-69 (fixed maximum fractions), 100 (no start-up
+ * perturbation, the "kick" after 2(m+n) iterations), and below 50 "user is in charge" (10^value) without the
+ * <= -10 experiments.  Row costs are never modified (modifyRowCosts is forced false at :6745), the Cbc
+ * branches are out.
+ * Returns 1 when the reference would rather use primal (all costs zero, :6588). */
+static int perturb(OrcModel *M)
 {
   const int m = M->m, n = M->n;
+  if (M->perturbation > 100)
+    return 0; /* perturbed already */
+  if (M->perturbation == 100)
+    M->perturbation = 50; /* treat as normal */
+  const int savePerturbation = M->perturbation;
+  double perturbation = 1.0e-20;
+  double maximumFraction = 1.0e-5; /* maximum fraction of cost to perturb */
+  const double constantPerturbation = 100.0 * M->dualTolerance;
+  int maxLength = 0, minLength = m;
+  double averageCost = 0.0;
+  int numberNonZero = 0;
+  if (!M->numberIterations && M->perturbation >= 50) {
+    /* see if we need to perturb (:6562-6606) */
+    double *sort = DALLOC(n > 0 ? n : 1);
+    for (int i = 0; i < n; i++) {
+      double value = fabs(M->objBeforeScaling[i]);
+      sort[i] = value;
+      averageCost += value;
+      if (value)
+        numberNonZero++;
+    }
+    if (numberNonZero)
+      averageCost /= (double)numberNonZero;
+    else
+      averageCost = 1.0;
+    qsort(sort, (size_t)n, sizeof(double), compareDoubles);
+    int number = 1;
+    double last = n ? sort[0] : 0.0;
+    for (int i = 1; i < n; i++) {
+      if (last != sort[i])
+        number++;
+      last = sort[i];
+    }
+    free(sort);
+    if (!numberNonZero && M->perturbation < 55)
+      return 1; /* safer to use primal */
+    if (number * 4 > n) {
+      M->perturbation = 100;
+      return 0; /* good enough */
+    }
+  }
+  for (int j = 0; j < n; j++) {
+    if (M->lower[j] < M->upper[j]) {
+      int length = M->colStart[j + 1] - M->colStart[j];
+      if (length > 2) {
+        if (length > maxLength)
+          maxLength = length;
+        if (length < minLength)
+          minLength = length;
+      }
+    }
+  }
+  if (M->perturbation >= 70)
+    M->perturbation -= 20; /* "do rows" -- but row costs are left alone, :6745 */
+  if (M->perturbation > 50) {
+    static const double fractions[] = { 1.0e-10, 1.0e-9, 1.0e-8, 1.0e-7, 1.0e-6, 1.0e-5, 1.0e-4, 1.0e-3, 1.0e-2, 1.0e-1, 1.0 };
+    int whichOne = M->perturbation - 51;
+    maximumFraction = fractions[whichOne < 10 ? whichOne : 10];
+  }
+  double smallestNonZero = 1.0e100;
+  if (M->perturbation >= 50) {
+    perturbation = 1.0e-8;
+    if (M->perturbation > 50 && M->perturbation < 60)
+      perturbation = dmax(1.0e-8, maximumFraction);
+    int allSame = 1;
+    double lastValue = 0.0;
+    for (int i = 0; i < m; i++) {
+      double lo = M->lower[n + i], up = M->upper[n + i];
+      if (lo < up) {
+        double value = fabs(M->cost[n + i]);
+        perturbation = dmax(perturbation, value);
+        if (value)
+          smallestNonZero = dmin(smallestNonZero, value);
+      }
+      if (lo && lo > -1.0e10) {
+        lo = fabs(lo);
+        if (!lastValue)
+          lastValue = lo;
+        else if (fabs(lo - lastValue) > 1.0e-7)
+          allSame = 0;
+      }
+      if (up && up < 1.0e10) {
+        up = fabs(up);
+        if (!lastValue)
+          lastValue = up;
+        else if (fabs(up - lastValue) > 1.0e-7)
+          allSame = 0;
+      }
+    }
+    double lastValue2 = 0.0;
+    for (int j = 0; j < n; j++) {
+      double lo = M->lower[j], up = M->upper[j];
+      if (lo < up) {
+        double value = fabs(M->cost[j]);
+        perturbation = dmax(perturbation, value);
+        if (value)
+          smallestNonZero = dmin(smallestNonZero, value);
+      }
+      if (lo && lo > -1.0e10) {
+        lo = fabs(lo);
+        if (!lastValue2)
+          lastValue2 = lo;
+        else if (fabs(lo - lastValue2) > 1.0e-7)
+          allSame = 0;
+      }
+      if (up && up < 1.0e10) {
+        up = fabs(up);
+        if (!lastValue2)
+          lastValue2 = up;
+        else if (fabs(up - lastValue2) > 1.0e-7)
+          allSame = 0;
+      }
+    }
+    if (allSame) {
+      /* ClpPackedMatrix::rangeOfElements, src/ClpPackedMatrix.cpp:5229 */
+      double smallestNegative = -DBL_MAX, largestNegative = 0.0, smallestPositive = DBL_MAX, largestPositive = 0.0;
+      for (int p = 0; p < M->colStart[n]; p++) {
+        double value = M->elem[p];
+        if (value > 0.0) {
+          smallestPositive = dmin(smallestPositive, value);
+          largestPositive = dmax(largestPositive, value);
+        } else if (value < 0.0) {
+          smallestNegative = dmax(smallestNegative, value);
+          largestNegative = dmin(largestNegative, value);
+        }
+      }
+      if (smallestNegative == largestNegative && smallestPositive == largestPositive) {
+        /* really hit perturbation */
+        double adjust = dmin(100.0 * maximumFraction, 1.0e-3 * dmax(lastValue, lastValue2));
+        maximumFraction = dmax(adjust, maximumFraction);
+      }
+    }
+    perturbation = dmin(perturbation, smallestNonZero / maximumFraction);
+  } else {
+    /* user is in charge */
+    maximumFraction = 1.0e-1;
+    perturbation = pow(10.0, (double)M->perturbation);
+  }
+  double largestZero = 0.0, largest = 0.0;
+  static const double weight[] = { 1.0e-4, 1.0e-2, 5.0e-1, 1.0, 2.0, 5.0, 10.0, 20.0, 30.0, 40.0, 100.0 };
+  /* constantPerturbation is 100 x dualTolerance here, so the "scale back" of :6784 never applies */
+  double factor = 1.0;
+  if (maxLength)
+    factor = 3.0 / (double)minLength;
+  const double m1 = 0.5;
+  const double smallestAllowed = dmin(1.0e-2 * M->dualTolerance, maximumFraction);
+  double largestAllowed = dmax(1.0e3 * M->dualTolerance, maximumFraction * averageCost);
+  if (M->perturbation == 51)
+    largestAllowed = dmax(M->dualTolerance, maximumFraction);
+  if (!M->perturbationArray) {
+    M->perturbationArray = DALLOC(2 * n + 1);
+    for (int j = 0; j < 2 * n; j++)
+      M->perturbationArray[j] = randomDouble(M);
+  }
+  for (int j = 0; j < n; j++) {
+    if (M->lower[j] < M->upper[j] && getStatus(M, j) != ST_BASIC) {
+      double value = perturbation;
+      const double currentValue = M->cost[j];
+      value = dmin(value, constantPerturbation + maximumFraction * (fabs(currentValue) + 1.0e-1 * perturbation + 1.0e-8));
+      double value2 = constantPerturbation + 1.0e-1 * smallestNonZero;
+      if (M->lower[j] > -M->largeValue) {
+        if (fabs(M->lower[j]) < fabs(M->upper[j])) {
+          value *= (1.0 - m1 + m1 * M->perturbationArray[2 * j]);
+          value2 *= (1.0 - m1 + m1 * M->perturbationArray[2 * j + 1]);
+        } else {
+          value = 0.0;
+        }
+      } else if (M->upper[j] < M->largeValue) {
+        value *= -(1.0 - m1 + m1 * M->perturbationArray[2 * j]);
+        value2 *= -(1.0 - m1 + m1 * M->perturbationArray[2 * j + 1]);
+      } else {
+        value = 0.0;
+      }
+      if (value) {
+        int length = M->colStart[j + 1] - M->colStart[j];
+        if (length > 3) {
+          length = (int)((double)length * factor);
+          if (length < 3)
+            length = 3;
+        }
+        value *= (length < 10) ? weight[length] : weight[10];
+        value = dmin(value, value2);
+        if (savePerturbation < 50 || savePerturbation > 60) {
+          if (fabs(value) <= M->dualTolerance)
+            value = 0.0;
+        } else if (value) {
+          /* get in range */
+          if (fabs(value) <= smallestAllowed) {
+            value *= 10.0;
+            while (fabs(value) <= smallestAllowed)
+              value *= 10.0;
+          } else if (fabs(value) > largestAllowed) {
+            value *= 0.1;
+            while (fabs(value) > largestAllowed)
+              value *= 0.1;
+          }
+        }
+        if (currentValue)
+          largest = dmax(largest, fabs(value));
+        else
+          largestZero = dmax(largestZero, fabs(value));
+        /* but negative if at ub */
+        if (getStatus(M, j) == ST_UPPER)
+          value = -value;
+        M->cost[j] += value;
+      }
+    }
+  }
+  if (largestZero > 1.0 * largest && largest) {
+    /* the perturbation of a zero cost must not dwarf those of the others (:6902-6917) */
+    double test = dmax(1.0e-8, largest);
+    for (int j = 0; j < n; j++) {
+      if (!M->objBeforeScaling[j]) {
+        double cost = M->cost[j];
+        while (fabs(cost) > test)
+          cost *= 0.5;
+        M->cost[j] = cost;
+      }
+    }
+  }
+  M->perturbation = 101; /* say perturbed */
+  M->numberPerturbations++;
+  return 0;
+}
+
+/* createRim4(false): the original costs back (src/ClpSimplex.cpp:4645) */
+static void restoreCosts(OrcModel *M)
+{
+  for (int j = 0; j < M->n; j++)
+    M->cost[j] = M->obj[j];
+  for (int i = 0; i < M->m; i++)
+    M->cost[M->n + i] = 0.0;
+}
+
+/* ClpSimplexDual::statusOfProblemInDual :4996-6343, the parts that matter without values pass, Cbc
+ * options or primal fallback (status 10 is returned to the caller). */
+static void statusOfProblemInDual(OrcModel *M, int *lastCleaned, int type)
+{
+  const int m = M->m;
   int numberPivots = M->fac.nEta;
   int tentativeStatus = M->problemStatus;
   int weightsSaved = 0;
@@ -2444,6 +2701,21 @@ static void statusOfProblemInDual(OrcModel *M, int *lastCleaned, int type)
         numberChangedBounds = (M->dualBound < 1.0e20) ? changeBounds(M, 0, M->rowWork3, &changeCost) : 0;
         memset(M->rowWork3, 0, sizeof(double) * (size_t)m);
         if (numberChangedBounds <= 0 && !M->numberDualInfeasibilities) {
+          if (M->perturbation == 101) {
+            /* looks optimal with perturbed costs: the true costs back and look again (:5708-5733) */
+            M->perturbation = 102; /* stop any perturbations */
+            cleanDuals = 1;
+            changeBounds(M, 1, NULL, &changeCost); /* make sure fake bounds are back */
+            restoreCosts(M);
+            computeDuals(M); /* make sure duals are current */
+            checkDualSolution(M);
+            if (M->numberDualInfeasibilities) {
+              M->numberChanged = 1; /* force something to happen */
+              *lastCleaned = M->numberIterations - 1;
+            } else {
+              checkPrimalSolution(M); /* computeObjectiveValue(true) */
+            }
+          }
           if (*lastCleaned < M->numberIterations && M->numberTimesOptimal < 4) {
             doOriginalTolerance = 2;
             M->numberTimesOptimal++;
@@ -2465,6 +2737,13 @@ static void statusOfProblemInDual(OrcModel *M, int *lastCleaned, int type)
               M->problemStatus = 2;
             else
               M->problemStatus = -3;
+            if (M->problemStatus == 2 && M->perturbation == 101) {
+              /* unbounded only for the perturbed costs? (:5814-5820) */
+              M->perturbation = 102;
+              cleanDuals = 1;
+              restoreCosts(M);
+              M->problemStatus = -1;
+            }
           } else {
             doOriginalTolerance = 2;
           }
@@ -2476,6 +2755,8 @@ static void statusOfProblemInDual(OrcModel *M, int *lastCleaned, int type)
         if ((numberChangedBounds <= 0 || M->dualBound > 1.0e20 || (M->largestPrimalError > 1.0 && M->dualBound > 1.0e17))
             && (numberPivots < 4 || M->sumPrimalInfeasibilities > 1.0e-6)) {
           M->problemStatus = 1; /* infeasible */
+          if (M->perturbation == 101)
+            M->perturbation = 102; /* stop any perturbations (:5860) */
           if (!M->numberPrimalInfeasibilities) {
             M->problemStatus = -1;
             doOriginalTolerance = 2;
@@ -2494,11 +2775,8 @@ static void statusOfProblemInDual(OrcModel *M, int *lastCleaned, int type)
       if (doOriginalTolerance == 2) {
         *lastCleaned = M->numberIterations;
         M->numberChanged = 0;
-        /* createRim4(false): original costs back */
-        for (int j = 0; j < n; j++)
-          M->cost[j] = M->obj[j];
-        for (int i = 0; i < m; i++)
-          M->cost[n + i] = 0.0;
+        M->perturbation = 102; /* stop any perturbations (:5891) */
+        restoreCosts(M);
         computeDuals(M);
         checkDualSolution(M);
         if (cleanDuals != 2) {
@@ -2625,6 +2903,8 @@ static int dualOnRim(OrcModel *M)
   M->numberFake = 0;
   M->numberChanged = 0;
   M->numberTimesOptimal = 0;
+  M->perturbation = M->perturbationOption; /* ClpDataSave: every dual() starts from the caller's value */
+  M->numberPerturbations = 0;
   for (int i = 0; i < ORC_CYCLE; i++) { /* progress_.startCheck(), ClpSimplexDual.cpp:452 */
     M->cycIn[i] = M->cycOut[i] = -1;
     M->cycWay[i] = 0;
@@ -2644,12 +2924,25 @@ static int dualOnRim(OrcModel *M)
     changeBounds(M, 1, NULL, &dummy);
   }
   gutsOfSolution(M);
+  if (M->perturbation < 100) {
+    /* startupSolve :335-341.  perturb() returning 1 ("safer to use primal", all costs zero) is only a hint
+       there (usePrimal, read by callers that hold a primal); dual carries on unperturbed. */
+    perturb(M);
+    gutsOfSolution(M);
+  }
+  if (!M->numberDualInfeasibilities && !M->numberPrimalInfeasibilities && M->perturbation < 101)
+    M->problemStatus = 0; /* ClpSimplexDual::dual :664-666: nothing to do */
   int lastCleaned = 0;
   int factorType = 0;
   while (M->problemStatus < 0) {
     for (int i = 0; i < m; i++)
       M->rowWork0[i] = M->rowWork1[i] = M->rowWork2[i] = M->rowWork3[i] = 0.0;
     M->numberPi = M->numberColNz = M->numberW = 0;
+    if (M->perturbation < 101 && M->numberIterations > 2 * (m + n)) {
+      /* if getting nowhere - why not give it a kick (gutsOfDual :488-492) */
+      perturb(M);
+      gutsOfSolution(M);
+    }
     statusOfProblemInDual(M, &lastCleaned, factorType);
     factorType = 1;
     if (M->problemStatus < 0) {
@@ -2659,8 +2952,8 @@ static int dualOnRim(OrcModel *M)
   }
   clock_gettime(CLOCK_MONOTONIC, &t1);
   M->seconds = (double)(t1.tv_sec - t0.tv_sec) + 1.0e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
-  if (M->problemStatus == 0 || M->problemStatus == 3) {
-    /* finish(): true objective from original costs */
+  if (M->problemStatus == 0 || M->problemStatus == 3 || M->problemStatus == 10) {
+    /* finish(): true objective from original costs (10 = "clean up with primal": the point primal would start from) */
     double objective = 0.0;
     for (int j = 0; j < n; j++)
       objective += M->obj[j] * M->sol[j];
@@ -2896,6 +3189,7 @@ int orc_dual(OrcModel *M)
 {
   const int m = M->m, n = M->n;
   M->scalingApplied = 0;
+  M->objBeforeScaling = M->obj;
   if (M->scalingMode <= 0)
     return dualOnRim(M);
   free(M->rowScale);
@@ -2949,7 +3243,7 @@ int orc_dual(OrcModel *M)
     M->sol[n + i] /= rs[i];
     M->dj[n + i] *= rs[i];
   }
-  if (status == 0 || status == 3) {
+  if (status == 0 || status == 3 || status == 10) {
     double objective = 0.0;
     for (int j = 0; j < n; j++)
       objective += M->obj[j] * M->sol[j];
@@ -2976,9 +3270,37 @@ int orc_get_scale_factors(const OrcModel *M, double *rowScale, double *columnSca
   return M->scalingApplied;
 }
 
+/* test hook: ClpSimplexDual::perturb on a fresh rim (createRim: the model's bounds and costs, unscaled) with the given
+ * statuses, as if numberIterations pivots had been made.  cost[n+m] receives the perturbed costs; returns
+ * 1000 * (perturb's return code) + perturbation_ afterwards.  tests/test_perturb_host.py holds the engine's host
+ * arithmetic (clp_amd/csrc/perturb_host.h) against this, bit for bit. */
+int orc_test_perturb(OrcModel *M, int perturbation, int numberIterations, const unsigned char *status, double *cost)
+{
+  const int m = M->m, n = M->n;
+  for (int j = 0; j < n; j++) {
+    M->lower[j] = M->colLower[j];
+    M->upper[j] = M->colUpper[j];
+    M->cost[j] = M->obj[j];
+  }
+  for (int i = 0; i < m; i++) {
+    M->lower[n + i] = M->rowLower[i];
+    M->upper[n + i] = M->rowUpper[i];
+    M->cost[n + i] = 0.0;
+  }
+  memcpy(M->status, status, (size_t)(m + n));
+  M->perturbation = perturbation;
+  M->numberIterations = numberIterations;
+  M->objBeforeScaling = M->obj;
+  M->dualTolerance = M->dualToleranceBase;
+  int rc = perturb(M);
+  memcpy(cost, M->cost, sizeof(double) * (size_t)(m + n));
+  return 1000 * rc + M->perturbation;
+}
+
 int orc_number_iterations(const OrcModel *M) { return M->numberIterations; }
 double orc_objective_value(const OrcModel *M) { return M->objectiveValue; }
 int orc_number_refactorizations(const OrcModel *M) { return M->numberRefactorizations; }
+int orc_number_perturbations(const OrcModel *M) { return M->numberPerturbations; }
 double orc_iteration_seconds(const OrcModel *M) { return M->seconds; }
 void orc_get_solution(const OrcModel *M, double *s) { memcpy(s, M->sol, sizeof(double) * (size_t)(M->m + M->n)); }
 void orc_get_reduced_costs(const OrcModel *M, double *d) { memcpy(d, M->dj, sizeof(double) * (size_t)(M->m + M->n)); }

@@ -59,8 +59,10 @@ void orc_destroy(OrcModel *model);
  * "dual_bound"; "primal_tolerance"; "dual_tolerance"; "log_level"; "random_seed";
  * "scaling" 0 off (default) / 1 equilibrium / 2 geometric / 3,4 auto: ClpPackedMatrix::scale
  * (src/ClpPackedMatrix.cpp:4120) applied as createRim does; results are returned unscaled, the pivot
- * log's theta/alpha/dualOut are in scaled units.  Groundwork for SURVEY 8(f)3 -- the HIP engine does
- * not scale yet. */
+ * log's theta/alpha/dualOut are in scaled units;
+ * "perturbation" ClpSimplex::perturbation_ at entry: 102 never (default here), 100 the reference's constructor
+ * default (no start-up perturbation, the kick after 2(m+n) iterations), 50 the clp command's default, 51-69
+ * fixed fractions (ClpSimplexDual::perturb, src/ClpSimplexDual.cpp:6533). */
 int orc_set_option(OrcModel *model, const char *name, double value);
 
 /* optional starting basis: status[0..n+m) with ClpSimplex::Status codes (src/ClpSimplex.hpp:119) */
@@ -73,6 +75,8 @@ int orc_dual(OrcModel *model);
 int orc_number_iterations(const OrcModel *model);
 double orc_objective_value(const OrcModel *model);
 int orc_number_refactorizations(const OrcModel *model);
+/* times ClpSimplexDual::perturb changed the costs during the last orc_dual (0, 1: start-up or kick) */
+int orc_number_perturbations(const OrcModel *model);
 /* copies n+m doubles, [columns | rows] */
 void orc_get_solution(const OrcModel *model, double *solution);
 void orc_get_reduced_costs(const OrcModel *model, double *dj);
@@ -106,6 +110,8 @@ int orc_price_row_fused(const OrcModel *model, int numberPi, const int *piIndex,
 /* factorization of the basis given by status (basic==1): returns 0 or -1 singular; fills pivotVariable */
 /* ClpSimplexProgress::cycle (src/ClpSolve.cpp:4726-4825) over a sequence of pivots, from empty history */
 void orc_test_cycle(int n, const int *in, const int *out, const int *wayIn, const int *wayOut, int *matched);
+/* test hook: ClpSimplexDual::perturb on a fresh rim with the given statuses; see the definition */
+int orc_test_perturb(OrcModel *model, int perturbation, int numberIterations, const unsigned char *status, double *cost);
 int orc_factorize(OrcModel *model, const unsigned char *status, int *pivotVariable);
 /* in-place dense (length m) solves with the current factorization (+ eta file) */
 void orc_ftran(OrcModel *model, double *region);

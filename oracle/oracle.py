@@ -51,6 +51,8 @@ def lib():
         L.orc_dual.argtypes = [p]
         L.orc_number_iterations.argtypes = [p]
         L.orc_number_refactorizations.argtypes = [p]
+        L.orc_number_perturbations.argtypes = [p]
+        L.orc_test_perturb.argtypes = [p, C.c_int, C.c_int, up, dp]
         L.orc_objective_value.argtypes = [p]
         L.orc_objective_value.restype = C.c_double
         L.orc_iteration_seconds.argtypes = [p]
@@ -109,6 +111,16 @@ class OracleSimplex:
     @property
     def refactorizations(self):
         return lib().orc_number_refactorizations(self._h)
+
+    def test_perturb(self, perturbation, iterations, status):
+        """(return code, perturbation_ afterwards, perturbed costs) of ClpSimplexDual::perturb on a fresh rim."""
+        cost = np.zeros(self.m + self.n)
+        r = lib().orc_test_perturb(self._h, int(perturbation), int(iterations), np.ascontiguousarray(status, dtype=np.uint8), cost)
+        return r // 1000, r % 1000, cost
+
+    @property
+    def perturbations(self):
+        return lib().orc_number_perturbations(self._h)
 
     @property
     def objective(self):

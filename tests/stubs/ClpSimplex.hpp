@@ -41,6 +41,7 @@ public:
   int primal(int ifValuesPass = 0, int startFinishOptions = 0);
   inline ClpFactorization *factorization() const;
   inline double dualBound() const;
+  inline int perturbation() const;
   inline CoinIndexedVector *rowArray(int index) const;
   inline ClpDualRowPivot *dualRowPivot() const;
   inline double zeroTolerance() const;
