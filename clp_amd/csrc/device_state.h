@@ -47,6 +47,7 @@ struct Ctrl {
   int rowOfSlackOut;
   int maximumPivots, maximumIterations, forceFactorization, stepLimit;
   int numberChanged;
+  int progressFlag;  // ClpSimplex::progressFlag_ bits 1 (a fixed variable left) and 2 (a free one came in), set per pivot (ClpSimplex.cpp:2096-2100)
   int logCount, logCapacity;
   int pivotRule;
   int lastBadIteration;
@@ -182,6 +183,7 @@ struct Dev {
   double *partial;   // gemvT partials [(kcap/64+1) * kcap]
   // dual row pivot
   double *weights, *altWeights, *infeas, *weightBySeq;
+  double *savedWeightBySeq;  // ClpDualRowSteepest::savedWeights_: the by-sequence weights of the last saveWeights(2), what mode 4 restores
   int *infIndex;
   // ratio test
   unsigned char *candFlag;  // [N] by key (rows first, then columns)

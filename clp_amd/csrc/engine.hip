@@ -148,6 +148,22 @@ struct clpgpu_context {
   // kick after 2(m+n) iterations, 50 the clp command's default, 51-69 fixed fractions) and the running state
   // (101 = the costs are perturbed now, 102 = no more perturbing in this solve)
   int perturbationOption = 102, perturbation = 102, numberPerturbations = 0;
+  // ClpSimplexProgress (src/ClpSolve.cpp:4289-4725), the part the dual uses: objective (less the possible improvement),
+  // sum and number of primal infeasibilities and iteration count of the last five status checks, newest last
+  static const int PROGRESS = 5;
+  double progObjective[PROGRESS], progInfeasibility[PROGRESS];
+  int progNumberInfeasibilities[PROGRESS], progIteration[PROGRESS];
+  int progTimes = 0, progBadTimes = 0, progReallyBadTimes = 0, progTimesFlagged = 0;
+  int progressFlag = 0;  // ClpSimplex::progressFlag_: 1 / 2 from the device (housekeeping), 4 costs copied, 8 has looked optimal
+  std::vector<double> costCopy;          // the second half of cost_ once progressFlag_ & 4 (:5381-5390)
+  double bestPossibleImprovement = 0.0;  // ClpSimplex::checkDualSolution :3087
+  int numberBackwards = 0, numberLoopFlags = 0;  // statistics: backwards-objective restores, loops acted upon
+  int debugBackwardsAt = -1;  // fault injection (option debug_backwards_at), as in the oracle
+  void progressReset();
+  void progressStartCheck();
+  int progressLooping();
+  bool looksOptimal() const;
+  void resetFakeBoundsToOriginal();
   std::vector<double> perturbationArray;  // ClpSimplex::perturbationArray_: 2n uniform numbers, drawn once per problem
   bool started = false, needStatus = true, weightsInitialized = false;
   bool rebuildRowCopy = true;  // the device keeps the [basic|nonbasic] row partition current between refactorizations
@@ -797,6 +813,7 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   rc |= dalloc(D.altWeights, m);
   rc |= dalloc(D.infeas, m);
   rc |= dalloc(D.weightBySeq, N);
+  rc |= dalloc(D.savedWeightBySeq, N);
   rc |= dalloc(D.infIndex, m);
   rc |= dalloc(D.candFlag, (size_t)N + 8 * 256 + 64);
   rc |= dalloc(D.candSeq, N);
@@ -1786,6 +1803,8 @@ void clpgpu_context::checkPrimalSolution()
 void clpgpu_context::checkDualSolution()
 {
   double relaxedTolerance = dualTolerance + fmin(1.0e-2, largestDualError);
+  const double possTolerance = 5.0 * relaxedTolerance;  // :3093
+  bestPossibleImprovement = 0.0;
   sumDualInfeasibilities = 0.0;
   numberDualInfeasibilities = 0;
   sumOfRelaxedDualInfeasibilities = 0.0;
@@ -1798,6 +1817,8 @@ void clpgpu_context::checkDualSolution()
           double v = -value;
           if (v > dualTolerance) {
             sumDualInfeasibilities += v - dualTolerance;
+            if (v > possTolerance)
+              bestPossibleImprovement += fmin(distanceUp, 1.0e10) * v;
             if (v > relaxedTolerance)
               sumOfRelaxedDualInfeasibilities += v - relaxedTolerance;
             numberDualInfeasibilities++;
@@ -1806,6 +1827,8 @@ void clpgpu_context::checkDualSolution()
         if (distanceDown > primalTolerance && value > 0.0) {
           if (value > dualTolerance) {
             sumDualInfeasibilities += value - dualTolerance;
+            if (value > possTolerance)
+              bestPossibleImprovement += value * fmin(distanceDown, 1.0e10);
             if (value > relaxedTolerance)
               sumOfRelaxedDualInfeasibilities += value - relaxedTolerance;
             numberDualInfeasibilities++;
@@ -1946,6 +1969,116 @@ int clpgpu_context::changeBounds(int initialize, double &changeCost)
 
 // ClpSimplexDual::resetFakeBounds(1) (src/ClpSimplexDual.cpp:8505-8596): working bounds rebuilt from the
 // original ones and the fake-bound flags of the status bytes
+// ---------------------------------------------------------------------------------------------
+// ClpSimplexProgress for the dual (src/ClpSolve.cpp:4289-4725), host side: one record per status check
+// ---------------------------------------------------------------------------------------------
+void clpgpu_context::progressReset()  // ::reset :4613, algorithm_ < 0
+{
+  for (int i = 0; i < PROGRESS; i++) {
+    progObjective[i] = -DBL_MAX * 1.0e-50;
+    progInfeasibility[i] = -1.0;
+    progNumberInfeasibilities[i] = -1;
+    progIteration[i] = -1;
+  }
+  progTimes = progBadTimes = progReallyBadTimes = progTimesFlagged = 0;
+}
+
+// ::startCheck :4715 -- the small-cycle detector lives in the control block (ring buffer, kernels.hip cycleStep)
+void clpgpu_context::progressStartCheck()
+{
+  for (int i = 0; i < 12; i++) {
+    hCtrl->cycIn[i] = hCtrl->cycOut[i] = -1;
+    hCtrl->cycWay[i] = 0;
+  }
+  hCtrl->cycHead = 0;
+}
+
+// ClpSimplexDual::resetFakeBounds(0) :8303-8309: createRim1(false), then changeBounds(3)
+void clpgpu_context::resetFakeBoundsToOriginal()
+{
+  lower = origLower;
+  upper = origUpper;
+  double dummy = 0.0;
+  changeBounds(3, dummy);
+}
+
+// ClpDualRowSteepest::looksOptimal (src/ClpDualRowSteepest.cpp:1070); ClpDualRowPivot's own says no (Dantzig)
+bool clpgpu_context::looksOptimal() const
+{
+  if (!pivotRule)
+    return false;
+  const double tolerance = fmin(1000.0, primalTolerance + fmin(1.0e-2, largestPrimalError));
+  for (int iRow = 0; iRow < m; iRow++) {
+    const int iPivot = pivotVariable[iRow];
+    if (sol[iPivot] < lower[iPivot] - tolerance || sol[iPivot] > upper[iPivot] + tolerance)
+      return false;
+  }
+  return true;
+}
+
+// ::looping :4438-4611 for the dual.  -1 carry on; -2 something was changed (tolerance, dual bound, a flag: the host rim
+// is then ahead of the device); 0 declare victory; 3 / 4 give up.
+int clpgpu_context::progressLooping()
+{
+  const double objective = objectiveValue - bestPossibleImprovement, infeasibility = sumPrimalInfeasibilities;
+  const int count = numberPrimalInfeasibilities;
+  auto sameBits = [](double a, double b) { return memcmp(&a, &b, sizeof(double)) == 0; };  // equalDouble :4424
+  int numberMatched = 0, matched = 0, same = 0;
+  for (int i = 0; i < PROGRESS; i++) {
+    if (sameBits(objective, progObjective[i]) && sameBits(infeasibility, progInfeasibility[i]) && count == progNumberInfeasibilities[i]) {
+      matched |= 1 << i;
+      if (numberIterations != progIteration[i])
+        numberMatched++;
+      else
+        same++;
+    }
+    if (i) {
+      progObjective[i - 1] = progObjective[i];
+      progInfeasibility[i - 1] = progInfeasibility[i];
+      progNumberInfeasibilities[i - 1] = progNumberInfeasibilities[i];
+      progIteration[i - 1] = progIteration[i];
+    }
+  }
+  progObjective[PROGRESS - 1] = objective;
+  progInfeasibility[PROGRESS - 1] = infeasibility;
+  progNumberInfeasibilities[PROGRESS - 1] = count;
+  progIteration[PROGRESS - 1] = numberIterations;
+  if (same == PROGRESS)
+    numberMatched = PROGRESS;
+  if (progressFlag & 3)
+    numberMatched = 0;
+  progTimes++;
+  if (progTimes < 10)
+    numberMatched = 0;
+  if (matched == (1 << (PROGRESS - 1)))
+    numberMatched = 0;
+  if (!numberMatched)
+    return -1;
+  numberLoopFlags++;
+  progBadTimes++;
+  if (progBadTimes >= 10)
+    return infeasibility < 1.0e-4 ? 0 : 3;
+  forceFactorization = 1;
+  if (progBadTimes < 2) {
+    progressStartCheck();
+    dualTolerance *= 1.05;
+    if (dualBound < 1.0e17) {
+      dualBound *= 1.1;
+      resetFakeBoundsToOriginal();
+    }
+  } else {
+    if (dualBound > 1.0e14)
+      dualBound = 1.0e14;
+    const int newest = hCtrl->cycIn[(hCtrl->cycHead + 11) % 12];  // in_[CLP_CYCLE - 1]
+    if (newest < 0)
+      return 4;
+    status[newest] |= FLAGGED_BIT;
+    progressStartCheck();
+    progBadTimes = 2;
+  }
+  return -2;
+}
+
 // ClpSimplexDual::perturb (src/ClpSimplexDual.cpp:6533): the arithmetic is in perturb_host.h; the caller pushes the costs
 int clpgpu_context::perturb()
 {
@@ -2067,14 +2200,26 @@ int clpgpu_context::saveWeights(int mode)
   if (mode == 1) {
     if (pivotRule && weightsInitialized) {
       hipLaunchKernelGGL(k_fill, dim3(cdiv(N, 256)), dim3(256), 0, stream, D.weightBySeq, -1.0, N);
-      hipLaunchKernelGGL(k_weights_to_seq, dim3(g), dim3(256), 0, stream, D);
+      hipLaunchKernelGGL(k_weights_to_seq, dim3(g), dim3(256), 0, stream, D, D.weightBySeq);
     }
     return 0;
   }
   if (!pivotRule)
     return 0;
   if (mode == 2 || mode == 4) {
-    hipLaunchKernelGGL(k_weights_from_seq, dim3(g), dim3(256), 0, stream, D, weightsInitialized ? 0 : 1);
+    // :875-915.  Mode 2 keeps what mode 1 recorded (sequence -> weight of the basis being left) as savedWeights_ and maps it
+    // onto the new basis; mode 4 maps the copy kept by the LAST mode 2 -- the weights that went with the basis a restore
+    // (singular factorization, objective going backwards) comes back to -- and leaves that copy alone.
+    if (!weightsInitialized) {
+      hipLaunchKernelGGL(k_weights_from_seq, dim3(g), dim3(256), 0, stream, D, (const double *)D.weightBySeq, 1);
+      hipLaunchKernelGGL(k_fill, dim3(cdiv(N, 256)), dim3(256), 0, stream, D.savedWeightBySeq, -1.0, N);
+      hipLaunchKernelGGL(k_weights_to_seq, dim3(g), dim3(256), 0, stream, D, D.savedWeightBySeq);
+    } else if (mode == 2) {
+      (void)hipMemcpyAsync(D.savedWeightBySeq, D.weightBySeq, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, stream);
+      hipLaunchKernelGGL(k_weights_from_seq, dim3(g), dim3(256), 0, stream, D, (const double *)D.weightBySeq, 0);
+    } else {
+      hipLaunchKernelGGL(k_weights_from_seq, dim3(g), dim3(256), 0, stream, D, (const double *)D.savedWeightBySeq, 0);
+    }
     weightsInitialized = true;
   } else if (mode == 5 || mode == 7) {
     // strong branching entry (:786, :815-822): weights start again at 1.0 (the default steepest mode
@@ -2167,6 +2312,10 @@ int clpgpu_context::startup()
   // ClpDataSave: every dual() is entered with the caller's perturbation_; fastDual (:7260) does not perturb at all
   perturbation = fastDualMode ? 102 : perturbationOption;
   numberPerturbations = 0;
+  progressReset();  // ClpSimplex::saveData -> progress_.fillFromModel (src/ClpSimplex.cpp:9732)
+  progressFlag = 0;  // :461
+  bestPossibleImprovement = 0.0;
+  numberBackwards = numberLoopFlags = 0;
   forceFactorization = -1;
   lastBadIteration = -999999;
   lastCleaned = 0;
@@ -2471,12 +2620,135 @@ int clpgpu_context::statusOfProblemInDual(int type)
     if (problemStatus != -4 || numberPivots > 10)
       problemStatus = -3;
   }
+  const bool adaptTolerance = progInfeasibility[0] < 1.0e-1 && primalTolerance == 1.0e-7 && progIteration[0] > 0
+                              && progIteration[PROGRESS - 1] - progIteration[0] > 25;
+  if (adaptTolerance) {
+    // the default primal tolerance is loosened when the last five checks all show tiny infeasibilities (:5136-5160)
+    int iP;
+    double minAverage = DBL_MAX, maxAverage = 0.0;
+    for (iP = 0; iP < PROGRESS; iP++) {
+      const int count = progNumberInfeasibilities[iP];
+      if (!count)
+        break;
+      double average = progInfeasibility[iP];
+      if (average > 0.1)
+        break;
+      average /= (double)count;
+      minAverage = std::min(minAverage, average);
+      maxAverage = std::max(maxAverage, average);
+    }
+    if (iP == PROGRESS && minAverage < 1.0e-5 && maxAverage < 1.0e-3)
+      primalTolerance = optPrimalTolerance = 1.0e-6;  // dblParam_[ClpPrimalTolerance] too
+  }
   if (type && !gutsDone) {
     rc |= gutsOfSolution();
     if (logLevel > 1)
       fprintf(stderr, "clpgpu: iteration %d, nucleus %d re-inverted: errors %g %g\n", numberIterations, kNucleus, largestPrimalError, largestDualError);
+  } else if (type && adaptTolerance) {
+    checkPrimalSolution();  // the refresh recomputed the solutions before the tolerance moved
+    checkDualSolution();
   }
+  bool unflagVariables = true, reallyBadProblems = false;
+  if (progIteration[PROGRESS - 1] == numberIterations) {
+    // double check infeasibility if no action (:5326-5330)
+    if (looksOptimal()) {
+      numberPrimalInfeasibilities = 0;
+      sumPrimalInfeasibilities = 0.0;
+    }
+  } else {
+    // has the objective gone backwards since the last check? (:5332-5488)
+    const double thisObj = objectiveValue - bestPossibleImprovement;
+    double lastObj = progObjective[PROGRESS - 1];
+    double testTol = 5.0e-3;
+    if (progTimesFlagged > 10)
+      testTol *= pow(2.0, progTimesFlagged - 8);
+    else if (progTimesFlagged > 5)
+      testTol *= 5.0;
+    if (debugBackwardsAt >= 0 && numberIterations >= debugBackwardsAt && numberIterations > 0) {
+      // fault injection, as in the oracle: two checks in a row see a drop, the first small, the second large
+      lastObj = thisObj + ((progressFlag & 4) ? 2.0e4 : 1.0) * (testTol * 4.0 * (fabs(thisObj) + 1.0) + 1.0);
+      if (progressFlag & 4)
+        debugBackwardsAt = -1;
+    }
+    if (lastObj > thisObj + testTol * (fabs(thisObj) + fabs(lastObj)) + testTol) {
+      if (progTimesFlagged > 10)
+        progReallyBadTimes++;
+      if (fastDualMode) {
+        problemStatus = 3;  // in fast dual give up (:5478-5483)
+      } else if (maximumPivots > 1) {
+        if ((progressFlag & 4) == 0 && lastObj < thisObj + 1.0e4 && largestPrimalError < 1.0e2) {
+          costCopy = cost;  // just save costs
+          progressFlag |= 4;
+        } else if (!haveSnapshot) {
+          setError("objective going backwards at iteration %d with no saved basis", numberIterations);
+        } else {
+          // back to the basis of the last good check; refactorize after every pivot for a while
+          numberBackwards++;
+          forceFactorization = 1;
+          unflagVariables = false;
+          status = saveStatus;
+          sol = savedSolution;
+          if ((progressFlag & 4) == 0) {
+            costCopy = cost;
+            progressFlag |= 4;
+          } else {
+            cost = costCopy;
+          }
+          rebuildRowCopy = true;
+          const int frc = factorize(false);  // the saved basis factorized before
+          consecutiveRefreshes = 0;
+          if (frc) {
+            problemStatus = 4;
+            return frc;
+          }
+          resetFakeBoundsToOriginal();
+          type = 2;  // so will restore weights
+          rc |= pushRim();
+          rc |= gutsOfSolution();
+          if (numberPivots < 2 && hCtrl->sequenceOut >= 0 && hCtrl->sequenceOut < N) {
+            // need to reject something
+            status[hCtrl->sequenceOut] |= FLAGGED_BIT;
+            rc |= h2d(D.status, status.data(), N);
+            progBadTimes = 0;
+            progTimesFlagged++;
+          }
+          if (numberPivots < 10)
+            reallyBadProblems = true;
+          progObjective[PROGRESS - 1] = objectiveValue - bestPossibleImprovement;
+          if (logLevel > 0)
+            fprintf(stderr, "clpgpu: objective went backwards at iteration %d: back to the last good basis\n", numberIterations);
+        }
+      }
+    } else if (lastObj < thisObj - 1.0e-5 * std::max(fabs(thisObj), fabs(lastObj)) - 1.0e-3) {
+      numberTimesOptimal = 0;
+    }
+  }
+  // check if looping (:5506-5536)
+  const int loop = (type != 2) ? progressLooping() : -1;
+  if (progReallyBadTimes > 10)
+    problemStatus = 10;
   int situationChanged = 0;
+  if (loop >= 0) {
+    problemStatus = loop;
+    if (!problemStatus) {
+      numberPrimalInfeasibilities = 0;  // declaring victory
+      sumPrimalInfeasibilities = 0.0;
+    } else if (problemStatus != 3) {
+      problemStatus = 10;
+    }
+    return rc;
+  } else if (loop < -1) {
+    rc |= pushRim();  // something may have changed
+    rc |= gutsOfSolution();
+    situationChanged = 1;
+  }
+  if (progressFlag & 2)
+    situationChanged = 2;
+  progressFlag &= ~3;
+  if (progressFlag & 4)
+    costCopy = cost;  // :5543-5547
+  if (!numberPrimalInfeasibilities && !numberDualInfeasibilities)
+    progressFlag |= 8;
   bool needCleanFake = false, dirty = false;
   double saveDualBound = dualBound;
   while (problemStatus <= -3 && saveDualBound == dualBound) {
@@ -2494,6 +2766,7 @@ int clpgpu_context::statusOfProblemInDual(int type)
       sumPrimalInfeasibilities = 0.0;
     }
     if (numberDualInfeasibilities == 0 || problemStatus == -4) {
+      progObjective[PROGRESS - 1] = objectiveValue - bestPossibleImprovement;  // progress_.modifyObjective, :5645
       if (numberPrimalInfeasibilities == 0) {
         numberChangedBounds = (dualBound < 1.0e20) ? changeBounds(0, changeCost) : 0;
         dirty = true;
@@ -2506,6 +2779,7 @@ int clpgpu_context::statusOfProblemInDual(int type)
             restoreCosts();
             rc |= pushRim();
             rc |= gutsOfSolution();  // computeDuals + checkDualSolution with the true costs
+            progObjective[PROGRESS - 1] = -DBL_MAX;
             if (numberDualInfeasibilities) {
               numberChanged = 1;  // force something to happen
               lastCleaned = numberIterations - 1;
@@ -2535,6 +2809,7 @@ int clpgpu_context::statusOfProblemInDual(int type)
               cleanDuals = 1;
               restoreCosts();
               rc |= h2d(D.cost, cost.data(), N);
+              progObjective[PROGRESS - 1] = -DBL_MAX;
               problemStatus = -1;
             }
           } else {
@@ -2571,6 +2846,7 @@ int clpgpu_context::statusOfProblemInDual(int type)
         numberChanged = 0;
         perturbation = 102;  // stop any perturbations (:5891)
         restoreCosts();
+        progObjective[PROGRESS - 1] = -DBL_MAX;
         // computeDuals with the original costs, on the device
         rc |= pushRim();
         rc |= gutsOfSolution();
@@ -2609,7 +2885,7 @@ int clpgpu_context::statusOfProblemInDual(int type)
       }
     }
   }
-  if (tentativeStatus != -2 && tentativeStatus != -1) {
+  if (tentativeStatus != -2 && tentativeStatus != -1 && unflagVariables) {
     int numberFlagged = 0;
     for (int iRow = 0; iRow < m; iRow++) {
       int iPivot = pivotVariable[iRow];
@@ -2636,19 +2912,36 @@ int clpgpu_context::statusOfProblemInDual(int type)
     }
     if (dirty)
       rc |= pushRim();
-    // the basis just factorized is the one to come back to (saveStatus_ / savedSolution_, :6212-6222)
-    saveStatus = status;
-    savedSolution = sol;
-    haveSnapshot = true;
+    if (type == 0 || type == 1) {
+      // the basis just factorized is the one to come back to (saveStatus_ / savedSolution_, :6160-6175)
+      saveStatus = status;
+      savedSolution = sol;
+      haveSnapshot = true;
+    }
     if (weightsSaved) {
-      if (tentativeStatus > -3)
-        rc |= saveWeights((type < 2) ? 2 : 4);
-      else
-        rc |= saveWeights(3);
+      if (!reallyBadProblems && (largestPrimalError < 100.0 || numberPivots > 10)) {
+        if (tentativeStatus > -3)
+          rc |= saveWeights((type < 2) ? 2 : 4);
+        else
+          rc |= saveWeights(3);
+      } else {
+        rc |= saveWeights(6);  // reset weights or scale back
+      }
     }
   } else if (dirty) {
     rc |= pushRim();
   }
+  {
+    // refactorize more often when the recorded objective fell between the last two checks (:6316-6328)
+    const double thisObj = progObjective[PROGRESS - 1], lastObj = progObjective[PROGRESS - 2];
+    if (lastObj > thisObj + 1.0e-4 * std::max(fabs(thisObj), fabs(lastObj)) + 1.0e-4 && maximumPivots > 10) {
+      if (forceFactorization < 0)
+        forceFactorization = maximumPivots;
+      forceFactorization = std::max(1, forceFactorization >> 1);
+    }
+  }
+  if (problemStatus == 1 && (progressFlag & 8) != 0 && fabs(objectiveValue) > 1.0e10)
+    problemStatus = 10;  // infeasible - but has looked feasible (:6338)
   return rc;
 }
 
@@ -2993,6 +3286,8 @@ int clpgpu_context::whileIterating(int stepTarget)
   hCtrl->forceFactorization = forceFactorization;
   hCtrl->numberChanged = numberChanged;
   hCtrl->seed = seed;  // perturb() draws from the same generator on the host
+  hCtrl->progressFlag = progressFlag & 3;
+  hCtrl->primalTolerance = primalTolerance;
   hCtrl->lastBadIteration = lastBadIteration;
   hCtrl->maximumPivots = luActive ? luEtaLimit : maximumPivots;
   hCtrl->maximumIterations = maximumIterations;
@@ -3065,6 +3360,7 @@ int clpgpu_context::whileIterating(int stepTarget)
   numberChanged = hCtrl->numberChanged;
   acceptablePivot = hCtrl->acceptablePivotBase;
   seed = hCtrl->seed;
+  progressFlag = (progressFlag & ~3) | (hCtrl->progressFlag & 3);
   const int state = hCtrl->state;
   lastExitState = state;
   const int g = cdiv(m, 256);
@@ -3096,6 +3392,7 @@ int clpgpu_context::whileIterating(int stepTarget)
     } else {
       rc |= pullRim(true);
       status[hCtrl->sequenceOut] |= FLAGGED_BIT;
+      progBadTimes = 0;  // progress_.clearBadTimes(), :1487
       rc |= pushRim();
       lastBadIteration = numberIterations;
       if (fabs(hCtrl->alpha) < 1.0e-10 && fabs(hCtrl->btranAlpha) < 1.0e-8 && numberIterations > 100)
@@ -3130,6 +3427,7 @@ int clpgpu_context::whileIterating(int stepTarget)
     } else {
       rc |= pullRim(true);
       status[hCtrl->sequenceOut] |= FLAGGED_BIT;
+      progBadTimes = 0;  // :1646
       rc |= pushRim();
       lastBadIteration = numberIterations;
       problemStatus = -2;
@@ -3189,6 +3487,7 @@ int clpgpu_context::whileIterating(int stepTarget)
           numberChanged = 0;
           perturbation = 102;  // :2222-2224
           restoreCosts();
+          progObjective[PROGRESS - 1] = -DBL_MAX;
           rc |= pushRim();
           rc |= gutsOfSolution();
           if (numberDualInfeasibilities)
@@ -4260,6 +4559,7 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "acceptable_pivot")) ctx->acceptablePivot = ctx->optAcceptablePivot = v;
   else if (!strcmp(name, "random_seed")) ctx->seed = (unsigned int)v;
   else if (!strcmp(name, "perturbation")) ctx->perturbationOption = (int)v;
+  else if (!strcmp(name, "debug_backwards_at")) ctx->debugBackwardsAt = (int)v;
   else if (!strcmp(name, "log_level")) ctx->logLevel = (int)v;
   else if (!strcmp(name, "check_every")) {
     ctx->checkEvery = (int)v < 1 ? 1 : (int)v;
@@ -4719,6 +5019,8 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
   stats->lu_build_ms = ctx->luBuildSeconds * 1.0e3;
   stats->eta_count = ctx->hCtrl->pivots;
   stats->perturbations = ctx->numberPerturbations;
+  stats->backwards_restores = ctx->numberBackwards;
+  stats->loop_flags = ctx->numberLoopFlags;
   stats->nucleus_capacity = ctx->kcap;
   stats->refreshes = ctx->numberRefreshes;
   stats->refreshes_rejected = ctx->numberRefreshesRejected;

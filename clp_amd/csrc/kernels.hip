@@ -1926,6 +1926,16 @@ __device__ void houseBody(Dev D, int skipColumns = 0)
   c->numberIterations++;
   D.pivotVariable[pivotRow] = seqIn;
   D.sol[seqIn] = valueIn;
+  {
+    // "making real progress" (:2096-2100): read by ClpSimplexProgress::looping at the next status check
+    int flag = 0;
+    if (D.upper[seqIn] > 1.0e20 && D.lower[seqIn] < -1.0e20)
+      flag |= 2;
+    if (D.upper[seqOut] - D.lower[seqOut] < 1.0e-12)
+      flag |= 1;
+    if (flag)
+      c->progressFlag |= flag;
+  }
   unsigned char stIn = D.status[seqIn], stOut = D.status[seqOut];
   if (seqIn != seqOut) {
     stIn = (unsigned char)((stIn & ~7) | ST_BASIC);
@@ -5646,19 +5656,19 @@ __global__ void k_djs(Dev D, const double *y, int wide = 0)
 
 // saveWeights (src/ClpDualRowSteepest.cpp:773): weights follow their sequence across a
 // refactorization; mode >= 2 rebuilds the infeasibility list in ascending position order
-__global__ void k_weights_to_seq(Dev D)
+__global__ void k_weights_to_seq(Dev D, double *bySeq)
 {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < D.m)
-    D.weightBySeq[D.pivotVariable[p]] = D.weights[p];
+    bySeq[D.pivotVariable[p]] = D.weights[p];
 }
-__global__ void k_weights_from_seq(Dev D, int initialize)
+__global__ void k_weights_from_seq(Dev D, const double *bySeq, int initialize)
 {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < D.m) {
     double wgt = 1.0;
     if (!initialize) {
-      wgt = D.weightBySeq[D.pivotVariable[p]];
+      wgt = bySeq[D.pivotVariable[p]];
       if (wgt < 0.0)
         wgt = 1.0;  // "odd": was not basic at save time
       else if (wgt < DEVEX_TRY_NORM)

@@ -65,6 +65,8 @@ typedef struct {
   double lu_build_ms;      /* level schedules + uploads */
   long eta_count;          /* basis updates since the last factorization (length of the eta file in LU mode) */
   long perturbations;      /* times ClpSimplexDual::perturb changed the costs in the last solve (option perturbation) */
+  long backwards_restores; /* times statusOfProblemInDual went back to the last good basis because the objective fell (:5395-5476) */
+  long loop_flags;         /* times ClpSimplexProgress::looping found a repeat over status checks and acted (ClpSolve.cpp:4553) */
 } clpgpu_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------- */

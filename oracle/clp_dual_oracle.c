@@ -14,7 +14,9 @@
  *    remaining nucleus, product-form eta updates (replaceColumnPart3).  Because a slack column -e_i
  *    has a single entry, doing the slacks first leaves the other columns untouched, so this is
  *    arithmetically the dense factorization of the whole basis with the zero work skipped.
- *  - the "objective going backwards" restore logic of statusOfProblemInDual (:5331-5480) is not restated.
+ *  - of statusOfProblemInDual: the "bad accuracy, treat as singular" restore (:5237-5318), the cost rescale after
+ *    4(m+n) iterations (:5009-5021) and the Cbc-only branches are not restated; a singular refactorization ends
+ *    the solve with status 4 (the reference goes back to the saved basis).
  *  - nonbasic free columns are given "bothFake" bounds at start (the reference keeps them isFree and
  *    uses the general branch of dualColumn0).
  *  - CoinThreadRandom lives in CoinUtils (absent); the 32-bit LCG form is used [unverifiable here].
@@ -58,6 +60,7 @@ typedef struct {
 } Factor;
 
 #define ORC_CYCLE 12 /* CLP_CYCLE, src/ClpSolve.hpp:435 */
+#define ORC_PROGRESS 5 /* CLP_PROGRESS, src/ClpSolve.hpp */
 struct OrcModel {
   int m, n;
   int *colStart, *row;
@@ -94,6 +97,18 @@ struct OrcModel {
   double *perturbationArray;            /* ClpSimplex::perturbationArray_ [2n], filled on the first perturb() */
   const double *objBeforeScaling;       /* objective() as the caller gave it (perturb() looks at that one, :6566) */
   int numberPerturbations;              /* how many times perturb() changed costs in the last solve (test hook) */
+  /* ClpSimplexProgress (src/ClpSolve.cpp:4289-4725), the part the dual uses: the last ORC_PROGRESS status checks */
+  double progObjective[ORC_PROGRESS], progInfeasibility[ORC_PROGRESS];
+  int progNumberInfeasibilities[ORC_PROGRESS], progIteration[ORC_PROGRESS];
+  int progTimes, progBadTimes, progReallyBadTimes, progTimesFlagged;
+  int progressFlag;               /* ClpSimplex::progressFlag_: 1 a fixed variable left, 2 a free one came in, 4 costs copied, 8 has looked optimal */
+  double *costCopy;               /* the second half of cost_ once progressFlag_ & 4 (:5381-5390) */
+  double bestPossibleImprovement; /* ClpSimplex::checkDualSolution :3087 */
+  unsigned char *saveStatus;      /* ClpSimplex::saveStatus_ / savedSolution_: the basis of the last good status check (:6160-6175) */
+  double *savedSolution;
+  int numberBackwards, numberLoopFlags; /* test hooks: times the "objective going backwards" restore ran, times looping() acted */
+  int debugBackwardsAt;           /* fault injection (option "debug_backwards_at"): pretend the objective dropped at the first status
+                                     check at or after this iteration; -1 off */
   int cycIn[ORC_CYCLE], cycOut[ORC_CYCLE]; /* ClpSimplexProgress in_ / out_ / way_ */
   char cycWay[ORC_CYCLE];
   int scalingMode;            /* ClpModel::scaling(): 0 off (default here), 1 equilibrium, 2 geometric, 3/4 auto */
@@ -142,6 +157,11 @@ static inline int flagged(const OrcModel *M, int i) { return (M->status[i] & FLA
 static inline void setFlagged(OrcModel *M, int i) { M->status[i] |= FLAGGED_BIT; }
 static inline void clearFlagged(OrcModel *M, int i) { M->status[i] &= (unsigned char)~FLAGGED_BIT; }
 static void restoreCosts(OrcModel *M);
+/* ClpSimplexProgress accessors (src/ClpSolve.cpp:4676-4712); slot ORC_PROGRESS-1 is the newest status check */
+static inline double progressLastObjective(const OrcModel *M, int back) { return M->progObjective[ORC_PROGRESS - 1 - back]; }
+static inline int progressLastIteration(const OrcModel *M, int back) { return M->progIteration[ORC_PROGRESS - 1 - back]; }
+static inline void progressModifyObjective(OrcModel *M, double value) { M->progObjective[ORC_PROGRESS - 1] = value; }
+static inline void progressClearBadTimes(OrcModel *M) { M->progBadTimes = 0; }
 static inline double dmin(double a, double b) { return a < b ? a : b; }
 static inline double dmax(double a, double b) { return a > b ? a : b; }
 
@@ -221,6 +241,10 @@ OrcModel *orc_create(int m, int n, const int *colStart, const int *row, const do
   M->pivotRule = 1;
   M->maximumPivots = 200; /* CoinAbcBaseFactorization1.cpp:142 default */
   M->seed = 1234567u;     /* src/ClpModel.cpp:149 */
+  M->debugBackwardsAt = -1;
+  M->saveStatus = (unsigned char *)calloc((size_t)N + 1, 1);
+  M->savedSolution = DALLOC(N);
+  M->costCopy = DALLOC(N);
   M->perturbationOption = 102; /* off; the reference's constructor default is 100 (src/ClpSimplex.cpp:114), the clp CLI's 50 */
   M->forceFactorization = -1;
   M->lastBadIteration = -999999;
@@ -286,6 +310,7 @@ void orc_destroy(OrcModel *M)
   for (int i = 0; i < 2; i++) { free(M->spareIndex[i]); free(M->spareValue[i]); }
   free(M->rowFlip); free(M->colFlip); free(M->log);
   free(M->perturbationArray);
+  free(M->saveStatus); free(M->savedSolution); free(M->costCopy);
   free(M);
 }
 
@@ -315,6 +340,7 @@ int orc_set_option(OrcModel *M, const char *name, double v)
   else if (!strcmp(name, "price_by_row")) M->priceByRow = (int)v;
   else if (!strcmp(name, "scaling")) M->scalingMode = (int)v;
   else if (!strcmp(name, "perturbation")) M->perturbationOption = (int)v;
+  else if (!strcmp(name, "debug_backwards_at")) M->debugBackwardsAt = (int)v;
   else return -1;
   return 0;
 }
@@ -916,6 +942,8 @@ static void checkDualSolution(OrcModel *M)
 {
   const int N = M->m + M->n, n = M->n;
   double relaxedTolerance = M->dualTolerance + dmin(1.0e-2, M->largestDualError);
+  const double possTolerance = 5.0 * relaxedTolerance; /* a bigger tolerance for the possible improvement (:3093) */
+  M->bestPossibleImprovement = 0.0;
   M->sumDualInfeasibilities = 0.0;
   M->numberDualInfeasibilities = 0;
   M->sumOfRelaxedDualInfeasibilities = 0.0;
@@ -931,6 +959,8 @@ static void checkDualSolution(OrcModel *M)
             double v = -value;
             if (v > M->dualTolerance) {
               M->sumDualInfeasibilities += v - M->dualTolerance;
+              if (v > possTolerance)
+                M->bestPossibleImprovement += dmin(distanceUp, 1.0e10) * v;
               if (v > relaxedTolerance)
                 M->sumOfRelaxedDualInfeasibilities += v - relaxedTolerance;
               M->numberDualInfeasibilities++;
@@ -941,6 +971,8 @@ static void checkDualSolution(OrcModel *M)
           if (value > 0.0) {
             if (value > M->dualTolerance) {
               M->sumDualInfeasibilities += value - M->dualTolerance;
+              if (value > possTolerance)
+                M->bestPossibleImprovement += value * dmin(distanceDown, 1.0e10);
               if (value > relaxedTolerance)
                 M->sumOfRelaxedDualInfeasibilities += value - relaxedTolerance;
               M->numberDualInfeasibilities++;
@@ -1215,6 +1247,13 @@ static void saveWeights(OrcModel *M, int mode)
       }
       free(back);
     }
+  }
+  if (mode == 6) {
+    /* scale back weights as primal errors (:930-950; the reference stores `allowed` in every weight) */
+    double primalError = M->largestPrimalError;
+    double allowed = primalError > 1.0e3 ? 10.0 : (primalError > 1.0e2 ? 50.0 : (primalError > 1.0e1 ? 100.0 : 1000.0));
+    for (int i = 0; i < m; i++)
+      M->weights[i] = allowed;
   }
   if (mode >= 2) {
     for (int i = 0; i < M->numberInfeasible; i++)
@@ -2089,7 +2128,11 @@ static int housekeeping(OrcModel *M, double objectiveChange, int numberFlipped)
   M->numberIterations++;
   if (M->pivotRow >= 0)
     M->pivotVariable[M->pivotRow] = M->sequenceIn;
+  if (M->upper[M->sequenceIn] > 1.0e20 && M->lower[M->sequenceIn] < -1.0e20)
+    M->progressFlag |= 2; /* making real progress (:2096-2100) */
   M->sol[M->sequenceIn] = M->valueIn;
+  if (M->upper[M->sequenceOut] - M->lower[M->sequenceOut] < 1.0e-12)
+    M->progressFlag |= 1;
   if (M->sequenceIn != M->sequenceOut) {
     setStatus(M, M->sequenceIn, ST_BASIC);
     if (M->upper[M->sequenceOut] - M->lower[M->sequenceOut] > 0) {
@@ -2228,6 +2271,8 @@ static int whileIterating(OrcModel *M)
             if (fabs(btranAlpha) < 1.0e-12 || fabs(M->alpha) < 1.0e-12 || fabs(btranAlpha - M->alpha) > test) {
               unrollWeights(M);
               setFlagged(M, M->sequenceOut);
+            progressClearBadTimes(M);
+              progressClearBadTimes(M);
               M->lastBadIteration = M->numberIterations;
               M->numberPi = M->numberColNz = M->numberW = 0;
               if (fabs(M->alpha) < 1.0e-10 && fabs(btranAlpha) < 1.0e-8 && M->numberIterations > 100) {
@@ -2382,6 +2427,7 @@ static int whileIterating(OrcModel *M)
               M->perturbation = 102; /* stop any perturbations */
               restoreCosts(M);
               computeDuals(M);
+              progressModifyObjective(M, -DBL_MAX);
               checkDualSolution(M);
               if (M->numberDualInfeasibilities)
                 M->problemStatus = 10;
@@ -2401,6 +2447,102 @@ static int whileIterating(OrcModel *M)
     }
   }
   return returnCode;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* ClpSimplexProgress for the dual (src/ClpSolve.cpp:4289-4725): what happened at the last        */
+/* ORC_PROGRESS status checks.  Slot ORC_PROGRESS-1 is the newest.                                 */
+/* ------------------------------------------------------------------------------------------ */
+static void progressReset(OrcModel *M) /* ClpSimplexProgress::reset :4613, algorithm_ < 0 */
+{
+  for (int i = 0; i < ORC_PROGRESS; i++) {
+    M->progObjective[i] = -DBL_MAX * 1.0e-50;
+    M->progInfeasibility[i] = -1.0; /* an impossible value */
+    M->progNumberInfeasibilities[i] = -1;
+    M->progIteration[i] = -1;
+  }
+  M->progTimes = M->progBadTimes = M->progReallyBadTimes = M->progTimesFlagged = 0;
+}
+static void progressStartCheck(OrcModel *M) /* :4715 */
+{
+  for (int i = 0; i < ORC_CYCLE; i++) {
+    M->cycIn[i] = M->cycOut[i] = -1;
+    M->cycWay[i] = 0;
+  }
+}
+static int sameBits(double a, double b) /* equalDouble :4424 */
+{
+  return memcmp(&a, &b, sizeof(double)) == 0;
+}
+static void resetFakeBounds0(OrcModel *M);
+
+/* ClpSimplexProgress::looping :4438-4611 for algorithm_ < 0.  Returns -1 carry on, -2 something was changed
+ * (tolerance / dual bound / a variable flagged), 0 "declare victory", 3 / 4 give up. */
+static int progressLooping(OrcModel *M)
+{
+  const double objective = M->objectiveValue - M->bestPossibleImprovement;
+  const double infeasibility = M->sumPrimalInfeasibilities;
+  const int numberInfeasibilities = M->numberPrimalInfeasibilities;
+  const int iterationNumber = M->numberIterations;
+  int numberMatched = 0, matched = 0, nsame = 0;
+  for (int i = 0; i < ORC_PROGRESS; i++) {
+    if (sameBits(objective, M->progObjective[i]) && sameBits(infeasibility, M->progInfeasibility[i])
+        && numberInfeasibilities == M->progNumberInfeasibilities[i]) {
+      matched |= (1 << i);
+      if (iterationNumber != M->progIteration[i])
+        numberMatched++; /* not the same iteration */
+      else
+        nsame++; /* stuck but code should notice */
+    }
+    if (i) {
+      M->progObjective[i - 1] = M->progObjective[i];
+      M->progInfeasibility[i - 1] = M->progInfeasibility[i];
+      M->progNumberInfeasibilities[i - 1] = M->progNumberInfeasibilities[i];
+      M->progIteration[i - 1] = M->progIteration[i];
+    }
+  }
+  M->progObjective[ORC_PROGRESS - 1] = objective;
+  M->progInfeasibility[ORC_PROGRESS - 1] = infeasibility;
+  M->progNumberInfeasibilities[ORC_PROGRESS - 1] = numberInfeasibilities;
+  M->progIteration[ORC_PROGRESS - 1] = iterationNumber;
+  if (nsame == ORC_PROGRESS)
+    numberMatched = ORC_PROGRESS; /* really stuck */
+  if (M->progressFlag & 3)
+    numberMatched = 0;
+  M->progTimes++;
+  if (M->progTimes < 10)
+    numberMatched = 0;
+  if (matched == (1 << (ORC_PROGRESS - 1)))
+    numberMatched = 0; /* just last time: may be checking something */
+  if (!numberMatched)
+    return -1;
+  M->numberLoopFlags++;
+  M->progBadTimes++;
+  if (M->progBadTimes < 10) {
+    M->forceFactorization = 1; /* factorize every iteration */
+    if (M->progBadTimes < 2) {
+      progressStartCheck(M); /* clear other loop check */
+      M->dualTolerance *= 1.05;
+      if (M->dualBound < 1.0e17) { /* if infeasible increase dual bound */
+        M->dualBound *= 1.1;
+        resetFakeBounds0(M);
+      }
+    } else {
+      if (M->dualBound > 1.0e14)
+        M->dualBound = 1.0e14;
+      int iSequence = M->cycIn[ORC_CYCLE - 1];
+      if (iSequence >= 0) {
+        setFlagged(M, iSequence);
+        progressStartCheck(M);
+      } else {
+        return 4; /* all flagged? give up */
+      }
+      M->progBadTimes = 2;
+    }
+    return -2;
+  }
+  /* look at solution and maybe declare victory */
+  return infeasibility < 1.0e-4 ? 0 : 3;
 }
 
 static int compareDoubles(const void *a, const void *b)
@@ -2653,6 +2795,37 @@ static void restoreCosts(OrcModel *M)
     M->cost[M->n + i] = 0.0;
 }
 
+/* ClpSimplexDual::resetFakeBounds(0) :8303-8309: original bounds back (createRim1), then the fake ones again */
+static void resetFakeBounds0(OrcModel *M)
+{
+  const int N = M->m + M->n;
+  for (int i = 0; i < N; i++) {
+    M->lower[i] = originalLower(M, i);
+    M->upper[i] = originalUpper(M, i);
+  }
+  double dummy = 0.0;
+  changeBounds(M, 3, NULL, &dummy);
+}
+
+/* ClpDualRowSteepest::looksOptimal (src/ClpDualRowSteepest.cpp:1070); the base class (Dantzig) says no */
+static int looksOptimal(const OrcModel *M)
+{
+  if (M->pivotRule == 0)
+    return 0;
+  double tolerance = M->primalTolerance + dmin(1.0e-2, M->largestPrimalError);
+  tolerance = dmin(1000.0, tolerance);
+  int numberInfeasible = 0;
+  for (int iRow = 0; iRow < M->m; iRow++) {
+    int iPivot = M->pivotVariable[iRow];
+    double value = M->sol[iPivot];
+    if (value < M->lower[iPivot] - tolerance)
+      numberInfeasible++;
+    else if (value > M->upper[iPivot] + tolerance)
+      numberInfeasible++;
+  }
+  return numberInfeasible == 0;
+}
+
 /* ClpSimplexDual::statusOfProblemInDual :4996-6343, the parts that matter without values pass, Cbc
  * options or primal fallback (status 10 is returned to the caller). */
 static void statusOfProblemInDual(OrcModel *M, int *lastCleaned, int type)
@@ -2675,9 +2848,120 @@ static void statusOfProblemInDual(OrcModel *M, int *lastCleaned, int type)
     if (M->problemStatus != -4 || numberPivots > 10)
       M->problemStatus = -3;
   }
+  if (M->progInfeasibility[0] < 1.0e-1 && M->primalTolerance == 1.0e-7 && M->progIteration[0] > 0
+      && M->progIteration[ORC_PROGRESS - 1] - M->progIteration[0] > 25) {
+    /* the default primal tolerance (so the user did not set it) is loosened when the last checks all show tiny
+       infeasibilities (:5136-5160) */
+    int iP;
+    double minAverage = DBL_MAX, maxAverage = 0.0;
+    for (iP = 0; iP < ORC_PROGRESS; iP++) {
+      int count = M->progNumberInfeasibilities[iP];
+      if (!count)
+        break;
+      double average = M->progInfeasibility[iP];
+      if (average > 0.1)
+        break;
+      average /= (double)count;
+      minAverage = dmin(minAverage, average);
+      maxAverage = dmax(maxAverage, average);
+    }
+    if (iP == ORC_PROGRESS && minAverage < 1.0e-5 && maxAverage < 1.0e-3)
+      M->primalTolerance = 1.0e-6;
+  }
   if (type)
     gutsOfSolution(M);
+  int unflagVariables = 1, reallyBadProblems = 0;
+  if (progressLastIteration(M, 0) == M->numberIterations) {
+    /* double check infeasibility if no action (:5326-5330) */
+    if (looksOptimal(M)) {
+      M->numberPrimalInfeasibilities = 0;
+      M->sumPrimalInfeasibilities = 0.0;
+    }
+  } else {
+    /* has the objective gone backwards since the last check? (:5332-5488) */
+    const double thisObj = M->objectiveValue - M->bestPossibleImprovement;
+    double lastObj = progressLastObjective(M, 0);
+    double testTol = 5.0e-3;
+    if (M->progTimesFlagged > 10)
+      testTol *= pow(2.0, M->progTimesFlagged - 8);
+    else if (M->progTimesFlagged > 5)
+      testTol *= 5.0;
+    if (M->debugBackwardsAt >= 0 && M->numberIterations >= M->debugBackwardsAt && M->numberIterations > 0) {
+      /* fault injection: two checks in a row see a drop, the first small (costs saved), the second large (restore) */
+      lastObj = thisObj + ((M->progressFlag & 4) ? 2.0e4 : 1.0) * (testTol * 4.0 * (fabs(thisObj) + 1.0) + 1.0);
+      if (M->progressFlag & 4)
+        M->debugBackwardsAt = -1;
+    }
+    if (lastObj > thisObj + testTol * (fabs(thisObj) + fabs(lastObj)) + testTol) {
+      if (M->progTimesFlagged > 10)
+        M->progReallyBadTimes++;
+      if (M->maximumPivots > 1) {
+        if ((M->progressFlag & 4) == 0 && lastObj < thisObj + 1.0e4 && M->largestPrimalError < 1.0e2) {
+          /* just save costs */
+          memcpy(M->costCopy, M->cost, sizeof(double) * (size_t)(m + M->n));
+          M->progressFlag |= 4;
+        } else {
+          /* back to the basis of the last good check, refactorize every iteration */
+          M->numberBackwards++;
+          M->forceFactorization = 1;
+          unflagVariables = 0;
+          memcpy(M->status, M->saveStatus, (size_t)(m + M->n));
+          memcpy(M->sol, M->savedSolution, sizeof(double) * (size_t)(m + M->n));
+          if ((M->progressFlag & 4) == 0) {
+            memcpy(M->costCopy, M->cost, sizeof(double) * (size_t)(m + M->n));
+            M->progressFlag |= 4;
+          } else {
+            memcpy(M->cost, M->costCopy, sizeof(double) * (size_t)(m + M->n));
+          }
+          if (factorize(M)) { /* internalFactorize(1); the saved basis factorized before */
+            M->problemStatus = 4;
+            return;
+          }
+          resetFakeBounds0(M);
+          type = 2; /* so will restore weights */
+          gutsOfSolution(M);
+          if (numberPivots < 2) {
+            /* need to reject something */
+            setFlagged(M, M->sequenceOut);
+            progressClearBadTimes(M);
+            M->progTimesFlagged++;
+          }
+          if (numberPivots < 10)
+            reallyBadProblems = 1;
+          progressModifyObjective(M, M->objectiveValue - M->bestPossibleImprovement);
+        }
+      }
+    } else if (lastObj < thisObj - 1.0e-5 * dmax(fabs(thisObj), fabs(lastObj)) - 1.0e-3) {
+      M->numberTimesOptimal = 0;
+    }
+  }
+  /* check if looping (:5506-5536) */
+  int loop = (type != 2) ? progressLooping(M) : -1;
+  if (M->progReallyBadTimes > 10)
+    M->problemStatus = 10; /* instead - try other algorithm */
   int situationChanged = 0;
+  if (loop >= 0) {
+    M->problemStatus = loop; /* exit if in loop */
+    if (!M->problemStatus) {
+      /* declaring victory */
+      M->numberPrimalInfeasibilities = 0;
+      M->sumPrimalInfeasibilities = 0.0;
+    } else if (M->problemStatus != 3) {
+      M->problemStatus = 10;
+    }
+    return;
+  } else if (loop < -1) {
+    /* something may have changed */
+    gutsOfSolution(M);
+    situationChanged = 1;
+  }
+  if (M->progressFlag & 2)
+    situationChanged = 2; /* really for free variables in */
+  M->progressFlag &= ~3;
+  if (M->progressFlag & 4)
+    memcpy(M->costCopy, M->cost, sizeof(double) * (size_t)(m + M->n)); /* save copy of cost_ (:5543-5547) */
+  if (!M->numberPrimalInfeasibilities && !M->numberDualInfeasibilities)
+    M->progressFlag |= 8; /* mark as having gone optimal if looks like it */
   int needCleanFake = 0;
   double saveDualBound = M->dualBound;
   while (M->problemStatus <= -3 && saveDualBound == M->dualBound) {
@@ -2695,6 +2979,7 @@ static void statusOfProblemInDual(OrcModel *M, int *lastCleaned, int type)
       M->sumPrimalInfeasibilities = 0.0;
     }
     if (M->numberDualInfeasibilities == 0 || M->problemStatus == -4) {
+      progressModifyObjective(M, M->objectiveValue - M->bestPossibleImprovement); /* :5645 */
       if (M->numberPrimalInfeasibilities == 0) {
         /* may be optimal - or may be bounds are wrong (:5689-5764) */
         memset(M->rowWork3, 0, sizeof(double) * (size_t)m);
@@ -2709,6 +2994,7 @@ static void statusOfProblemInDual(OrcModel *M, int *lastCleaned, int type)
             restoreCosts(M);
             computeDuals(M); /* make sure duals are current */
             checkDualSolution(M);
+            progressModifyObjective(M, -DBL_MAX);
             if (M->numberDualInfeasibilities) {
               M->numberChanged = 1; /* force something to happen */
               *lastCleaned = M->numberIterations - 1;
@@ -2742,6 +3028,7 @@ static void statusOfProblemInDual(OrcModel *M, int *lastCleaned, int type)
               M->perturbation = 102;
               cleanDuals = 1;
               restoreCosts(M);
+              progressModifyObjective(M, -DBL_MAX);
               M->problemStatus = -1;
             }
           } else {
@@ -2777,6 +3064,7 @@ static void statusOfProblemInDual(OrcModel *M, int *lastCleaned, int type)
         M->numberChanged = 0;
         M->perturbation = 102; /* stop any perturbations (:5891) */
         restoreCosts(M);
+        progressModifyObjective(M, -DBL_MAX);
         computeDuals(M);
         checkDualSolution(M);
         if (cleanDuals != 2) {
@@ -2811,7 +3099,7 @@ static void statusOfProblemInDual(OrcModel *M, int *lastCleaned, int type)
       }
     }
   }
-  if (tentativeStatus != -2 && tentativeStatus != -1) {
+  if (tentativeStatus != -2 && tentativeStatus != -1 && unflagVariables) {
     /* unflag (:6079-6120) */
     int numberFlagged = 0;
     for (int iRow = 0; iRow < m; iRow++) {
@@ -2835,13 +3123,35 @@ static void statusOfProblemInDual(OrcModel *M, int *lastCleaned, int type)
       double dummy = 0.0;
       changeBounds(M, 3, NULL, &dummy);
     }
+    if (type == 0 || type == 1) {
+      /* the basis just checked is the one to come back to (saveStatus_ / savedSolution_, :6160-6175) */
+      memcpy(M->saveStatus, M->status, (size_t)(m + M->n));
+      memcpy(M->savedSolution, M->sol, sizeof(double) * (size_t)(m + M->n));
+    }
     if (weightsSaved) {
-      if (tentativeStatus > -3)
-        saveWeights(M, (type < 2) ? 2 : 4);
-      else
-        saveWeights(M, 3);
+      if (!reallyBadProblems && (M->largestPrimalError < 100.0 || numberPivots > 10)) {
+        if (tentativeStatus > -3)
+          saveWeights(M, (type < 2) ? 2 : 4);
+        else
+          saveWeights(M, 3);
+      } else {
+        saveWeights(M, 6); /* reset weights or scale back */
+      }
     }
   }
+  {
+    /* refactorize more often when the recorded objective fell between the last two checks (:6316-6328) */
+    const double thisObj = progressLastObjective(M, 0), lastObj = progressLastObjective(M, 1);
+    if (lastObj > thisObj + 1.0e-4 * dmax(fabs(thisObj), fabs(lastObj)) + 1.0e-4) {
+      if (M->maximumPivots > 10) {
+        if (M->forceFactorization < 0)
+          M->forceFactorization = M->maximumPivots;
+        M->forceFactorization = (M->forceFactorization >> 1) > 1 ? (M->forceFactorization >> 1) : 1;
+      }
+    }
+  }
+  if (M->problemStatus == 1 && (M->progressFlag & 8) != 0 && fabs(M->objectiveValue) > 1.0e10)
+    M->problemStatus = 10; /* infeasible - but has looked feasible (:6338) */
 }
 
 /* ClpSimplexDual::dual :637 -> startupSolve :230 -> gutsOfDual :432 */
@@ -2905,6 +3215,10 @@ static int dualOnRim(OrcModel *M)
   M->numberTimesOptimal = 0;
   M->perturbation = M->perturbationOption; /* ClpDataSave: every dual() starts from the caller's value */
   M->numberPerturbations = 0;
+  progressReset(M); /* ClpSimplex::saveData -> progress_.fillFromModel, src/ClpSimplex.cpp:9732 */
+  M->progressFlag = 0; /* :461 */
+  M->bestPossibleImprovement = 0.0;
+  M->numberBackwards = M->numberLoopFlags = 0;
   for (int i = 0; i < ORC_CYCLE; i++) { /* progress_.startCheck(), ClpSimplexDual.cpp:452 */
     M->cycIn[i] = M->cycOut[i] = -1;
     M->cycWay[i] = 0;
@@ -3301,6 +3615,8 @@ int orc_number_iterations(const OrcModel *M) { return M->numberIterations; }
 double orc_objective_value(const OrcModel *M) { return M->objectiveValue; }
 int orc_number_refactorizations(const OrcModel *M) { return M->numberRefactorizations; }
 int orc_number_perturbations(const OrcModel *M) { return M->numberPerturbations; }
+int orc_number_backwards(const OrcModel *M) { return M->numberBackwards; }
+int orc_number_loop_flags(const OrcModel *M) { return M->numberLoopFlags; }
 double orc_iteration_seconds(const OrcModel *M) { return M->seconds; }
 void orc_get_solution(const OrcModel *M, double *s) { memcpy(s, M->sol, sizeof(double) * (size_t)(M->m + M->n)); }
 void orc_get_reduced_costs(const OrcModel *M, double *d) { memcpy(d, M->dj, sizeof(double) * (size_t)(M->m + M->n)); }

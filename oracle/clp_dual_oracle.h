@@ -77,6 +77,10 @@ double orc_objective_value(const OrcModel *model);
 int orc_number_refactorizations(const OrcModel *model);
 /* times ClpSimplexDual::perturb changed the costs during the last orc_dual (0, 1: start-up or kick) */
 int orc_number_perturbations(const OrcModel *model);
+/* times the "objective going backwards" restore of statusOfProblemInDual ran (:5395-5476), and times
+ * ClpSimplexProgress::looping found a repeat and acted, during the last orc_dual */
+int orc_number_backwards(const OrcModel *model);
+int orc_number_loop_flags(const OrcModel *model);
 /* copies n+m doubles, [columns | rows] */
 void orc_get_solution(const OrcModel *model, double *solution);
 void orc_get_reduced_costs(const OrcModel *model, double *dj);

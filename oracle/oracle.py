@@ -52,6 +52,8 @@ def lib():
         L.orc_number_iterations.argtypes = [p]
         L.orc_number_refactorizations.argtypes = [p]
         L.orc_number_perturbations.argtypes = [p]
+        L.orc_number_backwards.argtypes = [p]
+        L.orc_number_loop_flags.argtypes = [p]
         L.orc_test_perturb.argtypes = [p, C.c_int, C.c_int, up, dp]
         L.orc_objective_value.argtypes = [p]
         L.orc_objective_value.restype = C.c_double
@@ -117,6 +119,14 @@ class OracleSimplex:
         cost = np.zeros(self.m + self.n)
         r = lib().orc_test_perturb(self._h, int(perturbation), int(iterations), np.ascontiguousarray(status, dtype=np.uint8), cost)
         return r // 1000, r % 1000, cost
+
+    @property
+    def backwards(self):
+        return lib().orc_number_backwards(self._h)
+
+    @property
+    def loop_flags(self):
+        return lib().orc_number_loop_flags(self._h)
 
     @property
     def perturbations(self):

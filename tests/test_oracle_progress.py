@@ -1,0 +1,41 @@
+"""CPU tests of the oracle's restatement of ClpSimplexProgress for the dual (src/ClpSolve.cpp:4438-4725) and of the
+"objective going backwards" restore of statusOfProblemInDual (src/ClpSimplexDual.cpp:5326-5488).  No LP of the suite makes
+the objective fall by itself (that takes numerical trouble), so the restore is driven by fault injection (option
+debug_backwards_at: the first two status checks at or after that iteration see a drop -- the first a small one, which only
+saves the costs, :5379-5390, the second a large one, which goes back to the last good basis, :5392-5476)."""
+import numpy as np
+import pytest
+
+from clp_amd import problems as P
+from oracle.oracle import OracleSimplex
+
+
+def solve(lp, rule, **opts):
+    o = OracleSimplex(lp)
+    o.set_option("pivot_rule", rule)
+    for k, v in opts.items():
+        o.set_option(k, v)
+    return o, o.dual()
+
+
+@pytest.mark.parametrize("rule", [0, 1])
+@pytest.mark.parametrize("maker,args,at", [("sparse_lp", (300, 1200, 8, 11), 300), ("netlib_shaped_lp", (400, 1500, 9000, 3), 250),
+                                           ("nqueens", (20,), 200)])
+def test_backwards_restore_returns_to_the_saved_basis_and_still_finishes(maker, args, at, rule):
+    lp = getattr(P, maker)(*args)
+    plain, s0 = solve(lp, rule)
+    hurt, s1 = solve(lp, rule, debug_backwards_at=at)
+    assert s0 == s1 == 0 and plain.backwards == 0 and hurt.backwards == 1
+    assert abs(plain.objective - hurt.objective) <= 1e-9 * (1 + abs(plain.objective))
+    # the pivots up to the injection are the undisturbed ones; after it a stretch is done again, refactorizing every few pivots
+    a, b = plain.pivot_log()["sequenceIn"], hurt.pivot_log()["sequenceIn"]
+    assert np.array_equal(a[:at], b[:at])
+    assert hurt.iterations > plain.iterations and hurt.refactorizations > plain.refactorizations + 5
+
+
+def test_progress_machinery_is_inert_on_healthy_solves():
+    """No repeat over status checks, no fall of the objective: the solve is pivot for pivot what it was without it
+    (iteration counts of the degenerate generators as committed before this logic existed)."""
+    for n, rule, expected in [(8, 0, 91), (8, 1, 73), (20, 0, 553), (20, 1, 572)]:
+        o, s = solve(P.nqueens(n), rule)
+        assert s == 0 and o.iterations == expected and o.backwards == 0 and o.loop_flags == 0
