@@ -159,6 +159,7 @@ struct clpgpu_context {
   double bestPossibleImprovement = 0.0;  // ClpSimplex::checkDualSolution :3087
   int numberBackwards = 0, numberLoopFlags = 0;  // statistics: backwards-objective restores, loops acted upon
   int debugBackwardsAt = -1;  // fault injection (option debug_backwards_at), as in the oracle
+  int debugPoisonInverseAt = -1, numberPoisoned = 0;  // fault injection (option debug_poison_inverse_at)
   void progressReset();
   void progressStartCheck();
   int progressLooping();
@@ -2562,6 +2563,14 @@ int clpgpu_context::statusOfProblemInDual(int type)
   if (problemStatus > -3 || numberPivots > 0) {
     rc |= saveWeights(1);
     weightsSaved = true;
+    if (type && debugPoisonInverseAt >= 0 && numberIterations >= debugPoisonInverseAt && refreshEligible()) {
+      // fault injection (option debug_poison_inverse_at): a NaN in the kept inverse right before a verified refresh,
+      // which then has to be refused (the maxima of the check chain propagate NaN) and followed by a re-inversion
+      const double poison = nan("");
+      rc |= h2d(D.Minv + (size_t)(hCtrl->k / 2) * ld + hCtrl->k / 3, &poison, 1);
+      debugPoisonInverseAt = -1;
+      numberPoisoned++;
+    }
     if (type && refreshEligible() && (!refreshRefine || refineInverse() == 0)) {
       rc |= pullRim(true);
       rc |= refreshFactor();
@@ -4560,6 +4569,7 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "random_seed")) ctx->seed = (unsigned int)v;
   else if (!strcmp(name, "perturbation")) ctx->perturbationOption = (int)v;
   else if (!strcmp(name, "debug_backwards_at")) ctx->debugBackwardsAt = (int)v;
+  else if (!strcmp(name, "debug_poison_inverse_at")) ctx->debugPoisonInverseAt = (int)v;
   else if (!strcmp(name, "log_level")) ctx->logLevel = (int)v;
   else if (!strcmp(name, "check_every")) {
     ctx->checkEvery = (int)v < 1 ? 1 : (int)v;

@@ -219,7 +219,10 @@ int clpgpu_unroll_weights(clpgpu_context *ctx);
  * "lu_inverse_fill_cap" (front / explicit-inverse controls), "lu_max_pivots", "lu_min_pivots", "lu_adaptive" (eta-file
  * length), "lu_polish", "lu_polish_tolerance" (Newton-Schulz steps on the tail inverse),
  * "gemm_backend" (0 the engine's own MFMA f64 GEMM, 1 rocBLAS), "solution_refinements" / "refine_above" (iterative
- * refinement of the recomputed primal and dual solutions), "price_tiles" (1: pricing with pi tiles staged in LDS). */
+ * refinement of the recomputed primal and dual solutions), "price_tiles" (1: pricing with pi tiles staged in LDS).
+ * Fault injection for the tests: "debug_backwards_at" (the first two status checks at or after this iteration see the
+ * objective fall: drives the restore of src/ClpSimplexDual.cpp:5326-5488), "debug_poison_inverse_at" (a NaN in the
+ * kept inverse right before the next verified refresh). */
 int clpgpu_set_option(clpgpu_context *ctx, const char *name, double value);
 /* Whole-array replacement of bounds / costs with the matrix left resident
  * (ClpModel::chgRowLower ... chgObjCoefficients, src/ClpModel.hpp:254-262, src/ClpModel.cpp:2669-2770;

@@ -415,6 +415,28 @@ def test_verified_refresh_of_the_inverse(gpu_cls):
     assert np.array_equal(off.solution(), rej.solution())
 
 
+@pytest.mark.parametrize("refine", [0, 1])
+def test_poisoned_inverse_is_refused_by_the_verified_refresh(gpu_cls, refine):
+    """a NaN in the kept inverse must not read as a small residual.  Fault injection (option
+    debug_poison_inverse_at) writes one into Minv right before a verified refresh: without the Newton-Schulz step the
+    recomputed solutions carry it and the refresh is rejected (refreshes_rejected), with the step the residual itself
+    is not finite and the engine re-inverts at once; either way the solve ends at the oracle's optimum."""
+    lp = P.sparse_lp(300, 1200, 8, 11)
+    o = oracle(lp, 1)
+    assert o.dual() == 0
+    g = gpu_cls().loadProblem(lp)
+    for k, v in (("refresh_min_k", 50), ("refresh_max", 1000), ("refresh_refine", refine), ("max_pivots", 40), ("debug_poison_inverse_at", 200)):
+        g.set_option(k, v)
+    assert g.dual() == 0
+    st = g.stats()
+    assert st["refreshes"] > 3
+    if not refine:
+        assert st["refreshes_rejected"] >= 1
+    assert np.all(np.isfinite(g.solution())) and np.all(np.isfinite(g.reducedCosts()))
+    assert abs(g.objectiveValue() - o.objective) <= RTOL * (1 + abs(o.objective))
+    kkt(lp, g)
+
+
 def test_verified_refresh_dense_form(gpu_cls):
     """The same refresh on an LP with long rows (config-3 shape): the nucleus is gathered dense by slots and both
     halves of the Newton-Schulz step are GEMMs.  Forced on from nucleus order 20: oracle's optimum (1e-8), KKT,
