@@ -4058,6 +4058,50 @@ int clpgpu_test_cycle(clpgpu_context *ctx, int count, const int *in, const int *
   return rc;
 }
 
+// parity hook for the engine's restatement of ClpSimplexProgress::looping (src/ClpSolve.cpp:4438-4611), host code only: no
+// device is needed or touched.  A sequence of status checks goes through clpgpu_context::progressLooping on a scratch context
+// without rows or columns (tests/test_progress_looping.py holds it, the CPU checker's hook of the same shape and a Python
+// restatement of the reference together).  Sequences must be below 64.
+int clpgpu_test_looping(int count, const double *objective, const double *infeasibility, const int *numberInfeasibilities, const int *iteration,
+                        const int *flagBits, const int *newestIncoming, int *code, double *dualTolerance, double *dualBound, int *forceFactorization,
+                        int *flagged)
+{
+  if (count < 0 || (count && (!objective || !infeasibility || !numberInfeasibilities || !iteration || !flagBits || !newestIncoming || !code
+                              || !dualTolerance || !dualBound || !forceFactorization || !flagged)))
+    return -99;
+  clpgpu_context *ctx = new clpgpu_context();
+  Ctrl ctrl;
+  memset(&ctrl, 0, sizeof(ctrl));
+  ctx->hCtrl = &ctrl;
+  ctx->status.assign(64, 0);
+  ctx->dualTolerance = ctx->dualToleranceBase = 1.0e-7;
+  ctx->dualBound = 1.0e10;
+  ctx->forceFactorization = -1;
+  ctx->progressReset();
+  for (int i = 0; i < count; i++) {
+    ctx->objectiveValue = objective[i];
+    ctx->bestPossibleImprovement = 0.0;
+    ctx->sumPrimalInfeasibilities = infeasibility[i];
+    ctx->numberPrimalInfeasibilities = numberInfeasibilities[i];
+    ctx->numberIterations = iteration[i];
+    ctx->progressFlag = flagBits[i];
+    ctx->progressStartCheck();
+    ctrl.cycIn[11] = newestIncoming[i];  // with cycHead == 0 the newest entry sits in the last slot
+    std::fill(ctx->status.begin(), ctx->status.end(), (unsigned char)0);
+    code[i] = ctx->progressLooping();
+    dualTolerance[i] = ctx->dualTolerance;
+    dualBound[i] = ctx->dualBound;
+    forceFactorization[i] = ctx->forceFactorization;
+    flagged[i] = -1;
+    for (int j = 0; j < 64; j++)
+      if (ctx->status[j] & FLAGGED_BIT)
+        flagged[i] = j;
+  }
+  ctx->hCtrl = nullptr;
+  delete ctx;
+  return 0;
+}
+
 // the engine's own f64 MFMA GEMM on host arrays (row-major n x n): c = beta c + alpha a b.  A parity hook for the
 // kernel behind the Newton-Schulz steps (CoinAbcDgemm's role, src/CoinAbcHelperFunctions.cpp:1658).
 int clpgpu_dgemm(clpgpu_context *ctx, int nn, double alpha, const double *a, const double *b, double beta, double *c)

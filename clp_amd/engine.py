@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "clpgpu_chg_obj_coefficients", "clpgpu_scale_factors",
     "clpgpu_clone", "clpgpu_set_scales", "clpgpu_ftran_ft", "clpgpu_ftran_two_ft", "clpgpu_bind_rim", "clpgpu_pivot_row",
     "clpgpu_update_weights", "clpgpu_update_primal", "clpgpu_save_weights", "clpgpu_unroll_weights",
-    "clpgpu_get_kernel_times", "clpgpu_dgemm", "clpgpu_test_cycle",
+    "clpgpu_get_kernel_times", "clpgpu_dgemm", "clpgpu_test_cycle", "clpgpu_test_looping",
     "clpgpu_virtual_group_create", "clpgpu_virtual_group_destroy", "clpgpu_virtual_attach", "clpgpu_virtual_dual_steps",
 ]
 
@@ -449,6 +449,24 @@ class ClpGpuSimplex:
         ra, rp = self._opt(row_scale, np.float64)
         ca, cp = self._opt(column_scale, np.float64)
         self._check(lib().clpgpu_set_scales(self._h, rp, cp), "clpgpu_set_scales")
+
+
+def test_looping(objective, infeasibility, count, iteration, flag_bits, newest):
+    """The engine's host restatement of ClpSimplexProgress::looping over a sequence of status checks (clpgpu_test_looping);
+    host code only, runs without a GPU.  Returns (code, dualTolerance, dualBound, forceFactorization, flagged) arrays."""
+    dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+    ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    n = len(objective)
+    d = [np.ascontiguousarray(a, dtype=np.float64) for a in (objective, infeasibility)]
+    i = [np.ascontiguousarray(a, dtype=np.int32) for a in (count, iteration, flag_bits, newest)]
+    code, force, flagged = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+    tol, bound = np.zeros(n), np.zeros(n)
+    f = lib().clpgpu_test_looping
+    f.argtypes = [C.c_int, dp, dp, ip, ip, ip, ip, ip, dp, dp, ip, ip]
+    f.restype = C.c_int
+    if f(n, d[0], d[1], i[0], i[1], i[2], i[3], code, tol, bound, force, flagged) != 0:
+        raise RuntimeError("clpgpu_test_looping failed")
+    return code, tol, bound, force, flagged
 
 
 class VirtualRanks:

@@ -304,6 +304,15 @@ int clpgpu_virtual_dual_steps(clpgpu_virtual_group *group, int iterations, int *
  * empty history; matched[i] = its verdict at pivot i (0 none, k a cycle of length k, 100 irregular repeats).  A parity hook:
  * no LP here runs into a cycle on its own. */
 int clpgpu_test_cycle(clpgpu_context *ctx, int count, const int *in, const int *out, const int *wayIn, const int *wayOut, int *matched);
+/* Parity hook for the engine's host restatement of ClpSimplexProgress::looping (src/ClpSolve.cpp:4438-4611: the loop detector
+ * over status checks that statusOfProblemInDual consults, src/ClpSimplexDual.cpp:5506-5536).  Host code only -- needs no device.
+ * Check i sees objective[i] / infeasibility[i] / numberInfeasibilities[i] at iteration[i] with progressFlag_ & 3 = flagBits[i]
+ * and newestIncoming[i] as the last incoming variable of the small-cycle list; code[i] = looping()'s return (-1 carry on, -2
+ * something changed, 0 declare victory, 3 / 4 give up); dualTolerance / dualBound / forceFactorization = the solver's values
+ * afterwards (1e-7, 1e10, -1 to begin with); flagged[i] = the sequence (< 64) it flagged, or -1.  Returns 0, -99 on bad arguments. */
+int clpgpu_test_looping(int count, const double *objective, const double *infeasibility, const int *numberInfeasibilities, const int *iteration,
+                        const int *flagBits, const int *newestIncoming, int *code, double *dualTolerance, double *dualBound, int *forceFactorization,
+                        int *flagged);
 
 /* CoinAbcDgemm (src/CoinAbcHelperFunctions.cpp:1658; used by CoinAbcDgetrf, src/AbcSimplexParallel.cpp:2491-2534):
  * the engine's own f64 GEMM on the matrix cores, c = beta c + alpha a b for row-major n x n host arrays.  The

@@ -3584,6 +3584,44 @@ int orc_get_scale_factors(const OrcModel *M, double *rowScale, double *columnSca
   return M->scalingApplied;
 }
 
+/* test hook: a sequence of status checks through progressLooping (ClpSimplexProgress::looping for the dual) on a scratch
+ * model without rows or columns.  Check i sees objective[i] (the possible improvement taken as zero), infeasibility[i],
+ * numberInfeasibilities[i] at iteration[i], with progressFlag_ & 3 = flagBits[i] and newestIncoming[i] as the last entry of
+ * the cycle detector's in_ list.  Out: code[i] = what looping() returned, and the model's dual tolerance, dual bound,
+ * forceFactorization_ afterwards; flagged[i] = the sequence it flagged or -1.  Sequences must be below 64. */
+void orc_test_looping(int count, const double *objective, const double *infeasibility, const int *numberInfeasibilities,
+                      const int *iteration, const int *flagBits, const int *newestIncoming, int *code, double *dualTolerance,
+                      double *dualBound, int *forceFactorization, int *flaggedOut)
+{
+  OrcModel *M = (OrcModel *)calloc(1, sizeof(OrcModel));
+  M->status = (unsigned char *)calloc(64, 1);
+  M->dualTolerance = M->dualToleranceBase = 1.0e-7;
+  M->dualBound = 1.0e10;
+  M->forceFactorization = -1;
+  progressReset(M);
+  for (int i = 0; i < count; i++) {
+    M->objectiveValue = objective[i];
+    M->bestPossibleImprovement = 0.0;
+    M->sumPrimalInfeasibilities = infeasibility[i];
+    M->numberPrimalInfeasibilities = numberInfeasibilities[i];
+    M->numberIterations = iteration[i];
+    M->progressFlag = flagBits[i];
+    progressStartCheck(M);
+    M->cycIn[ORC_CYCLE - 1] = newestIncoming[i];
+    memset(M->status, 0, 64);
+    code[i] = progressLooping(M);
+    dualTolerance[i] = M->dualTolerance;
+    dualBound[i] = M->dualBound;
+    forceFactorization[i] = M->forceFactorization;
+    flaggedOut[i] = -1;
+    for (int j = 0; j < 64; j++)
+      if (flagged(M, j))
+        flaggedOut[i] = j;
+  }
+  free(M->status);
+  free(M);
+}
+
 /* test hook: ClpSimplexDual::perturb on a fresh rim (createRim: the model's bounds and costs, unscaled) with the given
  * statuses, as if numberIterations pivots had been made.  cost[n+m] receives the perturbed costs; returns
  * 1000 * (perturb's return code) + perturbation_ afterwards.  tests/test_perturb_host.py holds the engine's host

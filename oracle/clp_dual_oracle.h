@@ -114,6 +114,10 @@ int orc_price_row_fused(const OrcModel *model, int numberPi, const int *piIndex,
 /* factorization of the basis given by status (basic==1): returns 0 or -1 singular; fills pivotVariable */
 /* ClpSimplexProgress::cycle (src/ClpSolve.cpp:4726-4825) over a sequence of pivots, from empty history */
 void orc_test_cycle(int n, const int *in, const int *out, const int *wayIn, const int *wayOut, int *matched);
+/* test hook: a sequence of status checks through ClpSimplexProgress::looping as restated here; see the definition */
+void orc_test_looping(int count, const double *objective, const double *infeasibility, const int *numberInfeasibilities,
+                      const int *iteration, const int *flagBits, const int *newestIncoming, int *code, double *dualTolerance,
+                      double *dualBound, int *forceFactorization, int *flagged);
 /* test hook: ClpSimplexDual::perturb on a fresh rim with the given statuses; see the definition */
 int orc_test_perturb(OrcModel *model, int perturbation, int numberIterations, const unsigned char *status, double *cost);
 int orc_factorize(OrcModel *model, const unsigned char *status, int *pivotVariable);

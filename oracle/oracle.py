@@ -224,6 +224,26 @@ class OracleSimplex:
         return lib().orc_replace_column(self._h, np.ascontiguousarray(w, dtype=np.float64), int(pivot_row), float(alpha))
 
 
+def _looping_call(f, has_restype, objective, infeasibility, count, iteration, flag_bits, newest):
+    dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+    ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    n = len(objective)
+    d = [np.ascontiguousarray(a, dtype=np.float64) for a in (objective, infeasibility)]
+    i = [np.ascontiguousarray(a, dtype=np.int32) for a in (count, iteration, flag_bits, newest)]
+    code, force, flagged = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+    tol, bound = np.zeros(n), np.zeros(n)
+    f.argtypes = [C.c_int, dp, dp, ip, ip, ip, ip, ip, dp, dp, ip, ip]
+    f.restype = C.c_int if has_restype else None
+    r = f(n, d[0], d[1], i[0], i[1], i[2], i[3], code, tol, bound, force, flagged)
+    assert not has_restype or r == 0
+    return code, tol, bound, force, flagged
+
+
+def test_looping(objective, infeasibility, count, iteration, flag_bits, newest):
+    """ClpSimplexProgress::looping of the oracle over a sequence of status checks (orc_test_looping)"""
+    return _looping_call(lib().orc_test_looping, False, objective, infeasibility, count, iteration, flag_bits, newest)
+
+
 def test_cycle(seq_in, seq_out, way_in, way_out):
     """ClpSimplexProgress::cycle of the oracle over a sequence of pivots (orc_test_cycle)"""
     arr = [np.ascontiguousarray(a, dtype=np.int32) for a in (seq_in, seq_out, way_in, way_out)]
