@@ -114,3 +114,57 @@ def test_front_leaves_dependent_columns_to_the_tail(harness, tmp_path):
     assert 17 in fac[10].tolist()  # the empty column was never a pivot column
     assert 55 in fac[9].tolist()  # nor the empty row a pivot row
     assert np.min(np.abs(fac[2])) > 1e-11
+
+
+def _run_front(harness, tmp_path, C, density, min_tail):
+    k = C.shape[0]
+    src, dst = str(tmp_path / "C.bin"), str(tmp_path / "F.bin")
+    with open(src, "wb") as o:
+        o.write(struct.pack("qq", k, C.nnz))
+        o.write(C.indptr.astype(np.int32).tobytes())
+        o.write(C.indices.astype(np.int32).tobytes())
+        o.write(C.data.tobytes())
+    out = subprocess.run([harness, src, str(density), str(min_tail), dst], capture_output=True, text=True, check=True).stdout.split()
+    fac = read_vectors(dst, [np.int32, np.int32, np.float64, np.int32, np.int32, np.float64, np.int32, np.int32, np.float64, np.int32, np.int32,
+                             np.int32, np.int32, np.float64])
+    return int(out[0]), int(out[1]), fac
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_front_on_varied_structures(harness, tmp_path, seed):
+    """Shapes a simplex nucleus takes: slack-like singletons mixed in, a band, power-law column lengths, a few long rows, values
+    spread over six orders of magnitude.  Whatever the front decides (how far it gets, which pivots the threshold refuses), the
+    factors must solve with the matrix to 1e-8 relative to SuperLU -- the growth the threshold 0.1 allows stays small."""
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.integers(150, 1200))
+    kind = seed % 4
+    rows, cols, vals = [], [], []
+    for j in range(k):
+        if kind == 0:  # band + random
+            r = np.unique(np.clip(j + rng.integers(-6, 7, 5), 0, k - 1))
+        elif kind == 1:  # power-law column lengths
+            length = min(k, max(1, int(1.0 / rng.uniform(0.01, 1.0))))
+            r = rng.choice(k, length, replace=False)
+        elif kind == 2:  # singletons (slack-like) among short columns
+            r = np.array([rng.integers(k)]) if rng.uniform() < 0.4 else rng.choice(k, 3, replace=False)
+        else:  # a few long rows
+            r = np.unique(np.concatenate([rng.choice(k, 3, replace=False), rng.choice(5, 2)]))
+        v = rng.choice([-1.0, 1.0], len(r)) * 10.0 ** rng.uniform(-3.0, 3.0, len(r))
+        rows.append(r)
+        cols.append(np.full(len(r), j))
+        vals.append(v)
+    C = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(k, k))
+    C = (C + sp.diags(rng.choice([-1.0, 1.0], k) * 10.0 ** rng.uniform(0.0, 2.0, k))).tocsc()  # structurally nonsingular
+    C.sum_duplicates()
+    C.sort_indices()
+    lu = sla.splu(C)
+    if np.min(np.abs(lu.U.diagonal())) < 1e-8 * np.max(np.abs(lu.U.diagonal())):
+        pytest.skip("numerically singular draw")
+    for density, min_tail in ((0.012, 16), (1.0, 0)):
+        nF, k2, fac = _run_front(harness, tmp_path, C, density, min_tail)
+        assert nF + k2 == k
+        for _ in range(2):
+            b = rng.standard_normal(k)
+            ref = lu.solve(b)
+            x = solve_with_factors(k, fac, b)
+            assert np.max(np.abs(x - ref)) <= 1e-8 * (1.0 + np.max(np.abs(ref))), (seed, kind, density, nF, k2)
