@@ -47,7 +47,7 @@ typedef struct {
   int *rowToK;  /* [m] -1 when the row's slack is basic, else elimination step of that row */
   double *lu;   /* k*k column-major in pivoted row order: multipliers below the diagonal,
                    U on/above it, diagonal stored inverted (CoinAbcDenseFactorization.cpp:281) */
-  int luCap;
+  long luCap;
   double *t;    /* [m] scratch */
   /* product-form eta file (replaceColumnPart3 :480); stored sparse, arithmetic as dense */
   int nEta, maxEta;
@@ -617,12 +617,13 @@ static int factorize(OrcModel *M)
     if (F->rowToK[i] == -2)
       rrows[nr++] = i;
   if ((long)k * k > F->luCap) {
-    F->luCap = k * k + 16;
+    F->luCap = (long)k * k + 16;
     free(F->lu);
     F->lu = (double *)malloc(sizeof(double) * (size_t)F->luCap);
   }
   double *lu = F->lu;
-  memset(lu, 0, sizeof(double) * (size_t)k * (size_t)k);
+  if (k)
+    memset(lu, 0, sizeof(double) * (size_t)k * (size_t)k);
   int *where = F->krow; /* reuse as temp: row -> local index */
   int *local = (int *)malloc(sizeof(int) * (size_t)(m + 1));
   for (int i = 0; i < m; i++)
