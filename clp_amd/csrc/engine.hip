@@ -160,6 +160,7 @@ struct clpgpu_context {
   int numberBackwards = 0, numberLoopFlags = 0;  // statistics: backwards-objective restores, loops acted upon
   int debugBackwardsAt = -1;  // fault injection (option debug_backwards_at), as in the oracle
   int debugPoisonInverseAt = -1, numberPoisoned = 0;  // fault injection (option debug_poison_inverse_at)
+  int debugBadAccuracyAt = -1, numberAccuracyRestores = 0;  // fault injection (option debug_bad_accuracy_at) and its count
   void progressReset();
   void progressStartCheck();
   int progressLooping();
@@ -2316,7 +2317,7 @@ int clpgpu_context::startup()
   progressReset();  // ClpSimplex::saveData -> progress_.fillFromModel (src/ClpSimplex.cpp:9732)
   progressFlag = 0;  // :461
   bestPossibleImprovement = 0.0;
-  numberBackwards = numberLoopFlags = 0;
+  numberBackwards = numberLoopFlags = numberAccuracyRestores = 0;
   forceFactorization = -1;
   lastBadIteration = -999999;
   lastCleaned = 0;
@@ -2658,6 +2659,47 @@ int clpgpu_context::statusOfProblemInDual(int type)
     checkDualSolution();
   }
   bool unflagVariables = true, reallyBadProblems = false;
+  if (debugBadAccuracyAt >= 0 && numberIterations >= debugBadAccuracyAt && numberIterations > 0) {
+    largestPrimalError = 1.0e16;  // fault injection
+    debugBadAccuracyAt = -1;
+  }
+  if ((!(largestPrimalError <= 1.0e15) || !(largestDualError <= 1.0e15)) && numberIterations && haveSnapshot) {
+    // bad accuracy (or not a number at all): treat as singular -- back to the previous basis with a variable rejected (:5237-5318)
+    numberAccuracyRestores++;
+    unflagVariables = false;
+    for (int i = 0; i < N; i++)
+      if (status[i] & FLAGGED_BIT)
+        saveStatus[i] |= FLAGGED_BIT;  // keep any flagged variables
+    status = saveStatus;
+    sol = savedSolution;
+    resetFakeBounds();  // resetFakeBounds(1): correct bounds on all variables
+    int rejectedVariable = hCtrl->sequenceOut;
+    if (rejectedVariable < 0 || rejectedVariable >= N || (status[rejectedVariable] & FLAGGED_BIT)) {
+      rejectedVariable = -1;
+      for (int i = 0; i < m && rejectedVariable < 0; i++)
+        if (!(status[pivotVariable[i]] & FLAGGED_BIT))
+          rejectedVariable = pivotVariable[i];
+      if (rejectedVariable < 0) {
+        problemStatus = 10;  // real trouble
+        return rc;
+      }
+    }
+    status[rejectedVariable] |= FLAGGED_BIT;
+    progBadTimes = 0;
+    forceFactorization = 1;  // a bit drastic but ..
+    type = 2;
+    rebuildRowCopy = true;
+    const int frc = factorize(false);
+    consecutiveRefreshes = 0;
+    if (frc) {
+      problemStatus = 4;
+      return frc;
+    }
+    rc |= pushRim();
+    rc |= gutsOfSolution();
+    if (logLevel > 0)
+      fprintf(stderr, "clpgpu: bad accuracy at iteration %d: back to the last good basis, variable %d flagged\n", numberIterations, rejectedVariable);
+  }
   if (progIteration[PROGRESS - 1] == numberIterations) {
     // double check infeasibility if no action (:5326-5330)
     if (looksOptimal()) {
@@ -4614,6 +4656,7 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "perturbation")) ctx->perturbationOption = (int)v;
   else if (!strcmp(name, "debug_backwards_at")) ctx->debugBackwardsAt = (int)v;
   else if (!strcmp(name, "debug_poison_inverse_at")) ctx->debugPoisonInverseAt = (int)v;
+  else if (!strcmp(name, "debug_bad_accuracy_at")) ctx->debugBadAccuracyAt = (int)v;
   else if (!strcmp(name, "log_level")) ctx->logLevel = (int)v;
   else if (!strcmp(name, "check_every")) {
     ctx->checkEvery = (int)v < 1 ? 1 : (int)v;
@@ -5075,6 +5118,7 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
   stats->perturbations = ctx->numberPerturbations;
   stats->backwards_restores = ctx->numberBackwards;
   stats->loop_flags = ctx->numberLoopFlags;
+  stats->accuracy_restores = ctx->numberAccuracyRestores;
   stats->nucleus_capacity = ctx->kcap;
   stats->refreshes = ctx->numberRefreshes;
   stats->refreshes_rejected = ctx->numberRefreshesRejected;

@@ -14,8 +14,8 @@
  *    remaining nucleus, product-form eta updates (replaceColumnPart3).  Because a slack column -e_i
  *    has a single entry, doing the slacks first leaves the other columns untouched, so this is
  *    arithmetically the dense factorization of the whole basis with the zero work skipped.
- *  - of statusOfProblemInDual: the "bad accuracy, treat as singular" restore (:5237-5318), the cost rescale after
- *    4(m+n) iterations (:5009-5021) and the Cbc-only branches are not restated; a singular refactorization ends
+ *  - of statusOfProblemInDual: the cost rescale after 4(m+n) iterations (:5009-5021), the pivot-tolerance changes
+ *    (this factorization has none) and the Cbc-only branches are not restated; a singular refactorization ends
  *    the solve with status 4 (the reference goes back to the saved basis).
  *  - nonbasic free columns are given "bothFake" bounds at start (the reference keeps them isFree and
  *    uses the general branch of dualColumn0).
@@ -107,6 +107,9 @@ struct OrcModel {
   unsigned char *saveStatus;      /* ClpSimplex::saveStatus_ / savedSolution_: the basis of the last good status check (:6160-6175) */
   double *savedSolution;
   int numberBackwards, numberLoopFlags; /* test hooks: times the "objective going backwards" restore ran, times looping() acted */
+  int debugBadAccuracyAt;         /* fault injection (option "debug_bad_accuracy_at"): the first status check at or after this iteration
+                                     finds largestPrimalError_ = 1e16; -1 off */
+  int numberAccuracyRestores;     /* test hook: times the "bad accuracy, treat as singular" restore ran (:5237-5318) */
   int debugBackwardsAt;           /* fault injection (option "debug_backwards_at"): pretend the objective dropped at the first status
                                      check at or after this iteration; -1 off */
   int cycIn[ORC_CYCLE], cycOut[ORC_CYCLE]; /* ClpSimplexProgress in_ / out_ / way_ */
@@ -242,6 +245,7 @@ OrcModel *orc_create(int m, int n, const int *colStart, const int *row, const do
   M->maximumPivots = 200; /* CoinAbcBaseFactorization1.cpp:142 default */
   M->seed = 1234567u;     /* src/ClpModel.cpp:149 */
   M->debugBackwardsAt = -1;
+  M->debugBadAccuracyAt = -1;
   M->saveStatus = (unsigned char *)calloc((size_t)N + 1, 1);
   M->savedSolution = DALLOC(N);
   M->costCopy = DALLOC(N);
@@ -341,6 +345,7 @@ int orc_set_option(OrcModel *M, const char *name, double v)
   else if (!strcmp(name, "scaling")) M->scalingMode = (int)v;
   else if (!strcmp(name, "perturbation")) M->perturbationOption = (int)v;
   else if (!strcmp(name, "debug_backwards_at")) M->debugBackwardsAt = (int)v;
+  else if (!strcmp(name, "debug_bad_accuracy_at")) M->debugBadAccuracyAt = (int)v;
   else return -1;
   return 0;
 }
@@ -2808,6 +2813,46 @@ static void resetFakeBounds0(OrcModel *M)
   changeBounds(M, 3, NULL, &dummy);
 }
 
+/* ClpSimplexDual::resetFakeBounds(type > 0) :8487-8600: original bounds back, then every variable that carries a fake
+ * status gets the bound that status stands for again (and the value that goes with its nonbasic status) */
+static void resetFakeBounds1(OrcModel *M)
+{
+  const int N = M->m + M->n;
+  for (int i = 0; i < N; i++) {
+    M->lower[i] = originalLower(M, i);
+    M->upper[i] = originalUpper(M, i);
+  }
+  M->numberFake = 0;
+  for (int i = 0; i < N; i++) {
+    const int fakeStatus = getFake(M, i);
+    if (fakeStatus == FAKE_NONE)
+      continue;
+    const int st = getStatus(M, i);
+    if (st == ST_BASIC || st == ST_FIXED) {
+      setFake(M, i, FAKE_NONE);
+      continue;
+    }
+    const double lowerValue = M->lower[i], upperValue = M->upper[i], value = M->sol[i];
+    M->numberFake++;
+    if (fakeStatus == FAKE_UPPER) {
+      M->upper[i] = lowerValue + M->dualBound;
+      M->sol[i] = (st == ST_LOWER) ? lowerValue : M->upper[i];
+    } else if (fakeStatus == FAKE_LOWER) {
+      M->lower[i] = upperValue - M->dualBound;
+      M->sol[i] = (st == ST_LOWER) ? M->lower[i] : upperValue;
+    } else if (st == ST_LOWER) {
+      M->lower[i] = value;
+      M->upper[i] = value + M->dualBound;
+    } else if (st == ST_UPPER) {
+      M->upper[i] = value;
+      M->lower[i] = value - M->dualBound;
+    } else { /* isFree / superBasic */
+      M->lower[i] = value - 0.5 * M->dualBound;
+      M->upper[i] = value + 0.5 * M->dualBound;
+    }
+  }
+}
+
 /* ClpDualRowSteepest::looksOptimal (src/ClpDualRowSteepest.cpp:1070); the base class (Dantzig) says no */
 static int looksOptimal(const OrcModel *M)
 {
@@ -2872,6 +2917,45 @@ static void statusOfProblemInDual(OrcModel *M, int *lastCleaned, int type)
   if (type)
     gutsOfSolution(M);
   int unflagVariables = 1, reallyBadProblems = 0;
+  if (M->debugBadAccuracyAt >= 0 && M->numberIterations >= M->debugBadAccuracyAt && M->numberIterations > 0) {
+    M->largestPrimalError = 1.0e16; /* fault injection */
+    M->debugBadAccuracyAt = -1;
+  }
+  if ((M->largestPrimalError > 1.0e15 || M->largestDualError > 1.0e15) && M->numberIterations) {
+    /* bad accuracy: treat as singular -- back to the previous basis, reject a variable (:5237-5318) */
+    M->numberAccuracyRestores++;
+    unflagVariables = 0;
+    for (int i = 0; i < m + M->n; i++)
+      if (flagged(M, i))
+        M->saveStatus[i] |= FLAGGED_BIT; /* keep any flagged variables */
+    memcpy(M->status, M->saveStatus, (size_t)(m + M->n));
+    memcpy(M->sol, M->savedSolution, sizeof(double) * (size_t)(m + M->n));
+    resetFakeBounds1(M); /* get correct bounds on all variables */
+    int rejectedVariable = M->sequenceOut;
+    if (rejectedVariable < 0 || flagged(M, rejectedVariable)) {
+      rejectedVariable = -1;
+      for (int i = 0; i < m; i++) {
+        int iSequence = M->pivotVariable[i];
+        if (!flagged(M, iSequence)) {
+          rejectedVariable = iSequence;
+          break;
+        }
+      }
+      if (rejectedVariable < 0) {
+        M->problemStatus = 10; /* real trouble */
+        return;
+      }
+    }
+    setFlagged(M, rejectedVariable);
+    progressClearBadTimes(M);
+    M->forceFactorization = 1; /* a bit drastic but .. */
+    type = 2;
+    if (factorize(M)) {
+      M->problemStatus = 4;
+      return;
+    }
+    gutsOfSolution(M);
+  }
   if (progressLastIteration(M, 0) == M->numberIterations) {
     /* double check infeasibility if no action (:5326-5330) */
     if (looksOptimal(M)) {
@@ -3219,7 +3303,7 @@ static int dualOnRim(OrcModel *M)
   progressReset(M); /* ClpSimplex::saveData -> progress_.fillFromModel, src/ClpSimplex.cpp:9732 */
   M->progressFlag = 0; /* :461 */
   M->bestPossibleImprovement = 0.0;
-  M->numberBackwards = M->numberLoopFlags = 0;
+  M->numberBackwards = M->numberLoopFlags = M->numberAccuracyRestores = 0;
   for (int i = 0; i < ORC_CYCLE; i++) { /* progress_.startCheck(), ClpSimplexDual.cpp:452 */
     M->cycIn[i] = M->cycOut[i] = -1;
     M->cycWay[i] = 0;
@@ -3656,6 +3740,7 @@ int orc_number_refactorizations(const OrcModel *M) { return M->numberRefactoriza
 int orc_number_perturbations(const OrcModel *M) { return M->numberPerturbations; }
 int orc_number_backwards(const OrcModel *M) { return M->numberBackwards; }
 int orc_number_loop_flags(const OrcModel *M) { return M->numberLoopFlags; }
+int orc_number_accuracy_restores(const OrcModel *M) { return M->numberAccuracyRestores; }
 double orc_iteration_seconds(const OrcModel *M) { return M->seconds; }
 void orc_get_solution(const OrcModel *M, double *s) { memcpy(s, M->sol, sizeof(double) * (size_t)(M->m + M->n)); }
 void orc_get_reduced_costs(const OrcModel *M, double *d) { memcpy(d, M->dj, sizeof(double) * (size_t)(M->m + M->n)); }

@@ -63,3 +63,20 @@ def test_no_restore_and_no_loop_flag_on_a_healthy_solve(gpu_cls):
     st = g.stats()
     assert st["backwards_restores"] == 0 and st["loop_flags"] == 0 and o.backwards == 0 and o.loop_flags == 0
     assert np.array_equal(g.pivotLog()["sequenceIn"], o.pivot_log()["sequenceIn"])
+
+
+@pytest.mark.parametrize("rule", [0, 1])
+@pytest.mark.parametrize("maker,args,at", [("sparse_lp", (300, 1200, 8, 11), 300), ("netlib_shaped_lp", (400, 1500, 9000, 3), 250)])
+def test_bad_accuracy_restore_identical_pivot_sequence(gpu_cls, maker, args, at, rule):
+    """Errors beyond 1e15 after a refactorization are treated as a singular basis (src/ClpSimplexDual.cpp:5237-5318): previous
+    basis back, the leaving variable flagged, a refactorization after every pivot.  Fault injection on both sides (option
+    debug_bad_accuracy_at); from there on the engine has to make the oracle's pivots."""
+    lp = getattr(P, maker)(*args)
+    g, sg, o, so = both(gpu_cls, lp, rule, debug_bad_accuracy_at=at)
+    assert sg == so == 0
+    assert g.stats()["accuracy_restores"] == o.accuracy_restores == 1
+    lg, lo = g.pivotLog(), o.pivot_log()
+    assert len(lg) == len(lo)
+    assert np.array_equal(lg["sequenceIn"], lo["sequenceIn"]) and np.array_equal(lg["sequenceOut"], lo["sequenceOut"])
+    assert g.stats()["refactorizations"] == o.refactorizations
+    assert abs(g.objectiveValue() - o.objective) <= RTOL * (1 + abs(o.objective))

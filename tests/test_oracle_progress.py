@@ -39,3 +39,18 @@ def test_progress_machinery_is_inert_on_healthy_solves():
     for n, rule, expected in [(8, 0, 91), (8, 1, 73), (20, 0, 553), (20, 1, 572)]:
         o, s = solve(P.nqueens(n), rule)
         assert s == 0 and o.iterations == expected and o.backwards == 0 and o.loop_flags == 0
+
+
+@pytest.mark.parametrize("rule", [0, 1])
+@pytest.mark.parametrize("maker,args,at", [("sparse_lp", (300, 1200, 8, 11), 300), ("nqueens", (20,), 200)])
+def test_bad_accuracy_restore_rejects_a_variable_and_still_finishes(maker, args, at, rule):
+    """:5237-5318 through fault injection (option debug_bad_accuracy_at): the basis of the last good check comes back, the leaving
+    variable is flagged, every pivot is followed by a refactorization for a while; the optimum is the undisturbed one."""
+    lp = getattr(P, maker)(*args)
+    plain, s0 = solve(lp, rule)
+    hurt, s1 = solve(lp, rule, debug_bad_accuracy_at=at)
+    assert s0 == s1 == 0 and plain.accuracy_restores == 0 and hurt.accuracy_restores == 1
+    assert abs(plain.objective - hurt.objective) <= 1e-9 * (1 + abs(plain.objective))
+    a, b = plain.pivot_log()["sequenceIn"], hurt.pivot_log()["sequenceIn"]
+    assert np.array_equal(a[:at], b[:at])
+    assert hurt.refactorizations > plain.refactorizations + 5
