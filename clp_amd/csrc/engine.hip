@@ -161,6 +161,7 @@ struct clpgpu_context {
   int debugBackwardsAt = -1;  // fault injection (option debug_backwards_at), as in the oracle
   int debugPoisonInverseAt = -1, numberPoisoned = 0;  // fault injection (option debug_poison_inverse_at)
   int debugBadAccuracyAt = -1, numberAccuracyRestores = 0;  // fault injection (option debug_bad_accuracy_at) and its count
+  int debugSingularAt = -1, numberSingularRestores = 0;     // fault injection (option debug_singular_at) and the count of such restores
   void progressReset();
   void progressStartCheck();
   int progressLooping();
@@ -2317,7 +2318,7 @@ int clpgpu_context::startup()
   progressReset();  // ClpSimplex::saveData -> progress_.fillFromModel (src/ClpSimplex.cpp:9732)
   progressFlag = 0;  // :461
   bestPossibleImprovement = 0.0;
-  numberBackwards = numberLoopFlags = numberAccuracyRestores = 0;
+  numberBackwards = numberLoopFlags = numberAccuracyRestores = numberSingularRestores = 0;
   forceFactorization = -1;
   lastBadIteration = -999999;
   lastCleaned = 0;
@@ -2560,6 +2561,7 @@ int clpgpu_context::statusOfProblemInDual(int type)
   int tentativeStatus = problemStatus;
   bool weightsSaved = false;
   bool gutsDone = false;  // a verified refresh has already recomputed the solutions
+  bool unflagVariables = true, reallyBadProblems = false;
   double changeCost = 0.0;
   if (problemStatus > -3 || numberPivots > 0) {
     rc |= saveWeights(1);
@@ -2594,11 +2596,17 @@ int clpgpu_context::statusOfProblemInDual(int type)
       rc |= pullRim(true);
       int frc = factorize(false);
       consecutiveRefreshes = 0;
+      if (!frc && debugSingularAt >= 0 && numberIterations >= debugSingularAt && numberIterations > 0) {
+        frc = -1;  // fault injection (option debug_singular_at): this refactorization is taken as singular
+        debugSingularAt = -1;
+      }
       if (frc == -1) {
         // singular (ClpSimplexDual.cpp:5060-5125): back to the basis of the last good factorization with
         // the leaving variable flagged and a refactorization forced after every pivot; if that basis is
         // singular too, the repaired basis (dependent structurals out, slacks in)
         if (haveSnapshot) {
+          numberSingularRestores++;
+          unflagVariables = false;
           for (int i = 0; i < N; i++)
             if (status[i] & FLAGGED_BIT)
               saveStatus[i] |= FLAGGED_BIT;
@@ -2607,6 +2615,7 @@ int clpgpu_context::statusOfProblemInDual(int type)
           resetFakeBounds();
           if (hCtrl->sequenceOut >= 0 && hCtrl->sequenceOut < N)
             status[hCtrl->sequenceOut] |= FLAGGED_BIT;
+          progBadTimes = 0;  // progress_.clearBadTimes()
           forceFactorization = 1;
           rebuildRowCopy = true;
           frc = factorize(false);
@@ -2658,7 +2667,6 @@ int clpgpu_context::statusOfProblemInDual(int type)
     checkPrimalSolution();  // the refresh recomputed the solutions before the tolerance moved
     checkDualSolution();
   }
-  bool unflagVariables = true, reallyBadProblems = false;
   if (debugBadAccuracyAt >= 0 && numberIterations >= debugBadAccuracyAt && numberIterations > 0) {
     largestPrimalError = 1.0e16;  // fault injection
     debugBadAccuracyAt = -1;
@@ -4657,6 +4665,7 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "debug_backwards_at")) ctx->debugBackwardsAt = (int)v;
   else if (!strcmp(name, "debug_poison_inverse_at")) ctx->debugPoisonInverseAt = (int)v;
   else if (!strcmp(name, "debug_bad_accuracy_at")) ctx->debugBadAccuracyAt = (int)v;
+  else if (!strcmp(name, "debug_singular_at")) ctx->debugSingularAt = (int)v;
   else if (!strcmp(name, "log_level")) ctx->logLevel = (int)v;
   else if (!strcmp(name, "check_every")) {
     ctx->checkEvery = (int)v < 1 ? 1 : (int)v;
@@ -5119,6 +5128,7 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
   stats->backwards_restores = ctx->numberBackwards;
   stats->loop_flags = ctx->numberLoopFlags;
   stats->accuracy_restores = ctx->numberAccuracyRestores;
+  stats->singular_restores = ctx->numberSingularRestores;
   stats->nucleus_capacity = ctx->kcap;
   stats->refreshes = ctx->numberRefreshes;
   stats->refreshes_rejected = ctx->numberRefreshesRejected;

@@ -33,7 +33,7 @@ class Stats(C.Structure):
                 ("lu_active", C.c_long), ("lu_front", C.c_long), ("lu_tail", C.c_long), ("lu_factorizations", C.c_long),
                 ("lu_front_ms", C.c_double), ("lu_invert_ms", C.c_double), ("lu_build_ms", C.c_double), ("eta_count", C.c_long),
                 ("perturbations", C.c_long), ("backwards_restores", C.c_long), ("loop_flags", C.c_long),
-                ("accuracy_restores", C.c_long)]
+                ("accuracy_restores", C.c_long), ("singular_restores", C.c_long)]
 
 
 # every symbol include/clpgpu.h declares (tests/test_abi.py checks the library exports all of them)

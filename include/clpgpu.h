@@ -68,6 +68,7 @@ typedef struct {
   long backwards_restores; /* times statusOfProblemInDual went back to the last good basis because the objective fell (:5395-5476) */
   long loop_flags;         /* times ClpSimplexProgress::looping found a repeat over status checks and acted (ClpSolve.cpp:4553) */
   long accuracy_restores;  /* times errors beyond 1e15 sent statusOfProblemInDual back to the last good basis (:5237-5318) */
+  long singular_restores;  /* times a singular refactorization did (:5060-5125) */
 } clpgpu_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------- */
@@ -223,7 +224,8 @@ int clpgpu_unroll_weights(clpgpu_context *ctx);
  * refinement of the recomputed primal and dual solutions), "price_tiles" (1: pricing with pi tiles staged in LDS).
  * Fault injection for the tests: "debug_backwards_at" (the first two status checks at or after this iteration see the
  * objective fall: drives the restore of src/ClpSimplexDual.cpp:5326-5488), "debug_bad_accuracy_at" (the first status
- * check at or after this iteration finds a primal error of 1e16: the restore of :5237-5318), "debug_poison_inverse_at"
+ * check at or after this iteration finds a primal error of 1e16: the restore of :5237-5318), "debug_singular_at" (the
+ * refactorization of that check is taken as singular: the restore of :5060-5125), "debug_poison_inverse_at"
  * (a NaN in the kept inverse right before the next verified refresh). */
 int clpgpu_set_option(clpgpu_context *ctx, const char *name, double value);
 /* Whole-array replacement of bounds / costs with the matrix left resident

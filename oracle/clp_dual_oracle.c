@@ -15,8 +15,9 @@
  *    has a single entry, doing the slacks first leaves the other columns untouched, so this is
  *    arithmetically the dense factorization of the whole basis with the zero work skipped.
  *  - of statusOfProblemInDual: the cost rescale after 4(m+n) iterations (:5009-5021), the pivot-tolerance changes
- *    (this factorization has none) and the Cbc-only branches are not restated; a singular refactorization ends
- *    the solve with status 4 (the reference goes back to the saved basis).
+ *    (this factorization has none) and the Cbc-only branches are not restated; when the basis a singular
+ *    refactorization falls back to is singular too the solve ends with status 4 (the reference factorizes "safely"
+ *    with slacks put in, :5100-5117).
  *  - nonbasic free columns are given "bothFake" bounds at start (the reference keeps them isFree and
  *    uses the general branch of dualColumn0).
  *  - CoinThreadRandom lives in CoinUtils (absent); the 32-bit LCG form is used [unverifiable here].
@@ -107,6 +108,9 @@ struct OrcModel {
   unsigned char *saveStatus;      /* ClpSimplex::saveStatus_ / savedSolution_: the basis of the last good status check (:6160-6175) */
   double *savedSolution;
   int numberBackwards, numberLoopFlags; /* test hooks: times the "objective going backwards" restore ran, times looping() acted */
+  int debugSingularAt;            /* fault injection (option "debug_singular_at"): the refactorization of the first status check at or after
+                                     this iteration is taken as singular; -1 off */
+  int numberSingularRestores;     /* test hook: times a singular refactorization sent the solve back to the saved basis (:5060-5125) */
   int debugBadAccuracyAt;         /* fault injection (option "debug_bad_accuracy_at"): the first status check at or after this iteration
                                      finds largestPrimalError_ = 1e16; -1 off */
   int numberAccuracyRestores;     /* test hook: times the "bad accuracy, treat as singular" restore ran (:5237-5318) */
@@ -246,6 +250,7 @@ OrcModel *orc_create(int m, int n, const int *colStart, const int *row, const do
   M->seed = 1234567u;     /* src/ClpModel.cpp:149 */
   M->debugBackwardsAt = -1;
   M->debugBadAccuracyAt = -1;
+  M->debugSingularAt = -1;
   M->saveStatus = (unsigned char *)calloc((size_t)N + 1, 1);
   M->savedSolution = DALLOC(N);
   M->costCopy = DALLOC(N);
@@ -346,6 +351,7 @@ int orc_set_option(OrcModel *M, const char *name, double v)
   else if (!strcmp(name, "perturbation")) M->perturbationOption = (int)v;
   else if (!strcmp(name, "debug_backwards_at")) M->debugBackwardsAt = (int)v;
   else if (!strcmp(name, "debug_bad_accuracy_at")) M->debugBadAccuracyAt = (int)v;
+  else if (!strcmp(name, "debug_singular_at")) M->debugSingularAt = (int)v;
   else return -1;
   return 0;
 }
@@ -2880,15 +2886,35 @@ static void statusOfProblemInDual(OrcModel *M, int *lastCleaned, int type)
   int numberPivots = M->fac.nEta;
   int tentativeStatus = M->problemStatus;
   int weightsSaved = 0;
+  int unflagVariables = 1, reallyBadProblems = 0;
   double changeCost = 0.0;
   if (M->problemStatus > -3 || numberPivots > 0) {
     saveWeights(M, 1);
     weightsSaved = 1;
     if (type) {
       int rc = factorize(M);
+      if (!rc && M->debugSingularAt >= 0 && M->numberIterations >= M->debugSingularAt && M->numberIterations > 0) {
+        rc = 1; /* fault injection */
+        M->debugSingularAt = -1;
+      }
       if (rc) {
-        M->problemStatus = 4; /* singular basis: the reference restores the previous basis and flags */
-        return;
+        /* is factorization okay?  no - restore previous basis (:5061-5125) */
+        M->numberSingularRestores++;
+        unflagVariables = 0;
+        for (int i = 0; i < m + M->n; i++)
+          if (flagged(M, i))
+            M->saveStatus[i] |= FLAGGED_BIT; /* keep any flagged variables */
+        memcpy(M->status, M->saveStatus, (size_t)(m + M->n));
+        memcpy(M->sol, M->savedSolution, sizeof(double) * (size_t)(m + M->n));
+        resetFakeBounds1(M); /* get correct bounds on all variables */
+        setFlagged(M, M->sequenceOut); /* need to reject something */
+        progressClearBadTimes(M);
+        M->forceFactorization = 1; /* a bit drastic but .. */
+        type = 2;
+        if (factorize(M)) {
+          M->problemStatus = 4; /* the saved basis is singular too: the reference goes on to a safe factorization with slacks */
+          return;
+        }
       }
     }
     if (M->problemStatus != -4 || numberPivots > 10)
@@ -2916,7 +2942,6 @@ static void statusOfProblemInDual(OrcModel *M, int *lastCleaned, int type)
   }
   if (type)
     gutsOfSolution(M);
-  int unflagVariables = 1, reallyBadProblems = 0;
   if (M->debugBadAccuracyAt >= 0 && M->numberIterations >= M->debugBadAccuracyAt && M->numberIterations > 0) {
     M->largestPrimalError = 1.0e16; /* fault injection */
     M->debugBadAccuracyAt = -1;
@@ -3303,7 +3328,7 @@ static int dualOnRim(OrcModel *M)
   progressReset(M); /* ClpSimplex::saveData -> progress_.fillFromModel, src/ClpSimplex.cpp:9732 */
   M->progressFlag = 0; /* :461 */
   M->bestPossibleImprovement = 0.0;
-  M->numberBackwards = M->numberLoopFlags = M->numberAccuracyRestores = 0;
+  M->numberBackwards = M->numberLoopFlags = M->numberAccuracyRestores = M->numberSingularRestores = 0;
   for (int i = 0; i < ORC_CYCLE; i++) { /* progress_.startCheck(), ClpSimplexDual.cpp:452 */
     M->cycIn[i] = M->cycOut[i] = -1;
     M->cycWay[i] = 0;
@@ -3741,6 +3766,7 @@ int orc_number_perturbations(const OrcModel *M) { return M->numberPerturbations;
 int orc_number_backwards(const OrcModel *M) { return M->numberBackwards; }
 int orc_number_loop_flags(const OrcModel *M) { return M->numberLoopFlags; }
 int orc_number_accuracy_restores(const OrcModel *M) { return M->numberAccuracyRestores; }
+int orc_number_singular_restores(const OrcModel *M) { return M->numberSingularRestores; }
 double orc_iteration_seconds(const OrcModel *M) { return M->seconds; }
 void orc_get_solution(const OrcModel *M, double *s) { memcpy(s, M->sol, sizeof(double) * (size_t)(M->m + M->n)); }
 void orc_get_reduced_costs(const OrcModel *M, double *d) { memcpy(d, M->dj, sizeof(double) * (size_t)(M->m + M->n)); }

@@ -83,6 +83,8 @@ int orc_number_backwards(const OrcModel *model);
 int orc_number_loop_flags(const OrcModel *model);
 /* ... and times the "bad accuracy, treat as singular" restore ran (:5237-5318) */
 int orc_number_accuracy_restores(const OrcModel *model);
+/* ... and times a singular refactorization sent the solve back to the saved basis (:5060-5125) */
+int orc_number_singular_restores(const OrcModel *model);
 /* copies n+m doubles, [columns | rows] */
 void orc_get_solution(const OrcModel *model, double *solution);
 void orc_get_reduced_costs(const OrcModel *model, double *dj);

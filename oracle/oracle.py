@@ -55,6 +55,7 @@ def lib():
         L.orc_number_backwards.argtypes = [p]
         L.orc_number_loop_flags.argtypes = [p]
         L.orc_number_accuracy_restores.argtypes = [p]
+        L.orc_number_singular_restores.argtypes = [p]
         L.orc_test_perturb.argtypes = [p, C.c_int, C.c_int, up, dp]
         L.orc_objective_value.argtypes = [p]
         L.orc_objective_value.restype = C.c_double
@@ -124,6 +125,10 @@ class OracleSimplex:
     @property
     def backwards(self):
         return lib().orc_number_backwards(self._h)
+
+    @property
+    def singular_restores(self):
+        return lib().orc_number_singular_restores(self._h)
 
     @property
     def accuracy_restores(self):

@@ -80,3 +80,19 @@ def test_bad_accuracy_restore_identical_pivot_sequence(gpu_cls, maker, args, at,
     assert np.array_equal(lg["sequenceIn"], lo["sequenceIn"]) and np.array_equal(lg["sequenceOut"], lo["sequenceOut"])
     assert g.stats()["refactorizations"] == o.refactorizations
     assert abs(g.objectiveValue() - o.objective) <= RTOL * (1 + abs(o.objective))
+
+
+@pytest.mark.parametrize("rule", [0, 1])
+def test_singular_refactorization_restore_identical_pivot_sequence(gpu_cls, rule):
+    """A refactorization that comes out singular in the middle of a solve (src/ClpSimplexDual.cpp:5060-5125): previous basis back
+    with the flagged variables kept, the leaving variable flagged, a refactorization after every pivot.  Fault injection on both
+    sides (option debug_singular_at: the refactorization itself succeeds and is taken as singular)."""
+    lp = P.sparse_lp(300, 1200, 8, 11)
+    g, sg, o, so = both(gpu_cls, lp, rule, debug_singular_at=300)
+    assert sg == so == 0
+    assert g.stats()["singular_restores"] == o.singular_restores == 1
+    lg, lo = g.pivotLog(), o.pivot_log()
+    assert len(lg) == len(lo)
+    assert np.array_equal(lg["sequenceIn"], lo["sequenceIn"]) and np.array_equal(lg["sequenceOut"], lo["sequenceOut"])
+    assert g.stats()["refactorizations"] == o.refactorizations
+    assert abs(g.objectiveValue() - o.objective) <= RTOL * (1 + abs(o.objective))

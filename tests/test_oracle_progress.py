@@ -54,3 +54,15 @@ def test_bad_accuracy_restore_rejects_a_variable_and_still_finishes(maker, args,
     a, b = plain.pivot_log()["sequenceIn"], hurt.pivot_log()["sequenceIn"]
     assert np.array_equal(a[:at], b[:at])
     assert hurt.refactorizations > plain.refactorizations + 5
+
+
+@pytest.mark.parametrize("rule", [0, 1])
+def test_singular_refactorization_goes_back_to_the_saved_basis(rule):
+    """:5060-5125 through fault injection (option debug_singular_at)."""
+    lp = P.sparse_lp(300, 1200, 8, 11)
+    plain, s0 = solve(lp, rule)
+    hurt, s1 = solve(lp, rule, debug_singular_at=300)
+    assert s0 == s1 == 0 and plain.singular_restores == 0 and hurt.singular_restores == 1
+    assert abs(plain.objective - hurt.objective) <= 1e-9 * (1 + abs(plain.objective))
+    assert np.array_equal(plain.pivot_log()["sequenceIn"][:300], hurt.pivot_log()["sequenceIn"][:300])
+    assert hurt.refactorizations > plain.refactorizations + 5
