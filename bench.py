@@ -366,6 +366,9 @@ def main():
                          # the dual objective is a lower bound on the optimum and must not fall (cost shifting aside): checked per window
                          "dual_objective_monotone": bool(all(b >= a - 1e-9 * abs(a) for a, b in zip(objs, objs[1:]))),
                          "dual_objective_first_last": [objs[0], objs[-1]],
+                         # what the solve gains, next to how fast it pivots: on this LP the two do not go together
+                         "dual_objective_gain_per_s": (round((objs[-1] - objs[0]) / max(sum(c["seconds"] for c in chunks[1:]), 1e-9), 3)
+                                                       if len(chunks) > 1 else None),
                          "mature": pick[-1]["iterations_per_s"],
                          "note": "wall clock around clpgpu_dual_steps(2000) on the live solve, refactorizations (host Markowitz front + dense tail "
                                  "inversion) included; `mature` = the last window reached within the budget"}
