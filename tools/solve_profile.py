@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--budget", type=float, default=120.0)
     ap.add_argument("--chunk", type=int, default=1000)
     ap.add_argument("--opts", default="")
+    ap.add_argument("--theta-stats", action="store_true",
+                    help="per chunk, from the pivot log: share of pivots with a dual step below 1e-9, mean bound flips per pivot (DESIGN 8, item 0)")
     args = ap.parse_args()
     import torch  # noqa: F401
 
@@ -50,7 +52,13 @@ def main():
         now = time.perf_counter()
         st = g.stats()
         it = g.numberIterations()
-        print(json.dumps({"iterations": it, "elapsed_s": round(now - t0, 3), "chunk_it_per_s": round((it - last_it) / max(now - last_t, 1e-9), 1),
+        extra = {}
+        if args.theta_stats and it > last_it:
+            part = g.pivotLog()[last_it:it]  # the log holds 2^20 pivots
+            if len(part):
+                extra = {"tiny_step_share": round(float((abs(part["theta"]) < 1.0e-9).mean()), 4),
+                         "flips_per_pivot": round(float(part["numberFlipped"].mean()), 2)}
+        print(json.dumps({**extra, "iterations": it, "elapsed_s": round(now - t0, 3), "chunk_it_per_s": round((it - last_it) / max(now - last_t, 1e-9), 1),
                           "nucleus": st["nucleus"], "capacity": st["nucleus_capacity"], "refactorizations": st["refactorizations"],
                           "refreshes": st["refreshes"], "refreshes_rejected": st["refreshes_rejected"], "lu": [st["lu_active"], st["lu_front"], st["lu_tail"], st["lu_factorizations"], round(st["lu_front_ms"]), round(st["lu_invert_ms"]), round(st["lu_build_ms"])],
                           "objective": g.objectiveValue(), "status": status}), flush=True)
