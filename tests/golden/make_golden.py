@@ -12,6 +12,8 @@ DOES pin is asserted directly in tests/test_oracle_golden.py (objective values, 
   hello_lp.npz      : BASELINE config 1 (examples/hello.mps of the reference, 21 x 53, the plumbing
                       case) as parsed arrays -- written only where /root/reference exists; the
                       reference pins no objective for it, the stored optimum is HiGHS' and the oracle's
+  modified_afiro_lp.npz : the reference's other input fixture, examples/modified_afiro.mps (7 x 16 piecewise
+                      variant of AFIRO read by examples/piecewise.cpp:20), the same way
 """
 import json
 import os
@@ -54,22 +56,27 @@ def main():
 
 
 def hello():
-    src = "/root/reference/examples/hello.mps"
-    if not os.path.exists(src):
-        return
-    from scipy.optimize import linprog
-    import scipy.sparse as sp
+    # the two input fixtures the reference carries under examples/: hello.mps (read by hello.cpp:24) and
+    # modified_afiro.mps (a 7 x 16 piecewise variant of AFIRO, read by piecewise.cpp:20)
+    for name, out in (("hello.mps", "hello_lp.npz"), ("modified_afiro.mps", "modified_afiro_lp.npz")):
+        src = os.path.join("/root/reference/examples", name)
+        if not os.path.exists(src):
+            continue
+        from scipy.optimize import linprog
+        import scipy.sparse as sp
 
-    lp = read_mps(src)
-    o = OracleSimplex(lp)
-    assert o.dual() == 0
-    A = sp.csc_matrix((lp.elem, lp.row, lp.col_start), shape=(lp.m, lp.n))
-    r = linprog(lp.obj, A_ub=sp.vstack([A, -A]), b_ub=np.concatenate([lp.row_upper, -lp.row_lower]),
-                bounds=list(zip(lp.col_lower, lp.col_upper)), method="highs")
-    assert r.status == 0 and abs(r.fun - o.objective) < 1e-9
-    np.savez_compressed(os.path.join(HERE, "hello_lp.npz"), m=lp.m, n=lp.n, col_start=lp.col_start, row=lp.row, elem=lp.elem,
-                        col_lower=lp.col_lower, col_upper=lp.col_upper, obj=lp.obj, row_lower=lp.row_lower,
-                        row_upper=lp.row_upper, optimum=r.fun)
+        lp = read_mps(src)
+        o = OracleSimplex(lp)
+        assert o.dual() == 0
+        A = sp.csc_matrix((lp.elem, lp.row, lp.col_start), shape=(lp.m, lp.n))
+        lo, up = np.where(lp.row_lower < -1e29, -np.inf, lp.row_lower), np.where(lp.row_upper > 1e29, np.inf, lp.row_upper)
+        keep_up, keep_lo = np.isfinite(up), np.isfinite(lo)
+        r = linprog(lp.obj, A_ub=sp.vstack([A[keep_up], -A[keep_lo]]), b_ub=np.concatenate([up[keep_up], -lo[keep_lo]]),
+                    bounds=[(None if a < -1e29 else a, None if b > 1e29 else b) for a, b in zip(lp.col_lower, lp.col_upper)], method="highs")
+        assert r.status == 0 and abs(r.fun - o.objective) < 1e-9 * (1 + abs(r.fun)), (name, r.fun, o.objective)
+        np.savez_compressed(os.path.join(HERE, out), m=lp.m, n=lp.n, col_start=lp.col_start, row=lp.row, elem=lp.elem,
+                            col_lower=lp.col_lower, col_upper=lp.col_upper, obj=lp.obj, row_lower=lp.row_lower,
+                            row_upper=lp.row_upper, optimum=r.fun)
 
 
 if __name__ == "__main__":

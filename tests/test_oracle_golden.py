@@ -74,6 +74,26 @@ def test_hello_plumbing_case(built):
     assert st == 0 and abs(obj - float(d["optimum"])) < 1e-9
 
 
+def test_modified_afiro_fixture(built):
+    """The reference's other input fixture, examples/modified_afiro.mps (7 x 16: the piecewise variant of AFIRO that
+    examples/piecewise.cpp:20 reads; not Netlib AFIRO), stored as parsed arrays by tests/golden/make_golden.py.  No expected
+    objective in the reference; HiGHS and the oracle agree on -484.2061685711 under both pivot rules."""
+    from clp_amd.mps import LpData
+
+    d = np.load(os.path.join(HERE, "golden", "modified_afiro_lp.npz"))
+    lp = LpData({k: (int(d[k]) if k in ("m", "n") else d[k]) for k in d.files if k != "optimum"})
+    lp["name"] = "modified_afiro"
+    assert (lp.m, lp.n, len(lp.elem)) == (7, 16, 40)
+    for rule in (0, 1):
+        o = OracleSimplex(lp)
+        o.set_option("pivot_rule", rule)
+        assert o.dual() == 0
+        assert abs(o.objective - float(d["optimum"])) < 1e-9 * abs(float(d["optimum"]))
+        kkt_check(lp, o)
+    st, obj = highs_objective(lp)
+    assert st == 0 and abs(obj - float(d["optimum"])) < 1e-9 * abs(obj)
+
+
 def test_afiro_pivot_log_matches_committed_golden(built, afiro):
     gold = json.load(open(os.path.join(HERE, "golden", "afiro_pivots.json")))
     for rule, name in ((0, "dantzig"), (1, "steepest")):
