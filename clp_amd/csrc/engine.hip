@@ -169,6 +169,7 @@ struct clpgpu_context {
   void resetFakeBoundsToOriginal();
   std::vector<double> perturbationArray;  // ClpSimplex::perturbationArray_: 2n uniform numbers, drawn once per problem
   bool started = false, needStatus = true, weightsInitialized = false;
+  bool rimInfeasible = false;  // ClpSimplex::sanityCheck found lower > upper at start-up: status 1 without a solve
   bool rebuildRowCopy = true;  // the device keeps the [basic|nonbasic] row partition current between refactorizations
   // basis / solution at the last good refactorization (ClpSimplex::saveStatus_, savedSolution_): what a
   // singular refactorization falls back to (ClpSimplexDual.cpp:5060-5125)
@@ -2268,6 +2269,31 @@ int clpgpu_context::startup()
   origUpper = upper;
   if (h2d(const_cast<double *>(D.origLower), origLower.data(), N) || h2d(const_cast<double *>(D.origUpper), origUpper.data(), N))
     return -99;
+  rimInfeasible = false;
+  {
+    // ClpSimplex::sanityCheck (src/ClpSimplex.cpp:7645-7790), the bound part, as createRim(63) runs it at start-up (:4270):
+    // bounds that cross by more than the primal tolerance make the problem infeasible before anything is solved (status 1,
+    // :7773-7780 -- what a branch that empties a variable's range looks like); bounds closer than the tolerance are made
+    // equal in the working copy (:7695-7700)
+    double fixTolerance = primalTolerance;
+    if (fixTolerance < 2.0e-8)
+      fixTolerance *= 1.1;
+    int numberBad = 0;
+    for (int i = 0; i < N; i++) {
+      const double gap = upper[i] - lower[i];
+      if (gap < -primalTolerance)
+        numberBad++;
+      else if (gap <= fixTolerance && gap != 0.0)
+        upper[i] = lower[i];
+    }
+    if (numberBad) {
+      rimInfeasible = true;
+      problemStatus = 1;
+      numberIterations = numberRefactorizations = 0;
+      objectiveValue = 0.0;
+      return 0;
+    }
+  }
   if (haveStatus) {
     status = userStatus;
   } else {
@@ -3571,6 +3597,8 @@ int clpgpu_context::whileIterating(int stepTarget)
 
 void clpgpu_context::finish()
 {
+  if (rimInfeasible)
+    return;  // start-up found crossing bounds: nothing was put on the device
   pullRim(true);
   if (problemStatus == 0 || problemStatus == 3 || problemStatus == 10) {  // 10: the point a primal clean-up would start from
     double objective = 0.0;

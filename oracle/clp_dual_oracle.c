@@ -3280,6 +3280,31 @@ static int dualOnRim(OrcModel *M)
     M->upper[n + i] = M->rowUpper[i];
     M->cost[n + i] = 0.0;
   }
+  {
+    /* ClpSimplex::sanityCheck (src/ClpSimplex.cpp:7645-7790), the bound part, as createRim(63) runs it at start-up (:4270):
+       bounds that cross by more than the primal tolerance make the problem infeasible before anything is solved (status 1,
+       :7773-7780); bounds closer than the tolerance are made equal (:7695-7700) */
+    double fixTolerance = M->primalTolerance;
+    if (fixTolerance < 2.0e-8)
+      fixTolerance *= 1.1;
+    int numberBad = 0;
+    for (int i = 0; i < N; i++) {
+      double value = M->upper[i] - M->lower[i];
+      if (value < -M->primalTolerance)
+        numberBad++;
+      else if (value <= fixTolerance && value)
+        M->upper[i] = M->lower[i];
+    }
+    if (numberBad) {
+      M->problemStatus = 1;
+      M->numberIterations = 0;
+      M->numberRefactorizations = 0;
+      M->logCount = 0;
+      M->objectiveValue = 0.0;
+      M->seconds = 0.0;
+      return 1;
+    }
+  }
   if (!M->haveStatus) {
     for (int i = 0; i < m; i++)
       M->status[n + i] = ST_BASIC;

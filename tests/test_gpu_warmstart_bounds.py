@@ -1,0 +1,50 @@
+"""GPU test of ClpSimplex::sanityCheck's bound part at start-up (src/ClpSimplex.cpp:7645-7790, run by createRim(63) :4270):
+bounds that cross by more than the primal tolerance make the problem infeasible before anything is solved -- what a branch that
+empties a variable's range looks like in branch and bound.  Engine and oracle: status 1, no iteration; the context stays usable."""
+import numpy as np
+import pytest
+
+from clp_amd import problems as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu_cls(built):
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from clp_amd.engine import ClpGpuSimplex
+
+    return ClpGpuSimplex
+
+
+def test_crossing_bounds_infeasible_then_restored(gpu_cls):
+    from oracle.oracle import OracleSimplex
+
+    lp = P.sparse_lp(300, 1200, 8, 11)
+    g = gpu_cls().loadProblem(lp)
+    assert g.dual() == 0
+    optimum, status = g.objectiveValue(), g.statusArray().copy()
+    crossed = lp.col_upper.copy()
+    crossed[7] = lp.col_lower[7] - 1.0  # the branch "x7 <= lower - 1"
+    g.chgColumnUpper(crossed)
+    g.setStatusArray(status)
+    assert g.dual() == 1 and g.numberIterations() == 0
+    lp2 = type(lp)(lp)
+    lp2.col_upper = crossed
+    o = OracleSimplex(lp2)
+    assert o.dual() == 1 and o.iterations == 0
+    # the bounds back: the same context solves again, warm, to the same optimum
+    g.chgColumnUpper(lp.col_upper)
+    g.setStatusArray(status)
+    assert g.dual() == 0
+    assert abs(g.objectiveValue() - optimum) <= 1e-9 * (1 + abs(optimum))
+
+
+def test_crossing_row_bounds_on_a_fresh_model(gpu_cls):
+    lp = P.sparse_lp(120, 500, 5, 2)
+    lp.row_lower = lp.row_lower.copy()
+    lp.row_lower[3] = lp.row_upper[3] + 0.5
+    g = gpu_cls().loadProblem(lp)
+    assert g.dual() == 1 and g.numberIterations() == 0
