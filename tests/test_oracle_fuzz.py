@@ -94,3 +94,41 @@ def test_crossing_bounds_are_infeasible_before_any_pivot():
     assert st in (0, 1, 2, 10)
     if st == 0:
         assert abs(o.solution()[j] - 1.0) <= 1e-12
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_warm_resolve_after_branching_agrees_with_highs(seed):
+    """The branch-and-bound pattern: solve, tighten the bounds of three columns around their values, re-solve from the optimal basis
+    (a branch may empty the feasible region: status 1 then)."""
+    rng = np.random.default_rng(9000 + seed)
+    lp = make(rng)
+    hs, _ = highs(lp)
+    if hs != 0:
+        pytest.skip("not solvable")
+    for rule in (0, 1):
+        o = OracleSimplex(lp)
+        o.set_option("pivot_rule", rule)
+        if o.dual() != 0:
+            continue
+        status, x = o.status().copy(), o.solution()
+        lp2 = type(lp)(lp)
+        cu, cl = lp.col_upper.copy(), lp.col_lower.copy()
+        for j in rng.choice(lp.n, min(3, lp.n), replace=False):
+            if rng.uniform() < 0.5:
+                if x[j] > 0.5:
+                    cu[j] = min(cu[j], np.floor(x[j]))
+            elif cl[j] > -1e29:
+                cl[j] = max(cl[j], np.ceil(x[j]))
+        lp2.col_upper, lp2.col_lower = cu, cl
+        hs2, hobj2 = highs(lp2)
+        for opts in ({}, {"perturbation": 100}, {"max_pivots": 3}):
+            o2 = OracleSimplex(lp2)
+            o2.set_option("pivot_rule", rule)
+            for k, v in opts.items():
+                o2.set_option(k, v)
+            o2.set_status(status & 7)
+            st = o2.dual()
+            if hs2 == 0:
+                assert st == 0 and abs(o2.objective - hobj2) <= 1e-6 * (1 + abs(hobj2)), (seed, rule, opts, st)
+            elif hs2 == 2:
+                assert st in (1, 2, 10), (seed, rule, opts, st)
