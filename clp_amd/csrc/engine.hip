@@ -3664,6 +3664,10 @@ int clpgpu_context::run(int maxSteps)
     needStatus = true;
   }
   finish();
+  // ClpSimplex::dual's own second thought (src/ClpSimplex.cpp:5800-5803): an "infeasible" reached with fake bounds active is
+  // "clean up in primal as fake bounds" -- status 10.  Not in fastDual / strong branching, which do not go through ClpSimplex::dual.
+  if (problemStatus == 1 && !rimInfeasible && !fastDualMode && numberAtFakeBound() > 0)
+    problemStatus = 10;
   auto t1 = std::chrono::steady_clock::now();
   seconds += std::chrono::duration<double>(t1 - t0).count();
   return problemStatus;

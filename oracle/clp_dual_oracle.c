@@ -108,6 +108,7 @@ struct OrcModel {
   unsigned char *saveStatus;      /* ClpSimplex::saveStatus_ / savedSolution_: the basis of the last good status check (:6160-6175) */
   double *savedSolution;
   int numberBackwards, numberLoopFlags; /* test hooks: times the "objective going backwards" restore ran, times looping() acted */
+  int rimInfeasible;              /* the start-up sanity check found crossing bounds: status 1 without a rim to look at */
   int debugSingularAt;            /* fault injection (option "debug_singular_at"): the refactorization of the first status check at or after
                                      this iteration is taken as singular; -1 off */
   int numberSingularRestores;     /* test hook: times a singular refactorization sent the solve back to the saved basis (:5060-5125) */
@@ -3295,6 +3296,7 @@ static int dualOnRim(OrcModel *M)
       else if (value <= fixTolerance && value)
         M->upper[i] = M->lower[i];
     }
+    M->rimInfeasible = numberBad > 0;
     if (numberBad) {
       M->problemStatus = 1;
       M->numberIterations = 0;
@@ -3634,7 +3636,19 @@ static void scaleBounds(double lowerValue, double upperValue, double multiplier,
   }
 }
 
+static int dualScaledOrNot(OrcModel *M);
+
+/* ClpSimplex::dual (src/ClpSimplex.cpp:5631): ClpSimplexDual::dual, then its own second thought about an "infeasible" that
+ * was reached with fake bounds active -- "clean up in primal as fake bounds" (:5800-5803): status 10, not 1 */
 int orc_dual(OrcModel *M)
+{
+  int status = dualScaledOrNot(M);
+  if (status == 1 && !M->rimInfeasible && numberAtFakeBound(M) > 0)
+    status = M->problemStatus = 10;
+  return status;
+}
+
+static int dualScaledOrNot(OrcModel *M)
 {
   const int m = M->m, n = M->n;
   M->scalingApplied = 0;
