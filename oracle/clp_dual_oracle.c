@@ -108,6 +108,7 @@ struct OrcModel {
   unsigned char *saveStatus;      /* ClpSimplex::saveStatus_ / savedSolution_: the basis of the last good status check (:6160-6175) */
   double *savedSolution;
   int numberBackwards, numberLoopFlags; /* test hooks: times the "objective going backwards" restore ran, times looping() acted */
+  int checkBoth;                  /* option "check_both": gutsOfSolution ends in checkBothSolutions (groundwork, default 0) */
   int rimInfeasible;              /* the start-up sanity check found crossing bounds: status 1 without a rim to look at */
   int debugSingularAt;            /* fault injection (option "debug_singular_at"): the refactorization of the first status check at or after
                                      this iteration is taken as singular; -1 off */
@@ -353,6 +354,7 @@ int orc_set_option(OrcModel *M, const char *name, double v)
   else if (!strcmp(name, "debug_backwards_at")) M->debugBackwardsAt = (int)v;
   else if (!strcmp(name, "debug_bad_accuracy_at")) M->debugBadAccuracyAt = (int)v;
   else if (!strcmp(name, "debug_singular_at")) M->debugSingularAt = (int)v;
+  else if (!strcmp(name, "check_both")) M->checkBoth = (int)v;
   else return -1;
   return 0;
 }
@@ -997,12 +999,87 @@ static void checkDualSolution(OrcModel *M)
   }
 }
 
+/* ClpSimplex::checkBothSolutions :3226-3440 (no free / superbasic bookkeeping: firstFree_ is not used on this path).  What
+ * gutsOfSolution ends in in this reference version (:762).  GROUNDWORK: only taken with option "check_both" 1 -- the default
+ * stays the checkPrimalSolution + checkDualSolution pair the HIP engine restates too, see DESIGN.md section 2 (first gap). */
+static void checkBothSolutions(OrcModel *M)
+{
+  const int N = M->m + M->n;
+  const double primalTolerance = M->primalTolerance, dualTolerance = M->dualTolerance;
+  M->objectiveValue = 0.0;
+  M->sumPrimalInfeasibilities = 0.0;
+  M->numberPrimalInfeasibilities = 0;
+  /* we can't really trust infeasibilities if there is primal / dual error */
+  const double relaxedToleranceP = primalTolerance + dmin(1.0e-2, dmax(M->largestPrimalError, 0.0 * primalTolerance));
+  const double relaxedToleranceD = dualTolerance + dmin(1.0e-2, dmax(M->largestDualError, 5.0 * dualTolerance));
+  const double possTolerance = 5.0 * relaxedToleranceD; /* allow bigger tolerance for possible improvement */
+  M->sumOfRelaxedPrimalInfeasibilities = 0.0;
+  M->sumDualInfeasibilities = 0.0;
+  M->numberDualInfeasibilities = 0;
+  M->sumOfRelaxedDualInfeasibilities = 0.0;
+  M->bestPossibleImprovement = 0.0;
+  for (int i = 0; i < N; i++) {
+    const double value = M->sol[i];
+    M->objectiveValue += value * M->cost[i];
+    const double distanceUp = M->upper[i] - value, distanceDown = value - M->lower[i];
+    if (distanceUp < -primalTolerance) {
+      const double infeasibility = -distanceUp;
+      M->sumPrimalInfeasibilities += infeasibility - primalTolerance;
+      if (infeasibility > relaxedToleranceP)
+        M->sumOfRelaxedPrimalInfeasibilities += infeasibility - relaxedToleranceP;
+      M->numberPrimalInfeasibilities++;
+    } else if (distanceDown < -primalTolerance) {
+      const double infeasibility = -distanceDown;
+      M->sumPrimalInfeasibilities += infeasibility - primalTolerance;
+      if (infeasibility > relaxedToleranceP)
+        M->sumOfRelaxedPrimalInfeasibilities += infeasibility - relaxedToleranceP;
+      M->numberPrimalInfeasibilities++;
+    } else if (getStatus(M, i) != ST_BASIC && !flagged(M, i)) {
+      /* feasible (so could be free) and not basic */
+      double djValue = M->dj[i];
+      if (distanceDown < primalTolerance) {
+        if (distanceUp > primalTolerance && djValue < -dualTolerance) {
+          M->sumDualInfeasibilities -= djValue + dualTolerance;
+          if (djValue < -possTolerance)
+            M->bestPossibleImprovement -= distanceUp * djValue;
+          if (djValue < -relaxedToleranceD)
+            M->sumOfRelaxedDualInfeasibilities -= djValue + relaxedToleranceD;
+          M->numberDualInfeasibilities++;
+        }
+      } else if (distanceUp < primalTolerance) {
+        if (djValue > dualTolerance) {
+          M->sumDualInfeasibilities += djValue - dualTolerance;
+          if (djValue > possTolerance)
+            M->bestPossibleImprovement += distanceDown * djValue;
+          if (djValue > relaxedToleranceD)
+            M->sumOfRelaxedDualInfeasibilities += djValue - relaxedToleranceD;
+          M->numberDualInfeasibilities++;
+        }
+      } else {
+        /* strictly between its bounds: may be free */
+        djValue *= 100.0;
+        if (fabs(djValue) > dualTolerance) {
+          M->sumDualInfeasibilities += fabs(djValue) - dualTolerance;
+          M->bestPossibleImprovement = 1.0e100;
+          M->numberDualInfeasibilities++;
+          if (fabs(djValue) > relaxedToleranceD)
+            M->sumOfRelaxedDualInfeasibilities += value - relaxedToleranceD; /* sic: `value`, :3358 */
+        }
+      }
+    }
+  }
+}
+
 static void gutsOfSolution(OrcModel *M)
 {
   computePrimals(M);
   computeDuals(M);
-  checkPrimalSolution(M);
-  checkDualSolution(M);
+  if (M->checkBoth) {
+    checkBothSolutions(M);
+  } else {
+    checkPrimalSolution(M);
+    checkDualSolution(M);
+  }
 }
 
 /* ------------------------------------------------------------------------------------------ */

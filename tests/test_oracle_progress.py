@@ -66,3 +66,23 @@ def test_singular_refactorization_goes_back_to_the_saved_basis(rule):
     assert abs(plain.objective - hurt.objective) <= 1e-9 * (1 + abs(plain.objective))
     assert np.array_equal(plain.pivot_log()["sequenceIn"][:300], hurt.pivot_log()["sequenceIn"][:300])
     assert hurt.refactorizations > plain.refactorizations + 5
+
+
+@pytest.mark.parametrize("rule", [0, 1])
+def test_check_both_solutions_groundwork_changes_no_solve_here(rule):
+    """ClpSimplex::checkBothSolutions (src/ClpSimplex.cpp:3226) is what gutsOfSolution ends in in the reference; both sides here restate
+    the checkPrimalSolution + checkDualSolution pair (first gap).  The oracle carries the newer function as option
+    "check_both" (groundwork for the switch): on the LPs of this suite it changes no pivot -- the two differ only at the edge of the
+    relaxed tolerances."""
+    from clp_amd.mps import read_mps
+    import os
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    lps = [read_mps(os.path.join(here, "golden", "afiro.mps")), P.nqueens(20), P.ufl(10, 30, 99), P.sparse_lp(300, 1200, 8, 11),
+           P.netlib_shaped_lp(400, 1500, 9000, 3)]
+    for lp in lps:
+        a, sa = solve(lp, rule)
+        b, sb = solve(lp, rule, check_both=1)
+        assert sa == sb == 0
+        assert np.array_equal(a.pivot_log()["sequenceIn"], b.pivot_log()["sequenceIn"])
+        assert abs(a.objective - b.objective) <= 1e-9 * (1 + abs(a.objective))
