@@ -12,6 +12,7 @@ DOES pin is asserted directly in tests/test_oracle_golden.py (objective values, 
   hello_lp.npz      : BASELINE config 1 (examples/hello.mps of the reference, 21 x 53, the plumbing
                       case) as parsed arrays -- written only where /root/reference exists; the
                       reference pins no objective for it, the stored optimum is HiGHS' and the oracle's
+  exmip1_lp.npz     : exmip1 rebuilt from the values the reference's OSI test asserts (see exmip1() below)
   modified_afiro_lp.npz : the reference's other input fixture, examples/modified_afiro.mps (7 x 16 piecewise
                       variant of AFIRO read by examples/piecewise.cpp:20), the same way
 """
@@ -79,5 +80,32 @@ def hello():
                             row_upper=lp.row_upper, optimum=r.fun)
 
 
+def exmip1():
+    """exmip1 (5 x 8) as the reference's own OSI test pins it -- test/OsiClpSolverInterfaceTest.cpp: matrix by row :203-258
+    (14 elements, starts, indices), objective :194-201, row senses / right-hand sides / ranges :396-415 (G 2.5, L 2.1, E 4.0,
+    R [1.8, 5.0], R [3.0, 15.0]), column bounds :170-173 (cl0 2.5, cl1 0, cu1 4.1, cu2 1.0), the objective of the initial point 3.5
+    (:191-192, which fixes cl4 = 0.5).  The bounds that test does not assert are those of the public Data/Sample exmip1.mps
+    (cu3 = 1, cu4 = 4.0, cu7 = 4.3).  LP optimum 3.2368421 (src/unitTest.cpp:2572)."""
+    from scipy.optimize import linprog
+    import scipy.sparse as sp
+
+    elements = [3.0, 1.0, -2.0, -1.0, -1.0, 2.0, 1.1, 1.0, 1.0, 2.8, -1.2, 5.6, 1.0, 1.9]
+    starts = [0, 5, 7, 9, 11, 14]
+    indices = [0, 1, 3, 4, 7, 1, 2, 2, 5, 3, 6, 0, 4, 7]
+    A = sp.csr_matrix((elements, indices, starts), shape=(5, 8)).tocsc()
+    A.sort_indices()
+    big = 1.0e30
+    lp = dict(m=5, n=8, col_start=A.indptr.astype(np.int32), row=A.indices.astype(np.int32), elem=A.data.astype(np.float64),
+              col_lower=np.array([2.5, 0, 0, 0, 0.5, 0, 0, 0.0]), col_upper=np.array([big, 4.1, 1.0, 1.0, 4.0, big, big, 4.3]),
+              obj=np.array([1.0, 0, 0, 0, 2.0, 0, 0, -1.0]), row_lower=np.array([2.5, -big, 4.0, 1.8, 3.0]),
+              row_upper=np.array([big, 2.1, 4.0, 5.0, 15.0]))
+    assert abs(float(lp["obj"] @ lp["col_lower"]) - 3.5) < 1e-12
+    r = linprog(lp["obj"], A_ub=sp.vstack([A[[1, 3, 4]], -A[[0, 3, 4]]]), b_ub=np.array([2.1, 5.0, 15.0, -2.5, -1.8, -3.0]), A_eq=A[[2]], b_eq=[4.0],
+                bounds=[(a, None if b > 1e29 else b) for a, b in zip(lp["col_lower"], lp["col_upper"])], method="highs")
+    assert r.status == 0 and abs(r.fun - 3.2368421) < 1e-6, r.fun
+    np.savez_compressed(os.path.join(HERE, "exmip1_lp.npz"), optimum=r.fun, **lp)
+
+
 if __name__ == "__main__":
     main()
+    exmip1()

@@ -94,6 +94,33 @@ def test_modified_afiro_fixture(built):
     assert st == 0 and abs(obj - float(d["optimum"])) < 1e-9 * abs(obj)
 
 
+def test_exmip1_as_the_reference_test_pins_it(built):
+    """exmip1 (5 x 8) rebuilt from what test/OsiClpSolverInterfaceTest.cpp asserts about it (matrix by row :203-258, objective
+    :194-201, row senses / right-hand sides / ranges :396-415, the column bounds of :170-173; tests/golden/make_golden.py::exmip1).
+    Pinned by the reference: the by-column image of the matrix (:342-355), the objective of the initial point (3.5, :191-192), the LP
+    optimum 3.2368421 (src/unitTest.cpp:2572), and "infeasible bounds": column 0 given the bounds [1, 0] is not proven optimal
+    (:675-686) -- the start-up sanity check of src/ClpSimplex.cpp:7773."""
+    from clp_amd.mps import LpData
+
+    d = np.load(os.path.join(HERE, "golden", "exmip1_lp.npz"))
+    lp = LpData({k: (int(d[k]) if k in ("m", "n") else d[k]) for k in d.files if k != "optimum"})
+    lp["name"] = "exmip1"
+    assert lp.elem.tolist() == [3.0, 5.6, 1.0, 2.0, 1.1, 1.0, -2.0, 2.8, -1.0, 1.0, 1.0, -1.2, -1.0, 1.9]  # getMatrixByCol :342-355
+    assert abs(float(lp.obj @ lp.col_lower) - 3.5) < 1e-12
+    for rule in (0, 1):
+        o = OracleSimplex(lp)
+        o.set_option("pivot_rule", rule)
+        assert o.dual() == 0
+        assert abs(o.objective - 3.2368421) < 1e-6 and abs(o.objective - float(d["optimum"])) < 1e-9
+        kkt_check(lp, o)
+        bad = LpData(lp)
+        bad.col_lower, bad.col_upper = lp.col_lower.copy(), lp.col_upper.copy()
+        bad.col_lower[0], bad.col_upper[0] = 1.0, 0.0
+        o = OracleSimplex(bad)
+        o.set_option("pivot_rule", rule)
+        assert o.dual() == 1 and o.iterations == 0
+
+
 def test_afiro_pivot_log_matches_committed_golden(built, afiro):
     gold = json.load(open(os.path.join(HERE, "golden", "afiro_pivots.json")))
     for rule, name in ((0, "dantzig"), (1, "steepest")):
