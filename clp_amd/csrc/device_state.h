@@ -84,6 +84,7 @@ struct Ctrl {
   int appendGo, flipDense;  // flipDense: this pivot's flip rhs is left to k_flip_dense
   int updGo[2], updK, updPad;  // basis-update branch: go flag per pivot parity, k at the time of the fork
   long long dbgDc[8];
+  int pendingState, pendingPad;  // stepped run: what housekeeping decided on the pivot the step limit stopped at (RUN or EXIT_REFACTOR); acted on when the run resumes
   int wsJ, wsCount;  // ratio test: breakpoint class prefix of the working set k_dc_working_set compacted, and its size (wsJ < 0: none)  // ratio test, working-set path: calls, ticks of the whole kernel, ticks before the passes start, max ticks of one call
   double tailAlpha, tailValueOut;  // w[pivotRow] / sol[sequenceOut] handed to the serial tail of k_ftran_scatter3  // this pivot's primal update completed: its list appends may be scattered  // unordered append count of k_dj_flags (ordered later by k_flip_apply2)
 };

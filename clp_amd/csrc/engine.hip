@@ -190,6 +190,7 @@ struct clpgpu_context {
   int refreshMinK = 6144, refreshMax = 15, consecutiveRefreshes = 0, numberRefreshes = 0, numberRefreshesRejected = 0;
   double refreshTolerance = 1.0e-6;
   int lastExitState = EXIT_REFACTOR;  // why the iteration loop last stopped (whileIterating)
+  bool stepPendingRefactor = false;   // a stepped run stopped on a pivot whose housekeeping asked for a refactorization
   bool refreshEligible();
   int refreshFactor();
   // option "refresh_refine" (default 1): before the check, one Newton-Schulz step X += X (I - C X) on the kept
@@ -232,6 +233,8 @@ struct clpgpu_context {
   // option "lu_adaptive" (default 1): the eta file's length follows the measured refactorization time
   int luAdaptive = 1, luMinPivots = 200, luEtaLimit = 1000;
   double luRefactorSeconds = 0.0;
+  int fakeBoundCleanup = 0;  // option "fake_bound_cleanup": status 1 with fake bounds active becomes 10 (ClpSimplex::dual :5800-5803)
+  int luFillSkip = 0, luFillSkipBelowK = 0;  // refactorizations that skip the LU attempt after a fill-cap fallback
   double luInverseFillCap = 6.0e6;  // option "lu_inverse_fill_cap"
   int luUploadTri(const LuTriHost &h, LuTri &d, int slot);
   int luFtran(const double *v0, const double *v1, double *o0, double *o1);
@@ -898,6 +901,8 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   rc |= buildSell();
   rc |= sync();
   started = false;
+  luFillSkip = 0;
+  stepPendingRefactor = false;
   return rc;
 }
 
@@ -1536,13 +1541,22 @@ int clpgpu_context::factorizeOnce()
   const int k = (int)kcol.size();
   numberRefactorizations++;
   // (column-sharded runs keep the explicit inverse: the LU chain has not been run with an exchange in it)
-  const bool wantLu = k > 0 && !commActive && (factorMode == 1 || (factorMode < 0 && !wideRows && k >= luMinK));
+  bool wantLu = k > 0 && !commActive && (factorMode == 1 || (factorMode < 0 && !wideRows && k >= luMinK));
+  // an LP whose front inverses exceeded lu_inverse_fill_cap (factorizeLu -> -7) is not asked again at every refactorization
+  // (the front, the tail inversion and the polish would all run before the cap is seen): the next few refactorizations at a
+  // similar nucleus size go straight to the explicit inverse
+  if (wantLu && luFillSkip > 0 && k < luFillSkipBelowK && factorMode < 0) {
+    luFillSkip--;
+    wantLu = false;
+  }
   if (wantLu != luActive)
     dropGraph();  // the chain of a pivot differs between the two forms
   if (wantLu) {
     const int lrc = factorizeLu(kcol, rrows, localOfRow);
     if (lrc != -7)
       return lrc;
+    luFillSkip = 8;
+    luFillSkipBelowK = k + k / 4 + 64;
     if (luActive)
       dropGraph();
   }
@@ -1711,6 +1725,15 @@ int clpgpu_context::gutsOfSolution()
       largest = worst(largest, part[b]);
     return r;
   };
+  // diagnostics (log_level >= 2): what the incremental updates of the last stretch had drifted to, against the resync below
+  std::vector<double> driftDj, driftSol;
+  const bool drift = logLevel > 1 && started && numberIterations > 0;
+  if (drift) {
+    driftDj.resize(N);
+    driftSol.resize(N);
+    rc |= d2h(driftDj.data(), D.dj, N);
+    rc |= d2h(driftSol.data(), D.sol, N);
+  }
   hipLaunchKernelGGL(k_zero_basic, dim3(g), dim3(256), 0, stream, D);
   hipLaunchKernelGGL(k_primal_rhs, dim3(gr), dim3(256), 0, stream, D, D.vecV2, wideRows ? 1 : 0);
   ftranDevice(D.vecV2, D.x3);
@@ -1771,6 +1794,28 @@ int clpgpu_context::gutsOfSolution()
   hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, stream, D.vecV2, m);
   hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, stream, D.tau, m);
   hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, stream, D.x3, m);
+  if (drift) {
+    // nonbasic reduced costs: largest change, and how many sit on the wrong side of the tolerance only after the resync
+    // (those are the ones the next status check flips or shifts); basic primal values: largest absolute and relative change
+    double maxDj = 0.0, maxX = 0.0, maxXRel = 0.0, maxAbsX = 0.0;
+    int newlyBad = 0;
+    for (int i = 0; i < N; i++) {
+      const int st = status[i] & 7;
+      if (st == ST_BASIC) {
+        const double d = fabs(sol[i] - driftSol[i]);
+        maxX = worst(maxX, d);
+        maxXRel = worst(maxXRel, d / (1.0 + fabs(sol[i])));
+        maxAbsX = worst(maxAbsX, fabs(sol[i]));
+      } else {
+        maxDj = worst(maxDj, fabs(dj[i] - driftDj[i]));
+        const double sgn = (st == ST_UPPER) ? -1.0 : ((st == ST_LOWER) ? 1.0 : 0.0);
+        if (sgn != 0.0 && sgn * dj[i] < -dualTolerance && !(sgn * driftDj[i] < -dualTolerance))
+          newlyBad++;
+      }
+    }
+    fprintf(stderr, "clpgpu: drift at iteration %d: nonbasic dj max %g, %d newly dual infeasible; basic x max %g (relative %g, largest |x| %g)\n",
+            numberIterations, maxDj, newlyBad, maxX, maxXRel, maxAbsX);
+  }
   checkPrimalSolution();
   checkDualSolution();
   return rc;
@@ -2405,7 +2450,11 @@ int clpgpu_context::startup()
   changeBounds(1, dummy);
   rc |= pushRim();
   rc |= gutsOfSolution();
-  if (perturbation < 100) {
+  // startupSolve :330-336: "problemStatus_ = 0" when the starting basis is already optimal comes FIRST; the costs are
+  // perturbed only `if (problemStatus_ < 0 && perturbation_ < 100)` -- a warm-started optimal basis returns with no
+  // iterations and untouched costs
+  const bool optimalAtStart = !numberDualInfeasibilities && !numberPrimalInfeasibilities;
+  if (perturbation < 100 && !optimalAtStart) {
     // startupSolve :335-341.  perturb() == 1 ("safer to use primal": every cost is zero) is only a hint to
     // callers that hold a primal; dual carries on unperturbed.
     perturb();
@@ -3360,6 +3409,7 @@ int clpgpu_context::whileIterating(int stepTarget)
 {
   // push the scalars the device needs for this run of iterations
   hCtrl->state = RUN;
+  hCtrl->pendingState = RUN;
   hCtrl->stepLimit = stepTarget;
   hCtrl->saveSumDual = sumDualInfeasibilities;
   hCtrl->largestPrimalError = largestPrimalError;
@@ -3461,6 +3511,10 @@ int clpgpu_context::whileIterating(int stepTarget)
   lastReturnCode = -1;
   switch (state) {
   case EXIT_STEP_LIMIT:
+    // the pivot the run stopped on may have asked for a refactorization (houseBody): it is done when the run resumes,
+    // so that the basis handed back is the un-refactorized one (ClpSimplex::housekeeping returns on the iteration limit
+    // first, src/ClpSimplex.cpp:2391) and a resumed run continues exactly like an unstepped one
+    stepPendingRefactor = hCtrl->pendingState == EXIT_REFACTOR;
     return 1;
   case EXIT_REFACTOR:
     problemStatus = -2;
@@ -3613,12 +3667,22 @@ int clpgpu_context::run(int maxSteps)
   auto t0 = std::chrono::steady_clock::now();
   int rc = 0;
   if (!started) {
+    stepPendingRefactor = false;
     rc = startup();
     if (rc)
       return problemStatus = 4;
   }
   int stepTarget = (maxSteps < 0) ? -1 : numberIterations + maxSteps;
   int result = -1;
+  if (stepPendingRefactor) {
+    // the refactorization the last stepped run stopped in front of (see whileIterating, EXIT_STEP_LIMIT)
+    stepPendingRefactor = false;
+    if (problemStatus < 0 && !needStatus) {
+      lastExitState = EXIT_REFACTOR;
+      problemStatus = -2;
+      needStatus = true;
+    }
+  }
   while (problemStatus < 0) {
     if (needStatus && perturbation < 101 && numberIterations > 2 * (m + n) && !fastDualMode) {
       // "if getting nowhere - why not give it a kick" (gutsOfDual :488-492)
@@ -3666,7 +3730,9 @@ int clpgpu_context::run(int maxSteps)
   finish();
   // ClpSimplex::dual's own second thought (src/ClpSimplex.cpp:5800-5803): an "infeasible" reached with fake bounds active is
   // "clean up in primal as fake bounds" -- status 10.  Not in fastDual / strong branching, which do not go through ClpSimplex::dual.
-  if (problemStatus == 1 && !rimInfeasible && !fastDualMode && numberAtFakeBound() > 0)
+  // A caller with a primal behind it (the clpGpuDual adapter, which finishes a 10 with model.primal(1)) asks for this with
+  // option "fake_bound_cleanup" 1; a bare context has no primal and reports the 1 it found.
+  if (problemStatus == 1 && fakeBoundCleanup && !rimInfeasible && !fastDualMode && numberAtFakeBound() > 0)
     problemStatus = 10;
   auto t1 = std::chrono::steady_clock::now();
   seconds += std::chrono::duration<double>(t1 - t0).count();
@@ -4481,6 +4547,21 @@ clpgpu_context *clpgpu_clone(const clpgpu_context *src)
   ctx->refreshResidualMax = src->refreshResidualMax;
   ctx->scalingMode = src->scalingMode;
   ctx->flipListCap = src->flipListCap;
+  // every other user-settable option (clpgpu_set_option): a clone used for strong branching or a node re-solve runs with
+  // its parent's configuration
+  ctx->solutionRefinements = src->solutionRefinements;
+  ctx->refineAbove = src->refineAbove;
+  ctx->gemmBackend = src->gemmBackend;
+  ctx->luPolish = src->luPolish;
+  ctx->luPolishTolerance = src->luPolishTolerance;
+  ctx->luAdaptive = src->luAdaptive;
+  ctx->luMinPivots = src->luMinPivots;
+  ctx->luInverseFillCap = src->luInverseFillCap;
+  ctx->fakeBoundCleanup = src->fakeBoundCleanup;
+  ctx->refactorMode = src->refactorMode;
+  ctx->refactorMinK = src->refactorMinK;
+  ctx->forkUpdate = src->forkUpdate;
+  ctx->timing = src->timing;
   ctx->haveExternalScales = src->haveExternalScales;
   if (src->haveExternalScales) {
     ctx->rowScale = src->rowScale;
@@ -4650,11 +4731,23 @@ int clpgpu_virtual_dual_steps(clpgpu_virtual_group *g, int iterations, int *stat
     a->status = a->ctx->run(a->iterations);
     return nullptr;
   };
-  for (int r = 0; r < g->nranks; r++)
-    pthread_create(&th[r], nullptr, body, &args[r]);
+  bool created[8] = {};
   int rc = 0;
   for (int r = 0; r < g->nranks; r++) {
-    pthread_join(th[r], nullptr);
+    created[r] = pthread_create(&th[r], nullptr, body, &args[r]) == 0;
+    if (!created[r]) {
+      // a rank that never starts: the others must not wait for it in the exchange
+      pthread_mutex_lock(&g->mutex);
+      g->failed = true;
+      pthread_cond_broadcast(&g->cond);
+      pthread_mutex_unlock(&g->mutex);
+      args[r].status = -99;
+      rc = -2;
+    }
+  }
+  for (int r = 0; r < g->nranks; r++) {
+    if (created[r])
+      pthread_join(th[r], nullptr);
     if (statusOut)
       statusOut[r] = args[r].status;
     if (g->ctx[r]->commFailed)
@@ -4745,6 +4838,7 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "lu_adaptive")) ctx->luAdaptive = (int)v;
   else if (!strcmp(name, "lu_min_pivots")) ctx->luMinPivots = std::max(1, (int)v);
   else if (!strcmp(name, "lu_inverse_fill_cap")) ctx->luInverseFillCap = v;
+  else if (!strcmp(name, "fake_bound_cleanup")) ctx->fakeBoundCleanup = v != 0.0;
   else if (!strcmp(name, "fork_update")) { ctx->forkUpdate = (int)v; ctx->dropGraph(); }
   else if (!strcmp(name, "refresh_min_k")) ctx->refreshMinK = (int)v;
   else if (!strcmp(name, "refresh_min_k_dense")) ctx->refreshMinKDense = (int)v;

@@ -2039,6 +2039,14 @@ __device__ void houseBody(Dev D, int skipColumns = 0)
   }
   if (c->state == RUN && !D.luMode && c->k + 2 >= c->kcap)
     c->state = EXIT_REFACTOR;  // nucleus storage nearly full: host regrows it at the refactorization
+  // a stepped run (clpgpu_dual_steps) stops on its pivot BEFORE acting on the refactorization decision, the way
+  // ClpSimplex::housekeeping returns on hitMaximumIterations() (src/ClpSimplex.cpp:2391) ahead of :2435-2450; unlike an
+  // iteration limit the run can resume, so the decision taken above (and the cycle record) is kept for the resumption:
+  // a stepped run and an unstepped one make the same pivots and the same refactorizations.
+  if (c->stepLimit >= 0 && c->numberIterations >= c->stepLimit && (c->state == RUN || c->state == EXIT_REFACTOR)) {
+    c->pendingState = c->state;
+    c->state = EXIT_STEP_LIMIT;
+  }
 }
 
 

@@ -62,6 +62,32 @@ def _finish_feasible(rng, A_csc_parts, m, n, xmax, name):
                   row_lower=row_lower, row_upper=row_upper, obj_offset=0.0)
 
 
+_BIG = {}  # generated instances with >= 1e6 entries, by (generator, arguments): config 4 takes the generator ~15-30 s
+
+
+def _remember(fn):
+    """The big instances are generated once per process (several full-size tests and the bench legs build the same LP);
+    callers get a fresh LpData whose arrays are shared and read-only."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        key = (fn.__name__, args, tuple(sorted(kwargs.items())))
+        if key in _BIG:
+            return type(_BIG[key])(_BIG[key])
+        lp = fn(*args, **kwargs)
+        if len(lp.elem) >= 1_000_000:
+            for a in (lp.col_start, lp.row, lp.elem, lp.col_lower, lp.col_upper, lp.obj, lp.row_lower, lp.row_upper):
+                a.flags.writeable = False
+            if len(_BIG) >= 3:
+                _BIG.pop(next(iter(_BIG)))
+            _BIG[key] = lp
+            return type(lp)(lp)
+        return lp
+    return wrapped
+
+
+@_remember
 def dense_lp(m=5000, n=5000, seed=20260925):
     """BASELINE config 3: every entry of A nonzero, A_ij ~ U(-1,1), 0 <= x <= 10."""
     rng = np.random.default_rng(seed)
@@ -71,6 +97,7 @@ def dense_lp(m=5000, n=5000, seed=20260925):
     return _finish_feasible(rng, (col_start, row, elem), m, n, 10.0, f"dense{m}x{n}")
 
 
+@_remember
 def sparse_lp(m=50000, n=200000, mean_nnz_per_col=50, seed=20260926):
     """BASELINE config 4: each column draws k = 1 + Poisson(mean-1) distinct rows, values U(-1,1)
     pushed away from zero to |v| >= 0.05, 0 <= x <= 100."""
@@ -102,6 +129,7 @@ def sparse_lp(m=50000, n=200000, mean_nnz_per_col=50, seed=20260926):
     return _finish_feasible(rng, (col_start, row, elem), m, n, 100.0, f"sparse{m}x{n}")
 
 
+@_remember
 def netlib_shaped_lp(m=50000, n=200000, target_nnz=10_000_000, seed=20260927):
     """Netlib-shaped variant of config 4: power-law column counts, 20% equality rows,
     10% columns with infinite upper bound, values spanning 1e-3..1e3."""

@@ -40,6 +40,8 @@ int clpGpuDual(ClpSimplex &model, int device, bool scaling)
   // ClpSimplexDual.cpp:488 happen on the device side as they would in dual(); a solve that ends on perturbed costs with
   // dual infeasibilities for the true ones comes back as status 10 and is finished by primal below, as in ClpSimplex::dual
   clpgpu_set_option(ctx, "perturbation", model.perturbation());
+  // "infeasible" with fake bounds still active comes back as 10 (ClpSimplex::dual, src/ClpSimplex.cpp:5800-5803) and is finished by primal below
+  clpgpu_set_option(ctx, "fake_bound_cleanup", 1);
   if (model.statusArray())
     clpgpu_set_status(ctx, model.statusArray()); // warm start
   int problemStatus = clpgpu_dual(ctx);          // ClpSimplex::dual()

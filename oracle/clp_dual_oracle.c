@@ -3452,7 +3452,10 @@ static int dualOnRim(OrcModel *M)
     changeBounds(M, 1, NULL, &dummy);
   }
   gutsOfSolution(M);
-  if (M->perturbation < 100) {
+  /* startupSolve :330-336: an optimal starting basis sets problemStatus_ = 0 FIRST, and the costs are perturbed only
+     `if (problemStatus_ < 0 && perturbation_ < 100)` */
+  const int optimalAtStart = !M->numberDualInfeasibilities && !M->numberPrimalInfeasibilities;
+  if (M->perturbation < 100 && !optimalAtStart) {
     /* startupSolve :335-341.  perturb() returning 1 ("safer to use primal", all costs zero) is only a hint
        there (usePrimal, read by callers that hold a primal); dual carries on unperturbed. */
     perturb(M);

@@ -559,6 +559,32 @@ def test_iteration_limit_and_stepping(gpu_cls):
     assert g3.dual() == 3 and g3.numberIterations() == 50
 
 
+def test_step_limit_on_a_refactorization_pivot(gpu_cls):
+    """A stepped run that stops exactly on a pivot whose housekeeping asks for a refactorization (pivots == maximumPivots) hands
+    back the UN-refactorized basis, as ClpSimplex::housekeeping returns on hitMaximumIterations() (src/ClpSimplex.cpp:2391) ahead
+    of the refactorization decision (:2435-2450) -- pivotVariable and the refactorization count equal the oracle's stopped by
+    max_iterations at the same pivot -- and the refactorization is done when the run resumes: chunks of exactly the
+    refactorization interval make the same pivots and the same number of refactorizations as an uninterrupted run."""
+    lp = P.sparse_lp(300, 1200, 8, seed=11)
+    for rule in (0, 1):
+        g, o = _pivot_window(gpu_cls, lp, rule, 120, max_pivots=40)  # 120 = 3 x 40
+        _assert_same_window(g, o)
+        assert g.stats()["refactorizations"] == o.refactorizations
+    whole = gpu_cls().loadProblem(lp)
+    whole.set_option("max_pivots", 40)
+    assert whole.dual() == 0
+    stepped = gpu_cls().loadProblem(lp)
+    stepped.set_option("max_pivots", 40)
+    status = -1
+    while status == -1:
+        status = stepped.dual_steps(40)
+    assert status == 0 and stepped.numberIterations() == whole.numberIterations()
+    assert np.array_equal(whole.pivotLog()["sequenceIn"], stepped.pivotLog()["sequenceIn"])
+    assert np.array_equal(whole.pivotLog()["sequenceOut"], stepped.pivotLog()["sequenceOut"])
+    assert stepped.stats()["refactorizations"] == whole.stats()["refactorizations"]
+    assert np.array_equal(whole.solution(), stepped.solution())
+
+
 def test_column_range_shard_matches_full(gpu_cls):
     """Pricing restricted to a column range (the multi-GPU shard) + rank-major merge == unsharded."""
     from clp_amd.sharding import column_ranges, merge_candidates

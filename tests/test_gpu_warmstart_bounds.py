@@ -48,3 +48,28 @@ def test_crossing_row_bounds_on_a_fresh_model(gpu_cls):
     lp.row_lower[3] = lp.row_upper[3] + 0.5
     g = gpu_cls().loadProblem(lp)
     assert g.dual() == 1 and g.numberIterations() == 0
+
+
+@pytest.mark.parametrize("seed,dual_bound", [(3, 5.0), (11, 5.0), (21, 20.0), (28, 5.0)])
+def test_infeasible_with_fake_bounds_active_is_status_10(gpu_cls, seed, dual_bound):
+    """ClpSimplex::dual's second thought (src/ClpSimplex.cpp:5800-5803): "infeasible" reached while nonbasic variables still sit at
+    fake bounds is status 10, "clean up in primal".  LPs of the oracle fuzz with free columns and a dual bound far below the
+    solution's scale end that way on the oracle; the engine with option fake_bound_cleanup (what the clpGpuDual adapter sets, it
+    has a primal to finish with) makes the same pivots and reports the same 10, and a bare context reports the 1 it found."""
+    from oracle.oracle import OracleSimplex
+    from test_oracle_fuzz import make
+
+    lp = make(np.random.default_rng(7000 + seed))
+    o = OracleSimplex(lp)
+    o.set_option("pivot_rule", 1)
+    o.set_option("dual_bound", dual_bound)
+    assert o.dual() == 10
+    for cleanup, expect in ((1, 10), (0, 1)):
+        g = gpu_cls().loadProblem(lp)
+        g.set_option("pivot_rule", 1)
+        g.set_option("dual_bound", dual_bound)
+        g.set_option("fake_bound_cleanup", cleanup)
+        assert g.dual() == expect
+        assert g.numberIterations() == o.iterations
+        lg, lo = g.pivotLog(), o.pivot_log()
+        assert np.array_equal(lg["sequenceIn"], lo["sequenceIn"]) and np.array_equal(lg["sequenceOut"], lo["sequenceOut"])

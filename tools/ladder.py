@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Time-to-optimal ladder: config-4-shaped LPs (clp_amd.problems.sparse_lp: ranged rows of width <= 2 around A x*,
+columns in [0, 100], costs in [0.1, 1], four columns per row) at sizes an independent solver still finishes.
+
+    python tools/ladder.py highs <rung> [time limit s]   # HiGHS serial dual simplex (scipy), presolve off -> one JSON line
+    python tools/ladder.py oracle <rung> [max iterations] # the CPU oracle port (steepest edge), same LP -> one JSON line
+    python tools/ladder.py merge <files...>               # collects the lines into tests/golden/ladder_optima.json
+
+The rungs are fixed here (rows, columns, entries per column, seed); `ladder_lp(name)` is what the GPU test and bench.py build.
+The density follows BASELINE config 4 (0.1 %) with a floor of 10 entries per column, so that the small rungs are not trivially
+sparse; rung "1500" is the LP tests/test_gpu_lu.py already solves against HiGHS.
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+RUNGS = {
+    "1500": (1500, 6000, 10, 31),
+    "3000": (3000, 12000, 10, 32),
+    "5000": (5000, 20000, 10, 33),
+    "7000": (7000, 28000, 10, 34),
+    "10000": (10000, 40000, 10, 35),
+    "14000": (14000, 56000, 14, 36),
+    "20000": (20000, 80000, 20, 37),
+}
+
+
+def ladder_lp(name):
+    from clp_amd import problems as P
+    m, n, k, seed = RUNGS[str(name)]
+    return P.sparse_lp(m, n, k, seed)
+
+
+def run_highs(name, limit):
+    import numpy as np
+    import scipy
+    import scipy.sparse as sp
+    from scipy.optimize import linprog
+    lp = ladder_lp(name)
+    m, n = lp.m, lp.n
+    A = sp.csc_matrix((lp.elem, lp.row, lp.col_start), shape=(m, n))
+    t0 = time.time()
+    r = linprog(lp.obj, A_ub=sp.vstack([A, -A]).tocsr(), b_ub=np.concatenate([lp.row_upper, -lp.row_lower]),
+                bounds=np.column_stack([lp.col_lower, lp.col_upper]), method="highs-ds",
+                options={"presolve": False, "time_limit": float(limit)})
+    dt = time.time() - t0
+    return {"rung": str(name), "m": m, "n": n, "nnz": int(lp.col_start[-1]), "solver": f"HiGHS serial dual simplex (scipy {scipy.__version__}), presolve off",
+            "status": int(r.status), "iterations": int(r.nit), "seconds": round(dt, 2), "cores": 1,
+            "objective": (float(r.fun) if (r.status == 0 and r.fun is not None) else None)}
+
+
+def run_oracle(name, max_iterations):
+    from oracle.oracle import OracleSimplex
+    lp = ladder_lp(name)
+    o = OracleSimplex(lp)
+    o.set_option("pivot_rule", 1)
+    if max_iterations:
+        o.set_option("max_iterations", max_iterations)
+    t0 = time.time()
+    st = o.dual()
+    dt = time.time() - t0
+    return {"rung": str(name), "solver": "oracle port (dense LU, one core)", "status": int(st), "iterations": int(o.iterations),
+            "seconds": round(dt, 2), "cores": 1, "objective": float(o.objective)}
+
+
+def main():
+    what = sys.argv[1]
+    if what == "highs":
+        print(json.dumps(run_highs(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else 3600)), flush=True)
+    elif what == "oracle":
+        print(json.dumps(run_oracle(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 0)), flush=True)
+    elif what == "merge":
+        out = {}
+        for f in sys.argv[2:]:
+            for line in open(f):
+                line = line.strip()
+                if not line.startswith("{"):
+                    continue
+                rec = json.loads(line)
+                slot = out.setdefault(rec["rung"], {"rows": RUNGS[rec["rung"]][0], "columns": RUNGS[rec["rung"]][1],
+                                                    "entries_per_column": RUNGS[rec["rung"]][2], "seed": RUNGS[rec["rung"]][3]})
+                slot["oracle" if rec["solver"].startswith("oracle") else "highs"] = rec
+        path = os.path.join(ROOT, "tests", "golden", "ladder_optima.json")
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+            f.write("\n")
+        print(path)
+
+
+if __name__ == "__main__":
+    main()
