@@ -10,8 +10,12 @@ FTRAN x2, dual/primal/weight updates, basis update).  Workload: BASELINE.json co
 refactorization frequency); inputs are resident in HBM before the timed region.
 
 Legs (rank 0 prints ONE JSON line):
-  headline      W untimed warm-up pivots, then EXACTLY K pivots as captured hipGraphs, bracketed by
-                barrier + synchronize; `value` = K / max-over-ranks time.
+  headline      the context is WARM-STARTED FROM A MATURE BASIS of the same LP (tests/golden/basis_sparse_30000.npy: the status
+                array of this LP after 30 000 pivots, nucleus ~11 000, written by tools/dump_basis.py) -- the regime a solve of this
+                LP spends nearly all of its time in: pi dense, pricing by column, LU mode.  W untimed warm-up pivots (the start-up
+                factorization of that basis is part of them), then EXACTLY K pivots as captured hipGraphs, bracketed by barrier +
+                synchronize; `value` = K / max-over-ranks time.  `slack_start` = the same count of pivots from the slack basis
+                (the near-identity regime earlier rounds quoted as the headline), a secondary field.  --start slack restores it.
   roofline      a second context replays THE SAME pivots (the engine is deterministic) with eager
                 launches and HIP events on the engine's stream: pricing-kernel time per launch and the
                 algorithmic bytes the kernel counted (SURVEY.md 8d) -> achieved / peak = frac;
@@ -28,6 +32,10 @@ Legs (rank 0 prints ONE JSON line):
                 clp binary is on PATH; null otherwise.
   time_to_optimal  the solve continued to optimality within --tto-budget seconds (or how far it got); compared with
                 the independent optimum under tests/golden/bench_optima.json when there is one.
+  time_to_optimal_ladder  LPs of the same generator at sizes an independent solver finishes (tools/ladder.py, optima in
+                tests/golden/ladder_optima.json): the engine in its default mode from the slack basis to status 0, seconds and
+                iterations next to HiGHS' (one core) and the oracle port's, objective against HiGHS' to 1e-8; rungs in ascending
+                size while --ladder-budget seconds last.
   sustained     pivots/s of that continuation in windows of 2000 pivots: the first, the one where the nucleus passes
                 5000, and the last reached -- refactorizations included.
   roofline_mature  per-kernel time, algorithmic bytes and HBM fraction of the kernels that dominate the mature
@@ -60,10 +68,25 @@ def make_lp(args):
     return P.sparse_lp(args.rows, args.cols, args.nnz_per_col)
 
 
-def make_engine(args, lp, device):
+MATURE_BASIS = os.path.join(ROOT, "tests", "golden", "basis_sparse_30000.npy")
+
+
+def mature_basis(args):
+    """status array of the default bench LP after 30 000 pivots (tools/dump_basis.py sparse 30000), or None"""
+    default = (args.workload, args.rows, args.cols, args.nnz_per_col) == ("sparse", 50000, 200000, 50)
+    if args.start != "mature" or not default or not os.path.exists(MATURE_BASIS):
+        return None
+    import numpy as np
+
+    return np.load(MATURE_BASIS).astype(np.uint8)
+
+
+def make_engine(args, lp, device, basis=None):
     from clp_amd.engine import ClpGpuSimplex
 
     eng = ClpGpuSimplex(device).loadProblem(lp)
+    if basis is not None:
+        eng.setStatusArray(basis)
     eng.set_option("pivot_rule", args.pivot_rule)
     eng.set_option("check_every", args.check_every)
     # refactorization frequency as ClpSimplex::initialSolve sets it (defaultFactorizationFrequency:
@@ -89,7 +112,7 @@ def pmc_traffic(args, kernel_regex):
         cmd = [exe, "--pmc", counter, "--kernel-trace", "--kernel-include-regex", kernel_regex, "-d", d, "-o", "pmc", "--",
                sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", str(args.steps), "--warmup", str(args.warmup),
                "--rows", str(args.rows), "--cols", str(args.cols), "--nnz-per-col", str(args.nnz_per_col), "--workload", args.workload,
-               "--pivot-rule", str(args.pivot_rule), "--check-every", str(args.check_every)]
+               "--pivot-rule", str(args.pivot_rule), "--check-every", str(args.check_every), "--start", args.start]
         try:
             env = dict(os.environ, TMPDIR="/tmp")
             p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
@@ -163,6 +186,11 @@ def main():
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"], help="live PMC traffic of the pricing kernel via rocprofv3 child runs")
     ap.add_argument("--pmc-timeout", type=float, default=150.0)
     ap.add_argument("--clp-timeout", type=float, default=600.0)
+    ap.add_argument("--start", default="mature", choices=["mature", "slack"],
+                    help="mature (default): the timed context starts from the committed basis of the default LP after 30 000 pivots; "
+                         "slack: from the slack basis (other workloads always do)")
+    ap.add_argument("--ladder-budget", type=float, default=60.0, help="seconds allowed for the time-to-optimal ladder (0 skips it)")
+    ap.add_argument("--ladder-rungs", default="1500,3000,5000,7000,10000,14000,20000")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -185,10 +213,11 @@ def main():
     t0 = time.time()
     lp = make_lp(args)
     gen_s = time.time() - t0
+    basis = mature_basis(args)
 
     if args.pmc_child:
         # profiled child: the same warm-up + timed pivots, eager launches (one dispatch per kernel either way)
-        eng = make_engine(args, lp, 0)
+        eng = make_engine(args, lp, 0, basis)
         eng.set_option("use_graph", 0)
         eng.set_option("check_every", 1)  # no launches beyond the step limit: the last K dispatches are the timed pivots
         eng.set_option("row_price_frac", 0.0)  # the by-column sweep the roofline is quoted for
@@ -209,7 +238,7 @@ def main():
         torch.cuda.synchronize()
 
     # ---- headline: warm-up (startup: factorize, resync + W pivots), then exactly K timed pivots
-    eng = make_engine(args, lp, local_rank)
+    eng = make_engine(args, lp, local_rank, basis)
     attach(eng)
     status = eng.dual_steps(args.warmup)
     assert status == -1, f"LP finished during warmup (status {status})"
@@ -228,9 +257,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- secondary: the same count of pivots from the slack basis (near-identity basis, pricing by row, nucleus <= W + K)
+    slack_start = None
+    if basis is not None and rank == 0 and world == 1:
+        es = make_engine(args, lp, local_rank)
+        es.dual_steps(args.warmup)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        es.dual_steps(args.steps)
+        torch.cuda.synchronize()
+        ts = time.perf_counter() - ts
+        slack_start = {"value": args.steps / ts, "unit": "iterations/s", "pivot_window": [args.warmup + 1, args.warmup + args.steps],
+                       "nucleus_at_end_of_window": int(es.stats()["nucleus"]),
+                       "note": "the same LP from the slack basis: near-identity basis, pi sparse, pricing by row -- what rounds 1-3 quoted as the headline"}
+        del es
+
     # ---- replay legs: the same pivots again on fresh contexts (the engine is deterministic), eager launches + HIP events
     def replay(force_by_column):
-        e = make_engine(args, lp, local_rank)
+        e = make_engine(args, lp, local_rank, basis)
         attach(e)
         e.set_option("timing", 2)
         if force_by_column:
@@ -251,8 +295,12 @@ def main():
 
     # (1) as the headline runs (row pricing by row while pi is sparse): per-kernel times, the by-row form's numbers
     d_mix, per_kernel_us, same_pivots = replay(False)
-    # (2) row pricing forced by column: the HBM-bound sweep the roofline is quoted for, on the same pivots
-    d_col, per_kernel_us_col, same_pivots_col = replay(True)
+    # (2) row pricing forced by column: the HBM-bound sweep the roofline is quoted for, on the same pivots -- only when the
+    # timed window priced by row somewhere (the slack start); from the mature basis pi is dense and (1) IS the by-column form
+    if d_mix["row_launches"] > 0:
+        d_col, per_kernel_us_col, same_pivots_col = replay(True)
+    else:
+        d_col, per_kernel_us_col, same_pivots_col = d_mix, per_kernel_us, same_pivots
     launches = d_col["price_launches"]
     per_launch_bytes = d_col["price_bytes"] / max(launches, 1)
     per_launch_s = d_col["price_ms"] * 1e-3 / max(launches, 1)
@@ -420,6 +468,47 @@ def main():
                       "kernels": rl[:14],
                       "note": "eager launches with a HIP event after each (kernel + launch gap); `frac` = algorithmic bytes / time / 8 TB/s"}
 
+    # ---- time-to-optimal ladder: the same generator at sizes HiGHS finishes; the engine in its default mode, slack start, to status 0
+    ladder = None
+    if rank == 0 and world == 1 and args.ladder_budget > 0:
+        from tools.ladder import ladder_lp
+
+        gold_path = os.path.join(ROOT, "tests", "golden", "ladder_optima.json")
+        gold = json.load(open(gold_path)) if os.path.exists(gold_path) else {}
+        ladder = {"unit": "seconds to status 0 from the slack basis, default options (steepest edge, LU mode from 3072 basic structurals on)",
+                  "independent_solver": "HiGHS serial dual simplex (scipy), presolve off, one core -- tests/golden/ladder_optima.json, tools/ladder.py",
+                  "rungs": []}
+        t_l = time.perf_counter()
+        for name in filter(None, args.ladder_rungs.split(",")):
+            ref = gold.get(name, {}).get("highs")
+            if not ref or ref.get("objective") is None:
+                continue
+            if time.perf_counter() - t_l > args.ladder_budget:
+                ladder["rungs"].append({"rung": name, "skipped": "ladder budget spent"})
+                continue
+            llp = ladder_lp(name)
+            el = make_engine(args, llp, local_rank)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            stl = -1
+            while stl == -1 and time.perf_counter() - t_l < args.ladder_budget + 30.0:
+                stl = el.dual_steps(4000)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter() - t3
+            obj = el.objectiveValue()
+            orc = gold.get(name, {}).get("oracle")
+            ladder["rungs"].append({
+                "rung": name, "rows": int(llp.m), "cols": int(llp.n), "nnz": int(len(llp.elem)), "status": int(stl),
+                "engine_seconds": round(t3, 3) if stl == 0 else None, "engine_iterations": int(el.numberIterations()),
+                "engine_iterations_per_s": round(el.numberIterations() / max(t3, 1e-9), 1), "objective": obj,
+                "highs_objective": ref["objective"], "highs_seconds": ref["seconds"], "highs_iterations": ref["iterations"],
+                "objective_matches_highs": bool(stl == 0 and abs(obj - ref["objective"]) <= 1e-8 * abs(ref["objective"])),
+                "speedup_vs_highs": round(ref["seconds"] / t3, 2) if stl == 0 else None,
+                "oracle_port_seconds": orc["seconds"] if orc and orc.get("status") == 0 else None,
+                "oracle_port_iterations": orc["iterations"] if orc and orc.get("status") == 0 else None,
+                "nucleus_at_end": int(el.stats()["nucleus"])})
+            del el
+
     config_ref = {"sparse": "BASELINE.json configs[3]", "dense": "BASELINE.json configs[2]",
                   "netlib": "Netlib-shaped variant of BASELINE.json configs[3]"}[args.workload]
     if (args.rows, args.cols) != {"dense": (5000, 5000)}.get(args.workload, (50000, 200000)):
@@ -456,19 +545,26 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{args.workload} LP {lp.m}x{lp.n}, {len(lp.elem)} nonzeros ({config_ref}), "
-                                   + ("steepest-edge dual" if args.pivot_rule else "Dantzig dual") + " from the slack basis",
+                                   + ("steepest-edge dual" if args.pivot_rule else "Dantzig dual")
+                                   + (" warm-started from the committed basis of this LP after 30 000 pivots (tests/golden/basis_sparse_30000.npy)"
+                                      if basis is not None else " from the slack basis"),
+                       "start": "mature basis (pivot 30 000 of the same LP)" if basis is not None else "slack basis",
                        "rows": int(lp.m), "cols": int(lp.n), "nnz": int(len(lp.elem)),
                        "parallelism": f"column-range pricing x{world}" if world > 1 else "1 GPU",
                        "check_every": args.check_every, "generate_s": round(gen_s, 1),
                        "pivot_window": [int(it0) + 1, int(it0) + args.steps],
+                       "pivot_window_counts_from": "the warm start" if basis is not None else "the slack basis",
                        "nucleus_at_end_of_window": int(headline_stats["nucleus"])},
             "roofline": {"bound": "hbm", "kernel": " + ".join(sorted(price_names)) + " (row pricing + fused first ratio pass)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "bytes_per_launch": per_launch_bytes, "us_per_launch": per_launch_s * 1e6,
                          "launches": int(launches),
-                         "window": "FORCED-BY-COLUMN REPLAY of the timed pivots (eager, HIP events): the HBM-bound form of the pricing kernel. "
-                                   "The timed window itself prices by row while pi is sparse -- `row_pricing` is what ran there, "
-                                   "`roofline_mature` what runs once the basis has matured (pi dense, pricing by column)",
+                         "window": ("replay of the timed pivots (eager, HIP events on the engine's stream): pi is dense in this regime, so the "
+                                    "kernel form measured here (by column) is the one the timed window ran"
+                                    if d_col is d_mix else
+                                    "FORCED-BY-COLUMN REPLAY of the timed pivots (eager, HIP events): the HBM-bound form of the pricing kernel. "
+                                    "The timed window itself prices by row while pi is sparse -- `row_pricing` is what ran there, "
+                                    "`roofline_mature` what runs once the basis has matured (pi dense, pricing by column)"),
                          "form_in_timed_window": ("by row" if (row_pricing and row_pricing["launches"] * 2 > args.steps) else "by column"),
                          "bytes_counted": "streamed: 4 B per row index + 8 B per element fetched (conditional form fetches only under set bits of pi) "
                                           "+ lists; SURVEY 8d's B_col = 12 nnz(A_J) + ... is the unconditional form",
@@ -480,7 +576,9 @@ def main():
                          "dominant_by_time": dominant_by_time,
                          "per_kernel_note": "per pivot, eager launches: kernel + the launch gap before it; hipGraph replay (the headline) has smaller gaps"},
             "cpu_baseline": cpu,
+            "slack_start": slack_start,
             "time_to_optimal": tto,
+            "time_to_optimal_ladder": ladder,
             "sustained": sustained,
             "roofline_mature": regime,
             "refactorizations": int(headline_stats["refactorizations"]),

@@ -1,0 +1,50 @@
+"""Time-to-optimal ladder (-m gpu): config-4-shaped LPs (clp_amd.problems.sparse_lp, tools/ladder.py RUNGS) at sizes an INDEPENDENT solver
+finishes -- HiGHS' serial dual simplex, presolve off, optima committed in tests/golden/ladder_optima.json by tools/ladder.py.  The engine runs in
+its DEFAULT mode (steepest edge, the reference's refactorization frequency, LU mode from 3072 basic structurals on) from the slack basis to
+status 0; the objective must equal HiGHS' to 1e-8 relative (north_star).  This is the independent pin of the whole solve -- LU mode included --
+beyond the sizes the CPU oracle can follow pivot by pivot."""
+import json
+import os
+import time
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden", "ladder_optima.json")
+
+
+def _rungs():
+    if not os.path.exists(GOLD):
+        return []
+    gold = json.load(open(GOLD))
+    return sorted((k for k, v in gold.items() if v.get("highs", {}).get("objective") is not None), key=int)
+
+
+@pytest.fixture(scope="module")
+def gpu_cls(built):
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from clp_amd.engine import ClpGpuSimplex
+
+    return ClpGpuSimplex
+
+
+@pytest.mark.parametrize("rung", _rungs())
+def test_rung_reaches_the_independent_optimum(gpu_cls, rung):
+    from tools.ladder import ladder_lp
+
+    ref = json.load(open(GOLD))[rung]["highs"]
+    lp = ladder_lp(rung)
+    g = gpu_cls().loadProblem(lp)
+    g.set_option("pivot_rule", 1)
+    g.set_option("max_pivots", 0)
+    t0 = time.perf_counter()
+    status = -1
+    while status == -1 and time.perf_counter() - t0 < 600.0:
+        status = g.dual_steps(20000)
+    assert status == 0, f"rung {rung}: status {status} after {g.numberIterations()} pivots in {time.perf_counter() - t0:.1f} s"
+    assert abs(g.objectiveValue() - ref["objective"]) <= 1e-8 * abs(ref["objective"]), (g.objectiveValue(), ref["objective"])
+    if int(rung) >= 5000:
+        assert g.stats()["lu_factorizations"] > 0  # the big rungs are solved in LU mode
