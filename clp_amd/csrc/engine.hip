@@ -431,6 +431,7 @@ struct clpgpu_context {
   int launchBatch(int count = -1);
   bool capturing = false;
   int whileIterating(int stepTarget);
+  int debugPriceBench(int reps, int numberMasks, const int *masks, double *microseconds);
   // ClpSimplexDual::fastDual (src/ClpSimplexDual.cpp:7227): 0 = run() as clpgpu_dual does; 1 = in fastDual with
   // alwaysFinish, 2 = in fastDual without (stop at the first exit of the iteration loop that asks for a
   // refactorization: "can't say anything interesting - might as well return", :7422-7431)
@@ -3833,10 +3834,68 @@ int clpgpu_context::priceRow(int numberPi, const int *piIndex, const double *piV
   return rc;
 }
 
+// Development hook: the by-column pricing kernel as the chain launches it (variant 6, dense pi), timed with HIP events on the
+// engine's stream between two pivots, with parts of the kernel switched off by `masks` (see priceSellBody).  Touches only the
+// per-pivot scratch pricing rewrites on every pivot (tableau row, candidate flags, block counts) and pi, which it clears again.
+int clpgpu_context::debugPriceBench(int reps, int numberMasks, const int *masks, double *microseconds)
+{
+  if (!started || !D.colStart || nSellBlocks <= 0 || reps <= 0)
+    return -1;
+  int rc = sync();
+  const int nbRows = cdiv(m, PRICE_BLOCK);
+  const int nbCols = cdiv(D.lastColumn - D.firstColumn, PRICE_BLOCK);
+  const int nb = nbRows + nbCols;
+  const int nSlots = nSellBlocks + nLongBlocks;
+  const bool countInPrice = nb > 256;
+  const size_t words = (size_t)(m + 63) / 64 + 8;
+  std::vector<unsigned long long> ones(words, ~0ull);
+  rc |= h2d(D.piBits, ones.data(), words);
+  hipLaunchKernelGGL(k_fill, dim3(cdiv(m, 256)), dim3(256), 0, stream, D.piNeg, 0.37, m);
+  const int saveState = hCtrl->state;
+  hCtrl->state = RUN;
+  rc |= pushCtrl();
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  const size_t lds = (m > 64 * SELL_BITS_MAX) ? 0 : (size_t)((m + 63) / 64) * 8;
+  for (int v = 0; v < numberMasks && !rc; v++) {
+    for (int r = 0; r < reps + 2; r++) {
+      if (r == 2)
+        (void)hipEventRecord(e0, stream);
+      hipLaunchKernelGGL(k_price_sell, dim3(nSlots), dim3(256), lds, stream, D, (m > 64 * SELL_BITS_MAX) ? 1 : 6, countInPrice ? 1 : 0, nSellBlocks,
+                         nSlots, 0, 0, masks[v]);
+    }
+    (void)hipEventRecord(e1, stream);
+    rc |= sync();
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    microseconds[v] = 1.0e3 * ms / reps;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  std::vector<unsigned long long> zeros(words, 0ull);
+  rc |= h2d(D.piBits, zeros.data(), words);
+  hipLaunchKernelGGL(k_zero, dim3(cdiv(m, 256)), dim3(256), 0, stream, D.piNeg, m);
+  hipLaunchKernelGGL(k_zero, dim3(cdiv(n, 256)), dim3(256), 0, stream, D.alphaCol, n);
+  (void)hipMemsetAsync(D.blockCount, 0, sizeof(int) * (size_t)nb, stream);
+  (void)hipMemsetAsync(D.candFlag, 0, (size_t)N, stream);
+  hCtrl->state = saveState;
+  rc |= pushCtrl();
+  rc |= sync();
+  return rc;
+}
+
 // =============================================================================================
 // C ABI
 // =============================================================================================
 extern "C" {
+
+int clpgpu_debug_price_bench(clpgpu_context *ctx, int reps, int numberMasks, const int *masks, double *microseconds)
+{
+  if (!ctx || !masks || !microseconds)
+    return -1;
+  return ctx->debugPriceBench(reps, numberMasks, masks, microseconds);
+}
 
 clpgpu_context *clpgpu_create(int device)
 {

@@ -2375,7 +2375,10 @@ __global__ void k_gemvT_partial2(Dev D, const double *t, int iter)
 // PIPE: software-pipelined loads; NT: non-temporal matrix loads; BITS: gather pi only where the
 // row's bit is set (pi is sparse for most pivots: the gather traffic scales with nnz(pi)/m)
 template <bool PIPE, bool NT, bool BITS, bool COND = false>
-__device__ inline void priceSellBody(Dev D, unsigned long long *bits, int countCols = 0)
+// dbg (clpgpu_debug_price_bench only; 0 in the chain): switches parts of the kernel off so that their cost can be measured apart --
+// 1 no candidate-count atomics, 2 tableau row / flags stored in SELL order (coalesced) instead of by column, 4 no status / dj
+// gathers, 8 no matrix sweep, 16 no gather of pi
+__device__ inline void priceSellBody(Dev D, unsigned long long *bits, int countCols = 0, int dbg = 0)
 {
   const Ctrl *c = D.ctrl;
   __shared__ double shd[16];
@@ -2409,6 +2412,8 @@ __device__ inline void priceSellBody(Dev D, unsigned long long *bits, int countC
     }
   }
   auto piAt = [&](int r) -> double {
+    if (dbg & 16)
+      return 1.0;
     if (BITS) {
       return ((bits[r >> 6] >> (r & 63)) & 1ull) ? D.piNeg[r] : 0.0;
     } else {
@@ -2422,11 +2427,11 @@ __device__ inline void priceSellBody(Dev D, unsigned long long *bits, int countC
     int len = 0, wanted = 0;
     int hits = -1;  // elements really fetched (conditional form); -1: all of them
     if (j >= 0) {
-      wanted = (D.status[j] & 3) - 1;
+      wanted = (dbg & 4) ? 2 : (D.status[j] & 3) - 1;
       if (wanted)
         len = D.sellLen[idx];
     }
-    int maxLen = len;
+    int maxLen = (dbg & 8) ? 0 : len;
     for (int o = 32; o > 0; o >>= 1)
       maxLen = max(maxLen, __shfl_xor(maxLen, o));
     double value = 0.0;
@@ -2519,6 +2524,8 @@ __device__ inline void priceSellBody(Dev D, unsigned long long *bits, int countC
         }
       }
     }
+    if (dbg & 8)
+      value = len > 0 ? 1.0 + 1.0e-3 * lane : 0.0;
     if (j >= 0) {
       int flag = 0;
       if (wanted) {
@@ -2532,7 +2539,7 @@ __device__ inline void priceSellBody(Dev D, unsigned long long *bits, int countC
             double mult = (wanted == 1) ? -1.0 : 1.0;
             double alpha = value * mult;
             if (alpha > 0.0) {
-              double oldValue = D.dj[j] * mult;
+              double oldValue = ((dbg & 4) ? 1.0 : D.dj[j]) * mult;
               double v2 = oldValue - tentativeTheta * alpha;
               if (v2 < dualT) {
                 flag = 1;
@@ -2545,10 +2552,11 @@ __device__ inline void priceSellBody(Dev D, unsigned long long *bits, int countC
           value = 0.0;
         }
       }
-      D.alphaCol[j] = value;
-      D.candFlag[D.m + j] = (unsigned char)flag;
+      const int at = ((dbg & 2) && idx < D.n) ? idx : j;
+      D.alphaCol[at] = value;
+      D.candFlag[D.m + at] = (unsigned char)flag;
       // candidate count of the column's compaction block (integer atomic: order independent)
-      if (flag && countCols)
+      if (flag && countCols && !(dbg & 1))
         atomicAdd(&D.blockCount[((D.m + PRICE_BLOCK - 1) / PRICE_BLOCK) + ((j - D.firstColumn) / PRICE_BLOCK)], 1);
     }
   }
@@ -2977,7 +2985,7 @@ __global__ void __launch_bounds__(PT_THREADS) k_price_tiled(Dev D)
 }
 
 __global__ void __launch_bounds__(256) k_price_sell(Dev D, int variant, int countCols = 0, int nSellBlocks = 1 << 30, int nColBlocks = 1 << 30,
-                                                    int rowMax = 0, int fullRows = 0)
+                                                    int rowMax = 0, int fullRows = 0, int dbg = 0)
 {
   if (D.ctrl->state != RUN)
     return;
@@ -3012,7 +3020,7 @@ __global__ void __launch_bounds__(256) k_price_sell(Dev D, int variant, int coun
     priceSellBody<false, true, true>(D, sellBits, countCols);
     break;
   case 6:
-    priceSellBody<false, false, true, true>(D, sellBits, countCols);
+    priceSellBody<false, false, true, true>(D, sellBits, countCols, dbg);
     break;
   default:
     priceSellBody<false, false, false>(D, sellBits, countCols);

@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "clpgpu_chg_obj_coefficients", "clpgpu_scale_factors",
     "clpgpu_clone", "clpgpu_set_scales", "clpgpu_ftran_ft", "clpgpu_ftran_two_ft", "clpgpu_bind_rim", "clpgpu_pivot_row",
     "clpgpu_update_weights", "clpgpu_update_primal", "clpgpu_save_weights", "clpgpu_unroll_weights",
-    "clpgpu_get_kernel_times", "clpgpu_dgemm", "clpgpu_test_cycle", "clpgpu_test_looping",
+    "clpgpu_get_kernel_times", "clpgpu_dgemm", "clpgpu_test_cycle", "clpgpu_debug_price_bench", "clpgpu_test_looping",
     "clpgpu_virtual_group_create", "clpgpu_virtual_group_destroy", "clpgpu_virtual_attach", "clpgpu_virtual_dual_steps",
 ]
 
@@ -303,6 +303,16 @@ class ClpGpuSimplex:
         s = Stats()
         self._check(lib().clpgpu_get_stats(self._h, C.byref(s)), "clpgpu_get_stats")
         return {f: getattr(s, f) for f, _ in Stats._fields_}
+
+    def debugPriceBench(self, masks, reps=50):
+        """mean microseconds per launch of the by-column pricing kernel under each debug mask (clpgpu_debug_price_bench)"""
+        mk = np.ascontiguousarray(masks, dtype=np.int32)
+        out = np.zeros(len(mk))
+        f = lib().clpgpu_debug_price_bench
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS"),
+                      np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")]
+        self._check(f(self._h, int(reps), len(mk), mk, out), "clpgpu_debug_price_bench")
+        return out
 
     def kernelTimes(self):
         """{kernel: (total ms, launches)} gathered with option timing = 2"""

@@ -308,6 +308,12 @@ int clpgpu_virtual_dual_steps(clpgpu_virtual_group *group, int iterations, int *
  * empty history; matched[i] = its verdict at pivot i (0 none, k a cycle of length k, 100 irregular repeats).  A parity hook:
  * no LP here runs into a cycle on its own. */
 int clpgpu_test_cycle(clpgpu_context *ctx, int count, const int *in, const int *out, const int *wayIn, const int *wayOut, int *matched);
+/* Development hook (no Clp counterpart): the by-column row-pricing kernel -- ClpPackedMatrix::transposeTimesByColumn + the fused
+ * first ratio pass, src/ClpPackedMatrix.cpp:961, :1799 -- launched `reps` times with a dense pi between two pivots of a started
+ * context and timed with HIP events; masks[v] switches parts of the kernel off (1 candidate-count atomics, 2 by-column scatter of the
+ * tableau row, 4 status / dj gathers, 8 the matrix sweep, 16 the gather of pi) so that their cost is measured apart;
+ * microseconds[v] = mean launch time under masks[v].  The per-pivot scratch it overwrites is rewritten by the next pivot. */
+int clpgpu_debug_price_bench(clpgpu_context *ctx, int reps, int numberMasks, const int *masks, double *microseconds);
 /* Parity hook for the engine's host restatement of ClpSimplexProgress::looping (src/ClpSolve.cpp:4438-4611: the loop detector
  * over status checks that statusOfProblemInDual consults, src/ClpSimplexDual.cpp:5506-5536).  Host code only -- needs no device.
  * Check i sees objective[i] / infeasibility[i] / numberInfeasibilities[i] at iteration[i] with progressFlag_ & 3 = flagBits[i]
