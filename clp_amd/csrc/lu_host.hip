@@ -537,8 +537,13 @@ int clpgpu_context::factorizeLu(const std::vector<int> &kcol, const std::vector<
   // a refactorization costs R seconds -> the cost per pivot R / T + a T / 2 is least at T = sqrt(2 R / a)
   // (a = seconds per eta and pivot at the rate the eta kernel reaches); option "lu_max_pivots" caps it
   {
-    const double R = std::chrono::duration<double>(t3 - t0).count();
-    luRefactorSeconds = luRefactorSeconds > 0.0 ? 0.5 * (luRefactorSeconds + R) : R;
+    // R from a cost MODEL of this refactorization, not from the clock: a measured R makes the refactorization points -- and with
+    // them the whole pivot sequence of an ill-conditioned LP -- differ from run to run (two runs of config 4 with the same options
+    // stood 38 000 objective units apart at pivot 16 000, profiles/r04_objective_race.md).  Fitted to the measured phases on the
+    // MI355X box (profiles/r03_lu_final_kernel_stats.txt: k = 11 438, tail 7 162 -> host front 25 ms, tail inversion + polish
+    // 179 ms, build + upload 8 ms): host front ~ 2.2 us per nucleus column, tail ~ 4.9e-13 k2^3 s, 2 ms fixed.
+    const double R = 2.0e-3 + 2.2e-6 * (double)k + 4.9e-13 * (double)k2 * (double)k2 * (double)k2;
+    luRefactorSeconds = R;
     const double a = 8.0 * (double)m / 3.0e12;
     int T = (int)sqrt(2.0 * luRefactorSeconds / a);
     T = std::min(std::max(T, luMinPivots), std::min(luMaxPivots, hLu.tcap - 1));
