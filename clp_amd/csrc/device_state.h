@@ -218,6 +218,7 @@ struct Dev {
   const int *sellRow;
   const double *sellElem;
   int numSlices;
+  int sellWindowed, sellWinBase;  // windowed SELL copy: workgroup b of the pricing kernel holds the columns of compaction block sellWinBase + b (buildSell)
   // the same slices stored tile by tile for the dense-pi form (k_price_tiled): numTiles row tiles of tileRows;
   // segment (tile, slice) at tsStart[tile * numSlices + slice], entry t of lane l at + 64 t + l
   int numTiles, tileRows;

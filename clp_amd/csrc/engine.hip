@@ -273,6 +273,7 @@ struct clpgpu_context {
   // are the fused first ratio pass and the candidate bookkeeping over 10^5 candidates), while the tiled sweep -- one
   // slice per wave, three barrier-separated phases, one workgroup per CU -- takes 50 us (profiles/r03_tiled_pricing.txt)
   int priceTiles = 0;
+  int sellWindows = 1;  // option "sell_windows": the SELL copy sorted by length inside compaction-block windows (buildSell)
   size_t priceTileLds = 0;
   // option "flip_scatter": the waves that detect a bound flip scatter its column into per-row slots
   // (1: sparse LPs with light rows only; 2: any sparse LP -- tests); 0 = the single-workgroup assembly
@@ -1035,8 +1036,36 @@ int clpgpu_context::buildSell()
           tileCount[(size_t)i * numTiles + row[p] / tileRows]++;
     }
   }
+  // Windowed copy (default; option "sell_windows"): the columns are sorted by length only INSIDE windows of PRICE_BLOCK
+  // consecutive keys aligned with the compaction blocks of the N-wide kernels, four slices per window, so that one workgroup
+  // of the pricing kernel owns one compaction block: coalesced tableau-row / flag stores and one candidate count per workgroup
+  // (priceSellBody).  Costs ~9 % padding on Poisson column counts (the global sort pads ~0 %).  The tiled form keeps the
+  // global order (its tile profiles need it).
+  const bool windowed = sellWindows && numTiles == 0 && first >= D.firstColumn && (first - D.firstColumn) % PRICE_BLOCK == 0;
+  const int winBase = windowed ? (first - D.firstColumn) / PRICE_BLOCK : 0;
+  std::vector<int> windowLong;
+  if (windowed) {
+    const int nWin = count > 0 ? cdiv(last - D.firstColumn, PRICE_BLOCK) - winBase : 0;
+    std::vector<int> placed((size_t)nWin * PRICE_BLOCK, -1), cols;
+    for (int w = 0; w < nWin; w++) {
+      const int jlo = std::max(first, D.firstColumn + (winBase + w) * PRICE_BLOCK);
+      const int jhi = std::min(last, D.firstColumn + (winBase + w + 1) * PRICE_BLOCK);
+      cols.clear();
+      for (int j = jlo; j < jhi; j++) {
+        if (colStart[j + 1] - colStart[j] > SELL_LONG)
+          windowLong.push_back(j);
+        else
+          cols.push_back(j);
+      }
+      std::stable_sort(cols.begin(), cols.end(), [&](int a, int b) { return colStart[a + 1] - colStart[a] > colStart[b + 1] - colStart[b]; });
+      for (size_t i = 0; i < cols.size(); i++)
+        placed[(size_t)w * PRICE_BLOCK + i] = cols[i];
+    }
+    order.swap(placed);
+  }
   // columns by decreasing length; with tiles, columns of equal length by their entries per tile, so that the 64
   // columns of a slice have similar tile profiles and the per-tile segments pad by ~10 % instead of ~50 %
+  if (!windowed)
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
     const int la = colStart[a + 1] - colStart[a], lb = colStart[b + 1] - colStart[b];
     if (la != lb)
@@ -1053,19 +1082,26 @@ int clpgpu_context::buildSell()
   // the rest of the chip waits (power-law column counts): they leave the SELL copy and are priced by
   // a wave each (priceLongBody).  `order` is sorted by decreasing length, so they are its prefix.
   int nLong = 0;
-  while (nLong < count && colStart[order[nLong] + 1] - colStart[order[nLong]] > SELL_LONG)
-    nLong++;
-  std::vector<int> longCols(order.begin(), order.begin() + nLong);
-  order.erase(order.begin(), order.begin() + nLong);
+  std::vector<int> longCols;
   const int countAll = count;
-  count = countAll - nLong;
+  if (windowed) {
+    longCols = windowLong;
+    nLong = (int)longCols.size();
+    count = (int)order.size();  // positions, -1 where a window has fewer than 256 columns of its own
+  } else {
+    while (nLong < count && colStart[order[nLong] + 1] - colStart[order[nLong]] > SELL_LONG)
+      nLong++;
+    longCols.assign(order.begin(), order.begin() + nLong);
+    order.erase(order.begin(), order.begin() + nLong);
+    count = countAll - nLong;
+  }
   const int numSlices = cdiv(count, 64);
   std::vector<int> sellStart(numSlices + 1, 0), sellCol((size_t)numSlices * 64, -1), sellLen((size_t)numSlices * 64, 0);
   for (int s = 0; s < numSlices; s++) {
     int maxLen = 0;
     for (int l = 0; l < 64; l++) {
       int i = s * 64 + l;
-      if (i < count) {
+      if (i < count && order[i] >= 0) {
         int j = order[i];
         sellCol[i] = j;
         sellLen[i] = colStart[j + 1] - colStart[j];
@@ -1081,7 +1117,7 @@ int clpgpu_context::buildSell()
   for (int s = 0; s < numSlices; s++)
     for (int l = 0; l < 64; l++) {
       int i = s * 64 + l;
-      if (i >= count)
+      if (i >= count || order[i] < 0)
         continue;
       int j = order[i];
       size_t base = (size_t)sellStart[s] + l;
@@ -1192,6 +1228,8 @@ int clpgpu_context::buildSell()
   D.sellRow = dRow;
   D.sellElem = dElem;
   D.numSlices = numSlices;
+  D.sellWindowed = windowed ? 1 : 0;
+  D.sellWinBase = winBase;
   D.longCol = dLong;
   D.numLong = nLong;
   D.numTiles = 0;
@@ -4590,6 +4628,7 @@ clpgpu_context *clpgpu_clone(const clpgpu_context *src)
   ctx->registerPanel = src->registerPanel;
   ctx->rowPriceFrac = src->rowPriceFrac;
   ctx->priceTiles = src->priceTiles;
+  ctx->sellWindows = src->sellWindows;
   ctx->flipScatter = src->flipScatter;
   ctx->flipSlotCap = src->flipSlotCap;
   ctx->refreshMinK = src->refreshMinK;
@@ -4908,6 +4947,13 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "flip_slot_cap")) { ctx->flipSlotCap = std::max(1, std::min((int)v, (int)FLIP_SLOTS)); ctx->dropGraph(); }
   else if (!strcmp(name, "flip_scatter")) { ctx->flipScatter = v >= 2.0 ? 2 : (v != 0.0 ? 1 : 0); ctx->dropGraph(); }
   else if (!strcmp(name, "row_price_frac")) { ctx->rowPriceFrac = v < 0.0 ? 0.0 : v; ctx->dropGraph(); }
+  else if (!strcmp(name, "sell_windows")) {
+    ctx->sellWindows = v != 0.0;
+    if (ctx->n > 0 && ctx->D.colStart) {
+      ctx->dropGraph();
+      return ctx->buildSell();
+    }
+  }
   else if (!strcmp(name, "price_tiles")) {
     if (ctx->n > 0 && ctx->D.colStart)
       return -2;  // decides what buildSell lays out: set before clpgpu_load_problem

@@ -2421,6 +2421,8 @@ __device__ inline void priceSellBody(Dev D, unsigned long long *bits, int countC
     }
   };
   double ratio = 1.0e31, bytes = 0.0;
+  int jOut = -1, flagOut = 0;  // this lane's column and its results, for the windowed write-out below
+  double valueOut = 0.0;
   if (slice < D.numSlices) {
     const int idx = slice * 64 + lane;
     const int j = D.sellCol[idx];
@@ -2552,13 +2554,45 @@ __device__ inline void priceSellBody(Dev D, unsigned long long *bits, int countC
           value = 0.0;
         }
       }
-      const int at = ((dbg & 2) && idx < D.n) ? idx : j;
-      D.alphaCol[at] = value;
-      D.candFlag[D.m + at] = (unsigned char)flag;
-      // candidate count of the column's compaction block (integer atomic: order independent)
-      if (flag && countCols && !(dbg & 1))
-        atomicAdd(&D.blockCount[((D.m + PRICE_BLOCK - 1) / PRICE_BLOCK) + ((j - D.firstColumn) / PRICE_BLOCK)], 1);
+      jOut = j;
+      valueOut = value;
+      flagOut = flag;
+      if (!D.sellWindowed) {
+        const int at = ((dbg & 2) && idx < D.n) ? idx : j;
+        D.alphaCol[at] = value;
+        D.candFlag[D.m + at] = (unsigned char)flag;
+        // candidate count of the column's compaction block (integer atomic: order independent)
+        if (flag && countCols && !(dbg & 1))
+          atomicAdd(&D.blockCount[((D.m + PRICE_BLOCK - 1) / PRICE_BLOCK) + ((j - D.firstColumn) / PRICE_BLOCK)], 1);
+      }
     }
+  }
+  if (D.sellWindowed) {
+    // Windowed SELL copy (buildSell): this workgroup's four slices hold exactly the columns of ONE compaction block of the
+    // N-wide kernels -- keys j0 .. j0 + 255, sorted by length inside the window only -- so the tableau row and the flags
+    // go out as two coalesced stores through LDS, and the block's candidate count is one integer per workgroup: no
+    // 200 000 scattered 8-byte stores and no per-candidate atomics (measured apart with clpgpu_debug_price_bench: -10 us and
+    // -2 us of the 68 us launch, profiles/r04_price_probe.txt).  Columns of the window that live elsewhere (long columns:
+    // priceLongBody writes and counts them itself) keep the 0xFF mark and are left alone.
+    __shared__ double shAlpha[PRICE_BLOCK];
+    __shared__ unsigned char shFlag[PRICE_BLOCK];
+    __shared__ int shCount[17];
+    const int j0 = D.firstColumn + (D.sellWinBase + (int)blockIdx.x) * PRICE_BLOCK;
+    shFlag[threadIdx.x] = 0xFF;
+    __syncthreads();
+    if (jOut >= 0) {
+      shAlpha[jOut - j0] = valueOut;
+      shFlag[jOut - j0] = (unsigned char)flagOut;
+    }
+    __syncthreads();
+    const unsigned char f = shFlag[threadIdx.x];
+    if (f != 0xFF) {
+      D.alphaCol[j0 + threadIdx.x] = shAlpha[threadIdx.x];
+      D.candFlag[D.m + j0 + threadIdx.x] = f;
+    }
+    const int total = blockSumInt(f == 1 ? 1 : 0, shCount);
+    if (threadIdx.x == 0 && total && countCols && !(dbg & 1))
+      atomicAdd(&D.blockCount[((D.m + PRICE_BLOCK - 1) / PRICE_BLOCK) + D.sellWinBase + (int)blockIdx.x], total);
   }
   double bmin = blockMin(ratio, shd);
   double bsum = blockSum(bytes, shd);

@@ -590,7 +590,7 @@ int clpgpu_context::luBtran(const double *cPos, double *yRow)
   hipLaunchKernelGGL(k_lu_bt_gather, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 0, yRow);
   hipLaunchKernelGGL(k_lu_bt_front, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 0, D.slotA);
   if (k2)
-    hipLaunchKernelGGL(k_lu_gemvT, dim3(cdiv(k2, 4)), dim3(256), 0, stream, D, 0, (const double *)D.slotA);
+    hipLaunchKernelGGL(k_lu_gemvT, dim3(cdiv(k2, 16)), dim3(256), 0, stream, D, 0, (const double *)D.slotA);
   hipLaunchKernelGGL(k_lu_bt_back, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 0, yRow);
   return 0;
 }
@@ -603,7 +603,7 @@ void clpgpu_context::luLaunchBtran()
   KL("k_lu_cprime", k_lu_cprime, dim3(1), dim3(1024), 0, stream, D, 1, (const double *)nullptr);
   KL("k_lu_bt_gather", k_lu_bt_gather, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, (double *)nullptr);
   KL("k_lu_bt_front", k_lu_bt_front, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, D.slotA);
-  KL("k_lu_gemvT", k_lu_gemvT, dim3(cdiv(kc, 4)), dim3(256), 0, stream, D, 1, (const double *)D.slotA);
+  KL("k_lu_gemvT", k_lu_gemvT, dim3(cdiv(kc, 16)), dim3(256), 0, stream, D, 1, (const double *)D.slotA);
   KL("k_lu_bt_back", k_lu_bt_back, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, (double *)nullptr);
 }
 // ... and the three FTRANs (entering column, rho, flip rhs) up to the scatter with the eta file applied

@@ -33,11 +33,85 @@ namespace clpgpu {
 // while the captured launch graphs stay valid)
 #define LUD (*D.lu)
 #define LU_TCAP_MAX 2048  // capacity of the eta file (rows of G, LDS staging of its vectors)
+#define LUG_ROWS 4        // rows of the dense tail (inverse or its transpose) one wave carries through a GEMV
 
 // One sparse operator application in gather form: out[tgt] = (srcv[src] - sum val * vec[idx]) / div, every item
 // independent of the others.  The triangular factors of the front are applied through their EXPLICIT sparse
 // inverses (lu_host.hip builds them: on these LPs L^-1 and U11^-1 [I | -U12] hold < 2x the entries of L and U),
 // so a solve with the front is one such pass over the whole chip instead of a level-by-level dependency chain.
+// The dot products of one item per wave (items it = 4 * workgroup + wave), NV vectors at once: a[u] = -sum val * load(idx, u),
+// valid in lane 0.  Rows of the explicit inverses run from one entry to thousands, and a pass is only as fast as its longest
+// row: a row longer than LU_LONG_ROW is summed by the WHOLE workgroup (256 strided partial sums, a butterfly per wave, the four
+// waves in order -- a fixed tree, deterministic) instead of by its one wave in len / 64 dependent trips.  Every thread of the
+// workgroup must call this (it has barriers); items beyond nItems count as empty rows.
+#define LU_LONG_ROW 192
+template <int NV, class F> __device__ inline void luRowDots(const LuTri &T, int it, F load, double (&a)[NV])
+{
+  __shared__ int shE0[4], shLen[4];
+  __shared__ double shPart[4][NV][4];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int e0 = 0, len = 0;
+  if (it < T.nItems) {
+    e0 = T.entStart[it];
+    len = T.entStart[it + 1] - e0;
+  }
+  if (lane == 0) {
+    shE0[wv] = e0;
+    shLen[wv] = len;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < NV; u++)
+    a[u] = 0.0;
+  if (len <= LU_LONG_ROW) {
+    for (int e = e0 + lane; e < e0 + len; e += 64) {
+      const int idx = T.entIdx[e];
+      const double val = T.entVal[e];
+#pragma unroll
+      for (int u = 0; u < NV; u++)
+        a[u] -= val * load(idx, u);
+    }
+    if (len > 1) {
+#pragma unroll
+      for (int u = 0; u < NV; u++)
+        a[u] = waveSum(a[u]);
+    }
+  }
+  bool any = false;
+  for (int q = 0; q < 4; q++) {
+    const int lq = shLen[q];
+    if (lq <= LU_LONG_ROW)
+      continue;  // (uniform over the workgroup)
+    any = true;
+    const int b = shE0[q];
+    double p[NV];
+#pragma unroll
+    for (int u = 0; u < NV; u++)
+      p[u] = 0.0;
+    for (int e = b + (int)threadIdx.x; e < b + lq; e += 256) {
+      const int idx = T.entIdx[e];
+      const double val = T.entVal[e];
+#pragma unroll
+      for (int u = 0; u < NV; u++)
+        p[u] -= val * load(idx, u);
+    }
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+      p[u] = waveSum(p[u]);
+      if (lane == 0)
+        shPart[q][u][wv] = p[u];
+    }
+  }
+  if (any) {
+    __syncthreads();
+    if (len > LU_LONG_ROW) {
+#pragma unroll
+      for (int u = 0; u < NV; u++)
+        a[u] = ((shPart[wv][u][0] + shPart[wv][u][1]) + shPart[wv][u][2]) + shPart[wv][u][3];
+    }
+  }
+}
+
 // ---- FTRAN, front half: [y_F ; tail rhs] = L^-1 v for the three right-hand sides (given by row).
 // item = local nucleus row; target < k: a front row (work vector), >= k: tail slot target - k (the GEMV's input)
 __global__ void __launch_bounds__(256) k_lu_fwd(Dev D, int chain, const double *v0, const double *v1, const double *v2, double *t0,
@@ -49,32 +123,16 @@ __global__ void __launch_bounds__(256) k_lu_fwd(Dev D, int chain, const double *
   const LuTri T = LUD.Lf;
   // one wave per item: rows of the explicit inverses run from one entry to thousands
   const int it = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (it >= T.nItems)
-    return;
   bool l0 = v0 != nullptr, l1 = v1 != nullptr, l2 = v2 != nullptr;
   if (chain) {
     l1 = c->pivotRule != 0;
     l2 = c->numberFlips != 0;
   }
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-  const int e0 = T.entStart[it], e1 = T.entStart[it + 1];
-  for (int e = e0 + lane; e < e1; e += 64) {
-    const int idx = T.entIdx[e];
-    const double val = T.entVal[e];
-    if (l0)
-      a0 -= val * v0[idx];
-    if (l1)
-      a1 -= val * v1[idx];
-    if (l2)
-      a2 -= val * v2[idx];
-  }
-  if (e1 - e0 > 1) {
-    a0 = waveSum(a0);
-    a1 = waveSum(a1);
-    a2 = waveSum(a2);
-  }
-  if (lane != 0)
+  double acc[3];
+  luRowDots<3>(T, it, [&](int idx, int u) -> double { return u == 0 ? (l0 ? v0[idx] : 0.0) : (u == 1 ? (l1 ? v1[idx] : 0.0) : (l2 ? v2[idx] : 0.0)); }, acc);
+  if (it >= T.nItems || lane != 0)
     return;
+  double a0 = acc[0], a1 = acc[1], a2 = acc[2];
   const int src = T.src[it];
   a0 = l0 ? v0[src] + a0 : 0.0;
   a1 = l1 ? v1[src] + a1 : 0.0;
@@ -112,33 +170,19 @@ __global__ void __launch_bounds__(256) k_lu_bwd(Dev D, int chain, const double *
   }
   int col;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  const double *w0 = LUD.wr, *w1 = LUD.wr + kpad, *w2 = LUD.wr + 2 * kpad;
+  {
+    double acc[3];
+    luRowDots<3>(T, it, [&](int idx, int u) -> double {
+      if (idx < k)
+        return u == 0 ? (l0 ? w0[idx] : 0.0) : (u == 1 ? (l1 ? w1[idx] : 0.0) : (l2 ? w2[idx] : 0.0));
+      return u == 0 ? (l0 ? x0[idx - k] : 0.0) : (u == 1 ? (l1 ? x1[idx - k] : 0.0) : (l2 ? x2[idx - k] : 0.0));
+    }, acc);
+    a0 = acc[0];
+    a1 = acc[1];
+    a2 = acc[2];
+  }
   if (it < T.nItems) {
-    const double *w0 = LUD.wr, *w1 = LUD.wr + kpad, *w2 = LUD.wr + 2 * kpad;
-    const int e0 = T.entStart[it], e1 = T.entStart[it + 1];
-    for (int e = e0 + lane; e < e1; e += 64) {
-      const int idx = T.entIdx[e];
-      const double val = T.entVal[e];
-      if (idx < k) {
-        if (l0)
-          a0 -= val * w0[idx];
-        if (l1)
-          a1 -= val * w1[idx];
-        if (l2)
-          a2 -= val * w2[idx];
-      } else {
-        if (l0)
-          a0 -= val * x0[idx - k];
-        if (l1)
-          a1 -= val * x1[idx - k];
-        if (l2)
-          a2 -= val * x2[idx - k];
-      }
-    }
-    if (e1 - e0 > 1) {
-      a0 = waveSum(a0);
-      a1 = waveSum(a1);
-      a2 = waveSum(a2);
-    }
     if (lane != 0)
       return;
     const int src = T.src[it];
@@ -286,6 +330,67 @@ __device__ inline void luPfApply(const Dev &D, int t, int p, const double *s0, c
   }
 }
 
+// The same for the 256 positions base .. base + 255 of one workgroup, as the chain needs it: wave w takes the etas of quarter w of
+// the file for ALL 256 positions (four per lane), 4 etas x 4 positions = 16 loads in flight per lane, and the four partial sums of
+// a position are added in wave order -- 64 KB of H in flight per workgroup instead of 16 (one thread per position and eight loads
+// in flight left this stream at 0.35-0.42 of the HBM peak).  d1..d3 = -(H s) at position base + threadIdx.x.
+__device__ inline void luPfApplyWg(const Dev &D, int t, int base, const double *s0, const double *s1, const double *s2, double *part /*[4][3][256]*/,
+                                   double &d1, double &d2, double &d3)
+{
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t m = (size_t)D.m;
+  const int j0 = (int)(((long long)t * w) / 4), j1 = (int)(((long long)t * (w + 1)) / 4);
+  double acc[4][3];
+  bool live[4];
+  const double *Hp[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    acc[q][0] = acc[q][1] = acc[q][2] = 0.0;
+    const int p = base + lane + 64 * q;
+    live[q] = p < D.m;
+    Hp[q] = LUD.H + (live[q] ? p : 0);
+  }
+  int j = j0;
+  for (; j + 4 <= j1; j += 4) {
+    double h[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        h[u][q] = live[q] ? Hp[q][(size_t)(j + u) * m] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const double a = s0[j + u], b = s1[j + u], cc = s2[j + u];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        acc[q][0] -= h[u][q] * a;
+        acc[q][1] -= h[u][q] * b;
+        acc[q][2] -= h[u][q] * cc;
+      }
+    }
+  }
+  for (; j < j1; j++) {
+    const double a = s0[j], b = s1[j], cc = s2[j];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const double h = live[q] ? Hp[q][(size_t)j * m] : 0.0;
+      acc[q][0] -= h * a;
+      acc[q][1] -= h * b;
+      acc[q][2] -= h * cc;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+#pragma unroll
+    for (int v = 0; v < 3; v++)
+      part[(w * 3 + v) * 256 + lane + 64 * q] = acc[q][v];
+  __syncthreads();
+  const int tid = threadIdx.x;
+  d1 = ((part[(0 * 3 + 0) * 256 + tid] + part[(1 * 3 + 0) * 256 + tid]) + part[(2 * 3 + 0) * 256 + tid]) + part[(3 * 3 + 0) * 256 + tid];
+  d2 = ((part[(0 * 3 + 1) * 256 + tid] + part[(1 * 3 + 1) * 256 + tid]) + part[(2 * 3 + 1) * 256 + tid]) + part[(3 * 3 + 1) * 256 + tid];
+  d3 = ((part[(0 * 3 + 2) * 256 + tid] + part[(1 * 3 + 2) * 256 + tid]) + part[(2 * 3 + 2) * 256 + tid]) + part[(3 * 3 + 2) * 256 + tid];
+}
+
 // generic form (refactorization boundary, plug-in calls): out_r = x0_r - H s_r
 __global__ void __launch_bounds__(256) k_lu_pf_apply(Dev D, double *o0, double *o1, double *o2)
 {
@@ -426,18 +531,12 @@ __global__ void __launch_bounds__(256) k_lu_bt_front(Dev D, int chain, double *z
     return;
   const LuTri T = LUD.Utf;
   const int it = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (it >= T.nItems)
-    return;
   const double *tcv = LUD.tcv;
-  double acc = 0.0;
-  const int e0 = T.entStart[it], e1 = T.entStart[it + 1];
-  for (int e = e0 + lane; e < e1; e += 64)
-    acc -= T.entVal[e] * tcv[T.entIdx[e]];
-  if (e1 - e0 > 1)
-    acc = waveSum(acc);
-  if (lane != 0)
+  double dots[1];
+  luRowDots<1>(T, it, [&](int idx, int) -> double { return tcv[idx]; }, dots);
+  if (it >= T.nItems || lane != 0)
     return;
-  acc = (tcv[T.src[it]] + acc) / T.div[it];
+  double acc = (tcv[T.src[it]] + dots[0]) / T.div[it];
   const int tgt = T.tgt[it], k = LUD.k;
   if (tgt < k)
     LUD.wr[tgt] = acc;
@@ -454,25 +553,45 @@ __global__ void __launch_bounds__(256) k_lu_gemvT(Dev D, int chain, const double
     return;
   const int k2 = LUD.k2;
   const int lane = threadIdx.x & 63;
-  for (int ts = blockIdx.x * 4 + (threadIdx.x >> 6); ts < k2; ts += gridDim.x * 4) {
-    const double *row = LUD.MinvT + (size_t)ts * D.ld;
-    double a0 = 0.0, a1 = 0.0;
-    int i = lane;
-    for (; i + 64 < k2; i += 128) {
-      a0 += row[i] * zt[i];
-      a1 += row[i + 64] * zt[i + 64];
+  // four rows per wave, 16-byte loads, two strips of 128 columns per trip: 8 x 1 KB in flight per wave (one row per wave with two
+  // 8-byte loads in flight left the HBM stream at 0.52 of its peak, profiles/r03_bench_line_default.json)
+  for (int ts0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LUG_ROWS; ts0 < k2; ts0 += gridDim.x * 4 * LUG_ROWS) {
+    double acc[LUG_ROWS];
+    const double *row[LUG_ROWS];
+#pragma unroll
+    for (int r = 0; r < LUG_ROWS; r++) {
+      acc[r] = 0.0;
+      row[r] = LUD.MinvT + (size_t)min(ts0 + r, k2 - 1) * D.ld;
     }
-    if (i < k2)
-      a0 += row[i] * zt[i];
-    const double acc = waveSum(a0 + a1);
-    if (lane == 0)
-      LUD.wr[LUD.tailRow[ts]] = acc;
+    for (int i = 2 * lane; i < k2; i += 256) {
+      const int ib = i + 128;
+      const bool vb = ib < k2, ya = i + 1 < k2, yb = ib + 1 < k2;
+      double2 ma[LUG_ROWS], mb[LUG_ROWS];
+#pragma unroll
+      for (int r = 0; r < LUG_ROWS; r++) {
+        ma[r] = *reinterpret_cast<const double2 *>(row[r] + i);
+        mb[r] = vb ? *reinterpret_cast<const double2 *>(row[r] + ib) : make_double2(0.0, 0.0);
+      }
+      const double za0 = zt[i], za1 = ya ? zt[i + 1] : 0.0, zb0 = vb ? zt[ib] : 0.0, zb1 = yb ? zt[ib + 1] : 0.0;
+#pragma unroll
+      for (int r = 0; r < LUG_ROWS; r++) {
+        acc[r] += ma[r].x * za0;
+        acc[r] += (ya ? ma[r].y : 0.0) * za1;
+        acc[r] += mb[r].x * zb0;
+        acc[r] += (yb ? mb[r].y : 0.0) * zb1;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < LUG_ROWS; r++) {
+      const double sum = waveSum(acc[r]);
+      if (lane == 0 && ts0 + r < k2)
+        LUD.wr[LUD.tailRow[ts0 + r]] = sum;
+    }
   }
 }
 // x_T = S^-1 v_T for the three FTRAN right-hand sides in one sweep of the tail inverse.  One wave per FOUR rows:
 // the three vectors (slotV1 / rhoSlotF / flipSlot, from L2) are loaded once per column and used against four
 // matrix rows, so the kernel issues 7 loads per 12 multiply-adds instead of 4 per 3; skip rules as in k_gemv3g
-#define LUG_ROWS 4
 __global__ void __launch_bounds__(256) k_lu_gemv3(Dev D)
 {
   const Ctrl *c = D.ctrl;
@@ -490,17 +609,34 @@ __global__ void __launch_bounds__(256) k_lu_gemv3(Dev D)
       a1[r] = a2[r] = a3[r] = 0.0;
       row[r] = D.Minv + (size_t)min(sc0 + r, k2 - 1) * D.ld;
     }
-    for (int i = lane; i < k2; i += 64) {
-      const double x1 = v1[i], x2 = doTau ? v2[i] : 0.0, x3 = doFlip ? v3[i] : 0.0;
-      double mv[LUG_ROWS];
-#pragma unroll
-      for (int r = 0; r < LUG_ROWS; r++)
-        mv[r] = row[r][i];
+    // 16-byte loads, two strips of 128 columns per trip: 8 x 1 KB of the matrix in flight per wave
+    for (int i = 2 * lane; i < k2; i += 256) {
+      const int ib = i + 128;
+      const bool vb = ib < k2, ya = i + 1 < k2, yb = ib + 1 < k2;
+      double2 ma[LUG_ROWS], mb[LUG_ROWS];
 #pragma unroll
       for (int r = 0; r < LUG_ROWS; r++) {
-        a1[r] += mv[r] * x1;
-        a2[r] += mv[r] * x2;
-        a3[r] += mv[r] * x3;
+        ma[r] = *reinterpret_cast<const double2 *>(row[r] + i);
+        mb[r] = vb ? *reinterpret_cast<const double2 *>(row[r] + ib) : make_double2(0.0, 0.0);
+      }
+      double xs[3][4];  // [vector][strip a: i, i + 1; strip b: ib, ib + 1]
+      const int at[4] = { i, i + 1, ib, ib + 1 };
+      const bool ok[4] = { true, ya, vb, yb };
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        xs[0][u] = ok[u] ? v1[at[u]] : 0.0;
+        xs[1][u] = (ok[u] && doTau) ? v2[at[u]] : 0.0;
+        xs[2][u] = (ok[u] && doFlip) ? v3[at[u]] : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < LUG_ROWS; r++) {
+        const double mv[4] = { ma[r].x, ya ? ma[r].y : 0.0, mb[r].x, yb ? mb[r].y : 0.0 };
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          a1[r] += mv[u] * xs[0][u];
+          a2[r] += mv[u] * xs[1][u];
+          a3[r] += mv[u] * xs[2][u];
+        }
       }
     }
 #pragma unroll
@@ -553,17 +689,11 @@ __global__ void __launch_bounds__(256) k_lu_bt_back(Dev D, int chain, double *y)
       LUD.cp[g] = 0.0;
     }
   }
-  if (it >= T.nItems)
-    return;
   const double *wr = LUD.wr;
-  double acc = 0.0;
-  const int e0 = T.entStart[it], e1 = T.entStart[it + 1];
-  for (int e = e0 + lane; e < e1; e += 64)
-    acc -= T.entVal[e] * wr[T.entIdx[e]];
-  if (e1 - e0 > 1)
-    acc = waveSum(acc);
-  if (lane == 0)
-    yout[LUD.rowOfLocal[T.tgt[it]]] = wr[T.src[it]] + acc;
+  double dots[1];
+  luRowDots<1>(T, it, [&](int idx, int) -> double { return wr[idx]; }, dots);
+  if (it < T.nItems && lane == 0)
+    yout[LUD.rowOfLocal[T.tgt[it]]] = wr[T.src[it]] + dots[0];
 }
 
 // ---- the update: a new eta (column t of H), its position, and row t of G.
@@ -635,12 +765,14 @@ __global__ void __launch_bounds__(256) k_ftran_scatter3_lu(Dev D, int nbNorm, in
   const int tt = blockIdx.x * blockDim.x + threadIdx.x;
   int p = -1;
   double x1 = 0.0, x2 = 0.0, x3 = 0.0;
+  __shared__ double sPart[4 * 3 * 256];
+  double d1, d2, d3;
+  luPfApplyWg(D, t, blockIdx.x * blockDim.x, sS, sS + LU_TCAP_MAX, sS + 2 * LU_TCAP_MAX, sPart, d1, d2, d3);
   if (tt < D.m) {
     p = tt;
-    x1 = LUD.x0[p];
-    x2 = doTau ? LUD.x0[(size_t)D.m + p] : 0.0;
-    x3 = doFlip ? LUD.x0[2 * (size_t)D.m + p] : 0.0;
-    luPfApply(D, t, p, sS, sS + LU_TCAP_MAX, sS + 2 * LU_TCAP_MAX, x1, x2, x3);
+    x1 = LUD.x0[p] + d1;
+    x2 = doTau ? LUD.x0[(size_t)D.m + p] + d2 : 0.0;
+    x3 = doFlip ? LUD.x0[2 * (size_t)D.m + p] + d3 : 0.0;
     if (doFlip)
       D.flipRhs[tt] = 0.0;  // consumed by k_lu_fwd / k_lu_slack
   }

@@ -78,6 +78,30 @@ def test_price_row_bit_identical(gpu_cls, maker, args, density):
     for x, y in zip(a[:4], b[:4]):
         assert np.array_equal(x, y)
     assert a[4] == b[4]
+    # the globally sorted SELL copy (per-candidate atomics, scattered stores) next to the default windowed one: same bits
+    g.set_option("sell_windows", 0)
+    a = g.priceRow(idx, val, status, dj)
+    for x, y in zip(a[:4], b[:4]):
+        assert np.array_equal(x, y)
+    assert a[4] == b[4]
+
+
+def test_windowed_and_global_sell_copies_give_the_same_solve(gpu_cls):
+    """Whole solves through the engine's chain (pricing variant 6, candidate counts from the pricing kernel) with the windowed SELL
+    copy (default) and the globally sorted one: same pivots, same solution bits; also on a power-law LP whose long columns leave
+    the SELL copy (priceLongBody counts its own candidates next to the windows' per-workgroup counts)."""
+    for lp, rule in ((P.sparse_lp(2000, 70000, 12, 13), 1), (P.netlib_shaped_lp(2000, 66000, 400000, seed=21), 1)):
+        runs = []
+        for windows in (1, 0):
+            g = gpu_cls().loadProblem(lp)
+            g.set_option("pivot_rule", rule)
+            g.set_option("sell_windows", windows)
+            g.set_option("row_price_frac", 0.0)  # every tableau row by column
+            assert g.dual_steps(400) in (-1, 0)
+            runs.append(g)
+        a, b = runs[0].pivotLog(), runs[1].pivotLog()
+        assert len(a) == len(b) and np.array_equal(a["sequenceIn"], b["sequenceIn"]) and np.array_equal(a["sequenceOut"], b["sequenceOut"])
+        assert np.array_equal(runs[0].solution(), runs[1].solution())
 
 
 def test_price_row_committed_golden(gpu_cls):
