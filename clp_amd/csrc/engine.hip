@@ -160,6 +160,8 @@ struct clpgpu_context {
   int numberBackwards = 0, numberLoopFlags = 0;  // statistics: backwards-objective restores, loops acted upon
   int debugBackwardsAt = -1;  // fault injection (option debug_backwards_at), as in the oracle
   int debugPoisonInverseAt = -1, numberPoisoned = 0;  // fault injection (option debug_poison_inverse_at)
+  int debugResetWeightsAt = -1;  // option debug_reset_weights_at (experiment)
+  int dseResetEvery = 0, dseResetCounter = 0, numberWeightResets = 0;  // option dse_reset_every (experiment): uniform weights again every N-th refactorization
   int debugBadAccuracyAt = -1, numberAccuracyRestores = 0;  // fault injection (option debug_bad_accuracy_at) and its count
   int debugSingularAt = -1, numberSingularRestores = 0;     // fault injection (option debug_singular_at) and the count of such restores
   void progressReset();
@@ -1579,8 +1581,11 @@ int clpgpu_context::factorizeOnce()
   }
   const int k = (int)kcol.size();
   numberRefactorizations++;
-  // (column-sharded runs keep the explicit inverse: the LU chain has not been run with an exchange in it)
-  bool wantLu = k > 0 && !commActive && (factorMode == 1 || (factorMode < 0 && !wideRows && k >= luMinK));
+  // (column-sharded runs too: the factorization, both solves and the eta file live in row space and are replicated on every rank --
+  // only pricing, the candidate and flip lists and the reduced costs of the columns are sharded, and the two exchanges sit between
+  // kernels the LU chain does not touch; tests/test_gpu_virtual_ranks.py runs 2 and 4 loopback ranks in LU mode against the
+  // unsharded LU-mode engine)
+  bool wantLu = k > 0 && (factorMode == 1 || (factorMode < 0 && !wideRows && k >= luMinK));
   // an LP whose front inverses exceeded lu_inverse_fill_cap (factorizeLu -> -7) is not asked again at every refactorization
   // (the front, the tail inversion and the polish would all run before the cap is seen): the next few refactorizations at a
   // similar nucleus size go straight to the explicit inverse
@@ -3100,6 +3105,19 @@ int clpgpu_context::statusOfProblemInDual(int type)
       } else {
         rc |= saveWeights(6);  // reset weights or scale back
       }
+      // experiment knobs (profiles/r04_objective_race.md): what a mature config-4 run gains from fresh steepest-edge weights, or from
+      // its true costs, alone -- once, at the first status check from the given iteration on
+      if (dseResetEvery > 0 && type && ++dseResetCounter >= dseResetEvery) {
+        dseResetCounter = 0;
+        rc |= saveWeights(6);
+        numberWeightResets++;
+      }
+      if (debugResetWeightsAt >= 0 && numberIterations >= debugResetWeightsAt) {
+        debugResetWeightsAt = -1;
+        rc |= saveWeights(6);
+        if (logLevel > 0)
+          fprintf(stderr, "clpgpu: iteration %d: steepest-edge weights reset (debug_reset_weights_at)\n", numberIterations);
+      }
     }
   } else if (dirty) {
     rc |= pushRim();
@@ -3537,6 +3555,9 @@ int clpgpu_context::whileIterating(int stepTarget)
   progressFlag = (progressFlag & ~3) | (hCtrl->progressFlag & 3);
   const int state = hCtrl->state;
   lastExitState = state;
+  if (logLevel > 2)
+    fprintf(stderr, "clpgpu: loop left with state %d at iteration %d: pivotRow %d sequenceOut %d sequenceIn %d, %d pivots since the factorization, %d candidates, best possible pivot %g, acceptable %g\n",
+            state, numberIterations, hCtrl->pivotRow, hCtrl->sequenceOut, hCtrl->sequenceIn, pivots, hCtrl->numberCandidates, hCtrl->bestPossible, hCtrl->acceptablePivot);
   const int g = cdiv(m, 256);
   if (state != EXIT_REFACTOR && state != EXIT_STEP_LIMIT && state != EXIT_MAX_ITERATIONS) {
     // the pivot was abandoned part-way: k_house did not clear the sparse work vectors
@@ -3592,6 +3613,8 @@ int clpgpu_context::whileIterating(int stepTarget)
     commMode = 1;
     D.firstColumn = 0;
     D.lastColumn = n;
+    if (D.sellWindowed)
+      D.sellWinBase = D.priceFirst / PRICE_BLOCK;  // the windows stay aligned (shard starts are multiples of PRICE_BLOCK); their block numbers move
     dropGraph();
     if (logLevel > 0)
       fprintf(stderr, "clpgpu: rank %d: exchange buffer overflow at iteration %d, falling back to the dense row exchange\n", rank, numberIterations);
@@ -3614,6 +3637,10 @@ int clpgpu_context::whileIterating(int stepTarget)
   }
   case EXIT_NO_INCOMING: {
     // no incoming column is valid (:1869-2079)
+    // "spareIntArray_[3] = pivotRow_; pivotRow_ = -1;" (:1874-1875): the row is NOT the "last pivot row" of the next CHUZR
+    // (ClpDualRowSteepest::pivotRow makes that one a last-resort choice, src/ClpDualRowSteepest.cpp:224-232); found by the GPU fuzz
+    // (tools/fuzz_gpu.py: one pivot more than the oracle on infeasible LPs)
+    hCtrl->pivotRow = -1;
     problemStatus = -2;
     // "if (sequenceIn_ < 0 && acceptablePivot <= acceptablePivot_) if (!pivots) problemStatus_ = 1" (:1328)
     if (hCtrl->acceptablePivot <= acceptablePivot && !pivots)
@@ -4888,6 +4915,8 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "debug_backwards_at")) ctx->debugBackwardsAt = (int)v;
   else if (!strcmp(name, "debug_poison_inverse_at")) ctx->debugPoisonInverseAt = (int)v;
   else if (!strcmp(name, "debug_bad_accuracy_at")) ctx->debugBadAccuracyAt = (int)v;
+  else if (!strcmp(name, "debug_reset_weights_at")) ctx->debugResetWeightsAt = (int)v;
+  else if (!strcmp(name, "dse_reset_every")) ctx->dseResetEvery = std::max(0, (int)v);
   else if (!strcmp(name, "debug_singular_at")) ctx->debugSingularAt = (int)v;
   else if (!strcmp(name, "log_level")) ctx->logLevel = (int)v;
   else if (!strcmp(name, "check_every")) {

@@ -36,8 +36,7 @@ def same_pivots(a, b, n):
         and np.array_equal(a["pivotRow"][:n], b["pivotRow"][:n])
 
 
-@pytest.mark.parametrize("nranks", [2, 4, 8])
-@pytest.mark.parametrize("mode", [2, 1])
+@pytest.mark.parametrize("nranks,mode", [(2, 2), (4, 2), (8, 2), (4, 1)])
 def test_virtual_ranks_match_unsharded(gpu, nranks, mode):
     lp = P.sparse_lp(2000, 9000, 12, seed=13)
     base = gpu.ClpGpuSimplex(0).loadProblem(lp)
@@ -50,6 +49,33 @@ def test_virtual_ranks_match_unsharded(gpu, nranks, mode):
     assert vr.dual_steps(-1) == [0] * nranks
     ref = base.pivotLog()
     for r, e in enumerate(vr.engines):
+        log = e.pivotLog()
+        assert len(log) == len(ref), f"rank {r}"
+        assert same_pivots(log, ref, len(ref)), f"rank {r}"
+        assert e.objectiveValue() == base.objectiveValue()
+        assert np.array_equal(e.solution(), base.solution())
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_virtual_ranks_in_lu_mode_match_unsharded(gpu, nranks):
+    """The sharded chain with the LU factorization (sparse front + dense tail + eta file, from a nucleus of 256 on) instead of the
+    explicit inverse: factorization, solves and eta file are replicated row-space work, so every rank must make the pivots of the
+    unsharded LU-mode engine and end on the same solution bits."""
+    lp = P.sparse_lp(2000, 9000, 12, seed=13)
+
+    def lu(e, **opts):
+        configure(e, **opts)
+        e.set_option("factor_mode", -1)
+        e.set_option("lu_min_k", 256)
+
+    base = gpu.ClpGpuSimplex(0).loadProblem(lp)
+    lu(base)
+    assert base.dual() == 0 and base.stats()["lu_factorizations"] > 0
+    vr = gpu.VirtualRanks(lp, nranks, configure=lambda e: lu(e, comm_mode=2, shard_cand_cap=16384, shard_flip_cap=4096))
+    assert vr.dual_steps(-1) == [0] * nranks
+    ref = base.pivotLog()
+    for r, e in enumerate(vr.engines):
+        assert e.stats()["lu_factorizations"] > 0, f"rank {r} never factorized in LU mode"
         log = e.pivotLog()
         assert len(log) == len(ref), f"rank {r}"
         assert same_pivots(log, ref, len(ref)), f"rank {r}"
