@@ -26,7 +26,7 @@ Legs (rank 0 prints ONE JSON line):
                 under profiles/ (named in `traffic_source`) when rocprofv3 cannot run.
                 `moved_frac` = traffic / time / peak: what the memory system really delivered.
   cpu_baseline  the CPU oracle (a C restatement of the reference loop -- the reference needs CoinUtils and
-                cannot be built here) on the same LP from the slack basis for >= 500 pivots and >= 2 s,
+                cannot be built here) on the same LP from the slack basis for >= 500 pivots and >= 10 s (at most 2500 pivots),
                 one core; `gpu_same_window` is the engine over exactly those pivots, so the ratio
                 compares like with like.  `clp_upstream` = real `clp` on the same LP written as MPS, when a
                 clp binary is on PATH; null otherwise.
@@ -342,9 +342,9 @@ def main():
             o.set_option("max_pivots", 0)
             o.set_option("max_iterations", n_cpu)
             o.dual()
-            if args.cpu_iterations > 0 or o.seconds >= 2.0 or o.iterations < n_cpu or n_cpu >= 1500:
+            if args.cpu_iterations > 0 or o.seconds >= 10.0 or o.iterations < n_cpu or n_cpu >= 2500:
                 break
-            n_cpu += 500  # 500 -> 1000 -> 1500 pivots: 0.4 / 1.4 / 3.3 s of one Xeon core at config 4
+            n_cpu += 500  # 500 -> ... -> 2500 pivots: 0.4 / 1.4 / 3.3 / ~8 / ~18 s of one Xeon core at config 4 (dense nucleus LU: k^3)
         cpu = {"value": o.iterations / max(o.seconds, 1e-9), "unit": "iterations/s", "cores": 1, "kind": "port",
                "window": [1, int(o.iterations)], "seconds": round(o.seconds, 3),
                "sample": f"pivots 1..{o.iterations} of the same LP from the slack basis ({o.seconds:.2f} s, refactorizations included, "

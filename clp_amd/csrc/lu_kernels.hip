@@ -331,7 +331,7 @@ __device__ inline void luPfApply(const Dev &D, int t, int p, const double *s0, c
 }
 
 // The same for the 256 positions base .. base + 255 of one workgroup, as the chain needs it: wave w takes the etas of quarter w of
-// the file for ALL 256 positions (four per lane), 4 etas x 4 positions = 16 loads in flight per lane, and the four partial sums of
+// the file for ALL 256 positions (four per lane), 8 etas x 4 positions = 32 loads in flight per lane, and the four partial sums of
 // a position are added in wave order -- 64 KB of H in flight per workgroup instead of 16 (one thread per position and eight loads
 // in flight left this stream at 0.35-0.42 of the HBM peak).  d1..d3 = -(H s) at position base + threadIdx.x.
 __device__ inline void luPfApplyWg(const Dev &D, int t, int base, const double *s0, const double *s1, const double *s2, double *part /*[4][3][256]*/,
@@ -351,6 +351,25 @@ __device__ inline void luPfApplyWg(const Dev &D, int t, int base, const double *
     Hp[q] = LUD.H + (live[q] ? p : 0);
   }
   int j = j0;
+  // (one workgroup per CU at this grid: registers are not what limits residency, bytes in flight are -- 8 etas x 4 positions)
+  for (; j + 8 <= j1; j += 8) {
+    double h[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        h[u][q] = live[q] ? Hp[q][(size_t)(j + u) * m] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const double a = s0[j + u], b = s1[j + u], cc = s2[j + u];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        acc[q][0] -= h[u][q] * a;
+        acc[q][1] -= h[u][q] * b;
+        acc[q][2] -= h[u][q] * cc;
+      }
+    }
+  }
   for (; j + 4 <= j1; j += 4) {
     double h[4][4];
 #pragma unroll

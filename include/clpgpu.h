@@ -215,13 +215,20 @@ int clpgpu_unroll_weights(clpgpu_context *ctx);
  * refresh_refine is 0 (a sparse residual kernel + one f64 GEMM from rocBLAS), when the solutions recomputed with
  * it leave max |A x - s| and max basic |dj| below the tolerance, default 1e-6; it re-inverts otherwise and every
  * refresh_max-th time, default 15),
- * "factor_mode" (-1 auto: the LU form from "lu_min_k" = 3072 basic structurals on, for sparse LPs on one rank;
+ * "factor_mode" (-1 auto: the LU form from "lu_min_k" = 3072 basic structurals on, for sparse LPs;
  * 0 explicit inverse of the nucleus; 1 LU form: host Markowitz front + dense tail inverted on the matrix cores +
  * product-form eta file) with "lu_stop_density", "lu_min_tail", "lu_threshold",
  * "lu_inverse_fill_cap" (front / explicit-inverse controls), "lu_max_pivots", "lu_min_pivots", "lu_adaptive" (eta-file
- * length), "lu_polish", "lu_polish_tolerance" (Newton-Schulz steps on the tail inverse),
+ * length: from a cost model of the refactorization, the same on every run), "lu_polish", "lu_polish_tolerance" (Newton-Schulz steps on the tail inverse),
  * "gemm_backend" (0 the engine's own MFMA f64 GEMM, 1 rocBLAS), "solution_refinements" / "refine_above" (iterative
- * refinement of the recomputed primal and dual solutions), "price_tiles" (1: pricing with pi tiles staged in LDS).
+ * refinement of the recomputed primal and dual solutions), "price_tiles" (1: pricing with pi tiles staged in LDS),
+ * "sell_windows" (1 default: the pricing copy of A sorted by column length inside windows of 256 keys, one compaction block
+ * per workgroup -- coalesced tableau-row stores, one candidate count per workgroup; 0: sorted globally, per-candidate atomics),
+ * "fake_bound_cleanup" (1: "infeasible" reached with nonbasic variables still at fake bounds is reported as 10, "clean up in
+ * primal", as ClpSimplex::dual does, src/ClpSimplex.cpp:5800-5803 -- for callers that hold a primal, the clpGpuDual adapter sets
+ * it; 0 default: a bare context reports the 1 it found).  "factor_mode" -1 takes the LU form in column-sharded runs too.
+ * Experiment knobs (profiles/r04_objective_race.md): "dse_reset_every" (uniform steepest-edge weights again at every N-th
+ * refactorization), "debug_reset_weights_at" (once, from this iteration on).
  * Fault injection for the tests: "debug_backwards_at" (the first two status checks at or after this iteration see the
  * objective fall: drives the restore of src/ClpSimplexDual.cpp:5326-5488), "debug_bad_accuracy_at" (the first status
  * check at or after this iteration finds a primal error of 1e16: the restore of :5237-5318), "debug_singular_at" (the

@@ -186,14 +186,19 @@ class OracleSimplex:
         if first and os.path.isdir(_CACHE_DIR):
             path = os.path.join(_CACHE_DIR, self._key() + ".npz")
             if os.path.exists(path):
-                with np.load(path) as z:
-                    self._rec = {k: z[k] for k in z.files}
-                return int(self._rec["counters"][0])
+                try:
+                    with np.load(path) as z:
+                        self._rec = {k: z[k] for k in z.files}
+                    return int(self._rec["counters"][0])
+                except Exception:  # noqa: BLE001 -- an unreadable record is no record: solve live
+                    self._rec = None
         t0 = time.time()
         code = lib().orc_dual(self._h)
         if first and _CACHE_WRITE and time.time() - t0 >= _CACHE_MIN_S:
             os.makedirs(_CACHE_WRITE, exist_ok=True)
-            np.savez_compressed(os.path.join(_CACHE_WRITE, self._key() + ".npz"), **self._snapshot(code))
+            tmp = os.path.join(_CACHE_WRITE, f".{os.getpid()}.tmp.npz")
+            np.savez_compressed(tmp, **self._snapshot(code))
+            os.replace(tmp, os.path.join(_CACHE_WRITE, self._key() + ".npz"))  # a record is either whole or absent
         return code
 
     def _counter(self, index, fn):

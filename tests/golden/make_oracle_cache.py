@@ -57,10 +57,18 @@ class StandIn:
     def setStatusArray(self, status):
         self.o.set_status(np.asarray(status, dtype=np.uint8) & 7)
 
+    def _guard(self, pivots):
+        # engine-only tests on the full-size LPs (9000 pivots at 50 000 rows ...) would cost the dense-LU oracle hours and are
+        # compared with no oracle solve on the GPU box: refuse them here
+        if self.m >= 20000 and (pivots is None or self.n_done + pivots > 2600):
+            raise RuntimeError("stand-in engine: not an oracle-checked workload")
+
     def dual(self):
+        self._guard(None)
         return self.o.dual()
 
     def dual_steps(self, count):
+        self._guard(int(count))
         self.n_done += int(count)
         self.o.set_option("max_iterations", self.n_done)
         st = self.o.dual()
