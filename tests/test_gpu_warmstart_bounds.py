@@ -50,7 +50,7 @@ def test_crossing_row_bounds_on_a_fresh_model(gpu_cls):
     assert g.dual() == 1 and g.numberIterations() == 0
 
 
-@pytest.mark.parametrize("seed,dual_bound", [(28, 5.0)])
+@pytest.mark.parametrize("seed,dual_bound", [(7, 5.0), (28, 20.0), (29, 5.0), (48, 5.0)])
 def test_infeasible_with_fake_bounds_active_is_status_10(gpu_cls, seed, dual_bound):
     """ClpSimplex::dual's second thought (src/ClpSimplex.cpp:5800-5803): "infeasible" reached while nonbasic variables still sit at
     fake bounds is status 10, "clean up in primal".  LPs of the oracle fuzz with free columns and a dual bound far below the
