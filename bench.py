@@ -26,7 +26,7 @@ Legs (rank 0 prints ONE JSON line):
                 under profiles/ (named in `traffic_source`) when rocprofv3 cannot run.
                 `moved_frac` = traffic / time / peak: what the memory system really delivered.
   cpu_baseline  the CPU oracle (a C restatement of the reference loop -- the reference needs CoinUtils and
-                cannot be built here) on the same LP from the slack basis for >= 500 pivots and >= 10 s (at most 2500 pivots),
+                cannot be built here) on the same LP from the slack basis for >= 500 pivots and >= 5 s (at most 2000 pivots: ~17 s of CPU in all),
                 one core; `gpu_same_window` is the engine over exactly those pivots, so the ratio
                 compares like with like.  `clp_upstream` = real `clp` on the same LP written as MPS, when a
                 clp binary is on PATH; null otherwise.
@@ -112,7 +112,7 @@ def pmc_traffic(args, kernel_regex):
         cmd = [exe, "--pmc", counter, "--kernel-trace", "--kernel-include-regex", kernel_regex, "-d", d, "-o", "pmc", "--",
                sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", str(args.steps), "--warmup", str(args.warmup),
                "--rows", str(args.rows), "--cols", str(args.cols), "--nnz-per-col", str(args.nnz_per_col), "--workload", args.workload,
-               "--pivot-rule", str(args.pivot_rule), "--check-every", str(args.check_every), "--start", args.start]
+               "--pivot-rule", str(args.pivot_rule), "--check-every", str(args.check_every), "--start", args.start, "--preroll", str(args.preroll)]
         try:
             env = dict(os.environ, TMPDIR="/tmp")
             p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
@@ -189,6 +189,10 @@ def main():
     ap.add_argument("--start", default="mature", choices=["mature", "slack"],
                     help="mature (default): the timed context starts from the committed basis of the default LP after 30 000 pivots; "
                          "slack: from the slack basis (other workloads always do)")
+    ap.add_argument("--preroll", type=int, default=800,
+                    help="mature start only: untimed pivots between the start-up factorization of the committed basis and the W warm-up pivots, "
+                         "so that the timed window sits in the middle of an eta-file cycle (its length runs 0 .. ~1600) and not right "
+                         "behind a fresh factorization, where pivots are at their cheapest")
     ap.add_argument("--ladder-budget", type=float, default=60.0, help="seconds allowed for the time-to-optimal ladder (0 skips it)")
     ap.add_argument("--ladder-rungs", default="1500,3000,5000,7000,10000,14000,20000")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -221,6 +225,8 @@ def main():
         eng.set_option("use_graph", 0)
         eng.set_option("check_every", 1)  # no launches beyond the step limit: the last K dispatches are the timed pivots
         eng.set_option("row_price_frac", 0.0)  # the by-column sweep the roofline is quoted for
+        if basis is not None and args.preroll > 0:
+            eng.dual_steps(args.preroll)
         eng.dual_steps(args.warmup)
         eng.dual_steps(args.steps)
         torch.cuda.synchronize()
@@ -240,6 +246,9 @@ def main():
     # ---- headline: warm-up (startup: factorize, resync + W pivots), then exactly K timed pivots
     eng = make_engine(args, lp, local_rank, basis)
     attach(eng)
+    preroll = args.preroll if (basis is not None and args.preroll > 0) else 0
+    if preroll:
+        assert eng.dual_steps(preroll) == -1  # context preparation, not warm-up: see --preroll
     status = eng.dual_steps(args.warmup)
     assert status == -1, f"LP finished during warmup (status {status})"
     it0 = eng.numberIterations()
@@ -279,6 +288,8 @@ def main():
         e.set_option("timing", 2)
         if force_by_column:
             e.set_option("row_price_frac", 0.0)  # bit-identical tableau rows either way: same pivots
+        if preroll:
+            e.dual_steps(preroll)
         e.dual_steps(args.warmup)
         torch.cuda.synchronize()
         a0, b0 = e.stats(), e.kernelTimes()
@@ -342,9 +353,9 @@ def main():
             o.set_option("max_pivots", 0)
             o.set_option("max_iterations", n_cpu)
             o.dual()
-            if args.cpu_iterations > 0 or o.seconds >= 10.0 or o.iterations < n_cpu or n_cpu >= 2500:
+            if args.cpu_iterations > 0 or o.seconds >= 5.0 or o.iterations < n_cpu or n_cpu >= 2000:
                 break
-            n_cpu += 500  # 500 -> ... -> 2500 pivots: 0.4 / 1.4 / 3.3 / ~8 / ~18 s of one Xeon core at config 4 (dense nucleus LU: k^3)
+            n_cpu += 500  # 500 -> 1000 -> 1500 -> 2000 pivots: 0.4 / 1.4 / 3.3 / ~12 s of one Xeon core at config 4 (dense nucleus LU: k^3; 2500: 42 s)
         cpu = {"value": o.iterations / max(o.seconds, 1e-9), "unit": "iterations/s", "cores": 1, "kind": "port",
                "window": [1, int(o.iterations)], "seconds": round(o.seconds, 3),
                "sample": f"pivots 1..{o.iterations} of the same LP from the slack basis ({o.seconds:.2f} s, refactorizations included, "
@@ -549,6 +560,8 @@ def main():
                                    + (" warm-started from the committed basis of this LP after 30 000 pivots (tests/golden/basis_sparse_30000.npy)"
                                       if basis is not None else " from the slack basis"),
                        "start": "mature basis (pivot 30 000 of the same LP)" if basis is not None else "slack basis",
+                       "preparation": (f"start-up factorization of that basis + {preroll} untimed pivots, so that the window sits mid-way through an "
+                                       "eta-file cycle; then the W warm-up pivots") if basis is not None else None,
                        "rows": int(lp.m), "cols": int(lp.n), "nnz": int(len(lp.elem)),
                        "parallelism": f"column-range pricing x{world}" if world > 1 else "1 GPU",
                        "check_every": args.check_every, "generate_s": round(gen_s, 1),
