@@ -3764,7 +3764,13 @@ int clpgpu_context::run(int maxSteps)
         fprintf(stderr, "clpgpu: iteration %d > 2(m+n): costs perturbed\n", numberIterations);
     }
     if (needStatus) {
+      const auto ts0 = std::chrono::steady_clock::now();
       rc = statusOfProblemInDual(factorType);
+      if (logLevel > 1) {
+        (void)sync();
+        fprintf(stderr, "clpgpu: status check at iteration %d took %.1f ms in all (refactorization, resync, weights, bounds)\n", numberIterations,
+                1.0e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count());
+      }
       factorType = 1;
       needStatus = false;
       if (rc) {
