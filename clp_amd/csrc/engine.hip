@@ -160,6 +160,7 @@ struct clpgpu_context {
   int numberBackwards = 0, numberLoopFlags = 0;  // statistics: backwards-objective restores, loops acted upon
   int debugBackwardsAt = -1;  // fault injection (option debug_backwards_at), as in the oracle
   int debugPoisonInverseAt = -1, numberPoisoned = 0;  // fault injection (option debug_poison_inverse_at)
+  int checkBoth = 1;  // option "check_both": gutsOfSolution ends in checkBothSolutions (1, this reference version) or in the older pair (0)
   int debugResetWeightsAt = -1;  // option debug_reset_weights_at (experiment)
   int dseResetEvery = 0, dseResetCounter = 0, numberWeightResets = 0;  // option dse_reset_every (experiment): uniform weights again every N-th refactorization
   int debugBadAccuracyAt = -1, numberAccuracyRestores = 0;  // fault injection (option debug_bad_accuracy_at) and its count
@@ -422,6 +423,7 @@ struct clpgpu_context {
   int gutsOfSolution();
   void checkPrimalSolution();
   void checkDualSolution();
+  void checkBothSolutions();
   int changeBounds(int initialize, double &changeCost);
   int perturb();
   void restoreCosts();
@@ -1860,8 +1862,12 @@ int clpgpu_context::gutsOfSolution()
     fprintf(stderr, "clpgpu: drift at iteration %d: nonbasic dj max %g, %d newly dual infeasible; basic x max %g (relative %g, largest |x| %g)\n",
             numberIterations, maxDj, newlyBad, maxX, maxXRel, maxAbsX);
   }
-  checkPrimalSolution();
-  checkDualSolution();
+  if (checkBoth) {
+    checkBothSolutions();
+  } else {
+    checkPrimalSolution();
+    checkDualSolution();
+  }
   return rc;
 }
 
@@ -1932,6 +1938,75 @@ void clpgpu_context::checkDualSolution()
   }
 }
 
+
+// ClpSimplex::checkBothSolutions (src/ClpSimplex.cpp:3226-3440): what gutsOfSolution ends in in this reference version (:762) -- one
+// pass over [columns | rows] for the objective, the primal infeasibilities and, for feasible nonbasic unflagged variables, the dual
+// ones.  Against the older pair it relaxes the dual tolerance by at least 5 x dualTolerance (max(largestDualError, 5 dualTolerance),
+// :3255), puts no 1e10 cap on the possible improvement, takes a nonbasic variable strictly between its bounds as "may be free" (dj x 100,
+// improvement 1e100, and `value` -- sic, :3358 -- in the relaxed sum), and adds in sequence order.  firstFree_ / the free counters are
+// not kept (no free nonbasics on this path).  Option "check_both" 0 restores the pair.
+void clpgpu_context::checkBothSolutions()
+{
+  objectiveValue = 0.0;
+  sumPrimalInfeasibilities = 0.0;
+  numberPrimalInfeasibilities = 0;
+  const double relaxedToleranceP = primalTolerance + fmin(1.0e-2, fmax(largestPrimalError, 0.0 * primalTolerance));
+  const double relaxedToleranceD = dualTolerance + fmin(1.0e-2, fmax(largestDualError, 5.0 * dualTolerance));
+  const double possTolerance = 5.0 * relaxedToleranceD;
+  sumOfRelaxedPrimalInfeasibilities = 0.0;
+  sumDualInfeasibilities = 0.0;
+  numberDualInfeasibilities = 0;
+  sumOfRelaxedDualInfeasibilities = 0.0;
+  bestPossibleImprovement = 0.0;
+  for (int i = 0; i < N; i++) {
+    const double value = sol[i];
+    objectiveValue += value * cost[i];
+    const double distanceUp = upper[i] - value, distanceDown = value - lower[i];
+    if (distanceUp < -primalTolerance) {
+      const double infeasibility = -distanceUp;
+      sumPrimalInfeasibilities += infeasibility - primalTolerance;
+      if (infeasibility > relaxedToleranceP)
+        sumOfRelaxedPrimalInfeasibilities += infeasibility - relaxedToleranceP;
+      numberPrimalInfeasibilities++;
+    } else if (distanceDown < -primalTolerance) {
+      const double infeasibility = -distanceDown;
+      sumPrimalInfeasibilities += infeasibility - primalTolerance;
+      if (infeasibility > relaxedToleranceP)
+        sumOfRelaxedPrimalInfeasibilities += infeasibility - relaxedToleranceP;
+      numberPrimalInfeasibilities++;
+    } else if ((status[i] & 7) != ST_BASIC && !(status[i] & FLAGGED_BIT)) {
+      double djValue = dj[i];
+      if (distanceDown < primalTolerance) {
+        if (distanceUp > primalTolerance && djValue < -dualTolerance) {
+          sumDualInfeasibilities -= djValue + dualTolerance;
+          if (djValue < -possTolerance)
+            bestPossibleImprovement -= distanceUp * djValue;
+          if (djValue < -relaxedToleranceD)
+            sumOfRelaxedDualInfeasibilities -= djValue + relaxedToleranceD;
+          numberDualInfeasibilities++;
+        }
+      } else if (distanceUp < primalTolerance) {
+        if (djValue > dualTolerance) {
+          sumDualInfeasibilities += djValue - dualTolerance;
+          if (djValue > possTolerance)
+            bestPossibleImprovement += distanceDown * djValue;
+          if (djValue > relaxedToleranceD)
+            sumOfRelaxedDualInfeasibilities += djValue - relaxedToleranceD;
+          numberDualInfeasibilities++;
+        }
+      } else {
+        djValue *= 100.0;  // strictly between its bounds: may be free
+        if (fabs(djValue) > dualTolerance) {
+          sumDualInfeasibilities += fabs(djValue) - dualTolerance;
+          bestPossibleImprovement = 1.0e100;
+          numberDualInfeasibilities++;
+          if (fabs(djValue) > relaxedToleranceD)
+            sumOfRelaxedDualInfeasibilities += value - relaxedToleranceD;
+        }
+      }
+    }
+  }
+}
 
 // ClpSimplexDual::changeBounds (src/ClpSimplexDual.cpp:3148-3512) on the host mirrors
 int clpgpu_context::changeBounds(int initialize, double &changeCost)
@@ -4689,6 +4764,7 @@ clpgpu_context *clpgpu_clone(const clpgpu_context *src)
   ctx->luMinPivots = src->luMinPivots;
   ctx->luInverseFillCap = src->luInverseFillCap;
   ctx->fakeBoundCleanup = src->fakeBoundCleanup;
+  ctx->checkBoth = src->checkBoth;
   ctx->refactorMode = src->refactorMode;
   ctx->refactorMinK = src->refactorMinK;
   ctx->forkUpdate = src->forkUpdate;
@@ -4922,6 +4998,7 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "debug_poison_inverse_at")) ctx->debugPoisonInverseAt = (int)v;
   else if (!strcmp(name, "debug_bad_accuracy_at")) ctx->debugBadAccuracyAt = (int)v;
   else if (!strcmp(name, "debug_reset_weights_at")) ctx->debugResetWeightsAt = (int)v;
+  else if (!strcmp(name, "check_both")) ctx->checkBoth = v != 0.0;
   else if (!strcmp(name, "dse_reset_every")) ctx->dseResetEvery = std::max(0, (int)v);
   else if (!strcmp(name, "debug_singular_at")) ctx->debugSingularAt = (int)v;
   else if (!strcmp(name, "log_level")) ctx->logLevel = (int)v;

@@ -108,7 +108,7 @@ struct OrcModel {
   unsigned char *saveStatus;      /* ClpSimplex::saveStatus_ / savedSolution_: the basis of the last good status check (:6160-6175) */
   double *savedSolution;
   int numberBackwards, numberLoopFlags; /* test hooks: times the "objective going backwards" restore ran, times looping() acted */
-  int checkBoth;                  /* option "check_both": gutsOfSolution ends in checkBothSolutions (groundwork, default 0) */
+  int checkBoth;                  /* option "check_both": gutsOfSolution ends in checkBothSolutions (default 1) or in the older pair (0) */
   int rimInfeasible;              /* the start-up sanity check found crossing bounds: status 1 without a rim to look at */
   int debugSingularAt;            /* fault injection (option "debug_singular_at"): the refactorization of the first status check at or after
                                      this iteration is taken as singular; -1 off */
@@ -248,6 +248,7 @@ OrcModel *orc_create(int m, int n, const int *colStart, const int *row, const do
   M->largeValue = 1.0e15;
   M->maximumIterations = 2147483647;
   M->pivotRule = 1;
+  M->checkBoth = 1; /* gutsOfSolution ends in checkBothSolutions, as in this reference version (src/ClpSimplex.cpp:762) */
   M->maximumPivots = 200; /* CoinAbcBaseFactorization1.cpp:142 default */
   M->seed = 1234567u;     /* src/ClpModel.cpp:149 */
   M->debugBackwardsAt = -1;
@@ -1000,8 +1001,8 @@ static void checkDualSolution(OrcModel *M)
 }
 
 /* ClpSimplex::checkBothSolutions :3226-3440 (no free / superbasic bookkeeping: firstFree_ is not used on this path).  What
- * gutsOfSolution ends in in this reference version (:762).  GROUNDWORK: only taken with option "check_both" 1 -- the default
- * stays the checkPrimalSolution + checkDualSolution pair the HIP engine restates too, see DESIGN.md section 2 (first gap). */
+ * gutsOfSolution ends in in this reference version (:762); the default since round 4, on both sides (option "check_both" 0 restores the
+ * checkPrimalSolution + checkDualSolution pair, which statusOfProblemInDual still calls directly where the reference does). */
 static void checkBothSolutions(OrcModel *M)
 {
   const int N = M->m + M->n;

@@ -63,8 +63,8 @@ void orc_destroy(OrcModel *model);
  * "perturbation" ClpSimplex::perturbation_ at entry: 102 never (default here), 100 the reference's constructor
  * default (no start-up perturbation, the kick after 2(m+n) iterations), 50 the clp command's default, 51-69
  * fixed fractions (ClpSimplexDual::perturb, src/ClpSimplexDual.cpp:6533);
- * "check_both" 1: gutsOfSolution ends in ClpSimplex::checkBothSolutions (src/ClpSimplex.cpp:3226) instead of the
- * checkPrimalSolution + checkDualSolution pair (groundwork, default 0: the HIP engine restates the pair);
+ * "check_both" 1 (default): gutsOfSolution ends in ClpSimplex::checkBothSolutions (src/ClpSimplex.cpp:3226), 0: in the older
+ * checkPrimalSolution + checkDualSolution pair;
  * fault injection for the recovery paths of statusOfProblemInDual, each the iteration from which the next status check
  * is hit: "debug_backwards_at" (:5326-5488), "debug_bad_accuracy_at" (:5237-5318), "debug_singular_at" (:5060-5125). */
 int orc_set_option(OrcModel *model, const char *name, double value);

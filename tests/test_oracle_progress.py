@@ -69,11 +69,11 @@ def test_singular_refactorization_goes_back_to_the_saved_basis(rule):
 
 
 @pytest.mark.parametrize("rule", [0, 1])
-def test_check_both_solutions_groundwork_changes_no_solve_here(rule):
-    """ClpSimplex::checkBothSolutions (src/ClpSimplex.cpp:3226) is what gutsOfSolution ends in in the reference; both sides here restate
-    the checkPrimalSolution + checkDualSolution pair (first gap).  The oracle carries the newer function as option
-    "check_both" (groundwork for the switch): on the LPs of this suite it changes no pivot -- the two differ only at the edge of the
-    relaxed tolerances."""
+def test_check_both_solutions_against_the_older_pair(rule):
+    """ClpSimplex::checkBothSolutions (src/ClpSimplex.cpp:3226) is what gutsOfSolution ends in in the reference, and since round 4 on both
+    sides here (option "check_both" 1, the default; 0 = the older checkPrimalSolution + checkDualSolution pair).  On the well-behaved LPs of
+    this suite the two make the same pivots -- they differ at the edge of the relaxed tolerances -- and on LPs of the fuzz they do not: the
+    switch is a real one (the GPU twin of the second half is tests/test_gpu_fuzz.py::test_check_both_solutions_changes_these_solves)."""
     from clp_amd.mps import read_mps
     import os
 
@@ -81,8 +81,23 @@ def test_check_both_solutions_groundwork_changes_no_solve_here(rule):
     lps = [read_mps(os.path.join(here, "golden", "afiro.mps")), P.nqueens(20), P.ufl(10, 30, 99), P.sparse_lp(300, 1200, 8, 11),
            P.netlib_shaped_lp(400, 1500, 9000, 3)]
     for lp in lps:
-        a, sa = solve(lp, rule)
-        b, sb = solve(lp, rule, check_both=1)
+        a, sa = solve(lp, rule, check_both=0)
+        b, sb = solve(lp, rule)
         assert sa == sb == 0
         assert np.array_equal(a.pivot_log()["sequenceIn"], b.pivot_log()["sequenceIn"])
         assert abs(a.objective - b.objective) <= 1e-9 * (1 + abs(a.objective))
+
+
+def test_check_both_solutions_changes_fuzz_solves():
+    """LPs of the differential fuzz on which the two forms of the resync's bookkeeping end differently: 39 pivots under the pair, 20 under
+    checkBothSolutions (seed 59, steepest edge); "dual infeasible" (2) under the pair, "use primal" (10) under checkBothSolutions (seed 150)."""
+    from test_oracle_fuzz import make
+
+    lp = make(np.random.default_rng(7000 + 59))
+    old, s_old = solve(lp, 1, check_both=0)
+    new, s_new = solve(lp, 1)
+    assert (s_old, old.iterations) == (10, 39) and (s_new, new.iterations) == (10, 20)
+    lp = make(np.random.default_rng(7000 + 150))
+    old, s_old = solve(lp, 0, check_both=0)
+    new, s_new = solve(lp, 0)
+    assert s_old == 2 and s_new == 10 and old.iterations == new.iterations == 13
