@@ -3208,6 +3208,10 @@ int clpgpu_context::statusOfProblemInDual(int type)
   }
   if (problemStatus == 1 && (progressFlag & 8) != 0 && fabs(objectiveValue) > 1.0e10)
     problemStatus = 10;  // infeasible - but has looked feasible (:6338)
+  if (logLevel > 2)
+    fprintf(stderr, "STATUS it %d type %d -> problemStatus %d; primal %d (%.10g) dual %d (%.10g) relaxed %.6g %.6g; dualBound %g dualTol %g fake %d objective %.10g errors %.3g %.3g progressFlag %d\n",
+            numberIterations, type, problemStatus, numberPrimalInfeasibilities, sumPrimalInfeasibilities, numberDualInfeasibilities, sumDualInfeasibilities,
+            sumOfRelaxedPrimalInfeasibilities, sumOfRelaxedDualInfeasibilities, dualBound, dualTolerance, numberFake, objectiveValue, largestPrimalError, largestDualError, progressFlag);
   return rc;
 }
 
