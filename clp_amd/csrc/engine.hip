@@ -3730,7 +3730,11 @@ int clpgpu_context::whileIterating(int stepTarget)
       if (!numberAtFakeBound())
         dualTest = 0.0;
       if (hCtrl->bestPossible < 1.0e-11 && dualBound > dualTest) {
+        // "say infeasible ... unless primal feasible!!!!" (:1982-2027, specialOptions_ 0): the sums are those of the last status
+        // check; the -4 alternative (:1999) needs more than two pivots since the factorization and cannot be taken here
         problemStatus = 1;
+        if (sumPrimalInfeasibilities < 1.0e-3 || sumDualInfeasibilities > 1.0e-5)
+          problemStatus = 10;
       } else if (pivots == 0) {
         problemStatus = -4;
       }
@@ -3739,7 +3743,7 @@ int clpgpu_context::whileIterating(int stepTarget)
     if (pivots < 5 && acceptablePivot > 1.0e-8)
       acceptablePivot = 1.0e-8;
     hCtrl->acceptablePivotBase = acceptablePivot;
-    lastReturnCode = problemStatus == 1 ? 1 : -2;
+    lastReturnCode = (problemStatus == 1 || problemStatus == 10) ? 1 : -2;
     break;
   }
   case EXIT_NO_PIVOT_ROW: {

@@ -2477,7 +2477,13 @@ static int whileIterating(OrcModel *M)
           if (!numberAtFakeBound(M))
             dualTest = 0.0;
           if (bestPossiblePivot < 1.0e-11 && M->dualBound > dualTest) {
+            /* "say infeasible ... unless primal feasible!!!!" (:1982-2027, specialOptions_ 0): the sums are those of the last
+               status check; with fewer than two pivots since the factorization the -4 alternative (:1999: sumPrimal > 50 and
+               more than two pivots) cannot be taken, so a nearly primal feasible or a dual infeasible point ends as 10, "use
+               primal".  (The reference also drops the objective there, :2024; a caller of this port sees only the status.) */
             M->problemStatus = 1;
+            if (M->sumPrimalInfeasibilities < 1.0e-3 || M->sumDualInfeasibilities > 1.0e-5)
+              M->problemStatus = 10;
             returnCode = 1;
             break;
           }

@@ -73,3 +73,22 @@ def test_infeasible_with_fake_bounds_active_is_status_10(gpu_cls, seed, dual_bou
         assert g.numberIterations() == o.iterations
         lg, lo = g.pivotLog(), o.pivot_log()
         assert np.array_equal(lg["sequenceIn"], lo["sequenceIn"]) and np.array_equal(lg["sequenceOut"], lo["sequenceOut"])
+
+
+def test_no_incoming_column_second_thought(gpu_cls):
+    """ "say infeasible ... unless primal feasible!!!!" (src/ClpSimplexDual.cpp:1982-2027): no incoming column right after a factorization
+    is status 1 -- unless the sums of the last status check say nearly primal feasible or dual infeasible, then 10.  An LP of the fuzz
+    (seed 374, Dantzig, dual bound 5) that ends that way on the oracle after 41 pivots: same pivots and the same 10 on the engine."""
+    from oracle.oracle import OracleSimplex
+    from test_oracle_fuzz import make
+
+    lp = make(np.random.default_rng(7000 + 374))
+    o = OracleSimplex(lp)
+    g = gpu_cls().loadProblem(lp)
+    for s in (o, g):
+        s.set_option("pivot_rule", 0)
+        s.set_option("dual_bound", 5.0)
+    assert o.dual() == 10 and o.iterations == 41
+    assert g.dual() == 10 and g.numberIterations() == 41
+    lg, lo = g.pivotLog(), o.pivot_log()
+    assert np.array_equal(lg["sequenceIn"], lo["sequenceIn"]) and np.array_equal(lg["sequenceOut"], lo["sequenceOut"])
