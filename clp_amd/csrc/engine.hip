@@ -5453,9 +5453,9 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
     fprintf(stderr, "clpgpu dbg: dc small %lld big %lld passes %lld tries %lld sumNc %lld mapped %lld full %lld ticksSmall %lld ticksBig %lld | flip iters %lld flips %lld entries %lld sequential %lld | scattered %lld select rows %lld hot rows %lld\n",
             g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9], g[10], g[11], g[12], g[14], g[13], g[15]);
     const long long *q = ctx->hCtrl->dbgDc;
-    fprintf(stderr, "clpgpu dbg: ratio test working-set path: calls %lld, ticks/call %.0f, before the passes %.0f (class loads %.0f, totals %.0f, "
-                    "prefix %.0f, compaction %.0f: in k_dc_working_set since round 3), max %lld\n", q[0], q[0] ? (double)q[1] / q[0] : 0.0, q[0] ? (double)q[2] / q[0] : 0.0,
-            q[0] ? (double)q[4] / q[0] : 0.0, q[0] ? (double)q[5] / q[0] : 0.0, q[0] ? (double)q[6] / q[0] : 0.0, q[0] ? (double)q[7] / q[0] : 0.0, q[3]);
+    fprintf(stderr, "clpgpu dbg: ratio test working-set path: calls %lld, ticks/call %.0f, before the passes %.0f, max %lld; candidates of breakpoint class "
+                    "<= 0 / 1 / 2 summed over the pivots with a long list: %lld / %lld / %lld; fall-backs to the full list %lld (sum of their working-set classes %lld)\n",
+            q[0], q[0] ? (double)q[1] / q[0] : 0.0, q[0] ? (double)q[2] / q[0] : 0.0, q[3], q[4], q[5], q[6], q[7] % 1000000LL, q[7] / 1000000LL);
   }
   stats->price_bytes = ctx->hCtrl->statPriceBytes;
   stats->row_bytes = ctx->hCtrl->statRowBytes;

@@ -1176,7 +1176,8 @@ __device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nu
 #define DC_CPT 8
 #define DC_THREADS 512
 #define DC_SMALL (8 * 64)
-#define DC_WS_CAP (DC_CPT * DC_THREADS)
+#define DC_CPT2 16                           // candidates per thread of the large working-set form (4096 < set <= 8192)
+#define DC_WS_CAP (DC_CPT2 * DC_THREADS)
 #define DC_NB_PER 8                          // compaction blocks per thread of the class-prefix scan
 #define DC_NB_MAX (DC_NB_PER * DC_THREADS)   // beyond this many blocks (N > 1M) the working set is not used
 // One launch, 512 threads (256 VGPRs per lane available: no spills).
@@ -1238,6 +1239,11 @@ __global__ void __launch_bounds__(WS_THREADS) k_dc_working_set(Dev D, int nbClas
   for (int j = 0; j < 3; j++)
     if (cum[j] <= DC_WS_CAP && cum[j] < nc)
       J = j;
+  if (blockIdx.x == 0 && tid == 0) {  // development counters (CLPGPU_DEBUG_STATS): cumulative class sizes of the candidate lists
+    c->dbgDc[4] += cum[0];
+    c->dbgDc[5] += cum[1];
+    c->dbgDc[6] += cum[2];
+  }
   if (J < 0 || cum[J] <= 0) {
     if (blockIdx.x == 0 && tid == 0) {
       c->wsJ = -1;
@@ -1330,9 +1336,17 @@ __global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass)
         }
         __syncthreads();
         ok = s_done != 0;
-      } else {
+      } else if (ws <= DC_CPT * DC_THREADS) {
         ok = dualColumnImpl<DC_CPT, false, true>(D, wsIdx, ws, tau);
+      } else {
+        // 4 % of the mature-regime calls used to walk the full list of 10^5 candidates in global memory (1.1 ms each, 3 ms at worst):
+        // mostly pivots whose class <= 1 set (breakpoints up to 256 theta0) was a little over 4096 candidates, so the working set
+        // fell back to class 0 and the test ran past its guard (profiles/r04_dc_probe.txt).  Sixteen candidates per thread keep
+        // such a set in registers.
+        ok = dualColumnImpl<DC_CPT2, false, true>(D, wsIdx, ws, tau);
       }
+      if (!ok && tid == 0)
+        c->dbgDc[7] += 1 + 1000000LL * J;  // fall-backs to the full list (+ 1e6 x the class the working set had)
       if (ok) {
         if (tid == 0) {
           const long long dt = wall_clock64() - dcT0;
