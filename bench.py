@@ -194,7 +194,7 @@ def main():
                          "so that the timed window sits in the middle of an eta-file cycle (its length runs 0 .. ~1600) and not right "
                          "behind a fresh factorization, where pivots are at their cheapest")
     ap.add_argument("--ladder-budget", type=float, default=60.0, help="seconds allowed for the time-to-optimal ladder (0 skips it)")
-    ap.add_argument("--ladder-rungs", default="1500,3000,5000,7000,10000,14000,20000")
+    ap.add_argument("--ladder-rungs", default="1500,2000,3000,4000,5000,7000,10000")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 

@@ -617,5 +617,9 @@ void clpgpu_context::luLaunchFtran(int gm, int parity)
   KL("k_lu_slack", k_lu_slack, dim3(cdiv(m, 32), 3), dim3(256), 0, stream, D, 1, (const double *)D.vecV1, (const double *)D.rho,
        (const double *)D.flipRhs, 1, 1, 1);
   KL("k_lu_pf_s", k_lu_pf_s, dim3(128), dim3(256), 0, stream, D, 1, 1, 1, 1);
-  KL("k_ftran_scatter3_lu", k_ftran_scatter3_lu, dim3(gm), dim3(256), 0, stream, D, gm, parity);
+  {
+    // positions per workgroup: one round of workgroups over the 256 CUs (m = 50 000: 250 workgroups of 200 positions, not 196 of 256)
+    const int ppb = std::min(256, std::max(64, (cdiv(m, 256) + 7) & ~7));
+    KL("k_ftran_scatter3_lu", k_ftran_scatter3_lu, dim3(cdiv(m, ppb)), dim3(256), 0, stream, D, gm, parity, ppb);
+  }
 }

@@ -334,7 +334,7 @@ __device__ inline void luPfApply(const Dev &D, int t, int p, const double *s0, c
 // the file for ALL 256 positions (four per lane), 8 etas x 4 positions = 32 loads in flight per lane, and the four partial sums of
 // a position are added in wave order -- 64 KB of H in flight per workgroup instead of 16 (one thread per position and eight loads
 // in flight left this stream at 0.35-0.42 of the HBM peak).  d1..d3 = -(H s) at position base + threadIdx.x.
-__device__ inline void luPfApplyWg(const Dev &D, int t, int base, const double *s0, const double *s1, const double *s2, double *part /*[4][3][256]*/,
+__device__ inline void luPfApplyWg(const Dev &D, int t, int base, int ppb, const double *s0, const double *s1, const double *s2, double *part /*[4][3][256]*/,
                                    double &d1, double &d2, double &d3)
 {
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -347,7 +347,7 @@ __device__ inline void luPfApplyWg(const Dev &D, int t, int base, const double *
   for (int q = 0; q < 4; q++) {
     acc[q][0] = acc[q][1] = acc[q][2] = 0.0;
     const int p = base + lane + 64 * q;
-    live[q] = p < D.m;
+    live[q] = lane + 64 * q < ppb && p < D.m;  // ppb positions per workgroup (the launch balances m over the CUs)
     Hp[q] = LUD.H + (live[q] ? p : 0);
   }
   int j = j0;
@@ -765,7 +765,7 @@ __global__ void __launch_bounds__(256) k_lu_pf_append(Dev D, int chain, int gm)
 }
 
 // LU mode: x = x0 - H s per basis position (x0 from the k_lu_* sweeps, s from k_lu_pf_s), then the same back end
-__global__ void __launch_bounds__(256) k_ftran_scatter3_lu(Dev D, int nbNorm, int parity)
+__global__ void __launch_bounds__(256) k_ftran_scatter3_lu(Dev D, int nbNorm, int parity, int ppb)
 {
   const Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -781,13 +781,15 @@ __global__ void __launch_bounds__(256) k_ftran_scatter3_lu(Dev D, int nbNorm, in
     sS[2 * LU_TCAP_MAX + j] = doFlip ? LUD.s[2 * LUD.tcap + j] : 0.0;
   }
   __syncthreads();
-  const int tt = blockIdx.x * blockDim.x + threadIdx.x;
+  // ppb <= 256 positions per workgroup, chosen by the launch so that one round of workgroups covers the m positions on all CUs
+  // (256 positions each left 60 of the 256 CUs without work at m = 50 000)
+  const int tt = blockIdx.x * ppb + threadIdx.x;
   int p = -1;
   double x1 = 0.0, x2 = 0.0, x3 = 0.0;
   __shared__ double sPart[4 * 3 * 256];
   double d1, d2, d3;
-  luPfApplyWg(D, t, blockIdx.x * blockDim.x, sS, sS + LU_TCAP_MAX, sS + 2 * LU_TCAP_MAX, sPart, d1, d2, d3);
-  if (tt < D.m) {
+  luPfApplyWg(D, t, blockIdx.x * ppb, ppb, sS, sS + LU_TCAP_MAX, sS + 2 * LU_TCAP_MAX, sPart, d1, d2, d3);
+  if ((int)threadIdx.x < ppb && tt < D.m) {
     p = tt;
     x1 = LUD.x0[p] + d1;
     x2 = doTau ? LUD.x0[(size_t)D.m + p] + d2 : 0.0;

@@ -20,7 +20,9 @@ sys.path.insert(0, ROOT)
 
 RUNGS = {
     "1500": (1500, 6000, 10, 31),
+    "2000": (2000, 8000, 10, 38),
     "3000": (3000, 12000, 10, 32),
+    "4000": (4000, 16000, 10, 39),
     "5000": (5000, 20000, 10, 33),
     "7000": (7000, 28000, 10, 34),
     "10000": (10000, 40000, 10, 35),
