@@ -596,9 +596,13 @@ def main():
             "roofline_mature": regime,
             "refactorizations": int(headline_stats["refactorizations"]),
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()
+    # librccl prints a version banner to stdout when the process unloads it (after the line above, for any run that attached a
+    # communicator): the bench line must stay the last thing on stdout
+    sys.stdout.flush()
+    os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
 
 
 if __name__ == "__main__":
