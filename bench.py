@@ -568,7 +568,11 @@ def main():
                        "pivot_window": [int(it0) + 1, int(it0) + args.steps],
                        "pivot_window_counts_from": "the warm start" if basis is not None else "the slack basis",
                        "nucleus_at_end_of_window": int(headline_stats["nucleus"])},
-            "roofline": {"bound": "hbm", "kernel": " + ".join(sorted(price_names)) + " (row pricing + fused first ratio pass)",
+            "roofline": {"bound": "hbm",
+                         # by column the HIP events bracket the pricing kernel alone (k_price_row_finish returns at once and is left out): the
+                         # duration rocprofv3 reports for k_price_sell; by row both passes
+                         "kernel": ("k_price_sell" if (d_col is d_mix and "k_price_sell" in price_names) else " + ".join(sorted(price_names)))
+                                   + " (row pricing + fused first ratio pass)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "bytes_per_launch": per_launch_bytes, "us_per_launch": per_launch_s * 1e6,
                          "launches": int(launches),

@@ -324,7 +324,7 @@ struct clpgpu_context {
   int logCapacity = 0;
   // ---- stats
   clpgpu_stats stats;
-  std::vector<hipEvent_t> evStart, evStop;
+  std::vector<hipEvent_t> evStart, evStop, evMid;  // evMid: behind the by-column kernel, ahead of the by-row form's second pass
   int evUsed = 0;
   double seconds = 0.0;
   // per-kernel event marks (timing == 2)
@@ -3345,6 +3345,7 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   // PRICE + first ratio pass
   if (ev)
     (void)hipEventRecord(evStart[evUsed], stream);
+  bool midDone = false;
   if (priceKernel >= 1) {
     if (widePricing && priceKernel != 1)
       KL("k_price_wide", k_price_wide, dim3(nWideBlocks), dim3(256), 0, stream, D, denseColumns ? 1 : 0, countInPrice ? 1 : 0);
@@ -3354,9 +3355,15 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
       KL("k_price_sell", k_price_sell, dim3(nSlots + (rowMax > 0 ? gm : 0)), dim3(256),
          (m > 64 * SELL_BITS_MAX || priceKernel < 2) ? 0 : (size_t)((m + 63) / 64) * 8, stream, D,
          (m > 64 * SELL_BITS_MAX && priceKernel > 1) ? 1 : priceKernel, countInPrice ? 1 : 0, nSellBlocks, nSlots, rowMax);
+      if (ev) {
+        (void)hipEventRecord(evMid[evUsed], stream);  // a pivot priced by column ends here (k_price_row_finish returns at once)
+        midDone = true;
+      }
       if (rowMax > 0)
         KL("k_price_row_finish", k_price_row_finish, dim3(nbCols), dim3(PRICE_BLOCK), 0, stream, D, nbRows, rowMax);
     }
+    if (ev && !midDone)
+      (void)hipEventRecord(evMid[evUsed], stream);
     if (ev)
       (void)hipEventRecord(evStop[evUsed++], stream);
     if (gatherRows) {
@@ -3375,8 +3382,10 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
     }
   } else {
     KL("k_price", k_price, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows);
-    if (ev)
+    if (ev) {
+      (void)hipEventRecord(evMid[evUsed], stream);
       (void)hipEventRecord(evStop[evUsed++], stream);
+    }
     KL("k_scan_blocks", k_scan_blocks, dim3(1), dim3(1024), 0, stream, D, nb, 0, 1, 0);
   }
   KL("k_cand_scatter", k_cand_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, selfScanSell);
@@ -3566,9 +3575,11 @@ int clpgpu_context::whileIterating(int stepTarget)
   if (timing && evStart.empty()) {
     evStart.resize(checkEvery);
     evStop.resize(checkEvery);
+    evMid.resize(checkEvery);
     for (int i = 0; i < checkEvery; i++) {
       (void)hipEventCreate(&evStart[i]);
       (void)hipEventCreate(&evStop[i]);
+      (void)hipEventCreate(&evMid[i]);
     }
   }
   while (!rc) {
@@ -3605,8 +3616,10 @@ int clpgpu_context::whileIterating(int stepTarget)
       const bool haveRecs = timed > 0 && firstRec + timed <= logCapacity && !d2h(recs.data(), D.log + firstRec, timed);
       for (int i = 0; i < timed; i++) {
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, evStart[i], evStop[i]) == hipSuccess) {
-          if (haveRecs && (recs[i].reserved >> 30) & 1) {
+        const bool byRow = haveRecs && ((recs[i].reserved >> 30) & 1);
+        // by column: the pricing kernel alone (what rocprofv3's kernel duration is compared with); by row: both passes
+        if (hipEventElapsedTime(&ms, evStart[i], byRow ? evStop[i] : evMid[i]) == hipSuccess) {
+          if (byRow) {
             stats.row_ms += ms;
             stats.row_launches++;
           } else {
@@ -4109,6 +4122,8 @@ void clpgpu_destroy(clpgpu_context *ctx)
   for (auto &e : ctx->evStart)
     (void)hipEventDestroy(e);
   for (auto &e : ctx->evStop)
+    (void)hipEventDestroy(e);
+  for (auto &e : ctx->evMid)
     (void)hipEventDestroy(e);
   for (auto &e : ctx->ktEvents)
     (void)hipEventDestroy(e);
@@ -5015,8 +5030,10 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
     ctx->dropGraph();
     for (auto &e : ctx->evStart) (void)hipEventDestroy(e);
     for (auto &e : ctx->evStop) (void)hipEventDestroy(e);
+    for (auto &e : ctx->evMid) (void)hipEventDestroy(e);
     ctx->evStart.clear();
     ctx->evStop.clear();
+    ctx->evMid.clear();
     for (auto &e : ctx->ktEvents) (void)hipEventDestroy(e);
     ctx->ktEvents.clear();
   }
