@@ -1,8 +1,9 @@
 /*
  * clp_dual_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY; see clp_dual_oracle.h).
  *
- * Restates the revised dual simplex of coin-or/Clp for the fast branch "no free / superbasic
- * nonbasic variables" (moreSpecialOptions_&8, src/ClpSimplexDual.cpp:3685); scaling (option "scaling") and
+ * Restates the revised dual simplex of coin-or/Clp: by default for the fast branch "no free / superbasic
+ * nonbasic variables" (moreSpecialOptions_&8, src/ClpSimplexDual.cpp:3685), with option "free_nonbasic" the general
+ * one as well; scaling (option "scaling") and
  * cost perturbation (option "perturbation", ClpSimplexDual::perturb :6533) are off unless asked for.  Each
  * function cites the reference lines it follows.
  * Variable order is Clp's: sequences [0,n) structurals, [n,n+m) row slacks, slack column = -e_i
@@ -18,8 +19,12 @@
  *    (this factorization has none) and the Cbc-only branches are not restated; when the basis a singular
  *    refactorization falls back to is singular too the solve ends with status 4 (the reference factorizes "safely"
  *    with slacks put in, :5100-5117).
- *  - nonbasic free columns are given "bothFake" bounds at start (the reference keeps them isFree and
- *    uses the general branch of dualColumn0).
+ *  - nonbasic free columns are given "bothFake" bounds at start by default, which is what the HIP engine does and is compared
+ *    with.  Option "free_nonbasic" 1 keeps them isFree as the reference does: dualRow's free-first entry (:3005-3055), the
+ *    general branch of dualColumn0 (:4058-4179), the free branches of checkDualSolution / checkBothSolutions, firstFree_,
+ *    "only free dual infeasibilities: use primal" (:5619-5622).  Checked against HiGHS (tests/test_oracle_free.py), there being
+ *    no reference binary; the engine half is not written yet.
+ *  - gutsOfDual's "problems - try primal" exit (:537-547: a sum of primal infeasibilities 1e5 times the smallest seen) is not restated.
  *  - CoinThreadRandom lives in CoinUtils (absent); the 32-bit LCG form is used [unverifiable here].
  *
  * Build: gcc -O2 -ffp-contract=off (no FMA contraction, so the arithmetic order is the source order).
@@ -110,6 +115,16 @@ struct OrcModel {
   int numberBackwards, numberLoopFlags; /* test hooks: times the "objective going backwards" restore ran, times looping() acted */
   int checkBoth;                  /* option "check_both": gutsOfSolution ends in checkBothSolutions (default 1) or in the older pair (0) */
   int rimInfeasible;              /* the start-up sanity check found crossing bounds: status 1 without a rim to look at */
+  int freeNonbasic;               /* option "free_nonbasic": 1 = nonbasic free columns stay isFree as in the reference (dualRow's free-first entry
+                                     :2962-3140, the general branch of dualColumn0 :4058-4179); 0 (default, what the HIP engine does) = they
+                                     are given bothFake bounds at start */
+  int noFreeOrSuper;              /* moreSpecialOptions_ & 8: "no free or super basic" as the last checkBothSolutions saw it (always 1 with
+                                     free_nonbasic 0) */
+  int firstFree;                  /* ClpSimplex::firstFree_ */
+  int numberDualInfeasibilitiesWithoutFree;
+  double badFree;                 /* dualColumn0's badFree of the last pivot row */
+  int numberFreeFirstRows, numberFreeEntered; /* test hooks: pivot rows chosen by the free-first entry, pivots that brought a free variable in
+                                                 through the general branch's freePivot */
   int debugSingularAt;            /* fault injection (option "debug_singular_at"): the refactorization of the first status check at or after
                                      this iteration is taken as singular; -1 off */
   int numberSingularRestores;     /* test hook: times a singular refactorization sent the solve back to the saved basis (:5060-5125) */
@@ -249,6 +264,9 @@ OrcModel *orc_create(int m, int n, const int *colStart, const int *row, const do
   M->maximumIterations = 2147483647;
   M->pivotRule = 1;
   M->checkBoth = 1; /* gutsOfSolution ends in checkBothSolutions, as in this reference version (src/ClpSimplex.cpp:762) */
+  M->freeNonbasic = 0;
+  M->noFreeOrSuper = 1;
+  M->firstFree = -1;
   M->maximumPivots = 200; /* CoinAbcBaseFactorization1.cpp:142 default */
   M->seed = 1234567u;     /* src/ClpModel.cpp:149 */
   M->debugBackwardsAt = -1;
@@ -356,6 +374,7 @@ int orc_set_option(OrcModel *M, const char *name, double v)
   else if (!strcmp(name, "debug_bad_accuracy_at")) M->debugBadAccuracyAt = (int)v;
   else if (!strcmp(name, "debug_singular_at")) M->debugSingularAt = (int)v;
   else if (!strcmp(name, "check_both")) M->checkBoth = (int)v;
+  else if (!strcmp(name, "free_nonbasic")) M->freeNonbasic = (int)v;
   else return -1;
   return 0;
 }
@@ -953,16 +972,20 @@ static void checkPrimalSolution(OrcModel *M)
   }
 }
 
-/* ClpSimplex::checkDualSolution :3070-3250 (no free variables) */
+/* ClpSimplex::checkDualSolution :3070-3225.  With option free_nonbasic: the isFree branches ("free so relax a lot", :3125-3136), the count
+ * without free variables and firstFree_ (:3214-3219). */
 static void checkDualSolution(OrcModel *M)
 {
   const int N = M->m + M->n, n = M->n;
   double relaxedTolerance = M->dualTolerance + dmin(1.0e-2, M->largestDualError);
   const double possTolerance = 5.0 * relaxedTolerance; /* a bigger tolerance for the possible improvement (:3093) */
+  const int withFree = M->freeNonbasic;
+  int firstFreePrimal = -1, firstFreeDual = -1, numberSuperBasicWithDj = 0;
   M->bestPossibleImprovement = 0.0;
   M->sumDualInfeasibilities = 0.0;
   M->numberDualInfeasibilities = 0;
   M->sumOfRelaxedDualInfeasibilities = 0.0;
+  M->numberDualInfeasibilitiesWithoutFree = 0;
   for (int pass = 0; pass < 2; pass++) {
     int lo = pass ? n : 0, hi = pass ? N : n; /* columns first, then rows */
     for (int i = lo; i < hi; i++) {
@@ -970,16 +993,40 @@ static void checkDualSolution(OrcModel *M)
         double distanceUp = M->upper[i] - M->sol[i];
         double distanceDown = M->sol[i] - M->lower[i];
         double value = M->dj[i];
+        const int isFree = withFree && getStatus(M, i) == ST_FREE;
         if (distanceUp > M->primalTolerance) {
+          if (withFree && distanceDown > M->primalTolerance) { /* check if "free" (:3110-3118) */
+            if (fabs(value) > 1.0e2 * relaxedTolerance) {
+              numberSuperBasicWithDj++;
+              if (firstFreeDual < 0)
+                firstFreeDual = i;
+            }
+            if (firstFreePrimal < 0)
+              firstFreePrimal = i;
+          }
           if (value < 0.0) {
             double v = -value;
             if (v > M->dualTolerance) {
-              M->sumDualInfeasibilities += v - M->dualTolerance;
-              if (v > possTolerance)
-                M->bestPossibleImprovement += dmin(distanceUp, 1.0e10) * v;
-              if (v > relaxedTolerance)
-                M->sumOfRelaxedDualInfeasibilities += v - relaxedTolerance;
-              M->numberDualInfeasibilities++;
+              if (!(isFree && i < n)) { /* (the row loop has no relaxed form, :3180-3190) */
+                if (!isFree)
+                  M->numberDualInfeasibilitiesWithoutFree++;
+                M->sumDualInfeasibilities += v - M->dualTolerance;
+                if (v > possTolerance)
+                  M->bestPossibleImprovement += dmin(distanceUp, 1.0e10) * v;
+                if (v > relaxedTolerance)
+                  M->sumOfRelaxedDualInfeasibilities += v - relaxedTolerance;
+                M->numberDualInfeasibilities++;
+              } else {
+                v *= 0.01; /* free so relax a lot */
+                if (v > M->dualTolerance) {
+                  M->sumDualInfeasibilities += v - M->dualTolerance;
+                  if (v > possTolerance)
+                    M->bestPossibleImprovement = 1.0e100;
+                  if (v > relaxedTolerance)
+                    M->sumOfRelaxedDualInfeasibilities += v - relaxedTolerance;
+                  M->numberDualInfeasibilities++;
+                }
+              }
             }
           }
         }
@@ -992,17 +1039,26 @@ static void checkDualSolution(OrcModel *M)
               if (value > relaxedTolerance)
                 M->sumOfRelaxedDualInfeasibilities += value - relaxedTolerance;
               M->numberDualInfeasibilities++;
+              if (!isFree)
+                M->numberDualInfeasibilitiesWithoutFree++;
             }
           }
         }
       }
     }
   }
+  if (withFree) {
+    if (firstFreeDual >= 0)
+      M->firstFree = firstFreeDual;
+    else if (numberSuperBasicWithDj || progressLastIteration(M, 0) <= 0)
+      M->firstFree = firstFreePrimal;
+  }
 }
 
-/* ClpSimplex::checkBothSolutions :3226-3440 (no free / superbasic bookkeeping: firstFree_ is not used on this path).  What
- * gutsOfSolution ends in in this reference version (:762); the default since round 4, on both sides (option "check_both" 0 restores the
- * checkPrimalSolution + checkDualSolution pair, which statusOfProblemInDual still calls directly where the reference does). */
+/* ClpSimplex::checkBothSolutions :3226-3440.  What gutsOfSolution ends in in this reference version (:762); the default since round 4, on
+ * both sides (option "check_both" 0 restores the checkPrimalSolution + checkDualSolution pair, which statusOfProblemInDual still calls directly
+ * where the reference does).  With option free_nonbasic the bookkeeping for free and superbasic variables as well: moreSpecialOptions_ & 8
+ * ("no free or super basic", which picks the branch of dualColumn0), the count without free variables and firstFree_. */
 static void checkBothSolutions(OrcModel *M)
 {
   const int N = M->m + M->n;
@@ -1019,18 +1075,24 @@ static void checkBothSolutions(OrcModel *M)
   M->numberDualInfeasibilities = 0;
   M->sumOfRelaxedDualInfeasibilities = 0.0;
   M->bestPossibleImprovement = 0.0;
+  int numberDualInfeasibilitiesFree = 0, firstFreePrimal = -1, firstFreeDual = -1, numberSuperBasicWithDj = 0;
+  int noFreeOrSuper = 1; /* say no free or superbasic (:3273) */
   for (int i = 0; i < N; i++) {
     const double value = M->sol[i];
     M->objectiveValue += value * M->cost[i];
     const double distanceUp = M->upper[i] - value, distanceDown = value - M->lower[i];
     if (distanceUp < -primalTolerance) {
       const double infeasibility = -distanceUp;
+      if (getStatus(M, i) != ST_BASIC)
+        noFreeOrSuper = 0; /* say superbasic variables exist (:3294) */
       M->sumPrimalInfeasibilities += infeasibility - primalTolerance;
       if (infeasibility > relaxedToleranceP)
         M->sumOfRelaxedPrimalInfeasibilities += infeasibility - relaxedToleranceP;
       M->numberPrimalInfeasibilities++;
     } else if (distanceDown < -primalTolerance) {
       const double infeasibility = -distanceDown;
+      if (getStatus(M, i) != ST_BASIC)
+        noFreeOrSuper = 0;
       M->sumPrimalInfeasibilities += infeasibility - primalTolerance;
       if (infeasibility > relaxedToleranceP)
         M->sumOfRelaxedPrimalInfeasibilities += infeasibility - relaxedToleranceP;
@@ -1057,17 +1119,37 @@ static void checkBothSolutions(OrcModel *M)
           M->numberDualInfeasibilities++;
         }
       } else {
-        /* strictly between its bounds: may be free */
+        /* strictly between its bounds: may be free -- say free or superbasic (:3345) */
+        noFreeOrSuper = 0;
         djValue *= 100.0;
         if (fabs(djValue) > dualTolerance) {
+          if (getStatus(M, i) == ST_FREE)
+            numberDualInfeasibilitiesFree++;
           M->sumDualInfeasibilities += fabs(djValue) - dualTolerance;
           M->bestPossibleImprovement = 1.0e100;
           M->numberDualInfeasibilities++;
-          if (fabs(djValue) > relaxedToleranceD)
+          if (fabs(djValue) > relaxedToleranceD) {
             M->sumOfRelaxedDualInfeasibilities += value - relaxedToleranceD; /* sic: `value`, :3358 */
+            numberSuperBasicWithDj++;
+            if (firstFreeDual < 0)
+              firstFreeDual = i;
+            if (firstFreePrimal < 0)
+              firstFreePrimal = i;
+          }
+        } else if (getStatus(M, i) == ST_SUPER && firstFreePrimal < 0) {
+          firstFreePrimal = i;
         }
       }
     }
+  }
+  M->numberDualInfeasibilitiesWithoutFree = M->numberDualInfeasibilities;
+  if (M->freeNonbasic) {
+    M->noFreeOrSuper = noFreeOrSuper;
+    M->numberDualInfeasibilitiesWithoutFree = M->numberDualInfeasibilities - numberDualInfeasibilitiesFree;
+    if (firstFreeDual >= 0)
+      M->firstFree = firstFreeDual; /* dual (:3418) */
+    else if (numberSuperBasicWithDj || progressLastIteration(M, 0) <= 0)
+      M->firstFree = firstFreePrimal;
   }
 }
 
@@ -1078,6 +1160,8 @@ static void gutsOfSolution(OrcModel *M)
   if (M->checkBoth) {
     checkBothSolutions(M);
   } else {
+    if (M->freeNonbasic)
+      M->noFreeOrSuper = 0; /* "say may be free or superbasic", the old way of src/ClpSimplex.cpp:3228-3234 */
     checkPrimalSolution(M);
     checkDualSolution(M);
   }
@@ -1144,15 +1228,21 @@ static int changeBounds(OrcModel *M, int initialize, double *outputArray, double
         if (fabs(value - upperValue) > M->primalTolerance) {
           if (fabs(M->dj[i]) > 1.0e-9)
             numberInfeasibilities++;
-          else
+          else {
             setStatus(M, i, ST_SUPER);
+            if (M->freeNonbasic)
+              M->noFreeOrSuper = 0; /* moreSpecialOptions_ &= ~8 (:3181, :3192) */
+          }
         }
       } else if (st == ST_LOWER) {
         if (fabs(value - lowerValue) > M->primalTolerance) {
           if (fabs(M->dj[i]) > 1.0e-9)
             numberInfeasibilities++;
-          else
+          else {
             setStatus(M, i, ST_SUPER);
+            if (M->freeNonbasic)
+              M->noFreeOrSuper = 0; /* moreSpecialOptions_ &= ~8 (:3181, :3192) */
+          }
         }
       }
     }
@@ -1590,9 +1680,79 @@ static double updateWeights(OrcModel *M)
 /* ------------------------------------------------------------------------------------------ */
 
 /* ClpSimplexDual::dualRow :2962-3140 (no free variables, no values pass) */
+static void unpackColumn(OrcModel *M, double *dense, int iSequence);
+
+/* ClpSimplexDual::nextSuperBasic :8285-8302 */
+static int nextSuperBasic(OrcModel *M)
+{
+  if (M->firstFree >= 0) {
+    const int N = M->m + M->n;
+    int returnValue = M->firstFree;
+    int iColumn = M->firstFree + 1;
+    for (; iColumn < N; iColumn++) {
+      if (getStatus(M, iColumn) == ST_FREE)
+        if (fabs(M->dj[iColumn]) > 1.0e2 * M->dualTolerance)
+          break;
+    }
+    M->firstFree = iColumn;
+    if (M->firstFree == N)
+      M->firstFree = -1;
+    return returnValue;
+  } else {
+    return -1;
+  }
+}
+
+/* ClpSimplexDual::dualRow :2962-3140 */
 static void dualRow(OrcModel *M)
 {
-  M->pivotRow = M->pivotRule ? steepestPivotRow(M) : dantzigPivotRow(M);
+  int chosenRow = -1;
+  if (M->freeNonbasic) {
+    /* first see if any free variables and put them in basis (:3005-3055) */
+    int nextFree = nextSuperBasic(M);
+    if (nextFree >= 0) {
+      /* unpack vector and find a good pivot */
+      double *work = M->rowWork3;
+      unpackColumn(M, work, nextFree);
+      ftran(M, work);
+      double bestFeasibleAlpha = 0.0, bestInfeasibleAlpha = 0.0;
+      int bestFeasibleRow = -1, bestInfeasibleRow = -1;
+      for (int iRow = 0; iRow < M->m; iRow++) { /* (the reference walks the packed list of the updated column; the choices are strict
+                                                     maxima, so the order matters only between exact ties) */
+        double alpha = fabs(work[iRow]);
+        work[iRow] = 0.0;
+        if (alpha > 1.0e-3) {
+          int iSequence = M->pivotVariable[iRow];
+          double value = M->sol[iSequence], lower = M->lower[iSequence], upper = M->upper[iSequence];
+          double infeasibility = 0.0;
+          if (value > upper)
+            infeasibility = value - upper;
+          else if (value < lower)
+            infeasibility = lower - value;
+          if (infeasibility * alpha > bestInfeasibleAlpha && alpha > 1.0e-1) {
+            if (!flagged(M, iSequence)) {
+              bestInfeasibleAlpha = infeasibility * alpha;
+              bestInfeasibleRow = iRow;
+            }
+          }
+          if (alpha > bestFeasibleAlpha && (lower > -1.0e20 || upper < 1.0e20)) {
+            bestFeasibleAlpha = alpha;
+            bestFeasibleRow = iRow;
+          }
+        }
+      }
+      if (bestInfeasibleRow >= 0)
+        chosenRow = bestInfeasibleRow;
+      else if (bestFeasibleAlpha > 1.0e-2)
+        chosenRow = bestFeasibleRow;
+      if (chosenRow >= 0)
+        M->numberFreeFirstRows++;
+    }
+  }
+  if (chosenRow >= 0)
+    M->pivotRow = chosenRow;
+  else
+    M->pivotRow = M->pivotRule ? steepestPivotRow(M) : dantzigPivotRow(M);
   if (M->pivotRow >= 0) {
     M->sequenceOut = M->pivotVariable[M->pivotRow];
     M->valueOut = M->sol[M->sequenceOut];
@@ -1614,6 +1774,109 @@ static void dualRow(OrcModel *M)
       }
     }
   }
+}
+
+/* ClpSimplexDual::dualColumn0, the general branch "some free or super basic" (:4058-4179), run on the tableau row when the last
+ * checkBothSolutions cleared moreSpecialOptions_ & 8 (the fused first pass of the pricing is then not taken, ClpSimplexDual.cpp:1296-1300).
+ * Rows first, then columns.  A free or superbasic variable worth keeping becomes the incoming one (the largest |alpha| of them: freePivot)
+ * and is given fake bounds on the way when its value allows.  Fills candidate list 0; sets sequenceIn / theta / alpha for a free choice. */
+static void dualColumn0General(OrcModel *M, double acceptablePivot)
+{
+  const double tentativeTheta = 1.0e25;
+  double upperTheta = 1.0e31;
+  double freePivot = acceptablePivot;
+  int numberRemaining = 0;
+  int *index = M->spareIndex[0];
+  double *spare = M->spareValue[0];
+  double badFree = 0.0;
+  for (int iSection = 0; iSection < 2; iSection++) {
+    const int number = iSection ? M->numberColNz : M->numberPi;
+    const int *which = iSection ? M->colIndex : M->piIndex;
+    const double *work = iSection ? M->colValue : M->piValue;
+    const int addSequence = iSection ? 0 : M->n;
+    for (int i = 0; i < number; i++) {
+      const int jSequence = which[i] + addSequence;
+      if (jSequence == M->sequenceOut)
+        continue; /* the leaving variable is not a candidate (:4083) */
+      double alpha, oldValue, value;
+      int keep;
+      switch (getStatus(M, jSequence)) {
+      case ST_BASIC:
+      case ST_FIXED:
+        break;
+      case ST_FREE:
+      case ST_SUPER:
+        alpha = work[i];
+        oldValue = M->dj[jSequence];
+        if (oldValue > M->dualTolerance) {
+          keep = 1;
+        } else if (oldValue < -M->dualTolerance) {
+          keep = 1;
+        } else {
+          if (fabs(alpha) > dmax(10.0 * acceptablePivot, 1.0e-5)) {
+            keep = 1;
+          } else {
+            keep = 0;
+            badFree = dmax(badFree, fabs(alpha));
+          }
+        }
+        if (keep) {
+          /* free - choose largest */
+          if (fabs(alpha) > freePivot) {
+            freePivot = fabs(alpha);
+            M->sequenceIn = jSequence;
+            M->theta = oldValue / alpha;
+            M->alpha = alpha;
+          }
+          /* give fake bounds if possible */
+          if (2.0 * fabs(M->sol[jSequence]) < M->dualBound) {
+            setFake(M, jSequence, FAKE_BOTH);
+            M->numberFake++;
+            value = oldValue - tentativeTheta * alpha;
+            if (value > M->dualTolerance) {
+              /* pretend coming in from upper bound */
+              M->upper[jSequence] = M->sol[jSequence];
+              M->lower[jSequence] = M->upper[jSequence] - M->dualBound;
+              setStatus(M, jSequence, ST_UPPER);
+            } else {
+              /* pretend coming in from lower bound */
+              M->lower[jSequence] = M->sol[jSequence];
+              M->upper[jSequence] = M->lower[jSequence] + M->dualBound;
+              setStatus(M, jSequence, ST_LOWER);
+            }
+          }
+        }
+        break;
+      case ST_UPPER:
+        alpha = work[i];
+        oldValue = M->dj[jSequence];
+        value = oldValue - tentativeTheta * alpha;
+        if (value > M->dualTolerance) {
+          value = oldValue - upperTheta * alpha;
+          if (value > M->dualTolerance && -alpha >= acceptablePivot)
+            upperTheta = (oldValue - M->dualTolerance) / alpha;
+          spare[numberRemaining] = alpha;
+          index[numberRemaining++] = jSequence;
+        }
+        break;
+      case ST_LOWER:
+        alpha = work[i];
+        oldValue = M->dj[jSequence];
+        value = oldValue - tentativeTheta * alpha;
+        if (value < -M->dualTolerance) {
+          value = oldValue - upperTheta * alpha;
+          if (value < -M->dualTolerance && alpha >= acceptablePivot)
+            upperTheta = (oldValue + M->dualTolerance) / alpha;
+          spare[numberRemaining] = alpha;
+          index[numberRemaining++] = jSequence;
+        }
+        break;
+      }
+    }
+  }
+  M->numberCandidates = numberRemaining;
+  M->upperThetaFirst = upperTheta;
+  M->badFree = badFree;
 }
 
 /* ClpSimplexDual::dualColumn :4192-4927; the first pass was fused into pricing (spareIntArray_[0]
@@ -1646,13 +1909,17 @@ static double dualColumn(OrcModel *M, double acceptablePivot)
     swapped[i] = top;
   }
   double bestPossible = 1.0;
-  M->alpha = 0.0;
-  M->sequenceIn = -1;
+  const int freeChosen = M->sequenceIn >= 0; /* the general branch of dualColumn0 chose a free variable: "always choose" (:4321) */
+  if (!freeChosen) {
+    M->alpha = 0.0;
+    M->sequenceIn = -1;
+  }
   double tentativeTheta = 1.0e25;
   interesting[0] = numberRemaining;
-  if (!numberRemaining)
+  if (!numberRemaining && M->sequenceIn < 0)
     return 0.0; /* looks infeasible */
   int badSumPivots = 0;
+  if (!freeChosen) {
   M->theta = 1.0e50;
   tentativeTheta = dmax(10.0 * upperTheta, 1.0e-7);
   while (tentativeTheta < 1.0e22) {
@@ -1913,7 +2180,9 @@ static double dualColumn(OrcModel *M, double acceptablePivot)
       }
     }
   }
-  if (badSumPivots && M->fac.nEta) {
+  } /* !freeChosen */
+  if ((badSumPivots || fabs(M->theta * M->badFree) > 10.0 * M->dualTolerance) && M->fac.nEta) {
+    /* things look bad: force a refactorization (:4776-4784) */
     M->sequenceIn = -1;
     M->acceptablePivot_ = -M->acceptablePivot_;
   }
@@ -1957,6 +2226,8 @@ static double dualColumn(OrcModel *M, double acceptablePivot)
           double mult = 1.0;
           if (st == ST_UPPER)
             mult = -1.0;
+          if ((st == ST_FREE || st == ST_SUPER) && !M->noFreeOrSuper)
+            bestPossible = dmax(bestPossible, fabs(work[i])); /* :4889-4893 */
           if (st == ST_UPPER || st == ST_LOWER) {
             double alpha = work[i] * mult;
             if (alpha > 0.0) {
@@ -2044,6 +2315,8 @@ static int updateDualsInDual(OrcModel *M, double *outputArray, double theta, dou
         int iSequence = M->colIndex[i];
         double alphaI = M->colValue[i];
         int iStatus = (statusArray[iSequence] & 3) - 1;
+        if (!M->noFreeOrSuper && (statusArray[iSequence] & 7) == ST_SUPER)
+          continue; /* the general column loop (:2596-2651) has no case for a superbasic variable: its dj is left as it was */
         if (iStatus) {
           double value = reducedCost[iSequence] - theta * alphaI;
           reducedCost[iSequence] = value;
@@ -2334,6 +2607,11 @@ static int whileIterating(OrcModel *M)
       M->numberColNz = priceRowFused(M, M->numberPi, M->piIndex, M->piValue, M->rowWork1, M->status, M->dj, M->zeroTolerance,
                                      M->dualTolerance, acceptablePivot, M->colIndex, M->colValue, &M->numberCandidates,
                                      M->spareIndex[0], M->spareValue[0], &M->upperThetaFirst);
+      M->badFree = 0.0;
+      if (!M->noFreeOrSuper)
+        dualColumn0General(M, acceptablePivot); /* (the tableau row is the same; only the first pass differs) */
+      if (M->sequenceIn >= 0)
+        M->numberFreeEntered++;
       bestPossiblePivot = dualColumn(M, acceptablePivot);
       if (M->sequenceIn < 0 && acceptablePivot <= M->acceptablePivot_) {
         if (!M->fac.nEta)
@@ -3087,7 +3365,7 @@ static void statusOfProblemInDual(OrcModel *M, int *lastCleaned, int type)
       if (M->progressFlag & 4)
         M->debugBackwardsAt = -1;
     }
-    if (lastObj > thisObj + testTol * (fabs(thisObj) + fabs(lastObj)) + testTol) {
+    if (M->firstFree < 0 /* :5360 */ && lastObj > thisObj + testTol * (fabs(thisObj) + fabs(lastObj)) + testTol) {
       if (M->progTimesFlagged > 10)
         M->progReallyBadTimes++;
       if (M->maximumPivots > 1) {
@@ -3157,6 +3435,13 @@ static void statusOfProblemInDual(OrcModel *M, int *lastCleaned, int type)
     memcpy(M->costCopy, M->cost, sizeof(double) * (size_t)(m + M->n)); /* save copy of cost_ (:5543-5547) */
   if (!M->numberPrimalInfeasibilities && !M->numberDualInfeasibilities)
     M->progressFlag |= 8; /* mark as having gone optimal if looks like it */
+  /* if we are primal feasible and any dual infeasibilities are on free variables then it is better to go to primal (:5619-5622) */
+  if (M->freeNonbasic && !M->numberPrimalInfeasibilities && !M->numberDualInfeasibilitiesWithoutFree && M->numberDualInfeasibilities) {
+    M->problemStatus = 10;
+    if (M->logLevel > 3)
+      fprintf(stderr, "orc: iteration %d primal feasible, the %d dual infeasibilities are all on free variables: 10\n", M->numberIterations,
+              M->numberDualInfeasibilities);
+  }
   int needCleanFake = 0;
   double saveDualBound = M->dualBound;
   while (M->problemStatus <= -3 && saveDualBound == M->dualBound) {
@@ -3337,7 +3622,7 @@ static void statusOfProblemInDual(OrcModel *M, int *lastCleaned, int type)
   {
     /* refactorize more often when the recorded objective fell between the last two checks (:6316-6328) */
     const double thisObj = progressLastObjective(M, 0), lastObj = progressLastObjective(M, 1);
-    if (lastObj > thisObj + 1.0e-4 * dmax(fabs(thisObj), fabs(lastObj)) + 1.0e-4) {
+    if (lastObj > thisObj + 1.0e-4 * dmax(fabs(thisObj), fabs(lastObj)) + 1.0e-4 && M->firstFree < 0 /* :6319 */) {
       if (M->maximumPivots > 10) {
         if (M->forceFactorization < 0)
           M->forceFactorization = M->maximumPivots;
@@ -3400,7 +3685,8 @@ static int dualOnRim(OrcModel *M)
       } else if (M->colUpper[j] <= 0.0) {
         M->status[j] = ST_UPPER;
       } else if (M->colLower[j] < -1.0e20 && M->colUpper[j] > 1.0e20) {
-        M->status[j] = ST_UPPER; /* free: reference uses isFree; here bothFake bounds, see header */
+        M->status[j] = M->freeNonbasic ? ST_FREE : ST_UPPER; /* free: the reference's isFree (allSlackBasis :7846-7849) with option
+                                                                free_nonbasic, else bothFake bounds, see header */
       } else if (fabs(M->colLower[j]) < fabs(M->colUpper[j])) {
         M->status[j] = ST_LOWER;
       } else {
@@ -3426,6 +3712,10 @@ static int dualOnRim(OrcModel *M)
       setStatus(M, i, ST_LOWER);
       M->sol[i] = M->lower[i];
     }
+    if (M->freeNonbasic && (st == ST_LOWER || st == ST_UPPER) && M->lower[i] < -1.0e20 && M->upper[i] > 1.0e20) {
+      setStatus(M, i, ST_FREE); /* createRim's clean-up of a caller's basis, src/ClpSimplex.cpp:4317-4338 */
+      M->sol[i] = 0.0;
+    }
   }
   M->problemStatus = -1;
   M->numberIterations = 0;
@@ -3440,6 +3730,11 @@ static int dualOnRim(OrcModel *M)
   M->progressFlag = 0; /* :461 */
   M->bestPossibleImprovement = 0.0;
   M->numberBackwards = M->numberLoopFlags = M->numberAccuracyRestores = M->numberSingularRestores = 0;
+  M->noFreeOrSuper = 1;
+  M->firstFree = -1;
+  M->badFree = 0.0;
+  M->numberDualInfeasibilitiesWithoutFree = 0;
+  M->numberFreeFirstRows = M->numberFreeEntered = 0;
   for (int i = 0; i < ORC_CYCLE; i++) { /* progress_.startCheck(), ClpSimplexDual.cpp:452 */
     M->cycIn[i] = M->cycOut[i] = -1;
     M->cycWay[i] = 0;
@@ -3893,6 +4188,8 @@ int orc_number_backwards(const OrcModel *M) { return M->numberBackwards; }
 int orc_number_loop_flags(const OrcModel *M) { return M->numberLoopFlags; }
 int orc_number_accuracy_restores(const OrcModel *M) { return M->numberAccuracyRestores; }
 int orc_number_singular_restores(const OrcModel *M) { return M->numberSingularRestores; }
+int orc_number_free_first_rows(const OrcModel *M) { return M->numberFreeFirstRows; }
+int orc_number_free_entered(const OrcModel *M) { return M->numberFreeEntered; }
 double orc_iteration_seconds(const OrcModel *M) { return M->seconds; }
 void orc_get_solution(const OrcModel *M, double *s) { memcpy(s, M->sol, sizeof(double) * (size_t)(M->m + M->n)); }
 void orc_get_reduced_costs(const OrcModel *M, double *d) { memcpy(d, M->dj, sizeof(double) * (size_t)(M->m + M->n)); }

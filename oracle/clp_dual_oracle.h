@@ -65,6 +65,10 @@ void orc_destroy(OrcModel *model);
  * fixed fractions (ClpSimplexDual::perturb, src/ClpSimplexDual.cpp:6533);
  * "check_both" 1 (default): gutsOfSolution ends in ClpSimplex::checkBothSolutions (src/ClpSimplex.cpp:3226), 0: in the older
  * checkPrimalSolution + checkDualSolution pair;
+ * "free_nonbasic" 0 (default; what the HIP engine does): nonbasic free columns get bothFake bounds at start; 1: they stay isFree as in
+ * the reference -- dualRow's free-first entry (src/ClpSimplexDual.cpp:3005-3055, nextSuperBasic :8285), the general branch of
+ * dualColumn0 (:4058-4179) whenever the last checkBothSolutions saw a nonbasic variable off its bounds (moreSpecialOptions_ & 8),
+ * the free branches of checkDualSolution, "primal feasible and only free dual infeasibilities: 10" (:5619-5622); needs check_both 1;
  * fault injection for the recovery paths of statusOfProblemInDual, each the iteration from which the next status check
  * is hit: "debug_backwards_at" (:5326-5488), "debug_bad_accuracy_at" (:5237-5318), "debug_singular_at" (:5060-5125). */
 int orc_set_option(OrcModel *model, const char *name, double value);
@@ -89,6 +93,10 @@ int orc_number_loop_flags(const OrcModel *model);
 int orc_number_accuracy_restores(const OrcModel *model);
 /* ... and times a singular refactorization sent the solve back to the saved basis (:5060-5125) */
 int orc_number_singular_restores(const OrcModel *model);
+/* option "free_nonbasic" 1: pivot rows chosen by dualRow's free-first entry (:3005-3055), and pivots whose incoming variable was the
+ * free one picked by the general branch of dualColumn0 (:4115-4122), during the last orc_dual */
+int orc_number_free_first_rows(const OrcModel *model);
+int orc_number_free_entered(const OrcModel *model);
 /* copies n+m doubles, [columns | rows] */
 void orc_get_solution(const OrcModel *model, double *solution);
 void orc_get_reduced_costs(const OrcModel *model, double *dj);
