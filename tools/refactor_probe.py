@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the wall clock of a mature config-4 stretch goes: pivots against status checks (refactorization + resync), from the committed
-mature basis, 6000 pivots, option log_level 2 (per status check: its wall time; per LU factorization: host front / tail inversion / build)."""
+mature basis, 6000 pivots (argv[2]: another count), option log_level 2 (per status check: its wall time; per LU factorization: host front / tail inversion / build)."""
 import os
 import sys
 import time
@@ -26,10 +26,11 @@ g.dual_steps(100)
 torch.cuda.synchronize()
 s0 = g.stats()
 t0 = time.perf_counter()
-g.dual_steps(6000)
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 6000
+g.dual_steps(N)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 s1 = g.stats()
-print("PROBE 6000 pivots in %.3f s = %.1f it/s; LU factorizations %d: host front %.0f ms, tail inversion %.0f ms, build %.0f ms; refactorizations %d; nucleus %d tail %d" % (
-    dt, 6000 / dt, s1["lu_factorizations"] - s0["lu_factorizations"], s1["lu_front_ms"] - s0["lu_front_ms"], s1["lu_invert_ms"] - s0["lu_invert_ms"],
+print("PROBE %d pivots in %.3f s = %.1f it/s; LU factorizations %d: host front %.0f ms, tail inversion %.0f ms, build %.0f ms; refactorizations %d; nucleus %d tail %d" % (
+    N, dt, N / dt, s1["lu_factorizations"] - s0["lu_factorizations"], s1["lu_front_ms"] - s0["lu_front_ms"], s1["lu_invert_ms"] - s0["lu_invert_ms"],
     s1["lu_build_ms"] - s0["lu_build_ms"], s1["refactorizations"] - s0["refactorizations"], s1["nucleus"], s1["lu_tail"]))
