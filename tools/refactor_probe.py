@@ -31,6 +31,6 @@ g.dual_steps(N)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 s1 = g.stats()
-print("PROBE %d pivots in %.3f s = %.1f it/s; LU factorizations %d: host front %.0f ms, tail inversion %.0f ms, build %.0f ms; refactorizations %d; nucleus %d tail %d" % (
+print("PROBE %d pivots in %.3f s = %.1f it/s; LU factorizations %d: host front %.0f ms, tail inversion %.0f ms, build %.0f ms; refactorizations %d; nucleus %d tail %d; objective %.6f" % (
     N, dt, N / dt, s1["lu_factorizations"] - s0["lu_factorizations"], s1["lu_front_ms"] - s0["lu_front_ms"], s1["lu_invert_ms"] - s0["lu_invert_ms"],
-    s1["lu_build_ms"] - s0["lu_build_ms"], s1["refactorizations"] - s0["refactorizations"], s1["nucleus"], s1["lu_tail"]))
+    s1["lu_build_ms"] - s0["lu_build_ms"], s1["refactorizations"] - s0["refactorizations"], s1["nucleus"], s1["lu_tail"], g.objectiveValue()))
