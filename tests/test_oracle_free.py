@@ -113,3 +113,45 @@ def test_many_free_columns_the_reference_path_asks_for_primal():
     off = OracleSimplex(lp)
     off.set_option("pivot_rule", 1)
     assert off.dual() == 0 and off.iterations == 927 and abs(off.objective - hobj) <= 1e-7 * (1 + abs(hobj))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_warm_resolve_after_branching_with_free_columns(seed):
+    """The branch-and-bound pattern of tests/test_oracle_fuzz.py on the free path: solve, tighten three columns around their values, re-solve
+    from the optimal basis with the option still on.  The warm start's statuses come from the first solve: free columns are basic, at a
+    fake-bound status (cleaned back to isFree by the start-up, src/ClpSimplex.cpp:4317-4338) or still isFree."""
+    for attempt in range(20):
+        rng = np.random.default_rng(9000 + 20 * seed + attempt)
+        lp = make(rng)
+        if len(free_columns(lp)) and highs(lp)[0] == 0:
+            break
+    else:
+        pytest.skip("no solvable draw with a free column")
+    for rule in (0, 1):
+        o, st = solve(lp, rule)
+        if st != 0:
+            continue
+        status, x = o.status().copy(), o.solution()
+        lp2 = type(lp)(lp)
+        cu, cl = lp.col_upper.copy(), lp.col_lower.copy()
+        for j in rng.choice(lp.n, min(3, lp.n), replace=False):
+            if rng.uniform() < 0.5:
+                if x[j] > 0.5:
+                    cu[j] = min(cu[j], np.floor(x[j]))
+            elif cl[j] > -1e29:
+                cl[j] = max(cl[j], np.ceil(x[j]))
+        lp2.col_upper, lp2.col_lower = cu, cl
+        hs2, hobj2 = highs(lp2)
+        for opts in ({}, {"perturbation": 100}, {"max_pivots": 3}):
+            o2 = OracleSimplex(lp2)
+            o2.set_option("pivot_rule", rule)
+            o2.set_option("free_nonbasic", 1)
+            for k, v in opts.items():
+                o2.set_option(k, v)
+            o2.set_status(status & 7)
+            st2 = o2.dual()
+            where = (seed, rule, opts, hs2, st2)
+            if hs2 == 0:
+                assert st2 == 10 or (st2 == 0 and abs(o2.objective - hobj2) <= 1e-6 * (1 + abs(hobj2))), where
+            elif hs2 == 2:
+                assert st2 in (1, 2, 10), where
