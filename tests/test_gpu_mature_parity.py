@@ -1,0 +1,153 @@
+"""The regime the bench times -- config 4 warm-started from the committed mature basis (tests/golden/basis_sparse_30000.npy:
+nucleus 10 514, pi dense, pricing by column, LU mode) -- held against checkers that do not share the engine's factorization:
+
+  * the CPU oracle (dense nucleus LU, restated ClpSimplexDual) warm-started from the same statuses: same entering / leaving
+    VARIABLES, theta / alpha to 1e-6, for as long as no tie is broken by basis position (the oracle's solve is a committed
+    record, tests/golden/oracle_cache/, written by tests/golden/make_oracle_cache.py: ~25 minutes of one CPU core);
+  * the basis matrix itself (scipy sparse, no factorization at all): residuals of the engine's FTRAN / BTRAN,
+    ||B x - v|| and ||B^T y - v||, right after the factorization of that basis and again behind an eta file of 800
+    column replacements.
+
+Reference semantics: src/ClpSimplexDual.cpp:1447-1501 (the btran / ftran alpha check), src/ClpFactorization.cpp:2584-3106.
+Tolerances are written at each assertion."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from clp_amd import problems as P
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MATURE = os.path.join(ROOT, "tests", "golden", "basis_sparse_30000.npy")
+ORACLE_PIVOTS = 400  # below the refactorization interval of this LP (475): one dense LU of order 10 514 on the CPU
+
+
+@pytest.fixture(scope="module")
+def gpu_cls(built):
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from clp_amd.engine import ClpGpuSimplex
+
+    return ClpGpuSimplex
+
+
+def mature_status():
+    return (np.load(MATURE) & 7).astype(np.uint8)
+
+
+def test_lu_mode_from_the_mature_basis_follows_the_oracle(gpu_cls):
+    """Engine in its DEFAULT mode (LU: sparse front + dense tail + eta file) against the oracle's dense LU from the
+    same warm start.  The two factorizations put the basic variables at different positions, so the comparison is by
+    variable; it ends where a tie is broken by position.  Asserts the shared prefix and prints it."""
+    from oracle.oracle import OracleSimplex
+
+    lp = P.sparse_lp()
+    status = mature_status()
+    g = gpu_cls().loadProblem(lp)
+    g.setStatusArray(status)
+    g.set_option("pivot_rule", 1)
+    g.set_option("max_pivots", 0)
+    assert g.dual_steps(ORACLE_PIVOTS) == -1
+    st = g.stats()
+    assert st["lu_active"] == 1 and st["lu_front"] > 0 and st["lu_tail"] > 0, "the bench's regime is LU mode"
+    o = OracleSimplex(lp)
+    o.set_option("pivot_rule", 1)
+    o.set_option("max_pivots", 0)
+    o.set_status(status)
+    o.set_option("max_iterations", ORACLE_PIVOTS)
+    assert o.dual() == 3
+    a, b = g.pivotLog(), o.pivot_log()
+    assert len(a) == len(b) == ORACLE_PIVOTS
+    same = 0
+    while same < ORACLE_PIVOTS and a[same]["sequenceIn"] == b[same]["sequenceIn"] and a[same]["sequenceOut"] == b[same]["sequenceOut"]:
+        same += 1
+    print(f"mature basis, LU mode vs oracle: {same} of {ORACLE_PIVOTS} pivots identical (entering and leaving variables)")
+    assert same >= 100, f"pivot sequences part at pivot {same}"
+    pre = slice(0, same)
+    # theta and alpha of the shared prefix: 1e-6 relative (the bases of this stretch have condition numbers beyond 1e10)
+    for f in ("theta", "alpha", "dualOut"):
+        x, y = a[f][pre], b[f][pre]
+        assert float(np.max(np.abs(x - y) / (1e-6 + np.abs(y)))) < 1e-5 or float(np.max(np.abs(x - y) / (1.0 + np.abs(y)))) < 1e-6, f
+    assert np.array_equal(a["numberFlipped"][pre], b["numberFlipped"][pre])
+    if same == ORACLE_PIVOTS:
+        assert abs(g.objectiveValue() - o.objective) <= 1e-8 * abs(o.objective)
+
+
+def _basis(lp, pv):
+    m, n = lp.m, lp.n
+    A = sp.csc_matrix((lp.elem, lp.row, lp.col_start), shape=(m, n))
+    full = sp.hstack([A, -sp.identity(m, format="csc")]).tocsc()
+    return full[:, pv].tocsc()
+
+
+def _column(lp, q):
+    col = np.zeros(lp.m)
+    if q >= lp.n:
+        col[q - lp.n] = -1.0
+    else:
+        col[lp.row[lp.col_start[q]:lp.col_start[q + 1]]] = lp.elem[lp.col_start[q]:lp.col_start[q + 1]]
+    return col
+
+
+def test_solves_at_the_mature_basis_have_small_residuals(gpu_cls):
+    """No second factorization involved: with B assembled by scipy from the engine's pivotVariable, the FTRAN / BTRAN
+    of the default LU mode must satisfy B x = v and B^T y = v to 1e-9 of the solution's scale -- right after the
+    factorization (front + MFMA tail inversion + polish) and behind 800 product-form etas."""
+    lp = P.sparse_lp()
+    m, n = lp.m, lp.n
+    status = mature_status()
+    g = gpu_cls().loadProblem(lp)
+    g.set_option("lu_max_pivots", 2000)
+    rc, pv = g.factorize(status)
+    assert rc == 0, g.lastError()
+    st = g.stats()
+    assert st["lu_active"] == 1 and st["lu_tail"] > 2000
+    pv = np.asarray(pv).copy()
+    rng = np.random.default_rng(20260926)
+
+    def residuals(tag):
+        B = _basis(lp, pv)
+        worst = 0.0
+        for kind in range(3):
+            if kind == 0:
+                v = rng.standard_normal(m)
+            elif kind == 1:
+                v = rng.standard_normal(m) * (rng.random(m) < 0.01)  # a sparse right-hand side (an entering column's shape)
+            else:
+                v = np.zeros(m)
+                v[int(rng.integers(0, m))] = 1.0  # the pivot's unit vector
+            x, y = g.ftran(v), g.btran(v)
+            rf = float(np.max(np.abs(B @ x - v)) / (np.max(np.abs(v)) + np.max(np.abs(B)) * np.max(np.abs(x))))
+            rb = float(np.max(np.abs(B.T @ y - v)) / (np.max(np.abs(v)) + np.max(np.abs(B)) * np.max(np.abs(y))))
+            worst = max(worst, rf, rb)
+        print(f"{tag}: worst normwise backward error of FTRAN / BTRAN {worst:.2e}")
+        return worst
+
+    assert residuals("after the factorization") < 1e-9
+    basic = set(int(s) for s in pv)
+    lastp = -1
+    done = 0
+    while done < 800:
+        q = int(rng.integers(0, n + m))
+        if q in basic:
+            continue
+        w = g.ftran(_column(lp, q))
+        cand = np.nonzero(np.abs(w) > 0.1 * np.max(np.abs(w)))[0]
+        if not len(cand):
+            continue
+        p = lastp if (done % 7 == 6 and lastp >= 0 and abs(w[lastp]) > 0.05 * np.max(np.abs(w))) else int(cand[rng.integers(0, len(cand))])
+        assert g.replaceColumn(p, q) == 0
+        basic.discard(int(pv[p]))
+        basic.add(q)
+        pv[p] = q
+        lastp = p
+        done += 1
+        if done in (100, 400):
+            assert residuals(f"behind {done} etas") < 1e-8
+    assert g.pivots() == 800
+    assert residuals("behind 800 etas") < 1e-8
+    assert np.array_equal(np.asarray(g.pivotVariable()), pv)

@@ -1,0 +1,831 @@
+// Stand-alone probe of the dense-pi row-pricing kernel (round 5): pi from LDS row tiles, the column entries as a
+// tile-by-tile JAGGED stream (no padding), partial sums carried in registers from tile to tile.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o price_lds_bench tools/price_lds_bench.hip
+//   ./price_lds_bench [rows cols nnz_per_col]
+// Builds a config-4-shaped random matrix (1 + Poisson(nnz-1) distinct rows per column), prices a dense pi with
+//   V0  the round-4 form (windowed SELL-64, pi gathered from global memory / L2),
+//   V1  the LDS-tiled forms (template: threads per workgroup, steps per batch),
+// checks every column's dot product against the CPU's sequential sum BIT FOR BIT, and times each form with HIP events
+// around single launches separated by a cache-thrashing kernel (the matrix fits the 256 MB Infinity Cache; in a real
+// pivot ~1 GB of other streams pass between two pricing launches).
+// This file is lab equipment: the product kernel lives in clp_amd/csrc/kernels.hip (k_price_lds).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#define CHECK(x)                                                                                  \
+  do {                                                                                            \
+    hipError_t e_ = (x);                                                                          \
+    if (e_ != hipSuccess) {                                                                       \
+      fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_));          \
+      exit(1);                                                                                    \
+    }                                                                                             \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------------------------------------------------
+// layouts
+// ------------------------------------------------------------------------------------------------------------
+struct PlDev {
+  int m, n, numWindows, numTiles, tileRows;
+  const int *segStart;          // [numWindows * 4] first entry of the slice's stream (tiles back to back)
+  const unsigned char *cnt;     // [(slice * numTiles + tau) * 64 + p] entries in tile tau of the column at position p of THAT tile's order
+  const unsigned char *src;     // [(slice * numTiles + tau) * 64 + p] position (tile tau-1's order) of the same column; tau = 0 unused
+  const unsigned char *home;    // [slice * 64 + l] position (last tile's order) of the column at home position l
+  const int *col;               // [slice * 64 + l] column key at home position l, -1 none
+  const unsigned *rowPair;      // per record: the tile-local row indices of two consecutive steps of one column, 16 bits each
+  const double2 *elemPair;      // per record: their two elements (second 0.0 when the column has an odd count in the tile)
+  const double *piNeg;          // [m]
+  const unsigned char *status;  // [n]
+  const double *dj;             // [n]
+  double *alphaCol;             // [n]
+  unsigned char *candFlag;      // [n]
+  int *blockCount;              // [numWindows]
+  double *winMin;               // [numWindows]
+};
+
+struct SellDev {
+  int m, n, numSlices;
+  const int *sellStart, *sellCol, *sellLen, *sellRow;
+  const double *sellElem;
+  const double *piNeg;
+  const unsigned char *status;
+  const double *dj;
+  double *alphaCol;
+  unsigned char *candFlag;
+  int *blockCount;
+  double *winMin;
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// V0: round-4 form -- one wave per 64-column slice, four slices = one window of 256 keys per workgroup, pi from L2
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_v0(SellDev D)
+{
+  __shared__ double shAlpha[256];
+  __shared__ unsigned char shFlag[256];
+  const int lane = threadIdx.x & 63;
+  const int slice = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int jOut = -1, flagOut = 0;
+  double valueOut = 0.0;
+  if (slice < D.numSlices) {
+    const int idx = slice * 64 + lane;
+    const int j = D.sellCol[idx];
+    int len = 0, wanted = 0;
+    if (j >= 0) {
+      wanted = (D.status[j] & 3) - 1;
+      if (wanted)
+        len = D.sellLen[idx];
+    }
+    int maxLen = len;
+    for (int o = 32; o > 0; o >>= 1)
+      maxLen = max(maxLen, __shfl_xor(maxLen, o));
+    double value = 0.0;
+    const int start = D.sellStart[slice];
+    const int *rp = D.sellRow + start + lane;
+    const double *ep = D.sellElem + start + lane;
+    for (int t = 0; t < maxLen; t += 8) {
+      int r[8];
+      double e[8], pv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        r[u] = rp[(t + u) * 64];
+        e[u] = ep[(t + u) * 64];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        pv[u] = D.piNeg[r[u]];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (t + u < len)
+          value += pv[u] * e[u];
+    }
+    if (j >= 0) {
+      int flag = 0;
+      if (wanted) {
+        if (fabs(value) > 1.0e-13) {
+          if (wanted > 0) {
+            double mult = (wanted == 1) ? -1.0 : 1.0;
+            double alpha = value * mult;
+            if (alpha > 0.0) {
+              double oldValue = D.dj[j] * mult;
+              if (oldValue - 1.0e15 * alpha < -1.0e-7)
+                flag = 1;
+            }
+          }
+        } else {
+          value = 0.0;
+        }
+      }
+      jOut = j;
+      valueOut = value;
+      flagOut = flag;
+    }
+  }
+  const int j0 = blockIdx.x * 256;
+  shFlag[threadIdx.x] = 0xFF;
+  __syncthreads();
+  if (jOut >= 0) {
+    shAlpha[jOut - j0] = valueOut;
+    shFlag[jOut - j0] = (unsigned char)flagOut;
+  }
+  __syncthreads();
+  const unsigned char f = shFlag[threadIdx.x];
+  if (f != 0xFF) {
+    D.alphaCol[j0 + threadIdx.x] = shAlpha[threadIdx.x];
+    D.candFlag[j0 + threadIdx.x] = f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// V1: pi tiles in LDS, jagged tile-by-tile streams
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ldsBarrier()
+{
+  // LDS traffic of this wave has landed / been read; global loads stay in flight across the barrier
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int HP> struct Half {
+  unsigned r[HP];
+  double2 e[HP];
+};
+
+// HP consecutive step PAIRS of a segment whose lanes hold `cnt` entries (the lanes of a segment are sorted by count, so
+// the lanes with a record in a pair are a prefix); `off` is the wave-uniform record position of step t0 (even) and is
+// advanced past them.  Every lane loads (straight-line code, so the compiler's vmcnt bookkeeping stays exact): a lane
+// without a record re-reads the first record of the pair, which an active lane fetches anyway.
+template <int HP>
+__device__ __forceinline__ void loadHalf(Half<HP> &h, const unsigned *__restrict__ rowPair, const double2 *__restrict__ elemPair, int cnt, int t0,
+                                         unsigned &off, unsigned lane)
+{
+#pragma unroll
+  for (int u = 0; u < HP; u++) {
+    const bool act = cnt > t0 + 2 * u;
+    const unsigned k = (unsigned)__popcll(__ballot(act));
+    const unsigned *rp = rowPair + off;  // wave-uniform
+    const double2 *ep = elemPair + off;
+    const unsigned at = act ? lane : 0u;
+    h.r[u] = rp[at];
+    h.e[u] = ep[at];
+    off += k;
+  }
+}
+
+// `zero` = index of a permanent 0.0 behind the pi tile: a step without an entry multiplies its (finite) element by it, and
+// adding +-0.0 leaves the running sum as it is (the sum starts from +0.0 and can never become -0.0), so the chain of
+// dependent operations per step is one add
+template <int HP> __device__ __forceinline__ double consumeHalf(const Half<HP> &h, const double *piTile, int cnt, int t0, double acc, unsigned zero)
+{
+  constexpr int Q = (HP % 4 == 0) ? 4 : ((HP % 3 == 0) ? 3 : HP);
+#pragma unroll
+  for (int q0 = 0; q0 < HP; q0 += Q) {
+    double pa[Q], pb[Q];
+#pragma unroll
+    for (int u = 0; u < Q; u++) {
+      pa[u] = piTile[(cnt > t0 + 2 * (q0 + u)) ? (h.r[q0 + u] & 0xFFFFu) : zero];
+      pb[u] = piTile[(cnt > t0 + 2 * (q0 + u) + 1) ? (h.r[q0 + u] >> 16) : zero];
+    }
+#pragma unroll
+    for (int u = 0; u < Q; u++) {
+      acc = acc + pa[u] * h.e[q0 + u].x;
+      acc = acc + pb[u] * h.e[q0 + u].y;
+    }
+  }
+  return acc;
+}
+
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+typedef __attribute__((address_space(1))) const unsigned char glb_byte;
+
+// one 1 KB wave-chunk of pi straight into LDS (no VGPR round trip): lane l's 16 bytes land at ldsDst + 16 l
+__device__ __forceinline__ void gldsAsm(const double *gsrc, unsigned ldsDst)
+{
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(ldsDst)
+               : "memory");
+}
+
+// REFILL: how the next pi tile reaches LDS -- 0 through registers (loads issued a tile ahead), 1 LDS-DMA by the compiler's
+// builtin, 2 LDS-DMA by inline asm (invisible to the compiler's vmcnt bookkeeping: the waits are placed by hand).
+// NBUF: 1 = one pi tile in LDS (barrier, refill, barrier per tile); 2 = two half-size tiles, the next one filled while
+// this one is read (one barrier per tile).
+// DBG (probe only): 1 no consumption (the loaded values are folded into the sum without LDS or the ordered adds), 2 no ring loads,
+// 4 no pi refills after tile 0, 8 no barriers in the tile loop
+template <int THREADS, int HP, int NBUF, int REFILL, int PCH, int DBG = 0>
+__global__ void __launch_bounds__(THREADS, 4) k_v1(PlDev P)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NW = THREADS / 64, NQ = THREADS / 256;
+  constexpr int RING = 4 * HP;  // steps the two halves hold
+  const int tileBytes = P.tileRows * 8 + 16;  // + the permanent zero behind the tile
+  const unsigned zero = (unsigned)P.tileRows;
+  double *shAlpha = (double *)(smem + (size_t)NBUF * tileBytes);
+  unsigned char *shFlag = (unsigned char *)(shAlpha + NQ * 256);
+  int *shCnt = (int *)(shFlag + NQ * 256);
+  double *shMin = (double *)(shCnt + NW);
+  const int tid = threadIdx.x;
+  const unsigned lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int quad = wv >> 2;
+  const int window = (int)blockIdx.x + (int)gridDim.x * quad;
+  const bool live = window < P.numWindows;
+  const int slice = live ? window * 4 + (wv & 3) : 0;
+  const int T = P.numTiles;
+  const int nChunks = (P.tileRows * 8) >> 10;  // 1 KB wave-chunks per tile (tileRows is a multiple of 128)
+  const unsigned ldsBase = (unsigned)(size_t)(lds_byte *)smem;
+  // per-tile lane metadata (entries of the lane's column in the tile; where the column sat in the previous tile's order):
+  // fetched two tiles ahead, so that the load is older than every ring load in flight when its value is first needed
+  // (a wait for a YOUNGER load would drain the ring: vmcnt counts in order)
+  const unsigned char *metaCnt = P.cnt + (size_t)slice * T * 64 + lane, *metaSrc = P.src + (size_t)slice * T * 64 + lane;
+  int cntCur = metaCnt[0];
+  int rawCnt1 = metaCnt[min(1, T - 1) * 64], rawSrc1 = metaSrc[min(1, T - 1) * 64];
+  unsigned off = (unsigned)P.segStart[slice];
+  if (!live)
+    cntCur = 0;
+  off = __builtin_amdgcn_readfirstlane(off);
+  int maxCur = __builtin_amdgcn_readfirstlane(cntCur);
+  Half<HP> H0, H1;
+  loadHalf<HP>(H0, P.rowPair, P.elemPair, cntCur, 0, off, lane);
+  loadHalf<HP>(H1, P.rowPair, P.elemPair, cntCur, 2 * HP, off, lane);
+  double2 pr[REFILL == 0 ? PCH : 1];
+  // this wave's chunks of tile tau: global -> registers (REFILL 0) or global -> LDS buffer `buf` (REFILL 1, 2)
+  auto refillIssue = [&](int tau, int buf) {
+    const double *src = P.piNeg + (size_t)tau * P.tileRows;  // (zero-padded to numTiles * tileRows entries)
+#pragma unroll
+    for (int q = 0; q < PCH; q++) {
+      const int c = wv + q * NW;
+      if (REFILL == 0) {
+        pr[q] = ((const double2 *)(src + (size_t)min(c, nChunks - 1) * 128))[lane];
+      } else if (c < nChunks) {
+        if (REFILL == 1)
+          __builtin_amdgcn_global_load_lds((glb_byte *)(src + (size_t)c * 128 + lane * 2), (lds_byte *)smem + (size_t)buf * tileBytes + c * 1024, 16, 0, 0);
+        else
+          gldsAsm(src + (size_t)c * 128 + lane * 2, __builtin_amdgcn_readfirstlane(ldsBase + (unsigned)buf * tileBytes + c * 1024));
+      }
+    }
+  };
+  auto refillStore = [&](int buf) {  // REFILL 0 only
+#pragma unroll
+    for (int q = 0; q < PCH; q++) {
+      const int c = wv + q * NW;
+      if (c < nChunks)
+        ((double2 *)(smem + (size_t)buf * tileBytes + c * 1024))[lane] = pr[q];
+    }
+  };
+  if (tid < NBUF)
+    *(double *)(smem + (size_t)tid * tileBytes + (size_t)P.tileRows * 8) = 0.0;
+  // ---- tile 0 into buffer 0
+  refillIssue(0, 0);
+  if (REFILL == 0)
+    refillStore(0);
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ldsBarrier();
+  if (NBUF == 2 && T > 1)
+    refillIssue(1, 1);
+  if (NBUF == 1 && REFILL == 0 && T > 1)
+    refillIssue(1, 0);
+  double acc = 0.0;
+  for (int tau = 0; tau < T; tau++) {
+    const int rawCnt2 = metaCnt[min(tau + 2, T - 1) * 64], rawSrc2 = metaSrc[min(tau + 2, T - 1) * 64];
+    const bool haveNext = live && tau + 1 < T;
+    const int cntNext = haveNext ? rawCnt1 : 0, srcNext = haveNext ? rawSrc1 : (int)lane;
+    const double *piTile = (const double *)(smem + (size_t)(NBUF == 2 ? (tau & 1) : 0) * tileBytes);
+    // the ring holds steps t0 .. t0 + RING - 1 of this tile; the tile's step count is padded to a multiple of RING
+    // (steps with no active lane), so the roles of H0 / H1 are the same at every tile boundary
+    const int maxPad = max(RING, (maxCur + RING - 1) / RING * RING);
+    for (int t0 = 0; t0 < maxPad; t0 += RING) {
+      const bool more = t0 + RING < maxPad;  // wave-uniform
+      const int cntL = more ? cntCur : cntNext, tL = more ? t0 + RING : 0;
+      // (the scheduling barriers keep the issue order consume / refill / consume / refill: the loads of a refill stay
+      // in flight while the other half is consumed, and the compiler's vmcnt counts come out exact)
+      if (DBG & 1) {
+#pragma unroll
+        for (int u = 0; u < HP; u++)
+          acc += H0.e[u].x + H0.e[u].y + (double)H0.r[u];
+      } else
+        acc = consumeHalf<HP>(H0, piTile, cntCur, t0, acc, zero);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(DBG & 2))
+        loadHalf<HP>(H0, P.rowPair, P.elemPair, cntL, tL, off, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      if (DBG & 1) {
+#pragma unroll
+        for (int u = 0; u < HP; u++)
+          acc += H1.e[u].x + H1.e[u].y + (double)H1.r[u];
+      } else
+        acc = consumeHalf<HP>(H1, piTile, cntCur, t0 + 2 * HP, acc, zero);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(DBG & 2))
+        loadHalf<HP>(H1, P.rowPair, P.elemPair, cntL, tL + 2 * HP, off, lane);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (tau + 1 < T) {
+      acc = __shfl(acc, srcNext);
+      cntCur = cntNext;
+      maxCur = __builtin_amdgcn_readfirstlane(cntNext);
+      rawCnt1 = rawCnt2;
+      rawSrc1 = rawSrc2;
+      if (NBUF == 2) {
+        // tile tau + 1 was requested a whole tile phase ago; every load issued since is one of the ring's 4 HP
+        if (REFILL == 0)
+          refillStore((tau + 1) & 1);
+        else
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * HP) : "memory");
+        if (!(DBG & 8))
+          ldsBarrier();  // buffer (tau + 1) & 1 is complete, and nobody reads buffer tau & 1 any more
+        if (tau + 2 < T && !(DBG & 4))
+          refillIssue(tau + 2, tau & 1);
+      } else {
+        if (!(DBG & 8))
+          ldsBarrier();  // every wave is done reading the tile
+        if (REFILL == 0) {
+          refillStore(0);
+        } else if (!(DBG & 4)) {
+          refillIssue(tau + 1, 0);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (!(DBG & 8))
+          ldsBarrier();
+        if (REFILL == 0 && tau + 2 < T)
+          refillIssue(tau + 2, 0);
+      }
+    }
+  }
+  // back to the home order of the slice, then the fused first ratio pass and the windowed write-out
+  int j = -1;
+  double value = 0.0;
+  if (live) {
+    value = __shfl(acc, (int)P.home[(size_t)slice * 64 + lane]);
+    j = P.col[(size_t)slice * 64 + lane];
+  }
+  int flag = 0;
+  double ratio = 1.0e31;
+  if (j >= 0) {
+    const int wanted = (P.status[j] & 3) - 1;
+    if (wanted) {
+      if (fabs(value) > 1.0e-13) {
+        if (wanted > 0) {
+          double mult = (wanted == 1) ? -1.0 : 1.0;
+          double alpha = value * mult;
+          if (alpha > 0.0) {
+            double oldValue = P.dj[j] * mult;
+            if (oldValue - 1.0e15 * alpha < -1.0e-7) {
+              flag = 1;
+              if (alpha >= 1.0e-9)
+                ratio = (oldValue + 1.0e-7) / alpha;
+            }
+          }
+        }
+      } else {
+        value = 0.0;
+      }
+    } else {
+      value = 0.0;
+    }
+  }
+  const int wtid = tid & 255;  // position inside the window's four waves
+  shFlag[quad * 256 + wtid] = 0xFF;
+  ldsBarrier();
+  const int j0 = window * 256;
+  if (j >= 0) {
+    shAlpha[quad * 256 + (j - j0)] = value;
+    shFlag[quad * 256 + (j - j0)] = (unsigned char)flag;
+  }
+  for (int o = 32; o > 0; o >>= 1)
+    ratio = fmin(ratio, __shfl_xor(ratio, o));
+  const int wcount = (int)__popcll(__ballot(flag != 0));
+  if (lane == 0) {
+    shCnt[wv] = wcount;
+    shMin[wv] = ratio;
+  }
+  ldsBarrier();
+  if (live) {
+    const unsigned char f = shFlag[quad * 256 + wtid];
+    if (f != 0xFF) {
+      P.alphaCol[j0 + wtid] = shAlpha[quad * 256 + wtid];
+      P.candFlag[j0 + wtid] = f;
+    }
+    if (wtid == 0) {
+      P.blockCount[window] = shCnt[quad * 4] + shCnt[quad * 4 + 1] + shCnt[quad * 4 + 2] + shCnt[quad * 4 + 3];
+      P.winMin[window] = fmin(fmin(shMin[quad * 4], shMin[quad * 4 + 1]), fmin(shMin[quad * 4 + 2], shMin[quad * 4 + 3]));
+    }
+  }
+}
+
+// reference: the same bytes as plain contiguous streams (each wave sums its slice's records), same grid / LDS footprint
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS, 4) k_stream(PlDev P, int totalRecords)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, quad = wv >> 2;
+  const int window = (int)blockIdx.x + (int)gridDim.x * quad;
+  double acc = 0.0;
+  if (window < P.numWindows) {
+    const int slice = window * 4 + (wv & 3);
+    const int a = P.segStart[slice], b = slice + 1 < P.numWindows * 4 ? P.segStart[slice + 1] : totalRecords;
+    for (int i = a + lane; i < b; i += 64 * 8) {
+      double2 e[8];
+      unsigned r[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int at = min(i + 64 * u, b - 1);
+        e[u] = P.elemPair[at];
+        r[u] = P.rowPair[at];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        acc += e[u].x + e[u].y + (double)r[u];
+    }
+  }
+  if (acc == 1.2345e300)
+    P.alphaCol[tid] = acc + smem[tid];
+}
+
+__global__ void k_empty(PlDev P)
+{
+  if (P.m < 0)
+    P.alphaCol[threadIdx.x] = 0.0;
+}
+
+// read-only sweep of a buffer larger than L2 + Infinity Cache: leaves both full of CLEAN lines (a writing sweep would leave
+// dirty lines whose write-back competes with the timed kernel's reads)
+__global__ void k_thrash(const double *p, size_t n, double *sink)
+{
+  double acc = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    acc += p[i];
+  if (acc == 1.2345e300)
+    sink[0] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host
+// ------------------------------------------------------------------------------------------------------------
+template <class T> T *upload(const std::vector<T> &v)
+{
+  T *d;
+  CHECK(hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(T)));
+  if (!v.empty())
+    CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return d;
+}
+
+struct Csc {
+  int m, n;
+  std::vector<int> colStart, row;
+  std::vector<double> elem;
+};
+
+static Csc makeMatrix(int m, int n, int per)
+{
+  Csc A;
+  A.m = m;
+  A.n = n;
+  A.colStart.assign(n + 1, 0);
+  std::mt19937_64 rng(20260926);
+  std::poisson_distribution<int> pois(per - 1);
+  std::uniform_int_distribution<int> rrow(0, m - 1);
+  std::uniform_real_distribution<double> rval(-1.0, 1.0);
+  std::vector<int> mark(m, -1), rows;
+  for (int j = 0; j < n; j++) {
+    int k = std::min(m, 1 + pois(rng));
+    rows.clear();
+    while ((int)rows.size() < k) {
+      int r = rrow(rng);
+      if (mark[r] != j) {
+        mark[r] = j;
+        rows.push_back(r);
+      }
+    }
+    std::sort(rows.begin(), rows.end());
+    for (int r : rows) {
+      A.row.push_back(r);
+      double v = rval(rng);
+      if (fabs(v) < 0.05)
+        v = v < 0 ? -0.05 : 0.05;
+      A.elem.push_back(v);
+    }
+    A.colStart[j + 1] = (int)A.row.size();
+  }
+  return A;
+}
+
+struct JdsHost {
+  int numWindows, numTiles, tileRows;
+  std::vector<int> segStart, col;
+  std::vector<unsigned char> cnt, src, home;
+  std::vector<unsigned> rowPair;
+  std::vector<double2> elemPair;
+  long steps = 0;  // wave steps (sum over slices and tiles of the longest count)
+};
+
+static JdsHost buildJds(const Csc &A, int tileRows)
+{
+  JdsHost J;
+  const int n = A.n, m = A.m;
+  J.tileRows = tileRows;
+  J.numTiles = cdiv(m, tileRows);
+  J.numWindows = cdiv(n, 256);
+  const int T = J.numTiles, nSl = J.numWindows * 4;
+  J.segStart.assign(nSl, 0);
+  J.col.assign((size_t)nSl * 64, -1);
+  J.cnt.assign((size_t)nSl * T * 64, 0);
+  J.src.assign((size_t)nSl * T * 64, 0);
+  J.home.assign((size_t)nSl * 64, 0);
+  J.rowPair.reserve(A.row.size() / 2 + A.row.size() / 16);
+  J.elemPair.reserve(A.row.size() / 2 + A.row.size() / 16);
+  std::vector<int> cols, ord(64), prevPos(64), pos(64), ptr(64);
+  std::vector<int> cntHome((size_t)T * 64);
+  for (int w = 0; w < J.numWindows; w++) {
+    cols.clear();
+    for (int j = w * 256; j < std::min(n, (w + 1) * 256); j++)
+      cols.push_back(j);
+    std::stable_sort(cols.begin(), cols.end(), [&](int a, int b) { return A.colStart[a + 1] - A.colStart[a] > A.colStart[b + 1] - A.colStart[b]; });
+    for (int s = 0; s < 4; s++) {
+      const int slice = w * 4 + s;
+      int h[64];
+      for (int l = 0; l < 64; l++) {
+        const size_t i = (size_t)s * 64 + l;
+        h[l] = i < cols.size() ? cols[i] : -1;
+        J.col[(size_t)slice * 64 + l] = h[l];
+      }
+      std::fill(cntHome.begin(), cntHome.end(), 0);
+      for (int l = 0; l < 64; l++)
+        if (h[l] >= 0)
+          for (int p = A.colStart[h[l]]; p < A.colStart[h[l] + 1]; p++)
+            cntHome[(size_t)(A.row[p] / tileRows) * 64 + l]++;
+      for (int l = 0; l < 64; l++) {
+        prevPos[l] = l;  // position of home lane l in the previous tile's order (tile 0: unused)
+        ptr[l] = h[l] >= 0 ? A.colStart[h[l]] : 0;
+      }
+      J.segStart[slice] = (int)J.rowPair.size();
+      for (int tau = 0; tau < T; tau++) {
+        for (int l = 0; l < 64; l++)
+          ord[l] = l;
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return cntHome[(size_t)tau * 64 + a] > cntHome[(size_t)tau * 64 + b]; });
+        int maxc = 0;
+        for (int p = 0; p < 64; p++) {
+          const int c = cntHome[(size_t)tau * 64 + ord[p]];
+          if (c > 255) {
+            fprintf(stderr, "column with more than 255 entries in a tile\n");
+            exit(1);
+          }
+          J.cnt[((size_t)slice * T + tau) * 64 + p] = (unsigned char)c;
+          J.src[((size_t)slice * T + tau) * 64 + p] = (unsigned char)prevPos[ord[p]];
+          pos[ord[p]] = p;
+          maxc = std::max(maxc, c);
+        }
+        J.steps += maxc;
+        for (int t = 0; t < maxc; t += 2)
+          for (int p = 0; p < 64; p++) {
+            const int l = ord[p], c = cntHome[(size_t)tau * 64 + l];
+            if (c > t) {
+              const int q = ptr[l] + t;
+              unsigned rr = (unsigned)(A.row[q] - tau * tileRows);
+              double2 ee = make_double2(A.elem[q], 0.0);
+              if (c > t + 1) {
+                rr |= (unsigned)(A.row[q + 1] - tau * tileRows) << 16;
+                ee.y = A.elem[q + 1];
+              }
+              J.rowPair.push_back(rr);
+              J.elemPair.push_back(ee);
+            }
+          }
+        for (int l = 0; l < 64; l++) {
+          ptr[l] += cntHome[(size_t)tau * 64 + l];
+          prevPos[l] = pos[l];
+        }
+      }
+      for (int l = 0; l < 64; l++)
+        J.home[(size_t)slice * 64 + l] = (unsigned char)prevPos[l];
+    }
+  }
+  J.rowPair.resize(J.rowPair.size() + 64, 0u);  // a pair with no active lane reads the record behind the stream
+  J.elemPair.resize(J.elemPair.size() + 64, make_double2(0.0, 0.0));
+  return J;
+}
+
+struct SellHost {
+  int numSlices;
+  std::vector<int> sellStart, sellCol, sellLen, sellRow;
+  std::vector<double> sellElem;
+};
+
+static SellHost buildSell(const Csc &A)
+{
+  SellHost S;
+  const int n = A.n;
+  const int nWin = cdiv(n, 256);
+  S.numSlices = nWin * 4;
+  S.sellStart.assign(S.numSlices + 1, 0);
+  S.sellCol.assign((size_t)S.numSlices * 64, -1);
+  S.sellLen.assign((size_t)S.numSlices * 64, 0);
+  std::vector<int> cols;
+  for (int w = 0; w < nWin; w++) {
+    cols.clear();
+    for (int j = w * 256; j < std::min(n, (w + 1) * 256); j++)
+      cols.push_back(j);
+    std::stable_sort(cols.begin(), cols.end(), [&](int a, int b) { return A.colStart[a + 1] - A.colStart[a] > A.colStart[b + 1] - A.colStart[b]; });
+    for (size_t i = 0; i < cols.size(); i++) {
+      S.sellCol[(size_t)w * 256 + i] = cols[i];
+      S.sellLen[(size_t)w * 256 + i] = A.colStart[cols[i] + 1] - A.colStart[cols[i]];
+    }
+  }
+  for (int s = 0; s < S.numSlices; s++) {
+    int maxLen = 0;
+    for (int l = 0; l < 64; l++)
+      maxLen = std::max(maxLen, S.sellLen[(size_t)s * 64 + l]);
+    maxLen = (maxLen + 7) / 8 * 8;
+    S.sellStart[s + 1] = S.sellStart[s] + maxLen * 64;
+  }
+  S.sellRow.assign(S.sellStart[S.numSlices], 0);
+  S.sellElem.assign(S.sellStart[S.numSlices], 0.0);
+  for (int s = 0; s < S.numSlices; s++)
+    for (int l = 0; l < 64; l++) {
+      const int j = S.sellCol[(size_t)s * 64 + l];
+      if (j < 0)
+        continue;
+      for (int p = A.colStart[j], t = 0; p < A.colStart[j + 1]; p++, t++) {
+        S.sellRow[(size_t)S.sellStart[s] + (size_t)t * 64 + l] = A.row[p];
+        S.sellElem[(size_t)S.sellStart[s] + (size_t)t * 64 + l] = A.elem[p];
+      }
+    }
+  return S;
+}
+
+static double *dThrash;
+static size_t nThrash = (size_t)96 << 20;  // 768 MB of doubles
+
+template <class F> static double timeKernel(F launch, int reps)
+{
+  hipEvent_t a, b;
+  CHECK(hipEventCreate(&a));
+  CHECK(hipEventCreate(&b));
+  double total = 0.0;
+  for (int i = -3; i < reps; i++) {
+    hipLaunchKernelGGL(k_thrash, dim3(2048), dim3(256), 0, 0, dThrash, nThrash, dThrash);
+    CHECK(hipEventRecord(a, 0));
+    launch();
+    CHECK(hipEventRecord(b, 0));
+    CHECK(hipEventSynchronize(b));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, a, b));
+    if (i >= 0)
+      total += ms;
+  }
+  CHECK(hipGetLastError());
+  return 1e3 * total / reps;  // us
+}
+
+int main(int argc, char **argv)
+{
+  const int m = argc > 1 ? atoi(argv[1]) : 50000, n = argc > 2 ? atoi(argv[2]) : 200000, per = argc > 3 ? atoi(argv[3]) : 50;
+  Csc A = makeMatrix(m, n, per);
+  const size_t nnz = A.row.size();
+  printf("matrix %d x %d, %zu entries\n", m, n, nnz);
+  std::mt19937_64 rng(7);
+  std::normal_distribution<double> nd(0.0, 1.0);
+  std::vector<double> pi(m + 32768, 0.0), dj(n);  // zero-padded past the last tile
+  std::vector<unsigned char> status(n);
+  for (int i = 0; i < m; i++)
+    pi[i] = nd(rng);
+  std::uniform_real_distribution<double> ud(0.0, 2.0);
+  for (int j = 0; j < n; j++) {
+    const double u = ud(rng);
+    status[j] = u < 0.1 ? 1 : (u < 0.7 ? 3 : 2);  // 5 % basic, rest at lower / upper
+    dj[j] = (status[j] == 2 ? -1.0 : 1.0) * ud(rng);
+  }
+  // CPU reference: sequential sums, no contraction
+  std::vector<double> ref(n, 0.0);
+  size_t nnzWanted = 0;
+  for (int j = 0; j < n; j++) {
+    double v = 0.0;
+    for (int p = A.colStart[j]; p < A.colStart[j + 1]; p++)
+      v += pi[A.row[p]] * A.elem[p];
+    if (status[j] == 1 || fabs(v) <= 1.0e-13)
+      v = 0.0;
+    ref[j] = v;
+    if (status[j] != 1)
+      nnzWanted += A.colStart[j + 1] - A.colStart[j];
+  }
+  const double algBytes = 12.0 * nnzWanted + 4.0 * n + 1.0 * n + 8.0 * m + 20.0 * n * 0.95;  // SURVEY 8d's B_col
+  CHECK(hipMalloc(&dThrash, nThrash * sizeof(double)));
+  CHECK(hipMemset(dThrash, 0, nThrash * sizeof(double)));
+  double *dPi = upload(pi), *dDj = upload(dj);
+  unsigned char *dStatus = upload(status);
+  double *dAlpha, *dWinMin;
+  unsigned char *dFlag;
+  int *dCount;
+  const int nWin = cdiv(n, 256);
+  CHECK(hipMalloc(&dAlpha, (size_t)nWin * 256 * 8));
+  CHECK(hipMalloc(&dFlag, (size_t)nWin * 256));
+  CHECK(hipMalloc(&dCount, nWin * 4));
+  CHECK(hipMalloc(&dWinMin, nWin * 8));
+  std::vector<double> out(n);
+  auto verify = [&](const char *name) {
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMemcpy(out.data(), dAlpha, (size_t)n * 8, hipMemcpyDeviceToHost));
+    size_t bad = 0;
+    for (int j = 0; j < n; j++)
+      if (memcmp(&out[j], &ref[j], 8) != 0 && !(out[j] == 0.0 && ref[j] == 0.0))
+        bad++;
+    printf("  %-28s %zu of %d columns differ from the sequential sum%s\n", name, bad, n, bad ? "   <-- WRONG" : " (bit-identical)");
+    CHECK(hipMemset(dAlpha, 0xFF, (size_t)n * 8));
+    return bad;
+  };
+  // ---- V0
+  {
+    SellHost S = buildSell(A);
+    SellDev D{m, n, S.numSlices, upload(S.sellStart), upload(S.sellCol), upload(S.sellLen), upload(S.sellRow), upload(S.sellElem),
+              dPi, dStatus, dDj, dAlpha, dFlag, dCount, dWinMin};
+    CHECK(hipMemset(dAlpha, 0xFF, (size_t)n * 8));
+    hipLaunchKernelGGL(k_v0, dim3(nWin), dim3(256), 0, 0, D);
+    verify("V0 windowed SELL, pi from L2");
+    const double us = timeKernel([&] { hipLaunchKernelGGL(k_v0, dim3(nWin), dim3(256), 0, 0, D); }, 20);
+    printf("V0  %7.2f us   %.2f TB/s on B_col = %.1f MB (12 B / entry)   padding %.1f %%\n", us, algBytes / us * 1e-6, algBytes * 1e-6,
+           100.0 * ((double)S.sellRow.size() / nnz - 1.0));
+    hipFree((void *)D.sellRow);
+    hipFree((void *)D.sellElem);
+  }
+  // ---- V1 family
+  auto runV1 = [&](int threads, int U, int nbuf, int refill, int tileRows, int dbg = 0, int gridOverride = 0) {
+    JdsHost J = buildJds(A, tileRows);
+    PlDev P{m, n, J.numWindows, J.numTiles, J.tileRows, upload(J.segStart), upload(J.cnt), upload(J.src), upload(J.home), upload(J.col),
+            upload(J.rowPair), upload(J.elemPair), dPi, dStatus, dDj, dAlpha, dFlag, dCount, dWinMin};
+    const int nq = threads / 256, nw = threads / 64;
+    const size_t lds = (size_t)nbuf * (tileRows * 8 + 16) + (size_t)nq * 256 * 9 + nw * 4 + nw * 8 + 64;
+    const int grid = gridOverride ? gridOverride : std::min(J.numWindows, threads == 1024 ? 256 : 512);  // workgroup b takes windows b, b + grid, ...
+    const int pch = cdiv(tileRows * 8 / 1024, nw);
+    char name[96];
+    snprintf(name, sizeof name, "V1 T=%d HP=%d buf=%d refill=%d tiles=%dx%d dbg=%d", threads, U, nbuf, refill, J.numTiles, tileRows, dbg);
+    auto launch = [&]() {
+#define L(TH, UU, NB, RF, PC, DB)                                                                                                  \
+  if (threads == TH && U == UU && nbuf == NB && refill == RF && pch <= PC && dbg == DB) {                                         \
+    CHECK(hipFuncSetAttribute((const void *)k_v1<TH, UU, NB, RF, PC, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((k_v1<TH, UU, NB, RF, PC, DB>), dim3(grid), dim3(TH), lds, 0, P);                                           \
+    return;                                                                                                                        \
+  }
+      L(1024, 4, 1, 2, 9, 0)
+      L(1024, 2, 1, 2, 9, 0)
+      L(1024, 4, 1, 2, 9, 1)
+      L(1024, 4, 1, 2, 9, 2)
+      L(1024, 4, 1, 2, 9, 4)
+      L(1024, 4, 1, 2, 9, 12)
+      L(1024, 4, 1, 2, 9, 13)
+      L(1024, 4, 1, 2, 9, 14)
+      L(1024, 8, 1, 2, 9, 0)
+      L(1024, 8, 1, 2, 9, 13)
+      L(1024, 8, 1, 2, 9, 14)
+      L(1024, 6, 1, 2, 9, 0)
+      L(1024, 4, 2, 2, 5, 0)
+      L(1024, 4, 2, 2, 5, 12)
+      L(1024, 4, 2, 2, 5, 13)
+      L(1024, 4, 2, 2, 5, 14)
+      if (dbg == 98) {
+        hipLaunchKernelGGL(k_empty, dim3(grid), dim3(1024), lds, 0, P);
+        return;
+      }
+      if (dbg == 99) {
+        CHECK(hipFuncSetAttribute((const void *)k_stream<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_stream<1024>), dim3(grid), dim3(1024), lds, 0, P, (int)J.rowPair.size() - 64);
+        return;
+      }
+#undef L
+      fprintf(stderr, "no instance for %s (chunks %d)\n", name, pch);
+      exit(1);
+    };
+    CHECK(hipMemset(dAlpha, 0xFF, (size_t)n * 8));
+    launch();
+    CHECK(hipGetLastError());
+    const size_t bad = verify(name);
+    const double us = timeKernel(launch, 20);
+    const double streamed = 20.0 * (J.rowPair.size() - 64) + 4.0 * n + 1.0 * n + 8.0 * m + 20.0 * n * 0.95 + 0.0 * nq;  // what this form moves: 20-byte pair records
+    printf("%-28s %7.2f us   %.2f TB/s on B_col (12 B / entry) = frac %.3f   %.2f TB/s on the record stream (%.1f %% pair padding)   wave steps / mean %.2f   grid %d  lds %zu%s\n",
+           name, us, algBytes / us * 1e-6, algBytes / us * 1e-6 / 8.0, streamed / us * 1e-6, 100.0 * (2.0 * (J.rowPair.size() - 64) / nnz - 1.0), (double)J.steps * 64 / nnz, grid, lds, bad ? "  WRONG" : "");
+    for (const void *p : {(const void *)P.segStart, (const void *)P.cnt, (const void *)P.src, (const void *)P.home, (const void *)P.col, (const void *)P.rowPair,
+                          (const void *)P.elemPair})
+      hipFree((void *)p);
+  };
+  const int rows3 = (cdiv(m, 3) + 127) & ~127;  // three tiles, one buffer
+  const int rows6 = (cdiv(m, 6) + 127) & ~127;  // six tiles, two buffers
+  runV1(1024, 4, 1, 2, rows3, 98);   // an empty kernel with the same launch configuration: what the event pair itself costs
+  runV1(1024, 4, 1, 2, rows3, 99);   // the same bytes as plain streams
+  runV1(1024, 4, 1, 2, rows3);       // everything
+  runV1(1024, 2, 1, 2, rows3);
+  runV1(1024, 4, 1, 2, rows3, 0, 196);  // 196 workgroups of exactly four windows (60 CUs idle) instead of 256 of three or four
+  runV1(1024, 2, 1, 2, rows3, 0, 196);
+  return 0;
+}
