@@ -451,7 +451,7 @@ def main():
             eta = 0.5 * (i0["eta_count"] + i1["eta_count"]) if i1["eta_count"] >= i0["eta_count"] else 0.5 * i1["eta_count"]
             # (the launch counters switch source with the timing option; the byte counters are the device's own throughout)
             by_row = int(round((i1["row_bytes"] - i0["row_bytes"]) > 0))
-            n_price = kern.get("k_price_sell", (0.0, n_piv))[1]
+            n_price = kern.get("k_price_lds", kern.get("k_price_sell", (0.0, n_piv)))[1]
             price_b = (i1["price_bytes"] - i0["price_bytes"]) / max(n_price, 1) if i1["price_bytes"] > i0["price_bytes"] else None
             model = {  # algorithmic bytes per launch of the kernels that stream a matrix in this regime
                 "k_gemv3g": (8.0 * kd * kd, "hbm", "three FTRAN right-hand sides through the dense " + ("tail inverse" if lu else "nucleus inverse") + ": 8 k^2 B"),
@@ -459,8 +459,8 @@ def main():
                 "k_lu_gemv3": (8.0 * kd * kd, "hbm", "three FTRAN right-hand sides through the dense tail inverse in one sweep: 8 k^2 B"),
                 "k_ftran_scatter3_lu": (8.0 * lp.m * eta + 3 * 8.0 * lp.m, "hbm", "eta file: x = x0 - H s over the m positions, 8 m t B (t = etas since the factorization)"),
                 "k_primal_rank1": (16.0 * kd * kd, "hbm", "rank-1 update of the explicit nucleus inverse: 16 k^2 B"),
-                "k_price_sell": (None if "k_price_tiled" in kern else price_b, "hbm", "row pricing by column: bytes the kernel streams (4 B per row index, 8 B per element fetched, lists)"),
-                "k_price_tiled": (price_b, "hbm", "row pricing by column with pi tiles in LDS: 2-byte row index + 8-byte element per entry of the nonbasic columns (padding of the tile segments not counted); k_price_sell then only runs the fused first ratio pass on the result"),
+                "k_price_sell": (None if "k_price_lds" in kern else price_b, "hbm", "row pricing by column: bytes the kernel streams (4 B per row index, 8 B per element fetched, lists)"),
+                "k_price_lds": (price_b, "hbm", "row pricing by column with pi tiles in LDS (jagged tile-by-tile streams of the SELL windows, fused first ratio pass): SURVEY 8d's B_col = 12 B per entry of the scanned columns + lists"),
             }
             rl = []
             for name, (us, cnt) in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
@@ -571,7 +571,8 @@ def main():
             "roofline": {"bound": "hbm",
                          # by column the HIP events bracket the pricing kernel alone (k_price_row_finish returns at once and is left out): the
                          # duration rocprofv3 reports for k_price_sell; by row both passes
-                         "kernel": ("k_price_sell" if (d_col is d_mix and "k_price_sell" in price_names) else " + ".join(sorted(price_names)))
+                         "kernel": ("k_price_lds" if "k_price_lds" in price_names else
+                                    ("k_price_sell" if (d_col is d_mix and "k_price_sell" in price_names) else " + ".join(sorted(price_names))))
                                    + " (row pricing + fused first ratio pass)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "bytes_per_launch": per_launch_bytes, "us_per_launch": per_launch_s * 1e6,
@@ -583,8 +584,10 @@ def main():
                                     "The timed window itself prices by row while pi is sparse -- `row_pricing` is what ran there, "
                                     "`roofline_mature` what runs once the basis has matured (pi dense, pricing by column)"),
                          "form_in_timed_window": ("by row" if (row_pricing and row_pricing["launches"] * 2 > args.steps) else "by column"),
-                         "bytes_counted": "streamed: 4 B per row index + 8 B per element fetched (conditional form fetches only under set bits of pi) "
-                                          "+ lists; SURVEY 8d's B_col = 12 nnz(A_J) + ... is the unconditional form",
+                         "bytes_counted": ("SURVEY 8d's B_col = 12 nnz(A_J) + 4 |J| + n + 8 m + 20 nnz_out, counted by the kernel (k_price_lds itself streams "
+                                           "20-byte records of two entries: 10 B per entry + 3 % pair padding)") if "k_price_lds" in price_names else
+                                          ("streamed: 4 B per row index + 8 B per element fetched (conditional form fetches only under set bits of pi) "
+                                           "+ lists; SURVEY 8d's B_col = 12 nnz(A_J) + ... is the unconditional form"),
                          "replay_identical": bool(same_pivots and same_pivots_col),
                          "row_pricing": row_pricing,
                          "traffic": traffic, "traffic_source": traffic_source,

@@ -68,6 +68,7 @@ struct Ctrl {
   double scratchSum;
   double statPriceBytes, statPriceLaunches;  // by-column bytes; launches of either form
   double statRowBytes, statRowLaunches;      // the by-row form's share
+  double statDensePi;                        // pricing launches whose pi was dense (12 nnz >= m): what the host picks the chain's pricing kernel by
   // CHUZR hand-over between its three kernels
   double chuzrTolerance;
   int chuzrNumber, chuzrStart, chuzrLast, chuzrPad;
@@ -219,14 +220,19 @@ struct Dev {
   const double *sellElem;
   int numSlices;
   int sellWindowed, sellWinBase;  // windowed SELL copy: workgroup b of the pricing kernel holds the columns of compaction block sellWinBase + b (buildSell)
-  // the same slices stored tile by tile for the dense-pi form (k_price_tiled): numTiles row tiles of tileRows;
-  // segment (tile, slice) at tsStart[tile * numSlices + slice], entry t of lane l at + 64 t + l
-  int numTiles, tileRows;
-  const int *tsStart;            // [numTiles * numSlices]
-  const unsigned char *tsLen;    // [numTiles * numSlices * 64] entries of the lane's column in the tile
-  const unsigned short *tsRow;   // row index local to the tile
-  const double *tsElem;
-  double *priceAcc;              // [numSlices * 64] dot products left by k_price_tiled
+  // the same windows stored for the dense-pi form (k_price_lds, round 5): the rows cut into jdsTiles tiles of jdsTileRows (a pi
+  // tile lives in LDS), every slice's entries as ONE jagged stream, tile after tile: inside a (slice, tile) segment the 64
+  // columns are ordered by their entry count in that tile, so the lanes that still hold an entry at step t are a prefix and
+  // the segment is stored without padding -- per PAIR of steps one record per such lane: two 16-bit tile-local row indices
+  // (jdsRowPair) and two elements (jdsElemPair; the second 0.0 when the column's count in the tile is odd)
+  int jdsWindows, jdsTiles, jdsTileRows;
+  const int *jdsSegStart;         // [jdsWindows * 4] first record of the slice's stream
+  const unsigned char *jdsCnt;    // [(slice * jdsTiles + tile) * 64 + p] entries in the tile of the column at position p of THAT tile's order
+  const unsigned char *jdsSrc;    // [(slice * jdsTiles + tile) * 64 + p] position of the same column in the previous tile's order
+  const unsigned char *jdsHome;   // [slice * 64 + l] position, in the last tile's order, of the column at home position l
+  const int *jdsCol;              // [slice * 64 + l] column key at home position l (sorted by length inside the window), -1 none
+  const unsigned *jdsRowPair;
+  const double2 *jdsElemPair;
   int *touchCol;  // [n] by-row pricing: contributors per column while a tableau row is assembled (zero otherwise)
   int *touchRow;  // [n * 8] their rows ...
   double *touchVal;  // [n * 8] ... and products, in ticket order

@@ -193,6 +193,7 @@ struct clpgpu_context {
   int refreshMinK = 6144, refreshMax = 15, consecutiveRefreshes = 0, numberRefreshes = 0, numberRefreshesRejected = 0;
   double refreshTolerance = 1.0e-6;
   int lastExitState = EXIT_REFACTOR;  // why the iteration loop last stopped (whileIterating)
+  long exitScheduled = 0, exitAlphaCheck = 0, exitBackwards = 0, exitBadUpdate = 0, priceFormSwitches = 0;  // what sent the loop to a status check
   bool stepPendingRefactor = false;   // a stepped run stopped on a pivot whose housekeeping asked for a refactorization
   bool refreshEligible();
   int refreshFactor();
@@ -270,14 +271,21 @@ struct clpgpu_context {
   // option "row_price_frac": row pricing goes BY ROW when nnz(pi) <= frac * m (the reference's switch,
   // src/ClpPackedMatrix.cpp:727-754, with the crossover measured on the MI355X); 0 = always by column
   double rowPriceFrac = 0.02;
-  // option "price_tiles" (default 0; before the load): keep a second, row-tiled SELL copy and price dense tableau rows
-  // with pi in LDS (k_price_tiled).  Bit-identical to the plain form (tests) but measured SLOWER on the MI355X: the
-  // matrix sweep of k_price_sell already runs at ~0.58 of the HBM peak (26 us for 120 MB; the other 41 us of that kernel
-  // are the fused first ratio pass and the candidate bookkeeping over 10^5 candidates), while the tiled sweep -- one
-  // slice per wave, three barrier-separated phases, one workgroup per CU -- takes 50 us (profiles/r03_tiled_pricing.txt)
-  int priceTiles = 0;
+  // option "price_lds" (default 1; before the load): keep a jagged, row-tiled copy of the SELL windows and price DENSE tableau
+  // rows with pi in LDS (k_price_lds, kernels.hip).  Bit-identical to k_price_sell (tests).  The chain carries one pricing
+  // form per captured graph: priceMode 1 = k_price_lds alone, 0 = k_price_sell + the by-row form; the host switches between
+  // them from the share of dense-pi pivots in the last batch (Ctrl::statDensePi) -- either form prices any pi correctly, so
+  // the choice changes the speed of a pivot, never its result.
+  int priceLds = 1;
+  int priceLdsMinWindows = 256;  // option "price_lds_min_windows": narrower LPs keep k_price_sell (a one-workgroup-per-CU launch needs work for every CU)
+  int priceLdsGridCap = 256;     // option "price_lds_grid" (test knob): fewer workgroups than CUs, so that a workgroup takes several rounds of windows
+  int priceMode = 0, graphPriceMode = 0;
+  double modePriced = 0.0, modeDense = 0.0;
+  bool jdsReady = false;
+  size_t priceLdsBytes = 0;
+  int priceLdsGrid = 0;
+  std::vector<void *> sellBuffers;  // device buffers of the current SELL / jagged copies (freed when buildSell runs again)
   int sellWindows = 1;  // option "sell_windows": the SELL copy sorted by length inside compaction-block windows (buildSell)
-  size_t priceTileLds = 0;
   // option "flip_scatter": the waves that detect a bound flip scatter its column into per-row slots
   // (1: sparse LPs with light rows only; 2: any sparse LP -- tests); 0 = the single-workgroup assembly
   // from the flip records
@@ -402,6 +410,7 @@ struct clpgpu_context {
   int checkLaunches(const char *where);
   int allocNucleus(int kNeeded);
   int buildSell();
+  int buildJds(const std::vector<int> &order, int numSlices);
   void dropGraph();
   int pushCtrl();
   int pullCtrl();
@@ -811,7 +820,7 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   rc |= dalloc(D.slotOfCol, n);
   rc |= dalloc(D.vecC, m);
   rc |= dalloc(D.rho, m);
-  rc |= dalloc(D.piNeg, m);
+  rc |= dalloc(D.piNeg, (size_t)m + 2 * PL_MAX_TILE_ROWS);  // zero-padded: k_price_lds reads whole row tiles
   rc |= dalloc(D.piBits, (size_t)(m + 63) / 64 + 8);
   rc |= dalloc(D.tIndex, (size_t)n + 1);
   rc |= dalloc(D.tValue, (size_t)n + 1);
@@ -845,7 +854,9 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   rc |= dalloc(D.flipRecObj, FLIP_LIST_CAP);
   rc |= dalloc(D.flipRecStart, FLIP_LIST_CAP);
   rc |= dalloc(D.flipRecLen, FLIP_LIST_CAP);
-  int nb = cdiv(m, PRICE_BLOCK) + cdiv(n, PRICE_BLOCK) + 2;
+  // per-workgroup slots of the N-wide kernels (one per 256 keys) -- and of k_ftran_scatter3_lu, whose workgroups hold as few as
+  // 64 basis positions each (luLaunchFtran): with n < ~3 m that launch has more workgroups than there are 256-key blocks
+  int nb = std::max(cdiv(m, PRICE_BLOCK) + cdiv(n, PRICE_BLOCK), cdiv(m, 64)) + 2;
   rc |= dalloc(D.blockCount, nb);
   rc |= dalloc(D.blockOffset, nb);
   rc |= dalloc(D.classBlock, 3 * (size_t)nb);
@@ -1009,43 +1020,25 @@ int clpgpu_context::checkLaunches(const char *where)
 // the entries inside a column is untouched, so the summation order per column is the CSC order.
 int clpgpu_context::buildSell()
 {
+  // (called again by set_option("sell_windows") after the load and by the shard fallback: the previous copies go first)
+  for (void *q : sellBuffers) {
+    auto it = std::find(allocations.begin(), allocations.end(), q);
+    if (it != allocations.end()) {
+      allocations.erase(it);
+      (void)hipFree(q);
+    }
+  }
+  sellBuffers.clear();
   const int first = D.priceFirst, last = D.priceLast;
   int count = last - first;
   std::vector<int> order(count);
   for (int i = 0; i < count; i++)
     order[i] = first + i;
-  // Row tiles of the dense-pi pricing form (k_price_tiled): pi tile <= 133 KB of LDS, 2-byte local row indices.
-  // Needs the rows of every column in ascending order (tile after tile is then the column's own entry order).
-  int numTiles = 0, tileRows = 0;
-  if (priceTiles && count >= 64 * 64 && m >= 4096) {
-    numTiles = (int)(((size_t)m * 8 + 135999) / 136000);
-    tileRows = ((m + numTiles - 1) / numTiles + 7) & ~7;
-    bool sorted = tileRows <= 65535 && numTiles <= 8;
-    for (int j = first; j < last && sorted; j++)
-      for (int p = colStart[j] + 1; p < colStart[j + 1]; p++)
-        if (row[p] <= row[p - 1]) {
-          sorted = false;
-          break;
-        }
-    if (!sorted)
-      numTiles = 0;
-  }
-  std::vector<unsigned char> tileCount;  // [count][numTiles] entries of a column per tile (columns of <= SELL_LONG entries)
-  if (numTiles) {
-    tileCount.assign((size_t)count * numTiles, 0);
-    for (int i = 0; i < count; i++) {
-      const int j = first + i;
-      if (colStart[j + 1] - colStart[j] <= SELL_LONG)
-        for (int p = colStart[j]; p < colStart[j + 1]; p++)
-          tileCount[(size_t)i * numTiles + row[p] / tileRows]++;
-    }
-  }
   // Windowed copy (default; option "sell_windows"): the columns are sorted by length only INSIDE windows of PRICE_BLOCK
   // consecutive keys aligned with the compaction blocks of the N-wide kernels, four slices per window, so that one workgroup
   // of the pricing kernel owns one compaction block: coalesced tableau-row / flag stores and one candidate count per workgroup
-  // (priceSellBody).  Costs ~9 % padding on Poisson column counts (the global sort pads ~0 %).  The tiled form keeps the
-  // global order (its tile profiles need it).
-  const bool windowed = sellWindows && numTiles == 0 && first >= D.firstColumn && (first - D.firstColumn) % PRICE_BLOCK == 0;
+  // (priceSellBody).  Costs ~9 % padding on Poisson column counts (the global sort pads ~0 %).
+  const bool windowed = sellWindows && first >= D.firstColumn && (first - D.firstColumn) % PRICE_BLOCK == 0;
   const int winBase = windowed ? (first - D.firstColumn) / PRICE_BLOCK : 0;
   std::vector<int> windowLong;
   if (windowed) {
@@ -1067,21 +1060,9 @@ int clpgpu_context::buildSell()
     }
     order.swap(placed);
   }
-  // columns by decreasing length; with tiles, columns of equal length by their entries per tile, so that the 64
-  // columns of a slice have similar tile profiles and the per-tile segments pad by ~10 % instead of ~50 %
+  // columns by decreasing length
   if (!windowed)
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-    const int la = colStart[a + 1] - colStart[a], lb = colStart[b + 1] - colStart[b];
-    if (la != lb)
-      return la > lb;
-    if (numTiles) {
-      const unsigned char *ca = &tileCount[(size_t)(a - first) * numTiles], *cb = &tileCount[(size_t)(b - first) * numTiles];
-      for (int q = 0; q + 1 < numTiles; q++)
-        if (ca[q] != cb[q])
-          return ca[q] > cb[q];
-    }
-    return false;
-  });
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return colStart[a + 1] - colStart[a] > colStart[b + 1] - colStart[b]; });
   // columns longer than SELL_LONG entries would keep one lane busy for len/8 dependent trips while
   // the rest of the chip waits (power-law column counts): they leave the SELL copy and are priced by
   // a wave each (priceLongBody).  `order` is sorted by decreasing length, so they are its prefix.
@@ -1130,56 +1111,6 @@ int clpgpu_context::buildSell()
         sellElem[base + (size_t)t * 64] = elem[p];
       }
     }
-  if (numSlices > PT_MAXS * 256 * (PT_THREADS / 64))
-    numTiles = 0;  // more slices than the persistent grid's waves can carry in registers
-  std::vector<int> tsStart;
-  std::vector<unsigned char> tsLen;
-  std::vector<unsigned short> tsRow;
-  std::vector<double> tsElem;
-  if (numTiles) {
-    tsStart.assign((size_t)numTiles * numSlices, 0);
-    tsLen.assign((size_t)numTiles * numSlices * 64, 0);
-    size_t totalT = 0;
-    for (int q = 0; q < numTiles; q++)
-      for (int s = 0; s < numSlices; s++) {
-        int maxLen = 0;
-        for (int l = 0; l < 64; l++) {
-          const int i = s * 64 + l;
-          if (i < count) {
-            const unsigned char cnt = tileCount[(size_t)(order[i] - first) * numTiles + q];
-            tsLen[((size_t)q * numSlices + s) * 64 + l] = cnt;
-            maxLen = std::max(maxLen, (int)cnt);
-          }
-        }
-        maxLen = (maxLen + 1) & ~1;
-        if (totalT + (size_t)maxLen * 64 > 2000000000u) {
-          numTiles = 0;
-          break;
-        }
-        tsStart[(size_t)q * numSlices + s] = (int)totalT;
-        totalT += (size_t)maxLen * 64;
-      }
-    if (numTiles) {
-      tsRow.assign(totalT ? totalT : 1, 0);
-      tsElem.assign(totalT ? totalT : 1, 0.0);
-      for (int s = 0; s < numSlices; s++)
-        for (int l = 0; l < 64; l++) {
-          const int i = s * 64 + l;
-          if (i >= count)
-            continue;
-          const int j = order[i];
-          int p = colStart[j];
-          for (int q = 0; q < numTiles; q++) {
-            const size_t base = (size_t)tsStart[(size_t)q * numSlices + s] + l;
-            const int cnt = tsLen[((size_t)q * numSlices + s) * 64 + l];
-            for (int u = 0; u < cnt; u++, p++) {
-              tsRow[base + (size_t)u * 64] = (unsigned short)(row[p] - q * tileRows);
-              tsElem[base + (size_t)u * 64] = elem[p];
-            }
-          }
-        }
-    }
-  }
   int *dStart, *dCol, *dLen, *dRow, *dLong;
   double *dElem;
   int rc = 0;
@@ -1236,40 +1167,140 @@ int clpgpu_context::buildSell()
   D.sellWinBase = winBase;
   D.longCol = dLong;
   D.numLong = nLong;
-  D.numTiles = 0;
-  if (numTiles && !rc) {
-    int *dTs;
-    unsigned char *dTl;
-    unsigned short *dTr;
-    double *dTe, *dAcc;
-    rc |= dalloc(dTs, tsStart.size());
-    rc |= dalloc(dTl, tsLen.size());
-    rc |= dalloc(dTr, tsRow.size());
-    rc |= dalloc(dTe, tsElem.size());
-    rc |= dalloc(dAcc, (size_t)numSlices * 64);
-    if (!rc) {
-      rc |= h2d(dTs, tsStart.data(), tsStart.size());
-      rc |= h2d(dTl, tsLen.data(), tsLen.size());
-      rc |= h2d(dTr, tsRow.data(), tsRow.size());
-      rc |= h2d(dTe, tsElem.data(), tsElem.size());
-      rc |= sync();
-      // the pi tile needs more dynamic LDS than the default limit allows
-      priceTileLds = (size_t)tileRows * sizeof(double);
-      if (hipFuncSetAttribute((const void *)k_price_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, (int)priceTileLds) == hipSuccess) {
-        D.tsStart = dTs;
-        D.tsLen = dTl;
-        D.tsRow = dTr;
-        D.tsElem = dTe;
-        D.priceAcc = dAcc;
-        D.tileRows = tileRows;
-        D.numTiles = numTiles;
-      } else {
-        (void)hipGetLastError();
-      }
-    }
-  }
+  for (void *q : {(void *)dLong, (void *)dStart, (void *)dCol, (void *)dLen, (void *)dRow, (void *)dElem})
+    sellBuffers.push_back(q);
+  jdsReady = false;
+  D.jdsWindows = 0;
+  if (!rc && windowed && priceLds)
+    rc |= buildJds(order, numSlices);
   dropGraph();
   return rc;
+}
+
+// Jagged row-tiled copy of the windowed SELL slices for k_price_lds (layout: device_state.h; kernel: kernels.hip).
+// `order` is buildSell's placement: position w * 256 + i holds the i-th longest column of window w (or -1).
+int clpgpu_context::buildJds(const std::vector<int> &order, int numSlices)
+{
+  const int nWin = (int)(order.size() / PRICE_BLOCK);
+  // worth a one-workgroup-per-CU launch only on wide LPs; needs every column's rows in ascending order (tile after tile
+  // is then the column's own entry order) and 16-bit tile-local row indices
+  if (nWin < priceLdsMinWindows || nWin * 4 != numSlices || m < 4096 || widePricing)
+    return 0;
+  const int T = cdiv(m, PL_MAX_TILE_ROWS);
+  const int tileRows = (cdiv(m, T) + 127) & ~127;
+  if (tileRows > PL_MAX_TILE_ROWS || (size_t)T * tileRows > (size_t)m + 2 * PL_MAX_TILE_ROWS)
+    return 0;
+  for (int j : order)
+    if (j >= 0)
+      for (int p = colStart[j] + 1; p < colStart[j + 1]; p++)
+        if (row[p] <= row[p - 1])
+          return 0;
+  std::vector<int> segStart(numSlices, 0), col((size_t)numSlices * 64, -1);
+  std::vector<unsigned char> cnt((size_t)numSlices * T * 64, 0), src((size_t)numSlices * T * 64, 0), home((size_t)numSlices * 64, 0);
+  std::vector<unsigned> rowPair;
+  std::vector<double2> elemPair;
+  rowPair.reserve((size_t)nnz / 2 + (size_t)nnz / 16 + 64);
+  elemPair.reserve((size_t)nnz / 2 + (size_t)nnz / 16 + 64);
+  std::vector<int> ord(64), prevPos(64), pos(64), ptr(64), cntHome((size_t)T * 64);
+  for (int slice = 0; slice < numSlices; slice++) {
+    int h[64];
+    for (int l = 0; l < 64; l++) {
+      h[l] = order[(size_t)slice * 64 + l];
+      col[(size_t)slice * 64 + l] = h[l];
+    }
+    std::fill(cntHome.begin(), cntHome.end(), 0);
+    for (int l = 0; l < 64; l++)
+      if (h[l] >= 0)
+        for (int p = colStart[h[l]]; p < colStart[h[l] + 1]; p++)
+          cntHome[(size_t)(row[p] / tileRows) * 64 + l]++;
+    for (int l = 0; l < 64; l++) {
+      prevPos[l] = l;
+      ptr[l] = h[l] >= 0 ? colStart[h[l]] : 0;
+    }
+    if (rowPair.size() > 2000000000u)
+      return 0;
+    segStart[slice] = (int)rowPair.size();
+    for (int tau = 0; tau < T; tau++) {
+      for (int l = 0; l < 64; l++)
+        ord[l] = l;
+      std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return cntHome[(size_t)tau * 64 + a] > cntHome[(size_t)tau * 64 + b]; });
+      int maxc = 0;
+      for (int q = 0; q < 64; q++) {
+        const int c = cntHome[(size_t)tau * 64 + ord[q]];
+        if (c > 255)
+          return 0;  // (columns longer than SELL_LONG never get here)
+        cnt[((size_t)slice * T + tau) * 64 + q] = (unsigned char)c;
+        src[((size_t)slice * T + tau) * 64 + q] = (unsigned char)prevPos[ord[q]];
+        pos[ord[q]] = q;
+        maxc = std::max(maxc, c);
+      }
+      for (int t = 0; t < maxc; t += 2)
+        for (int q = 0; q < 64; q++) {
+          const int l = ord[q], c = cntHome[(size_t)tau * 64 + l];
+          if (c > t) {
+            const int e = ptr[l] + t;
+            unsigned rr = (unsigned)(row[e] - tau * tileRows);
+            double2 ee = make_double2(elem[e], 0.0);
+            if (c > t + 1) {
+              rr |= (unsigned)(row[e + 1] - tau * tileRows) << 16;
+              ee.y = elem[e + 1];
+            }
+            rowPair.push_back(rr);
+            elemPair.push_back(ee);
+          }
+        }
+      for (int l = 0; l < 64; l++) {
+        ptr[l] += cntHome[(size_t)tau * 64 + l];
+        prevPos[l] = pos[l];
+      }
+    }
+    for (int l = 0; l < 64; l++)
+      home[(size_t)slice * 64 + l] = (unsigned char)prevPos[l];
+  }
+  rowPair.resize(rowPair.size() + 64, 0u);  // a pair with no active lane reads the record behind the stream
+  elemPair.resize(elemPair.size() + 64, make_double2(0.0, 0.0));
+  int *dSeg, *dColJ;
+  unsigned char *dCnt, *dSrc, *dHome;
+  unsigned *dRp;
+  double2 *dEp;
+  int rc = 0;
+  rc |= dalloc(dSeg, segStart.size());
+  rc |= dalloc(dColJ, col.size());
+  rc |= dalloc(dCnt, cnt.size());
+  rc |= dalloc(dSrc, src.size());
+  rc |= dalloc(dHome, home.size());
+  rc |= dalloc(dRp, rowPair.size());
+  rc |= dalloc(dEp, elemPair.size());
+  if (rc)
+    return rc;
+  for (void *q : {(void *)dSeg, (void *)dColJ, (void *)dCnt, (void *)dSrc, (void *)dHome, (void *)dRp, (void *)dEp})
+    sellBuffers.push_back(q);
+  rc |= h2d(dSeg, segStart.data(), segStart.size());
+  rc |= h2d(dColJ, col.data(), col.size());
+  rc |= h2d(dCnt, cnt.data(), cnt.size());
+  rc |= h2d(dSrc, src.data(), src.size());
+  rc |= h2d(dHome, home.data(), home.size());
+  rc |= h2d(dRp, rowPair.data(), rowPair.size());
+  rc |= h2d(dEp, elemPair.data(), elemPair.size());
+  rc |= sync();
+  priceLdsBytes = ((size_t)tileRows * 8 + 16 + (PL_THREADS / 256) * 256 * 9 + (PL_THREADS / 64) * 20 + 15) & ~(size_t)15;
+  if (rc || hipFuncSetAttribute((const void *)k_price_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)priceLdsBytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return rc;
+  }
+  D.jdsSegStart = dSeg;
+  D.jdsCol = dColJ;
+  D.jdsCnt = dCnt;
+  D.jdsSrc = dSrc;
+  D.jdsHome = dHome;
+  D.jdsRowPair = dRp;
+  D.jdsElemPair = dEp;
+  D.jdsTiles = T;
+  D.jdsTileRows = tileRows;
+  D.jdsWindows = nWin;
+  priceLdsGrid = std::max(1, std::min(priceLdsGridCap, cdiv(nWin, PL_THREADS / 256)));
+  jdsReady = true;
+  return 0;
 }
 
 void clpgpu_context::dropGraph()
@@ -3338,7 +3369,9 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   const bool countInPrice = priceKernel >= 1 && !gatherRows && nb > 256;
   // by-row pricing for sparse pi (needs the bitmap and the count-in-price compaction scheme)
   const int nSlots = nSellBlocks + nLongBlocks;
-  const int rowMax = (rowPriceFrac > 0.0 && countInPrice && !widePricing && priceKernel >= 2 && m <= 64 * SELL_BITS_MAX && nSlots > 0)
+  // (the dense chain needs the count-in-price compaction scheme, as the by-row form does)
+  const bool denseChain = priceMode == 1 && jdsReady && countInPrice && !widePricing && priceKernel >= 2;
+  const int rowMax = (!denseChain && rowPriceFrac > 0.0 && countInPrice && !widePricing && priceKernel >= 2 && m <= 64 * SELL_BITS_MAX && nSlots > 0)
                          ? std::max(1, (int)(rowPriceFrac * m))
                          : 0;
   KL("k_rho_finish3", k_rho_finish3, dim3(gm), dim3(256), 0, stream, D, wideRows ? 1 : 0, countInPrice ? nbCols : -1, rowMax > 0 ? nSlots : 0);
@@ -3349,9 +3382,12 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   if (priceKernel >= 1) {
     if (widePricing && priceKernel != 1)
       KL("k_price_wide", k_price_wide, dim3(nWideBlocks), dim3(256), 0, stream, D, denseColumns ? 1 : 0, countInPrice ? 1 : 0);
-    else if (nSlots > 0) {
-      if (D.numTiles > 0 && priceKernel == 6)
-        KL("k_price_tiled", k_price_tiled, dim3(256), dim3(PT_THREADS), priceTileLds, stream, D);
+    else if (nSlots > 0 && denseChain) {
+      // pi dense on (nearly) every pivot of late: the tile-by-tile sweep with pi in LDS; it prices a sparse pi correctly too
+      KL("k_price_lds", k_price_lds, dim3(priceLdsGrid), dim3(PL_THREADS), priceLdsBytes, stream, D, countInPrice ? 1 : 0);
+      if (nLongBlocks > 0)  // columns too long for a SELL lane keep their own workgroups
+        KL("k_price_sell", k_price_sell, dim3(nSlots), dim3(256), 0, stream, D, 1, countInPrice ? 1 : 0, nSellBlocks, nSlots, 0, 0, 32);
+    } else if (nSlots > 0) {
       KL("k_price_sell", k_price_sell, dim3(nSlots + (rowMax > 0 ? gm : 0)), dim3(256),
          (m > 64 * SELL_BITS_MAX || priceKernel < 2) ? 0 : (size_t)((m + 63) / 64) * 8, stream, D,
          (m > 64 * SELL_BITS_MAX && priceKernel > 1) ? 1 : priceKernel, countInPrice ? 1 : 0, nSellBlocks, nSlots, rowMax);
@@ -3506,7 +3542,7 @@ int clpgpu_context::launchBatch(int count)
     joinUpdateBranch();
     return checkLaunches("launchIteration");
   }
-  if (!graphExec || graphIterations != checkEvery) {
+  if (!graphExec || graphIterations != checkEvery || graphPriceMode != priceMode) {
     // (the full-size graph is always built first, also when a tail batch is what runs now: a stepped run
     // that warms up with a few pivots must not pay for its instantiation later)
     dropGraph();
@@ -3520,6 +3556,7 @@ int clpgpu_context::launchBatch(int count)
       return checkLaunches("launchIteration");
     }
     graphIterations = checkEvery;
+    graphPriceMode = priceMode;
   }
   hipGraphExec_t exec = graphExec;
   if (count < checkEvery) {
@@ -3585,6 +3622,7 @@ int clpgpu_context::whileIterating(int stepTarget)
   while (!rc) {
     evUsed = 0;
     double launchesBefore = hCtrl->statPriceLaunches;
+    const double denseBefore = hCtrl->statDensePi;
     const int logBefore = hCtrl->logCount;
     // a stepped run (clpgpu_dual_steps) ends on the pivot asked for: the last batches are 8, 4, 2, 1 pivots
     // long instead of a full batch that idles through the pivots behind the limit
@@ -3605,6 +3643,25 @@ int clpgpu_context::whileIterating(int stepTarget)
     rc |= pullCtrl();
     if (!rc && hCtrl->state == RUN && stepTarget >= 0 && hCtrl->numberIterations >= stepTarget)
       hCtrl->state = EXIT_STEP_LIMIT;  // the batch ended exactly on the limit: the device never saw a pivot beyond it
+    if (!rc && jdsReady && priceLds) {
+      // which pricing form the next batch's chain carries.  A dense-pi pivot costs ~52 us in k_price_sell and ~32 in k_price_lds,
+      // a sparse-pi one ~12 us by row and ~32 in k_price_lds: the forms break even at half the pivots dense.  k_price_lds from
+      // 55 % dense on, back below 30 % (both forms give the same bits for any pi: the choice never changes a pivot)
+      // (counted over at least 16 pricing launches: a stepped or timed run may come in batches of one pivot)
+      modePriced += hCtrl->statPriceLaunches - launchesBefore;
+      modeDense += hCtrl->statDensePi - denseBefore;
+      if (priceLds >= 2)
+        priceMode = 1;
+      else if (modePriced >= 16.0) {
+        const int before = priceMode;
+        if (priceMode == 0 && modeDense >= 0.55 * modePriced)
+          priceMode = 1;
+        else if (priceMode == 1 && modeDense <= 0.30 * modePriced)
+          priceMode = 0;
+        modePriced = modeDense = 0.0;
+        priceFormSwitches += priceMode != before;
+      }
+    }
     if (timing) {
       // the device counts a pricing launch only while the loop is live; those are the first ones
       int timed = (int)(hCtrl->statPriceLaunches - launchesBefore);
@@ -3661,6 +3718,10 @@ int clpgpu_context::whileIterating(int stepTarget)
     hipLaunchKernelGGL(k_zero, dim3(cdiv(n, 256)), dim3(256), 0, stream, D.alphaCol, n);
   }
   lastReturnCode = -1;
+  exitScheduled += state == EXIT_REFACTOR;
+  exitAlphaCheck += state == EXIT_ALPHA_CHECK;
+  exitBackwards += state == EXIT_BACKWARDS;
+  exitBadUpdate += state == EXIT_BAD_UPDATE;
   switch (state) {
   case EXIT_STEP_LIMIT:
     // the pivot the run stopped on may have asked for a refactorization (houseBody): it is done when the run resumes,
@@ -3952,15 +4013,16 @@ int clpgpu_context::priceRow(int numberPi, const int *piIndex, const double *piV
     hipLaunchKernelGGL(k_cand_scatter, dim3(nb), dim3(PRICE_BLOCK), 0, stream, D, nbRows, nSlots);
   } else if (priceKernel >= 1) {
     if (nSlots > 0) {
-      if (D.numTiles > 0 && priceKernel == 6 && 12LL * numberPi >= (long long)m && m <= 64 * SELL_BITS_MAX) {
-        // dense pi: the tiled form (pi tiles in LDS), as the iteration chain takes it; the bitmap of pi's rows first
-        std::vector<unsigned long long> bitsHost((size_t)((m + 63) / 64) + 4, 0ull);
+      if (jdsReady && priceLds && 12LL * numberPi >= (long long)m) {
+        // dense pi: the form the iteration chain takes then (pi tiles in LDS); long columns keep their own workgroups
+        std::vector<unsigned long long> bitsHost((size_t)((m + 63) / 64) + 8, 0ull);
         for (int i = 0; i < numberPi; i++)
           if (piValue[i] != 0.0)
             bitsHost[piIndex[i] >> 6] |= 1ull << (piIndex[i] & 63);
         rc |= h2d(D.piBits, bitsHost.data(), bitsHost.size());
-        hipLaunchKernelGGL(k_price_tiled, dim3(256), dim3(PT_THREADS), priceTileLds, stream, D);
-        hipLaunchKernelGGL(k_price_sell, dim3(nSlots), dim3(256), (size_t)((m + 63) / 64) * 8, stream, D, 6, 0, nSellBlocks);
+        hipLaunchKernelGGL(k_price_lds, dim3(priceLdsGrid), dim3(PL_THREADS), priceLdsBytes, stream, D, 0);
+        if (nLongBlocks > 0)
+          hipLaunchKernelGGL(k_price_sell, dim3(nSlots), dim3(256), 0, stream, D, 1, 0, nSellBlocks, nSlots, 0, 0, 32);
       } else {
         hipLaunchKernelGGL(k_price_sell, dim3(nSlots), dim3(256), 0, stream, D, 1, 0, nSellBlocks);
       }
@@ -4758,7 +4820,9 @@ clpgpu_context *clpgpu_clone(const clpgpu_context *src)
   ctx->blockedRefactor = src->blockedRefactor;
   ctx->registerPanel = src->registerPanel;
   ctx->rowPriceFrac = src->rowPriceFrac;
-  ctx->priceTiles = src->priceTiles;
+  ctx->priceLds = src->priceLds;
+  ctx->priceLdsMinWindows = src->priceLdsMinWindows;
+  ctx->priceLdsGridCap = src->priceLdsGridCap;
   ctx->sellWindows = src->sellWindows;
   ctx->flipScatter = src->flipScatter;
   ctx->flipSlotCap = src->flipSlotCap;
@@ -5091,10 +5155,20 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
       return ctx->buildSell();
     }
   }
-  else if (!strcmp(name, "price_tiles")) {
+  else if (!strcmp(name, "price_lds_min_windows") || !strcmp(name, "price_lds_grid")) {
     if (ctx->n > 0 && ctx->D.colStart)
-      return -2;  // decides what buildSell lays out: set before clpgpu_load_problem
-    ctx->priceTiles = (int)v;
+      return -2;  // read by buildSell: set before clpgpu_load_problem
+    (name[10] == 'm' ? ctx->priceLdsMinWindows : ctx->priceLdsGridCap) = std::max(1, (int)v);
+  }
+  else if (!strcmp(name, "price_lds")) {
+    // 0: never; 1 (default): the host picks the chain's pricing form per batch; 2: the LDS form on every pivot (tests)
+    if (v != 0.0 && !ctx->priceLds && ctx->n > 0 && ctx->D.colStart)
+      return -2;  // decides what buildSell lays out: switch it ON before clpgpu_load_problem
+    if ((int)v != ctx->priceLds)
+      ctx->dropGraph();
+    ctx->priceLds = (int)v;
+    if (!ctx->priceLds)
+      ctx->priceMode = 0;
   }
   else if (!strcmp(name, "scaling")) {
     if (ctx->n > 0 && ctx->D.colStart)
@@ -5497,6 +5571,13 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
   stats->loop_flags = ctx->numberLoopFlags;
   stats->accuracy_restores = ctx->numberAccuracyRestores;
   stats->singular_restores = ctx->numberSingularRestores;
+  stats->price_form = (ctx->priceMode == 1 && ctx->jdsReady) ? 1 : 0;
+  stats->dense_pi_launches = (long)ctx->hCtrl->statDensePi;
+  stats->price_form_switches = ctx->priceFormSwitches;
+  stats->exits_scheduled = ctx->exitScheduled;
+  stats->exits_alpha_check = ctx->exitAlphaCheck;
+  stats->exits_backwards = ctx->exitBackwards;
+  stats->exits_bad_update = ctx->exitBadUpdate;
   stats->nucleus_capacity = ctx->kcap;
   stats->refreshes = ctx->numberRefreshes;
   stats->refreshes_rejected = ctx->numberRefreshesRejected;

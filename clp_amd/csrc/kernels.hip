@@ -2517,10 +2517,6 @@ __device__ inline void priceSellBody(Dev D, unsigned long long *bits, int countC
               hits++;
             }
         }
-      } else if (COND && D.numTiles > 0) {
-        // dense pi: k_price_tiled has left every column's dot product (pi tiles in LDS, same summation order)
-        value = (len > 0) ? D.priceAcc[idx] : 0.0;
-        hits = -2;
       } else {
         for (int t = 0; t < maxLen; t += SELL_U) {
           int r[SELL_U];
@@ -2547,8 +2543,7 @@ __device__ inline void priceSellBody(Dev D, unsigned long long *bits, int countC
       if (wanted) {
         // bytes this column really streams: every row index (4 B), the element (8 B) only where it is fetched --
         // all of them in the unconditional forms, those under a set bit of pi in the conditional one
-        bytes = hits == -2 ? 10.0 * len + 12.0  // tiled form: 2-byte row index + element per entry, accumulator, column index
-                           : 4.0 * len + 8.0 * (hits < 0 ? len : hits) + 4.0;
+        bytes = 4.0 * len + 8.0 * (hits < 0 ? len : hits) + 4.0;
         if (fabs(value) > zeroTolerance) {
           bytes += 20.0;
           if (wanted > 0) {
@@ -2936,100 +2931,256 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_price_row_init(Dev D, int nbCol
 // workgroups [0, nSellBlocks) sweep the SELL slices, the next numLong the long columns; the last
 // nRowBlocks (= cdiv(m, 256), only when rowMax > 0) are pass 1 of the by-row form.  rowMax > 0: nnz(pi)
 // <= rowMax sends the launch by row (the by-column workgroups return), otherwise by column.
-// Row pricing by column with pi in LDS (round 3; the dense-pi regime).  The gather of pi -- 8 bytes out of a 64-byte
-// line, one per matrix entry, 10^7 per launch -- saturates the L2 request path at a fifth of the HBM rate when pi is a
-// plain global array.  Here the rows are cut into D.numTiles tiles of D.tileRows (pi tile <= 133 KB of LDS), the SELL
-// copy is stored tile by tile (same 64-column slices, columns ordered by (length, entries per tile) so that a slice
-// pads by ~10 %; 2-byte row index local to the tile + 8-byte element), and a persistent grid of one 1024-thread
-// workgroup per CU walks the tiles in order: every wave owns one slice (up to PT_MAXS), loads nothing but its streams,
-// gathers pi from LDS, and keeps each column's partial sum in a register from tile to tile -- rows ascend within a
-// column, so the sum is the reference's sequential sum, bit for bit (ClpPackedMatrix.cpp:1799-1993).  The result goes
-// to D.priceAcc by SELL position; k_price_sell then does its fused first ratio pass on it without touching the matrix.
-// Sparse pi (12 nnz < m, the rule of priceSellBody) leaves the launch at once: those pivots price by row or by the
-// conditional-fetch form.
-#define PT_THREADS 1024
-#define PT_MAXS 4
-__global__ void __launch_bounds__(PT_THREADS) k_price_tiled(Dev D)
+// Row pricing by column with pi in LDS (round 5; the dense-pi regime the mature solve lives in).
+// The gather of pi -- 8 bytes out of a 64-byte sector, one per matrix entry, 10^7 per launch at config 4 -- is what held
+// k_price_sell at a quarter of the HBM rate while pi was a global array served by L2 (profiles/r04_price_probe_final.txt:
+// 30 of 62 us).  Here the rows are cut into D.jdsTiles tiles of D.jdsTileRows (a pi tile of <= 134 KB in LDS) and one
+// 1024-thread workgroup per CU walks the tiles: wave w owns slice (w & 3) of window blockIdx.x + gridDim.x * (w >> 2) --
+// the windows are the 256-key compaction blocks of the windowed SELL copy, so the write-out is the coalesced one of
+// priceSellBody -- and keeps each column's partial sum in a register from tile to tile.  Rows ascend inside a column, so
+// the sum is the reference's sequential sum (ClpPackedMatrix.cpp:1872-1886), bit for bit.
+// Streams: a slice's entries are stored tile after tile as a JAGGED sequence (device_state.h, buildJds): inside a tile the
+// lanes are re-ordered by their entry count in that tile, the lanes of a step are a prefix of the wave and nothing is
+// padded; the running sum changes lanes between tiles with one ds_bpermute.  Two steps share a record (one 4-byte and one
+// 16-byte load per lane).  The loads do not depend on pi: a ring of two half-batches keeps RING steps of the stream in
+// flight ACROSS the tile barriers (raw s_barrier + lgkmcnt only; the straight-line, all-lanes load code keeps the
+// compiler's vmcnt counts exact), the next tile's first steps are requested while this tile is still being summed.
+// pi tiles arrive by LDS-DMA (global_load_lds_dwordx4, 1 KB per wave-instruction, no VGPR round trip), issued by inline
+// asm so that the compiler does not drain the ring for them; the wait is placed by hand.
+// A step without an entry reads a permanent 0.0 behind the tile: adding +-0.0 to the running sum is exact (the sum
+// starts from +0.0 and cannot become -0.0), so the dependent chain per step is one add.
+// Measured stand-alone (tools/price_lds_bench.hip, profiles/r05_price_lds_microbench*.txt): 31.7 us per launch at config 4
+// against 66.9 us for the same windows with pi gathered from L2; plain streaming of the same bytes takes 19.8 us.
+#define PL_THREADS 1024
+#define PL_HP 2              // step pairs per half of the ring: RING = 4 PL_HP steps in flight per lane
+#define PL_MAX_TILE_ROWS 16768
+typedef __attribute__((address_space(3))) unsigned char pl_lds_byte;
+
+__device__ __forceinline__ void plBarrier()
+{
+  // this wave's LDS traffic is done; global loads stay in flight across the barrier
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// one 1 KB wave-chunk of pi straight into LDS: lane l's 16 bytes land at ldsDst + 16 l (ldsDst wave-uniform)
+__device__ __forceinline__ void plGlds16(const double *gsrc, unsigned ldsDst)
+{
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(ldsDst)
+               : "memory");
+}
+
+struct PlHalf {
+  unsigned r[PL_HP];
+  double2 e[PL_HP];
+};
+
+// PL_HP consecutive step pairs of a segment whose lanes hold `cnt` entries; `off` = wave-uniform record position of step
+// t0 (even), advanced past them.  Every lane loads: a lane without a record re-reads the first record of the pair.
+__device__ __forceinline__ void plLoadHalf(PlHalf &h, const unsigned *__restrict__ rowPair, const double2 *__restrict__ elemPair, int cnt, int t0,
+                                           unsigned &off, unsigned lane)
+{
+#pragma unroll
+  for (int u = 0; u < PL_HP; u++) {
+    const bool act = cnt > t0 + 2 * u;
+    const unsigned k = (unsigned)__popcll(__ballot(act));
+    const unsigned *rp = rowPair + off;  // wave-uniform
+    const double2 *ep = elemPair + off;
+    const unsigned at = act ? lane : 0u;
+    h.r[u] = rp[at];
+    h.e[u] = ep[at];
+    off += k;
+  }
+}
+
+__device__ __forceinline__ double plConsumeHalf(const PlHalf &h, const double *piTile, int cnt, int t0, double acc, unsigned zero)
+{
+  double pa[PL_HP], pb[PL_HP];
+#pragma unroll
+  for (int u = 0; u < PL_HP; u++) {
+    pa[u] = piTile[(cnt > t0 + 2 * u) ? (h.r[u] & 0xFFFFu) : zero];
+    pb[u] = piTile[(cnt > t0 + 2 * u + 1) ? (h.r[u] >> 16) : zero];
+  }
+#pragma unroll
+  for (int u = 0; u < PL_HP; u++) {
+    acc = acc + pa[u] * h.e[u].x;
+    acc = acc + pb[u] * h.e[u].y;
+  }
+  return acc;
+}
+
+// countCols as in k_price_sell; the launch has min(256, cdiv(jdsWindows, 4)) workgroups and
+// jdsTileRows * 8 + 16 + 4 * 256 * 9 + 16 * 12 + 64 bytes of dynamic LDS
+__global__ void __launch_bounds__(PL_THREADS) k_price_lds(Dev D, int countCols)
 {
   const Ctrl *c = D.ctrl;
   if (c->state != RUN)
     return;
-  extern __shared__ double piTile[];
-  __shared__ int shPop[PT_THREADS / 64];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  {
+  extern __shared__ __attribute__((aligned(16))) unsigned char plSmem[];
+  constexpr int NW = PL_THREADS / 64, NQ = PL_THREADS / 256, RING = 4 * PL_HP;
+  const int tileRows = D.jdsTileRows, T = D.jdsTiles;
+  const int tileBytes = tileRows * 8 + 16;  // + the permanent zero behind the tile
+  const unsigned zero = (unsigned)tileRows;
+  const double *piTile = (const double *)plSmem;
+  double *shAlpha = (double *)(plSmem + tileBytes);
+  unsigned char *shFlag = (unsigned char *)(shAlpha + NQ * 256);
+  int *shCnt = (int *)(shFlag + NQ * 256);
+  double *shMin = (double *)(shCnt + NW);
+  double *shBytes = shMin + NW;
+  const int tid = threadIdx.x;
+  const unsigned lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int quad = wv >> 2;
+  const int nChunks = (tileRows * 8) >> 10;  // 1 KB wave-chunks per tile (jdsTileRows is a multiple of 128)
+  const unsigned ldsBase = (unsigned)(size_t)(pl_lds_byte *)plSmem;
+  if (tid == 0)
+    *(double *)(plSmem + (size_t)tileRows * 8) = 0.0;
+  if (blockIdx.x == 0 && wv == 0) {
+    // how many pivots had a dense pi: the host chooses between this kernel and k_price_sell (+ by-row form) by it
     int pop = 0;
-    const int nwords = (D.m + 63) >> 6;
-    for (int w = tid; w < nwords; w += PT_THREADS)
+    for (int w = (int)lane; w < ((D.m + 63) >> 6); w += 64)
       pop += __popcll(D.piBits[w]);
     for (int o = 32; o > 0; o >>= 1)
       pop += __shfl_xor(pop, o);
-    if (lane == 0)
-      shPop[wv] = pop;
-    __syncthreads();
-    pop = 0;
-    for (int w = 0; w < PT_THREADS / 64; w++)
-      pop += shPop[w];
-    if (12 * (long long)pop < (long long)D.m)
-      return;
+    if (lane == 0 && 12LL * pop >= (long long)D.m)
+      D.ctrl->statDensePi += 1.0;
   }
-  const int numSlices = D.numSlices, wavesTotal = gridDim.x * (PT_THREADS / 64);
-  const int gw = blockIdx.x * (PT_THREADS / 64) + wv;
-  double acc[PT_MAXS];
-  bool want[PT_MAXS];
-#pragma unroll
-  for (int q = 0; q < PT_MAXS; q++) {
-    acc[q] = 0.0;
-    const int s = gw + q * wavesTotal;
-    want[q] = false;
-    if (s < numSlices) {
-      const int j = D.sellCol[s * 64 + lane];
-      want[q] = j >= 0 && ((D.status[j] & 3) - 1) != 0;  // basic columns are not priced
-    }
-  }
-  for (int tau = 0; tau < D.numTiles; tau++) {
-    __syncthreads();
-    const int r0 = tau * D.tileRows, rn = min(D.tileRows, D.m - r0);
-    for (int i = tid; i < rn; i += PT_THREADS)
-      piTile[i] = D.piNeg[r0 + i];
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < PT_MAXS; q++) {
-      const int s = gw + q * wavesTotal;
-      if (s >= numSlices)
-        continue;
-      const size_t seg = (size_t)tau * numSlices + s;
-      const int len = want[q] ? (int)D.tsLen[seg * 64 + lane] : 0;
-      int maxLen = len;
-      for (int o = 32; o > 0; o >>= 1)
-        maxLen = max(maxLen, __shfl_xor(maxLen, o));
-      const unsigned short *rp = D.tsRow + D.tsStart[seg] + lane;
-      const double *ep = D.tsElem + D.tsStart[seg] + lane;
-      double a = acc[q];
-      // (segments are padded to an even number of steps; four steps in flight)
-      for (int t = 0; t < maxLen; t += 4) {
-        unsigned short r[4];
-        double e[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const bool in = t + u < maxLen;
-          r[u] = in ? rp[(size_t)(t + u) * 64] : (unsigned short)0;
-          e[u] = in ? ep[(size_t)(t + u) * 64] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-          if (t + u < len)
-            a += piTile[r[u]] * e[u];
+  // a workgroup takes four windows at a time (one per wave quad); more than 4 * gridDim.x windows: further rounds
+  for (int window0 = (int)blockIdx.x; window0 < D.jdsWindows; window0 += 4 * (int)gridDim.x) {
+    const int window = window0 + (int)gridDim.x * quad;
+    const bool live = window < D.jdsWindows;
+    const int slice = live ? window * 4 + (wv & 3) : 0;
+    // per-tile lane metadata, fetched two tiles ahead: the load is then older than every ring load in flight when its
+    // value is first needed (a wait for a YOUNGER load would drain the ring: vmcnt counts in order)
+    const unsigned char *metaCnt = D.jdsCnt + (size_t)slice * T * 64 + lane, *metaSrc = D.jdsSrc + (size_t)slice * T * 64 + lane;
+    int cntCur = metaCnt[0];
+    int rawCnt1 = metaCnt[min(1, T - 1) * 64], rawSrc1 = metaSrc[min(1, T - 1) * 64];
+    unsigned off = (unsigned)D.jdsSegStart[slice];
+    if (!live)
+      cntCur = 0;
+    off = __builtin_amdgcn_readfirstlane(off);
+    int maxCur = __builtin_amdgcn_readfirstlane(cntCur);
+    PlHalf H0, H1;
+    plLoadHalf(H0, D.jdsRowPair, D.jdsElemPair, cntCur, 0, off, lane);
+    plLoadHalf(H1, D.jdsRowPair, D.jdsElemPair, cntCur, 2 * PL_HP, off, lane);
+    double acc = 0.0;
+    for (int tau = 0; tau < T; tau++) {
+      // ---- pi tile tau into LDS
+      if (tau > 0 || window0 != (int)blockIdx.x)
+        plBarrier();  // every wave is done reading the previous tile (or the staging area of the previous round)
+      {
+        const double *src = D.piNeg + (size_t)tau * tileRows;  // (piNeg is zero-padded to jdsTiles * jdsTileRows entries)
+        for (int ch = wv; ch < nChunks; ch += NW)
+          plGlds16(src + (size_t)ch * 128 + lane * 2, __builtin_amdgcn_readfirstlane(ldsBase + (unsigned)ch * 1024u));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      acc[q] = a;
+      plBarrier();
+      const int rawCnt2 = metaCnt[min(tau + 2, T - 1) * 64], rawSrc2 = metaSrc[min(tau + 2, T - 1) * 64];
+      const bool haveNext = live && tau + 1 < T;
+      const int cntNext = haveNext ? rawCnt1 : 0, srcNext = haveNext ? rawSrc1 : (int)lane;
+      // the ring holds steps t0 .. t0 + RING - 1 of this tile; the tile's step count is padded to a multiple of RING
+      // (steps with no active lane), so the roles of H0 / H1 are the same at every tile boundary
+      const int maxPad = max(RING, (maxCur + RING - 1) / RING * RING);
+      for (int t0 = 0; t0 < maxPad; t0 += RING) {
+        const bool more = t0 + RING < maxPad;  // wave-uniform
+        const int cntL = more ? cntCur : cntNext, tL = more ? t0 + RING : 0;
+        // (the scheduling barriers pin the issue order consume / refill / consume / refill: the loads of a refill stay
+        // in flight while the other half is consumed)
+        acc = plConsumeHalf(H0, piTile, cntCur, t0, acc, zero);
+        __builtin_amdgcn_sched_barrier(0);
+        plLoadHalf(H0, D.jdsRowPair, D.jdsElemPair, cntL, tL, off, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = plConsumeHalf(H1, piTile, cntCur, t0 + 2 * PL_HP, acc, zero);
+        __builtin_amdgcn_sched_barrier(0);
+        plLoadHalf(H1, D.jdsRowPair, D.jdsElemPair, cntL, tL + 2 * PL_HP, off, lane);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (tau + 1 < T) {
+        acc = __shfl(acc, srcNext);
+        cntCur = cntNext;
+        maxCur = __builtin_amdgcn_readfirstlane(cntNext);
+        rawCnt1 = rawCnt2;
+        rawSrc1 = rawSrc2;
+      }
+    }
+    // ---- back to the home order of the slice; fused first ratio pass (ClpPackedMatrix.cpp:1799-1993) as in priceSellBody
+    int j = -1;
+    double value = 0.0;
+    if (live) {
+      value = __shfl(acc, (int)D.jdsHome[(size_t)slice * 64 + lane]);
+      j = D.jdsCol[(size_t)slice * 64 + lane];
+    }
+    int flag = 0;
+    double ratio = 1.0e31, bytes = 0.0;
+    if (j >= 0) {
+      const int wanted = (D.status[j] & 3) - 1;
+      if (wanted) {
+        // SURVEY 8d's B_col for the scanned column: 12 B per entry + colStart; + 20 per emitted nonzero
+        bytes = 12.0 * (double)D.sellLen[(size_t)slice * 64 + lane] + 4.0;
+        if (fabs(value) > c->zeroTolerance) {
+          bytes += 20.0;
+          if (wanted > 0) {
+            const double mult = (wanted == 1) ? -1.0 : 1.0;
+            const double alpha = value * mult;
+            if (alpha > 0.0) {
+              const double dualT = -c->dualTolerance;
+              const double oldValue = D.dj[j] * mult;
+              const double v2 = oldValue - 1.0e15 * alpha;
+              if (v2 < dualT) {
+                flag = 1;
+                if (alpha >= c->acceptablePivot)
+                  ratio = (oldValue - dualT) / alpha;
+              }
+            }
+          }
+        } else {
+          value = 0.0;
+        }
+      } else {
+        value = 0.0;  // basic / fixed columns are not priced (their sums are computed and dropped)
+      }
+    }
+    const int wtid = tid & 255;  // position inside the window's four waves
+    shFlag[quad * 256 + wtid] = 0xFF;
+    plBarrier();
+    const int j0 = D.firstColumn + (D.sellWinBase + window) * PRICE_BLOCK;
+    if (j >= 0) {
+      shAlpha[quad * 256 + (j - j0)] = value;
+      shFlag[quad * 256 + (j - j0)] = (unsigned char)flag;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      ratio = fmin(ratio, __shfl_xor(ratio, o));
+      bytes += __shfl_xor(bytes, o);
+    }
+    const int wcount = (int)__popcll(__ballot(flag != 0));
+    if (lane == 0) {
+      shCnt[wv] = wcount;
+      shMin[wv] = ratio;
+      shBytes[wv] = bytes;
+    }
+    plBarrier();
+    if (live) {
+      const unsigned char f = shFlag[quad * 256 + wtid];
+      if (f != 0xFF) {
+        D.alphaCol[j0 + wtid] = shAlpha[quad * 256 + wtid];
+        D.candFlag[D.m + j0 + wtid] = f;
+      }
+      if (wtid == 0) {
+        const int q4 = quad * 4;
+        const int total = shCnt[q4] + shCnt[q4 + 1] + shCnt[q4 + 2] + shCnt[q4 + 3];
+        if (total && countCols)
+          atomicAdd(&D.blockCount[((D.m + PRICE_BLOCK - 1) / PRICE_BLOCK) + D.sellWinBase + window], total);
+        D.sellMin[window] = fmin(fmin(shMin[q4], shMin[q4 + 1]), fmin(shMin[q4 + 2], shMin[q4 + 3]));
+        D.sellBytes[window] = ((shBytes[q4] + shBytes[q4 + 1]) + shBytes[q4 + 2]) + shBytes[q4 + 3];
+      }
     }
   }
-#pragma unroll
-  for (int q = 0; q < PT_MAXS; q++) {
-    const int s = gw + q * wavesTotal;
-    if (s < numSlices)
-      D.priceAcc[s * 64 + lane] = acc[q];
-  }
+  if (blockIdx.x == 0 && tid == 0)
+    D.ctrl->lastPriceByRow = 0;
 }
 
 __global__ void __launch_bounds__(256) k_price_sell(Dev D, int variant, int countCols = 0, int nSellBlocks = 1 << 30, int nColBlocks = 1 << 30,
@@ -3037,10 +3188,15 @@ __global__ void __launch_bounds__(256) k_price_sell(Dev D, int variant, int coun
 {
   if (D.ctrl->state != RUN)
     return;
+  // dbg & 32: the launch prices the long columns only (the SELL windows were priced by k_price_lds)
+  if ((dbg & 32) && (int)blockIdx.x < nSellBlocks)
+    return;
   bool byRow = false;
-  if (rowMax > 0) {
+  if (rowMax > 0 || (blockIdx.x == 0 && !(dbg & 32))) {
     const int pop = piPopcount256(D);
-    byRow = pop <= rowMax;
+    byRow = rowMax > 0 && pop <= rowMax;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && 12LL * pop >= (long long)D.m)
+      D.ctrl->statDensePi += 1.0;
   }
   if ((int)blockIdx.x >= nColBlocks) {
     if (byRow)

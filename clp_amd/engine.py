@@ -33,7 +33,10 @@ class Stats(C.Structure):
                 ("lu_active", C.c_long), ("lu_front", C.c_long), ("lu_tail", C.c_long), ("lu_factorizations", C.c_long),
                 ("lu_front_ms", C.c_double), ("lu_invert_ms", C.c_double), ("lu_build_ms", C.c_double), ("eta_count", C.c_long),
                 ("perturbations", C.c_long), ("backwards_restores", C.c_long), ("loop_flags", C.c_long),
-                ("accuracy_restores", C.c_long), ("singular_restores", C.c_long)]
+                ("accuracy_restores", C.c_long), ("singular_restores", C.c_long),
+                ("price_form", C.c_long), ("dense_pi_launches", C.c_long), ("price_form_switches", C.c_long),
+                ("exits_scheduled", C.c_long), ("exits_alpha_check", C.c_long), ("exits_backwards", C.c_long),
+                ("exits_bad_update", C.c_long)]
 
 
 # every symbol include/clpgpu.h declares (tests/test_abi.py checks the library exports all of them)

@@ -69,6 +69,15 @@ typedef struct {
   long loop_flags;         /* times ClpSimplexProgress::looping found a repeat over status checks and acted (ClpSolve.cpp:4553) */
   long accuracy_restores;  /* times errors beyond 1e15 sent statusOfProblemInDual back to the last good basis (:5237-5318) */
   long singular_restores;  /* times a singular refactorization did (:5060-5125) */
+  /* row pricing form of the iteration chain (option price_lds) */
+  long price_form;          /* 1: the captured chain now prices with pi tiles in LDS (dense pi), 0: k_price_sell + the by-row form */
+  long dense_pi_launches;   /* pricing launches whose pi was dense (12 nnz >= m) */
+  long price_form_switches; /* times the host changed the chain's pricing form */
+  /* what ended the batches of whileIterating that led to a status check (src/ClpSimplexDual.cpp:1849 / :1451 / :1574 / :1618) */
+  long exits_scheduled;     /* housekeeping asked for the refactorization (eta-file length, forced factorization) */
+  long exits_alpha_check;   /* btran / ftran alpha disagreed */
+  long exits_backwards;     /* objective going backwards */
+  long exits_bad_update;    /* the basis update reported a singular pivot */
 } clpgpu_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------- */
@@ -221,7 +230,7 @@ int clpgpu_unroll_weights(clpgpu_context *ctx);
  * "lu_inverse_fill_cap" (front / explicit-inverse controls), "lu_max_pivots", "lu_min_pivots", "lu_adaptive" (eta-file
  * length: from a cost model of the refactorization, the same on every run), "lu_polish", "lu_polish_tolerance" (Newton-Schulz steps on the tail inverse),
  * "gemm_backend" (0 the engine's own MFMA f64 GEMM, 1 rocBLAS), "solution_refinements" / "refine_above" (iterative
- * refinement of the recomputed primal and dual solutions), "price_tiles" (1: pricing with pi tiles staged in LDS),
+ * refinement of the recomputed primal and dual solutions), "price_lds" (1 default: dense tableau rows priced with pi tiles staged in LDS, the chain's form chosen per batch; 2: on every pivot; 0: never; "price_lds_min_windows", "price_lds_grid": its layout knobs),
  * "sell_windows" (1 default: the pricing copy of A sorted by column length inside windows of 256 keys, one compaction block
  * per workgroup -- coalesced tableau-row stores, one candidate count per workgroup; 0: sorted globally, per-candidate atomics),
  * "fake_bound_cleanup" (1: "infeasible" reached with nonbasic variables still at fake bounds is reported as 10, "clean up in

@@ -237,6 +237,34 @@ def test_lu_solve_matches_independent_solver(gpu_cls):
     assert abs(g.objectiveValue() - r.fun) <= 1e-8 * abs(r.fun)
 
 
+@pytest.mark.parametrize("args", [(1000, 1200, 8, 41), (2500, 2600, 10, 43)])
+def test_lu_mode_on_nearly_square_lps(gpu_cls, args):
+    """LU mode with n ~ m: the eta-file kernel then runs more workgroups (64 basis positions each) than the LP has 256-key
+    compaction blocks, and its per-workgroup slots must be sized for that."""
+    lp = P.sparse_lp(*args)
+    # the checker: the oracle on the small LP (7 s of CPU), the engine's explicit-inverse mode on the larger one (the oracle needs minutes)
+    if lp.m <= 1000:
+        o = oracle(lp)
+        assert o.dual() == 0
+        ref_obj, ref_sol = o.objective, o.solution()
+    else:
+        base = gpu_cls().loadProblem(lp)
+        base.set_option("pivot_rule", 1)
+        base.set_option("factor_mode", 0)
+        assert base.dual() == 0
+        ref_obj, ref_sol = base.objectiveValue(), base.solution()
+    g = gpu_cls().loadProblem(lp)
+    g.set_option("pivot_rule", 1)
+    g.set_option("factor_mode", 1)
+    g.set_option("lu_stop_density", 0.3)
+    g.set_option("lu_min_tail", 4)
+    g.set_option("lu_max_pivots", 60)
+    assert g.dual() == 0
+    assert g.stats()["lu_factorizations"] > 0
+    assert abs(g.objectiveValue() - ref_obj) <= 1e-8 * (1.0 + abs(ref_obj))
+    assert rel(g.solution(), ref_sol) < 1e-7
+
+
 @pytest.mark.parametrize("n", [37, 128, 300, 1111])
 def test_own_mfma_gemm_matches_numpy(gpu_cls, n):
     """The engine's f64 GEMM on the matrix cores (the kernel behind the Newton-Schulz steps) against numpy:
@@ -252,18 +280,21 @@ def test_own_mfma_gemm_matches_numpy(gpu_cls, n):
 
 
 # ---------------------------------------------------------------- row pricing with pi in LDS ----------------
-@pytest.mark.parametrize("args", [(20000, 40000, 8, 29), (50000, 200000, 50, 20260926)])
-def test_tiled_pricing_bit_identical_to_oracle(gpu_cls, args):
-    """Dense tableau rows are priced by k_price_tiled (row tiles of pi in LDS, tile-by-tile SELL copy): the tableau row,
-    the candidate list and upperTheta must be the oracle's bit for bit, on a two-tile LP and on config 4 (three tiles)."""
+@pytest.mark.parametrize("args,grid", [((20000, 40000, 8, 29), 256), ((20000, 40000, 8, 29), 8), ((4200, 70000, 6, 31), 256),
+                                       ((50000, 200000, 50, 20260926), 256)])
+def test_lds_pricing_bit_identical_to_oracle(gpu_cls, args, grid):
+    """Dense tableau rows are priced by k_price_lds (row tiles of pi in LDS, jagged tile-by-tile streams of the SELL windows): the
+    tableau row, the candidate list and upperTheta must be the oracle's bit for bit -- on a two-tile LP, with eight workgroups
+    only (every workgroup walks five rounds of windows), on a one-tile LP, and on config 4 (three tiles)."""
     lp = P.sparse_lp(*args)
     g = gpu_cls()
-    g.set_option("price_tiles", 1)  # (off by default: measured slower than the plain sweep, DESIGN section 5)
+    g.set_option("price_lds_min_windows", 1)
+    g.set_option("price_lds_grid", grid)
     g.loadProblem(lp)
     o = oracle(lp)
     rng = np.random.default_rng(17)
     m, n = lp.m, lp.n
-    for density in (0.5, 0.12):
+    for density in (1.0, 0.5, 0.12):
         k = int(density * m)
         idx = np.sort(rng.choice(m, k, replace=False)).astype(np.int32)
         val = rng.standard_normal(k)
@@ -275,14 +306,16 @@ def test_tiled_pricing_bit_identical_to_oracle(gpu_cls, args):
         assert a[4] == b[4]
 
 
-def test_tiled_pricing_engine_runs_match_untiled(gpu_cls):
-    """The same solve stretch with and without the tiled form (option price_tiles): identical pivots and solution bits,
-    far enough into the solve for pi to be dense on most pivots."""
+def test_lds_pricing_engine_runs_match_plain(gpu_cls):
+    """The same solve stretch with the LDS form on every pivot (price_lds 2), chosen per batch by the host (1, the default) and
+    never (0): identical pivots and solution bits, far enough into the solve for pi to be dense on most pivots; the default
+    run must really have switched forms."""
     lp = P.sparse_lp(20000, 40000, 8, seed=29)
     runs = []
-    for tiles in (1, 0):
+    for mode in (2, 1, 0):
         g = gpu_cls()
-        g.set_option("price_tiles", tiles)
+        g.set_option("price_lds_min_windows", 1)
+        g.set_option("price_lds", mode)
         g.loadProblem(lp)
         g.set_option("pivot_rule", 1)
         g.set_option("check_every", 16)
@@ -290,6 +323,12 @@ def test_tiled_pricing_engine_runs_match_untiled(gpu_cls):
         g.set_option("factor_mode", 0)
         g.dual_steps(6000)
         runs.append(g)
-    a, b = runs[0].pivotLog(), runs[1].pivotLog()
-    assert len(a) == len(b) and np.array_equal(a["sequenceIn"], b["sequenceIn"]) and np.array_equal(a["sequenceOut"], b["sequenceOut"])
-    assert np.array_equal(runs[0].solution(), runs[1].solution())
+    a = runs[2].pivotLog()
+    for r in runs[:2]:
+        b = r.pivotLog()
+        assert len(a) == len(b) and np.array_equal(a["sequenceIn"], b["sequenceIn"]) and np.array_equal(a["sequenceOut"], b["sequenceOut"])
+        assert np.array_equal(r.solution(), runs[2].solution())
+    st = [r.stats() for r in runs]
+    assert st[0]["price_form"] == 1 and st[2]["price_form"] == 0 and st[2]["price_form_switches"] == 0
+    print({k: st[1][k] for k in ("price_form", "price_form_switches", "dense_pi_launches", "iterations")})
+    assert st[1]["price_form_switches"] >= 1 and st[1]["dense_pi_launches"] > 100, st[1]  # (pi is dense on ~400 of these 6000 pivots)
