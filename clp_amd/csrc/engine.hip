@@ -276,6 +276,7 @@ struct clpgpu_context {
   // form per captured graph: priceMode 1 = k_price_lds alone, 0 = k_price_sell + the by-row form; the host switches between
   // them from the share of dense-pi pivots in the last batch (Ctrl::statDensePi) -- either form prices any pi correctly, so
   // the choice changes the speed of a pivot, never its result.
+  int dcWide = 1;  // option "dc_wide": 1 (default) lists beyond one workgroup's registers go to k_dual_column_wide, 2 every list does (tests), 0 the single-workgroup walk
   int priceLds = 1;
   int priceLdsMinWindows = 256;  // option "price_lds_min_windows": narrower LPs keep k_price_sell (a one-workgroup-per-CU launch needs work for every CU)
   int priceLdsGridCap = 256;     // option "price_lds_grid" (test knob): fewer workgroups than CUs, so that a workgroup takes several rounds of windows
@@ -850,6 +851,7 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   rc |= dalloc(D.candBlk, N);
   rc |= dalloc(D.candRk, N);
   rc |= dalloc(D.wsIdxG, DC_WS_CAP);
+  rc |= dalloc(D.dcPart, 2 * (size_t)DCW_BLOCKS * DCW_PART);
   rc |= dalloc(D.flipRecMv, FLIP_LIST_CAP);
   rc |= dalloc(D.flipRecObj, FLIP_LIST_CAP);
   rc |= dalloc(D.flipRecStart, FLIP_LIST_CAP);
@@ -3440,7 +3442,9 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
     KL("k_shard_classes", k_shard_classes, dim3(nbClass), dim3(PRICE_BLOCK), 0, stream, D);
   }
   KL("k_dc_working_set", k_dc_working_set, dim3(128), dim3(WS_THREADS), 0, stream, D, nbClass);
-  KL("k_dual_column", k_dual_column, dim3(1), dim3(DC_THREADS), 0, stream, D, nbClass);
+  KL("k_dual_column", k_dual_column, dim3(1), dim3(DC_THREADS), 0, stream, D, nbClass, dcWide);
+  if (dcWide)  // lists too long for one workgroup's registers: the ratio test over the chip (returns at once otherwise)
+    KL("k_dual_column_wide", k_dual_column_wide, dim3(DCW_BLOCKS), dim3(DCW_THREADS), 0, stream, D);
   // dual update + flip detection (needs only theta), flip list, flip right-hand side
   // (+ 1: the extra workgroup unpacks the entering column)
   // sparse LPs, columns owned by this GPU or replicated: the waves that find a flip scatter its column
@@ -3643,6 +3647,10 @@ int clpgpu_context::whileIterating(int stepTarget)
     rc |= pullCtrl();
     if (!rc && hCtrl->state == RUN && stepTarget >= 0 && hCtrl->numberIterations >= stepTarget)
       hCtrl->state = EXIT_STEP_LIMIT;  // the batch ended exactly on the limit: the device never saw a pivot beyond it
+    if (!rc && hCtrl->dcWide < 0) {
+      setError("k_dual_column_wide: a grid barrier timed out at iteration %d", hCtrl->numberIterations);
+      rc = -99;
+    }
     if (!rc && jdsReady && priceLds) {
       // which pricing form the next batch's chain carries.  A dense-pi pivot costs ~52 us in k_price_sell and ~32 in k_price_lds,
       // a sparse-pi one ~12 us by row and ~32 in k_price_lds: the forms break even at half the pivots dense.  k_price_lds from
@@ -4821,6 +4829,7 @@ clpgpu_context *clpgpu_clone(const clpgpu_context *src)
   ctx->registerPanel = src->registerPanel;
   ctx->rowPriceFrac = src->rowPriceFrac;
   ctx->priceLds = src->priceLds;
+  ctx->dcWide = src->dcWide;
   ctx->priceLdsMinWindows = src->priceLdsMinWindows;
   ctx->priceLdsGridCap = src->priceLdsGridCap;
   ctx->sellWindows = src->sellWindows;
@@ -5154,6 +5163,11 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
       ctx->dropGraph();
       return ctx->buildSell();
     }
+  }
+  else if (!strcmp(name, "dc_wide")) {
+    if ((int)v != ctx->dcWide)
+      ctx->dropGraph();
+    ctx->dcWide = (int)v;
   }
   else if (!strcmp(name, "price_lds_min_windows") || !strcmp(name, "price_lds_grid")) {
     if (ctx->n > 0 && ctx->D.colStart)
@@ -5547,6 +5561,11 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
     fprintf(stderr, "clpgpu dbg: ratio test working-set path: calls %lld, ticks/call %.0f, before the passes %.0f, max %lld; candidates of breakpoint class "
                     "<= 0 / 1 / 2 summed over the pivots with a long list: %lld / %lld / %lld; fall-backs to the full list %lld (sum of their working-set classes %lld)\n",
             q[0], q[0] ? (double)q[1] / q[0] : 0.0, q[0] ? (double)q[2] / q[0] : 0.0, q[3], q[4], q[5], q[6], q[7] % 1000000LL, q[7] / 1000000LL);
+    const long long *w = ctx->hCtrl->dbgCc;
+    fprintf(stderr, "clpgpu dbg: ratio test, final batch: moved into one wave %lld times, too large %lld times, mean size %.1f; ticks per call in the trips %.0f, "
+                    "in the coarse passes before them %.0f; calls of the wide kernel %lld\n",
+            w[0], w[1], (w[0] + w[1]) ? (double)w[2] / (double)(w[0] + w[1]) : 0.0, (w[0] + w[1] + w[5]) ? (double)w[3] / (double)(w[0] + w[1] + w[5]) : 0.0,
+            (w[0] + w[1] + w[5]) ? (double)w[4] / (double)(w[0] + w[1] + w[5]) : 0.0, w[5]);
   }
   stats->price_bytes = ctx->hCtrl->statPriceBytes;
   stats->row_bytes = ctx->hCtrl->statRowBytes;

@@ -494,6 +494,9 @@ template <bool COHERENT> __device__ inline void scanBlocksBody(const Dev &D, int
     if (what == 0) {
       c->numberCandidates = s_base;
       c->upperTheta = vmin;
+      c->dcArrive = 0;  // (as in k_cand_scatter's own scan)
+      if (c->dcWide > 0)
+        c->dcWide = 0;
       // algorithmic bytes of this pricing launch: per scanned column 12*len+4 (+20 per
       // emitted nonzero), plus status 1*n, pi 8*m, one extra colStart
       if (c->lastPriceByRow) {
@@ -601,6 +604,9 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_cand_scatter(Dev D, int nbRows,
         if (tid == 0) {
           c->numberCandidates = all;
           c->upperTheta = upperTheta;
+          c->dcArrive = 0;  // k_dual_column_wide: grid-barrier arrivals of this pivot, and whether the pivot's list is its
+          if (c->dcWide > 0)
+            c->dcWide = 0;
           // algorithmic bytes of this pricing launch, as in scanBlocksBody
           if (c->lastPriceByRow) {
             // B_row: 12 B per visited row entry and per pi nonzero, 8 per touched column, 20 per emitted one
@@ -792,15 +798,95 @@ template <int F> __device__ inline void dcReduce(DcAcc &a, double (*shd)[16], in
   }
 }
 
+// ---- the same reduction over the workgroups of a launch (k_dual_column_wide): per pass every workgroup leaves its partial
+// {sum thruThis, sum increaseInThis, min upperTheta, sum bad pivots, best |alpha| (first wins) with its dj / alpha / list
+// position, min breakpoint of the swapped} -- the dualColumnResult of the reference's blocked ratio test
+// (src/AbcSimplexDual.hpp:22-40, per-block pass src/AbcSimplexDual.cpp:1450-1528) -- then one grid barrier, then EVERY
+// workgroup combines all partials with the same fixed tree (the combine loop of :1623-1634), so all of them take the same
+// decisions without a broadcast.  The partial is also what a column-sharded run would all-reduce per pass.
+#define DCW_BLOCKS 128
+#define DCW_THREADS 256
+#define DCW_PART 10  // doubles per partial
+// all workgroups of the launch are resident (128 x 256 threads); the counter is zeroed by k_cand_scatter earlier in the
+// pivot's chain.  Producer: plain stores -> __syncthreads -> lane 0 release fence -> drained -> relaxed arrive; consumer:
+// relaxed polls -> one acquire fence -> __syncthreads -> plain loads (MI355X guide, inter-workgroup visibility).  The spin
+// is bounded: a launch that cannot complete reports EXIT_NO_INCOMING with an error mark instead of hanging the device.
+__device__ inline bool dcGridBarrier(Ctrl *c, int no, int G)
+{
+  __shared__ int shOk;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(&c->dcArrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 0;
+    for (int spin = 0; spin < (1 << 22); spin++) {
+      if (__hip_atomic_load(&c->dcArrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= no * G) {
+        ok = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    shOk = ok;
+  }
+  __syncthreads();
+  return shOk != 0;
+}
+template <int F> __device__ inline bool dcReduceGrid(DcAcc &a, double (*shd)[16], int *shk, const Dev &D, int &barrierNo)
+{
+  dcReduce<F>(a, shd, shk);
+  const int G = gridDim.x, tid = threadIdx.x;
+  barrierNo++;
+  double *part = D.dcPart + (size_t)(barrierNo & 1) * DCW_BLOCKS * DCW_PART;  // two sets: a fast workgroup is at most one pass ahead
+  if (tid == 0) {
+    double *p = part + (size_t)blockIdx.x * DCW_PART;
+    p[0] = a.thru;
+    p[1] = a.incr;
+    p[2] = a.ut;
+    p[3] = a.sumBad;
+    p[4] = a.bestPivot;
+    p[5] = a.ut2;
+    p[6] = a.bestDj;
+    p[7] = a.bestAlpha;
+    p[8] = (double)a.bestIdx;
+  }
+  const bool ok = dcGridBarrier(D.ctrl, barrierNo, G);
+  DcAcc b = { 0.0, 0.0, 1.0e50, 0.0, a.bestPivot, 1.0e50, -1, 0.0, 0.0 };
+  if (tid < G) {
+    const double *p = part + (size_t)tid * DCW_PART;
+    b.thru = p[0];
+    b.incr = p[1];
+    b.ut = p[2];
+    b.sumBad = p[3];
+    b.bestPivot = p[4];
+    b.ut2 = p[5];
+    b.bestDj = p[6];
+    b.bestAlpha = p[7];
+    b.bestIdx = (int)p[8];
+  }
+  dcReduce<F>(b, shd, shk);
+  a = b;
+  return ok;
+}
+
 // CPT > 0: every thread keeps CPT candidates (alpha, dj, range, state) in registers, a pass is
 // pure ALU + one reduction; CPT == 0: candidates stay in global memory (very long rows).
-template <int CPT, bool ONEWAVE, bool MAPPED = false>
-__device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nullptr, int count = -1, double tauGuard = 0.0)
+// WIDE: the launch has several workgroups (k_dual_column_wide); candidates are dealt over all its threads, every reduction
+// is grid-wide (dcReduceGrid) and every workgroup follows the same decisions.
+#define DC_CC 4                   // candidates per lane of the compacted final batch (one wave)
+#define DC_COMPACT (DC_CC * 64)
+template <int CPT, bool ONEWAVE, bool MAPPED = false, bool WIDE = false>
+__device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nullptr, int count = -1, double tauGuard = 0.0, void *ccScratch = nullptr)
 {
   Ctrl *c = D.ctrl;
   __shared__ double shd[8][16];
   __shared__ int shk[16];
-  const int tid = threadIdx.x, nthr = ONEWAVE ? 64 : blockDim.x;
+  // (tid / nthr: this thread's place among all threads that share the candidate list)
+  const int tid = WIDE ? (int)(blockIdx.x * blockDim.x + threadIdx.x) : (int)threadIdx.x;
+  const int nthr = ONEWAVE ? 64 : (WIDE ? (int)(gridDim.x * blockDim.x) : (int)blockDim.x);
+  int barrierNo = 0;
+  bool gridOk = true;
   const int nc = MAPPED ? count : c->numberCandidates;  // MAPPED: a prefiltered working set (see k_dual_column)
   const double acceptablePivot = c->acceptablePivot;
   const double dualTolerance = c->dualTolerance;
@@ -810,6 +896,8 @@ __device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nu
     constexpr int F = decltype(fields)::value;
     if constexpr (ONEWAVE)
       dcReduceWave<F>(a);
+    else if constexpr (WIDE)
+      gridOk = dcReduceGrid<F>(a, shd, shk, D, barrierNo) && gridOk;
     else
       dcReduce<F>(a, shd, shk);
   };
@@ -933,6 +1021,8 @@ __device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nu
       }
     });
     reduce(acc, std::integral_constant<int, F_THRU | F_INCR | F_UT | F_BEST | F_UT2>());
+    if (WIDE && !gridOk)
+      break;
     double thruThis = acc.thru, increaseInThis = acc.incr, bestPivot = acc.bestPivot;
     int bestIdx = acc.bestIdx;
     upperTheta = acc.ut;
@@ -943,22 +1033,81 @@ __device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nu
     check += 1.0e-8 + 1.0e-10 * check;
     if (check >= absDualOut || increaseInObjective + increaseInThis < 0.0) {
       // ---- pivot in this batch: the list becomes the swapped set of this pass (:4427-4434)
+      const long long dbgT1 = wall_clock64();
       forEach([&](int, double, double, double, double, bool &live, int &tag) { live = (tag == passId); });
       if constexpr (CPT == 0)
         __syncthreads();
-      int iTry;
-      const int MAXTRY = 100;
-      double nextUt = acc.ut2;
-      for (iTry = 0; iTry < MAXTRY; iTry++) {
-        passId++;
-        dbgTries++;
-        // smallest remaining breakpoint of the live set (:4441-4462); it was computed by the pass
-        // that produced the live set (the coarse pass, or the previous trip's removal pass)
-        upperTheta = nextUt;
-        badSumPivots = 0;
-        upperTheta *= 1.0000000001;
-        DcAcc a2 = { 0.0, 0.0, 1.0e50, 0.0, acceptablePivot, 1.0e50, -1, 0.0, 0.0 };
-        forEach([&](int i, double alpha, double djv, double range, double ratio, bool &live, int &tag) {
+      // the inner loop (:4436-4638) over whatever holds the batch: `fe` visits its candidates, `rd` reduces over them
+      // `pass(a2)` swaps what upperTheta reaches out of the batch and leaves the reduced sums / minimum / best pivot in a2
+      auto tries = [&](auto &&pass, double nextUt) {
+        int iTry;
+        const int MAXTRY = 100;
+        for (iTry = 0; iTry < MAXTRY; iTry++) {
+          passId++;
+          dbgTries++;
+          // smallest remaining breakpoint of the live set (:4441-4462); it was computed by the pass
+          // that produced the live set (the coarse pass, or the previous trip's removal pass)
+          upperTheta = nextUt;
+          badSumPivots = 0;
+          upperTheta *= 1.0000000001;
+          DcAcc a2 = { 0.0, 0.0, 1.0e50, 0.0, acceptablePivot, 1.0e50, -1, 0.0, 0.0 };
+          pass(a2);
+          if (WIDE && !gridOk)
+            break;
+          nextUt = a2.ut;
+          thruThis = a2.thru;
+          increaseInThis = a2.incr;
+          bestPivot = a2.bestPivot;
+          bestIdx = a2.bestIdx;
+          double sumBadPivots = a2.sumBad;
+          if (bestIdx < 0)
+            bestPivot = acceptablePivot;
+          seqIdx = bestIdx;
+          if (bestIdx >= 0)
+            theta = a2.bestDj / a2.bestAlpha;  // dj / alpha of the chosen candidate (:4566)
+          if (sumBadPivots > 1.0e4) {
+            if (c->pivots > 3) {
+              badSumPivots = 1;
+              break;
+            }
+          }
+          sid[1 - iFlip] = passId;
+          double increase = (absDualOut - totalThru) * theta;
+          increase += increaseInObjective;
+          if (theta < 0.0)
+            thruThis += absDualOut;  // force using this one
+          if (increaseInObjective < 0.0 && increase < 0.0 && lastIdx >= 0) {
+            bestPivot = 0.0;
+          } else {
+            totalThru += thruThis;
+            increaseInObjective += increaseInThis;
+          }
+          if (bestPivot < 0.1 * bestEverPivot && bestEverPivot > 1.0e-6 && (bestPivot < 1.0e-3 || totalThru * 2.0 > absDualOut)) {
+            seqIdx = lastIdx;
+            iFlip = 1 - iFlip;
+            break;
+          } else if (seqIdx == -1 && upperTheta > c->largeValue) {
+            if (lastPivot > acceptablePivot) {
+              seqIdx = lastIdx;
+              iFlip = 1 - iFlip;
+            }
+            break;
+          } else if (totalThru >= absDualOut) {
+            modifyCosts = 1;
+            break;
+          } else {
+            lastIdx = seqIdx;
+            if (bestPivot > bestEverPivot)
+              bestEverPivot = bestPivot;
+            iFlip = 1 - iFlip;
+            modifyCosts = 1;
+          }
+        }
+        if (iTry == MAXTRY)
+          iFlip = 1 - iFlip;
+      };
+      auto passAll = [&](DcAcc &a2) {
+      forEach([&](int i, double alpha, double djv, double range, double ratio, bool &live, int &tag) {
           if (!live)
             return;
           double value = djv - upperTheta * alpha;
@@ -1001,57 +1150,164 @@ __device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nu
           }
         });
         reduce(a2, std::integral_constant<int, F_THRU | F_INCR | F_UT | F_BAD | F_BEST | F_BESTV>());
-        nextUt = a2.ut;
-        thruThis = a2.thru;
-        increaseInThis = a2.incr;
-        bestPivot = a2.bestPivot;
-        bestIdx = a2.bestIdx;
-        double sumBadPivots = a2.sumBad;
-        if (bestIdx < 0)
-          bestPivot = acceptablePivot;
-        seqIdx = bestIdx;
-        if (bestIdx >= 0)
-          theta = a2.bestDj / a2.bestAlpha;  // dj / alpha of the chosen candidate (:4566)
-        if (sumBadPivots > 1.0e4) {
-          if (c->pivots > 3) {
-            badSumPivots = 1;
-            break;
-          }
+      };
+      bool compacted = false;
+      if constexpr (!ONEWAVE && !WIDE && CPT > 0 && CPT <= 8) if (ccScratch != nullptr) {
+        // The batch is usually a few dozen candidates out of a working set of thousands, and the loop above makes ~9 trips
+        // (profiles/r04_dc_probe_after.txt), each a workgroup-wide reduction.  A batch of at most DC_COMPACT candidates is
+        // moved into the registers of wave 0 (slot = exclusive scan of the per-thread counts: a fixed order, so the sums
+        // are the same on every run), the trips become register butterflies of one wave -- no LDS exchange, no barrier --
+        // and the tags go back to their owners for the cost shifting below.  (Ties of "largest |alpha|" are broken by
+        // the candidate's list position, which travels with it: the slot order does not matter.)
+        // (LDS: the caller's working-set index array, no longer needed once the candidates are in registers)
+        double *ccA = (double *)ccScratch, *ccD = ccA + DC_COMPACT, *ccR = ccD + DC_COMPACT, *ccQ = ccR + DC_COMPACT, *ccOutD = ccQ + DC_COMPACT;
+        int *ccI = (int *)(ccOutD + 2), *ccT = ccI + DC_COMPACT, *ccScan = ccT + DC_COMPACT, *ccOutI = ccScan + 18;
+        int mine = 0;
+        forEach([&](int, double, double, double, double, bool &live, int &) { mine += live ? 1 : 0; });
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+        int incl = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+          const int t = __shfl_up(incl, o);
+          if (lane >= o)
+            incl += t;
         }
-        sid[1 - iFlip] = passId;
-        double increase = (absDualOut - totalThru) * theta;
-        increase += increaseInObjective;
-        if (theta < 0.0)
-          thruThis += absDualOut;  // force using this one
-        if (increaseInObjective < 0.0 && increase < 0.0 && lastIdx >= 0) {
-          bestPivot = 0.0;
-        } else {
-          totalThru += thruThis;
-          increaseInObjective += increaseInThis;
+        __syncthreads();
+        if (lane == 63)
+          ccScan[wv] = incl;
+        __syncthreads();
+        int base = incl - mine, total = 0;
+        for (int w = 0; w < nw; w++) {
+          if (w < wv)
+            base += ccScan[w];
+          total += ccScan[w];
         }
-        if (bestPivot < 0.1 * bestEverPivot && bestEverPivot > 1.0e-6 && (bestPivot < 1.0e-3 || totalThru * 2.0 > absDualOut)) {
-          seqIdx = lastIdx;
-          iFlip = 1 - iFlip;
-          break;
-        } else if (seqIdx == -1 && upperTheta > c->largeValue) {
-          if (lastPivot > acceptablePivot) {
-            seqIdx = lastIdx;
-            iFlip = 1 - iFlip;
+        if (threadIdx.x == 0) {
+          c->dbgCc[total <= DC_COMPACT ? 0 : 1]++;
+          c->dbgCc[2] += total;
+        }
+        if (total <= DC_COMPACT) {  // uniform
+          int slot = base;
+          forEach([&](int i, double alpha, double djv, double range, double ratio, bool &live, int &) {
+            if (live) {
+              ccA[slot] = alpha;
+              ccD[slot] = djv;
+              ccR[slot] = range;
+              ccQ[slot] = ratio;
+              ccI[slot] = i;
+              slot++;
+            }
+          });
+          __syncthreads();
+          if (threadIdx.x < 64) {
+            double ca[DC_CC], cd[DC_CC], cr[DC_CC], cq[DC_CC];
+            int ci[DC_CC], ct[DC_CC];
+            bool cl[DC_CC];
+#pragma unroll
+            for (int q = 0; q < DC_CC; q++) {
+              const int sl = lane + 64 * q;
+              const bool in = sl < total;
+              ca[q] = in ? ccA[sl] : 0.0;
+              cd[q] = in ? ccD[sl] : 0.0;
+              cr[q] = in ? ccR[sl] : 0.0;
+              cq[q] = in ? ccQ[sl] : 1.0e50;
+              ci[q] = in ? ccI[sl] : -1;
+              ct[q] = passId;
+              cl[q] = in;
+            }
+            // One trip on the compacted batch: the swap test per lane, then the (usually one or two) swapped candidates are
+            // read out lane by lane (v_readlane) and summed in slot order by every lane alike -- the only wave-wide
+            // reduction left is the minimum over the remaining breakpoints.
+            auto rdl = [&](double v, int l) {
+              return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+            };
+            auto passC = [&](DcAcc &a2) {
+              double utLocal = 1.0e50;
+#pragma unroll
+              for (int q = 0; q < DC_CC; q++) {
+                const double value = cd[q] - upperTheta * ca[q];
+                const bool swap = cl[q] && ((ca[q] < 0.0) ? (value >= 0.0) : (value <= 0.0));
+                if (cl[q] && !swap)
+                  utLocal = fmin(utLocal, cq[q]);
+                unsigned long long mask = __ballot(swap);
+                if (swap) {
+                  cl[q] = false;
+                  ct[q] = passId;
+                }
+                while (mask) {
+                  const int l = __builtin_ctzll(mask);
+                  mask &= mask - 1;
+                  const double alpha = rdl(ca[q], l), djv = rdl(cd[q], l), range = rdl(cr[q], l);
+                  const int idx = __builtin_amdgcn_readlane(ci[q], l);
+                  const double val = djv - upperTheta * alpha;
+                  const double badDj = (alpha < 0.0) ? -djv - dualTolerance : djv - dualTolerance;
+                  const double absAlpha = fabs(alpha);
+                  if (absAlpha > a2.bestPivot || (absAlpha == a2.bestPivot && a2.bestIdx >= 0 && idx < a2.bestIdx)) {
+                    a2.bestPivot = absAlpha;
+                    a2.bestIdx = idx;
+                    a2.bestDj = djv;
+                    a2.bestAlpha = alpha;
+                  }
+                  if (absAlpha < acceptablePivot && upperTheta < 1.0e20) {
+                    if (alpha < 0.0) {
+                      if (val > dualTolerance)
+                        a2.sumBad += (range < 1.0e20) ? val * range : 1.0e20;
+                    } else {
+                      if (val < -dualTolerance)
+                        a2.sumBad += (range < 1.0e20) ? -(val * range) : 1.0e20;
+                    }
+                  }
+                  a2.thru += range * fabs(alpha);
+                  a2.incr += badDj * range;
+                }
+              }
+              DcAcc mn = { 0.0, 0.0, utLocal, 0.0, 0.0, 1.0e50, -1, 0.0, 0.0 };
+              dcReduceWave<F_UT>(mn);
+              a2.ut = mn.ut;
+            };
+            tries(passC, acc.ut2);
+#pragma unroll
+            for (int q = 0; q < DC_CC; q++)
+              if (lane + 64 * q < total)
+                ccT[lane + 64 * q] = ct[q];
+            if (lane == 0) {
+              ccOutD[0] = theta;
+              ccOutI[0] = seqIdx;
+              ccOutI[1] = iFlip;
+              ccOutI[2] = sid[0];
+              ccOutI[3] = sid[1];
+              ccOutI[4] = modifyCosts;
+              ccOutI[5] = badSumPivots;
+              ccOutI[6] = lastIdx;
+              ccOutI[7] = passId;
+              ccOutI[8] = dbgTries;
+            }
           }
-          break;
-        } else if (totalThru >= absDualOut) {
-          modifyCosts = 1;
-          break;
-        } else {
-          lastIdx = seqIdx;
-          if (bestPivot > bestEverPivot)
-            bestEverPivot = bestPivot;
-          iFlip = 1 - iFlip;
-          modifyCosts = 1;
+          __syncthreads();
+          theta = ccOutD[0];
+          seqIdx = ccOutI[0];
+          iFlip = ccOutI[1];
+          sid[0] = ccOutI[2];
+          sid[1] = ccOutI[3];
+          modifyCosts = ccOutI[4];
+          badSumPivots = ccOutI[5];
+          lastIdx = ccOutI[6];
+          passId = ccOutI[7];
+          dbgTries = ccOutI[8];
+          slot = base;
+          forEach([&](int, double, double, double, double, bool &live, int &tag) {
+            if (live)
+              tag = ccT[slot++];
+          });
+          compacted = true;
         }
       }
-      if (iTry == MAXTRY)
-        iFlip = 1 - iFlip;
+      if (!compacted)
+        tries(passAll, acc.ut2);
+      if (tid == 0 && !ONEWAVE) {
+        c->dbgCc[3] += wall_clock64() - dbgT1;
+        c->dbgCc[4] += dbgT1 - dbgT0;
+        c->dbgCc[5] += WIDE ? 1 : 0;
+      }
       break;
     } else {
       // ---- skip this lot (:4640-4657)
@@ -1067,6 +1323,17 @@ __device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nu
       totalThru += thruThis;
       passId++;
     }
+  }
+  if (WIDE && !gridOk) {
+    // a grid barrier timed out (never seen; the spin is bounded so that a fault cannot hang the device): no pivot, and the host is told
+    if (tid == 0) {
+      c->dcWide = -1;
+      c->sequenceIn = -1;
+      c->alpha = 0.0;
+      c->bestPossible = 0.0;
+      c->state = EXIT_NO_INCOMING;
+    }
+    return true;
   }
   if (seqIdx < 0 && lastIdx >= 0) {
     seqIdx = lastIdx;
@@ -1285,7 +1552,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_dc_working_set(Dev D, int nbClas
   }
 }
 
-__global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass)
+__global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass, int wide = 0)
 {
   Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -1302,6 +1569,15 @@ __global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass)
     }
     return;
   }
+  // wide > 0: k_dual_column_wide follows in the chain (DCW_BLOCKS workgroups): a list too long for one workgroup's registers --
+  // the working set's guard failed, or there is no working set -- is left to it instead of being walked in global memory by
+  // this one workgroup (1-3 ms at 10^5 candidates, profiles/r04_dc_probe_after.txt); wide == 2 (test knob) defers every list
+  const bool canDefer = wide > 0 && nc <= 16 * DCW_BLOCKS * DCW_THREADS;
+  if (wide == 2 && canDefer) {
+    if (tid == 0)
+      c->dcWide = 1;
+    return;
+  }
   if (nc <= DC_SMALL) {
     if (tid < 64) {
       if (nc <= 4 * 64)
@@ -1311,7 +1587,7 @@ __global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass)
     }
     return;
   }
-  __shared__ int wsIdx[DC_WS_CAP];
+  __shared__ __attribute__((aligned(16))) int wsIdx[DC_WS_CAP];  // (>= the 10.5 KB the batch compaction of dualColumnImpl borrows)
   __shared__ int s_done;
   if (nbClass <= DC_NB_MAX) {
     // the working set (candidates of breakpoint class <= J, in list order) was compacted over the whole chip by
@@ -1337,7 +1613,7 @@ __global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass)
         __syncthreads();
         ok = s_done != 0;
       } else if (ws <= DC_CPT * DC_THREADS) {
-        ok = dualColumnImpl<DC_CPT, false, true>(D, wsIdx, ws, tau);
+        ok = dualColumnImpl<DC_CPT, false, true>(D, wsIdx, ws, tau, wsIdx);
       } else {
         // 4 % of the mature-regime calls used to walk the full list of 10^5 candidates in global memory (1.1 ms each, 3 ms at worst):
         // mostly pivots whose class <= 1 set (breakpoints up to 256 theta0) was a little over 4096 candidates, so the working set
@@ -1362,10 +1638,32 @@ __global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass)
     }
   }
   if (nc <= DC_CPT * (int)blockDim.x) {
-    dualColumnImpl<DC_CPT, false>(D);
+    dualColumnImpl<DC_CPT, false>(D, nullptr, -1, 0.0, wsIdx);
+  } else if (canDefer) {
+    if (tid == 0)
+      c->dcWide = 1;
   } else {
     dualColumnImpl<0, false>(D);
   }
+}
+
+// The ratio test over DCW_BLOCKS workgroups for the lists k_dual_column left alone (c->dcWide): the candidates are dealt over
+// all threads of the launch (4 / 8 / 16 per thread, in registers), the logic is dualColumnImpl's unchanged, every pass ends in
+// one grid-wide reduction of the per-workgroup partials (dcReduceGrid) -- the blocked ratio test of the reference's parallel
+// engine (src/AbcSimplexDual.cpp:1450-1528, combine :1623-1634).  Returns at once on every other pivot.
+__global__ void __launch_bounds__(DCW_THREADS) k_dual_column_wide(Dev D)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN || c->dcWide != 1)
+    return;
+  const int nc = c->numberCandidates;
+  const int nthr = gridDim.x * blockDim.x;
+  if (nc <= 4 * nthr)
+    dualColumnImpl<4, false, false, true>(D);
+  else if (nc <= 8 * nthr)
+    dualColumnImpl<8, false, false, true>(D);
+  else
+    dualColumnImpl<16, false, false, true>(D);
 }
 
 __global__ void k_ftran_gather(Dev D, const double *v1, const double *v2, double *g1, double *g2, int iter)
