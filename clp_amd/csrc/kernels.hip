@@ -1199,35 +1199,27 @@ __device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nu
           });
           __syncthreads();
           if (threadIdx.x < 64) {
-            double ca[DC_CC], cd[DC_CC], cr[DC_CC], cq[DC_CC];
-            int ci[DC_CC], ct[DC_CC];
+            // (the batch stays in LDS: wave 0 keeps only each slot's state in registers -- the kernel is at its register limit)
+            int ct[DC_CC];
             bool cl[DC_CC];
 #pragma unroll
             for (int q = 0; q < DC_CC; q++) {
-              const int sl = lane + 64 * q;
-              const bool in = sl < total;
-              ca[q] = in ? ccA[sl] : 0.0;
-              cd[q] = in ? ccD[sl] : 0.0;
-              cr[q] = in ? ccR[sl] : 0.0;
-              cq[q] = in ? ccQ[sl] : 1.0e50;
-              ci[q] = in ? ccI[sl] : -1;
               ct[q] = passId;
-              cl[q] = in;
+              cl[q] = lane + 64 * q < total;
             }
             // One trip on the compacted batch: the swap test per lane, then the (usually one or two) swapped candidates are
-            // read out lane by lane (v_readlane) and summed in slot order by every lane alike -- the only wave-wide
-            // reduction left is the minimum over the remaining breakpoints.
-            auto rdl = [&](double v, int l) {
-              return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-            };
+            // visited in slot order by every lane alike (uniform LDS reads) -- the only wave-wide reduction left is the minimum
+            // over the remaining breakpoints.
             auto passC = [&](DcAcc &a2) {
               double utLocal = 1.0e50;
 #pragma unroll
               for (int q = 0; q < DC_CC; q++) {
-                const double value = cd[q] - upperTheta * ca[q];
-                const bool swap = cl[q] && ((ca[q] < 0.0) ? (value >= 0.0) : (value <= 0.0));
+                const int sl = min(lane + 64 * q, DC_COMPACT - 1);
+                const double alphaQ = ccA[sl], djQ = ccD[sl];
+                const double value = djQ - upperTheta * alphaQ;
+                const bool swap = cl[q] && ((alphaQ < 0.0) ? (value >= 0.0) : (value <= 0.0));
                 if (cl[q] && !swap)
-                  utLocal = fmin(utLocal, cq[q]);
+                  utLocal = fmin(utLocal, ccQ[sl]);
                 unsigned long long mask = __ballot(swap);
                 if (swap) {
                   cl[q] = false;
@@ -1236,8 +1228,9 @@ __device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nu
                 while (mask) {
                   const int l = __builtin_ctzll(mask);
                   mask &= mask - 1;
-                  const double alpha = rdl(ca[q], l), djv = rdl(cd[q], l), range = rdl(cr[q], l);
-                  const int idx = __builtin_amdgcn_readlane(ci[q], l);
+                  const int ss = l + 64 * q;  // (wave-uniform: every lane reads the same slot)
+                  const double alpha = ccA[ss], djv = ccD[ss], range = ccR[ss];
+                  const int idx = ccI[ss];
                   const double val = djv - upperTheta * alpha;
                   const double badDj = (alpha < 0.0) ? -djv - dualTolerance : djv - dualTolerance;
                   const double absAlpha = fabs(alpha);
@@ -1443,8 +1436,7 @@ __device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nu
 #define DC_CPT 8
 #define DC_THREADS 512
 #define DC_SMALL (8 * 64)
-#define DC_CPT2 16                           // candidates per thread of the large working-set form (4096 < set <= 8192)
-#define DC_WS_CAP (DC_CPT2 * DC_THREADS)
+#define DC_WS_CAP (DC_CPT * DC_THREADS)      // largest working set kept in registers
 #define DC_NB_PER 8                          // compaction blocks per thread of the class-prefix scan
 #define DC_NB_MAX (DC_NB_PER * DC_THREADS)   // beyond this many blocks (N > 1M) the working set is not used
 // One launch, 512 threads (256 VGPRs per lane available: no spills).
@@ -1612,14 +1604,11 @@ __global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass, 
         }
         __syncthreads();
         ok = s_done != 0;
-      } else if (ws <= DC_CPT * DC_THREADS) {
-        ok = dualColumnImpl<DC_CPT, false, true>(D, wsIdx, ws, tau, wsIdx);
       } else {
-        // 4 % of the mature-regime calls used to walk the full list of 10^5 candidates in global memory (1.1 ms each, 3 ms at worst):
-        // mostly pivots whose class <= 1 set (breakpoints up to 256 theta0) was a little over 4096 candidates, so the working set
-        // fell back to class 0 and the test ran past its guard (profiles/r04_dc_probe.txt).  Sixteen candidates per thread keep
-        // such a set in registers.
-        ok = dualColumnImpl<DC_CPT2, false, true>(D, wsIdx, ws, tau);
+        // (working sets beyond DC_CPT x DC_THREADS = 4096 candidates are not built: round 4 kept sets up to 8192 in registers at
+        // sixteen per thread, which made the kernel spill 464 bytes per lane into scratch -- every pass then waited on scratch
+        // traffic, 60 against 45 us per call; such pivots take a smaller class and, if its guard fails, the wide kernel)
+        ok = dualColumnImpl<DC_CPT, false, true>(D, wsIdx, ws, tau, wsIdx);
       }
       if (!ok && tid == 0)
         c->dbgDc[7] += 1 + 1000000LL * J;  // fall-backs to the full list (+ 1e6 x the class the working set had)

@@ -182,11 +182,16 @@ class OracleSimplex:
         self._start = np.ascontiguousarray(status, dtype=np.uint8).copy()
         lib().orc_set_status(self._h, self._start)
 
-    def dual(self):
+    def has_record(self):
+        """True when the next first dual() of this model would be answered from a committed record"""
+        return self._duals == 0 and os.path.exists(os.path.join(_CACHE_DIR, self._key() + ".npz"))
+
+    def dual(self, live=False):
+        """live=True: never answered from a committed record (a timing must be this machine's: bench.py's cpu_baseline)"""
         self._live()
         self._duals += 1
         first = self._duals == 1
-        if first and os.path.isdir(_CACHE_DIR):
+        if first and not live and os.path.isdir(_CACHE_DIR):
             path = os.path.join(_CACHE_DIR, self._key() + ".npz")
             if os.path.exists(path):
                 try:
@@ -262,9 +267,17 @@ class OracleSimplex:
 
     @property
     def seconds(self):
+        """wall time of the last dual() ON THIS MACHINE; a solve answered from a committed record has none (the record's clock is
+        the authoring box's: `recorded_seconds` says so explicitly)"""
         if self._rec is not None:
-            return float(self._rec["scalars"][1])
+            raise RuntimeError("OracleSimplex.seconds: this solve was answered from a committed record; use dual(live=True) to time it here, "
+                               "or recorded_seconds for the authoring box's clock")
         return lib().orc_iteration_seconds(self._h)
+
+    @property
+    def recorded_seconds(self):
+        """the authoring box's wall time of a solve answered from a committed record, else None"""
+        return float(self._rec["scalars"][1]) if self._rec is not None else None
 
     def _vec(self, fn, dtype=np.float64, size=None):
         out = np.zeros(size or (self.m + self.n), dtype=dtype)

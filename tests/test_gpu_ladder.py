@@ -2,7 +2,10 @@
 finishes -- HiGHS' serial dual simplex, presolve off, optima committed in tests/golden/ladder_optima.json by tools/ladder.py.  The engine runs in
 its DEFAULT mode (steepest edge, the reference's refactorization frequency, LU mode from 3072 basic structurals on) from the slack basis to
 status 0; the objective must equal HiGHS' to 1e-8 relative (north_star).  This is the independent pin of the whole solve -- LU mode included --
-beyond the sizes the CPU oracle can follow pivot by pivot."""
+beyond the sizes the CPU oracle can follow pivot by pivot.
+Rungs HiGHS does not finish (7 000 rows on: ten-hour limit, profiles/r04_highs_rungs_7000_10000_time_limit.jsonl) are accepted on an
+optimality certificate computed OUTSIDE the engine from the returned point (tools/kkt_certificate.py: primal and dual feasibility to 1e-7,
+duality gap to 1e-8 relative, recomputed here on every run); the committed objective of such a rung only guards against drift."""
 import json
 import os
 import time
@@ -29,6 +32,35 @@ def gpu_cls(built):
     from clp_amd.engine import ClpGpuSimplex
 
     return ClpGpuSimplex
+
+
+def _kkt_rungs():
+    if not os.path.exists(GOLD):
+        return []
+    gold = json.load(open(GOLD))
+    return sorted((k for k, v in gold.items() if v.get("highs", {}).get("objective") is None and (v.get("kkt") or {}).get("objective") is not None), key=int)
+
+
+@pytest.mark.parametrize("rung", _kkt_rungs())
+def test_rung_beyond_highs_is_certified_optimal(gpu_cls, rung):
+    from tools.kkt_certificate import certify, row_duals_from_engine
+    from tools.ladder import ladder_lp
+
+    ref = json.load(open(GOLD))[rung]["kkt"]
+    lp = ladder_lp(rung)
+    g = gpu_cls().loadProblem(lp)
+    g.set_option("pivot_rule", 1)
+    g.set_option("max_pivots", 0)
+    t0 = time.perf_counter()
+    status = -1
+    while status == -1 and time.perf_counter() - t0 < 900.0:
+        status = g.dual_steps(20000)
+    assert status == 0, f"rung {rung}: status {status} after {g.numberIterations()} pivots in {time.perf_counter() - t0:.1f} s"
+    cert = certify(lp, g.solution(), row_duals_from_engine(lp, g))
+    print(f"rung {rung}: {g.numberIterations()} pivots in {time.perf_counter() - t0:.1f} s, certificate {cert}")
+    assert cert["optimal"], cert
+    assert abs(g.objectiveValue() - cert["primal_objective"]) <= 1e-9 * abs(cert["primal_objective"])
+    assert abs(g.objectiveValue() - ref["objective"]) <= 1e-8 * abs(ref["objective"]), (g.objectiveValue(), ref["objective"])
 
 
 @pytest.mark.parametrize("rung", _rungs())

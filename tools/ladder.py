@@ -4,6 +4,7 @@ columns in [0, 100], costs in [0.1, 1], four columns per row) at sizes an indepe
 
     python tools/ladder.py highs <rung> [time limit s]   # HiGHS serial dual simplex (scipy), presolve off -> one JSON line
     python tools/ladder.py oracle <rung> [max iterations] # the CPU oracle port (steepest edge), same LP -> one JSON line
+    python tools/ladder.py engine <rung> [time limit s]   # the HIP engine (needs the MI355X) + a KKT certificate computed outside it
     python tools/ladder.py merge <files...>               # collects the lines into tests/golden/ladder_optima.json
 
 The rungs are fixed here (rows, columns, entries per column, seed); `ladder_lp(name)` is what the GPU test and bench.py build.
@@ -69,14 +70,41 @@ def run_oracle(name, max_iterations):
             "seconds": round(dt, 2), "cores": 1, "objective": float(o.objective)}
 
 
+def run_engine(name, limit):
+    """The engine in its default mode from the slack basis to status 0, and the optimality certificate of the point it returns --
+    computed by tools/kkt_certificate.py from the LP and (x, y) alone: what the ladder accepts where HiGHS does not finish."""
+    import torch  # noqa: F401
+
+    from clp_amd.engine import ClpGpuSimplex
+    from tools.kkt_certificate import certify, row_duals_from_engine
+    lp = ladder_lp(name)
+    g = ClpGpuSimplex(0).loadProblem(lp)
+    g.set_option("pivot_rule", 1)
+    g.set_option("max_pivots", 0)
+    t0 = time.perf_counter()
+    st = -1
+    while st == -1 and time.perf_counter() - t0 < float(limit):
+        st = g.dual_steps(20000)
+    dt = time.perf_counter() - t0
+    cert = certify(lp, g.solution(), row_duals_from_engine(lp, g)) if st == 0 else None
+    info = g.stats()
+    return {"rung": str(name), "m": int(lp.m), "n": int(lp.n), "nnz": int(lp.col_start[-1]), "solver": "kkt: HIP engine (default options) + KKT certificate computed outside it",
+            "status": int(st), "iterations": int(g.numberIterations()), "seconds": round(dt, 2), "objective": float(g.objectiveValue()) if st == 0 else None,
+            "refactorizations": int(info["refactorizations"]), "nucleus": int(info["nucleus"]), "certificate": cert}
+
+
 def main():
     what = sys.argv[1]
+    if what == "engine":
+        print(json.dumps(run_engine(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else 900)), flush=True)
+        return
     if what == "highs":
         print(json.dumps(run_highs(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else 3600)), flush=True)
     elif what == "oracle":
         print(json.dumps(run_oracle(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 0)), flush=True)
     elif what == "merge":
-        out = {}
+        path = os.path.join(ROOT, "tests", "golden", "ladder_optima.json")
+        out = json.load(open(path)) if os.path.exists(path) else {}
         for f in sys.argv[2:]:
             for line in open(f):
                 line = line.strip()
@@ -85,8 +113,7 @@ def main():
                 rec = json.loads(line)
                 slot = out.setdefault(rec["rung"], {"rows": RUNGS[rec["rung"]][0], "columns": RUNGS[rec["rung"]][1],
                                                     "entries_per_column": RUNGS[rec["rung"]][2], "seed": RUNGS[rec["rung"]][3]})
-                slot["oracle" if rec["solver"].startswith("oracle") else "highs"] = rec
-        path = os.path.join(ROOT, "tests", "golden", "ladder_optima.json")
+                slot["oracle" if rec["solver"].startswith("oracle") else ("kkt" if rec["solver"].startswith("kkt") else "highs")] = rec
         with open(path, "w") as f:
             json.dump(out, f, indent=1)
             f.write("\n")
