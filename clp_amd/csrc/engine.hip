@@ -311,6 +311,7 @@ struct clpgpu_context {
   // rank's records outgrow the exchange buffer
   int commMode = 2;
   int shardCandCap = 2048, shardFlipCap = 512;  // options "shard_cand_cap", "shard_flip_cap"
+  int shardGrow = 1;  // option "shard_grow": 0 = an overflow goes straight to the dense row exchange (tests)
   double *dCandSend = nullptr, *dCandRecv = nullptr, *dFlipSend = nullptr, *dFlipRecv = nullptr;
   int allocShardBuffers();
   void *comm = nullptr;
@@ -3766,11 +3767,26 @@ int clpgpu_context::whileIterating(int stepTarget)
     hipLaunchKernelGGL(k_unroll_weights, dim3(g), dim3(256), 0, stream, D);
     problemStatus = -2;
     break;
-  case EXIT_SHARD_OVERFLOW:
-    // a rank's candidate or flip records outgrew the exchange buffer (every rank sees the same headers,
-    // so all of them arrive here at the same pivot): the pivot is abandoned, the run continues with the
-    // dense row-slice exchange, and the refactorization + resync that follows recomputes every reduced
-    // cost (the non-owned ones were stale) and the basic solution
+  case EXIT_SHARD_OVERFLOW: {
+    // a rank's candidate or flip records outgrew the exchange buffer (every rank sees the same headers, so all of them arrive
+    // here at the same pivot): the pivot is abandoned and the refactorization + resync that follows recomputes every reduced
+    // cost (the non-owned ones were stale) and the basic solution.  First the buffers grow -- once, to what a shard can ever
+    // need: every column of the shard a candidate (in the mature regime of config 4 half of them are: 12 500 per rank at
+    // eight ranks against the start-up buffer of 2048), a quarter of them flips -- and the list exchange carries on; only
+    // if the full-size buffers overflow too (they cannot) or cannot be had does the run continue with the dense row exchange.
+    const int fullCand = std::max(shardChunk, 256), fullFlip = std::max(shardChunk / 4, 512);
+    if (commMode == 2 && shardGrow && (shardCandCap < fullCand || shardFlipCap < fullFlip)) {
+      shardCandCap = std::max(shardCandCap, fullCand);
+      shardFlipCap = std::max(shardFlipCap, fullFlip);
+      dropGraph();
+      if (!allocShardBuffers()) {
+        if (logLevel > 0)
+          fprintf(stderr, "clpgpu: rank %d: exchange buffer overflow at iteration %d, buffers grown to %d candidates / %d flips per rank\n", rank,
+                  numberIterations, shardCandCap, shardFlipCap);
+        problemStatus = -2;
+        break;
+      }
+    }
     commMode = 1;
     D.firstColumn = 0;
     D.lastColumn = n;
@@ -3781,6 +3797,7 @@ int clpgpu_context::whileIterating(int stepTarget)
       fprintf(stderr, "clpgpu: rank %d: exchange buffer overflow at iteration %d, falling back to the dense row exchange\n", rank, numberIterations);
     problemStatus = -2;
     break;
+  }
   case EXIT_BAD_UPDATE: {
     // updateStatus == 2 (:1618-1659)
     hipLaunchKernelGGL(k_unroll_weights, dim3(g), dim3(256), 0, stream, D);
@@ -4830,6 +4847,7 @@ clpgpu_context *clpgpu_clone(const clpgpu_context *src)
   ctx->rowPriceFrac = src->rowPriceFrac;
   ctx->priceLds = src->priceLds;
   ctx->dcWide = src->dcWide;
+  ctx->shardGrow = src->shardGrow;
   ctx->priceLdsMinWindows = src->priceLdsMinWindows;
   ctx->priceLdsGridCap = src->priceLdsGridCap;
   ctx->sellWindows = src->sellWindows;
@@ -5164,6 +5182,8 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
       return ctx->buildSell();
     }
   }
+  else if (!strcmp(name, "shard_grow"))
+    ctx->shardGrow = v != 0.0;
   else if (!strcmp(name, "dc_wide")) {
     if ((int)v != ctx->dcWide)
       ctx->dropGraph();
@@ -5597,6 +5617,8 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
   stats->exits_alpha_check = ctx->exitAlphaCheck;
   stats->exits_backwards = ctx->exitBackwards;
   stats->exits_bad_update = ctx->exitBadUpdate;
+  stats->comm_mode = ctx->commActive ? ctx->commMode : 0;
+  stats->shard_cand_cap = ctx->shardCandCap;
   stats->nucleus_capacity = ctx->kcap;
   stats->refreshes = ctx->numberRefreshes;
   stats->refreshes_rejected = ctx->numberRefreshesRejected;

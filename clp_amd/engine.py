@@ -36,7 +36,7 @@ class Stats(C.Structure):
                 ("accuracy_restores", C.c_long), ("singular_restores", C.c_long),
                 ("price_form", C.c_long), ("dense_pi_launches", C.c_long), ("price_form_switches", C.c_long),
                 ("exits_scheduled", C.c_long), ("exits_alpha_check", C.c_long), ("exits_backwards", C.c_long),
-                ("exits_bad_update", C.c_long)]
+                ("exits_bad_update", C.c_long), ("comm_mode", C.c_long), ("shard_cand_cap", C.c_long)]
 
 
 # every symbol include/clpgpu.h declares (tests/test_abi.py checks the library exports all of them)
@@ -487,7 +487,8 @@ class VirtualRanks:
     """N loopback ranks on one GPU (include/clpgpu.h, clpgpu_virtual_*): the column-sharded engine with real rank
     offsets, the exchanges done by device-to-device copies.  `engines[r]` is rank r's ClpGpuSimplex."""
 
-    def __init__(self, lp, nranks, configure=None, device=0):
+    def __init__(self, lp, nranks, configure=None, device=0, preconfigure=None):
+        """configure(e) runs on every rank's engine after its LP is loaded, preconfigure(e) before (layout options)"""
         L = lib()
         L.clpgpu_virtual_group_create.restype = C.c_void_p
         L.clpgpu_virtual_group_create.argtypes = [C.c_int]
@@ -499,7 +500,10 @@ class VirtualRanks:
             raise RuntimeError("clpgpu_virtual_group_create failed")
         self.engines = []
         for r in range(nranks):
-            e = ClpGpuSimplex(device).loadProblem(lp)
+            e = ClpGpuSimplex(device)
+            if preconfigure:
+                preconfigure(e)
+            e.loadProblem(lp)
             if configure:
                 configure(e)
             rc = L.clpgpu_virtual_attach(e._h, self._g, r)

@@ -78,6 +78,9 @@ typedef struct {
   long exits_alpha_check;   /* btran / ftran alpha disagreed */
   long exits_backwards;     /* objective going backwards */
   long exits_bad_update;    /* the basis update reported a singular pivot */
+  /* column-sharded runs */
+  long comm_mode;           /* 0 not sharded, 2 candidate / flip lists exchanged, 1 dense row slices (the fall-back) */
+  long shard_cand_cap;      /* candidates per rank the exchange buffer holds now (grown once on overflow) */
 } clpgpu_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------- */

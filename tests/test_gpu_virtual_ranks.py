@@ -83,31 +83,61 @@ def test_virtual_ranks_in_lu_mode_match_unsharded(gpu, nranks):
         assert np.array_equal(e.solution(), base.solution())
 
 
-def test_virtual_ranks_overflow_fallback_agrees(gpu):
-    """exchange buffers far too small: every rank sees the overflow at the same pivot, all fall back to the dense
-    row-slice exchange together and reach the unsharded optimum"""
+@pytest.mark.parametrize("grow,lu", [(1, 0), (0, 0), (0, 1)])
+def test_virtual_ranks_overflow_agrees(gpu, grow, lu):
+    """exchange buffers far too small: every rank sees the overflow at the same pivot.  Default (shard_grow 1): the buffers grow
+    to the shard's size and the list exchange carries on; shard_grow 0: all ranks fall back to the dense row-slice exchange
+    together -- also in LU mode, where the windowed SELL copy moves its window base with the fall-back.
+    Either way every rank makes the same pivots and reaches the unsharded optimum."""
     lp = P.sparse_lp(2000, 9000, 12, seed=13)
+
+    def conf(e, **opts):
+        configure(e, **opts)
+        if lu:
+            e.set_option("factor_mode", -1)
+            e.set_option("lu_min_k", 256)
+
     base = gpu.ClpGpuSimplex(0).loadProblem(lp)
-    configure(base)
+    conf(base)
     assert base.dual() == 0
-    vr = gpu.VirtualRanks(lp, 4, configure=lambda e: configure(e, shard_cand_cap=4, shard_flip_cap=2))
+    vr = gpu.VirtualRanks(lp, 4, configure=lambda e: conf(e, shard_cand_cap=4, shard_flip_cap=2, shard_grow=grow))
     assert vr.dual_steps(-1) == [0, 0, 0, 0]
     its = {e.numberIterations() for e in vr.engines}
     assert len(its) == 1
     for e in vr.engines:
+        st = e.stats()
+        assert st["comm_mode"] == (2 if grow else 1), st["comm_mode"]
+        assert (st["shard_cand_cap"] >= 2000) == bool(grow)
         assert abs(e.objectiveValue() - base.objectiveValue()) <= 1e-9 * abs(base.objectiveValue())
 
 
-def test_virtual_ranks_full_size(gpu):
-    """config 5 in miniature: the 50 000 x 200 000 LP of config 4, columns sharded over 8 loopback ranks, first 300
-    pivots against the unsharded engine"""
+def test_virtual_ranks_full_size_from_the_mature_basis(gpu):
+    """config 5 in miniature, in the regime a solve of this LP lives in: the 50 000 x 200 000 LP of config 4 warm-started from the
+    committed mature basis (nucleus 10 514, LU mode, ~10^5 candidates per pivot = 12 500 per rank), columns sharded over 8
+    loopback ranks, 200 pivots against the unsharded engine: identical pivots on every rank, identical solution bits, the
+    list exchange still on (buffers sized for the shard: no overflow, no extra resync)."""
+    import os
+
     lp = P.sparse_lp()
+    status = (np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "basis_sparse_30000.npy")) & 7).astype(np.uint8)
+
+    def conf(e, **opts):
+        e.set_option("pivot_rule", 1)
+        e.set_option("max_pivots", 0)
+        for k, v in opts.items():
+            e.set_option(k, v)
+        e.setStatusArray(status)
+
     base = gpu.ClpGpuSimplex(0).loadProblem(lp)
-    configure(base)
-    base.dual_steps(300)
-    vr = gpu.VirtualRanks(lp, 8, configure=lambda e: configure(e, shard_cand_cap=8192, shard_flip_cap=2048))
-    assert vr.dual_steps(300) == [-1] * 8
+    conf(base)
+    assert base.dual_steps(200) == -1
+    assert base.stats()["lu_active"] == 1
+    # (the ranks' shards are 98 windows wide: below the width the LDS pricing form is laid out for -- not built at the full-width load either)
+    vr = gpu.VirtualRanks(lp, 8, configure=lambda e: conf(e, shard_cand_cap=32768, shard_flip_cap=8192), preconfigure=lambda e: e.set_option("price_lds", 0))
+    assert vr.dual_steps(200) == [-1] * 8
     ref = base.pivotLog()
     for r, e in enumerate(vr.engines):
-        assert same_pivots(e.pivotLog(), ref, 300), f"rank {r}"
+        st = e.stats()
+        assert st["lu_active"] == 1 and st["comm_mode"] == 2, f"rank {r}"
+        assert same_pivots(e.pivotLog(), ref, 200), f"rank {r}"
         assert np.array_equal(e.solution(), base.solution())
