@@ -937,6 +937,10 @@ void clpgpu_context::releaseProblem()
   for (void *p : allocations)
     (void)hipFree(p);
   allocations.clear();
+  sellBuffers.clear();  // (they were among the allocations; a stale entry could name a later allocation's address)
+  jdsReady = false;
+  priceMode = 0;
+  modePriced = modeDense = 0.0;
   for (DBuf &b : luBuf) {
     if (b.p)
       (void)hipFree(b.p);
