@@ -3284,8 +3284,10 @@ __device__ __forceinline__ void plLoadHalf(PlHalf &h, const unsigned *__restrict
   }
 }
 
-__device__ __forceinline__ double plConsumeHalf(const PlHalf &h, const double *piTile, int cnt, int t0, double acc, unsigned zero)
+__device__ __forceinline__ double plConsumeHalf(const PlHalf &h, const double *piTile, int cnt, int t0, double acc, unsigned zero, int maxCnt)
 {
+  if (t0 >= maxCnt)  // wave-uniform: a padding half (the tile's steps are rounded up to the ring), nothing to add
+    return acc;
   double pa[PL_HP], pb[PL_HP];
 #pragma unroll
   for (int u = 0; u < PL_HP; u++) {
@@ -3309,6 +3311,8 @@ __global__ void __launch_bounds__(PL_THREADS) k_price_lds(Dev D, int countCols)
     return;
   extern __shared__ __attribute__((aligned(16))) unsigned char plSmem[];
   constexpr int NW = PL_THREADS / 64, NQ = PL_THREADS / 256, RING = 4 * PL_HP;
+  // (read now: behind the memory-clobbering barriers below these loads would sit, unhidden, in front of the write-out)
+  const double zeroTolerance = c->zeroTolerance, dualT = -c->dualTolerance, acceptablePivot = c->acceptablePivot;
   const int tileRows = D.jdsTileRows, T = D.jdsTiles;
   const int tileBytes = tileRows * 8 + 16;  // + the permanent zero behind the tile
   const unsigned zero = (unsigned)tileRows;
@@ -3326,16 +3330,6 @@ __global__ void __launch_bounds__(PL_THREADS) k_price_lds(Dev D, int countCols)
   const unsigned ldsBase = (unsigned)(size_t)(pl_lds_byte *)plSmem;
   if (tid == 0)
     *(double *)(plSmem + (size_t)tileRows * 8) = 0.0;
-  if (blockIdx.x == 0 && wv == 0) {
-    // how many pivots had a dense pi: the host chooses between this kernel and k_price_sell (+ by-row form) by it
-    int pop = 0;
-    for (int w = (int)lane; w < ((D.m + 63) >> 6); w += 64)
-      pop += __popcll(D.piBits[w]);
-    for (int o = 32; o > 0; o >>= 1)
-      pop += __shfl_xor(pop, o);
-    if (lane == 0 && 12LL * pop >= (long long)D.m)
-      D.ctrl->statDensePi += 1.0;
-  }
   // a workgroup takes four windows at a time (one per wave quad); more than 4 * gridDim.x windows: further rounds
   for (int window0 = (int)blockIdx.x; window0 < D.jdsWindows; window0 += 4 * (int)gridDim.x) {
     const int window = window0 + (int)gridDim.x * quad;
@@ -3354,6 +3348,13 @@ __global__ void __launch_bounds__(PL_THREADS) k_price_lds(Dev D, int countCols)
     PlHalf H0, H1;
     plLoadHalf(H0, D.jdsRowPair, D.jdsElemPair, cntCur, 0, off, lane);
     plLoadHalf(H1, D.jdsRowPair, D.jdsElemPair, cntCur, 2 * PL_HP, off, lane);
+    // what the write-out needs of this lane's home column, requested now (a chain of three dependent loads -- home position /
+    // column key -> status -> reduced cost -- at the tail of the kernel would add its full latency to the launch)
+    const int homePos = live ? (int)D.jdsHome[(size_t)slice * 64 + lane] : (int)lane;
+    const int j = live ? D.jdsCol[(size_t)slice * 64 + lane] : -1;
+    const int wanted = j >= 0 ? (D.status[j] & 3) - 1 : 0;
+    const double djHome = j >= 0 ? D.dj[j] : 0.0;
+    const int lenHome = j >= 0 ? D.sellLen[(size_t)slice * 64 + lane] : 0;
     double acc = 0.0;
     for (int tau = 0; tau < T; tau++) {
       // ---- pi tile tau into LDS
@@ -3377,11 +3378,11 @@ __global__ void __launch_bounds__(PL_THREADS) k_price_lds(Dev D, int countCols)
         const int cntL = more ? cntCur : cntNext, tL = more ? t0 + RING : 0;
         // (the scheduling barriers pin the issue order consume / refill / consume / refill: the loads of a refill stay
         // in flight while the other half is consumed)
-        acc = plConsumeHalf(H0, piTile, cntCur, t0, acc, zero);
+        acc = plConsumeHalf(H0, piTile, cntCur, t0, acc, zero, maxCur);
         __builtin_amdgcn_sched_barrier(0);
         plLoadHalf(H0, D.jdsRowPair, D.jdsElemPair, cntL, tL, off, lane);
         __builtin_amdgcn_sched_barrier(0);
-        acc = plConsumeHalf(H1, piTile, cntCur, t0 + 2 * PL_HP, acc, zero);
+        acc = plConsumeHalf(H1, piTile, cntCur, t0 + 2 * PL_HP, acc, zero, maxCur);
         __builtin_amdgcn_sched_barrier(0);
         plLoadHalf(H1, D.jdsRowPair, D.jdsElemPair, cntL, tL + 2 * PL_HP, off, lane);
         __builtin_amdgcn_sched_barrier(0);
@@ -3395,31 +3396,24 @@ __global__ void __launch_bounds__(PL_THREADS) k_price_lds(Dev D, int countCols)
       }
     }
     // ---- back to the home order of the slice; fused first ratio pass (ClpPackedMatrix.cpp:1799-1993) as in priceSellBody
-    int j = -1;
-    double value = 0.0;
-    if (live) {
-      value = __shfl(acc, (int)D.jdsHome[(size_t)slice * 64 + lane]);
-      j = D.jdsCol[(size_t)slice * 64 + lane];
-    }
+    double value = __shfl(acc, homePos);
     int flag = 0;
     double ratio = 1.0e31, bytes = 0.0;
     if (j >= 0) {
-      const int wanted = (D.status[j] & 3) - 1;
       if (wanted) {
         // SURVEY 8d's B_col for the scanned column: 12 B per entry + colStart; + 20 per emitted nonzero
-        bytes = 12.0 * (double)D.sellLen[(size_t)slice * 64 + lane] + 4.0;
-        if (fabs(value) > c->zeroTolerance) {
+        bytes = 12.0 * (double)lenHome + 4.0;
+        if (fabs(value) > zeroTolerance) {
           bytes += 20.0;
           if (wanted > 0) {
             const double mult = (wanted == 1) ? -1.0 : 1.0;
             const double alpha = value * mult;
             if (alpha > 0.0) {
-              const double dualT = -c->dualTolerance;
-              const double oldValue = D.dj[j] * mult;
+              const double oldValue = djHome * mult;
               const double v2 = oldValue - 1.0e15 * alpha;
               if (v2 < dualT) {
                 flag = 1;
-                if (alpha >= c->acceptablePivot)
+                if (alpha >= acceptablePivot)
                   ratio = (oldValue - dualT) / alpha;
               }
             }
@@ -3466,8 +3460,20 @@ __global__ void __launch_bounds__(PL_THREADS) k_price_lds(Dev D, int countCols)
       }
     }
   }
-  if (blockIdx.x == 0 && tid == 0)
-    D.ctrl->lastPriceByRow = 0;
+  if (blockIdx.x == gridDim.x - 1 && wv == NW - 1) {
+    // how many pivots had a dense pi: the host chooses between this kernel and k_price_sell (+ by-row form) by it.  (Counted by the
+    // wave most likely to have had no window, after its work: at the head of workgroup 0 these loads delayed the whole launch.)
+    int pop = 0;
+    for (int w = (int)lane; w < ((D.m + 63) >> 6); w += 64)
+      pop += __popcll(D.piBits[w]);
+    for (int o = 32; o > 0; o >>= 1)
+      pop += __shfl_xor(pop, o);
+    if (lane == 0) {
+      if (12LL * pop >= (long long)D.m)
+        D.ctrl->statDensePi += 1.0;
+      D.ctrl->lastPriceByRow = 0;
+    }
+  }
 }
 
 __global__ void __launch_bounds__(256) k_price_sell(Dev D, int variant, int countCols = 0, int nSellBlocks = 1 << 30, int nColBlocks = 1 << 30,

@@ -184,11 +184,14 @@ __device__ __forceinline__ void loadHalf(Half<HP> &h, const unsigned *__restrict
 // `zero` = index of a permanent 0.0 behind the pi tile: a step without an entry multiplies its (finite) element by it, and
 // adding +-0.0 leaves the running sum as it is (the sum starts from +0.0 and can never become -0.0), so the chain of
 // dependent operations per step is one add
-template <int HP> __device__ __forceinline__ double consumeHalf(const Half<HP> &h, const double *piTile, int cnt, int t0, double acc, unsigned zero)
+template <int HP, bool SKIP = false>
+__device__ __forceinline__ double consumeHalf(const Half<HP> &h, const double *piTile, int cnt, int t0, double acc, unsigned zero, int maxCnt = 1 << 30)
 {
   constexpr int Q = (HP % 4 == 0) ? 4 : ((HP % 3 == 0) ? 3 : HP);
 #pragma unroll
   for (int q0 = 0; q0 < HP; q0 += Q) {
+    if (SKIP && t0 + 2 * q0 >= maxCnt)  // wave-uniform: no lane holds an entry from this step on
+      break;
     double pa[Q], pb[Q];
 #pragma unroll
     for (int u = 0; u < Q; u++) {
@@ -316,7 +319,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_v1(PlDev P)
         for (int u = 0; u < HP; u++)
           acc += H0.e[u].x + H0.e[u].y + (double)H0.r[u];
       } else
-        acc = consumeHalf<HP>(H0, piTile, cntCur, t0, acc, zero);
+        acc = consumeHalf<HP, (DBG & 16) != 0>(H0, piTile, cntCur, t0, acc, zero, maxCur);
       __builtin_amdgcn_sched_barrier(0);
       if (!(DBG & 2))
         loadHalf<HP>(H0, P.rowPair, P.elemPair, cntL, tL, off, lane);
@@ -326,7 +329,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_v1(PlDev P)
         for (int u = 0; u < HP; u++)
           acc += H1.e[u].x + H1.e[u].y + (double)H1.r[u];
       } else
-        acc = consumeHalf<HP>(H1, piTile, cntCur, t0 + 2 * HP, acc, zero);
+        acc = consumeHalf<HP, (DBG & 16) != 0>(H1, piTile, cntCur, t0 + 2 * HP, acc, zero, maxCur);
       __builtin_amdgcn_sched_barrier(0);
       if (!(DBG & 2))
         loadHalf<HP>(H1, P.rowPair, P.elemPair, cntL, tL + 2 * HP, off, lane);
@@ -780,6 +783,10 @@ int main(int argc, char **argv)
   }
       L(1024, 4, 1, 2, 9, 0)
       L(1024, 2, 1, 2, 9, 0)
+      L(1024, 2, 1, 2, 9, 16)
+      L(1024, 3, 1, 2, 9, 0)
+      L(512, 2, 1, 2, 9, 0)
+      L(512, 2, 1, 2, 9, 16)
       L(1024, 4, 1, 2, 9, 1)
       L(1024, 4, 1, 2, 9, 2)
       L(1024, 4, 1, 2, 9, 4)
@@ -822,10 +829,10 @@ int main(int argc, char **argv)
   const int rows3 = (cdiv(m, 3) + 127) & ~127;  // three tiles, one buffer
   const int rows6 = (cdiv(m, 6) + 127) & ~127;  // six tiles, two buffers
   runV1(1024, 4, 1, 2, rows3, 98);   // an empty kernel with the same launch configuration: what the event pair itself costs
-  runV1(1024, 4, 1, 2, rows3, 99);   // the same bytes as plain streams
-  runV1(1024, 4, 1, 2, rows3);       // everything
-  runV1(1024, 2, 1, 2, rows3);
-  runV1(1024, 4, 1, 2, rows3, 0, 196);  // 196 workgroups of exactly four windows (60 CUs idle) instead of 256 of three or four
-  runV1(1024, 2, 1, 2, rows3, 0, 196);
+  runV1(1024, 2, 1, 2, rows3, 0, 196);   // the product's configuration
+  runV1(1024, 2, 1, 2, rows3, 16, 196);  // + steps no lane holds are not consumed
+  runV1(1024, 3, 1, 2, rows3, 0, 196);
+  runV1(512, 2, 1, 2, rows6, 0, 391);    // two 512-thread workgroups per CU, six tiles of 8 448 rows (72 KB of LDS each)
+  runV1(512, 2, 1, 2, rows6, 16, 391);
   return 0;
 }

@@ -34,3 +34,6 @@ s1 = g.stats()
 print("PROBE %d pivots in %.3f s = %.1f it/s; LU factorizations %d: host front %.0f ms, tail inversion %.0f ms, build %.0f ms; refactorizations %d; nucleus %d tail %d; objective %.6f" % (
     N, dt, N / dt, s1["lu_factorizations"] - s0["lu_factorizations"], s1["lu_front_ms"] - s0["lu_front_ms"], s1["lu_invert_ms"] - s0["lu_invert_ms"],
     s1["lu_build_ms"] - s0["lu_build_ms"], s1["refactorizations"] - s0["refactorizations"], s1["nucleus"], s1["lu_tail"], g.objectiveValue()))
+print("PROBE what sent the loop to its status checks: scheduled (eta file / forced) %d, alpha check %d, objective backwards %d, bad update %d; pricing form LDS %d (%d switches)" % (
+    s1["exits_scheduled"] - s0["exits_scheduled"], s1["exits_alpha_check"] - s0["exits_alpha_check"], s1["exits_backwards"] - s0["exits_backwards"],
+    s1["exits_bad_update"] - s0["exits_bad_update"], s1["price_form"], s1["price_form_switches"]))
