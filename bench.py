@@ -385,7 +385,7 @@ def main():
         # side is the COMMITTED RECORD of exactly this solve (tests/golden/oracle_cache, the one tests/test_gpu_mature_parity.py
         # compares pivot by pivot) with the authoring box's clock, said so; --cpu-mature-live times it on this box instead.
         # The engine's side is timed here either way, over the same 400 pivots, and must make the same pivots.
-        if basis is not None:
+        if basis is not None and len(basis) == lp.m + lp.n:
             om = OracleSimplex(lp)
             om.set_option("pivot_rule", args.pivot_rule)
             om.set_option("max_pivots", 0)

@@ -86,3 +86,15 @@ def test_bench_line_shape(monkeypatch, mature):
     first = 30 + 8 + 1 if mature else 8 + 1
     assert d["config"]["pivot_window"] == [first, first + 39]
     assert (d["slack_start"] is not None) == mature
+
+
+def test_gpus_without_a_launcher_is_refused(monkeypatch):
+    """`python bench.py --gpus 8` with no torch.distributed launcher behind it used to run on one GPU and print n_gpus 1: it must
+    stop with the launch line instead (one process per GPU; WORLD_SIZE is what the launcher provides)."""
+    import bench
+
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "torch.distributed.run" in str(e.value) and "--nproc-per-node 8" in str(e.value)

@@ -30,6 +30,15 @@ def test_recorded_solve_equals_live_solve(tmp_path, monkeypatch):
         assert np.array_equal(getattr(live, name)(), getattr(again, name)()), name
     assert np.array_equal(live.row_weights()[0], again.row_weights()[0]) and np.array_equal(live.row_weights()[1], again.row_weights()[1])
     assert (live.iterations, live.refactorizations, live.objective) == (again.iterations, again.refactorizations, again.objective)
+    # a recorded solve has no clock of this machine: `seconds` refuses, `recorded_seconds` names the authoring box's; live=True solves here
+    import pytest
+
+    with pytest.raises(RuntimeError):
+        again.seconds
+    assert again.recorded_seconds is not None and live.recorded_seconds is None and live.seconds >= 0.0
+    timed = O.OracleSimplex(lp)
+    timed.set_option("pivot_rule", 1)
+    assert timed.has_record() and timed.dual(live=True) == code and timed._rec is None and timed.seconds >= 0.0
     # another option set is another solve: no record, and it is written
     other, _ = solve(max_pivots=7)
     assert other._rec is None and len(os.listdir(tmp_path)) == 2
