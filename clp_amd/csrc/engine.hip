@@ -224,7 +224,7 @@ struct clpgpu_context {
   // product-form eta file between refactorizations.  Option "factor_mode": 0 = explicit inverse of the whole
   // nucleus (rank-1 updated), 1 = LU, -1 (default) = LU from "lu_min_k" basic structurals on (sparse LPs, one GPU).
   int factorMode = -1, luMinK = 3072, luMaxPivots = 2000, luMinTail = 16;
-  double luStopDensity = 0.012, luThreshold = 0.1;
+  double luStopDensity = 0.03, luThreshold = 0.1;  // (0.012 until round 5: profiles/r05_stop_density_probe.txt)
   bool luActive = false, luSlotsCleared = false;
   LuFront luF;
   LuDev hLu = {};

@@ -4,7 +4,8 @@ the 50 000 x 200 000 LP), forms the nucleus (basic structurals x rows whose slac
 (clp_amd/csrc/lu_front.h through tests/host/lu_front_harness.cpp) at several stop densities, and factors the remaining tail with SuperLU under
 three orderings to see what a sparse factorization of it would cost in fill.  Output kept as profiles/r04_tail_fill_study.txt.
 
-    python tools/tail_fill_study.py [--full]       # --full also runs the front with no density stop (about 7 minutes of host time)"""
+    python tools/tail_fill_study.py [--full]       # --full also runs the front with no density stop (about 7 minutes of host time)
+    python tools/tail_fill_study.py --netlib <basis.npy>   # the same study on the Netlib-shaped variant (power-law column counts, tools/dump_basis.py netlib N)"""
 import os
 import struct
 import subprocess
@@ -28,15 +29,19 @@ def main():
     work = tempfile.mkdtemp(prefix="tailfill")
     exe = os.path.join(work, "harness")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "host", "lu_front_harness.cpp")])
-    lp = P.sparse_lp(50000, 200000, 50)
-    status = np.load(os.path.join(ROOT, "tests", "golden", "basis_sparse_30000.npy")).astype(np.uint8) & 7
+    if "--netlib" in sys.argv:
+        lp = P.netlib_shaped_lp()
+        status = np.load(sys.argv[sys.argv.index("--netlib") + 1]).astype(np.uint8) & 7
+    else:
+        lp = P.sparse_lp(50000, 200000, 50)
+        status = np.load(os.path.join(ROOT, "tests", "golden", "basis_sparse_30000.npy")).astype(np.uint8) & 7
     m, n = lp.m, lp.n
     A = sp.csc_matrix((lp.elem, lp.row, lp.col_start), shape=(m, n))
     columns, rows = np.flatnonzero(status[:n] == 1), np.flatnonzero(status[n:] != 1)
     k = len(columns)
     C = A[:, columns][rows, :].tocsc()
     C.sort_indices()
-    print(f"basis after 30 000 pivots: {k} basic structurals, {m - k} basic slacks; nucleus {k} x {k}, {C.nnz} nonzeros ({C.nnz / k:.1f} per column)")
+    print(f"basis ({'Netlib-shaped variant' if '--netlib' in sys.argv else 'config 4 after 30 000 pivots'}): {k} basic structurals, {m - k} basic slacks; nucleus {k} x {k}, {C.nnz} nonzeros ({C.nnz / k:.1f} per column)")
     src, dst = os.path.join(work, "C.bin"), os.path.join(work, "F.bin")
     with open(src, "wb") as o:
         o.write(struct.pack("qq", k, C.nnz))
