@@ -332,3 +332,25 @@ def test_lds_pricing_engine_runs_match_plain(gpu_cls):
     assert st[0]["price_form"] == 1 and st[2]["price_form"] == 0 and st[2]["price_form_switches"] == 0
     print({k: st[1][k] for k in ("price_form", "price_form_switches", "dense_pi_launches", "iterations")})
     assert st[1]["price_form_switches"] >= 1 and st[1]["dense_pi_launches"] > 100, st[1]  # (pi is dense on ~400 of these 6000 pivots)
+
+
+def test_lds_pricing_with_long_columns(gpu_cls):
+    """Power-law column counts: the columns longer than SELL_LONG = 128 entries stay outside the SELL windows and keep their own
+    workgroups (priceLongBody), launched beside k_price_lds when the chain prices with pi in LDS.  The same 2 500 pivots with the
+    LDS form on every pivot and never: identical pivots and solution bits."""
+    lp = P.netlib_shaped_lp(4500, 9000, 150000, seed=23)
+    assert (np.diff(lp.col_start) > 128).sum() >= 10, "instance no longer has long columns"
+    runs = []
+    for mode in (2, 0):
+        g = gpu_cls()
+        g.set_option("price_lds_min_windows", 1)
+        g.set_option("price_lds", mode)
+        g.loadProblem(lp)
+        g.set_option("pivot_rule", 1)
+        g.set_option("factor_mode", 0)
+        g.dual_steps(2500)
+        runs.append(g)
+    assert runs[0].stats()["price_form"] == 1 and runs[1].stats()["price_form"] == 0
+    a, b = runs[0].pivotLog(), runs[1].pivotLog()
+    assert len(a) == len(b) and np.array_equal(a["sequenceIn"], b["sequenceIn"]) and np.array_equal(a["sequenceOut"], b["sequenceOut"])
+    assert np.array_equal(runs[0].solution(), runs[1].solution())
