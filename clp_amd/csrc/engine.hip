@@ -1291,7 +1291,10 @@ int clpgpu_context::buildJds(const std::vector<int> &order, int numSlices)
   rc |= h2d(dEp, elemPair.data(), elemPair.size());
   rc |= sync();
   priceLdsBytes = ((size_t)tileRows * 8 + 16 + (PL_THREADS / 256) * 256 * 9 + (PL_THREADS / 64) * 20 + 15) & ~(size_t)15;
-  if (rc || hipFuncSetAttribute((const void *)k_price_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)priceLdsBytes) != hipSuccess) {
+  // (the attribute belongs to the kernel, not to this context: always the largest tile any context can ask for, so that a
+  // second, smaller LP loaded in the same process does not lower it under a first one's launches)
+  const size_t ldsMax = ((size_t)PL_MAX_TILE_ROWS * 8 + 16 + (PL_THREADS / 256) * 256 * 9 + (PL_THREADS / 64) * 20 + 15) & ~(size_t)15;
+  if (rc || hipFuncSetAttribute((const void *)k_price_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsMax) != hipSuccess) {
     (void)hipGetLastError();
     return rc;
   }
