@@ -347,6 +347,21 @@ def main():
                     traffic_source = f"profiles/{name} (committed rocprofv3 --pmc summary of the default bench line; live pass unavailable: {why})"
                     break
     moved = traffic / per_launch_s / 1e9 if (traffic and per_launch_s > 0) else None
+    # the committed rocprofv3 summary of this command (profiles/, tools/closing_bench.sh): the kernel's own duration, without the
+    # event pair and the eager launch gap the live figure above includes (an empty kernel of k_price_lds' launch shape costs 6 us there)
+    profile_ref = None
+    if default_workload:
+        for name in ("r05_bench_kernel_stats.txt",):
+            path = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(path):
+                for line in open(path):
+                    m_ = re.match(r"\s*clpgpu::(k_price_lds|k_price_sell)\(.*?\)\s+(\d+)\s+(\d+)\s+([0-9.]+)", line)
+                    if m_ and m_.group(1) in " ".join(price_names):
+                        us = float(m_.group(4))
+                        profile_ref = {"file": f"profiles/{name}", "kernel": m_.group(1), "launches": int(m_.group(2)), "avg_us": us,
+                                       "frac_on_the_live_bytes": (per_launch_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS) if us > 0 else None,
+                                       "note": "rocprofv3 --kernel-trace --stats of `python bench.py --cpu-iterations 0 --pmc off --tto-budget 0 --ladder-budget 0` on the MI355X, committed"}
+                        break
 
     # ---- CPU baseline: the oracle over >= 500 pivots and >= 2 s of the same LP, and the engine over the same pivots
     cpu = same_window = clp = None
@@ -565,7 +580,8 @@ def main():
                     "engine_seconds": round(t3, 3) if stl == 0 else None, "engine_iterations": int(el.numberIterations()),
                     "engine_iterations_per_s": round(el.numberIterations() / max(t3, 1e-9), 1), "objective": obj,
                     "independent_check": "KKT certificate computed outside the engine (tools/kkt_certificate.py): HiGHS hit its ten-hour limit on this rung",
-                    "certificate": cert, "certified_optimal": bool(cert and cert["optimal"]),
+                    "certificate": cert, "certified_optimal": bool(cert and cert["optimal"]) if stl == 0 else None,
+                    "note": None if stl == 0 else "not finished within the ladder budget (100-270 s on the MI355X depending on the trajectory: python tools/ladder.py engine 7000)",
                     "committed_objective": kkt_ref["objective"],
                     "objective_matches_committed": bool(stl == 0 and abs(obj - kkt_ref["objective"]) <= 1e-8 * abs(kkt_ref["objective"])),
                     "nucleus_at_end": int(el.stats()["nucleus"])})
@@ -653,6 +669,7 @@ def main():
                                            "+ lists; SURVEY 8d's B_col = 12 nnz(A_J) + ... is the unconditional form"),
                          "replay_identical": bool(same_pivots and same_pivots_col),
                          "row_pricing": row_pricing,
+                         "rocprofv3_reference": profile_ref,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "moved": moved, "moved_frac": (moved / HBM_PEAK_GBS) if moved else None,
                          "per_kernel_us": per_kernel_us,
