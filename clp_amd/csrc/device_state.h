@@ -87,7 +87,7 @@ struct Ctrl {
   long long dbgDc[8];
   int pendingState, pendingPad;  // stepped run: what housekeeping decided on the pivot the step limit stopped at (RUN or EXIT_REFACTOR); acted on when the run resumes
   int wsJ, wsCount;  // ratio test: breakpoint class prefix of the working set k_dc_working_set compacted, and its size (wsJ < 0: none)  // ratio test, working-set path: calls, ticks of the whole kernel, ticks before the passes start, max ticks of one call
-  long long dbgCc[6];  // development counters of the ratio test's final batch: compacted calls, too large to compact, sum of batch sizes, ticks of the trips, ticks of the coarse passes, wide calls
+  long long dbgCc[8];  // development counters of the ratio test's final batch: compacted calls, too large to compact, sum of batch sizes, ticks of the trips, ticks of the coarse passes, wide calls
   int dcArrive, dcWide;  // k_dual_column_wide: grid-barrier arrivals of this pivot; 1 = this pivot's ratio test was left to it, -1 = a barrier timed out
   double tailAlpha, tailValueOut;  // w[pivotRow] / sol[sequenceOut] handed to the serial tail of k_ftran_scatter3  // this pivot's primal update completed: its list appends may be scattered  // unordered append count of k_dj_flags (ordered later by k_flip_apply2)
 };

@@ -5593,6 +5593,7 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
                     "in the coarse passes before them %.0f; calls of the wide kernel %lld\n",
             w[0], w[1], (w[0] + w[1]) ? (double)w[2] / (double)(w[0] + w[1]) : 0.0, (w[0] + w[1] + w[5]) ? (double)w[3] / (double)(w[0] + w[1] + w[5]) : 0.0,
             (w[0] + w[1] + w[5]) ? (double)w[4] / (double)(w[0] + w[1] + w[5]) : 0.0, w[5]);
+    fprintf(stderr, "clpgpu dbg: ratio test, multi-wave working-set calls %lld, of which the test ended below 8 theta0 (class 0 would have sufficed) %lld\n", w[6], w[7]);
   }
   stats->price_bytes = ctx->hCtrl->statPriceBytes;
   stats->row_bytes = ctx->hCtrl->statRowBytes;

@@ -1389,6 +1389,13 @@ __device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nu
     c->dbg[4] += nc;
     c->dbg[ONEWAVE ? 7 : 8] += wall_clock64() - dbgT0;
     c->dbg[MAPPED ? 5 : 6]++;
+    if (MAPPED && !ONEWAVE) {
+      // would the smallest class (breakpoints up to 8 theta0) have been enough for this pivot?
+      const double theta0dbg = fmax(10.0 * c->upperTheta, 1.0e-7);
+      c->dbgCc[6]++;
+      if (tentativeTheta < 8.0 * theta0dbg)
+        c->dbgCc[7]++;
+    }
     c->badSumPivots = badSumPivots;
     c->modifyCosts = modifyCosts;
     if (sequenceIn >= 0) {
