@@ -259,6 +259,7 @@ def main():
     status = eng.dual_steps(args.warmup)
     assert status == -1, f"LP finished during warmup (status {status})"
     it0 = eng.numberIterations()
+    nucleus_at_start = int(eng.stats()["nucleus"])
     barrier()
     t1 = time.perf_counter()
     status = eng.dual_steps(args.steps)
@@ -646,7 +647,7 @@ def main():
                        "check_every": args.check_every, "generate_s": round(gen_s, 1),
                        "pivot_window": [int(it0) + 1, int(it0) + args.steps],
                        "pivot_window_counts_from": "the warm start" if basis is not None else "the slack basis",
-                       "nucleus_at_end_of_window": int(headline_stats["nucleus"])},
+                       "nucleus_at_start_of_window": nucleus_at_start, "nucleus_at_end_of_window": int(headline_stats["nucleus"])},
             "roofline": {"bound": "hbm",
                          # by column the HIP events bracket the pricing kernel alone (k_price_row_finish returns at once and is left out): the
                          # duration rocprofv3 reports for k_price_sell; by row both passes

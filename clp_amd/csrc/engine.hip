@@ -3837,7 +3837,13 @@ int clpgpu_context::whileIterating(int stepTarget)
         dualTest = 0.0;
       if (hCtrl->bestPossible < 1.0e-11 && dualBound > dualTest) {
         // "say infeasible ... unless primal feasible!!!!" (:1982-2027, specialOptions_ 0): the sums are those of the last status
-        // check; the -4 alternative (:1999) needs more than two pivots since the factorization and cannot be taken here
+        // check; the -4 alternative (:1999) needs more than two pivots since the factorization and cannot be taken here.
+        // This 10 is whileIterating's own and reaches every caller in the reference, fastDual and strong branching included
+        // (they get it from ClpSimplexDual::whileIterating as well), so it is NOT behind option fake_bound_cleanup the way
+        // ClpSimplex::dual's rewrite of a finished 1 is (src/ClpSimplex.cpp:5800-5803).  The reference also
+        // replaces the objective by a zero one here ("Get rid of objective", :2022-2024: the primal that follows then only
+        // looks for feasibility); the engine has no primal behind it and keeps its costs -- a caller that finishes a 10
+        // with Clp's primal (the clpGpuDual adapter) hands it the model's own objective, as after any other 10.
         problemStatus = 1;
         if (sumPrimalInfeasibilities < 1.0e-3 || sumDualInfeasibilities > 1.0e-5)
           problemStatus = 10;
