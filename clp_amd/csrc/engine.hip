@@ -1350,16 +1350,16 @@ int clpgpu_context::allocNucleus(int kNeeded)
   rc |= dalloc(D.slotRow, kcap);
   rc |= dalloc(D.slotCol, kcap);
   rc |= dalloc(D.slotPos, kcap);
-  rc |= dalloc(D.slotA, kcap);
+  rc |= dalloc(D.slotA, (size_t)kcap + 2);  // (+ 2: the tail GEMVs read these as 16-byte pairs)
   rc |= dalloc(D.slotB, kcap);
   rc |= dalloc(D.slotC, kcap);
   rc |= dalloc(D.slotD, kcap);
   rc |= dalloc(D.slotE, kcap);
   rc |= dalloc(D.slotF, kcap);
   rc |= dalloc(D.rhoSlot, kcap);
-  rc |= dalloc(D.slotV1, kcap);
-  rc |= dalloc(D.rhoSlotF, kcap);
-  rc |= dalloc(D.flipSlot, kcap);
+  rc |= dalloc(D.slotV1, (size_t)kcap + 2);  // (+ 2: the tail GEMVs read these as 16-byte pairs)
+  rc |= dalloc(D.rhoSlotF, (size_t)kcap + 2);  // (+ 2: the tail GEMVs read these as 16-byte pairs)
+  rc |= dalloc(D.flipSlot, (size_t)kcap + 2);  // (+ 2: the tail GEMVs read these as 16-byte pairs)
   rc |= dalloc(D.perm, kcap);
   rc |= dalloc(D.gjL, (size_t)kcap * GJ_B);
   rc |= dalloc(D.gjU, (size_t)GJ_B * 2 * ld);

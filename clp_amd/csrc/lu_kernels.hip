@@ -591,7 +591,13 @@ __global__ void __launch_bounds__(256) k_lu_gemvT(Dev D, int chain, const double
         ma[r] = *reinterpret_cast<const double2 *>(row[r] + i);
         mb[r] = vb ? *reinterpret_cast<const double2 *>(row[r] + ib) : make_double2(0.0, 0.0);
       }
-      const double za0 = zt[i], za1 = ya ? zt[i + 1] : 0.0, zb0 = vb ? zt[ib] : 0.0, zb1 = yb ? zt[ib + 1] : 0.0;
+      double za0, za1, zb0, zb1;
+      if (chain) {  // (uniform) the chain's vector is D.slotA: 16-byte pairs, as in k_lu_gemv3; a caller's vector is read entry by entry
+        const double2 pa = *reinterpret_cast<const double2 *>(zt + i), pb = vb ? *reinterpret_cast<const double2 *>(zt + ib) : make_double2(0.0, 0.0);
+        za0 = pa.x, za1 = ya ? pa.y : 0.0, zb0 = pb.x, zb1 = yb ? pb.y : 0.0;
+      } else {
+        za0 = zt[i], za1 = ya ? zt[i + 1] : 0.0, zb0 = vb ? zt[ib] : 0.0, zb1 = yb ? zt[ib + 1] : 0.0;
+      }
 #pragma unroll
       for (int r = 0; r < LUG_ROWS; r++) {
         acc[r] += ma[r].x * za0;
@@ -638,15 +644,16 @@ __global__ void __launch_bounds__(256) k_lu_gemv3(Dev D)
         ma[r] = *reinterpret_cast<const double2 *>(row[r] + i);
         mb[r] = vb ? *reinterpret_cast<const double2 *>(row[r] + ib) : make_double2(0.0, 0.0);
       }
+      // the three vectors as 16-byte pairs (i and ib are even, the slot vectors carry two spare entries): 6 instead of 12 vector
+      // loads beside the 8 matrix loads of a trip; entries past k2 are masked (they may hold anything)
       double xs[3][4];  // [vector][strip a: i, i + 1; strip b: ib, ib + 1]
-      const int at[4] = { i, i + 1, ib, ib + 1 };
-      const bool ok[4] = { true, ya, vb, yb };
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        xs[0][u] = ok[u] ? v1[at[u]] : 0.0;
-        xs[1][u] = (ok[u] && doTau) ? v2[at[u]] : 0.0;
-        xs[2][u] = (ok[u] && doFlip) ? v3[at[u]] : 0.0;
-      }
+      const double2 zero2 = make_double2(0.0, 0.0);
+      const double2 p1a = *reinterpret_cast<const double2 *>(v1 + i), p1b = vb ? *reinterpret_cast<const double2 *>(v1 + ib) : zero2;
+      const double2 p2a = doTau ? *reinterpret_cast<const double2 *>(v2 + i) : zero2, p2b = (doTau && vb) ? *reinterpret_cast<const double2 *>(v2 + ib) : zero2;
+      const double2 p3a = doFlip ? *reinterpret_cast<const double2 *>(v3 + i) : zero2, p3b = (doFlip && vb) ? *reinterpret_cast<const double2 *>(v3 + ib) : zero2;
+      xs[0][0] = p1a.x, xs[0][1] = ya ? p1a.y : 0.0, xs[0][2] = p1b.x, xs[0][3] = yb ? p1b.y : 0.0;
+      xs[1][0] = p2a.x, xs[1][1] = ya ? p2a.y : 0.0, xs[1][2] = p2b.x, xs[1][3] = yb ? p2b.y : 0.0;
+      xs[2][0] = p3a.x, xs[2][1] = ya ? p3a.y : 0.0, xs[2][2] = p3b.x, xs[2][3] = yb ? p3b.y : 0.0;
 #pragma unroll
       for (int r = 0; r < LUG_ROWS; r++) {
         const double mv[4] = { ma[r].x, ya ? ma[r].y : 0.0, mb[r].x, yb ? mb[r].y : 0.0 };
