@@ -1184,30 +1184,22 @@ int clpgpu_context::buildSell()
   return rc;
 }
 
-// Jagged row-tiled copy of the windowed SELL slices for k_price_lds (layout: device_state.h; kernel: kernels.hip).
-// `order` is buildSell's placement: position w * 256 + i holds the i-th longest column of window w (or -1).
-int clpgpu_context::buildJds(const std::vector<int> &order, int numSlices)
+// The jagged row-tiled layout itself (device_state.h; consumed by k_price_lds), host arithmetic only: `order` holds, per slice
+// of 64 positions, the column keys in the slice's home order (-1 none).  false: a column has more than 255 entries in a tile or
+// the stream does not fit 31-bit record indices.  Also behind clpgpu_test_jds_layout, which lets a CPU test walk the layout the
+// way the kernel does (tests/test_host_logic.py).
+static bool jdsLayout(int m, const int *colStart, const int *row, const double *elem, const std::vector<int> &order, int numSlices, int T,
+                      int tileRows, std::vector<int> &segStart, std::vector<int> &col, std::vector<unsigned char> &cnt, std::vector<unsigned char> &src,
+                      std::vector<unsigned char> &home, std::vector<unsigned> &rowPair, std::vector<double2> &elemPair)
 {
-  const int nWin = (int)(order.size() / PRICE_BLOCK);
-  // worth a one-workgroup-per-CU launch only on wide LPs; needs every column's rows in ascending order (tile after tile
-  // is then the column's own entry order) and 16-bit tile-local row indices
-  if (nWin < priceLdsMinWindows || nWin * 4 != numSlices || m < 4096 || widePricing)
-    return 0;
-  const int T = cdiv(m, PL_MAX_TILE_ROWS);
-  const int tileRows = (cdiv(m, T) + 127) & ~127;
-  if (tileRows > PL_MAX_TILE_ROWS || (size_t)T * tileRows > (size_t)m + 2 * PL_MAX_TILE_ROWS)
-    return 0;
-  for (int j : order)
-    if (j >= 0)
-      for (int p = colStart[j] + 1; p < colStart[j + 1]; p++)
-        if (row[p] <= row[p - 1])
-          return 0;
-  std::vector<int> segStart(numSlices, 0), col((size_t)numSlices * 64, -1);
-  std::vector<unsigned char> cnt((size_t)numSlices * T * 64, 0), src((size_t)numSlices * T * 64, 0), home((size_t)numSlices * 64, 0);
-  std::vector<unsigned> rowPair;
-  std::vector<double2> elemPair;
-  rowPair.reserve((size_t)nnz / 2 + (size_t)nnz / 16 + 64);
-  elemPair.reserve((size_t)nnz / 2 + (size_t)nnz / 16 + 64);
+  (void)m;
+  segStart.assign(numSlices, 0);
+  col.assign((size_t)numSlices * 64, -1);
+  cnt.assign((size_t)numSlices * T * 64, 0);
+  src.assign((size_t)numSlices * T * 64, 0);
+  home.assign((size_t)numSlices * 64, 0);
+  rowPair.clear();
+  elemPair.clear();
   std::vector<int> ord(64), prevPos(64), pos(64), ptr(64), cntHome((size_t)T * 64);
   for (int slice = 0; slice < numSlices; slice++) {
     int h[64];
@@ -1225,7 +1217,7 @@ int clpgpu_context::buildJds(const std::vector<int> &order, int numSlices)
       ptr[l] = h[l] >= 0 ? colStart[h[l]] : 0;
     }
     if (rowPair.size() > 2000000000u)
-      return 0;
+      return false;
     segStart[slice] = (int)rowPair.size();
     for (int tau = 0; tau < T; tau++) {
       for (int l = 0; l < 64; l++)
@@ -1235,7 +1227,7 @@ int clpgpu_context::buildJds(const std::vector<int> &order, int numSlices)
       for (int q = 0; q < 64; q++) {
         const int c = cntHome[(size_t)tau * 64 + ord[q]];
         if (c > 255)
-          return 0;  // (columns longer than SELL_LONG never get here)
+          return false;  // (columns longer than SELL_LONG never get here)
         cnt[((size_t)slice * T + tau) * 64 + q] = (unsigned char)c;
         src[((size_t)slice * T + tau) * 64 + q] = (unsigned char)prevPos[ord[q]];
         pos[ord[q]] = q;
@@ -1264,6 +1256,40 @@ int clpgpu_context::buildJds(const std::vector<int> &order, int numSlices)
     for (int l = 0; l < 64; l++)
       home[(size_t)slice * 64 + l] = (unsigned char)prevPos[l];
   }
+  return true;
+}
+static void jdsTiling(int m, int &T, int &tileRows)
+{
+  T = cdiv(m, PL_MAX_TILE_ROWS);
+  tileRows = (cdiv(m, T) + 127) & ~127;
+}
+
+// Jagged row-tiled copy of the windowed SELL slices for k_price_lds (layout: device_state.h; kernel: kernels.hip).
+// `order` is buildSell's placement: position w * 256 + i holds the i-th longest column of window w (or -1).
+int clpgpu_context::buildJds(const std::vector<int> &order, int numSlices)
+{
+  const int nWin = (int)(order.size() / PRICE_BLOCK);
+  // worth a one-workgroup-per-CU launch only on wide LPs; needs every column's rows in ascending order (tile after tile
+  // is then the column's own entry order) and 16-bit tile-local row indices
+  if (nWin < priceLdsMinWindows || nWin * 4 != numSlices || m < 4096 || widePricing)
+    return 0;
+  int T, tileRows;
+  jdsTiling(m, T, tileRows);
+  if (tileRows > PL_MAX_TILE_ROWS || (size_t)T * tileRows > (size_t)m + 2 * PL_MAX_TILE_ROWS)
+    return 0;
+  for (int j : order)
+    if (j >= 0)
+      for (int p = colStart[j] + 1; p < colStart[j + 1]; p++)
+        if (row[p] <= row[p - 1])
+          return 0;
+  std::vector<int> segStart, col;
+  std::vector<unsigned char> cnt, src, home;
+  std::vector<unsigned> rowPair;
+  std::vector<double2> elemPair;
+  rowPair.reserve((size_t)nnz / 2 + (size_t)nnz / 16 + 64);
+  elemPair.reserve((size_t)nnz / 2 + (size_t)nnz / 16 + 64);
+  if (!jdsLayout(m, colStart.data(), row.data(), elem.data(), order, numSlices, T, tileRows, segStart, col, cnt, src, home, rowPair, elemPair))
+    return 0;
   rowPair.resize(rowPair.size() + 64, 0u);  // a pair with no active lane reads the record behind the stream
   elemPair.resize(elemPair.size() + 64, make_double2(0.0, 0.0));
   int *dSeg, *dColJ;
@@ -4532,6 +4558,44 @@ int clpgpu_test_cycle(clpgpu_context *ctx, int count, const int *in, const int *
   (void)hipFree(scratch);
   (void)hipFree(d);
   return rc;
+}
+
+// test hook for the jagged row-tiled pricing layout (jdsLayout above; consumed by k_price_lds), host code only: no device is
+// needed or touched.  `order` = numSlices * 64 column keys in home order (-1 none).  Called with capRecords = 0 it only
+// reports the sizes (tiles, tileRows, records); called again with room it fills the arrays the kernel reads.  A CPU test walks
+// them the way the kernel does and holds every column's dot product to the sequential one (tests/test_host_logic.py).
+// Returns 0, 1 when the layout refuses the matrix (a column with more than 255 entries in one tile), -99 on bad arguments.
+int clpgpu_test_jds_layout(int m, int n, const int *colStart, const int *row, const double *elem, int numSlices, const int *order, int *tiles,
+                           int *tileRows, long long *records, long long capRecords, int *segStart, unsigned char *cnt, unsigned char *src,
+                           unsigned char *home, unsigned *rowPair, double *elemPair)
+{
+  if (m <= 0 || n <= 0 || numSlices <= 0 || !colStart || !row || !elem || !order || !tiles || !tileRows || !records)
+    return -99;
+  for (size_t i = 0; i < (size_t)numSlices * 64; i++)
+    if (order[i] >= n)
+      return -99;
+  int T, tr;
+  jdsTiling(m, T, tr);
+  std::vector<int> ord(order, order + (size_t)numSlices * 64), seg, col;
+  std::vector<unsigned char> c, sr, hm;
+  std::vector<unsigned> rp;
+  std::vector<double2> ep;
+  if (!jdsLayout(m, colStart, row, elem, ord, numSlices, T, tr, seg, col, c, sr, hm, rp, ep))
+    return 1;
+  *tiles = T;
+  *tileRows = tr;
+  *records = (long long)rp.size();
+  if (capRecords <= 0)
+    return 0;
+  if (capRecords < (long long)rp.size() || !segStart || !cnt || !src || !home || !rowPair || !elemPair)
+    return -99;
+  memcpy(segStart, seg.data(), seg.size() * sizeof(int));
+  memcpy(cnt, c.data(), c.size());
+  memcpy(src, sr.data(), sr.size());
+  memcpy(home, hm.data(), hm.size());
+  memcpy(rowPair, rp.data(), rp.size() * sizeof(unsigned));
+  memcpy(elemPair, ep.data(), ep.size() * sizeof(double2));
+  return 0;
 }
 
 // parity hook for the engine's restatement of ClpSimplexProgress::looping (src/ClpSolve.cpp:4438-4611), host code only: no

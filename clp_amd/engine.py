@@ -52,6 +52,7 @@ ABI_SYMBOLS = [
     "clpgpu_clone", "clpgpu_set_scales", "clpgpu_ftran_ft", "clpgpu_ftran_two_ft", "clpgpu_bind_rim", "clpgpu_pivot_row",
     "clpgpu_update_weights", "clpgpu_update_primal", "clpgpu_save_weights", "clpgpu_unroll_weights",
     "clpgpu_get_kernel_times", "clpgpu_dgemm", "clpgpu_test_cycle", "clpgpu_debug_price_bench", "clpgpu_test_looping",
+    "clpgpu_test_jds_layout",
     "clpgpu_virtual_group_create", "clpgpu_virtual_group_destroy", "clpgpu_virtual_attach", "clpgpu_virtual_dual_steps",
 ]
 
@@ -481,6 +482,43 @@ def test_looping(objective, infeasibility, count, iteration, flag_bits, newest):
     if f(n, d[0], d[1], i[0], i[1], i[2], i[3], code, tol, bound, force, flagged) != 0:
         raise RuntimeError("clpgpu_test_looping failed")
     return code, tol, bound, force, flagged
+
+
+def jds_layout(lp, order):
+    """The jagged row-tiled pricing layout k_price_lds reads (clpgpu_test_jds_layout), built by the engine's host code without a
+    GPU.  `order` = column keys in home order, 64 per slice (-1 none).  Returns a dict of the arrays, or None where the layout
+    refuses the matrix."""
+    ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+    bp = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+    up = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+    order = np.ascontiguousarray(order, dtype=np.int32)
+    assert order.size % 64 == 0 and order.size
+    slices = order.size // 64
+    cs = np.ascontiguousarray(lp.col_start, dtype=np.int32)
+    row = np.ascontiguousarray(lp.row, dtype=np.int32)
+    elem = np.ascontiguousarray(lp.elem, dtype=np.float64)
+    f = lib().clpgpu_test_jds_layout
+    f.argtypes = [C.c_int, C.c_int, ip, ip, dp, C.c_int, ip, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.c_longlong,
+                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    f.restype = C.c_int
+    tiles, tile_rows, records = C.c_int(0), C.c_int(0), C.c_longlong(0)
+    rc = f(int(lp.m), int(lp.n), cs, row, elem, slices, order, C.byref(tiles), C.byref(tile_rows), C.byref(records), 0, None, None, None, None, None, None)
+    if rc == 1:
+        return None
+    if rc != 0:
+        raise RuntimeError(f"clpgpu_test_jds_layout failed ({rc})")
+    T, R = tiles.value, records.value
+    seg = np.zeros(slices, np.int32)
+    cnt, src = np.zeros(slices * T * 64, np.uint8), np.zeros(slices * T * 64, np.uint8)
+    home = np.zeros(slices * 64, np.uint8)
+    rp, ep = np.zeros(max(R, 1), np.uint32), np.zeros(2 * max(R, 1), np.float64)
+    rc = f(int(lp.m), int(lp.n), cs, row, elem, slices, order, C.byref(tiles), C.byref(tile_rows), C.byref(records), max(R, 1),
+           seg.ctypes.data, cnt.ctypes.data, src.ctypes.data, home.ctypes.data, rp.ctypes.data, ep.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"clpgpu_test_jds_layout failed ({rc})")
+    return {"tiles": T, "tile_rows": tile_rows.value, "records": R, "seg_start": seg, "cnt": cnt.reshape(slices, T, 64),
+            "src": src.reshape(slices, T, 64), "home": home.reshape(slices, 64), "row_pair": rp[:R], "elem_pair": ep[:2 * R].reshape(R, 2)}
 
 
 class VirtualRanks:

@@ -343,6 +343,15 @@ int clpgpu_test_looping(int count, const double *objective, const double *infeas
                         const int *flagBits, const int *newestIncoming, int *code, double *dualTolerance, double *dualBound, int *forceFactorization,
                         int *flagged);
 
+/* Test hook (no Clp counterpart; the reference prices a dense pi by column straight from the CSC copy,
+ * ClpPackedMatrix::transposeTimesByColumn, src/ClpPackedMatrix.cpp:961): the jagged row-tiled layout k_price_lds reads, built on
+ * the host without a device.  order = numSlices * 64 column keys (-1 none); with capRecords = 0 only *tiles, *tileRows and
+ * *records come back; with room, segStart[numSlices], cnt / src [numSlices * tiles * 64], home[numSlices * 64],
+ * rowPair[records], elemPair[2 * records].  Returns 0, 1 = the layout refuses the matrix, -99 on bad arguments. */
+int clpgpu_test_jds_layout(int m, int n, const int *colStart, const int *row, const double *elem, int numSlices, const int *order, int *tiles,
+                           int *tileRows, long long *records, long long capRecords, int *segStart, unsigned char *cnt, unsigned char *src,
+                           unsigned char *home, unsigned *rowPair, double *elemPair);
+
 /* CoinAbcDgemm (src/CoinAbcHelperFunctions.cpp:1658; used by CoinAbcDgetrf, src/AbcSimplexParallel.cpp:2491-2534):
  * the engine's own f64 GEMM on the matrix cores, c = beta c + alpha a b for row-major n x n host arrays.  The
  * kernel behind the Newton-Schulz steps on the explicit (tail) inverse; exposed so that tests hold it to numpy. */
