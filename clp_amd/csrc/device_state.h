@@ -89,6 +89,14 @@ struct Ctrl {
   int wsJ, wsCount;  // ratio test: breakpoint class prefix of the working set k_dc_working_set compacted, and its size (wsJ < 0: none)  // ratio test, working-set path: calls, ticks of the whole kernel, ticks before the passes start, max ticks of one call
   long long dbgCc[8];  // development counters of the ratio test's final batch: compacted calls, too large to compact, sum of batch sizes, ticks of the trips, ticks of the coarse passes, wide calls
   int dcArrive, dcWide;  // k_dual_column_wide: grid-barrier arrivals of this pivot; 1 = this pivot's ratio test was left to it, -1 = a barrier timed out
+  // option free_nonbasic (isFree / superbasic nonbasics, src/ClpSimplexDual.cpp:3005-3055, :4058-4179); all zero without it.
+  // presetRowPlus1: the host's free-first row for this pivot (dualRow :3005-3055), taken by CHUZR's final selection instead of its own;
+  // freeHold: the tail of the pivot does not run the head of the next CHUZR (the host decides first whether that pivot is free-first);
+  // freeCount: entries of Dev::freeList (0: the fast branch of dualColumn0, no k_free_scan work); freeChosen: k_free_scan brought a
+  // free variable in, the ratio test is skipped (:4321 "always choose"); badFree: dualColumn0's badFree_ of this pivot row
+  int presetRowPlus1, freeHold, freeCount, freeChosen;
+  double badFree;
+  int freeEntered, freePad;
   double tailAlpha, tailValueOut;  // w[pivotRow] / sol[sequenceOut] handed to the serial tail of k_ftran_scatter3  // this pivot's primal update completed: its list appends may be scattered  // unordered append count of k_dj_flags (ordered later by k_flip_apply2)
 };
 
@@ -197,6 +205,8 @@ struct Dev {
   unsigned char *candLive;
   double *candDj, *candRange;  // [N] dj and upper - lower of every candidate (snapshot taken by k_cand_scatter)
   int *wsIdxG;                 // [DC_WS_CAP] working set of the ratio test (candidate indices, list order)
+  int *freeList;               // [N] option free_nonbasic: the sequences whose status was isFree / superBasic at the last status check, rows first
+                               // (the order dualColumn0's general branch meets them in); Ctrl::freeCount of them
   double *dcPart;              // [2 * DCW_BLOCKS * DCW_PART] per-workgroup partials of k_dual_column_wide, two sets
   int *candBlk, *candRk;       // [N] compaction block of the candidate; its rank among classes <= 0 / 1 / 2 inside that block (10 bits each)
   double *flipRecMv, *flipRecObj;   // [FLIP_LIST_CAP] per appended flip: movement, objective term

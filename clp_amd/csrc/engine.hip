@@ -160,6 +160,19 @@ struct clpgpu_context {
   int numberBackwards = 0, numberLoopFlags = 0;  // statistics: backwards-objective restores, loops acted upon
   int debugBackwardsAt = -1;  // fault injection (option debug_backwards_at), as in the oracle
   int debugPoisonInverseAt = -1, numberPoisoned = 0;  // fault injection (option debug_poison_inverse_at)
+  // option "free_nonbasic" 1: nonbasic free columns stay isFree as in the reference instead of being given bothFake bounds at start
+  // (DESIGN section 2): free-first row choice (dualRow, src/ClpSimplexDual.cpp:3005-3055; host-assisted, freeFirstRow below), the
+  // general branch of dualColumn0 (:4058-4179; k_free_scan), firstFree_ and the free counters of the status checks
+  int freeNonbasic = 0;
+  int firstFree = -1;      // ClpSimplex::firstFree_
+  int noFreeOrSuper = 1;   // moreSpecialOptions_ & 8 as the last status check left it ("no free or super basic")
+  int numberDualInfeasibilitiesWithoutFree = 0;
+  int numberFreeFirstRows = 0, numberFreeEntered = 0;  // diagnostics: pivots whose row came from the free-first entry / that brought a free column in
+  std::vector<int> freeListHost;
+  int *dFreeList = nullptr;
+  size_t freeListCap = 0;
+  int freeFirstRow(int &chosenRow);
+  int pushFreeList();
   int checkBoth = 1;  // option "check_both": gutsOfSolution ends in checkBothSolutions (1, this reference version) or in the older pair (0)
   int debugResetWeightsAt = -1;  // option debug_reset_weights_at (experiment)
   int dseResetEvery = 0, dseResetCounter = 0, numberWeightResets = 0;  // option dse_reset_every (experiment): uniform weights again every N-th refactorization
@@ -281,6 +294,7 @@ struct clpgpu_context {
   int priceLdsMinWindows = 256;  // option "price_lds_min_windows": narrower LPs keep k_price_sell (a one-workgroup-per-CU launch needs work for every CU)
   int priceLdsGridCap = 256;     // option "price_lds_grid" (test knob): fewer workgroups than CUs, so that a workgroup takes several rounds of windows
   int priceMode = 0, graphPriceMode = 0;
+  bool freeActive = false, graphFreeActive = false;  // the chain carries k_free_scan (option free_nonbasic and free / superbasic nonbasics about)
   double modePriced = 0.0, modeDense = 0.0;
   bool jdsReady = false;
   size_t priceLdsBytes = 0;
@@ -941,6 +955,8 @@ void clpgpu_context::releaseProblem()
   jdsReady = false;
   priceMode = 0;
   modePriced = modeDense = 0.0;
+  dFreeList = nullptr;  // (was in `allocations`)
+  freeActive = graphFreeActive = false;
   for (DBuf &b : luBuf) {
     if (b.p)
       (void)hipFree(b.p);
@@ -1932,6 +1948,8 @@ int clpgpu_context::gutsOfSolution()
   if (checkBoth) {
     checkBothSolutions();
   } else {
+    if (freeNonbasic)
+      noFreeOrSuper = 0;  // "say may be free or superbasic", the old way of src/ClpSimplex.cpp:3228-3234
     checkPrimalSolution();
     checkDualSolution();
   }
@@ -1974,20 +1992,51 @@ void clpgpu_context::checkDualSolution()
   sumDualInfeasibilities = 0.0;
   numberDualInfeasibilities = 0;
   sumOfRelaxedDualInfeasibilities = 0.0;
+  numberDualInfeasibilitiesWithoutFree = 0;
+  // with option free_nonbasic: the isFree branches ("free so relax a lot", :3125-3136), the count without free variables and
+  // firstFree_ (:3214-3219)
+  const bool withFree = freeNonbasic != 0;
+  int firstFreePrimal = -1, firstFreeDual = -1, numberSuperBasicWithDj = 0;
   for (int pass = 0; pass < 2; pass++) {
     int lo = pass ? n : 0, hi = pass ? N : n;
     for (int i = lo; i < hi; i++) {
       if ((status[i] & 7) != ST_BASIC && !(status[i] & FLAGGED_BIT)) {
         double distanceUp = upper[i] - sol[i], distanceDown = sol[i] - lower[i], value = dj[i];
-        if (distanceUp > primalTolerance && value < 0.0) {
-          double v = -value;
-          if (v > dualTolerance) {
-            sumDualInfeasibilities += v - dualTolerance;
-            if (v > possTolerance)
-              bestPossibleImprovement += fmin(distanceUp, 1.0e10) * v;
-            if (v > relaxedTolerance)
-              sumOfRelaxedDualInfeasibilities += v - relaxedTolerance;
-            numberDualInfeasibilities++;
+        const bool isFree = withFree && (status[i] & 7) == ST_FREE;
+        if (distanceUp > primalTolerance) {
+          if (withFree && distanceDown > primalTolerance) {  // check if "free" (:3110-3118)
+            if (fabs(value) > 1.0e2 * relaxedTolerance) {
+              numberSuperBasicWithDj++;
+              if (firstFreeDual < 0)
+                firstFreeDual = i;
+            }
+            if (firstFreePrimal < 0)
+              firstFreePrimal = i;
+          }
+          if (value < 0.0) {
+            double v = -value;
+            if (v > dualTolerance) {
+              if (!(isFree && i < n)) {  // (the row loop has no relaxed form, :3180-3190)
+                if (!isFree)
+                  numberDualInfeasibilitiesWithoutFree++;
+                sumDualInfeasibilities += v - dualTolerance;
+                if (v > possTolerance)
+                  bestPossibleImprovement += fmin(distanceUp, 1.0e10) * v;
+                if (v > relaxedTolerance)
+                  sumOfRelaxedDualInfeasibilities += v - relaxedTolerance;
+                numberDualInfeasibilities++;
+              } else {
+                v *= 0.01;  // free so relax a lot
+                if (v > dualTolerance) {
+                  sumDualInfeasibilities += v - dualTolerance;
+                  if (v > possTolerance)
+                    bestPossibleImprovement = 1.0e100;
+                  if (v > relaxedTolerance)
+                    sumOfRelaxedDualInfeasibilities += v - relaxedTolerance;
+                  numberDualInfeasibilities++;
+                }
+              }
+            }
           }
         }
         if (distanceDown > primalTolerance && value > 0.0) {
@@ -1998,10 +2047,18 @@ void clpgpu_context::checkDualSolution()
             if (value > relaxedTolerance)
               sumOfRelaxedDualInfeasibilities += value - relaxedTolerance;
             numberDualInfeasibilities++;
+            if (!isFree)
+              numberDualInfeasibilitiesWithoutFree++;
           }
         }
       }
     }
+  }
+  if (withFree) {
+    if (firstFreeDual >= 0)
+      firstFree = firstFreeDual;
+    else if (numberSuperBasicWithDj || progIteration[PROGRESS - 1] <= 0)
+      firstFree = firstFreePrimal;
   }
 }
 
@@ -2025,18 +2082,25 @@ void clpgpu_context::checkBothSolutions()
   numberDualInfeasibilities = 0;
   sumOfRelaxedDualInfeasibilities = 0.0;
   bestPossibleImprovement = 0.0;
+  // option free_nonbasic: moreSpecialOptions_ & 8 (:3273, :3294, :3345), the count without free variables and firstFree_ (:3414-3424)
+  int numberDualInfeasibilitiesFree = 0, firstFreePrimal = -1, firstFreeDual = -1, numberSuperBasicWithDj = 0;
+  int noneFreeOrSuper = 1;
   for (int i = 0; i < N; i++) {
     const double value = sol[i];
     objectiveValue += value * cost[i];
     const double distanceUp = upper[i] - value, distanceDown = value - lower[i];
     if (distanceUp < -primalTolerance) {
       const double infeasibility = -distanceUp;
+      if ((status[i] & 7) != ST_BASIC)
+        noneFreeOrSuper = 0;  // say superbasic variables exist (:3294)
       sumPrimalInfeasibilities += infeasibility - primalTolerance;
       if (infeasibility > relaxedToleranceP)
         sumOfRelaxedPrimalInfeasibilities += infeasibility - relaxedToleranceP;
       numberPrimalInfeasibilities++;
     } else if (distanceDown < -primalTolerance) {
       const double infeasibility = -distanceDown;
+      if ((status[i] & 7) != ST_BASIC)
+        noneFreeOrSuper = 0;
       sumPrimalInfeasibilities += infeasibility - primalTolerance;
       if (infeasibility > relaxedToleranceP)
         sumOfRelaxedPrimalInfeasibilities += infeasibility - relaxedToleranceP;
@@ -2062,16 +2126,36 @@ void clpgpu_context::checkBothSolutions()
           numberDualInfeasibilities++;
         }
       } else {
+        noneFreeOrSuper = 0;  // say free or superbasic (:3345)
         djValue *= 100.0;  // strictly between its bounds: may be free
         if (fabs(djValue) > dualTolerance) {
+          if ((status[i] & 7) == ST_FREE)
+            numberDualInfeasibilitiesFree++;
           sumDualInfeasibilities += fabs(djValue) - dualTolerance;
           bestPossibleImprovement = 1.0e100;
           numberDualInfeasibilities++;
-          if (fabs(djValue) > relaxedToleranceD)
+          if (fabs(djValue) > relaxedToleranceD) {
             sumOfRelaxedDualInfeasibilities += value - relaxedToleranceD;
+            numberSuperBasicWithDj++;
+            if (firstFreeDual < 0)
+              firstFreeDual = i;
+            if (firstFreePrimal < 0)
+              firstFreePrimal = i;
+          }
+        } else if ((status[i] & 7) == ST_SUPER && firstFreePrimal < 0) {
+          firstFreePrimal = i;
         }
       }
     }
+  }
+  numberDualInfeasibilitiesWithoutFree = numberDualInfeasibilities;
+  if (freeNonbasic) {
+    noFreeOrSuper = noneFreeOrSuper;
+    numberDualInfeasibilitiesWithoutFree = numberDualInfeasibilities - numberDualInfeasibilitiesFree;
+    if (firstFreeDual >= 0)
+      firstFree = firstFreeDual;  // dual (:3418)
+    else if (numberSuperBasicWithDj || progIteration[PROGRESS - 1] <= 0)
+      firstFree = firstFreePrimal;
   }
 }
 
@@ -2095,15 +2179,21 @@ int clpgpu_context::changeBounds(int initialize, double &changeCost)
         if (fabs(value - upper[i]) > primalTolerance) {
           if (fabs(dj[i]) > 1.0e-9)
             numberInfeasibilities++;
-          else
+          else {
             status[i] = withStatus(status[i], ST_SUPER);
+            if (freeNonbasic)
+              noFreeOrSuper = 0;  // moreSpecialOptions_ &= ~8 (:3181)
+          }
         }
       } else if (st == ST_LOWER) {
         if (fabs(value - lower[i]) > primalTolerance) {
           if (fabs(dj[i]) > 1.0e-9)
             numberInfeasibilities++;
-          else
+          else {
             status[i] = withStatus(status[i], ST_SUPER);
+            if (freeNonbasic)
+              noFreeOrSuper = 0;  // (:3192)
+          }
         }
       }
     }
@@ -2537,7 +2627,8 @@ int clpgpu_context::startup()
       else if (colUpper[j] <= 0.0)
         status[j] = ST_UPPER;
       else if (colLower[j] < -1.0e20 && colUpper[j] > 1.0e20)
-        status[j] = ST_UPPER;  // free: given bothFake bounds by changeBounds(1)
+        status[j] = freeNonbasic ? ST_FREE : ST_UPPER;  // free: the reference's isFree (allSlackBasis :7846-7849) with option free_nonbasic, else
+                                                        // given bothFake bounds by changeBounds(1)
       else if (fabs(colLower[j]) < fabs(colUpper[j]))
         status[j] = ST_LOWER;
       else
@@ -2562,8 +2653,16 @@ int clpgpu_context::startup()
       status[i] = withStatus(status[i], ST_LOWER);
       sol[i] = lower[i];
     }
+    if (freeNonbasic && (st == ST_LOWER || st == ST_UPPER) && lower[i] < -1.0e20 && upper[i] > 1.0e20) {
+      status[i] = withStatus(status[i], ST_FREE);  // createRim's clean-up of a caller's basis, src/ClpSimplex.cpp:4317-4338
+      sol[i] = 0.0;
+    }
     dj[i] = 0.0;
   }
+  noFreeOrSuper = 1;
+  firstFree = -1;
+  numberDualInfeasibilitiesWithoutFree = 0;
+  numberFreeFirstRows = numberFreeEntered = 0;
   problemStatus = -1;
   numberIterations = 0;
   numberRefactorizations = 0;
@@ -2990,7 +3089,7 @@ int clpgpu_context::statusOfProblemInDual(int type)
       if (progressFlag & 4)
         debugBackwardsAt = -1;
     }
-    if (lastObj > thisObj + testTol * (fabs(thisObj) + fabs(lastObj)) + testTol) {
+    if (firstFree < 0 /* :5360 */ && lastObj > thisObj + testTol * (fabs(thisObj) + fabs(lastObj)) + testTol) {
       if (progTimesFlagged > 10)
         progReallyBadTimes++;
       if (fastDualMode) {
@@ -3069,6 +3168,13 @@ int clpgpu_context::statusOfProblemInDual(int type)
     costCopy = cost;  // :5543-5547
   if (!numberPrimalInfeasibilities && !numberDualInfeasibilities)
     progressFlag |= 8;
+  // if we are primal feasible and any dual infeasibilities are on free variables then it is better to go to primal (:5619-5622)
+  if (freeNonbasic && !numberPrimalInfeasibilities && !numberDualInfeasibilitiesWithoutFree && numberDualInfeasibilities) {
+    problemStatus = 10;
+    if (logLevel > 3)
+      fprintf(stderr, "clpgpu: iteration %d primal feasible, the %d dual infeasibilities are all on free variables: 10\n", numberIterations,
+              numberDualInfeasibilities);
+  }
   bool needCleanFake = false, dirty = false;
   double saveDualBound = dualBound;
   while (problemStatus <= -3 && saveDualBound == dualBound) {
@@ -3267,7 +3373,7 @@ int clpgpu_context::statusOfProblemInDual(int type)
   {
     // refactorize more often when the recorded objective fell between the last two checks (:6316-6328)
     const double thisObj = progObjective[PROGRESS - 1], lastObj = progObjective[PROGRESS - 2];
-    if (lastObj > thisObj + 1.0e-4 * std::max(fabs(thisObj), fabs(lastObj)) + 1.0e-4 && maximumPivots > 10) {
+    if (lastObj > thisObj + 1.0e-4 * std::max(fabs(thisObj), fabs(lastObj)) + 1.0e-4 && firstFree < 0 /* :6319 */ && maximumPivots > 10) {
       if (forceFactorization < 0)
         forceFactorization = maximumPivots;
       forceFactorization = std::max(1, forceFactorization >> 1);
@@ -3370,6 +3476,108 @@ void clpgpu_context::allGather(const void *send, void *recv, size_t count, int d
   // nobody may overwrite its send buffer before every copy out of it has executed
   if (hipStreamSynchronize(stream) != hipSuccess || !g->barrier())
     commFailed = true;
+}
+
+// option free_nonbasic: the sequences that are isFree / superBasic now, rows first and then columns -- the order the general branch
+// of dualColumn0 walks the tableau row in (src/ClpSimplexDual.cpp:4066-4070) -- for k_free_scan.  Nothing becomes free or superbasic
+// between two status checks (a leaving variable goes to a bound, :2068-2094 of ClpSimplex.cpp), so the list stays a superset; the
+// kernel looks at the status again.  freeCount is 0 while moreSpecialOptions_ & 8 ("no free or super basic") holds: the fast
+// branch, which is what the pricing kernels fuse.
+int clpgpu_context::pushFreeList()
+{
+  freeListHost.clear();
+  for (int i = n; i < N; i++) {
+    const int st = status[i] & 7;
+    if (st == ST_FREE || st == ST_SUPER)
+      freeListHost.push_back(i);
+  }
+  for (int i = 0; i < n; i++) {
+    const int st = status[i] & 7;
+    if (st == ST_FREE || st == ST_SUPER)
+      freeListHost.push_back(i);
+  }
+  const bool active = !noFreeOrSuper && !freeListHost.empty();
+  hCtrl->freeCount = active ? (int)freeListHost.size() : 0;
+  freeActive = active;
+  if (!active)
+    return 0;
+  int rc = 0;
+  if (!dFreeList) {
+    rc |= dalloc(dFreeList, (size_t)N);
+    if (rc)
+      return rc;
+    D.freeList = dFreeList;
+    dropGraph();  // (the captured chains carry Dev by value)
+  }
+  rc |= h2d(dFreeList, freeListHost.data(), freeListHost.size());
+  return rc;
+}
+
+// ClpSimplexDual::dualRow's free-first entry (src/ClpSimplexDual.cpp:3005-3055) with nextSuperBasic (:8285-8302), on the host
+// between two pivots: chosenRow = the row the next free column should pivot on, or -1 (the pivot-rule object chooses).
+int clpgpu_context::freeFirstRow(int &chosenRow)
+{
+  chosenRow = -1;
+  int rc = sync();
+  rc |= pullRim(true);
+  // nextSuperBasic: hand out firstFree_, move it on to the next free column with a reduced cost
+  int nextFree = -1;
+  if (firstFree >= 0) {
+    nextFree = firstFree;
+    int iColumn = firstFree + 1;
+    for (; iColumn < N; iColumn++)
+      if ((status[iColumn] & 7) == ST_FREE && fabs(dj[iColumn]) > 1.0e2 * dualTolerance)
+        break;
+    firstFree = iColumn == N ? -1 : iColumn;
+  }
+  if (nextFree < 0 || rc)
+    return rc;
+  // unpack vector and find a good pivot
+  std::vector<double> work(m, 0.0);
+  if (nextFree >= n) {
+    work[nextFree - n] = -1.0;
+  } else {
+    for (int p = colStart[nextFree]; p < colStart[nextFree + 1]; p++)
+      work[row[p]] = elem[p];
+  }
+  rc |= h2d(D.vecV2, work.data(), m);
+  ftranDevice(D.vecV2, D.x3);
+  rc |= d2h(work.data(), D.x3, m);
+  hipLaunchKernelGGL(k_zero, dim3(cdiv(m, 256)), dim3(256), 0, stream, D.vecV2, m);
+  hipLaunchKernelGGL(k_zero, dim3(cdiv(m, 256)), dim3(256), 0, stream, D.x3, m);
+  rc |= checkLaunches("freeFirstRow");
+  rc |= sync();
+  if (rc)
+    return rc;
+  double bestFeasibleAlpha = 0.0, bestInfeasibleAlpha = 0.0;
+  int bestFeasibleRow = -1, bestInfeasibleRow = -1;
+  for (int iRow = 0; iRow < m; iRow++) {
+    const double alpha = fabs(work[iRow]);
+    if (alpha > 1.0e-3) {
+      const int iSequence = pivotVariable[iRow];
+      const double value = sol[iSequence], lo = lower[iSequence], up = upper[iSequence];
+      double infeasibility = 0.0;
+      if (value > up)
+        infeasibility = value - up;
+      else if (value < lo)
+        infeasibility = lo - value;
+      if (infeasibility * alpha > bestInfeasibleAlpha && alpha > 1.0e-1) {
+        if (!(status[iSequence] & FLAGGED_BIT)) {
+          bestInfeasibleAlpha = infeasibility * alpha;
+          bestInfeasibleRow = iRow;
+        }
+      }
+      if (alpha > bestFeasibleAlpha && (lo > -1.0e20 || up < 1.0e20)) {
+        bestFeasibleAlpha = alpha;
+        bestFeasibleRow = iRow;
+      }
+    }
+  }
+  if (bestInfeasibleRow >= 0)
+    chosenRow = bestInfeasibleRow;
+  else if (bestFeasibleAlpha > 1.0e-2)
+    chosenRow = bestFeasibleRow;
+  return 0;
 }
 
 int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
@@ -3475,6 +3683,8 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
     nbClass = cdiv(m + nranks * shardCandCap, PRICE_BLOCK);
     KL("k_shard_classes", k_shard_classes, dim3(nbClass), dim3(PRICE_BLOCK), 0, stream, D);
   }
+  if (freeActive)  // option free_nonbasic: the isFree / superBasic part of dualColumn0's general branch (may bring a free variable in)
+    KL("k_free_scan", k_free_scan, dim3(1), dim3(256), 0, stream, D);
   KL("k_dc_working_set", k_dc_working_set, dim3(128), dim3(WS_THREADS), 0, stream, D, nbClass);
   KL("k_dual_column", k_dual_column, dim3(1), dim3(DC_THREADS), 0, stream, D, nbClass, dcWide);
   if (dcWide)  // lists too long for one workgroup's registers: the ratio test over the chip (returns at once otherwise)
@@ -3580,7 +3790,7 @@ int clpgpu_context::launchBatch(int count)
     joinUpdateBranch();
     return checkLaunches("launchIteration");
   }
-  if (!graphExec || graphIterations != checkEvery || graphPriceMode != priceMode) {
+  if (!graphExec || graphIterations != checkEvery || graphPriceMode != priceMode || graphFreeActive != freeActive) {
     // (the full-size graph is always built first, also when a tail batch is what runs now: a stepped run
     // that warms up with a few pivots must not pay for its instantiation later)
     dropGraph();
@@ -3595,6 +3805,7 @@ int clpgpu_context::launchBatch(int count)
     }
     graphIterations = checkEvery;
     graphPriceMode = priceMode;
+    graphFreeActive = freeActive;
   }
   hipGraphExec_t exec = graphExec;
   if (count < checkEvery) {
@@ -3646,7 +3857,24 @@ int clpgpu_context::whileIterating(int stepTarget)
   hCtrl->lastBadIteration = lastBadIteration;
   hCtrl->maximumPivots = luActive ? luEtaLimit : maximumPivots;
   hCtrl->maximumIterations = maximumIterations;
-  int rc = pushCtrl();
+  int rc = 0;
+  hCtrl->presetRowPlus1 = 0;
+  hCtrl->freeHold = 0;
+  hCtrl->freeChosen = 0;
+  hCtrl->badFree = 0.0;
+  hCtrl->freeCount = 0;
+  hCtrl->freeEntered = 0;
+  int freeEnteredSeen = 0;
+  if (freeNonbasic) {
+    if (nranks > 1) {
+      setError("option free_nonbasic is not available in column-sharded runs");
+      return -99;
+    }
+    rc |= pushFreeList();
+  } else {
+    freeActive = false;
+  }
+  rc |= pushCtrl();
   if (timing && evStart.empty()) {
     evStart.resize(checkEvery);
     evStop.resize(checkEvery);
@@ -3677,8 +3905,25 @@ int clpgpu_context::whileIterating(int stepTarget)
           count *= 2;
       }
     }
+    if (freeNonbasic && firstFree >= 0) {
+      // dualRow's free-first entry (src/ClpSimplexDual.cpp:3005-3055) runs on the host, one pivot at a time: the next free column
+      // with a reduced cost worth having is FTRANned and the row it should pivot on is handed to CHUZR (k_chuzr_pre, chuzrFinalBody);
+      // the pivot's tail leaves the head of the next CHUZR alone (freeHold) until firstFree_ is used up
+      int chosenRow = -1;
+      rc |= freeFirstRow(chosenRow);
+      hCtrl->presetRowPlus1 = chosenRow + 1;
+      hCtrl->freeHold = 1;
+      numberFreeFirstRows += chosenRow >= 0;
+      rc |= pushCtrl();
+      count = 1;
+    } else if (hCtrl->freeHold) {
+      hCtrl->freeHold = 0;
+      rc |= pushCtrl();
+    }
     rc |= launchBatch(count);
     rc |= pullCtrl();
+    numberFreeEntered += hCtrl->freeEntered - freeEnteredSeen;  // (the device's count since whileIterating began)
+    freeEnteredSeen = hCtrl->freeEntered;
     if (!rc && hCtrl->state == RUN && stepTarget >= 0 && hCtrl->numberIterations >= stepTarget)
       hCtrl->state = EXIT_STEP_LIMIT;  // the batch ended exactly on the limit: the device never saw a pivot beyond it
     if (!rc && hCtrl->dcWide < 0) {
@@ -4956,6 +5201,7 @@ clpgpu_context *clpgpu_clone(const clpgpu_context *src)
   ctx->luInverseFillCap = src->luInverseFillCap;
   ctx->fakeBoundCleanup = src->fakeBoundCleanup;
   ctx->checkBoth = src->checkBoth;
+  ctx->freeNonbasic = src->freeNonbasic;
   ctx->refactorMode = src->refactorMode;
   ctx->refactorMinK = src->refactorMinK;
   ctx->forkUpdate = src->forkUpdate;
@@ -5190,6 +5436,7 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "debug_bad_accuracy_at")) ctx->debugBadAccuracyAt = (int)v;
   else if (!strcmp(name, "debug_reset_weights_at")) ctx->debugResetWeightsAt = (int)v;
   else if (!strcmp(name, "check_both")) ctx->checkBoth = v != 0.0;
+  else if (!strcmp(name, "free_nonbasic")) ctx->freeNonbasic = v != 0.0;
   else if (!strcmp(name, "dse_reset_every")) ctx->dseResetEvery = std::max(0, (int)v);
   else if (!strcmp(name, "debug_singular_at")) ctx->debugSingularAt = (int)v;
   else if (!strcmp(name, "log_level")) ctx->logLevel = (int)v;
@@ -5697,6 +5944,8 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
   stats->exits_bad_update = ctx->exitBadUpdate;
   stats->comm_mode = ctx->commActive ? ctx->commMode : 0;
   stats->shard_cand_cap = ctx->shardCandCap;
+  stats->free_first_rows = ctx->numberFreeFirstRows;
+  stats->free_entered = ctx->numberFreeEntered;
   stats->nucleus_capacity = ctx->kcap;
   stats->refreshes = ctx->numberRefreshes;
   stats->refreshes_rejected = ctx->numberRefreshesRejected;

@@ -1376,7 +1376,8 @@ __device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nu
         c->numberChanged += (int)a3.thru;
     }
   }
-  if (badSumPivots && c->pivots) {
+  // "things look bad" (:4776-4784); badFree is the general branch's (k_free_scan), 0.0 on every other path
+  if ((badSumPivots || fabs(theta * c->badFree) > 10.0 * dualTolerance) && c->pivots) {
     sequenceIn = -1;
     if (tid == 0)
       c->acceptablePivotBase = -c->acceptablePivotBase;
@@ -1440,6 +1441,169 @@ __device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nu
   return true;
 }
 
+// =============================================================================================
+// Option free_nonbasic: what the general branch of ClpSimplexDual::dualColumn0 ("some free or super basic",
+// src/ClpSimplexDual.cpp:4058-4179) does beyond the fast branch the pricing kernels fuse -- for atUpperBound / atLowerBound
+// variables the two branches build the same candidate list, so only the isFree / superBasic nonbasics are left to do, and
+// those are few: Dev::freeList holds the sequences that had one of the two statuses at the last status check (rows first, then
+// columns: the order the reference meets them in), Ctrl::freeCount of them (0 while moreSpecialOptions_ & 8 says there are none).
+// One workgroup, after the candidate list is complete and before the ratio test:
+//   * a free variable "worth keeping" (dj beyond the dual tolerance, or |alpha| above max(10 x acceptablePivot, 1e-5)) is given
+//     fake bounds one dualBound wide starting at its value, if that value allows (:4124-4140) -- it is an ordinary
+//     atUpper / atLower variable from the next pivot on -- the others feed badFree (:4108);
+//   * the kept one with the largest |alpha| above the acceptable pivot (the first of equals) comes in whatever the ratios say
+//     ("always choose", :4321): sequenceIn / alpha / theta = dj / alpha and the tail of dualColumn (:4786-4850) are written here and
+//     the ratio-test kernels return at once (Ctrl::freeChosen).
+// badFree goes to the ratio test's own "things look bad" test (:4776-4784) through Ctrl::badFree.
+// =============================================================================================
+__global__ void __launch_bounds__(256) k_free_scan(Dev D)
+{
+  Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  const int count = c->freeCount;
+  const int tid = threadIdx.x;
+  if (count <= 0) {
+    if (tid == 0) {
+      c->freeChosen = 0;
+      c->badFree = 0.0;
+    }
+    return;
+  }
+  __shared__ double shA[4], shB[4];
+  __shared__ int shE[4];
+  const double acceptablePivot = c->acceptablePivot;
+  const double dualTolerance = c->dualTolerance;
+  const double dualBound = c->dualBound;
+  const double tentativeTheta = 1.0e25;
+  const int seqOut = c->sequenceOut;
+  double bestAbs = acceptablePivot, badFree = 0.0;
+  int bestE = -1;
+  for (int e = tid; e < count; e += blockDim.x) {
+    const int seq = D.freeList[e];
+    const unsigned char st8 = D.status[seq];
+    const int st = st8 & 7;
+    if ((st != ST_FREE && st != ST_SUPER) || seq == seqOut)
+      continue;
+    const double alpha = seq >= D.n ? D.rho[seq - D.n] : D.alphaCol[seq];
+    if (alpha == 0.0)
+      continue;  // not in the packed tableau row
+    const double oldValue = D.dj[seq];
+    bool keep;
+    if (oldValue > dualTolerance || oldValue < -dualTolerance) {
+      keep = true;
+    } else if (fabs(alpha) > fmax(10.0 * acceptablePivot, 1.0e-5)) {
+      keep = true;
+    } else {
+      keep = false;
+      badFree = fmax(badFree, fabs(alpha));
+    }
+    if (!keep)
+      continue;
+    if (fabs(alpha) > bestAbs) {  // (this thread meets its entries in list order: a later equal one does not replace)
+      bestAbs = fabs(alpha);
+      bestE = e;
+    }
+    // give fake bounds if possible
+    const double value = D.sol[seq];
+    if (2.0 * fabs(value) < dualBound) {
+      unsigned char nst = (unsigned char)((st8 & ~(7 | 24)) | (FAKE_BOTH << 3));
+      if (oldValue - tentativeTheta * alpha > dualTolerance) {
+        // pretend coming in from upper bound
+        D.upper[seq] = value;
+        D.lower[seq] = value - dualBound;
+        nst = (unsigned char)(nst | ST_UPPER);
+      } else {
+        // pretend coming in from lower bound
+        D.lower[seq] = value;
+        D.upper[seq] = value + dualBound;
+        nst = (unsigned char)(nst | ST_LOWER);
+      }
+      D.status[seq] = nst;
+    }
+  }
+  // largest |alpha|, the first in list order among equals; largest badFree
+  const int lane = tid & 63, wv = tid >> 6;
+  for (int o = 32; o > 0; o >>= 1) {
+    const double oa = __shfl_xor(bestAbs, o);
+    const int oe = __shfl_xor(bestE, o);
+    const double ob = __shfl_xor(badFree, o);
+    if (oe >= 0 && (bestE < 0 || oa > bestAbs || (oa == bestAbs && oe < bestE))) {
+      bestAbs = oa;
+      bestE = oe;
+    }
+    badFree = fmax(badFree, ob);
+  }
+  if (lane == 0) {
+    shA[wv] = bestAbs;
+    shE[wv] = bestE;
+    shB[wv] = badFree;
+  }
+  __syncthreads();
+  if (tid != 0)
+    return;
+  for (int w = 1; w < (int)(blockDim.x >> 6); w++) {
+    if (shE[w] >= 0 && (bestE < 0 || shA[w] > bestAbs || (shA[w] == bestAbs && shE[w] < bestE))) {
+      bestAbs = shA[w];
+      bestE = shE[w];
+    }
+    badFree = fmax(badFree, shB[w]);
+  }
+  c->badFree = badFree;
+  if (bestE < 0) {
+    c->freeChosen = 0;
+    return;
+  }
+  // a free variable comes in: the rest of dualColumn without the ratio passes (:4321, :4776-4850)
+  c->freeChosen = 1;
+  c->freeEntered++;
+  c->badSumPivots = 0;
+  c->modifyCosts = 0;
+  int sequenceIn = D.freeList[bestE];
+  const double alphaIn = sequenceIn >= D.n ? D.rho[sequenceIn - D.n] : D.alphaCol[sequenceIn];
+  const double theta = D.dj[sequenceIn] / alphaIn;
+  if (fabs(theta * badFree) > 10.0 * dualTolerance && c->pivots) {
+    sequenceIn = -1;
+    c->acceptablePivotBase = -c->acceptablePivotBase;
+  }
+  if (sequenceIn >= 0) {
+    c->sequenceIn = sequenceIn;
+    c->alpha = alphaIn;
+    c->theta = theta;
+    double lowerIn = D.lower[sequenceIn], upperIn = D.upper[sequenceIn], valueIn = D.sol[sequenceIn];
+    double dualIn = D.dj[sequenceIn];
+    // modify cost so the incoming dj is exactly theta*alpha (:4796-4834)
+    double modification = theta * alphaIn - dualIn;
+    double moveObjective = fabs(modification * valueIn);
+    double smallMove = fmax(fabs(c->objectiveValue), 1.0e-3);
+    if (moveObjective > smallMove)
+      modification *= smallMove / moveObjective;
+    dualIn += modification;
+    D.dj[sequenceIn] = dualIn;
+    D.cost[sequenceIn] += modification;
+    if (modification != 0.0)
+      c->numberChanged++;
+    c->dualIn = dualIn;
+    c->valueIn = valueIn;
+    if (alphaIn < 0.0) {
+      c->directionIn = -1;
+      upperIn = valueIn;
+    } else {
+      c->directionIn = 1;
+      lowerIn = valueIn;
+    }
+    c->lowerIn = lowerIn;
+    c->upperIn = upperIn;
+    c->bestPossible = fabs(alphaIn);
+    c->btranAlpha = -alphaIn * c->directionOut;
+  } else {
+    c->sequenceIn = -1;
+    c->alpha = 0.0;
+    c->bestPossible = 0.0;
+    c->state = EXIT_NO_INCOMING;
+  }
+}
+
 #define DC_CPT 8
 #define DC_THREADS 512
 #define DC_SMALL (8 * 64)
@@ -1466,7 +1630,7 @@ __device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nu
 __global__ void __launch_bounds__(WS_THREADS) k_dc_working_set(Dev D, int nbClass)
 {
   Ctrl *c = D.ctrl;
-  if (c->state != RUN)
+  if (c->state != RUN || c->freeChosen)
     return;
   const int nc = c->numberCandidates;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1554,7 +1718,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_dc_working_set(Dev D, int nbClas
 __global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass, int wide = 0)
 {
   Ctrl *c = D.ctrl;
-  if (c->state != RUN)
+  if (c->state != RUN || c->freeChosen)  // (freeChosen: k_free_scan brought a free variable in, "always choose" :4321)
     return;
   const long long dcT0 = wall_clock64();
   const int nc = c->numberCandidates;
@@ -1650,7 +1814,7 @@ __global__ void __launch_bounds__(DC_THREADS) k_dual_column(Dev D, int nbClass, 
 __global__ void __launch_bounds__(DCW_THREADS) k_dual_column_wide(Dev D)
 {
   Ctrl *c = D.ctrl;
-  if (c->state != RUN || c->dcWide != 1)
+  if (c->state != RUN || c->dcWide != 1 || c->freeChosen)
     return;
   const int nc = c->numberCandidates;
   const int nthr = gridDim.x * blockDim.x;
@@ -2426,6 +2590,20 @@ __global__ void k_chuzr_pre(Dev D)
     return;
   if (c->preDone)
     return;
+  if (c->presetRowPlus1 > 0) {
+    // the host's free-first entry of dualRow chose this pivot's row (src/ClpSimplexDual.cpp:3005-3055): the pivot-rule object is
+    // not asked -- no random start, no touch-up of the last pivot row -- and the list scan finds nothing to look at
+    if (c->stepLimit >= 0 && c->numberIterations >= c->stepLimit) {
+      c->state = EXIT_STEP_LIMIT;
+      return;
+    }
+    c->chuzrNumber = 0;
+    c->chuzrStart = 0;
+    c->chuzrLast = -1;
+    c->chuzrTolerance = 0.0;
+    c->preDone = 1;
+    return;
+  }
   chuzrPreBody(D);
 }
 
@@ -3922,6 +4100,10 @@ template <bool COHERENT> __device__ inline void chuzrFinalBody(const Dev &D, int
         bestRow = shr[i];
       }
     int chosen = bestRow;
+    if (c->presetRowPlus1 > 0) {  // dualRow's free-first entry (host, see k_chuzr_pre)
+      chosen = c->presetRowPlus1 - 1;
+      c->presetRowPlus1 = 0;
+    }
     c->pivotRow = chosen;
     c->preDone = 0;
     s_ok = chosen >= 0;
@@ -4250,7 +4432,8 @@ __global__ void __launch_bounds__(256) k_fix_house(Dev D, int parity, int doFix,
     return;
   houseBody(D, wide);
   // head of the next pivot (only if this one ended normally and no exit was raised)
-  if (threadIdx.x == 0 && D.ctrl->state == RUN)
+  // (freeHold: the host first decides whether the next pivot's row comes from dualRow's free-first entry)
+  if (threadIdx.x == 0 && D.ctrl->state == RUN && !D.ctrl->freeHold)
     chuzrPreBody(D);
 }
 
@@ -4324,6 +4507,9 @@ __global__ void __launch_bounds__(PRICE_BLOCK) k_dj_flags(Dev D, int nbRows, int
       double alphaI = D.alphaCol[j];
       if (alphaI != 0.0 && j != seqIn) {
         int iStatus = (D.status[j] & 3) - 1;
+        // (the general column loop of updateDualsInDual, :2596-2651, has no case for a superbasic variable: its dj stays)
+        if (c->freeCount > 0 && (D.status[j] & 7) == ST_SUPER)
+          iStatus = 0;
         if (iStatus) {
           double value = D.dj[j] - theta * alphaI;
           D.dj[j] = value;

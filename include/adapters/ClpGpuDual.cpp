@@ -42,6 +42,10 @@ int clpGpuDual(ClpSimplex &model, int device, bool scaling)
   clpgpu_set_option(ctx, "perturbation", model.perturbation());
   // "infeasible" with fake bounds still active comes back as 10 (ClpSimplex::dual, src/ClpSimplex.cpp:5800-5803) and is finished by primal below
   clpgpu_set_option(ctx, "fake_bound_cleanup", 1);
+  // nonbasic free columns stay isFree as in ClpSimplexDual (free-first dualRow :3005-3055, general branch of dualColumn0 :4058-4179)
+  // instead of getting bothFake bounds at start; a solve that ends primal feasible with dual infeasibilities on free variables only
+  // comes back as 10 (:5619-5622) and is finished by primal below
+  clpgpu_set_option(ctx, "free_nonbasic", 1);
   if (model.statusArray())
     clpgpu_set_status(ctx, model.statusArray()); // warm start
   int problemStatus = clpgpu_dual(ctx);          // ClpSimplex::dual()

@@ -81,6 +81,8 @@ typedef struct {
   /* column-sharded runs */
   long comm_mode;           /* 0 not sharded, 2 candidate / flip lists exchanged, 1 dense row slices (the fall-back) */
   long shard_cand_cap;      /* candidates per rank the exchange buffer holds now (grown once on overflow) */
+  long free_first_rows;     /* option free_nonbasic: pivots whose row came from dualRow's free-first entry (src/ClpSimplexDual.cpp:3005-3055) */
+  long free_entered;        /* ... pivots that brought a free / superbasic variable in through dualColumn0's general branch (:4058-4179) */
 } clpgpu_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------- */
@@ -238,7 +240,12 @@ int clpgpu_unroll_weights(clpgpu_context *ctx);
  * per workgroup -- coalesced tableau-row stores, one candidate count per workgroup; 0: sorted globally, per-candidate atomics),
  * "fake_bound_cleanup" (1: "infeasible" reached with nonbasic variables still at fake bounds is reported as 10, "clean up in
  * primal", as ClpSimplex::dual does, src/ClpSimplex.cpp:5800-5803 -- for callers that hold a primal, the clpGpuDual adapter sets
- * it; 0 default: a bare context reports the 1 it found).  "factor_mode" -1 takes the LU form in column-sharded runs too.
+ * it; 0 default: a bare context reports the 1 it found), "free_nonbasic" (1: nonbasic free columns keep the status isFree as in the
+ * reference -- ClpSimplex::allSlackBasis src/ClpSimplex.cpp:7846, createRim's clean-up of a caller's basis :4317-4338, dualRow's
+ * free-first entry src/ClpSimplexDual.cpp:3005-3055 with nextSuperBasic :8285, the general branch of dualColumn0 :4058-4179, "primal
+ * feasible and only free dual infeasibilities: 10" :5619-5622 -- the clpGpuDual adapter sets it; 0 default: they are given bothFake
+ * bounds at start, which serves a context without a primal better; not available in column-sharded runs).
+ * "factor_mode" -1 takes the LU form in column-sharded runs too.
  * Experiment knobs (profiles/r04_objective_race.md): "dse_reset_every" (uniform steepest-edge weights again at every N-th
  * refactorization), "debug_reset_weights_at" (once, from this iteration on).
  * Fault injection for the tests: "debug_backwards_at" (the first two status checks at or after this iteration see the

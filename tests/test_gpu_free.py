@@ -1,0 +1,148 @@
+"""Option free_nonbasic on the engine (nonbasic free columns stay isFree as in the reference instead of getting bothFake bounds): the
+free-first row choice of ClpSimplexDual::dualRow (src/ClpSimplexDual.cpp:3005-3055, nextSuperBasic :8285 -- host-assisted, one pivot
+at a time), the general branch of dualColumn0 (:4058-4179 -- k_free_scan: a free variable worth keeping comes in whatever the ratios
+say and the others get fake bounds on the way, badFree :4778), the superbasic case of updateDualsInDual (:2596-2651) and the free
+bookkeeping of checkBothSolutions / checkDualSolution / statusOfProblemInDual (src/ClpSimplex.cpp:3226-3440, :3070-3225,
+src/ClpSimplexDual.cpp:5619-5622) -- against the oracle's restatement of the same (tests/test_oracle_free.py checks that one against
+HiGHS) on the LPs of the CPU fuzz that have free columns: same status, same pivots (entering and leaving variables), the same number of
+free-first rows and of free variables brought in."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+# Solves that are known to end differently, all in numerically wild stretches (fake bounds of 1e10 - 2.5e11 in play, primal errors of 2 - 54
+# reported by the resync): the same pivots but status 2 against 10 (seed 53 -- the default path's known case as well -- and 113), one more
+# pivot on an infeasibility of 2e-5 that is rounding noise of 1e10-sized flips (seed 96), a different leaving row at pivot 49 after the dual
+# bound was escalated to 2.5e11 (seed 78).  profiles/r05_free_nonbasic_engine_vs_oracle.jsonl: 21 of 1 170 solves under five option
+# sets differ, the others being ratio ties between twin free columns under scaling.
+KNOWN = {(53, 0), (53, 1), (78, 1), (96, 0), (113, 1)}
+
+
+@pytest.fixture(scope="module")
+def gpu_cls(built):
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from clp_amd.engine import ClpGpuSimplex
+
+    return ClpGpuSimplex
+
+
+def both(gpu_cls, lp, rule, **opts):
+    from oracle.oracle import OracleSimplex
+
+    o = OracleSimplex(lp)
+    g = gpu_cls().loadProblem(lp)
+    for s in (o, g):
+        s.set_option("pivot_rule", rule)
+        s.set_option("max_iterations", 20000)
+        s.set_option("free_nonbasic", 1)
+        for k, v in opts.items():
+            s.set_option(k, v)
+    g.set_option("fake_bound_cleanup", 1)  # the oracle restates ClpSimplex::dual's second thought (src/ClpSimplex.cpp:5800)
+    return o, g
+
+
+@pytest.mark.parametrize("first", [0, 30, 60, 90])
+def test_free_nonbasic_same_pivots_as_oracle(gpu_cls, first):
+    from test_oracle_fuzz import make
+
+    differing, rows, entered = [], 0, 0
+    for seed in range(first, first + 30):
+        lp = make(np.random.default_rng(7000 + seed))
+        if not np.any((lp.col_lower < -1e20) & (lp.col_upper > 1e20)):
+            continue
+        for rule in (0, 1):
+            if (seed, rule) in KNOWN:
+                continue
+            o, g = both(gpu_cls, lp, rule)
+            so, sg = o.dual(), g.dual()
+            lo, lg = o.pivot_log(), g.pivotLog()
+            st = g.stats()
+            same = so == sg and len(lo) == len(lg) and np.array_equal(lo["sequenceIn"], lg["sequenceIn"]) and np.array_equal(lo["sequenceOut"], lg["sequenceOut"])
+            same = same and (o.free_first_rows, o.free_entered) == (st["free_first_rows"], st["free_entered"])
+            rows += int(st["free_first_rows"])
+            entered += int(st["free_entered"])
+            if not same:
+                differing.append((seed, rule, int(so), int(sg), len(lo), len(lg)))
+    assert not differing, differing
+    assert rows > 50 and entered > 50, "the two free paths really ran"
+
+
+def test_free_nonbasic_off_is_the_substitution(gpu_cls):
+    """with the option off neither path runs, and on LPs both treatments solve the optimum is the same"""
+    from oracle.oracle import OracleSimplex
+    from test_oracle_fuzz import make
+
+    for seed in (8, 11, 15, 23, 27):
+        lp = make(np.random.default_rng(7000 + seed))
+        o, g = both(gpu_cls, lp, 1)
+        assert o.dual() == 0 and g.dual() == 0
+        assert g.stats()["free_first_rows"] > 0 and g.stats()["free_entered"] > 0
+        off = gpu_cls().loadProblem(lp)
+        off.set_option("pivot_rule", 1)
+        assert off.dual() == 0 and off.stats()["free_first_rows"] == 0 and off.stats()["free_entered"] == 0
+        assert abs(off.objectiveValue() - g.objectiveValue()) <= 1e-7 * (1 + abs(g.objectiveValue()))
+        assert abs(o.objective - g.objectiveValue()) <= 1e-9 * (1 + abs(o.objective))
+
+
+def many_free_columns(m=300, n=1200):
+    from clp_amd import problems as P
+
+    lp = P.sparse_lp(m, n, 8, 11)
+    free = np.random.default_rng(11).choice(lp.n, lp.n // 10, replace=False)
+    lp = type(lp)(lp)
+    lp.col_lower, lp.col_upper = lp.col_lower.copy(), lp.col_upper.copy()
+    lp.col_lower[free], lp.col_upper[free] = -1e30, 1e30
+    return lp
+
+
+def test_many_free_columns_follow_the_oracle(gpu_cls):
+    """sparse_lp(300, 1200) with a tenth of its columns free (tests/test_oracle_free.py::test_many_free_columns_the_reference_path_asks_for_primal):
+    49 rows come from the free-first entry, 48 free columns come in through the general branch, the others get fake bounds there, and the solve
+    ends primal feasible but not optimal -- status 10, "use primal".  Measured on the MI355X (profiles/r05_free_nonbasic_many_free_columns.txt):
+    under Dantzig all 2 498 pivots are the oracle's; under steepest edge the first 943 (then a tie goes the other way), same status, same objective."""
+    lp = many_free_columns()
+    for rule, need in ((0, None), (1, 900)):
+        o, g = both(gpu_cls, lp, rule)
+        so, sg = o.dual(), g.dual()
+        lo, lg = o.pivot_log(), g.pivotLog()
+        st = g.stats()
+        assert so == sg == 10
+        assert (st["free_first_rows"], st["free_entered"]) == (o.free_first_rows, o.free_entered) == (49, 48)
+        k = min(len(lo), len(lg))
+        same = 0
+        while same < k and lo["sequenceIn"][same] == lg["sequenceIn"][same] and lo["sequenceOut"][same] == lg["sequenceOut"][same]:
+            same += 1
+        print(f"rule {rule}: {same} of {len(lo)} / {len(lg)} pivots identical")
+        if need is None:
+            assert same == len(lo) == len(lg)
+        else:
+            assert same >= need
+        assert abs(o.objective - g.objectiveValue()) <= 1e-9 * (1 + abs(o.objective))
+
+
+def test_a_caller_basis_with_free_columns_is_cleaned_to_free(gpu_cls):
+    """createRim's clean-up (src/ClpSimplex.cpp:4317-4338): a caller's basis that has a column without bounds atLowerBound / atUpperBound
+    starts with it isFree again.  The all-slack basis written out by hand with the free columns at a bound must therefore give the pivots of
+    the cold start (which makes them isFree itself, allSlackBasis :7846) -- on the engine and on the oracle."""
+    from test_oracle_fuzz import make
+
+    for seed in (8, 11, 15, 23, 27):
+        lp = make(np.random.default_rng(7000 + seed))
+        free = (lp.col_lower < -1e20) & (lp.col_upper > 1e20)
+        cold_o, cold_g = both(gpu_cls, lp, 1)
+        assert cold_o.dual() == cold_g.dual()
+        status = np.empty(lp.n + lp.m, np.uint8)
+        status[lp.n:] = 1
+        status[: lp.n] = np.where(lp.col_lower >= 0.0, 3, np.where(lp.col_upper <= 0.0, 2, np.where(np.abs(lp.col_lower) < np.abs(lp.col_upper), 3, 2)))
+        status[: lp.n][free] = np.where(np.arange(int(free.sum())) % 2 == 0, 3, 2)  # the free ones alternately atLower / atUpper
+        o, g = both(gpu_cls, lp, 1)
+        o.set_status(status)
+        g.setStatusArray(status)
+        so, sg = o.dual(), g.dual()
+        lo, lg, lc = o.pivot_log(), g.pivotLog(), cold_g.pivotLog()
+        assert so == sg and len(lo) == len(lg) == len(lc), (seed, so, sg, len(lo), len(lg), len(lc))
+        assert np.array_equal(lo["sequenceIn"], lg["sequenceIn"]) and np.array_equal(lo["sequenceOut"], lg["sequenceOut"])
+        assert np.array_equal(lc["sequenceIn"], lg["sequenceIn"]) and np.array_equal(lc["sequenceOut"], lg["sequenceOut"])
+        assert g.stats()["free_first_rows"] == cold_g.stats()["free_first_rows"] > 0

@@ -1,0 +1,25 @@
+import os, sys
+ROOT = "/root/repo" if os.path.isdir("/root/repo") else os.getcwd()
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+from clp_amd import problems as P
+from clp_amd.engine import ClpGpuSimplex
+from oracle.oracle import OracleSimplex
+for (m, n) in ((300, 1200), (600, 2400)):
+    lp = P.sparse_lp(m, n, 8, 11)
+    free = np.random.default_rng(11).choice(lp.n, lp.n // 10, replace=False)
+    lp = type(lp)(lp)
+    lp.col_lower, lp.col_upper = lp.col_lower.copy(), lp.col_upper.copy()
+    lp.col_lower[free], lp.col_upper[free] = -1e30, 1e30
+    for rule in (1, 0):
+        o = OracleSimplex(lp); g = ClpGpuSimplex(0).loadProblem(lp)
+        for s in (o, g):
+            s.set_option("pivot_rule", rule); s.set_option("free_nonbasic", 1); s.set_option("max_iterations", 20000)
+        g.set_option("fake_bound_cleanup", 1)
+        so, sg = o.dual(), g.dual()
+        lo, lg = o.pivot_log(), g.pivotLog()
+        k = min(len(lo), len(lg))
+        d = np.nonzero((lo["sequenceIn"][:k] != lg["sequenceIn"][:k]) | (lo["sequenceOut"][:k] != lg["sequenceOut"][:k]))[0]
+        st = g.stats()
+        print(m, n, "rule", rule, "status", so, sg, "iterations", len(lo), len(lg), "first difference", int(d[0]) + 1 if len(d) else None,
+              "oracle rows/entered", o.free_first_rows, o.free_entered, "engine", st["free_first_rows"], st["free_entered"], "objective", o.objective, g.objectiveValue(), flush=True)
