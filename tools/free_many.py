@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Option free_nonbasic on LPs with many free columns (sparse_lp with a tenth of its columns freed: tests/test_oracle_free.py), engine against
+oracle under both pivot rules: status, pivots, first difference, free counters.  On the GPU box: python tools/free_many.py"""
 import os, sys
-ROOT = "/root/repo" if os.path.isdir("/root/repo") else os.getcwd()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from clp_amd import problems as P
