@@ -1,5 +1,6 @@
 """CPU tests of the oracle's restatement of the reference's handling of nonbasic FREE variables in the dual (option "free_nonbasic" 1; 0,
-the default, is the bothFake substitution both sides of this repo use, and what the HIP engine is compared with):
+the default, is the bothFake substitution both sides of this repo use by default; the HIP engine has the same option since round 5 and is held
+to this oracle path in tests/test_gpu_free.py):
   - ClpSimplex::allSlackBasis gives a free column the status isFree at value 0 (src/ClpSimplex.cpp:7846-7849), changeBounds leaves it alone;
   - ClpSimplex::checkBothSolutions (:3226-3440) clears moreSpecialOptions_ & 8 when a nonbasic variable sits off its bounds, counts the dual
     infeasibilities of free variables apart and sets firstFree_;
@@ -96,7 +97,7 @@ def test_many_free_columns_the_reference_path_asks_for_primal():
     """sparse_lp(300, 1200) with a tenth of its columns made free: the reference's path brings 48 of the 120 in through freePivot (49 rows chosen by
     the free-first entry), gives the others fake bounds as the general branch meets them -- [value, value + dualBound] or [value - dualBound,
     value], so they sit at a fake bound that is their starting value -- and ends primal feasible on those bounds but not optimal: status 10,
-    "use primal", which ClpSimplex::dual would then run.  The bothFake substitution (option off; what the engine does) reaches HiGHS's optimum in
+    "use primal", which ClpSimplex::dual would then run.  The bothFake substitution (option off; the default on both sides) reaches HiGHS's optimum in
     half the pivots.  Pinned as measured, as a record of what the restated path does at that density of free columns."""
     from clp_amd import problems as P
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""CPU only.  The oracle's two treatments of nonbasic free columns -- the bothFake substitution (option free_nonbasic 0: what the engine does)
+"""CPU only.  The oracle's two treatments of nonbasic free columns -- the bothFake substitution (option free_nonbasic 0: the default of oracle and engine)
 and the reference's isFree path (1) -- against HiGHS on the LPs of tests/test_oracle_fuzz.py that have free columns, and on sparse_lp with a tenth
 of the columns made free.  Output: the table kept as profiles/r04_oracle_free_nonbasic.txt.
 
