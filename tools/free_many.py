@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Option free_nonbasic on LPs with many free columns (sparse_lp with a tenth of its columns freed: tests/test_oracle_free.py), engine against
-oracle under both pivot rules: status, pivots, first difference, free counters.  On the GPU box: python tools/free_many.py"""
+oracle under both pivot rules: status, pivots, first difference, free counters.  On the GPU box: python tools/free_many.py [engine option=value ...]
+(e.g. factor_mode=1: the LU form of the factorization under the free path)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -8,6 +9,7 @@ import numpy as np, torch
 from clp_amd import problems as P
 from clp_amd.engine import ClpGpuSimplex
 from oracle.oracle import OracleSimplex
+EXTRA = dict((a.split("=")[0], float(a.split("=")[1])) for a in sys.argv[1:])
 for (m, n) in ((300, 1200), (600, 2400)):
     lp = P.sparse_lp(m, n, 8, 11)
     free = np.random.default_rng(11).choice(lp.n, lp.n // 10, replace=False)
@@ -19,6 +21,8 @@ for (m, n) in ((300, 1200), (600, 2400)):
         for s in (o, g):
             s.set_option("pivot_rule", rule); s.set_option("free_nonbasic", 1); s.set_option("max_iterations", 20000)
         g.set_option("fake_bound_cleanup", 1)
+        for k, v in EXTRA.items():
+            g.set_option(k, v)
         so, sg = o.dual(), g.dual()
         lo, lg = o.pivot_log(), g.pivotLog()
         k = min(len(lo), len(lg))
