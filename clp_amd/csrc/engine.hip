@@ -744,7 +744,7 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
     scaled = true;
     for (int j = 0; j < n; j++) {
       for (int p = colStart[j]; p < colStart[j + 1]; p++)
-        elem[p] = elem[p] * colScale[j] * rowScale[row[p]];
+        elem[p] = elem[p] * (colScale[j] * rowScale[row[p]]);  // element *= scale * rowScale[iRow], src/ClpPackedMatrix.cpp:4789-4794
       obj[j] *= colScale[j];
       scaleBoundPair(cl[j], cu[j], 1.0 / colScale[j], primalTolerance, colLower[j], colUpper[j]);
     }
@@ -762,7 +762,7 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
       dualToleranceBase = dualTolerance;
       for (int j = 0; j < n; j++) {
         for (int p = colStart[j]; p < colStart[j + 1]; p++)
-          elem[p] = elem[p] * colScale[j] * rowScale[row[p]];
+          elem[p] = elem[p] * (colScale[j] * rowScale[row[p]]);  // element *= scale * rowScale[iRow], src/ClpPackedMatrix.cpp:4789-4794
         obj[j] *= colScale[j];
         scaleBoundPair(cl[j], cu[j], 1.0 / colScale[j], primalTolerance, colLower[j], colUpper[j]);
       }

@@ -19,11 +19,11 @@
  *    (this factorization has none) and the Cbc-only branches are not restated; when the basis a singular
  *    refactorization falls back to is singular too the solve ends with status 4 (the reference factorizes "safely"
  *    with slacks put in, :5100-5117).
- *  - nonbasic free columns are given "bothFake" bounds at start by default, which is what the HIP engine does and is compared
- *    with.  Option "free_nonbasic" 1 keeps them isFree as the reference does: dualRow's free-first entry (:3005-3055), the
+ *  - nonbasic free columns are given "bothFake" bounds at start by default, on this side and on the HIP engine's.  Option
+ *    "free_nonbasic" 1 (the same option there) keeps them isFree as the reference does: dualRow's free-first entry (:3005-3055), the
  *    general branch of dualColumn0 (:4058-4179), the free branches of checkDualSolution / checkBothSolutions, firstFree_,
  *    "only free dual infeasibilities: use primal" (:5619-5622).  Checked against HiGHS (tests/test_oracle_free.py), there being
- *    no reference binary; the engine half is not written yet.
+ *    no reference binary; the engine's half is held to this one in tests/test_gpu_free.py.
  *  - gutsOfDual's "problems - try primal" exit (:537-547: a sum of primal infeasibilities 1e5 times the smallest seen) is not restated.
  *  - CoinThreadRandom lives in CoinUtils (absent); the 32-bit LCG form is used [unverifiable here].
  *
@@ -4053,13 +4053,14 @@ static int dualScaledOrNot(OrcModel *M)
   double *rlS = (double *)malloc(sizeof(double) * (size_t)(m + 1)), *ruS = (double *)malloc(sizeof(double) * (size_t)(m + 1));
   for (int j = 0; j < n; j++) {
     for (int p = M->colStart[j]; p < M->colStart[j + 1]; p++)
-      elemS[p] = M->elem[p] * cs[j] * rs[M->row[p]];
+      elemS[p] = M->elem[p] * (cs[j] * rs[M->row[p]]); /* element *= scale * rowScale[iRow], src/ClpPackedMatrix.cpp:4789-4794 */
     objS[j] = M->obj[j] * cs[j];
     scaleBounds(M->colLower[j], M->colUpper[j], 1.0 / cs[j], M->primalTolerance, &clS[j], &cuS[j]);
   }
   for (int i = 0; i < m; i++) {
     for (int q = M->rowStart[i]; q < M->rowStart[i + 1]; q++)
-      relemS[q] = M->relem[q] * rs[i] * cs[M->rcol[q]];
+      relemS[q] = M->relem[q] * (rs[i] * cs[M->rcol[q]]); /* the row copy: element *= scale * columnScale[iColumn], :5577-5584 -- the same
+                                                             product, so the two copies hold the same numbers */
     scaleBounds(M->rowLower[i], M->rowUpper[i], rs[i], M->primalTolerance, &rlS[i], &ruS[i]);
   }
   double *saveElem = M->elem, *saveRelem = M->relem, *saveCl = M->colLower, *saveCu = M->colUpper, *saveObj = M->obj,

@@ -25,6 +25,11 @@ _LIB = None
 _CACHE_DIR = os.environ.get("CLP_ORACLE_CACHE", os.path.join(os.path.dirname(_HERE), "tests", "golden", "oracle_cache"))
 _CACHE_WRITE = os.environ.get("CLP_ORACLE_CACHE_WRITE", "")  # a directory: solves longer than _CACHE_MIN_S are recorded there
 _CACHE_MIN_S = float(os.environ.get("CLP_ORACLE_CACHE_MIN_S", "2.0"))
+# Carrying records across a source change that cannot change them.  tests/golden/make_oracle_cache.py --rekey-from HASH: a first dual() that
+# finds no record under the current source hash but one under HASH copies it to its new name instead of solving again (the mature-basis
+# record alone is twenty minutes of one core).  Only for a change confined to the SCALED path of the oracle -- the guard below refuses any
+# record whose solve applied scale factors or asked for scaling -- and the change must be named in the commit that uses it.
+_REKEY_FROM = os.environ.get("CLP_ORACLE_REKEY_FROM", "")
 _SRC_HASH = None
 
 
@@ -125,7 +130,7 @@ class OracleSimplex:
         self._lp_hash = None
 
     # ---- recorded solves ----
-    def _key(self):
+    def _key(self, source=None):
         if self._lp_hash is None:
             h = hashlib.sha1()
             lp = self.lp
@@ -135,11 +140,27 @@ class OracleSimplex:
                 h.update(np.ascontiguousarray(a, dtype=dt).tobytes())
             self._lp_hash = h.hexdigest()
         h = hashlib.sha1()
-        h.update(_source_hash().encode())
+        h.update((source or _source_hash()).encode())
         h.update(self._lp_hash.encode())
         h.update(repr(sorted(self._opts.items())).encode())
         h.update(b"none" if self._start is None else self._start.tobytes())
         return h.hexdigest()
+
+    def _rekey(self, path):
+        """copy the record this solve had under the source hash _REKEY_FROM to `path`; True if there was one and it may be carried over"""
+        if not (_REKEY_FROM and _CACHE_WRITE) or self._opts.get("scaling", 0.0) != 0.0:
+            return False
+        old = os.path.join(_CACHE_DIR, self._key(_REKEY_FROM) + ".npz")
+        if not os.path.exists(old):
+            return False
+        with np.load(old) as z:
+            if int(z["counters"][8]) != 0:  # the recorded solve applied scale factors: not carried over
+                return False
+        import shutil
+
+        shutil.copyfile(old, path)
+        print(f"oracle record {os.path.basename(old)[:12]} -> {os.path.basename(path)[:12]} (m {self.m}, n {self.n})", flush=True)
+        return True
 
     def _live(self):
         """bring the C model to the state the record describes (replays the recorded solve)"""
@@ -193,7 +214,7 @@ class OracleSimplex:
         first = self._duals == 1
         if first and not live and os.path.isdir(_CACHE_DIR):
             path = os.path.join(_CACHE_DIR, self._key() + ".npz")
-            if os.path.exists(path):
+            if os.path.exists(path) or self._rekey(path):
                 try:
                     with np.load(path) as z:
                         self._rec = {k: z[k] for k in z.files}

@@ -7,11 +7,17 @@ GPU box -- same LP, same options, same starting statuses, hence the same record 
 
     python tests/golden/make_oracle_cache.py [pytest selection ...]        # default: every -m gpu test
 Records are keyed by the oracle's source hash: after a change to oracle/clp_dual_oracle.c, re-run this script (stale records are
-never read; this script deletes them)."""
+never read; this script deletes them).
+    python tests/golden/make_oracle_cache.py --rekey-from OLDHASH [pytest selection ...]
+carries the records written under the source hash OLDHASH over to the current one instead of solving again -- for a source change that
+cannot touch them (oracle/oracle.py, _REKEY_FROM: only records of unscaled solves, for a change confined to the scaled path)."""
 import collections
 import os
 import sys
 
+if len(sys.argv) > 2 and sys.argv[1] == "--rekey-from":
+    os.environ["CLP_ORACLE_REKEY_FROM"] = sys.argv[2]
+    del sys.argv[1:3]
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
@@ -117,6 +123,10 @@ def main():
     pytest.main(["-m", "gpu", "-q", "-x" if False else "--tb=no", "-p", "no:cacheprovider", *sel])
     after = set(os.listdir(OUT))
     print(f"oracle source {keep[:12]}: {len(after - before)} new record(s), {len(after)} in {OUT}")
+    if os.environ.get("CLP_ORACLE_REKEY_FROM") and len(after - before) == len(before):
+        for name in before:  # every old record has its copy under the new name: the stale ones go
+            os.remove(os.path.join(OUT, name))
+        print(f"removed the {len(before)} records of source {os.environ['CLP_ORACLE_REKEY_FROM'][:12]}")
 
 
 if __name__ == "__main__":

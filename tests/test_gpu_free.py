@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 # Solves that are known to end differently, all in numerically wild stretches (fake bounds of 1e10 - 2.5e11 in play, primal errors of 2 - 54
 # reported by the resync): the same pivots but status 2 against 10 (seed 53 -- the default path's known case as well -- and 113), one more
 # pivot on an infeasibility of 2e-5 that is rounding noise of 1e10-sized flips (seed 96), a different leaving row at pivot 49 after the dual
-# bound was escalated to 2.5e11 (seed 78).  profiles/r05_free_nonbasic_engine_vs_oracle.jsonl: 21 of 1 170 solves under five option
-# sets differ, the others being ratio ties between twin free columns under scaling.
+# bound was escalated to 2.5e11 (seed 78).  profiles/r05_free_nonbasic_engine_vs_oracle.jsonl: 13 of 1 170 solves under five option
+# sets differ, all of these kinds.
 KNOWN = {(53, 0), (53, 1), (78, 1), (96, 0), (113, 1)}
 
 
