@@ -3478,6 +3478,44 @@ void clpgpu_context::allGather(const void *send, void *recv, size_t count, int d
     commFailed = true;
 }
 
+// The row a free column should pivot on (src/ClpSimplexDual.cpp:3016-3049): `work` = the FTRANned column by basis position.  Among the
+// positions with |alpha| > 1e-3: the unflagged one with the largest infeasibility x |alpha| (and |alpha| > 0.1), else -- if its |alpha|
+// passes 0.01 -- the one with the largest |alpha| whose variable has a bound at all; strict maxima, the first of equals.  -1: none.
+// Host arithmetic only; also behind clpgpu_test_free_first_row (tests/test_free_first_row.py).
+static int freeFirstChoice(int m, const double *work, const int *pivotVariable, const double *sol, const double *lower, const double *upper,
+                           const unsigned char *status)
+{
+  double bestFeasibleAlpha = 0.0, bestInfeasibleAlpha = 0.0;
+  int bestFeasibleRow = -1, bestInfeasibleRow = -1;
+  for (int iRow = 0; iRow < m; iRow++) {
+    const double alpha = fabs(work[iRow]);
+    if (alpha > 1.0e-3) {
+      const int iSequence = pivotVariable[iRow];
+      const double value = sol[iSequence], lo = lower[iSequence], up = upper[iSequence];
+      double infeasibility = 0.0;
+      if (value > up)
+        infeasibility = value - up;
+      else if (value < lo)
+        infeasibility = lo - value;
+      if (infeasibility * alpha > bestInfeasibleAlpha && alpha > 1.0e-1) {
+        if (!(status[iSequence] & FLAGGED_BIT)) {
+          bestInfeasibleAlpha = infeasibility * alpha;
+          bestInfeasibleRow = iRow;
+        }
+      }
+      if (alpha > bestFeasibleAlpha && (lo > -1.0e20 || up < 1.0e20)) {
+        bestFeasibleAlpha = alpha;
+        bestFeasibleRow = iRow;
+      }
+    }
+  }
+  if (bestInfeasibleRow >= 0)
+    return bestInfeasibleRow;
+  if (bestFeasibleAlpha > 1.0e-2)
+    return bestFeasibleRow;
+  return -1;
+}
+
 // option free_nonbasic: the sequences that are isFree / superBasic now, rows first and then columns -- the order the general branch
 // of dualColumn0 walks the tableau row in (src/ClpSimplexDual.cpp:4066-4070) -- for k_free_scan.  Nothing becomes free or superbasic
 // between two status checks (a leaving variable goes to a bound, :2068-2094 of ClpSimplex.cpp), so the list stays a superset; the
@@ -3549,34 +3587,7 @@ int clpgpu_context::freeFirstRow(int &chosenRow)
   rc |= sync();
   if (rc)
     return rc;
-  double bestFeasibleAlpha = 0.0, bestInfeasibleAlpha = 0.0;
-  int bestFeasibleRow = -1, bestInfeasibleRow = -1;
-  for (int iRow = 0; iRow < m; iRow++) {
-    const double alpha = fabs(work[iRow]);
-    if (alpha > 1.0e-3) {
-      const int iSequence = pivotVariable[iRow];
-      const double value = sol[iSequence], lo = lower[iSequence], up = upper[iSequence];
-      double infeasibility = 0.0;
-      if (value > up)
-        infeasibility = value - up;
-      else if (value < lo)
-        infeasibility = lo - value;
-      if (infeasibility * alpha > bestInfeasibleAlpha && alpha > 1.0e-1) {
-        if (!(status[iSequence] & FLAGGED_BIT)) {
-          bestInfeasibleAlpha = infeasibility * alpha;
-          bestInfeasibleRow = iRow;
-        }
-      }
-      if (alpha > bestFeasibleAlpha && (lo > -1.0e20 || up < 1.0e20)) {
-        bestFeasibleAlpha = alpha;
-        bestFeasibleRow = iRow;
-      }
-    }
-  }
-  if (bestInfeasibleRow >= 0)
-    chosenRow = bestInfeasibleRow;
-  else if (bestFeasibleAlpha > 1.0e-2)
-    chosenRow = bestFeasibleRow;
+  chosenRow = freeFirstChoice(m, work.data(), pivotVariable.data(), sol.data(), lower.data(), upper.data(), status.data());
   return 0;
 }
 
@@ -4841,6 +4852,19 @@ int clpgpu_test_jds_layout(int m, int n, const int *colStart, const int *row, co
   memcpy(rowPair, rp.data(), rp.size() * sizeof(unsigned));
   memcpy(elemPair, ep.data(), ep.size() * sizeof(double2));
   return 0;
+}
+
+// test hook for the row choice of dualRow's free-first entry (freeFirstChoice above), host code only.  Returns the row or -1; -99 on bad
+// arguments.
+int clpgpu_test_free_first_row(int m, int numberSequences, const double *work, const int *pivotVariable, const double *solution, const double *lower,
+                               const double *upper, const unsigned char *status)
+{
+  if (m <= 0 || numberSequences <= 0 || !work || !pivotVariable || !solution || !lower || !upper || !status)
+    return -99;
+  for (int i = 0; i < m; i++)
+    if (pivotVariable[i] < 0 || pivotVariable[i] >= numberSequences)
+      return -99;
+  return freeFirstChoice(m, work, pivotVariable, solution, lower, upper, status);
 }
 
 // parity hook for the engine's restatement of ClpSimplexProgress::looping (src/ClpSolve.cpp:4438-4611), host code only: no

@@ -53,7 +53,7 @@ ABI_SYMBOLS = [
     "clpgpu_clone", "clpgpu_set_scales", "clpgpu_ftran_ft", "clpgpu_ftran_two_ft", "clpgpu_bind_rim", "clpgpu_pivot_row",
     "clpgpu_update_weights", "clpgpu_update_primal", "clpgpu_save_weights", "clpgpu_unroll_weights",
     "clpgpu_get_kernel_times", "clpgpu_dgemm", "clpgpu_test_cycle", "clpgpu_debug_price_bench", "clpgpu_test_looping",
-    "clpgpu_test_jds_layout",
+    "clpgpu_test_jds_layout", "clpgpu_test_free_first_row",
     "clpgpu_virtual_group_create", "clpgpu_virtual_group_destroy", "clpgpu_virtual_attach", "clpgpu_virtual_dual_steps",
 ]
 
@@ -483,6 +483,23 @@ def test_looping(objective, infeasibility, count, iteration, flag_bits, newest):
     if f(n, d[0], d[1], i[0], i[1], i[2], i[3], code, tol, bound, force, flagged) != 0:
         raise RuntimeError("clpgpu_test_looping failed")
     return code, tol, bound, force, flagged
+
+
+def free_first_row(work, pivot_variable, solution, lower, upper, status):
+    """The row a free column should pivot on, as the engine's host code chooses it for dualRow's free-first entry
+    (clpgpu_test_free_first_row; host code only, runs without a GPU).  -1: none."""
+    dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+    ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    bp = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+    f = lib().clpgpu_test_free_first_row
+    f.argtypes = [C.c_int, C.c_int, dp, ip, dp, dp, dp, bp]
+    f.restype = C.c_int
+    work = np.ascontiguousarray(work, dtype=np.float64)
+    rc = f(len(work), len(solution), work, np.ascontiguousarray(pivot_variable, dtype=np.int32), np.ascontiguousarray(solution, dtype=np.float64),
+           np.ascontiguousarray(lower, dtype=np.float64), np.ascontiguousarray(upper, dtype=np.float64), np.ascontiguousarray(status, dtype=np.uint8))
+    if rc == -99:
+        raise ValueError("clpgpu_test_free_first_row: bad input")
+    return rc
 
 
 def jds_layout(lp, order):

@@ -359,6 +359,12 @@ int clpgpu_test_jds_layout(int m, int n, const int *colStart, const int *row, co
                            int *tileRows, long long *records, long long capRecords, int *segStart, unsigned char *cnt, unsigned char *src,
                            unsigned char *home, unsigned *rowPair, double *elemPair);
 
+/* Test hook for the row choice of ClpSimplexDual::dualRow's free-first entry (src/ClpSimplexDual.cpp:3016-3049; option "free_nonbasic"),
+ * host code only: work[m] = the FTRANned free column by basis position, pivotVariable[m], and solution / lower / upper / status by
+ * sequence (numberSequences of them).  Returns the row the column should pivot on, -1 if none qualifies, -99 on bad arguments. */
+int clpgpu_test_free_first_row(int m, int numberSequences, const double *work, const int *pivotVariable, const double *solution, const double *lower,
+                               const double *upper, const unsigned char *status);
+
 /* CoinAbcDgemm (src/CoinAbcHelperFunctions.cpp:1658; used by CoinAbcDgetrf, src/AbcSimplexParallel.cpp:2491-2534):
  * the engine's own f64 GEMM on the matrix cores, c = beta c + alpha a b for row-major n x n host arrays.  The
  * kernel behind the Newton-Schulz steps on the explicit (tail) inverse; exposed so that tests hold it to numpy. */
