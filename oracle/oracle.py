@@ -218,6 +218,8 @@ class OracleSimplex:
                 try:
                     with np.load(path) as z:
                         self._rec = {k: z[k] for k in z.files}
+                    if os.environ.get("CLP_ORACLE_TRACE"):
+                        print(f"oracle record {os.path.basename(path)[:12]} answers a solve (m {self.m}, n {self.n})", flush=True)
                     return int(self._rec["counters"][0])
                 except Exception:  # noqa: BLE001 -- an unreadable record is no record: solve live
                     self._rec = None

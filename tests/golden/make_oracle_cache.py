@@ -8,6 +8,7 @@ GPU box -- same LP, same options, same starting statuses, hence the same record 
     python tests/golden/make_oracle_cache.py [pytest selection ...]        # default: every -m gpu test
 Records are keyed by the oracle's source hash: after a change to oracle/clp_dual_oracle.c, re-run this script (stale records are
 never read; this script deletes them).
+    python tests/golden/make_oracle_cache.py --out DIR [pytest selection ...]      # records into DIR (none are read from the committed ones)
     python tests/golden/make_oracle_cache.py --rekey-from OLDHASH [pytest selection ...]
 carries the records written under the source hash OLDHASH over to the current one instead of solving again -- for a source change that
 cannot touch them (oracle/oracle.py, _REKEY_FROM: only records of unscaled solves, for a change confined to the scaled path)."""
@@ -22,6 +23,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(HERE, "oracle_cache")
+if len(sys.argv) > 2 and sys.argv[1] == "--out":  # write (and look) somewhere else: re-solving committed records to check them
+    OUT = os.path.abspath(sys.argv[2])
+    del sys.argv[1:3]
 os.environ["CLP_ORACLE_CACHE_WRITE"] = OUT
 os.environ["CLP_ORACLE_CACHE"] = OUT
 
