@@ -157,6 +157,10 @@ struct clpgpu_context {
   int progressFlag = 0;  // ClpSimplex::progressFlag_: 1 / 2 from the device (housekeeping), 4 costs copied, 8 has looked optimal
   std::vector<double> costCopy;          // the second half of cost_ once progressFlag_ & 4 (:5381-5390)
   double bestPossibleImprovement = 0.0;  // ClpSimplex::checkDualSolution :3087
+  // gutsOfDual's "problems - try primal" exit (src/ClpSimplexDual.cpp:533-547; option "try_primal": 0 default -- a bare context has no primal to hand
+  // over to -- the clpGpuDual adapter sets 1): state across the status checks
+  int tryPrimal = 0, numberTryPrimal = 0;
+  double smallestPrimalInfeasibility = DBL_MAX, lastObjectiveValueGuts = -1.0e100;
   int numberBackwards = 0, numberLoopFlags = 0;  // statistics: backwards-objective restores, loops acted upon
   int debugBackwardsAt = -1;  // fault injection (option debug_backwards_at), as in the oracle
   int debugPoisonInverseAt = -1, numberPoisoned = 0;  // fault injection (option debug_poison_inverse_at)
@@ -2675,6 +2679,9 @@ int clpgpu_context::startup()
   progressFlag = 0;  // :461
   bestPossibleImprovement = 0.0;
   numberBackwards = numberLoopFlags = numberAccuracyRestores = numberSingularRestores = 0;
+  numberTryPrimal = 0;
+  smallestPrimalInfeasibility = DBL_MAX;  // gutsOfDual :442
+  lastObjectiveValueGuts = -1.0e100;      // :460
   forceFactorization = -1;
   lastBadIteration = -999999;
   lastCleaned = 0;
@@ -4255,6 +4262,25 @@ int clpgpu_context::run(int maxSteps)
           problemStatus = 4;
         break;
       }
+      if (!fastDualMode) {
+        // "problems - try primal" (gutsOfDual :533-547): the primal infeasibilities have grown 1e5-fold since the smallest sum seen while
+        // the objective stood still -- and either the last two recorded objectives say the solve fell off a cliff or the growth is
+        // 1e10-fold (what a runaway escalation of the dual bound looks like): status 10, the caller's primal takes over
+        if (objectiveValue > 1.0e-4 + 1.0e-9 * fabs(lastObjectiveValueGuts) + lastObjectiveValueGuts)
+          smallestPrimalInfeasibility = DBL_MAX;  // reset smallest
+        smallestPrimalInfeasibility = std::min(smallestPrimalInfeasibility, sumPrimalInfeasibilities);
+        lastObjectiveValueGuts = objectiveValue;
+        if (sumPrimalInfeasibilities > 1.0e5 && sumPrimalInfeasibilities > 1.0e5 * smallestPrimalInfeasibility
+            && ((progObjective[PROGRESS - 1] < -1.0e10 && -progObjective[PROGRESS - 2] > -1.0e5)
+                || sumPrimalInfeasibilities > 1.0e10 * smallestPrimalInfeasibility)
+            && problemStatus < 0 && tryPrimal) {
+          problemStatus = 10;
+          sumPrimalInfeasibilities = -123456789.0;  // mark as large infeasibility cost wanted
+          numberTryPrimal++;
+          if (logLevel > 0)
+            fprintf(stderr, "clpgpu: iteration %d: primal infeasibilities running away, status 10 (try primal)\n", numberIterations);
+        }
+      }
       if (problemStatus >= 0)
         break;
     }
@@ -5226,6 +5252,7 @@ clpgpu_context *clpgpu_clone(const clpgpu_context *src)
   ctx->fakeBoundCleanup = src->fakeBoundCleanup;
   ctx->checkBoth = src->checkBoth;
   ctx->freeNonbasic = src->freeNonbasic;
+  ctx->tryPrimal = src->tryPrimal;
   ctx->refactorMode = src->refactorMode;
   ctx->refactorMinK = src->refactorMinK;
   ctx->forkUpdate = src->forkUpdate;
@@ -5461,6 +5488,7 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "debug_reset_weights_at")) ctx->debugResetWeightsAt = (int)v;
   else if (!strcmp(name, "check_both")) ctx->checkBoth = v != 0.0;
   else if (!strcmp(name, "free_nonbasic")) ctx->freeNonbasic = v != 0.0;
+  else if (!strcmp(name, "try_primal")) ctx->tryPrimal = v != 0.0;
   else if (!strcmp(name, "dse_reset_every")) ctx->dseResetEvery = std::max(0, (int)v);
   else if (!strcmp(name, "debug_singular_at")) ctx->debugSingularAt = (int)v;
   else if (!strcmp(name, "log_level")) ctx->logLevel = (int)v;
@@ -5970,6 +5998,7 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
   stats->shard_cand_cap = ctx->shardCandCap;
   stats->free_first_rows = ctx->numberFreeFirstRows;
   stats->free_entered = ctx->numberFreeEntered;
+  stats->try_primal_exits = ctx->numberTryPrimal;
   stats->nucleus_capacity = ctx->kcap;
   stats->refreshes = ctx->numberRefreshes;
   stats->refreshes_rejected = ctx->numberRefreshesRejected;

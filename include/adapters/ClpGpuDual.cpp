@@ -46,6 +46,9 @@ int clpGpuDual(ClpSimplex &model, int device, bool scaling)
   // instead of getting bothFake bounds at start; a solve that ends primal feasible with dual infeasibilities on free variables only
   // comes back as 10 (:5619-5622) and is finished by primal below
   clpgpu_set_option(ctx, "free_nonbasic", 1);
+  // "problems - try primal" (gutsOfDual, src/ClpSimplexDual.cpp:533-547): a solve whose primal infeasibilities run away while the
+  // objective stands still comes back as 10 instead of escalating the dual bound further
+  clpgpu_set_option(ctx, "try_primal", 1);
   if (model.statusArray())
     clpgpu_set_status(ctx, model.statusArray()); // warm start
   int problemStatus = clpgpu_dual(ctx);          // ClpSimplex::dual()

@@ -83,6 +83,7 @@ typedef struct {
   long shard_cand_cap;      /* candidates per rank the exchange buffer holds now (grown once on overflow) */
   long free_first_rows;     /* option free_nonbasic: pivots whose row came from dualRow's free-first entry (src/ClpSimplexDual.cpp:3005-3055) */
   long free_entered;        /* ... pivots that brought a free / superbasic variable in through dualColumn0's general branch (:4058-4179) */
+  long try_primal_exits;    /* 1 if the solve ended in gutsOfDual's "problems - try primal" exit (status 10, src/ClpSimplexDual.cpp:540-547) */
 } clpgpu_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------- */
@@ -244,7 +245,10 @@ int clpgpu_unroll_weights(clpgpu_context *ctx);
  * reference -- ClpSimplex::allSlackBasis src/ClpSimplex.cpp:7846, createRim's clean-up of a caller's basis :4317-4338, dualRow's
  * free-first entry src/ClpSimplexDual.cpp:3005-3055 with nextSuperBasic :8285, the general branch of dualColumn0 :4058-4179, "primal
  * feasible and only free dual infeasibilities: 10" :5619-5622 -- the clpGpuDual adapter sets it; 0 default: they are given bothFake
- * bounds at start, which serves a context without a primal better; not available in column-sharded runs).
+ * bounds at start, which serves a context without a primal better; not available in column-sharded runs),
+ * "try_primal" (1: gutsOfDual's "problems - try primal" exit, src/ClpSimplexDual.cpp:533-547 -- primal infeasibilities that grew
+ * 1e5-fold while the objective stood still, the signature of a runaway dual-bound escalation, end the solve with status 10; the
+ * clpGpuDual adapter sets it; 0 default: a bare context has no primal to hand over to and carries on).
  * "factor_mode" -1 takes the LU form in column-sharded runs too.
  * Experiment knobs (profiles/r04_objective_race.md): "dse_reset_every" (uniform steepest-edge weights again at every N-th
  * refactorization), "debug_reset_weights_at" (once, from this iteration on).

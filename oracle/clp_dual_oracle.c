@@ -24,7 +24,6 @@
  *    general branch of dualColumn0 (:4058-4179), the free branches of checkDualSolution / checkBothSolutions, firstFree_,
  *    "only free dual infeasibilities: use primal" (:5619-5622).  Checked against HiGHS (tests/test_oracle_free.py), there being
  *    no reference binary; the engine's half is held to this one in tests/test_gpu_free.py.
- *  - gutsOfDual's "problems - try primal" exit (:537-547: a sum of primal infeasibilities 1e5 times the smallest seen) is not restated.
  *  - CoinThreadRandom lives in CoinUtils (absent); the 32-bit LCG form is used [unverifiable here].
  *
  * Build: gcc -O2 -ffp-contract=off (no FMA contraction, so the arithmetic order is the source order).
@@ -127,6 +126,8 @@ struct OrcModel {
                                                  through the general branch's freePivot */
   int debugSingularAt;            /* fault injection (option "debug_singular_at"): the refactorization of the first status check at or after
                                      this iteration is taken as singular; -1 off */
+  int tryPrimal;                  /* option "try_primal" (0 default, as the engine's): 1 = gutsOfDual's "problems - try primal" exit is there */
+  int numberTryPrimal;            /* test hook: times gutsOfDual's "problems - try primal" exit was taken (:540-547) */
   int numberSingularRestores;     /* test hook: times a singular refactorization sent the solve back to the saved basis (:5060-5125) */
   int debugBadAccuracyAt;         /* fault injection (option "debug_bad_accuracy_at"): the first status check at or after this iteration
                                      finds largestPrimalError_ = 1e16; -1 off */
@@ -265,6 +266,7 @@ OrcModel *orc_create(int m, int n, const int *colStart, const int *row, const do
   M->pivotRule = 1;
   M->checkBoth = 1; /* gutsOfSolution ends in checkBothSolutions, as in this reference version (src/ClpSimplex.cpp:762) */
   M->freeNonbasic = 0;
+  M->tryPrimal = 0;
   M->noFreeOrSuper = 1;
   M->firstFree = -1;
   M->maximumPivots = 200; /* CoinAbcBaseFactorization1.cpp:142 default */
@@ -375,6 +377,7 @@ int orc_set_option(OrcModel *M, const char *name, double v)
   else if (!strcmp(name, "debug_singular_at")) M->debugSingularAt = (int)v;
   else if (!strcmp(name, "check_both")) M->checkBoth = (int)v;
   else if (!strcmp(name, "free_nonbasic")) M->freeNonbasic = (int)v;
+  else if (!strcmp(name, "try_primal")) M->tryPrimal = (int)v;
   else return -1;
   return 0;
 }
@@ -3730,6 +3733,7 @@ static int dualOnRim(OrcModel *M)
   M->progressFlag = 0; /* :461 */
   M->bestPossibleImprovement = 0.0;
   M->numberBackwards = M->numberLoopFlags = M->numberAccuracyRestores = M->numberSingularRestores = 0;
+  M->numberTryPrimal = 0;
   M->noFreeOrSuper = 1;
   M->firstFree = -1;
   M->badFree = 0.0;
@@ -3767,6 +3771,8 @@ static int dualOnRim(OrcModel *M)
     M->problemStatus = 0; /* ClpSimplexDual::dual :664-666: nothing to do */
   int lastCleaned = 0;
   int factorType = 0;
+  double smallestPrimalInfeasibility = 1.7976931348623157e308; /* COIN_DBL_MAX, gutsOfDual :442 */
+  double lastObjectiveValue = -1.0e100;                         /* :460 */
   while (M->problemStatus < 0) {
     for (int i = 0; i < m; i++)
       M->rowWork0[i] = M->rowWork1[i] = M->rowWork2[i] = M->rowWork3[i] = 0.0;
@@ -3778,6 +3784,20 @@ static int dualOnRim(OrcModel *M)
     }
     statusOfProblemInDual(M, &lastCleaned, factorType);
     factorType = 1;
+    /* "problems - try primal" (gutsOfDual :533-547): the primal infeasibilities have grown 1e5-fold since the smallest sum seen while the
+       objective stood still -- and either the last two recorded objectives say the solve fell off a cliff or the growth is 1e10-fold */
+    if (M->objectiveValue > 1.0e-4 + 1.0e-9 * fabs(lastObjectiveValue) + lastObjectiveValue)
+      smallestPrimalInfeasibility = 1.7976931348623157e308; /* reset smallest */
+    smallestPrimalInfeasibility = dmin(smallestPrimalInfeasibility, M->sumPrimalInfeasibilities);
+    lastObjectiveValue = M->objectiveValue;
+    if (M->sumPrimalInfeasibilities > 1.0e5 && M->sumPrimalInfeasibilities > 1.0e5 * smallestPrimalInfeasibility
+        && ((progressLastObjective(M, 0) < -1.0e10 && -progressLastObjective(M, 1) > -1.0e5)
+            || M->sumPrimalInfeasibilities > 1.0e10 * smallestPrimalInfeasibility)
+        && M->problemStatus < 0 && M->tryPrimal) {
+      M->problemStatus = 10;
+      M->sumPrimalInfeasibilities = -123456789.0; /* mark as large infeasibility cost wanted */
+      M->numberTryPrimal++;
+    }
     if (M->problemStatus < 0) {
       M->problemStatus = -1;
       whileIterating(M);
@@ -4189,6 +4209,7 @@ int orc_number_backwards(const OrcModel *M) { return M->numberBackwards; }
 int orc_number_loop_flags(const OrcModel *M) { return M->numberLoopFlags; }
 int orc_number_accuracy_restores(const OrcModel *M) { return M->numberAccuracyRestores; }
 int orc_number_singular_restores(const OrcModel *M) { return M->numberSingularRestores; }
+int orc_number_try_primal(const OrcModel *M) { return M->numberTryPrimal; }
 int orc_number_free_first_rows(const OrcModel *M) { return M->numberFreeFirstRows; }
 int orc_number_free_entered(const OrcModel *M) { return M->numberFreeEntered; }
 double orc_iteration_seconds(const OrcModel *M) { return M->seconds; }

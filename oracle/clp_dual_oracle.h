@@ -93,6 +93,7 @@ int orc_number_loop_flags(const OrcModel *model);
 int orc_number_accuracy_restores(const OrcModel *model);
 /* ... and times a singular refactorization sent the solve back to the saved basis (:5060-5125) */
 int orc_number_singular_restores(const OrcModel *model);
+int orc_number_try_primal(const OrcModel *model); /* times gutsOfDual's "problems - try primal" exit was taken (src/ClpSimplexDual.cpp:540-547) */
 /* option "free_nonbasic" 1: pivot rows chosen by dualRow's free-first entry (:3005-3055), and pivots whose incoming variable was the
  * free one picked by the general branch of dualColumn0 (:4115-4122), during the last orc_dual */
 int orc_number_free_first_rows(const OrcModel *model);

@@ -85,6 +85,7 @@ def lib():
         L.orc_number_loop_flags.argtypes = [p]
         L.orc_number_accuracy_restores.argtypes = [p]
         L.orc_number_singular_restores.argtypes = [p]
+        L.orc_number_try_primal.argtypes = [p]
         L.orc_number_free_first_rows.argtypes = [p]
         L.orc_number_free_entered.argtypes = [p]
         L.orc_test_perturb.argtypes = [p, C.c_int, C.c_int, up, dp]
@@ -181,7 +182,7 @@ class OracleSimplex:
         counters = np.array([code, L.orc_number_iterations(self._h), L.orc_number_refactorizations(self._h), L.orc_number_perturbations(self._h),
                              L.orc_number_backwards(self._h), L.orc_number_loop_flags(self._h), L.orc_number_accuracy_restores(self._h),
                              L.orc_number_singular_restores(self._h), applied, L.orc_number_free_first_rows(self._h),
-                             L.orc_number_free_entered(self._h)], dtype=np.int64)
+                             L.orc_number_free_entered(self._h), L.orc_number_try_primal(self._h)], dtype=np.int64)
         return dict(counters=counters, scalars=np.array([L.orc_objective_value(self._h), L.orc_iteration_seconds(self._h)]),
                     solution=self._vec("orc_get_solution"), reduced_costs=self._vec("orc_get_reduced_costs"),
                     status=self._vec("orc_get_status", np.uint8), pivot_variable=self._vec("orc_get_pivot_variable", np.int32, self.m),
@@ -269,6 +270,11 @@ class OracleSimplex:
     def free_entered(self):
         """pivots whose incoming variable was a free one taken by the general branch of dualColumn0 (option free_nonbasic 1)"""
         return self._counter(10, "orc_number_free_entered")
+
+    @property
+    def try_primal(self):
+        """times gutsOfDual's "problems - try primal" exit ended the solve with status 10 (src/ClpSimplexDual.cpp:540-547)"""
+        return self._counter(11, "orc_number_try_primal")
 
     @property
     def accuracy_restores(self):

@@ -69,3 +69,35 @@ def test_check_both_solutions_changes_these_solves(gpu_cls):
             assert np.array_equal(lo["sequenceIn"], lg["sequenceIn"]) and np.array_equal(lo["sequenceOut"], lg["sequenceOut"])
             ends.append((so, len(lo)))
         assert ends[0] != ends[1], (seed, ends)
+
+
+def test_problems_try_primal_exit_follows_the_oracle(gpu_cls):
+    """gutsOfDual's "problems - try primal" exit (src/ClpSimplexDual.cpp:533-547; option try_primal 1, set by the clpGpuDual adapter) on the
+    fuzz LPs, where a runaway escalation of the dual bound is what triggers it (tests/test_oracle_progress.py::test_problems_try_primal_exit):
+    engine and oracle take it at the same status check -- same status 10, same pivots up to there -- and solves that do not take it are
+    unchanged.  It also ends the solves before the stretches with dual bounds of 1e17 in which the default path's known differences live."""
+    from oracle.oracle import OracleSimplex
+    from test_oracle_fuzz import make
+
+    differing, took = [], 0
+    for seed in range(0, 60):
+        lp = make(np.random.default_rng(7000 + seed))
+        for rule in (0, 1):
+            o = OracleSimplex(lp)
+            g = gpu_cls().loadProblem(lp)
+            for s in (o, g):
+                s.set_option("pivot_rule", rule)
+                s.set_option("max_iterations", 20000)
+                s.set_option("try_primal", 1)
+            g.set_option("fake_bound_cleanup", 1)
+            so, sg = o.dual(), g.dual()
+            lo, lg = o.pivot_log(), g.pivotLog()
+            same = so == sg and len(lo) == len(lg) and np.array_equal(lo["sequenceIn"], lg["sequenceIn"]) and np.array_equal(lo["sequenceOut"], lg["sequenceOut"])
+            same = same and o.try_primal == g.stats()["try_primal_exits"]
+            took += int(o.try_primal)
+            if not same:
+                differing.append((seed, rule, int(so), int(sg), len(lo), len(lg), int(o.try_primal), int(g.stats()["try_primal_exits"])))
+    print(f"{took} of 120 solves took the exit; differing: {differing}")
+    assert took >= 10  # measured: 21
+    # measured: one solve differs, and not at the exit -- seed 53 under Dantzig, the default path's known 2-against-10 ending (module docstring)
+    assert all((d[0], d[1]) in KNOWN for d in differing), differing

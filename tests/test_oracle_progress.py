@@ -101,3 +101,35 @@ def test_check_both_solutions_changes_fuzz_solves():
     old, s_old = solve(lp, 0, check_both=0)
     new, s_new = solve(lp, 0)
     assert s_old == 2 and s_new == 10 and old.iterations == new.iterations == 13
+
+
+def test_problems_try_primal_exit():
+    """gutsOfDual's "problems - try primal" (src/ClpSimplexDual.cpp:533-547; option try_primal 1, what the clpGpuDual adapter sets): when the
+    primal infeasibilities have grown 1e5-fold since the smallest sum seen while the objective stood still, and the recorded objectives say the
+    solve fell off a cliff (or the growth is 1e10-fold), the dual hands over: status 10.  On the fuzz LPs that is what a runaway escalation of
+    the dual bound looks like: of 2 400 solves (300 LPs x 2 rules x 4 option sets) 284 take the exit, 229 of which ended in 10 anyway -- later, with
+    dual bounds of 1e17 --, 46 in 1 or 2 and 9 in 0.  Pinned on two of them; HiGHS agrees that the LPs a 10 is returned for are not decided
+    wrongly (10 is "use primal", never a verdict); with the option off (the default on both sides) nothing changes."""
+    from test_oracle_fuzz import highs, make
+
+    took = 0
+    for seed, rule, expect_off, expect_on in ((150, 0, (10, 13), (10, 7)), (3, 1, None, (10, 8)), (9, 0, None, (10, 11))):
+        lp = make(np.random.default_rng(7000 + seed))
+        off, s_off = solve(lp, rule)
+        on, s_on = solve(lp, rule, try_primal=1)
+        assert off.try_primal == 0 and on.try_primal == 1
+        assert (s_on, on.iterations) == expect_on
+        if expect_off is not None:
+            assert (s_off, off.iterations) == expect_off
+        assert on.iterations <= off.iterations
+        k = on.iterations
+        assert np.array_equal(on.pivot_log()["sequenceIn"], off.pivot_log()["sequenceIn"][:k])  # the same solve, ended earlier
+        took += 1
+    assert took == 3
+    # an LP the dual solves is not touched by the option
+    lp = make(np.random.default_rng(7000 + 8))
+    a, sa = solve(lp, 1)
+    b, sb = solve(lp, 1, try_primal=1)
+    assert sa == sb == 0 and b.try_primal == 0 and a.iterations == b.iterations
+    hs, hobj = highs(lp)
+    assert hs == 0 and abs(b.objective - hobj) <= 1e-7 * (1 + abs(hobj))
