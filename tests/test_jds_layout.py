@@ -140,3 +140,26 @@ def test_layout_refuses_a_column_too_long_for_a_tile(built):
     lp = P.dense_lp(300, 64)
     order = np.arange(64, dtype=np.int32)
     assert jds_layout(lp, order) is None
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_layout_walk_on_ragged_shapes(built, seed):
+    """column counts that are no multiple of the window or the slice, empty columns, a last window with a handful of columns, rows that
+    leave the last tile nearly empty: the walk must still reproduce every column bit for bit"""
+    from clp_amd.engine import jds_layout
+
+    rng = np.random.default_rng(100 + seed)
+    m = int(rng.choice([4097, 16769, 17000, 33600]))
+    n = int(rng.integers(300, 900))
+    lp = P.sparse_lp(m, n, int(rng.integers(2, 12)), seed=200 + seed)
+    lp = type(lp)(lp)
+    # empty some columns (their entries go, the starts close up)
+    lens = np.diff(lp.col_start)
+    drop = rng.random(n) < 0.05
+    keep = np.repeat(~drop, lens)
+    lp.row, lp.elem = lp.row[keep], lp.elem[keep]
+    lp.col_start = np.concatenate([[0], np.cumsum(np.where(drop, 0, lens))]).astype(lp.col_start.dtype)
+    order = window_order(lp, rng.random(n) < 0.03)
+    lay = jds_layout(lp, order)
+    assert lay is not None and lay["tiles"] == -(-m // 16768)
+    walk(lp, order, lay, rng.standard_normal(m))
