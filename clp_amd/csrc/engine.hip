@@ -4880,6 +4880,54 @@ int clpgpu_test_jds_layout(int m, int n, const int *colStart, const int *row, co
   return 0;
 }
 
+// test hook for the host side of the basis factorization (lu_front.h luFrontFactor: Markowitz LU of the nucleus that stops at a dense
+// tail), host code only: no device is needed or touched.  C (k x k) by columns; counts[6] = { pivots, entries of L, entries of U (off the
+// pivots), order of the tail, entries of the tail, fill-in }.  With capacities of 0 only the counts come back; with room the pivots
+// (frow, fcol, fpiv), L by pivot (lStart[pivots + 1], lRow, lVal: multipliers), U by pivot (uStart, uCol, uVal: the pivot row off the
+// pivot) and the tail (tailRow, tailCol, then its entries as (slot row, slot col, value)).  A CPU test rebuilds C = L U + S from them
+// (tests/test_lu_front.py).  Returns 0, -99 on bad arguments.
+int clpgpu_test_lu_front(int k, const int *cStart, const int *cRow, const double *cVal, double stopDensity, int minTail, double threshold,
+                         long long *counts, int have, int *frow, int *fcol, double *fpiv, int *lStart, int *lRow, double *lVal, int *uStart,
+                         int *uCol, double *uVal, int *tailRow, int *tailCol, int *sRow, int *sCol, double *sVal)
+{
+  if (k <= 0 || !cStart || !cRow || !cVal || !counts)
+    return -99;
+  for (int p = 0; p < cStart[k]; p++)
+    if (cRow[p] < 0 || cRow[p] >= k)
+      return -99;
+  LuFront F;
+  luFrontFactor(k, cStart, cRow, cVal, stopDensity, minTail, threshold, 1.0e-11, F);
+  counts[0] = F.nF;
+  counts[1] = (long long)F.lRow.size();
+  counts[2] = (long long)F.uCol.size();
+  counts[3] = F.k2;
+  counts[4] = (long long)F.sVal.size();
+  counts[5] = F.fill;
+  if (!have)
+    return 0;
+  if (!frow || !fcol || !fpiv || !lStart || !lRow || !lVal || !uStart || !uCol || !uVal || !tailRow || !tailCol || !sRow || !sCol || !sVal)
+    return -99;
+  auto put = [](auto *dst, const auto &v) {
+    if (!v.empty())
+      memcpy(dst, v.data(), v.size() * sizeof(v[0]));
+  };
+  put(frow, F.frow);
+  put(fcol, F.fcol);
+  put(fpiv, F.fpiv);
+  put(lStart, F.lStart);
+  put(lRow, F.lRow);
+  put(lVal, F.lVal);
+  put(uStart, F.uStart);
+  put(uCol, F.uCol);
+  put(uVal, F.uVal);
+  put(tailRow, F.tailRow);
+  put(tailCol, F.tailCol);
+  put(sRow, F.sRow);
+  put(sCol, F.sCol);
+  put(sVal, F.sVal);
+  return 0;
+}
+
 // test hook for the row choice of dualRow's free-first entry (freeFirstChoice above), host code only.  Returns the row or -1; -99 on bad
 // arguments.
 int clpgpu_test_free_first_row(int m, int numberSequences, const double *work, const int *pivotVariable, const double *solution, const double *lower,

@@ -53,7 +53,7 @@ ABI_SYMBOLS = [
     "clpgpu_clone", "clpgpu_set_scales", "clpgpu_ftran_ft", "clpgpu_ftran_two_ft", "clpgpu_bind_rim", "clpgpu_pivot_row",
     "clpgpu_update_weights", "clpgpu_update_primal", "clpgpu_save_weights", "clpgpu_unroll_weights",
     "clpgpu_get_kernel_times", "clpgpu_dgemm", "clpgpu_test_cycle", "clpgpu_debug_price_bench", "clpgpu_test_looping",
-    "clpgpu_test_jds_layout", "clpgpu_test_free_first_row",
+    "clpgpu_test_jds_layout", "clpgpu_test_free_first_row", "clpgpu_test_lu_front",
     "clpgpu_virtual_group_create", "clpgpu_virtual_group_destroy", "clpgpu_virtual_attach", "clpgpu_virtual_dual_steps",
 ]
 
@@ -483,6 +483,43 @@ def test_looping(objective, infeasibility, count, iteration, flag_bits, newest):
     if f(n, d[0], d[1], i[0], i[1], i[2], i[3], code, tol, bound, force, flagged) != 0:
         raise RuntimeError("clpgpu_test_looping failed")
     return code, tol, bound, force, flagged
+
+
+def lu_front(matrix, stop_density=0.03, min_tail=0, threshold=0.1):
+    """The engine's host Markowitz LU of a square sparse matrix (scipy sparse or dense) up to its dense tail
+    (clpgpu_test_lu_front; host code only, runs without a GPU).  Returns a dict: pivots (frow, fcol, fpiv), L and U by
+    pivot (CSR-like starts), the tail's rows / columns and entries, fill."""
+    import scipy.sparse as sp
+
+    M = sp.csc_matrix(matrix)
+    M.sort_indices()
+    k = M.shape[0]
+    assert M.shape == (k, k)
+    cs = np.ascontiguousarray(M.indptr, dtype=np.int32)
+    cr = np.ascontiguousarray(M.indices, dtype=np.int32)
+    cv = np.ascontiguousarray(M.data, dtype=np.float64)
+    f = lib().clpgpu_test_lu_front
+    ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+    lp_ = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+    f.argtypes = [C.c_int, ip, ip, dp, C.c_double, C.c_int, C.c_double, lp_, C.c_int] + [C.c_void_p] * 14
+    f.restype = C.c_int
+    counts = np.zeros(6, np.int64)
+    if f(k, cs, cr, cv, float(stop_density), int(min_tail), float(threshold), counts, 0, *([None] * 14)) != 0:
+        raise ValueError("clpgpu_test_lu_front: bad input")
+    nF, nL, nU, k2, nS, fill = (int(x) for x in counts)
+    i32, f64 = (lambda n: np.zeros(max(n, 1), np.int32)), (lambda n: np.zeros(max(n, 1), np.float64))
+    frow, fcol, fpiv = i32(nF), i32(nF), f64(nF)
+    lStart, lRow, lVal = i32(nF + 1), i32(nL), f64(nL)
+    uStart, uCol, uVal = i32(nF + 1), i32(nU), f64(nU)
+    tailRow, tailCol = i32(k2), i32(k2)
+    sRow, sCol, sVal = i32(nS), i32(nS), f64(nS)
+    arrs = [frow, fcol, fpiv, lStart, lRow, lVal, uStart, uCol, uVal, tailRow, tailCol, sRow, sCol, sVal]
+    if f(k, cs, cr, cv, float(stop_density), int(min_tail), float(threshold), counts, 1, *[a.ctypes.data for a in arrs]) != 0:
+        raise ValueError("clpgpu_test_lu_front: bad input")
+    return {"k": k, "pivots": nF, "tail": k2, "fill": fill, "frow": frow[:nF], "fcol": fcol[:nF], "fpiv": fpiv[:nF], "lStart": lStart[: nF + 1],
+            "lRow": lRow[:nL], "lVal": lVal[:nL], "uStart": uStart[: nF + 1], "uCol": uCol[:nU], "uVal": uVal[:nU], "tailRow": tailRow[:k2],
+            "tailCol": tailCol[:k2], "sRow": sRow[:nS], "sCol": sCol[:nS], "sVal": sVal[:nS]}
 
 
 def free_first_row(work, pivot_variable, solution, lower, upper, status):

@@ -363,6 +363,16 @@ int clpgpu_test_jds_layout(int m, int n, const int *colStart, const int *row, co
                            int *tileRows, long long *records, long long capRecords, int *segStart, unsigned char *cnt, unsigned char *src,
                            unsigned char *home, unsigned *rowPair, double *elemPair);
 
+/* Test hook for the host side of the basis factorization (clp_amd/csrc/lu_front.h: the Markowitz LU of the nucleus that stops at a
+ * dense tail -- what stands in for CoinAbcBaseFactorization::factorSparse, src/CoinAbcBaseFactorization2.cpp:18, and wantToGoDense,
+ * src/CoinAbcBaseFactorization1.cpp:2409-2462), host code only.  C is k x k by columns; counts[6] = pivots, entries of L, entries of U off
+ * the pivots, order of the tail, entries of the tail, fill-in.  have = 0: counts only; 1: the arrays too (sizes from a first call):
+ * frow / fcol / fpiv [pivots], lStart / uStart [pivots + 1], lRow / lVal, uCol / uVal, tailRow / tailCol [tail], sRow / sCol / sVal.
+ * Returns 0, -99 on bad arguments. */
+int clpgpu_test_lu_front(int k, const int *cStart, const int *cRow, const double *cVal, double stopDensity, int minTail, double threshold,
+                         long long *counts, int have, int *frow, int *fcol, double *fpiv, int *lStart, int *lRow, double *lVal, int *uStart,
+                         int *uCol, double *uVal, int *tailRow, int *tailCol, int *sRow, int *sCol, double *sVal);
+
 /* Test hook for the row choice of ClpSimplexDual::dualRow's free-first entry (src/ClpSimplexDual.cpp:3016-3049; option "free_nonbasic"),
  * host code only: work[m] = the FTRANned free column by basis position, pivotVariable[m], and solution / lower / upper / status by
  * sequence (numberSequences of them).  Returns the row the column should pivot on, -1 if none qualifies, -99 on bad arguments. */
