@@ -112,3 +112,33 @@ def test_full_elimination_solves_like_scipy(built):
     ref = spla.spsolve(C, b)
     assert np.max(np.abs(x - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref)))
     assert np.max(np.abs(C @ x - b)) <= 1e-10 * max(1.0, np.max(np.abs(b)))
+
+
+def test_front_at_the_mature_basis_of_config_4(built):
+    """The nucleus the bench's timed window starts from (tests/golden/basis_sparse_30000.npy: order 10 514, 115 766 entries): the front / tail
+    splits the engine reports on the GPU for it (tests/test_gpu_mature_parity.py: 4 869 + 5 645 under the default stop density 0.03,
+    4 267 + 6 247 under 0.012) come out of the host code alone, and C = L U + S holds entry for entry (sparse arithmetic: the dense form would
+    be 0.9 GB)."""
+    import os
+
+    from clp_amd.engine import lu_front
+
+    lp = P.sparse_lp()
+    here = os.path.dirname(os.path.abspath(__file__))
+    status = np.load(os.path.join(here, "golden", "basis_sparse_30000.npy")) & 7
+    C = nucleus(lp, status)
+    assert C.shape == (10514, 10514) and C.nnz == 115766
+    for stop, split in ((0.03, (4869, 5645)), (0.012, (4267, 6247))):
+        F = lu_front(C, stop, 0, 0.1)
+        assert (F["pivots"], F["tail"]) == split
+        k, nF = F["k"], F["pivots"]
+        lcount, ucount = np.diff(F["lStart"]), np.diff(F["uStart"])
+        L = sp.csr_matrix((np.concatenate([np.ones(nF), F["lVal"]]), (np.concatenate([F["frow"], F["lRow"]]),
+                                                                     np.concatenate([np.arange(nF), np.repeat(np.arange(nF), lcount)]))), shape=(k, nF))
+        U = sp.csr_matrix((np.concatenate([F["fpiv"], F["uVal"]]), (np.concatenate([np.arange(nF), np.repeat(np.arange(nF), ucount)]),
+                                                                    np.concatenate([F["fcol"], F["uCol"]]))), shape=(nF, k))
+        S = sp.csr_matrix((F["sVal"], (F["tailRow"][F["sRow"]], F["tailCol"][F["sCol"]])), shape=(k, k))
+        D = (L @ U + S - C).tocoo()
+        err = float(np.max(np.abs(D.data))) if D.nnz else 0.0
+        print(f"stop density {stop}: front {nF} + tail {F['tail']}, fill {F['fill']}, tail entries {len(F['sVal'])} ({len(F['sVal']) / F['tail'] ** 2:.2f} dense), max |L U + S - C| {err:.1e}")
+        assert err < 1e-10
