@@ -97,6 +97,14 @@ struct Ctrl {
   int presetRowPlus1, freeHold, freeCount, freeChosen;
   double badFree;
   int freeEntered, freePad;
+  // ClpDualRowSteepest::pivotRow's partial scan and second call (src/ClpDualRowSteepest.cpp:258-278, :329-346): steepestMode = mode_
+  // (option steepest_mode, 3 = the constructor's default); factorElements = what stands for factorization()->numberElements() as of the
+  // last factorization (host, option steepest_elements); chuzrWanted = numberWanted of this call, chuzrTolChanged = toleranceChanged;
+  // counters: calls that stopped on numberWanted / second calls
+  int steepestMode, chuzrWanted, chuzrTolChanged, chuzrRecalls;
+  long long factorElements;
+  int chuzrPartialScans, chuzrFloor;  // chuzrFloor: the 2000 of :260-276 (option debug_chuzr_floor)
+  double debugToleranceFactor;  // option debug_tolerance_factor (fault injection for the changed tolerance of CHUZR); 0 off
   double tailAlpha, tailValueOut;  // w[pivotRow] / sol[sequenceOut] handed to the serial tail of k_ftran_scatter3  // this pivot's primal update completed: its list appends may be scattered  // unordered append count of k_dj_flags (ordered later by k_flip_apply2)
 };
 

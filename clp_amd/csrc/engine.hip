@@ -160,6 +160,12 @@ struct clpgpu_context {
   // gutsOfDual's "problems - try primal" exit (src/ClpSimplexDual.cpp:533-547; option "try_primal": 0 default -- a bare context has no primal to hand
   // over to -- the clpGpuDual adapter sets 1): state across the status checks
   int tryPrimal = 0, numberTryPrimal = 0;
+  // ClpDualRowSteepest::mode_ (src/ClpDualRowSteepest.hpp:118: the constructor's default is 3) and what stands for
+  // factorization()->numberElements() in its mode 3 (src/ClpDualRowSteepest.cpp:262): 0 = entries of the basic structural columns (the
+  // count of an LU without fill; what the oracle computes too), 1 = this factorization's own stored entries
+  int steepestMode = 3, steepestElements = 0, chuzrFloor = 2000, debugLastBadIteration = -999999;
+  long long pendingFactorElements = 0, luOwnElements = 0;
+  double debugToleranceFactor = 0.0;
   double smallestPrimalInfeasibility = DBL_MAX, lastObjectiveValueGuts = -1.0e100;
   int numberBackwards = 0, numberLoopFlags = 0;  // statistics: backwards-objective restores, loops acted upon
   int debugBackwardsAt = -1;  // fault injection (option debug_backwards_at), as in the oracle
@@ -1670,6 +1676,11 @@ int clpgpu_context::factorizeOnce()
   }
   const int k = (int)kcol.size();
   numberRefactorizations++;
+  // what ClpDualRowSteepest::pivotRow will read as factorization()->numberElements() (option steepest_elements 0; 1: set below from
+  // the form that was built)
+  pendingFactorElements = 0;
+  for (int c = 0; c < k; c++)
+    pendingFactorElements += colStart[kcol[c] + 1] - colStart[kcol[c]];
   // (column-sharded runs too: the factorization, both solves and the eta file live in row space and are replicated on every rank --
   // only pricing, the candidate and flip lists and the reduced costs of the columns are sharded, and the two exchanges sit between
   // kernels the LU chain does not touch; tests/test_gpu_virtual_ranks.py runs 2 and 4 loopback ranks in LU mode against the
@@ -1686,6 +1697,8 @@ int clpgpu_context::factorizeOnce()
     dropGraph();  // the chain of a pivot differs between the two forms
   if (wantLu) {
     const int lrc = factorizeLu(kcol, rrows, localOfRow);
+    if (lrc == 0)
+      hCtrl->factorElements = steepestElements ? luOwnElements : pendingFactorElements;
     if (lrc != -7)
       return lrc;
     luFillSkip = 8;
@@ -1751,6 +1764,7 @@ int clpgpu_context::factorizeOnce()
   hCtrl->k = k;
   hCtrl->pivots = 0;
   hCtrl->kcap = kcap;
+  hCtrl->factorElements = steepestElements ? (long long)k * k : pendingFactorElements;
   return rc;
 }
 
@@ -1820,6 +1834,9 @@ void clpgpu_context::preparePlugin()
   h->maximumPivots = maximumPivots;
   h->maximumIterations = 2147483647;
   h->lastBadIteration = lastBadIteration;
+  h->steepestMode = steepestMode;
+  h->chuzrFloor = chuzrFloor;
+  h->debugToleranceFactor = debugToleranceFactor;
   h->acceptablePivotBase = acceptablePivot;
   h->kcap = kcap;
   if (!started) {
@@ -2683,7 +2700,7 @@ int clpgpu_context::startup()
   smallestPrimalInfeasibility = DBL_MAX;  // gutsOfDual :442
   lastObjectiveValueGuts = -1.0e100;      // :460
   forceFactorization = -1;
-  lastBadIteration = -999999;
+  lastBadIteration = debugLastBadIteration;  // -999999 unless option debug_last_bad_iteration (fault injection for CHUZR's changed tolerance)
   lastCleaned = 0;
   factorType = 0;
   weightsInitialized = false;
@@ -2717,6 +2734,9 @@ int clpgpu_context::startup()
   hCtrl->stepLimit = -1;
   hCtrl->logCapacity = logCapacity;
   hCtrl->pivotRule = pivotRule;
+  hCtrl->steepestMode = steepestMode;
+  hCtrl->chuzrFloor = chuzrFloor;
+  hCtrl->debugToleranceFactor = debugToleranceFactor;
   hCtrl->lastBadIteration = lastBadIteration;
   hCtrl->seed = seed;
   hCtrl->acceptablePivotBase = acceptablePivot;
@@ -5301,6 +5321,11 @@ clpgpu_context *clpgpu_clone(const clpgpu_context *src)
   ctx->checkBoth = src->checkBoth;
   ctx->freeNonbasic = src->freeNonbasic;
   ctx->tryPrimal = src->tryPrimal;
+  ctx->steepestMode = src->steepestMode;
+  ctx->steepestElements = src->steepestElements;
+  ctx->chuzrFloor = src->chuzrFloor;
+  ctx->debugToleranceFactor = src->debugToleranceFactor;
+  ctx->debugLastBadIteration = src->debugLastBadIteration;
   ctx->refactorMode = src->refactorMode;
   ctx->refactorMinK = src->refactorMinK;
   ctx->forkUpdate = src->forkUpdate;
@@ -5537,6 +5562,11 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "check_both")) ctx->checkBoth = v != 0.0;
   else if (!strcmp(name, "free_nonbasic")) ctx->freeNonbasic = v != 0.0;
   else if (!strcmp(name, "try_primal")) ctx->tryPrimal = v != 0.0;
+  else if (!strcmp(name, "steepest_mode")) ctx->steepestMode = std::max(0, std::min((int)v, 3));
+  else if (!strcmp(name, "steepest_elements")) ctx->steepestElements = v != 0.0;
+  else if (!strcmp(name, "debug_last_bad_iteration")) ctx->debugLastBadIteration = (int)v;
+  else if (!strcmp(name, "debug_tolerance_factor")) ctx->debugToleranceFactor = v;
+  else if (!strcmp(name, "debug_chuzr_floor")) ctx->chuzrFloor = std::max(1, (int)v);
   else if (!strcmp(name, "dse_reset_every")) ctx->dseResetEvery = std::max(0, (int)v);
   else if (!strcmp(name, "debug_singular_at")) ctx->debugSingularAt = (int)v;
   else if (!strcmp(name, "log_level")) ctx->logLevel = (int)v;
@@ -6047,6 +6077,9 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
   stats->free_first_rows = ctx->numberFreeFirstRows;
   stats->free_entered = ctx->numberFreeEntered;
   stats->try_primal_exits = ctx->numberTryPrimal;
+  stats->chuzr_partial_scans = ctx->hCtrl->chuzrPartialScans;
+  stats->chuzr_recalls = ctx->hCtrl->chuzrRecalls;
+  stats->factor_elements = (long)ctx->hCtrl->factorElements;
   stats->nucleus_capacity = ctx->kcap;
   stats->refreshes = ctx->numberRefreshes;
   stats->refreshes_rejected = ctx->numberRefreshesRejected;

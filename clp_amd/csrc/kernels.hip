@@ -2527,10 +2527,12 @@ __device__ void houseBody(Dev D, int skipColumns = 0)
 // =============================================================================================
 
 // ---- CHUZR split in three so the list scan uses the whole chip ---------------------------------
-__device__ void chuzrPreBody(Dev D)
+// secondCall: the call of src/ClpDualRowSteepest.cpp:338-346 -- everything again (the touch-up of the last pivot row, another random
+// number), with largestDualError_ 0, i.e. without the changed tolerance
+__device__ void chuzrPreBody(Dev D, bool secondCall = false)
 {
   Ctrl *c = D.ctrl;
-  if (c->stepLimit >= 0 && c->numberIterations >= c->stepLimit) {
+  if (!secondCall && c->stepLimit >= 0 && c->numberIterations >= c->stepLimit) {
     c->state = EXIT_STEP_LIMIT;
     return;
   }
@@ -2559,19 +2561,54 @@ __device__ void chuzrPreBody(Dev D)
         D.infeas[last] = REALLY_TINY;
       }
     }
-    if (c->numberIterations < c->lastBadIteration + 200) {
-      if (c->largestDualError > c->largestPrimalError)
+    int toleranceChanged = 0;
+    if (!secondCall && c->numberIterations < c->lastBadIteration + 200) {
+      if (c->largestDualError > c->largestPrimalError) {
         tolerance *= fmin(c->largestDualError / c->largestPrimalError, 1000.0);
+        toleranceChanged = 1;
+      } else if (c->debugToleranceFactor > 0.0) {
+        // fault injection (option debug_tolerance_factor): which of two rounding-noise errors is larger is not reproducible between two
+        // factorizations, so tests arm this branch with a factor of their own
+        tolerance *= c->debugToleranceFactor;
+        toleranceChanged = 1;
+      }
     }
     int number = c->numberInfeasible;
+    // numberWanted (src/ClpDualRowSteepest.cpp:258-278): how many entries above the tolerance one call looks at
+    int numberWanted;
+    if (c->steepestMode < 2) {
+      numberWanted = number + 1;
+    } else if (c->steepestMode == 2) {
+      numberWanted = max(c->chuzrFloor, number / 8);
+    } else {
+      double ratio = (double)c->factorElements / (double)D.m;
+      numberWanted = max(c->chuzrFloor, number / 8);
+      if (ratio < 1.0) {
+        numberWanted = max(c->chuzrFloor, number / 20);
+      } else if (ratio > 10.0) {
+        ratio = number * (ratio / 80.0);
+        if (ratio > number)
+          numberWanted = number + 1;
+        else
+          numberWanted = max(c->chuzrFloor, (int)ratio);
+      }
+    }
+    if (c->largestPrimalError > 1.0e-3)
+      numberWanted = number + 1;  // "be safe"
+    if (numberWanted <= number)
+      c->chuzrPartialScans++;
     double dstart = ((double)number) * randomDouble(c);
     c->chuzrNumber = number;
     c->chuzrStart = (int)dstart;
+    c->chuzrWanted = numberWanted;
+    c->chuzrTolChanged = toleranceChanged;
   } else {
     if (c->largestPrimalError > 1.0e-8)
       tolerance *= c->largestPrimalError / 1.0e-8;
     c->chuzrNumber = D.m;
     c->chuzrStart = 0;
+    c->chuzrWanted = D.m + 1;
+    c->chuzrTolChanged = 0;
   }
   c->chuzrTolerance = tolerance;
   c->chuzrLast = last;
@@ -2608,7 +2645,183 @@ __global__ void k_chuzr_pre(Dev D)
 }
 
 #define CHZ_ITEMS 2
-template <bool COHERENT> __device__ inline void chuzrFinalBody(const Dev &D, int nblocks, int wide);
+// ---- the list scan of ClpDualRowSteepest::pivotRow in ITS order, by one workgroup (src/ClpDualRowSteepest.cpp:279-335) ----
+// Used where the order decides more than ties: the partial scan of modes 2 / 3 (the call stops after numberWanted entries above the
+// tolerance, counted from the random start) and the second call of :338-346.  The list is walked in rank order (rank 0 = the random
+// start) a chunk of CHZ_CHUNK entries at a time; the dependent loads of a chunk (list -> row -> basic variable -> value and bounds) are
+// requested level by level for all of it and the result staged in LDS.  A chunk without a flagged candidate and without the last pivot
+// row is finished in parallel: the entries above the tolerance are counted by ballots, the first `remaining` of them are eligible, the
+// best ratio among those (first of equals) is compared with what the earlier chunks left.  The two exceptions make the count depend on
+// the running maximum (a flagged candidate that would have been chosen hands its ticket back, the last pivot row put off by
+// `continue` never takes one), so a chunk that holds one is walked by one thread from the staged copy with the reference's own
+// statements.
+#define CHZ_CHUNK_ITEMS 4
+#define CHZ_CHUNK (256 * CHZ_CHUNK_ITEMS)
+struct ChzStage {
+  double value[CHZ_CHUNK], weight[CHZ_CHUNK];
+  int row[CHZ_CHUNK];
+  unsigned char flag[CHZ_CHUNK];  // 1 above the tolerance, 2 flagged, 4 really infeasible, 8 the last pivot row
+  int waveCount[CHZ_CHUNK_ITEMS * 4];
+  double shv[4];
+  int shk[4], shr[4];
+  double best;  // ratio of the chosen row so far (the reference's `largest`)
+  int bestKey, bestRow, remaining, special;
+};
+__device__ inline void chuzrOrderedScan(const Dev &D, ChzStage *S, double tolerance, int number, int start, int last, int wanted)
+{
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (t == 0) {
+    S->best = 0.0;
+    S->bestKey = -1;
+    S->bestRow = -1;
+    S->remaining = wanted;
+  }
+  __syncthreads();
+  for (int base = 0; base < number; base += CHZ_CHUNK) {
+    int iRow[CHZ_CHUNK_ITEMS], iSeq[CHZ_CHUNK_ITEMS];
+    double value[CHZ_CHUNK_ITEMS], weight[CHZ_CHUNK_ITEMS];
+#pragma unroll
+    for (int q = 0; q < CHZ_CHUNK_ITEMS; q++) {
+      const int rank = base + q * 256 + t;
+      int i = start + rank;
+      if (i >= number)
+        i -= number;
+      iRow[q] = rank < number ? D.infIndex[i] : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < CHZ_CHUNK_ITEMS; q++) {
+      const int r = iRow[q] >= 0 ? iRow[q] : 0;
+      value[q] = D.infeas[r];
+      weight[q] = D.weights[r];
+      iSeq[q] = D.pivotVariable[r];
+    }
+    unsigned char fl[CHZ_CHUNK_ITEMS];
+    int special = 0;
+#pragma unroll
+    for (int q = 0; q < CHZ_CHUNK_ITEMS; q++) {
+      const unsigned char st = D.status[iSeq[q]];
+      const double sv = D.sol[iSeq[q]], up = D.upper[iSeq[q]], lo = D.lower[iSeq[q]];
+      unsigned char f = 0;
+      if (iRow[q] >= 0 && value[q] > tolerance) {
+        f = 1;
+        if (st & FLAGGED_BIT)
+          f |= 2;
+        if (sv > up + tolerance || sv < lo - tolerance)
+          f |= 4;
+        if (iRow[q] == last)
+          f |= 8;
+        if (f & 10)
+          special = 1;
+      }
+      fl[q] = f;
+      weight[q] = fmin(weight[q], 1.0e50);
+      const int slot = q * 256 + t;
+      S->value[slot] = value[q];
+      S->weight[slot] = weight[q];
+      S->row[slot] = iRow[q];
+      S->flag[slot] = f;
+      const unsigned long long above = __ballot(f & 1);
+      if (lane == 0)
+        S->waveCount[q * 4 + wv] = __popcll(above);
+    }
+    special = __syncthreads_or(special);
+    const int remaining = S->remaining;
+    if (!special) {
+      double best = 0.0;
+      int bestKey = -1, bestRow = -1, seen = 0;
+#pragma unroll
+      for (int q = 0; q < CHZ_CHUNK_ITEMS; q++) {
+        int before = 0;
+        for (int w = 0; w < q * 4 + wv; w++)
+          before += S->waveCount[w];
+        const unsigned long long above = __ballot(fl[q] & 1);
+        before += __popcll(above & ((1ull << lane) - 1ull));
+        if ((fl[q] & 5) == 5 && before < remaining) {
+          const double ratio = value[q] / weight[q];
+          const int rank = base + q * 256 + t;
+          if (ratio > best || (ratio == best && bestKey >= 0 && rank < bestKey)) {
+            best = ratio;
+            bestKey = rank;
+            bestRow = iRow[q];
+          }
+        }
+      }
+      for (int w = 0; w < CHZ_CHUNK_ITEMS * 4; w++)
+        seen += S->waveCount[w];
+      for (int o = 32; o > 0; o >>= 1) {
+        double ov = __shfl_down(best, o);
+        int ok = __shfl_down(bestKey, o);
+        int orow = __shfl_down(bestRow, o);
+        if (ok >= 0 && (bestKey < 0 || ov > best || (ov == best && ok < bestKey))) {
+          best = ov;
+          bestKey = ok;
+          bestRow = orow;
+        }
+      }
+      if (lane == 0) {
+        S->shv[wv] = best;
+        S->shk[wv] = bestKey;
+        S->shr[wv] = bestRow;
+      }
+      __syncthreads();
+      if (t == 0) {
+        for (int i = 1; i < 4; i++)
+          if (S->shk[i] >= 0 && (bestKey < 0 || S->shv[i] > best || (S->shv[i] == best && S->shk[i] < bestKey))) {
+            best = S->shv[i];
+            bestKey = S->shk[i];
+            bestRow = S->shr[i];
+          }
+        // value > largest * weight (:296): a later chunk only wins with a strictly larger ratio
+        if (bestKey >= 0 && best > S->best) {
+          S->best = best;
+          S->bestKey = bestKey;
+          S->bestRow = bestRow;
+        }
+        S->remaining = seen >= remaining ? 0 : remaining - seen;
+      }
+    } else if (t == 0) {
+      double largest = S->best;
+      int left = remaining, chosenKey = S->bestKey, chosenRow = S->bestRow;
+      const int count = min(CHZ_CHUNK, number - base);
+      for (int j = 0; j < count; j++) {
+        const unsigned char f = S->flag[j];
+        if (!(f & 1))
+          continue;
+        double v = S->value[j];
+        const double weight = S->weight[j];
+        if (v > largest * weight) {
+          if (f & 8) {
+            if (v * 1.0e-10 < largest * weight)
+              continue;
+            else
+              v *= 1.0e-10;
+          }
+          if (!(f & 2)) {
+            if (f & 4) {
+              chosenRow = S->row[j];
+              chosenKey = base + j;
+              largest = v / weight;
+            }
+          } else {
+            left++;
+          }
+        }
+        left--;
+        if (!left)
+          break;
+      }
+      S->best = largest;
+      S->bestKey = chosenKey;
+      S->bestRow = chosenRow;
+      S->remaining = left;
+    }
+    __syncthreads();
+    if (S->remaining <= 0)
+      break;
+  }
+}
+
+template <bool COHERENT> __device__ inline void chuzrFinalBody(const Dev &D, int nblocks, int wide, ChzStage *S);
 // fuseFinal >= 0: the last workgroup to finish also makes the final selection and builds the BTRAN
 // t-vector (no separate launch); the value is the wide-row flag of that stage
 __global__ void __launch_bounds__(256) k_chuzr_scan(Dev D, int fuseFinal = -1)
@@ -2618,10 +2831,28 @@ __global__ void __launch_bounds__(256) k_chuzr_scan(Dev D, int fuseFinal = -1)
     return;
   __shared__ double shv[4];
   __shared__ int shk[4], shr[4];
+  __shared__ ChzStage stage;
   const double tolerance = c->chuzrTolerance;
   const int number = c->chuzrNumber, start = c->chuzrStart, last = c->chuzrLast;
   double best = 0.0;
   int bestKey = -1, bestRow = -1;
+  if (c->pivotRule != 0 && c->chuzrWanted <= number) {
+    // partial scan (modes 2 / 3): the order of the list decides what is looked at -- workgroup 0 walks it, the others report nothing
+    if (blockIdx.x == 0) {
+      chuzrOrderedScan(D, &stage, tolerance, number, start, last, c->chuzrWanted);
+      best = stage.best;
+      bestKey = stage.bestKey;
+      bestRow = stage.bestRow;
+    }
+    if (threadIdx.x == 0) {
+      stc(&D.chzBest[blockIdx.x], best);
+      stc(&D.chzKey[blockIdx.x], bestKey);
+      stc(&D.chzRow[blockIdx.x], bestRow);
+    }
+    if (fuseFinal >= 0 && lastBlockDone(D.ctrl, 3))
+      chuzrFinalBody<true>(D, gridDim.x, fuseFinal, &stage);
+    return;
+  }
   const int base = blockIdx.x * (256 * CHZ_ITEMS);
   // the chain list entry -> row -> basic variable -> its value and bounds is three dependent loads
   // deep: every level is requested for all of this thread's items before anything is used
@@ -2713,7 +2944,7 @@ __global__ void __launch_bounds__(256) k_chuzr_scan(Dev D, int fuseFinal = -1)
     stc(&D.chzRow[blockIdx.x], bestRow);
   }
   if (fuseFinal >= 0 && lastBlockDone(D.ctrl, 3))
-    chuzrFinalBody<true>(D, gridDim.x, fuseFinal);
+    chuzrFinalBody<true>(D, gridDim.x, fuseFinal, &stage);
 }
 
 // iteration BTRAN, back end: rho[i] = slack part or sum of the gemvT partials, flush tiny, piNeg,
@@ -4055,12 +4286,12 @@ __global__ void __launch_bounds__(256) k_shard_merge_flips(Dev D, const double *
 
 // CHUZR final selection + the analytic front end of the BTRAN in one workgroup
 // COHERENT: run by the last workgroup of k_chuzr_scan (the per-block winners are read with ldc)
-template <bool COHERENT> __device__ inline void chuzrFinalBody(const Dev &D, int nblocks, int wide)
+template <bool COHERENT> __device__ inline void chuzrFinalBody(const Dev &D, int nblocks, int wide, ChzStage *S)
 {
   Ctrl *c = D.ctrl;
   __shared__ double shv[4];
   __shared__ int shk[4], shr[4];
-  __shared__ int s_ok;
+  __shared__ int s_ok, s_again;
   double best = 0.0;
   int bestKey = -1, bestRow = -1;
   int used = (c->chuzrNumber + 256 * CHZ_ITEMS - 1) / (256 * CHZ_ITEMS);
@@ -4099,7 +4330,24 @@ template <bool COHERENT> __device__ inline void chuzrFinalBody(const Dev &D, int
         bestKey = shk[i];
         bestRow = shr[i];
       }
-    int chosen = bestRow;
+    // "won't line up with checkPrimalSolution - do again" (src/ClpDualRowSteepest.cpp:338-346): nothing chosen under the changed
+    // tolerance -> the whole call once more with largestDualError_ 0
+    s_again = bestRow < 0 && c->pivotRule != 0 && c->chuzrTolChanged && c->presetRowPlus1 <= 0;
+    if (s_again) {
+      c->chuzrRecalls++;
+      chuzrPreBody(D, true);
+    }
+    shr[0] = bestRow;
+  }
+  __syncthreads();
+  if (s_again) {
+    chuzrOrderedScan(D, S, c->chuzrTolerance, c->chuzrNumber, c->chuzrStart, c->chuzrLast, c->chuzrWanted);
+    if (threadIdx.x == 0)
+      shr[0] = S->bestRow;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    int chosen = shr[0];
     if (c->presetRowPlus1 > 0) {  // dualRow's free-first entry (host, see k_chuzr_pre)
       chosen = c->presetRowPlus1 - 1;
       c->presetRowPlus1 = 0;
@@ -4206,7 +4454,8 @@ __global__ void __launch_bounds__(256) k_chuzr_final_btran(Dev D, int nblocks, i
 {
   if (D.ctrl->state != RUN)
     return;
-  chuzrFinalBody<false>(D, nblocks, wide);
+  __shared__ ChzStage stage;
+  chuzrFinalBody<false>(D, nblocks, wide, &stage);
 }
 
 // append scan with absolute offsets + the scalar tail of the primal / flip updates

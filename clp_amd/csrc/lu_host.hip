@@ -120,6 +120,9 @@ int clpgpu_context::factorizeLu(const std::vector<int> &kcol, const std::vector<
       }
   }
   const int nF = F.nF, k2 = F.k2;
+  // this factorization's own count in CoinFactorization's convention: L and U of the front (pivots included), the dense block, the
+  // frozen slack part of the basic structurals (option steepest_elements 1)
+  luOwnElements = (long long)F.lVal.size() + (long long)F.uVal.size() + nF + (long long)k2 * k2 + (long long)sColVal.size();
   const auto t1 = std::chrono::steady_clock::now();
   // ---- dense tail: S -> S^-1 on the device (MFMA re-inversion)
   rc = allocNucleus(k2);

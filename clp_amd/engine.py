@@ -37,7 +37,8 @@ class Stats(C.Structure):
                 ("price_form", C.c_long), ("dense_pi_launches", C.c_long), ("price_form_switches", C.c_long),
                 ("exits_scheduled", C.c_long), ("exits_alpha_check", C.c_long), ("exits_backwards", C.c_long),
                 ("exits_bad_update", C.c_long), ("comm_mode", C.c_long), ("shard_cand_cap", C.c_long),
-                ("free_first_rows", C.c_long), ("free_entered", C.c_long), ("try_primal_exits", C.c_long)]
+                ("free_first_rows", C.c_long), ("free_entered", C.c_long), ("try_primal_exits", C.c_long),
+                ("chuzr_partial_scans", C.c_long), ("chuzr_recalls", C.c_long), ("factor_elements", C.c_long)]
 
 
 # every symbol include/clpgpu.h declares (tests/test_abi.py checks the library exports all of them)

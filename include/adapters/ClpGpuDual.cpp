@@ -3,6 +3,7 @@
 // let Clp re-derive what it wants (:777-811).  Call next to dealWithAbc in ClpSimplex::initialSolve (:1935).
 #include <vector>
 
+#include "ClpDualRowSteepest.hpp"
 #include "ClpPackedMatrix.hpp"
 #include "ClpSimplex.hpp"
 #include "CoinHelperFunctions.hpp"
@@ -31,6 +32,12 @@ int clpGpuDual(ClpSimplex &model, int device, bool scaling)
   clpgpu_load_problem(ctx, numberRows, numberColumns, A->getVectorStarts(), A->getIndices(), A->getElements(),
     model.columnLower(), model.columnUpper(), cost.data(), model.rowLower(), model.rowUpper());
   clpgpu_set_option(ctx, "pivot_rule", model.dualRowPivot()->type() == 2 ? 1 : 0);
+  // ClpDualRowSteepest::mode_ decides how much of the infeasibility list one pivotRow() call scans (src/ClpDualRowSteepest.cpp:258-278:
+  // 0 / 1 everything, 2 max(2000, number / 8), 3 -- the constructor's default -- sized by factorization()->numberElements() / rows);
+  // behind this entry point the factorization is the engine's own, so its own count is what that ratio is taken from
+  if (const ClpDualRowSteepest *steepest = dynamic_cast< const ClpDualRowSteepest * >(model.dualRowPivot()))
+    clpgpu_set_option(ctx, "steepest_mode", steepest->mode());
+  clpgpu_set_option(ctx, "steepest_elements", 1);
   clpgpu_set_option(ctx, "max_iterations", model.maximumIterations());
   clpgpu_set_option(ctx, "max_pivots", model.factorization()->maximumPivots());
   clpgpu_set_option(ctx, "dual_bound", model.dualBound());

@@ -95,7 +95,14 @@ public:
   }
   virtual int *indices() const override { return NULL; }
   virtual int *permute() const override { return NULL; }  // ClpDualRowSteepest then skips permutation (:442-460)
-  virtual int numberElements() const override { return numberRows_; }
+  // read by ClpDualRowSteepest::pivotRow in mode 3 (src/ClpDualRowSteepest.cpp:262): the entries this factorization holds
+  virtual int numberElements() const override
+  {
+    clpgpu_stats stats;
+    if (clpgpu_get_stats(ctx_.get(), &stats))
+      return numberRows_;
+    return stats.factor_elements > 2147483647L ? 2147483647 : static_cast< int >(stats.factor_elements);
+  }
 
 private:
   int solve(CoinIndexedVector *region, int (*fn)(clpgpu_context *, double *)) const

@@ -84,6 +84,10 @@ typedef struct {
   long free_first_rows;     /* option free_nonbasic: pivots whose row came from dualRow's free-first entry (src/ClpSimplexDual.cpp:3005-3055) */
   long free_entered;        /* ... pivots that brought a free / superbasic variable in through dualColumn0's general branch (:4058-4179) */
   long try_primal_exits;    /* 1 if the solve ended in gutsOfDual's "problems - try primal" exit (status 10, src/ClpSimplexDual.cpp:540-547) */
+  /* ClpDualRowSteepest::pivotRow (option steepest_mode, src/ClpDualRowSteepest.cpp:258-346) */
+  long chuzr_partial_scans; /* calls that looked at numberWanted entries of the infeasibility list instead of all of them (:258-278, :329-335) */
+  long chuzr_recalls;       /* second calls with largestDualError 0 after a changed tolerance found no row (:338-346) */
+  long factor_elements;     /* what stands for factorization()->numberElements() since the last factorization (option steepest_elements) */
 } clpgpu_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------- */

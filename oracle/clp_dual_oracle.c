@@ -127,6 +127,16 @@ struct OrcModel {
   int debugSingularAt;            /* fault injection (option "debug_singular_at"): the refactorization of the first status check at or after
                                      this iteration is taken as singular; -1 off */
   int tryPrimal;                  /* option "try_primal" (0 default, as the engine's): 1 = gutsOfDual's "problems - try primal" exit is there */
+  int steepestMode;               /* option "steepest_mode": ClpDualRowSteepest::mode_ (0 uninitialized, 1 full, 2 partial, 3 = the
+                                     constructor's default: partial scan sized by the factorization's fill, :258-278); start-up weights
+                                     are the unit weights of every mode but 1 */
+  int steepestElements;           /* option "steepest_elements": what stands for factorization()->numberElements() in mode 3 (see
+                                     factorElementsModel): 0 = entries of the basic structural columns, 1 = this LU's own nonzeros */
+  long factorElements;            /* as of the last factorization */
+  double debugToleranceFactor;    /* option "debug_tolerance_factor" (fault injection, see steepestPivotRow); 0 off */
+  int chuzrFloor;                 /* option "debug_chuzr_floor": the 2000 of :260-276 (tests lower it so that small LPs scan partially) */
+  int numberPartialScans, numberChuzrRecalls; /* test hooks: pivotRow calls that scanned part of the list; second calls (:338-346) */
+  int debugPlainLu;               /* option "debug_plain_lu": 1 = the nucleus is eliminated by the unblocked loop (luPlain) */
   int numberTryPrimal;            /* test hook: times gutsOfDual's "problems - try primal" exit was taken (:540-547) */
   int numberSingularRestores;     /* test hook: times a singular refactorization sent the solve back to the saved basis (:5060-5125) */
   int debugBadAccuracyAt;         /* fault injection (option "debug_bad_accuracy_at"): the first status check at or after this iteration
@@ -270,6 +280,8 @@ OrcModel *orc_create(int m, int n, const int *colStart, const int *row, const do
   M->noFreeOrSuper = 1;
   M->firstFree = -1;
   M->maximumPivots = 200; /* CoinAbcBaseFactorization1.cpp:142 default */
+  M->chuzrFloor = 2000;
+  M->steepestMode = 3;    /* ClpDualRowSteepest(int mode = 3), src/ClpDualRowSteepest.hpp:118; ClpSimplex's constructor takes it, src/ClpSimplex.cpp:158 */
   M->seed = 1234567u;     /* src/ClpModel.cpp:149 */
   M->debugBackwardsAt = -1;
   M->debugBadAccuracyAt = -1;
@@ -378,6 +390,12 @@ int orc_set_option(OrcModel *M, const char *name, double v)
   else if (!strcmp(name, "check_both")) M->checkBoth = (int)v;
   else if (!strcmp(name, "free_nonbasic")) M->freeNonbasic = (int)v;
   else if (!strcmp(name, "try_primal")) M->tryPrimal = (int)v;
+  else if (!strcmp(name, "debug_plain_lu")) M->debugPlainLu = (int)v;
+  else if (!strcmp(name, "steepest_mode")) M->steepestMode = (int)v;
+  else if (!strcmp(name, "steepest_elements")) M->steepestElements = (int)v;
+  else if (!strcmp(name, "debug_last_bad_iteration")) M->lastBadIteration = (int)v; /* fault injection: lastBadIteration_ the solve starts with (-999999) */
+  else if (!strcmp(name, "debug_tolerance_factor")) M->debugToleranceFactor = v;
+  else if (!strcmp(name, "debug_chuzr_floor")) M->chuzrFloor = (int)v > 1 ? (int)v : 1;
   else return -1;
   return 0;
 }
@@ -618,6 +636,208 @@ static void facReserveEta(Factor *F, int maxEta, long nnz)
   }
 }
 
+/* The elimination of CoinAbcDenseFactorization::factor :262-313 on the k x k nucleus (column-major, lu[r + c k]): first largest
+ * pivot of column i among rows >= i, multipliers a_ji (1 / pivot), a_jc -= a_ic l_j.  luPlain is that loop as written (one pass over
+ * the whole trailing matrix per pivot: 8 k^3 / 3 bytes through memory, twenty minutes at k = 10 500); luBlocked makes the same
+ * floating-point operations on every entry in the same order -- each a_jc still receives its updates one at a time, by ascending
+ * pivot -- but panel by panel, LAPACK style: a panel of LU_NB columns is eliminated on its own, its row interchanges are applied to
+ * the other columns afterwards, and its LU_NB updates reach the columns to the right while a tile of the panel's multipliers sits in
+ * cache.  Updates with a_ic == 0 are skipped (an exact no-op: active entries are never -0.0), which is most of them while the
+ * nucleus is sparse.  Bit-identical results, tests/test_oracle_golden.py::test_blocked_lu_is_the_plain_loop; option
+ * "debug_plain_lu" 1 runs luPlain. */
+static int luPlain(double *lu, int k, int *perm, double zeroTolerance)
+{
+  double *elements = lu;
+  for (int i = 0; i < k; i++) {
+    int iRow = -1;
+    double largest = zeroTolerance;
+    for (int j = i; j < k; j++) {
+      double value = fabs(elements[j]);
+      if (value > largest) {
+        largest = value;
+        iRow = j;
+      }
+    }
+    if (iRow < 0)
+      return -1;
+    if (iRow != i) {
+      /* full row swap (the reference swaps columns <= i now and later columns lazily, :271-300) */
+      for (int c = 0; c < k; c++) {
+        double value = lu[i + (size_t)c * k];
+        lu[i + (size_t)c * k] = lu[iRow + (size_t)c * k];
+        lu[iRow + (size_t)c * k] = value;
+      }
+      int ip = perm[i];
+      perm[i] = perm[iRow];
+      perm[iRow] = ip;
+    }
+    double pivotValue = 1.0 / elements[i];
+    elements[i] = pivotValue;
+    for (int j = i + 1; j < k; j++)
+      elements[j] *= pivotValue;
+    double *elementsA = elements;
+    for (int c = i + 1; c < k; c++) {
+      elementsA += k;
+      double value = elementsA[i];
+      for (int j = i + 1; j < k; j++)
+        elementsA[j] -= value * elements[j];
+    }
+    elements += k;
+  }
+  return 0;
+}
+
+#define LU_NB 64   /* panel width */
+#define LU_RT 256  /* rows of the panel's multipliers kept in cache while they are applied (256 x 64 doubles = 128 KB) */
+/* columns [c0, c1) to the right of the panel [p, p + nb): the panel's nb updates, ascending pivot order per entry */
+__attribute__((target_clones("avx2", "default"))) static void luApplyPanel(double *lu, int k, int p, int nb, int c0, int c1)
+{
+  const int pe = p + nb;
+  /* rows inside the panel: the column's entries of U come out one after the other */
+  for (int c = c0; c < c1; c++) {
+    double *a = lu + (size_t)c * k;
+    for (int i = p; i < pe; i++) {
+      const double value = a[i];
+      if (value) {
+        const double *l = lu + (size_t)i * k;
+        for (int j = i + 1; j < pe; j++)
+          a[j] -= value * l[j];
+      }
+    }
+  }
+  /* rows below the panel, a tile of rows at a time, four columns per pass over the tile */
+  for (int r0 = pe; r0 < k; r0 += LU_RT) {
+    const int r1 = r0 + LU_RT < k ? r0 + LU_RT : k;
+    int c = c0;
+    for (; c + 4 <= c1; c += 4) {
+      double *a0 = lu + (size_t)c * k, *a1 = a0 + k, *a2 = a1 + k, *a3 = a2 + k;
+      for (int i = p; i < pe; i++) {
+        const double u0 = a0[i], u1 = a1[i], u2 = a2[i], u3 = a3[i];
+        if (u0 == 0.0 && u1 == 0.0 && u2 == 0.0 && u3 == 0.0)
+          continue;
+        const double *l = lu + (size_t)i * k;
+        if (u0 != 0.0 && u1 != 0.0 && u2 != 0.0 && u3 != 0.0) {
+          for (int j = r0; j < r1; j++) {
+            const double lj = l[j];
+            a0[j] -= u0 * lj;
+            a1[j] -= u1 * lj;
+            a2[j] -= u2 * lj;
+            a3[j] -= u3 * lj;
+          }
+        } else {
+          if (u0 != 0.0)
+            for (int j = r0; j < r1; j++)
+              a0[j] -= u0 * l[j];
+          if (u1 != 0.0)
+            for (int j = r0; j < r1; j++)
+              a1[j] -= u1 * l[j];
+          if (u2 != 0.0)
+            for (int j = r0; j < r1; j++)
+              a2[j] -= u2 * l[j];
+          if (u3 != 0.0)
+            for (int j = r0; j < r1; j++)
+              a3[j] -= u3 * l[j];
+        }
+      }
+    }
+    for (; c < c1; c++) {
+      double *a = lu + (size_t)c * k;
+      for (int i = p; i < pe; i++) {
+        const double value = a[i];
+        if (value != 0.0) {
+          const double *l = lu + (size_t)i * k;
+          for (int j = r0; j < r1; j++)
+            a[j] -= value * l[j];
+        }
+      }
+    }
+  }
+}
+
+static int luBlocked(double *lu, int k, int *perm, double zeroTolerance)
+{
+  int swapWith[LU_NB];
+  for (int p = 0; p < k; p += LU_NB) {
+    const int nb = p + LU_NB < k ? LU_NB : k - p, pe = p + nb;
+    for (int i = p; i < pe; i++) {
+      double *elements = lu + (size_t)i * k;
+      int iRow = -1;
+      double largest = zeroTolerance;
+      for (int j = i; j < k; j++) {
+        double value = fabs(elements[j]);
+        if (value > largest) {
+          largest = value;
+          iRow = j;
+        }
+      }
+      if (iRow < 0)
+        return -1;
+      swapWith[i - p] = iRow;
+      if (iRow != i) {
+        for (int c = p; c < pe; c++) { /* the panel's own columns now, the others after the panel */
+          double value = lu[i + (size_t)c * k];
+          lu[i + (size_t)c * k] = lu[iRow + (size_t)c * k];
+          lu[iRow + (size_t)c * k] = value;
+        }
+        int ip = perm[i];
+        perm[i] = perm[iRow];
+        perm[iRow] = ip;
+      }
+      double pivotValue = 1.0 / elements[i];
+      elements[i] = pivotValue;
+      for (int j = i + 1; j < k; j++)
+        elements[j] *= pivotValue;
+      for (int c = i + 1; c < pe; c++) {
+        double *elementsA = lu + (size_t)c * k;
+        double value = elementsA[i];
+        if (value)
+          for (int j = i + 1; j < k; j++)
+            elementsA[j] -= value * elements[j];
+      }
+    }
+    for (int c = 0; c < k; c++) {
+      if (c == p) {
+        c = pe - 1;
+        continue;
+      }
+      double *a = lu + (size_t)c * k;
+      for (int i = p; i < pe; i++) {
+        const int iRow = swapWith[i - p];
+        if (iRow != i) {
+          double value = a[i];
+          a[i] = a[iRow];
+          a[iRow] = value;
+        }
+      }
+    }
+    if (pe < k)
+      luApplyPanel(lu, k, p, nb, pe, k);
+  }
+  return 0;
+}
+
+/* What ClpDualRowSteepest::pivotRow reads as model_->factorization()->numberElements() (src/ClpDualRowSteepest.cpp:262).  Behind
+ * ClpFactorization that is CoinFactorization::numberElements() = totalElements_ (CoinUtils, not in this tree; the in-tree twin keeps
+ * the same counter: entries of U less the slack pivots, src/CoinAbcBaseFactorization1.cpp:3800 / :3860, plus the dense block and L,
+ * :3282 / :3323) -- a property of that LU code's ordering and fill, which no other factorization reproduces.  Model 0 (default, and
+ * the one the HIP engine can compute bit for bit): the entries of the basic structural columns, i.e. that counter for an LU without
+ * fill -- exact for the slack basis (0) and for every basis that triangularizes, a lower bound otherwise.  Model 1: the nonzeros this
+ * oracle's own dense LU of the nucleus holds (what a plug-in factorization would answer, CoinOtherFactorization::numberElements). */
+static void factorElementsModel(OrcModel *M)
+{
+  const Factor *F = &M->fac;
+  long count = 0;
+  if (M->steepestElements == 0) {
+    for (int c = 0; c < F->k; c++)
+      count += M->colStart[F->kcol[c] + 1] - M->colStart[F->kcol[c]];
+  } else {
+    const size_t kk = (size_t)F->k * (size_t)F->k;
+    for (size_t q = 0; q < kk; q++)
+      count += F->lu[q] != 0.0;
+  }
+  M->factorElements = count;
+}
+
 /* ClpFactorization::factorize :1649 (collect basic rows then columns, slack value -1) +
  * CoinAbcDenseFactorization::factor :216-331 on the nucleus.  Returns 0, or -1 if singular. */
 static int factorize(OrcModel *M)
@@ -679,46 +899,7 @@ static int factorize(OrcModel *M)
   int *perm = (int *)malloc(sizeof(int) * (size_t)(k + 1));
   for (int i = 0; i < k; i++)
     perm[i] = i;
-  int status = 0;
-  double *elements = lu;
-  for (int i = 0; i < k; i++) {
-    int iRow = -1;
-    double largest = M->zeroTolerance;
-    for (int j = i; j < k; j++) {
-      double value = fabs(elements[j]);
-      if (value > largest) {
-        largest = value;
-        iRow = j;
-      }
-    }
-    if (iRow < 0) {
-      status = -1;
-      break;
-    }
-    if (iRow != i) {
-      /* full row swap (the reference swaps columns <= i now and later columns lazily, :271-300) */
-      for (int c = 0; c < k; c++) {
-        double value = lu[i + (size_t)c * k];
-        lu[i + (size_t)c * k] = lu[iRow + (size_t)c * k];
-        lu[iRow + (size_t)c * k] = value;
-      }
-      int ip = perm[i];
-      perm[i] = perm[iRow];
-      perm[iRow] = ip;
-    }
-    double pivotValue = 1.0 / elements[i];
-    elements[i] = pivotValue;
-    for (int j = i + 1; j < k; j++)
-      elements[j] *= pivotValue;
-    double *elementsA = elements;
-    for (int c = i + 1; c < k; c++) {
-      elementsA += k;
-      double value = elementsA[i];
-      for (int j = i + 1; j < k; j++)
-        elementsA[j] -= value * elements[j];
-    }
-    elements += k;
-  }
+  int status = M->debugPlainLu ? luPlain(lu, k, perm, M->zeroTolerance) : luBlocked(lu, k, perm, M->zeroTolerance);
   if (!status) {
     for (int c = 0; c < k; c++) {
       F->krow[c] = rrows[perm[c]];
@@ -730,6 +911,7 @@ static int factorize(OrcModel *M)
         M->pivotVariable[i] = n + i;
     for (int c = 0; c < k; c++)
       M->pivotVariable[F->krow[c]] = F->kcol[c];
+    factorElementsModel(M);
   }
   free(perm);
   free(local);
@@ -1494,7 +1676,13 @@ static int dantzigPivotRow(OrcModel *M)
   return chosenRow;
 }
 
-/* ClpDualRowSteepest::pivotRow :179-364 (full scan: numberWanted = number+1, mode_ < 2) */
+/* ClpDualRowSteepest::pivotRow :179-364, all of it: the touch-up of the last pivot row (:210-250), the "can't trust
+ * infeasibilities" tolerance (:251-257), numberWanted from mode_ (:258-278: the partial scan of modes 2 and 3 -- the constructor's
+ * default is mode 3, src/ClpDualRowSteepest.hpp:118), the random start and the two passes with the early break (:279-335; a flagged
+ * candidate hands its ticket back, the last pivot row that is put off by `continue` does not use one), and the second call with
+ * largestDualError_ = 0 when nothing was chosen under the changed tolerance (:338-346: everything again, another random number
+ * included).  `factorization()->numberElements()` (:262) is the one input that depends on the LU code behind ClpFactorization:
+ * M->factorElements, see factorElementsModel(). */
 static int steepestPivotRow(OrcModel *M)
 {
   double largest = 0.0;
@@ -1505,6 +1693,7 @@ static int steepestPivotRow(OrcModel *M)
   tolerance = tolerance + error;
   tolerance = dmin(1000.0, tolerance);
   tolerance *= tolerance;
+  int toleranceChanged = 0;
   if (lastPivotRow >= 0 && lastPivotRow < M->m) {
     int iPivot = M->pivotVariable[lastPivotRow];
     double value = M->sol[iPivot], lower = M->lower[iPivot], upper = M->upper[iPivot];
@@ -1522,12 +1711,40 @@ static int steepestPivotRow(OrcModel *M)
     }
   }
   int number = M->numberInfeasible;
-  /* the "can't trust infeasibilities" tolerance change (:267-273) needs lastBadIteration */
   if (M->numberIterations < M->lastBadIteration + 200) {
     if (M->largestDualError > M->largestPrimalError) {
       tolerance *= dmin(M->largestDualError / M->largestPrimalError, 1000.0);
+      toleranceChanged = 1;
+    } else if (M->debugToleranceFactor > 0.0 && M->largestDualError >= 0.0) {
+      /* fault injection (option "debug_tolerance_factor"): the two errors are rounding noise on a healthy LP and which of them is larger
+       * is not reproducible between two factorizations; tests arm the branch with a factor of their own (the second call sees
+       * largestDualError_ < 0 below and leaves it alone, as it leaves the real one) */
+      tolerance *= M->debugToleranceFactor;
+      toleranceChanged = 1;
     }
   }
+  int numberWanted;
+  if (M->steepestMode < 2) {
+    numberWanted = number + 1;
+  } else if (M->steepestMode == 2) {
+    numberWanted = number / 8 > M->chuzrFloor ? number / 8 : M->chuzrFloor;
+  } else {
+    double ratio = (double)M->factorElements / (double)M->m;
+    numberWanted = number / 8 > M->chuzrFloor ? number / 8 : M->chuzrFloor;
+    if (ratio < 1.0) {
+      numberWanted = number / 20 > M->chuzrFloor ? number / 20 : M->chuzrFloor;
+    } else if (ratio > 10.0) {
+      ratio = number * (ratio / 80.0);
+      if (ratio > number)
+        numberWanted = number + 1;
+      else
+        numberWanted = (int)ratio > M->chuzrFloor ? (int)ratio : M->chuzrFloor;
+    }
+  }
+  if (M->largestPrimalError > 1.0e-3)
+    numberWanted = number + 1; /* be safe */
+  if (numberWanted <= number)
+    M->numberPartialScans++;
   int start[4];
   start[1] = number;
   start[2] = 0;
@@ -1554,10 +1771,26 @@ static int steepestPivotRow(OrcModel *M)
               chosenRow = iRow;
               largest = value / weight;
             }
+          } else {
+            numberWanted++; /* "just to make sure we don't exit before got something" */
           }
         }
+        numberWanted--;
+        if (!numberWanted)
+          break;
       }
     }
+    if (!numberWanted)
+      break;
+  }
+  if (chosenRow < 0 && toleranceChanged) {
+    /* "won't line up with checkPrimalSolution - do again" (:338-346); cannot loop: the second call sees no dual error */
+    double saveError = M->largestDualError;
+    M->largestDualError = M->debugToleranceFactor > 0.0 ? -1.0 : 0.0; /* (-1 only tells the injected branch above that this is the second call) */
+    M->numberChuzrRecalls++;
+    chosenRow = steepestPivotRow(M);
+    number = M->numberInfeasible;
+    M->largestDualError = saveError;
   }
   if (chosenRow < 0 && lastPivotRow < 0) {
     int nLeft = 0;
@@ -3734,6 +3967,7 @@ static int dualOnRim(OrcModel *M)
   M->bestPossibleImprovement = 0.0;
   M->numberBackwards = M->numberLoopFlags = M->numberAccuracyRestores = M->numberSingularRestores = 0;
   M->numberTryPrimal = 0;
+  M->numberPartialScans = M->numberChuzrRecalls = 0;
   M->noFreeOrSuper = 1;
   M->firstFree = -1;
   M->badFree = 0.0;
@@ -4210,6 +4444,9 @@ int orc_number_loop_flags(const OrcModel *M) { return M->numberLoopFlags; }
 int orc_number_accuracy_restores(const OrcModel *M) { return M->numberAccuracyRestores; }
 int orc_number_singular_restores(const OrcModel *M) { return M->numberSingularRestores; }
 int orc_number_try_primal(const OrcModel *M) { return M->numberTryPrimal; }
+int orc_number_partial_scans(const OrcModel *M) { return M->numberPartialScans; }
+int orc_number_chuzr_recalls(const OrcModel *M) { return M->numberChuzrRecalls; }
+long orc_factor_elements(const OrcModel *M) { return M->factorElements; }
 int orc_number_free_first_rows(const OrcModel *M) { return M->numberFreeFirstRows; }
 int orc_number_free_entered(const OrcModel *M) { return M->numberFreeEntered; }
 double orc_iteration_seconds(const OrcModel *M) { return M->seconds; }

@@ -94,6 +94,9 @@ int orc_number_accuracy_restores(const OrcModel *model);
 /* ... and times a singular refactorization sent the solve back to the saved basis (:5060-5125) */
 int orc_number_singular_restores(const OrcModel *model);
 int orc_number_try_primal(const OrcModel *model); /* times gutsOfDual's "problems - try primal" exit was taken (src/ClpSimplexDual.cpp:540-547) */
+int orc_number_partial_scans(const OrcModel *model); /* ClpDualRowSteepest::pivotRow calls that stopped early on numberWanted (src/ClpDualRowSteepest.cpp:258-278, :329-335) */
+int orc_number_chuzr_recalls(const OrcModel *model); /* second calls with largestDualError 0 after a changed tolerance found no row (:338-346) */
+long orc_factor_elements(const OrcModel *model);     /* what stood for factorization()->numberElements() at the last factorization (option steepest_elements) */
 /* option "free_nonbasic" 1: pivot rows chosen by dualRow's free-first entry (:3005-3055), and pivots whose incoming variable was the
  * free one picked by the general branch of dualColumn0 (:4115-4122), during the last orc_dual */
 int orc_number_free_first_rows(const OrcModel *model);

@@ -86,6 +86,10 @@ def lib():
         L.orc_number_accuracy_restores.argtypes = [p]
         L.orc_number_singular_restores.argtypes = [p]
         L.orc_number_try_primal.argtypes = [p]
+        L.orc_number_partial_scans.argtypes = [p]
+        L.orc_number_chuzr_recalls.argtypes = [p]
+        L.orc_factor_elements.argtypes = [p]
+        L.orc_factor_elements.restype = C.c_long
         L.orc_number_free_first_rows.argtypes = [p]
         L.orc_number_free_entered.argtypes = [p]
         L.orc_test_perturb.argtypes = [p, C.c_int, C.c_int, up, dp]
@@ -182,7 +186,8 @@ class OracleSimplex:
         counters = np.array([code, L.orc_number_iterations(self._h), L.orc_number_refactorizations(self._h), L.orc_number_perturbations(self._h),
                              L.orc_number_backwards(self._h), L.orc_number_loop_flags(self._h), L.orc_number_accuracy_restores(self._h),
                              L.orc_number_singular_restores(self._h), applied, L.orc_number_free_first_rows(self._h),
-                             L.orc_number_free_entered(self._h), L.orc_number_try_primal(self._h)], dtype=np.int64)
+                             L.orc_number_free_entered(self._h), L.orc_number_try_primal(self._h), L.orc_number_partial_scans(self._h),
+                             L.orc_number_chuzr_recalls(self._h), L.orc_factor_elements(self._h)], dtype=np.int64)
         return dict(counters=counters, scalars=np.array([L.orc_objective_value(self._h), L.orc_iteration_seconds(self._h)]),
                     solution=self._vec("orc_get_solution"), reduced_costs=self._vec("orc_get_reduced_costs"),
                     status=self._vec("orc_get_status", np.uint8), pivot_variable=self._vec("orc_get_pivot_variable", np.int32, self.m),
@@ -275,6 +280,23 @@ class OracleSimplex:
     def try_primal(self):
         """times gutsOfDual's "problems - try primal" exit ended the solve with status 10 (src/ClpSimplexDual.cpp:540-547)"""
         return self._counter(11, "orc_number_try_primal")
+
+    @property
+    def partial_scans(self):
+        """ClpDualRowSteepest::pivotRow calls that stopped on numberWanted (src/ClpDualRowSteepest.cpp:258-278, :329-335)"""
+        return self._counter(12, "orc_number_partial_scans")
+
+    chuzr_partial_scans = partial_scans
+
+    @property
+    def chuzr_recalls(self):
+        """second calls of pivotRow with largestDualError 0 (:338-346)"""
+        return self._counter(13, "orc_number_chuzr_recalls")
+
+    @property
+    def factor_elements(self):
+        """what stood for factorization()->numberElements() at the last factorization (option steepest_elements)"""
+        return self._counter(14, "orc_factor_elements")
 
     @property
     def accuracy_restores(self):
