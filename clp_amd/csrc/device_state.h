@@ -104,6 +104,7 @@ struct Ctrl {
   int steepestMode, chuzrWanted, chuzrTolChanged, chuzrRecalls;
   long long factorElements;
   int chuzrPartialScans, chuzrFloor;  // chuzrFloor: the 2000 of :260-276 (option debug_chuzr_floor)
+  int debugDcTimeoutAt, debugPad;  // option debug_dc_wide_timeout_at: k_dual_column_wide reports a barrier timeout at this iteration
   double debugToleranceFactor;  // option debug_tolerance_factor (fault injection for the changed tolerance of CHUZR); 0 off
   double tailAlpha, tailValueOut;  // w[pivotRow] / sol[sequenceOut] handed to the serial tail of k_ftran_scatter3  // this pivot's primal update completed: its list appends may be scattered  // unordered append count of k_dj_flags (ordered later by k_flip_apply2)
 };

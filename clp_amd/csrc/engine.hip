@@ -299,6 +299,7 @@ struct clpgpu_context {
   // form per captured graph: priceMode 1 = k_price_lds alone, 0 = k_price_sell + the by-row form; the host switches between
   // them from the share of dense-pi pivots in the last batch (Ctrl::statDensePi) -- either form prices any pi correctly, so
   // the choice changes the speed of a pivot, never its result.
+  int numberDcWideTimeouts = 0, debugDcTimeoutAt = -1;
   int dcWide = 1;  // option "dc_wide": 1 (default) lists beyond one workgroup's registers go to k_dual_column_wide, 2 every list does (tests), 0 the single-workgroup walk
   int priceLds = 1;
   int priceLdsMinWindows = 256;  // option "price_lds_min_windows": narrower LPs keep k_price_sell (a one-workgroup-per-CU launch needs work for every CU)
@@ -1837,6 +1838,7 @@ void clpgpu_context::preparePlugin()
   h->steepestMode = steepestMode;
   h->chuzrFloor = chuzrFloor;
   h->debugToleranceFactor = debugToleranceFactor;
+  h->debugDcTimeoutAt = -1;
   h->acceptablePivotBase = acceptablePivot;
   h->kcap = kcap;
   if (!started) {
@@ -2737,6 +2739,7 @@ int clpgpu_context::startup()
   hCtrl->steepestMode = steepestMode;
   hCtrl->chuzrFloor = chuzrFloor;
   hCtrl->debugToleranceFactor = debugToleranceFactor;
+  hCtrl->debugDcTimeoutAt = debugDcTimeoutAt;
   hCtrl->lastBadIteration = lastBadIteration;
   hCtrl->seed = seed;
   hCtrl->acceptablePivotBase = acceptablePivot;
@@ -3965,8 +3968,19 @@ int clpgpu_context::whileIterating(int stepTarget)
     if (!rc && hCtrl->state == RUN && stepTarget >= 0 && hCtrl->numberIterations >= stepTarget)
       hCtrl->state = EXIT_STEP_LIMIT;  // the batch ended exactly on the limit: the device never saw a pivot beyond it
     if (!rc && hCtrl->dcWide < 0) {
-      setError("k_dual_column_wide: a grid barrier timed out at iteration %d", hCtrl->numberIterations);
-      rc = -99;
+      // k_dual_column_wide's grid barrier needs its 128 workgroups resident together; when another context of this process holds
+      // the CUs (clones in threads, the forked update branch) a launch can starve until the bounded spin gives up.  The pivot was
+      // abandoned before anything was written (no pivot, no flips): from here on this context keeps long lists in the
+      // single-workgroup walk (dc_wide 0) and the solve goes on through a status check, as after any abandoned pivot.
+      if (logLevel > 0)
+        fprintf(stderr, "clpgpu: k_dual_column_wide: grid barrier timed out at iteration %d -- dc_wide 0 from here on\n", hCtrl->numberIterations);
+      numberDcWideTimeouts++;
+      dcWide = 0;
+      dropGraph();
+      hCtrl->dcWide = 0;
+      hCtrl->pivotRow = -1;
+      hCtrl->state = EXIT_REFACTOR;
+      rc |= pushCtrl();
     }
     if (!rc && jdsReady && priceLds) {
       // which pricing form the next batch's chain carries.  A dense-pi pivot costs ~52 us in k_price_sell and ~32 in k_price_lds,
@@ -5475,6 +5489,10 @@ int clpgpu_virtual_attach(clpgpu_context *ctx, clpgpu_virtual_group *g, int rank
   if (ctx->allocShardBuffers())
     return -99;
   ctx->useGraph = 0;
+  // several ranks on ONE device: the grid barrier of k_dual_column_wide assumes its 128 workgroups are resident together, which N
+  // concurrent launches of it do not guarantee -- and a rank that gave up on a pivot alone would leave the others waiting in the
+  // next exchange.  Loopback ranks walk long lists in one workgroup (the same decisions, bit for bit).
+  ctx->dcWide = 0;
   return ctx->buildSell();
 }
 
@@ -5566,6 +5584,7 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "steepest_elements")) ctx->steepestElements = v != 0.0;
   else if (!strcmp(name, "debug_last_bad_iteration")) ctx->debugLastBadIteration = (int)v;
   else if (!strcmp(name, "debug_tolerance_factor")) ctx->debugToleranceFactor = v;
+  else if (!strcmp(name, "debug_dc_wide_timeout_at")) ctx->debugDcTimeoutAt = (int)v;
   else if (!strcmp(name, "debug_chuzr_floor")) ctx->chuzrFloor = std::max(1, (int)v);
   else if (!strcmp(name, "dse_reset_every")) ctx->dseResetEvery = std::max(0, (int)v);
   else if (!strcmp(name, "debug_singular_at")) ctx->debugSingularAt = (int)v;
@@ -6077,6 +6096,7 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
   stats->free_first_rows = ctx->numberFreeFirstRows;
   stats->free_entered = ctx->numberFreeEntered;
   stats->try_primal_exits = ctx->numberTryPrimal;
+  stats->dc_wide_timeouts = ctx->numberDcWideTimeouts;
   stats->chuzr_partial_scans = ctx->hCtrl->chuzrPartialScans;
   stats->chuzr_recalls = ctx->hCtrl->chuzrRecalls;
   stats->factor_elements = (long)ctx->hCtrl->factorElements;

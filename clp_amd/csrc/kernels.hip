@@ -1317,7 +1317,7 @@ __device__ __forceinline__ bool dualColumnImpl(const Dev &D, const int *map = nu
       passId++;
     }
   }
-  if (WIDE && !gridOk) {
+  if (WIDE && (!gridOk || c->numberIterations == c->debugDcTimeoutAt)) {  // (debugDcTimeoutAt: fault injection, -1 off)
     // a grid barrier timed out (never seen; the spin is bounded so that a fault cannot hang the device): no pivot, and the host is told
     if (tid == 0) {
       c->dcWide = -1;

@@ -1275,6 +1275,25 @@ def test_wide_ratio_test_identical_pivot_sequence(gpu_cls, maker, args, rule):
     assert rel(lg["theta"], lo["theta"]) < 1e-7 and rel(lg["alpha"], lo["alpha"]) < 1e-7
 
 
+def test_wide_ratio_test_barrier_timeout_falls_back(gpu_cls):
+    """k_dual_column_wide's grid barrier is a bounded spin: when its 128 workgroups are not resident together (another context of the
+    process holds the CUs) it gives up.  That used to end the solve with -99; now the abandoned pivot (nothing written yet) is
+    followed by a status check, the context keeps long lists in the single-workgroup walk (dc_wide 0) and the solve ends at the
+    optimum.  Fault injection: option debug_dc_wide_timeout_at."""
+    lp = P.sparse_lp(300, 1200, 8, 11)
+    o = oracle(lp, 1)
+    assert o.dual() == 0
+    g = gpu_cls().loadProblem(lp)
+    g.set_option("pivot_rule", 1)
+    g.set_option("dc_wide", 2)
+    g.set_option("debug_dc_wide_timeout_at", 40)
+    assert g.dual() == 0, g.lastError()
+    assert g.stats()["dc_wide_timeouts"] == 1
+    assert abs(g.objectiveValue() - o.objective) <= RTOL * (1 + abs(o.objective))
+    lg, lo = g.pivotLog(), o.pivot_log()
+    assert np.array_equal(lg["sequenceIn"][:40], lo["sequenceIn"][:40])  # the oracle's pivots up to the abandoned one
+
+
 def test_wide_ratio_test_at_full_size_from_the_mature_basis(gpu_cls):
     """Config 4 from the committed mature basis (10^5 candidates per pivot): the ratio test on every pivot by the wide kernel
     (dc_wide 2), only where one workgroup's registers do not hold the list (1, the default) and never (0, the single-workgroup
