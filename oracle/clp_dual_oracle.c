@@ -180,7 +180,7 @@ struct OrcModel {
   /* log */
   OrcPivotRecord *log;
   int logCount, logCap;
-  double seconds;
+  double seconds, startupSeconds; /* wall clock of the last orc_dual; its part before the first status check (start-up factorization + resync) */
 };
 
 /* ------------------------------------------------------------------------------------------ */
@@ -693,7 +693,9 @@ static int luPlain(double *lu, int k, int *perm, double zeroTolerance)
 __attribute__((target_clones("avx2", "default"))) static void luApplyPanel(double *lu, int k, int p, int nb, int c0, int c1)
 {
   const int pe = p + nb;
-  /* rows inside the panel: the column's entries of U come out one after the other */
+  /* (the columns are independent of one another: with OpenMP they are dealt over the threads, which changes no operation on any entry)
+     rows inside the panel: the column's entries of U come out one after the other */
+#pragma omp parallel for schedule(static) if (c1 - c0 >= 512)
   for (int c = c0; c < c1; c++) {
     double *a = lu + (size_t)c * k;
     for (int i = p; i < pe; i++) {
@@ -706,10 +708,13 @@ __attribute__((target_clones("avx2", "default"))) static void luApplyPanel(doubl
     }
   }
   /* rows below the panel, a tile of rows at a time, four columns per pass over the tile */
+  const int groups = (c1 - c0) / 4;
+#pragma omp parallel for schedule(dynamic, 16) if (c1 - c0 >= 512)
+  for (int gq = 0; gq < groups; gq++)
   for (int r0 = pe; r0 < k; r0 += LU_RT) {
     const int r1 = r0 + LU_RT < k ? r0 + LU_RT : k;
-    int c = c0;
-    for (; c + 4 <= c1; c += 4) {
+    {
+      const int c = c0 + 4 * gq;
       double *a0 = lu + (size_t)c * k, *a1 = a0 + k, *a2 = a1 + k, *a3 = a2 + k;
       for (int i = p; i < pe; i++) {
         const double u0 = a0[i], u1 = a1[i], u2 = a2[i], u3 = a3[i];
@@ -740,7 +745,10 @@ __attribute__((target_clones("avx2", "default"))) static void luApplyPanel(doubl
         }
       }
     }
-    for (; c < c1; c++) {
+  }
+  for (int r0 = pe; r0 < k; r0 += LU_RT) {
+    const int r1 = r0 + LU_RT < k ? r0 + LU_RT : k;
+    for (int c = c0 + 4 * groups; c < c1; c++) {
       double *a = lu + (size_t)c * k;
       for (int i = p; i < pe; i++) {
         const double value = a[i];
@@ -4007,6 +4015,11 @@ static int dualOnRim(OrcModel *M)
   int factorType = 0;
   double smallestPrimalInfeasibility = 1.7976931348623157e308; /* COIN_DBL_MAX, gutsOfDual :442 */
   double lastObjectiveValue = -1.0e100;                         /* :460 */
+  {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    M->startupSeconds = (double)(ts.tv_sec - t0.tv_sec) + 1.0e-9 * (double)(ts.tv_nsec - t0.tv_nsec);
+  }
   while (M->problemStatus < 0) {
     for (int i = 0; i < m; i++)
       M->rowWork0[i] = M->rowWork1[i] = M->rowWork2[i] = M->rowWork3[i] = 0.0;
@@ -4450,6 +4463,7 @@ long orc_factor_elements(const OrcModel *M) { return M->factorElements; }
 int orc_number_free_first_rows(const OrcModel *M) { return M->numberFreeFirstRows; }
 int orc_number_free_entered(const OrcModel *M) { return M->numberFreeEntered; }
 double orc_iteration_seconds(const OrcModel *M) { return M->seconds; }
+double orc_startup_seconds(const OrcModel *M) { return M->startupSeconds; }
 void orc_get_solution(const OrcModel *M, double *s) { memcpy(s, M->sol, sizeof(double) * (size_t)(M->m + M->n)); }
 void orc_get_reduced_costs(const OrcModel *M, double *d) { memcpy(d, M->dj, sizeof(double) * (size_t)(M->m + M->n)); }
 void orc_get_status(const OrcModel *M, unsigned char *s) { memcpy(s, M->status, (size_t)(M->m + M->n)); }

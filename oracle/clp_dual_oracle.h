@@ -110,6 +110,7 @@ void orc_get_row_duals(const OrcModel *model, double *dual);
 int orc_get_pivot_log(const OrcModel *model, OrcPivotRecord *out, int maxRecords);
 void orc_get_row_weights(const OrcModel *model, double *weights, double *infeasibility);
 double orc_iteration_seconds(const OrcModel *model);
+double orc_startup_seconds(const OrcModel *model);   /* the part of it before the first status check: start-up factorization + resync */
 /* row (m) and column (n) scale factors of the last orc_dual; returns 1 if that solve was scaled */
 int orc_get_scale_factors(const OrcModel *model, double *rowScale, double *columnScale);
 

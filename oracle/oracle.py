@@ -97,6 +97,8 @@ def lib():
         L.orc_objective_value.restype = C.c_double
         L.orc_iteration_seconds.argtypes = [p]
         L.orc_iteration_seconds.restype = C.c_double
+        L.orc_startup_seconds.argtypes = [p]
+        L.orc_startup_seconds.restype = C.c_double
         for f in ("orc_get_solution", "orc_get_reduced_costs", "orc_get_row_duals"):
             getattr(L, f).argtypes = [p, dp]
         L.orc_get_status.argtypes = [p, up]
@@ -315,6 +317,13 @@ class OracleSimplex:
         if self._rec is not None:
             return float(self._rec["scalars"][0])
         return lib().orc_objective_value(self._h)
+
+    @property
+    def startup_seconds(self):
+        """the part of `seconds` spent before the first status check (start-up factorization + resync), this machine's clock only"""
+        if self._rec is not None:
+            raise RuntimeError("a solve answered from a committed record has no clock of this machine (dual(live=True) times it here)")
+        return lib().orc_startup_seconds(self._h)
 
     @property
     def seconds(self):
