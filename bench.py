@@ -142,6 +142,44 @@ def pmc_traffic(args, kernel_regex):
         f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, mean of the last {args.steps} pricing dispatches, read = 2 x FETCH_SIZE"
 
 
+def kernel_trace_us(args, kernel_regex):
+    """the pricing kernel's OWN duration over the timed window: one `rocprofv3 --kernel-trace` pass of this script (the same child
+    as the PMC passes: warm-up + steps, eager launches, nothing else), mean of end - start over the last K dispatches.
+    Returns ({"avg_us", "min_us", "max_us", "dispatches", "kernel"}, note) or (None, why)."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    d = tempfile.mkdtemp(prefix="clpgpu_kt_")
+    cmd = [exe, "--kernel-trace", "--kernel-include-regex", kernel_regex, "-d", d, "-o", "kt", "--",
+           sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--rows", str(args.rows), "--cols", str(args.cols), "--nnz-per-col", str(args.nnz_per_col), "--workload", args.workload,
+           "--pivot-rule", str(args.pivot_rule), "--check-every", str(args.check_every), "--start", args.start, "--preroll", str(args.preroll)]
+    try:
+        p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
+        try:
+            p.communicate(timeout=args.pmc_timeout)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, 9)
+            p.communicate()
+            return None, "rocprofv3 --kernel-trace timed out"
+        dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("_results.db")]
+        if p.returncode != 0 or not dbs:
+            return None, f"rocprofv3 --kernel-trace failed (rc {p.returncode})"
+        cur = sqlite3.connect(dbs[0]).cursor()
+        rows = cur.execute("select name, (end - start) / 1e3 from kernels where name like ? order by start desc limit ?",
+                           (f"%{kernel_regex}%", args.steps)).fetchall()
+        if not rows:
+            return None, f"no dispatches of {kernel_regex}"
+        us = [r[1] for r in rows]
+        names = sorted({re.sub(r"\(.*", "", r[0]).replace("clpgpu::", "") for r in rows})
+        return {"avg_us": sum(us) / len(us), "min_us": min(us), "max_us": max(us), "dispatches": len(us), "kernel": " + ".join(names)}, \
+            f"live: rocprofv3 --kernel-trace child pass of this script, mean of end - start over the last {len(us)} pricing dispatches (the timed pivots, eager launches)"
+    except Exception as e:  # noqa: BLE001 -- the bench line must survive a profiler problem
+        return None, f"kernel trace: {e}"
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def clp_upstream(args, lp):
     """real coin-or/Clp on the same LP, when a clp binary exists on this box"""
     exe = shutil.which("clp")
@@ -195,8 +233,15 @@ def main():
                          "behind a fresh factorization, where pivots are at their cheapest")
     ap.add_argument("--ladder-budget", type=float, default=60.0, help="seconds allowed for the time-to-optimal ladder (0 skips it)")
     ap.add_argument("--ladder-rungs", default="1500,2000,3000,4000,5000,7000,10000")
-    ap.add_argument("--cpu-mature-live", action="store_true",
-                    help="time the CPU oracle from the mature basis on THIS box (~20 minutes of one core) instead of quoting the committed record's clock")
+    ap.add_argument("--cpu-mature-pivots", type=int, default=40,
+                    help="pivots of the CPU baseline in the headline's regime (oracle from the mature basis, ~0.4 s each after a ~15 s start-up; 0 skips it)")
+    ap.add_argument("--sub-timeout", type=float, default=240.0)
+    ap.add_argument("--sub-records", default="dense,netlib",
+                    help="default workload only: BASELINE configs[2] (dense 5000 x 5000) and the Netlib-shaped variant as sub-records of the line, "
+                         "each a child run of this script (window from the slack basis, pricing roofline, time to optimal); 'off' skips them")
+    ap.add_argument("--shard-proxy", default="1,2,4,8",
+                    help="default workload only: the pricing kernel of a column shard [0, n / R) timed on this one GPU for each R "
+                         "(what a rank of an R-GPU run launches per pivot); 'off' skips it")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -347,6 +392,20 @@ def main():
                     traffic = json.load(open(path))["traffic_bytes_per_launch"]
                     traffic_source = f"profiles/{name} (committed rocprofv3 --pmc summary of the default bench line; live pass unavailable: {why})"
                     break
+    # ---- the kernel's own duration: a rocprofv3 --kernel-trace pass over the same pivots.  The HIP-event figure above brackets an EAGER
+    # launch (event pair + launch gap: ~6 us for an empty kernel of k_price_lds' launch shape); the timed window itself replays hipGraphs,
+    # where that gap does not exist.  `roofline.frac` is quoted on the kernel's duration, the event figure stays as `eager_events`.
+    ktrace, ktrace_source = None, None
+    if rank == 0 and world == 1 and args.pmc == "auto" and price_names:
+        main_kernel = "k_price_lds" if "k_price_lds" in price_names else ("k_price_sell" if "k_price_sell" in price_names else "k_price")
+        ktrace, ktrace_source = kernel_trace_us(args, main_kernel)
+    events = {"us_per_launch": per_launch_s * 1e6, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+              "note": "HIP events on the engine's stream around each EAGER pricing launch of the replayed window: kernel + event pair + launch gap"}
+    duration_source = "HIP events around eager launches (no rocprofv3 pass: " + str(ktrace_source) + ")"
+    if ktrace:
+        per_launch_s = ktrace["avg_us"] * 1e-6
+        achieved = per_launch_bytes / per_launch_s / 1e9
+        duration_source = ktrace_source
     moved = traffic / per_launch_s / 1e9 if (traffic and per_launch_s > 0) else None
     # the committed rocprofv3 summary of this command (profiles/, tools/closing_bench.sh): the kernel's own duration, without the
     # event pair and the eager launch gap the live figure above includes (an empty kernel of k_price_lds' launch shape costs 6 us there)
@@ -396,43 +455,51 @@ def main():
                        "same_pivots_as_cpu": bool((eng_c.pivotLog()["sequenceIn"][: o.iterations] == o.pivot_log()["sequenceIn"]).all())}
         cpu["gpu_same_window"] = same_window
         del eng_c
-        # ---- the headline's OWN regime: the oracle warm-started from the committed mature basis over its first 400 pivots (one
-        # dense LU of order 10 514 + 400 pivots: ~20 minutes of one core, too long for the default run).  By default the oracle's
-        # side is the COMMITTED RECORD of exactly this solve (tests/golden/oracle_cache, the one tests/test_gpu_mature_parity.py
-        # compares pivot by pivot) with the authoring box's clock, said so; --cpu-mature-live times it on this box instead.
-        # The engine's side is timed here either way, over the same 400 pivots, and must make the same pivots.
-        if basis is not None and len(basis) == lp.m + lp.n:
+        # ---- the headline's OWN regime, live on this box: the oracle warm-started from the committed mature basis for a bounded number of
+        # pivots.  Its start-up (a dense LU of the order-10 514 nucleus: ~15 s with the blocked, threaded elimination; twenty minutes with the
+        # unblocked loop of rounds 1-5) is clocked apart (orc_startup_seconds) and left out on BOTH sides: `value` is pivots per second of
+        # one core once the basis is factorized, next to the engine over exactly those pivots after ITS start-up factorization.
+        if basis is not None and len(basis) == lp.m + lp.n and args.cpu_mature_pivots > 0:
             om = OracleSimplex(lp)
             om.set_option("pivot_rule", args.pivot_rule)
             om.set_option("max_pivots", 0)
+            # both sides under ClpDualRowSteepest's full scan in this leg: the default mode 3 scans the first numberWanted rows of the
+            # infeasibility list in BASIS-POSITION order, and two factorizations (the oracle's dense LU, the engine's front + tail) put
+            # the basic variables at different positions -- with it the two sides would time different pivots
+            om.set_option("steepest_mode", 1)
             om.set_status((basis & 7).astype(np.uint8))
-            om.set_option("max_iterations", 400)
-            rec_s = None
-            if args.cpu_mature_live:
-                om.dual(live=True)
-                rec_s, where = om.seconds, "this box (live)"
-            else:
-                if om.has_record() and om.dual() is not None and om.recorded_seconds is not None:
-                    rec_s, where = om.recorded_seconds, "the authoring container (committed record; an 8-core Xeon 2.1 GHz, one core used) -- NOT this box"
-            if rec_s:
-                em = make_engine(args, lp, local_rank, (basis & 7).astype(np.uint8))
-                em.dual_steps(0)  # start-up factorization of the basis: before the clock (the oracle's figure includes its own, said below)
-                torch.cuda.synchronize()
-                tm = time.perf_counter()
-                em.dual_steps(400)
-                torch.cuda.synchronize()
-                tm = time.perf_counter() - tm
-                lo, lg = om.pivot_log(), em.pivotLog()
-                n_same = 0
-                while n_same < min(len(lo), len(lg)) and lo[n_same]["sequenceIn"] == lg[n_same]["sequenceIn"] and lo[n_same]["sequenceOut"] == lg[n_same]["sequenceOut"]:
-                    n_same += 1
-                cpu["mature_window"] = {
-                    "window": "pivots 1..400 from the committed mature basis (the regime `value` is quoted in)",
-                    "cpu_port_seconds": round(rec_s, 2), "cpu_port_iterations_per_s": 400.0 / rec_s, "cpu_clock_of": where,
-                    "cpu_includes": "the start-up dense LU of the nucleus (order 10 514, most of the time) + 400 pivots",
-                    "gpu_seconds": round(tm, 4), "gpu_iterations_per_s": 400.0 / tm, "gpu_excludes": "the start-up factorization (0.3 s: clpgpu_dual_steps(0) before the clock)",
-                    "identical_pivots": int(n_same), "of": 400}
-                del em
+            om.set_option("max_iterations", args.cpu_mature_pivots)
+            om.dual(live=True)
+            n_m = int(om.iterations)
+            piv_s = max(om.seconds - om.startup_seconds, 1e-9)
+            em = make_engine(args, lp, local_rank, (basis & 7).astype(np.uint8))
+            em.set_option("steepest_mode", 1)
+            em.dual_steps(0)  # start-up factorization of the basis: before the clock, as on the CPU side
+            torch.cuda.synchronize()
+            tm = time.perf_counter()
+            em.dual_steps(n_m)
+            torch.cuda.synchronize()
+            tm = time.perf_counter() - tm
+            lo, lg = om.pivot_log(), em.pivotLog()
+            n_same = 0
+            while n_same < min(len(lo), len(lg)) and lo[n_same]["sequenceIn"] == lg[n_same]["sequenceIn"] and lo[n_same]["sequenceOut"] == lg[n_same]["sequenceOut"]:
+                n_same += 1
+            slack_pair = cpu
+            cpu = {"value": n_m / piv_s, "unit": "iterations/s", "cores": 1, "kind": "port",
+                   "regime": "the headline's: config 4 warm-started from the committed mature basis (nucleus 10 514, pi dense)",
+                   "window": [1, n_m], "seconds": round(piv_s, 3),
+                   "startup_seconds_excluded": round(om.startup_seconds, 2),
+                   "startup_threads": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)),
+                   "sample": f"pivots 1..{n_m} from the committed mature basis of the same LP, timed on this box: {piv_s:.2f} s of one core for the pivots "
+                             f"(dense LU solves of order 10 514: 4 per pivot); the start-up factorization ({om.startup_seconds:.1f} s, the only threaded "
+                             "part) is excluded here and on the GPU side.  CPU oracle = C restatement of ClpSimplexDual with a dense nucleus LU "
+                             "(the reference needs CoinUtils and cannot be built here; it is NOT Clp)",
+                   "gpu_same_window": {"value": n_m / tm, "unit": "iterations/s", "window": [1, n_m], "seconds": round(tm, 4),
+                                       "excludes": "the start-up factorization (clpgpu_dual_steps(0) before the clock)",
+                                       "speedup_vs_cpu_port": (n_m / tm) / (n_m / piv_s), "identical_pivots": int(n_same), "of": n_m,
+                                       "steepest_mode": "1 on both sides in this leg (full CHUZR scan: position-independent, so that both time the same pivots)"},
+                   "slack_start": slack_pair}
+            del em, om
         clp = clp_upstream(args, lp)
         cpu["clp_upstream"] = clp
 
@@ -600,6 +667,91 @@ def main():
                 "nucleus_at_end": int(el.stats()["nucleus"])})
             del el
 
+    # ---- what the ladder says about config 4's distance to its optimum: pivots to optimality against rows over the finished rungs
+    # (same generator, same density rule), least squares in log-log, extrapolated to this LP's rows
+    if tto is not None and tto.get("time_to_optimal_s") is None and ladder and default_workload:
+        done = [(r["rows"], r["engine_iterations"]) for r in ladder["rungs"] if r.get("status") == 0]
+        if len(done) >= 3:
+            lx, ly = np.log([d[0] for d in done]), np.log([d[1] for d in done])
+            slope, icpt = np.polyfit(lx, ly, 1)
+            need = float(np.exp(icpt + slope * np.log(lp.m)))
+            rate = (sustained or {}).get("mature") or (args.steps / elapsed)
+            tto["extrapolation"] = {
+                "law": f"pivots to optimality ~ rows^{slope:.2f} over the rungs finished in this run ({', '.join(str(d[0]) for d in done)} rows: "
+                       f"{', '.join(str(d[1]) for d in done)} pivots)",
+                "pivots_at_this_size": round(need), "at_the_sustained_rate_s": round(need / max(rate, 1e-9)),
+                "note": "an extrapolation of the same generator's smaller instances, not a measurement: the solve above is "
+                        f"{tto['iterations']} pivots in (counted from the committed basis at pivot 30 000 when started there)"}
+
+    # ---- BASELINE configs[2] and the Netlib-shaped variant as sub-records (children of this script on the same GPU, one after the other)
+    sub_records = None
+    if rank == 0 and world == 1 and default_workload and args.sub_records != "off":
+        sub_records = {}
+        shapes = {"dense": ["--rows", "5000", "--cols", "5000", "--steps", "300", "--warmup", "100", "--tto-budget", "30"],
+                  "netlib": ["--rows", "50000", "--cols", "200000", "--steps", "500", "--warmup", "200", "--tto-budget", "15"]}
+        for w in filter(None, args.sub_records.split(",")):
+            if w not in shapes:
+                continue
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, *shapes[w], "--cpu-iterations", "0", "--pmc", "off",
+                   "--ladder-budget", "0", "--sub-records", "off", "--shard-proxy", "off", "--start", "slack"]
+            t_sub = time.perf_counter()
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.sub_timeout)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                if r.returncode != 0 or not line:
+                    sub_records[w] = {"error": f"child rc {r.returncode}", "tail": (r.stderr or r.stdout)[-300:]}
+                    continue
+                c = json.loads(line[-1])
+                rf = c["roofline"]
+                sub_records[w] = {
+                    "workload": c["config"]["workload"], "value": c["value"], "unit": c["unit"], "ms_per_step": c["ms_per_step"],
+                    "pivot_window": c["config"]["pivot_window"], "window_counts_from": "the slack basis",
+                    "pricing": {"kernel": rf["kernel"], "bytes_per_launch": rf["bytes_per_launch"], "us_per_launch": rf["us_per_launch"],
+                                "achieved": rf["achieved"], "frac": rf["frac"], "duration_source": rf["duration_source"], "form_in_timed_window": rf["form_in_timed_window"]},
+                    "time_to_optimal": c["time_to_optimal"], "sustained": (c["sustained"] or {}).get("over_the_whole_leg"),
+                    "refactorizations": c["refactorizations"], "child_seconds": round(time.perf_counter() - t_sub, 1)}
+                prof = os.path.join(ROOT, "profiles", f"r06_mfma_{w}.txt")
+                if os.path.exists(prof):
+                    sub_records[w]["mfma_utilisation_profile"] = {"file": f"profiles/r06_mfma_{w}.txt", "text": open(prof).read()[-600:]}
+            except subprocess.TimeoutExpired:
+                sub_records[w] = {"error": f"child did not finish in {args.sub_timeout:.0f} s"}
+
+    # ---- what a rank of an R-GPU run launches per pivot, timed on this one GPU: the pricing kernel over the column shard [0, n / R)
+    # with a dense pi (the mature regime), for each R.  No 8-GPU node exists for this repository: this is the single-GPU proxy of the
+    # pricing part of the scaling curve; the two small list exchanges per pivot are NOT in it (loopback copies would
+    # time a host barrier, not xGMI).
+    shard_proxy = None
+    if rank == 0 and world == 1 and default_workload and args.shard_proxy != "off":
+        shard_proxy = {"unit": "us per launch (HIP events, 30 launches, dense pi)", "bytes": "SURVEY 8d B_col of the shard's columns", "ranks": []}
+        col_len = np.diff(np.asarray(lp.col_start))
+        for R in (int(x) for x in args.shard_proxy.split(",")):
+            last = (lp.n // R + 255) // 256 * 256 if R > 1 else lp.n
+            last = min(last, lp.n)
+            nnz_shard = int(col_len[:last].sum())
+            b_col = 12.0 * nnz_shard + 4.0 * (last + 1) + last + 8.0 * lp.m + 20.0 * last
+            ent = {"ranks": R, "columns": int(last), "nnz": nnz_shard, "bytes_per_launch": b_col}
+            try:
+                from clp_amd.engine import ClpGpuSimplex
+
+                for form, minwin in (("k_price_sell", None), ("k_price_lds", 1)):
+                    e = ClpGpuSimplex(local_rank)
+                    if minwin is not None:
+                        e.set_option("price_lds_min_windows", minwin)  # before the load: lays the shard out for the LDS form too
+                    e.loadProblem(lp)
+                    e.set_option("pivot_rule", args.pivot_rule)
+                    e.set_option("max_pivots", 0)
+                    if R > 1:
+                        e.setColumnRange(0, last)
+                    e.dual_steps(0)
+                    us = float(e.debugPriceBench([(1 << 20) if form == "k_price_lds" else 0], reps=30)[0])
+                    if us > 0:
+                        ent[form] = {"us": round(us, 2), "achieved": b_col / (us * 1e-6) / 1e9, "frac": b_col / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                     "aggregate_over_ranks": R * b_col / (us * 1e-6) / 1e9}
+                    del e
+            except Exception as ex:  # noqa: BLE001 -- a probe must not take the line down
+                ent["error"] = str(ex)[:200]
+            shard_proxy["ranks"].append(ent)
+
     config_ref = {"sparse": "BASELINE.json configs[3]", "dense": "BASELINE.json configs[2]",
                   "netlib": "Netlib-shaped variant of BASELINE.json configs[3]"}[args.workload]
     if (args.rows, args.cols) != {"dense": (5000, 5000)}.get(args.workload, (50000, 200000)):
@@ -656,6 +808,7 @@ def main():
                                    + " (row pricing + fused first ratio pass)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "bytes_per_launch": per_launch_bytes, "us_per_launch": per_launch_s * 1e6,
+                         "duration_source": duration_source, "kernel_trace": ktrace, "eager_events": events,
                          "launches": int(launches),
                          "window": ("replay of the timed pivots (eager, HIP events on the engine's stream): pi is dense in this regime, so the "
                                     "kernel form measured here (by column) is the one the timed window ran"
@@ -682,6 +835,8 @@ def main():
             "time_to_optimal_ladder": ladder,
             "sustained": sustained,
             "roofline_mature": regime,
+            "sub_records": sub_records,
+            "shard_pricing_proxy": shard_proxy,
             "refactorizations": int(headline_stats["refactorizations"]),
             # what sent the iteration loop to its status checks up to the end of the timed window (src/ClpSimplexDual.cpp:1849 scheduled,
             # :1451 alpha check, :1574 objective going backwards, :1618 bad update), and the chain's pricing form

@@ -263,6 +263,7 @@ struct Dev {
   double *sellMin, *sellBytes;  // per pricing workgroup
   double *chzBest;
   int *chzKey, *chzRow;
+  int *chzCnt;  // partial scan: entries above the tolerance in the workgroup's span of the list (bit 30: a flagged one or the last pivot row among them)
   double *normPartial;
   // refactorization scratch
   double *workW, *workX;  // [kcap*ld]

@@ -906,6 +906,7 @@ int clpgpu_context::loadProblem(int m_, int n_, const int *cs, const int *ri, co
   rc |= dalloc(D.chzBest, nChzBlocks);
   rc |= dalloc(D.chzKey, nChzBlocks);
   rc |= dalloc(D.chzRow, nChzBlocks);
+  rc |= dalloc(D.chzCnt, nChzBlocks);
   rc |= dalloc(D.normPartial, cdiv(m, 4) + 1);
   rc |= dalloc(dLocalOfRow, m);
   rc |= dalloc(dInfo, 4);
@@ -4471,9 +4472,20 @@ int clpgpu_context::debugPriceBench(int reps, int numberMasks, const int *masks,
     for (int r = 0; r < reps + 2; r++) {
       if (r == 2)
         (void)hipEventRecord(e0, stream);
-      hipLaunchKernelGGL(k_price_sell, dim3(nSlots), dim3(256), lds, stream, D, (m > 64 * SELL_BITS_MAX) ? 1 : 6, countInPrice ? 1 : 0, nSellBlocks,
-                         nSlots, 0, 0, masks[v]);
+      if (masks[v] & (1 << 20)) {
+        // bit 20: the dense-pi form of the chain (pi tiles in LDS) on this context's column range, when it was laid out
+        if (!jdsReady) {
+          microseconds[v] = -1.0;
+          break;
+        }
+        hipLaunchKernelGGL(k_price_lds, dim3(priceLdsGrid), dim3(PL_THREADS), priceLdsBytes, stream, D, countInPrice ? 1 : 0);
+      } else {
+        hipLaunchKernelGGL(k_price_sell, dim3(nSlots), dim3(256), lds, stream, D, (m > 64 * SELL_BITS_MAX) ? 1 : 6, countInPrice ? 1 : 0, nSellBlocks,
+                           nSlots, 0, 0, masks[v]);
+      }
     }
+    if ((masks[v] & (1 << 20)) && !jdsReady)
+      continue;
     (void)hipEventRecord(e1, stream);
     rc |= sync();
     float ms = 0.0f;

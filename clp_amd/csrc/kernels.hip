@@ -2667,17 +2667,22 @@ struct ChzStage {
   double best;  // ratio of the chosen row so far (the reference's `largest`)
   int bestKey, bestRow, remaining, special;
 };
-__device__ inline void chuzrOrderedScan(const Dev &D, ChzStage *S, double tolerance, int number, int start, int last, int wanted)
+// ranks [rankBegin, rankEnd) of the list, continuing from a choice made on the ranks before them (carryKey < 0: none)
+__device__ inline void chuzrOrderedScan(const Dev &D, ChzStage *S, double tolerance, int number, int start, int last, int wanted,
+                                        int rankBegin = 0, int rankEnd = 2147483647, double carryBest = 0.0, int carryKey = -1, int carryRow = -1)
 {
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  __syncthreads();
   if (t == 0) {
-    S->best = 0.0;
-    S->bestKey = -1;
-    S->bestRow = -1;
+    S->best = carryBest;
+    S->bestKey = carryKey;
+    S->bestRow = carryRow;
     S->remaining = wanted;
   }
   __syncthreads();
-  for (int base = 0; base < number; base += CHZ_CHUNK) {
+  if (rankEnd > number)
+    rankEnd = number;
+  for (int base = rankBegin; base < rankEnd; base += CHZ_CHUNK) {
     int iRow[CHZ_CHUNK_ITEMS], iSeq[CHZ_CHUNK_ITEMS];
     double value[CHZ_CHUNK_ITEMS], weight[CHZ_CHUNK_ITEMS];
 #pragma unroll
@@ -2686,7 +2691,7 @@ __device__ inline void chuzrOrderedScan(const Dev &D, ChzStage *S, double tolera
       int i = start + rank;
       if (i >= number)
         i -= number;
-      iRow[q] = rank < number ? D.infIndex[i] : -1;
+      iRow[q] = rank < rankEnd ? D.infIndex[i] : -1;
     }
 #pragma unroll
     for (int q = 0; q < CHZ_CHUNK_ITEMS; q++) {
@@ -2782,7 +2787,7 @@ __device__ inline void chuzrOrderedScan(const Dev &D, ChzStage *S, double tolera
     } else if (t == 0) {
       double largest = S->best;
       int left = remaining, chosenKey = S->bestKey, chosenRow = S->bestRow;
-      const int count = min(CHZ_CHUNK, number - base);
+      const int count = min(CHZ_CHUNK, rankEnd - base);
       for (int j = 0; j < count; j++) {
         const unsigned char f = S->flag[j];
         if (!(f & 1))
@@ -2837,17 +2842,85 @@ __global__ void __launch_bounds__(256) k_chuzr_scan(Dev D, int fuseFinal = -1)
   double best = 0.0;
   int bestKey = -1, bestRow = -1;
   if (c->pivotRule != 0 && c->chuzrWanted <= number) {
-    // partial scan (modes 2 / 3): the order of the list decides what is looked at -- workgroup 0 walks it, the others report nothing
-    if (blockIdx.x == 0) {
-      chuzrOrderedScan(D, &stage, tolerance, number, start, last, c->chuzrWanted);
-      best = stage.best;
-      bestKey = stage.bestKey;
-      bestRow = stage.bestRow;
+    // partial scan (modes 2 / 3): only the first numberWanted entries above the tolerance, counted from the random start, are looked
+    // at.  Every workgroup takes a span of RANKS (rank 0 = the random start) and reports the best of its span as if all of it counted,
+    // the number of entries above the tolerance in it, and whether a flagged candidate or the last pivot row is among them; the final
+    // selection finds the workgroup the cut falls into, takes the spans before it whole and walks that one span again in order
+    // (chuzrFinalBody).  Spans with the two exceptions send the final selection to the ordered walk of the whole list.
+    const int base = blockIdx.x * (256 * CHZ_ITEMS);
+    int iRow[CHZ_ITEMS], iSeq[CHZ_ITEMS];
+    double value[CHZ_ITEMS], rawWeight[CHZ_ITEMS];
+#pragma unroll
+    for (int q = 0; q < CHZ_ITEMS; q++) {
+      const int rank = base + q * 256 + threadIdx.x;
+      int i = start + rank;
+      if (i >= number)
+        i -= number;
+      iRow[q] = rank < number ? D.infIndex[i] : -1;
     }
+#pragma unroll
+    for (int q = 0; q < CHZ_ITEMS; q++) {
+      const int r = iRow[q] >= 0 ? iRow[q] : 0;
+      value[q] = D.infeas[r];
+      rawWeight[q] = D.weights[r];
+      iSeq[q] = D.pivotVariable[r];
+    }
+    int above = 0, special = 0;
+#pragma unroll
+    for (int q = 0; q < CHZ_ITEMS; q++) {
+      const unsigned char st = D.status[iSeq[q]];
+      const double sv = D.sol[iSeq[q]], up = D.upper[iSeq[q]], lo = D.lower[iSeq[q]];
+      if (iRow[q] >= 0 && value[q] > tolerance) {
+        above++;
+        if ((st & FLAGGED_BIT) || iRow[q] == last) {
+          special = 1;
+        } else if (sv > up + tolerance || sv < lo - tolerance) {
+          const double ratio = value[q] / fmin(rawWeight[q], 1.0e50);
+          const int rank = base + q * 256 + threadIdx.x;
+          if (ratio > best || (ratio == best && bestKey >= 0 && rank < bestKey)) {
+            best = ratio;
+            bestKey = rank;
+            bestRow = iRow[q];
+          }
+        }
+      }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int o = 32; o > 0; o >>= 1) {
+      double ov = __shfl_down(best, o);
+      int ok = __shfl_down(bestKey, o);
+      int orow = __shfl_down(bestRow, o);
+      above += __shfl_down(above, o);
+      special |= __shfl_down(special, o);
+      if (ok >= 0 && (bestKey < 0 || ov > best || (ov == best && ok < bestKey))) {
+        best = ov;
+        bestKey = ok;
+        bestRow = orow;
+      }
+    }
+    __shared__ int sha[4], shs[4];
+    if (lane == 0) {
+      shv[wv] = best;
+      shk[wv] = bestKey;
+      shr[wv] = bestRow;
+      sha[wv] = above;
+      shs[wv] = special;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
+      for (int i = 1; i < 4; i++) {
+        above += sha[i];
+        special |= shs[i];
+        if (shk[i] >= 0 && (bestKey < 0 || shv[i] > best || (shv[i] == best && shk[i] < bestKey))) {
+          best = shv[i];
+          bestKey = shk[i];
+          bestRow = shr[i];
+        }
+      }
       stc(&D.chzBest[blockIdx.x], best);
       stc(&D.chzKey[blockIdx.x], bestKey);
       stc(&D.chzRow[blockIdx.x], bestRow);
+      stc(&D.chzCnt[blockIdx.x], above | (special ? (1 << 30) : 0));
     }
     if (fuseFinal >= 0 && lastBlockDone(D.ctrl, 3))
       chuzrFinalBody<true>(D, gridDim.x, fuseFinal, &stage);
@@ -4297,6 +4370,30 @@ template <bool COHERENT> __device__ inline void chuzrFinalBody(const Dev &D, int
   int used = (c->chuzrNumber + 256 * CHZ_ITEMS - 1) / (256 * CHZ_ITEMS);
   if (used > nblocks)
     used = nblocks;
+  // partial scan: the workgroup the numberWanted-th entry above the tolerance falls into (k_chuzr_scan); spans before it count whole,
+  // that one is walked again in order, the ones behind it not at all
+  __shared__ int s_cut, s_before, s_special;
+  const bool partial = c->pivotRule != 0 && c->chuzrWanted <= c->chuzrNumber && c->presetRowPlus1 <= 0;
+  if (partial) {
+    if (threadIdx.x == 0) {
+      int before = 0, cut = used, special = 0;
+      for (int b = 0; b < used; b++) {
+        const int v = COHERENT ? ldc(&D.chzCnt[b]) : D.chzCnt[b];
+        special |= v >> 30;
+        const int cnt = v & ((1 << 30) - 1);
+        if (before + cnt >= c->chuzrWanted) {
+          cut = b;
+          break;
+        }
+        before += cnt;
+      }
+      s_cut = cut;
+      s_before = before;
+      s_special = special;
+    }
+    __syncthreads();
+    used = s_cut;  // (uniform)
+  }
   for (int b = threadIdx.x; b < used; b += blockDim.x) {
     double ov = COHERENT ? ldc(&D.chzBest[b]) : D.chzBest[b];
     int ok = COHERENT ? ldc(&D.chzKey[b]) : D.chzKey[b];
@@ -4330,6 +4427,34 @@ template <bool COHERENT> __device__ inline void chuzrFinalBody(const Dev &D, int
         bestKey = shk[i];
         bestRow = shr[i];
       }
+    shv[0] = best;
+    shk[0] = bestKey;
+    shr[0] = bestRow;
+  }
+  __syncthreads();
+  if (partial) {
+    // (all threads) the span of the cut in order, continuing from the best of the spans before it -- or, when a flagged candidate or
+    // the last pivot row sits in the scanned part, the whole list in order with the reference's own statements
+    const int cutBlocks = (c->chuzrNumber + 256 * CHZ_ITEMS - 1) / (256 * CHZ_ITEMS);
+    if (s_special)
+      chuzrOrderedScan(D, S, c->chuzrTolerance, c->chuzrNumber, c->chuzrStart, c->chuzrLast, c->chuzrWanted);
+    else if (s_cut < cutBlocks && s_cut < nblocks)
+      chuzrOrderedScan(D, S, c->chuzrTolerance, c->chuzrNumber, c->chuzrStart, c->chuzrLast, c->chuzrWanted - s_before, s_cut * (256 * CHZ_ITEMS),
+                       (s_cut + 1) * (256 * CHZ_ITEMS), shv[0], shk[0], shr[0]);
+    if (s_special || (s_cut < cutBlocks && s_cut < nblocks)) {
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        shv[0] = S->best;
+        shk[0] = S->bestKey;
+        shr[0] = S->bestRow;
+      }
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == 0) {
+    best = shv[0];
+    bestKey = shk[0];
+    bestRow = shr[0];
     // "won't line up with checkPrimalSolution - do again" (src/ClpDualRowSteepest.cpp:338-346): nothing chosen under the changed
     // tolerance -> the whole call once more with largestDualError_ 0
     s_again = bestRow < 0 && c->pivotRule != 0 && c->chuzrTolChanged && c->presetRowPlus1 <= 0;

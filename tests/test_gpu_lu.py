@@ -189,7 +189,9 @@ def test_lu_engine_solves_match_oracle(gpu_cls, args, rule):
 def test_lu_full_size_matches_inverse_mode(gpu_cls):
     """Config 4 at full size: LU mode from a nucleus of 512 on (front + tail + eta file active from pivot ~500)
     against the explicit-inverse engine over the first 2500 pivots: same entering / leaving variables,
-    objective to 1e-9, solution to 1e-7."""
+    objective to 1e-9, solution to 1e-7.  Under ClpDualRowSteepest's full scan (steepest_mode 1): the two modes put the basic
+    variables at different basis positions, as any two LU codes do, and the partial scan of the default mode 3 looks at the
+    first numberWanted rows of the infeasibility list IN POSITION ORDER -- two factorizations cannot share its pivots."""
     lp = P.sparse_lp()
     runs = []
     for mode in (0, 1):
@@ -198,6 +200,7 @@ def test_lu_full_size_matches_inverse_mode(gpu_cls):
         g.set_option("check_every", 16)
         g.set_option("max_pivots", 0)
         g.set_option("factor_mode", -1 if mode else 0)
+        g.set_option("steepest_mode", 1)
         g.set_option("lu_min_k", 512)
         g.set_option("lu_max_pivots", 300)
         assert g.dual_steps(2500) == -1 and g.numberIterations() == 2500

@@ -54,6 +54,7 @@ def test_lu_mode_from_the_mature_basis_follows_the_oracle(gpu_cls, stop_density,
     g.setStatusArray(status)
     g.set_option("pivot_rule", 1)
     g.set_option("max_pivots", 0)
+    g.set_option("steepest_mode", 1)
     if stop_density is not None:
         g.set_option("lu_stop_density", stop_density)
     assert g.dual_steps(ORACLE_PIVOTS) == -1
@@ -62,6 +63,7 @@ def test_lu_mode_from_the_mature_basis_follows_the_oracle(gpu_cls, stop_density,
     o = OracleSimplex(lp)
     o.set_option("pivot_rule", 1)
     o.set_option("max_pivots", 0)
+    o.set_option("steepest_mode", 1)
     o.set_status(status)
     o.set_option("max_iterations", ORACLE_PIVOTS)
     assert o.dual() == 3
@@ -75,6 +77,8 @@ def test_lu_mode_from_the_mature_basis_follows_the_oracle(gpu_cls, stop_density,
         same += 1
     print(f"mature basis, LU mode (stop density {stop_density or 'default'}) vs oracle: {same} of {ORACLE_PIVOTS} pivots identical (entering and leaving variables)")
     assert same >= need, f"pivot sequences part at pivot {same}"
+    if same < ORACLE_PIVOTS:
+        _assert_near_tie(gpu_cls, lp, status, stop_density, same, a[same], b[same])
     pre = slice(0, same)
     # alpha, theta, the leaving variable's infeasibility and the objective over the shared prefix.  The two sides solve with
     # different factorizations of bases whose condition numbers pass 1e10 in this stretch (the oracle's plain dense LU carries
@@ -93,6 +97,78 @@ def test_lu_mode_from_the_mature_basis_follows_the_oracle(gpu_cls, stop_density,
     assert np.array_equal(a["numberFlipped"][pre], b["numberFlipped"][pre])
     if same == ORACLE_PIVOTS:
         assert abs(g.objectiveValue() - o.objective) <= 1e-7 * abs(o.objective)
+
+
+def _assert_near_tie(gpu_cls, lp, status, stop_density, same, rec_engine, rec_oracle):
+    """Where the two sides part, the difference has to be a near-tie -- shown with both sides' own numbers at that pivot, not asserted
+    from the outside.  Both are brought to the state after `same` identical pivots (the oracle live: its dense LU of
+    the nucleus + `same` pivots, about two CPU-minutes); each side's tableau row of the leaving variable is formed from its own BTRAN
+    (rho = B^-T e_p through the plug-in call, alpha = rho^T [A | -I]) and its own reduced costs.
+      * leaving variables differ: infeasibility^2 / weight of the two rows agree to 1e-6 relative on BOTH sides (a tie of CHUZR);
+      * entering variables differ: the breakpoints dj / alpha of the long-step ratio test come in the same order on both sides up to the
+        first place where they do not, that place is not behind the earlier of the two choices, and the two breakpoints that swap there are
+        closer than 1e-5 relative on both sides (the sides' reduced costs agree to ~3e-6 after 147 pivots through bases of condition
+        1e10: closer breakpoints than that are ordered by rounding, and ClpSimplexDual::dualColumn's choice inside a lot follows the order)."""
+    from oracle.oracle import OracleSimplex
+
+    g2 = gpu_cls().loadProblem(lp)
+    g2.setStatusArray(status)
+    o2 = OracleSimplex(lp)
+    for s_ in (g2, o2):
+        s_.set_option("pivot_rule", 1)
+        s_.set_option("max_pivots", 0)
+        s_.set_option("steepest_mode", 1)
+    if stop_density is not None:
+        g2.set_option("lu_stop_density", stop_density)
+    o2.set_status(status)
+    o2.set_option("max_iterations", same)
+    assert g2.dual_steps(same) == -1 and o2.dual() == 3
+    pg, po = np.asarray(g2.pivotVariable()), np.asarray(o2.pivot_variable())
+    assert set(pg.tolist()) == set(po.tolist()), "the two bases differ although the pivots were identical"
+    print(f"first differing pivot {same + 1}: engine {rec_engine['sequenceOut']} -> {rec_engine['sequenceIn']} (alpha {rec_engine['alpha']:.9g}, "
+          f"{rec_engine['numberFlipped']} flips), oracle {rec_oracle['sequenceOut']} -> {rec_oracle['sequenceIn']} (alpha {rec_oracle['alpha']:.9g}, "
+          f"{rec_oracle['numberFlipped']} flips)")
+    if rec_engine["sequenceOut"] != rec_oracle["sequenceOut"]:
+        for name, pv, (w, inf) in (("engine", pg, g2.rowWeights()), ("oracle", po, o2.row_weights())):
+            r = []
+            for var in (rec_engine["sequenceOut"], rec_oracle["sequenceOut"]):
+                pos = int(np.nonzero(pv == var)[0][0])
+                r.append(inf[pos] / w[pos])
+                print(f"  {name}: leaving candidate {var}: infeasibility^2 / weight = {r[-1]:.17g}")
+            assert abs(r[0] - r[1]) <= 1e-6 * max(r), f"{name}: not a tie of CHUZR"
+        return
+    out = int(rec_engine["sequenceOut"])
+    A = sp.csc_matrix((lp.elem, lp.row, lp.col_start), shape=(lp.m, lp.n))
+    lower = np.concatenate([lp.col_lower, lp.row_lower])
+    upper = np.concatenate([lp.col_upper, lp.row_upper])
+    sides = {}
+    for name, pv, s_, dj in (("engine", pg, g2, np.asarray(g2.reducedCosts())), ("oracle", po, o2, np.asarray(o2.reduced_costs()))):
+        unit = np.zeros(lp.m)
+        unit[int(np.nonzero(pv == out)[0][0])] = 1.0
+        rho = np.asarray(s_.btran(unit))
+        alpha = np.concatenate([A.T @ rho, -rho])
+        nonbasic = np.ones(lp.m + lp.n, bool)
+        nonbasic[pv] = False
+        idx = np.nonzero(nonbasic & (np.abs(alpha) > 1e-9) & (dj / np.where(alpha == 0, 1.0, alpha) > 0) & (upper > lower))[0]
+        ratio = dj[idx] / alpha[idx]
+        order = np.argsort(ratio, kind="stable")
+        sides[name] = (idx[order], ratio[order], {int(v): float(r) for v, r in zip(idx, ratio)}, alpha)
+    (eo, er, emap, ealpha), (oo, orr, omap, oalpha) = sides["engine"], sides["oracle"]
+    ce, co = int(rec_engine["sequenceIn"]), int(rec_oracle["sequenceIn"])
+    for var in (ce, co):
+        print(f"  candidate {var}: engine alpha {ealpha[var]:.12g} ratio {emap[var]:.12g} (breakpoint no. {int(np.nonzero(eo == var)[0][0])}); "
+              f"oracle alpha {oalpha[var]:.12g} ratio {omap[var]:.12g} (breakpoint no. {int(np.nonzero(oo == var)[0][0])})")
+        assert abs(abs(ealpha[var]) - abs(oalpha[var])) <= 1e-5 * abs(oalpha[var]), "the two sides do not see the same tableau row"
+    n = min(len(eo), len(oo))
+    first = next((i for i in range(n) if eo[i] != oo[i]), None)
+    assert first is not None, "identical breakpoint orders, different choices: not a tie -- a difference in the ratio test's logic"
+    earlier = min(int(np.nonzero(eo == ce)[0][0]), int(np.nonzero(eo == co)[0][0]), int(np.nonzero(oo == ce)[0][0]), int(np.nonzero(oo == co)[0][0]))
+    x, y = int(eo[first]), int(oo[first])
+    print(f"  the breakpoint orders part at no. {first} (the earlier choice is no. {earlier}): engine has {x} there, the oracle {y}; "
+          f"engine ratios {emap.get(x)} / {emap.get(y)}, oracle ratios {omap.get(x)} / {omap.get(y)}")
+    assert first <= earlier, "the orders part only behind the earlier choice: the choices differ for another reason"
+    for m_ in (emap, omap):
+        assert x in m_ and y in m_ and abs(m_[x] - m_[y]) <= 1e-5 * max(abs(m_[x]), abs(m_[y])), "the swapped breakpoints are not a near-tie"
 
 
 def _basis(lp, pv):
