@@ -104,6 +104,7 @@ struct Ctrl {
   int steepestMode, chuzrWanted, chuzrTolChanged, chuzrRecalls;
   long long factorElements;
   int chuzrPartialScans, chuzrFloor;  // chuzrFloor: the 2000 of :260-276 (option debug_chuzr_floor)
+  int luCompactCount, luCompactOn;  // compact eta file: slots in use; 1 = the chain's FTRAN reads it (option lu_compact_eta)
   int debugDcTimeoutAt, debugPad;  // option debug_dc_wide_timeout_at: k_dual_column_wide reports a barrier timeout at this iteration
   double debugToleranceFactor;  // option debug_tolerance_factor (fault injection for the changed tolerance of CHUZR); 0 off
   double tailAlpha, tailValueOut;  // w[pivotRow] / sol[sequenceOut] handed to the serial tail of k_ftran_scatter3  // this pivot's primal update completed: its list appends may be scattered  // unordered append count of k_dj_flags (ordered later by k_flip_apply2)
@@ -153,6 +154,16 @@ struct LuDev {
   int *prevSame, *nextSame;  // [tcap] etas on the same position
   int *lastOfPos;      // [m]
   double *s, *g, *d;   // [3 * tcap], [tcap], [tcap]
+  // compact copy of the eta file for the chain's FTRAN (option lu_compact_eta): only the positions that hold -- or held at some pivot
+  // since the refactorization -- a structural.  Slot q < Ctrl::luCompactCount stands for position posOfCslot[q]; the structurals of the
+  // refactorization come first, in position order, then one slot per position whose slack left since (its column of H is copied in
+  // when that happens).  Every basic structural sits at a position with a slot; a position without one still holds the slack of its
+  // own row, and the FTRAN gets its value from the row itself: x_i = A[i, K] x_K - v_i over the row copy's basic part.
+  double *Hc;          // [tcap * ldc] eta j at Hc + j * ldc, by slot
+  int ldc;
+  int *cslotOfPos;     // [m] slot of a position, -1 none
+  int *posOfCslot;     // [ldc]
+  int *posOfBasicCol;  // [n] basis position of a basic structural (kept per pivot by the housekeeping kernel)
 };
 
 // All device pointers of one context.  Passed by value to kernels.

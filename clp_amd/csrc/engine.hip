@@ -100,7 +100,7 @@ struct DBuf {
 enum {
   LB_SROW, LB_SCOL, LB_SVAL, LB_ROWOFLOCAL, LB_POSOFCOL, LB_TAILROW, LB_TAILCOL, LB_SROWINDEX, LB_SROWSTART, LB_SROWCOL, LB_SROWVAL,
   LB_SCOLSTART, LB_SCOLROW, LB_SCOLVAL, LB_WR, LB_XC, LB_TCV, LB_X0, LB_CP, LB_Y, LB_H, LB_G, LB_GT, LB_P, LB_PREV, LB_NEXT, LB_S, LB_GV, LB_DV,
-  LB_LASTOFPOS, LB_TRI, LB_COUNT = LB_TRI + 35
+  LB_LASTOFPOS, LB_HC, LB_CSLOT, LB_POSOFCSLOT, LB_POSOFBASICCOL, LB_TRI, LB_COUNT = LB_TRI + 35
 };
 
 struct clpgpu_context {
@@ -300,6 +300,7 @@ struct clpgpu_context {
   // them from the share of dense-pi pivots in the last batch (Ctrl::statDensePi) -- either form prices any pi correctly, so
   // the choice changes the speed of a pivot, never its result.
   int numberDcWideTimeouts = 0, debugDcTimeoutAt = -1;
+  int luCompactEta = 1;  // option "lu_compact_eta": the chain's FTRAN reads the eta file over the structural positions only (device_state.h, LuDev::Hc)
   int dcWide = 1;  // option "dc_wide": 1 (default) lists beyond one workgroup's registers go to k_dual_column_wide, 2 every list does (tests), 0 the single-workgroup walk
   int priceLds = 1;
   int priceLdsMinWindows = 256;  // option "price_lds_min_windows": narrower LPs keep k_price_sell (a one-workgroup-per-CU launch needs work for every CU)
@@ -5343,6 +5344,7 @@ clpgpu_context *clpgpu_clone(const clpgpu_context *src)
   ctx->luAdaptive = src->luAdaptive;
   ctx->luMinPivots = src->luMinPivots;
   ctx->luInverseFillCap = src->luInverseFillCap;
+  ctx->luCompactEta = src->luCompactEta;
   ctx->fakeBoundCleanup = src->fakeBoundCleanup;
   ctx->checkBoth = src->checkBoth;
   ctx->freeNonbasic = src->freeNonbasic;
@@ -5649,6 +5651,7 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "lu_adaptive")) ctx->luAdaptive = (int)v;
   else if (!strcmp(name, "lu_min_pivots")) ctx->luMinPivots = std::max(1, (int)v);
   else if (!strcmp(name, "lu_inverse_fill_cap")) ctx->luInverseFillCap = v;
+  else if (!strcmp(name, "lu_compact_eta")) { ctx->luCompactEta = v != 0.0; ctx->dropGraph(); }
   else if (!strcmp(name, "fake_bound_cleanup")) ctx->fakeBoundCleanup = v != 0.0;
   else if (!strcmp(name, "fork_update")) { ctx->forkUpdate = (int)v; ctx->dropGraph(); }
   else if (!strcmp(name, "refresh_min_k")) ctx->refreshMinK = (int)v;

@@ -2332,7 +2332,20 @@ __device__ void houseBody(Dev D, int skipColumns = 0)
   int k = c->k;
   const int ucase = D.luMode ? -1 : c->updateCase;
   if (ucase < 0) {
-    // LU mode: the factorization's maps are frozen until the next refactorization
+    // LU mode: the factorization's maps are frozen until the next refactorization; the compact eta file's are not (device_state.h):
+    // the pivot's position gets a slot if it had none (k_lu_pf_append has filled the slot's column), the entering structural its
+    // position
+    const LuDev &L = *D.lu;
+    if (L.cslotOfPos[pivotRow] < 0 && c->luCompactCount < L.ldc) {
+      const int q = c->luCompactCount;
+      L.cslotOfPos[pivotRow] = q;
+      L.posOfCslot[q] = pivotRow;
+      c->luCompactCount = q + 1;
+    }
+    if (seqOut < n)
+      L.posOfBasicCol[seqOut] = -1;
+    if (seqIn < n)
+      L.posOfBasicCol[seqIn] = pivotRow;
   } else if (ucase == 0) {
     int a = c->slotColOut;
     D.slotOfCol[seqOut] = -1;

@@ -499,6 +499,35 @@ int clpgpu_context::factorizeLu(const std::vector<int> &kcol, const std::vector<
   L.d = (double *)luBuf[LB_DV].p;
   rc |= luBuf[LB_LASTOFPOS].need(this, sizeof(int) * (size_t)m, vp);
   L.lastOfPos = (int *)vp;
+  // compact eta file (device_state.h): slots of the positions that hold a structural now, in position order
+  {
+    std::vector<int> cslotOfPos(m, -1), posOfBasicCol(n, -1);
+    int count = 0;
+    for (int p = 0; p < m; p++)
+      if (pivotVariable[p] < n) {
+        cslotOfPos[p] = count++;
+        posOfBasicCol[pivotVariable[p]] = p;
+      }
+    const int ldc = std::min(m, (count + L.tcap + 63) & ~63);
+    std::vector<int> posOfCslot(ldc, -1);
+    for (int p = 0; p < m; p++)
+      if (cslotOfPos[p] >= 0)
+        posOfCslot[cslotOfPos[p]] = p;
+    rc |= luBuf[LB_CSLOT].put(this, cslotOfPos, ip);
+    L.cslotOfPos = ip;
+    rc |= luBuf[LB_POSOFCSLOT].put(this, posOfCslot, ip);
+    L.posOfCslot = ip;
+    rc |= luBuf[LB_POSOFBASICCOL].put(this, posOfBasicCol, ip);
+    L.posOfBasicCol = ip;
+    L.ldc = ldc;
+    L.Hc = nullptr;
+    if (luCompactEta) {
+      rc |= luBuf[LB_HC].need(this, sizeof(double) * (size_t)L.tcap * (size_t)ldc, vp);
+      L.Hc = (double *)vp;
+    }
+    hCtrl->luCompactCount = count;
+    hCtrl->luCompactOn = (luCompactEta && L.Hc) ? 1 : 0;
+  }
   if (rc)
     return rc;
   if (checkLaunches("factorizeLu (uploads)"))
@@ -547,7 +576,8 @@ int clpgpu_context::factorizeLu(const std::vector<int> &kcol, const std::vector<
     // 179 ms, build + upload 8 ms): host front ~ 2.2 us per nucleus column, tail ~ 4.9e-13 k2^3 s, 2 ms fixed.
     const double R = 2.0e-3 + 2.2e-6 * (double)k + 4.9e-13 * (double)k2 * (double)k2 * (double)k2;
     luRefactorSeconds = R;
-    const double a = 8.0 * (double)m / 3.0e12;
+    // (with the compact copy a pivot streams the etas over the ~k structural positions only)
+    const double a = 8.0 * (double)(hCtrl->luCompactOn ? std::min(m, k + 512) : m) / 3.0e12;
     int T = (int)sqrt(2.0 * luRefactorSeconds / a);
     T = std::min(std::max(T, luMinPivots), std::min(luMaxPivots, hLu.tcap - 1));
     luEtaLimit = luAdaptive ? T : std::min(luMaxPivots, hLu.tcap - 1);
@@ -623,6 +653,9 @@ void clpgpu_context::luLaunchFtran(int gm, int parity)
   {
     // positions per workgroup: one round of workgroups over the 256 CUs (m = 50 000: 250 workgroups of 200 positions, not 196 of 256)
     const int ppb = std::min(256, std::max(64, (cdiv(m, 256) + 7) & ~7));
-    KL("k_ftran_scatter3_lu", k_ftran_scatter3_lu, dim3(cdiv(m, ppb)), dim3(256), 0, stream, D, gm, parity, ppb);
+    const int compact = hCtrl->luCompactOn;
+    if (compact)  // x0 -= Hc s over the slots (the structural positions): 8 (k + conversions) t bytes instead of 8 m t
+      KL("k_lu_eta_apply", k_lu_eta_apply, dim3(256), dim3(256), 0, stream, D);
+    KL("k_ftran_scatter3_lu", k_ftran_scatter3_lu, dim3(cdiv(m, ppb)), dim3(256), 0, stream, D, gm, parity, ppb, compact);
   }
 }

@@ -334,11 +334,16 @@ __device__ inline void luPfApply(const Dev &D, int t, int p, const double *s0, c
 // the file for ALL 256 positions (four per lane), 8 etas x 4 positions = 32 loads in flight per lane, and the four partial sums of
 // a position are added in wave order -- 64 KB of H in flight per workgroup instead of 16 (one thread per position and eight loads
 // in flight left this stream at 0.35-0.42 of the HBM peak).  d1..d3 = -(H s) at position base + threadIdx.x.
+// (Hsrc / ld / limit: the full file H with stride m over the m positions by default; the compact copy Hc with stride ldc over its slots)
 __device__ inline void luPfApplyWg(const Dev &D, int t, int base, int ppb, const double *s0, const double *s1, const double *s2, double *part /*[4][3][256]*/,
-                                   double &d1, double &d2, double &d3)
+                                   double &d1, double &d2, double &d3, const double *Hsrc = nullptr, size_t ld = 0, int limit = -1)
 {
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const size_t m = (size_t)D.m;
+  const size_t m = Hsrc ? ld : (size_t)D.m;
+  if (!Hsrc)
+    Hsrc = LUD.H;
+  if (limit < 0)
+    limit = D.m;
   const int j0 = (int)(((long long)t * w) / 4), j1 = (int)(((long long)t * (w + 1)) / 4);
   double acc[4][3];
   bool live[4];
@@ -347,8 +352,8 @@ __device__ inline void luPfApplyWg(const Dev &D, int t, int base, int ppb, const
   for (int q = 0; q < 4; q++) {
     acc[q][0] = acc[q][1] = acc[q][2] = 0.0;
     const int p = base + lane + 64 * q;
-    live[q] = lane + 64 * q < ppb && p < D.m;  // ppb positions per workgroup (the launch balances m over the CUs)
-    Hp[q] = LUD.H + (live[q] ? p : 0);
+    live[q] = lane + 64 * q < ppb && p < limit;  // ppb positions per workgroup (the launch balances m over the CUs)
+    Hp[q] = Hsrc + (live[q] ? p : 0);
   }
   int j = j0;
   // (one workgroup per CU at this grid: registers are not what limits residency, bytes in flight are -- 8 etas x 4 positions)
@@ -741,7 +746,17 @@ __global__ void __launch_bounds__(256) k_lu_pf_append(Dev D, int chain, int gm)
       double v = D.w[p];
       if (p == r)
         v -= 1.0;
-      LUD.H[(size_t)t * D.m + p] = v / alpha;
+      v = v / alpha;
+      LUD.H[(size_t)t * D.m + p] = v;
+      if (c->luCompactOn) {
+        // the compact copy: the slot of this position; the pivot's position gets the next free slot when it has none yet (the maps are
+        // written by the housekeeping kernel behind this one, so every thread of this launch reads the same state)
+        int q = LUD.cslotOfPos[p];
+        if (q < 0 && p == r)
+          q = c->luCompactCount;
+        if (q >= 0)
+          LUD.Hc[(size_t)t * LUD.ldc + q] = v;
+      }
     }
     if (p == 0) {
       LUD.P[t] = r;
@@ -755,6 +770,12 @@ __global__ void __launch_bounds__(256) k_lu_pf_append(Dev D, int chain, int gm)
       LUD.GT[(size_t)t * LUD.tcap + t] = 1.0;
     }
     return;
+  }
+  if (c->luCompactOn && LUD.cslotOfPos[r] < 0) {
+    // the slack of row r leaves a position that had no slot: its column of H so far becomes the new slot's column
+    const int j = (blockIdx.x - gm) * blockDim.x + threadIdx.x;
+    if (j < t)
+      LUD.Hc[(size_t)j * LUD.ldc + c->luCompactCount] = LUD.H[(size_t)j * D.m + r];
   }
   // row t of G (and column t of GT): one wave per column i < t
   const int i = (blockIdx.x - gm) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -771,8 +792,45 @@ __global__ void __launch_bounds__(256) k_lu_pf_append(Dev D, int chain, int gm)
   }
 }
 
-// LU mode: x = x0 - H s per basis position (x0 from the k_lu_* sweeps, s from k_lu_pf_s), then the same back end
-__global__ void __launch_bounds__(256) k_ftran_scatter3_lu(Dev D, int nbNorm, int parity, int ppb)
+// compact eta file: x0 -= Hc s over the slots in use, for the three right-hand sides, in place (x0 by position).  The launch has one
+// workgroup per CU; the slots are dealt over them 64 at a time.
+__global__ void __launch_bounds__(256) k_lu_eta_apply(Dev D)
+{
+  const Ctrl *c = D.ctrl;
+  if (c->state != RUN)
+    return;
+  const int count = c->luCompactCount, t = c->pivots;
+  const int ppb = min(256, max(64, ((count + (int)gridDim.x - 1) / (int)gridDim.x + 63) & ~63));
+  const int base = blockIdx.x * ppb;
+  if (base >= count || t == 0)
+    return;
+  __shared__ double sS[3 * LU_TCAP_MAX];
+  __shared__ double sPart[4 * 3 * 256];
+  const bool doFlip = c->numberFlips != 0, doTau = c->pivotRule != 0;
+  for (int j = threadIdx.x; j < t; j += blockDim.x) {
+    sS[j] = LUD.s[j];
+    sS[LU_TCAP_MAX + j] = doTau ? LUD.s[LUD.tcap + j] : 0.0;
+    sS[2 * LU_TCAP_MAX + j] = doFlip ? LUD.s[2 * LUD.tcap + j] : 0.0;
+  }
+  __syncthreads();
+  double d1, d2, d3;
+  luPfApplyWg(D, t, base, ppb, sS, sS + LU_TCAP_MAX, sS + 2 * LU_TCAP_MAX, sPart, d1, d2, d3, LUD.Hc, (size_t)LUD.ldc, count);
+  const int q = base + threadIdx.x;
+  if ((int)threadIdx.x < ppb && q < count) {
+    const int p = LUD.posOfCslot[q];
+    LUD.x0[p] += d1;
+    if (doTau)
+      LUD.x0[(size_t)D.m + p] += d2;
+    if (doFlip)
+      LUD.x0[2 * (size_t)D.m + p] += d3;
+  }
+}
+
+// LU mode: x = x0 - H s per basis position (x0 from the k_lu_* sweeps, s from k_lu_pf_s), then the same back end.
+// compact: k_lu_eta_apply has already applied the eta file at the positions with a slot; the others hold the slack of their own row
+// since the refactorization and their value comes from that row of B x = v: x_i = A[i, K] x_K - v_i over the row copy's basic part
+// (8 lanes per position, fixed tree), with x_K read at the basic columns' positions.
+__global__ void __launch_bounds__(256) k_ftran_scatter3_lu(Dev D, int nbNorm, int parity, int ppb, int compact = 0)
 {
   const Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -794,13 +852,56 @@ __global__ void __launch_bounds__(256) k_ftran_scatter3_lu(Dev D, int nbNorm, in
   int p = -1;
   double x1 = 0.0, x2 = 0.0, x3 = 0.0;
   __shared__ double sPart[4 * 3 * 256];
-  double d1, d2, d3;
-  luPfApplyWg(D, t, blockIdx.x * ppb, ppb, sS, sS + LU_TCAP_MAX, sS + 2 * LU_TCAP_MAX, sPart, d1, d2, d3);
+  double d1 = 0.0, d2 = 0.0, d3 = 0.0;
+  if (compact) {
+    const size_t m = (size_t)D.m;
+    const int sub = threadIdx.x & 7;
+    for (int l0 = 0; l0 < ppb; l0 += 32) {
+      const int l = l0 + (threadIdx.x >> 3), i = blockIdx.x * ppb + l;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      const bool own = l < ppb && i < D.m && LUD.cslotOfPos[i] < 0;
+      if (own) {
+        const int s = D.rowStart[i], e = s + D.basicCount[i];
+        for (int q = s + sub; q < e; q += 8) {
+          const double el = D.relem[q];
+          const int pos = LUD.posOfBasicCol[D.ccol[q]];
+          a0 += el * LUD.x0[pos];
+          if (doTau)
+            a1 += el * LUD.x0[m + pos];
+          if (doFlip)
+            a2 += el * LUD.x0[2 * m + pos];
+        }
+      }
+      a0 += __shfl_xor(a0, 1);
+      a1 += __shfl_xor(a1, 1);
+      a2 += __shfl_xor(a2, 1);
+      a0 += __shfl_xor(a0, 2);
+      a1 += __shfl_xor(a1, 2);
+      a2 += __shfl_xor(a2, 2);
+      a0 += __shfl_xor(a0, 4);
+      a1 += __shfl_xor(a1, 4);
+      a2 += __shfl_xor(a2, 4);
+      if (own && sub == 0) {
+        sPart[l] = a0 - D.vecV1[i];
+        sPart[256 + l] = doTau ? a1 - D.rho[i] : 0.0;
+        sPart[512 + l] = doFlip ? a2 - D.flipRhs[i] : 0.0;
+      }
+    }
+    __syncthreads();
+  } else {
+    luPfApplyWg(D, t, blockIdx.x * ppb, ppb, sS, sS + LU_TCAP_MAX, sS + 2 * LU_TCAP_MAX, sPart, d1, d2, d3);
+  }
   if ((int)threadIdx.x < ppb && tt < D.m) {
     p = tt;
-    x1 = LUD.x0[p] + d1;
-    x2 = doTau ? LUD.x0[(size_t)D.m + p] + d2 : 0.0;
-    x3 = doFlip ? LUD.x0[2 * (size_t)D.m + p] + d3 : 0.0;
+    if (compact && LUD.cslotOfPos[p] < 0) {
+      x1 = sPart[threadIdx.x];
+      x2 = sPart[256 + threadIdx.x];
+      x3 = sPart[512 + threadIdx.x];
+    } else {
+      x1 = LUD.x0[p] + d1;
+      x2 = doTau ? LUD.x0[(size_t)D.m + p] + d2 : 0.0;
+      x3 = doFlip ? LUD.x0[2 * (size_t)D.m + p] + d3 : 0.0;
+    }
     if (doFlip)
       D.flipRhs[tt] = 0.0;  // consumed by k_lu_fwd / k_lu_slack
   }
