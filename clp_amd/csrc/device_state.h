@@ -159,8 +159,8 @@ struct LuDev {
   // refactorization come first, in position order, then one slot per position whose slack left since (its column of H is copied in
   // when that happens).  Every basic structural sits at a position with a slot; a position without one still holds the slack of its
   // own row, and the FTRAN gets its value from the row itself: x_i = A[i, K] x_K - v_i over the row copy's basic part.
-  double *Hc;          // [tcap * ldc] eta j at Hc + j * ldc, by slot
-  int ldc;
+  double *Hc;          // [ldc * tcap] slot-major: slot q holds its entries of etas 0 .. t - 1 at Hc + q * tcap
+  int ldc;             // slots allocated
   int *cslotOfPos;     // [m] slot of a position, -1 none
   int *posOfCslot;     // [ldc]
   int *posOfBasicCol;  // [n] basis position of a basic structural (kept per pivot by the housekeeping kernel)

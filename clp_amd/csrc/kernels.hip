@@ -4388,7 +4388,45 @@ template <bool COHERENT> __device__ inline void chuzrFinalBody(const Dev &D, int
   __shared__ int s_cut, s_before, s_special;
   const bool partial = c->pivotRule != 0 && c->chuzrWanted <= c->chuzrNumber && c->presetRowPlus1 <= 0;
   if (partial) {
-    if (threadIdx.x == 0) {
+    __shared__ int s_wave[4], s_wspec[4];
+    if (used <= (int)blockDim.x) {
+      // one count per thread, an inclusive scan over the workgroup, the first span whose running total reaches numberWanted
+      const int b = threadIdx.x, lane_ = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+      const int v = b < used ? (COHERENT ? ldc(&D.chzCnt[b]) : D.chzCnt[b]) : 0;
+      const int cnt = v & ((1 << 30) - 1);
+      int incl = cnt;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane_ >= o)
+          incl += up;
+      }
+      if (lane_ == 63)
+        s_wave[wv_] = incl;
+      if (threadIdx.x == 0) {
+        s_cut = used;
+        s_before = 0;
+        s_special = 0;
+      }
+      __syncthreads();
+      int offset = 0;
+      for (int w = 0; w < wv_; w++)
+        offset += s_wave[w];
+      incl += offset;
+      const int wanted = c->chuzrWanted;
+      const bool reached = b < used && incl >= wanted && incl - cnt < wanted;  // exactly one span (counts are >= 0), if any
+      if (reached) {
+        s_cut = b;
+        s_before = incl - cnt;
+      }
+      __syncthreads();
+      const int cut = s_cut;
+      const unsigned long long sp = __ballot(b < used && b <= cut && (v >> 30));
+      if (lane_ == 0)
+        s_wspec[wv_] = sp != 0ull;
+      __syncthreads();
+      if (threadIdx.x == 0)
+        s_special = s_wspec[0] | s_wspec[1] | s_wspec[2] | s_wspec[3];
+    } else if (threadIdx.x == 0) {
       int before = 0, cut = used, special = 0;
       for (int b = 0; b < used; b++) {
         const int v = COHERENT ? ldc(&D.chzCnt[b]) : D.chzCnt[b];

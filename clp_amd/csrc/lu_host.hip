@@ -655,7 +655,7 @@ void clpgpu_context::luLaunchFtran(int gm, int parity)
     const int ppb = std::min(256, std::max(64, (cdiv(m, 256) + 7) & ~7));
     const int compact = hCtrl->luCompactOn;
     if (compact)  // x0 -= Hc s over the slots (the structural positions): 8 (k + conversions) t bytes instead of 8 m t
-      KL("k_lu_eta_apply", k_lu_eta_apply, dim3(256), dim3(256), 0, stream, D);
+      KL("k_lu_eta_apply", k_lu_eta_apply, dim3(1024), dim3(256), 0, stream, D);
     KL("k_ftran_scatter3_lu", k_ftran_scatter3_lu, dim3(cdiv(m, ppb)), dim3(256), 0, stream, D, gm, parity, ppb, compact);
   }
 }

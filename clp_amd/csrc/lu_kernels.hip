@@ -755,7 +755,7 @@ __global__ void __launch_bounds__(256) k_lu_pf_append(Dev D, int chain, int gm)
         if (q < 0 && p == r)
           q = c->luCompactCount;
         if (q >= 0)
-          LUD.Hc[(size_t)t * LUD.ldc + q] = v;
+          LUD.Hc[(size_t)q * LUD.tcap + t] = v;
       }
     }
     if (p == 0) {
@@ -775,7 +775,7 @@ __global__ void __launch_bounds__(256) k_lu_pf_append(Dev D, int chain, int gm)
     // the slack of row r leaves a position that had no slot: its column of H so far becomes the new slot's column
     const int j = (blockIdx.x - gm) * blockDim.x + threadIdx.x;
     if (j < t)
-      LUD.Hc[(size_t)j * LUD.ldc + c->luCompactCount] = LUD.H[(size_t)j * D.m + r];
+      LUD.Hc[(size_t)c->luCompactCount * LUD.tcap + j] = LUD.H[(size_t)j * D.m + r];
   }
   // row t of G (and column t of GT): one wave per column i < t
   const int i = (blockIdx.x - gm) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -792,37 +792,69 @@ __global__ void __launch_bounds__(256) k_lu_pf_append(Dev D, int chain, int gm)
   }
 }
 
-// compact eta file: x0 -= Hc s over the slots in use, for the three right-hand sides, in place (x0 by position).  The launch has one
-// workgroup per CU; the slots are dealt over them 64 at a time.
+// compact eta file: x0 -= Hc s over the slots in use, for the three right-hand sides, in place (x0 by position).  Hc is slot-major
+// (slot q holds its t eta entries contiguously): a (slots x t) matrix against the three s vectors -- the shape of k_lu_gemv3, and its
+// form: one wave per four slots, 16-byte loads, two strips of 128 etas per trip.
 __global__ void __launch_bounds__(256) k_lu_eta_apply(Dev D)
 {
   const Ctrl *c = D.ctrl;
   if (c->state != RUN)
     return;
   const int count = c->luCompactCount, t = c->pivots;
-  const int ppb = min(256, max(64, ((count + (int)gridDim.x - 1) / (int)gridDim.x + 63) & ~63));
-  const int base = blockIdx.x * ppb;
-  if (base >= count || t == 0)
+  if (t == 0)
     return;
-  __shared__ double sS[3 * LU_TCAP_MAX];
-  __shared__ double sPart[4 * 3 * 256];
-  const bool doFlip = c->numberFlips != 0, doTau = c->pivotRule != 0;
-  for (int j = threadIdx.x; j < t; j += blockDim.x) {
-    sS[j] = LUD.s[j];
-    sS[LU_TCAP_MAX + j] = doTau ? LUD.s[LUD.tcap + j] : 0.0;
-    sS[2 * LU_TCAP_MAX + j] = doFlip ? LUD.s[2 * LUD.tcap + j] : 0.0;
-  }
-  __syncthreads();
-  double d1, d2, d3;
-  luPfApplyWg(D, t, base, ppb, sS, sS + LU_TCAP_MAX, sS + 2 * LU_TCAP_MAX, sPart, d1, d2, d3, LUD.Hc, (size_t)LUD.ldc, count);
-  const int q = base + threadIdx.x;
-  if ((int)threadIdx.x < ppb && q < count) {
-    const int p = LUD.posOfCslot[q];
-    LUD.x0[p] += d1;
-    if (doTau)
-      LUD.x0[(size_t)D.m + p] += d2;
-    if (doFlip)
-      LUD.x0[2 * (size_t)D.m + p] += d3;
+  const bool doTau = c->pivotRule != 0, doFlip = c->numberFlips != 0;
+  const int lane = threadIdx.x & 63;
+  const size_t ld = (size_t)LUD.tcap, m = (size_t)D.m;
+  const double *v1 = LUD.s, *v2 = LUD.s + LUD.tcap, *v3 = LUD.s + 2 * LUD.tcap;
+  for (int q0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LUG_ROWS; q0 < count; q0 += gridDim.x * 4 * LUG_ROWS) {
+    double a1[LUG_ROWS], a2[LUG_ROWS], a3[LUG_ROWS];
+    const double *row[LUG_ROWS];
+#pragma unroll
+    for (int r = 0; r < LUG_ROWS; r++) {
+      a1[r] = a2[r] = a3[r] = 0.0;
+      row[r] = LUD.Hc + (size_t)min(q0 + r, count - 1) * ld;
+    }
+    for (int i = 2 * lane; i < t; i += 256) {
+      const int ib = i + 128;
+      const bool vb = ib < t, ya = i + 1 < t, yb = ib + 1 < t;
+      double2 ma[LUG_ROWS], mb[LUG_ROWS];
+#pragma unroll
+      for (int r = 0; r < LUG_ROWS; r++) {
+        ma[r] = *reinterpret_cast<const double2 *>(row[r] + i);
+        mb[r] = vb ? *reinterpret_cast<const double2 *>(row[r] + ib) : make_double2(0.0, 0.0);
+      }
+      double xs[3][4];
+      const double2 zero2 = make_double2(0.0, 0.0);
+      const double2 p1a = *reinterpret_cast<const double2 *>(v1 + i), p1b = vb ? *reinterpret_cast<const double2 *>(v1 + ib) : zero2;
+      const double2 p2a = doTau ? *reinterpret_cast<const double2 *>(v2 + i) : zero2, p2b = (doTau && vb) ? *reinterpret_cast<const double2 *>(v2 + ib) : zero2;
+      const double2 p3a = doFlip ? *reinterpret_cast<const double2 *>(v3 + i) : zero2, p3b = (doFlip && vb) ? *reinterpret_cast<const double2 *>(v3 + ib) : zero2;
+      xs[0][0] = p1a.x, xs[0][1] = ya ? p1a.y : 0.0, xs[0][2] = p1b.x, xs[0][3] = yb ? p1b.y : 0.0;
+      xs[1][0] = p2a.x, xs[1][1] = ya ? p2a.y : 0.0, xs[1][2] = p2b.x, xs[1][3] = yb ? p2b.y : 0.0;
+      xs[2][0] = p3a.x, xs[2][1] = ya ? p3a.y : 0.0, xs[2][2] = p3b.x, xs[2][3] = yb ? p3b.y : 0.0;
+#pragma unroll
+      for (int r = 0; r < LUG_ROWS; r++) {
+        const double mv[4] = { ma[r].x, ya ? ma[r].y : 0.0, mb[r].x, yb ? mb[r].y : 0.0 };
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          a1[r] += mv[u] * xs[0][u];
+          a2[r] += mv[u] * xs[1][u];
+          a3[r] += mv[u] * xs[2][u];
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < LUG_ROWS; r++) {
+      const double r1 = waveSum(a1[r]), r2 = waveSum(a2[r]), r3 = waveSum(a3[r]);
+      if (lane == 0 && q0 + r < count) {
+        const int p = LUD.posOfCslot[q0 + r];
+        LUD.x0[p] -= r1;
+        if (doTau)
+          LUD.x0[m + p] -= r2;
+        if (doFlip)
+          LUD.x0[2 * m + p] -= r3;
+      }
+    }
   }
 }
 
@@ -854,40 +886,44 @@ __global__ void __launch_bounds__(256) k_ftran_scatter3_lu(Dev D, int nbNorm, in
   __shared__ double sPart[4 * 3 * 256];
   double d1 = 0.0, d2 = 0.0, d3 = 0.0;
   if (compact) {
+    // one thread per position of the workgroup's span; the entries of a row four at a time, every level of the chain
+    // entry -> column -> its position -> x requested for the four before anything is used
     const size_t m = (size_t)D.m;
-    const int sub = threadIdx.x & 7;
-    for (int l0 = 0; l0 < ppb; l0 += 32) {
-      const int l = l0 + (threadIdx.x >> 3), i = blockIdx.x * ppb + l;
+    const int i = blockIdx.x * ppb + threadIdx.x;
+    if ((int)threadIdx.x < ppb && i < D.m && LUD.cslotOfPos[i] < 0) {
+      const int s = D.rowStart[i], e = s + D.basicCount[i];
+      const double *x0 = LUD.x0, *x1v = LUD.x0 + m, *x2v = LUD.x0 + 2 * m;
       double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-      const bool own = l < ppb && i < D.m && LUD.cslotOfPos[i] < 0;
-      if (own) {
-        const int s = D.rowStart[i], e = s + D.basicCount[i];
-        for (int q = s + sub; q < e; q += 8) {
-          const double el = D.relem[q];
-          const int pos = LUD.posOfBasicCol[D.ccol[q]];
-          a0 += el * LUD.x0[pos];
-          if (doTau)
-            a1 += el * LUD.x0[m + pos];
-          if (doFlip)
-            a2 += el * LUD.x0[2 * m + pos];
+      for (int q = s; q < e; q += 4) {
+        double el[4];
+        int pos[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const bool in = q + u < e;
+          el[u] = in ? D.relem[q + u] : 0.0;
+          pos[u] = in ? D.ccol[q + u] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          pos[u] = pos[u] >= 0 ? LUD.posOfBasicCol[pos[u]] : 0;
+        double y0[4], y1[4], y2[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          y0[u] = x0[pos[u]];
+          y1[u] = doTau ? x1v[pos[u]] : 0.0;
+          y2[u] = doFlip ? x2v[pos[u]] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          a0 += el[u] * y0[u];
+          a1 += el[u] * y1[u];
+          a2 += el[u] * y2[u];
         }
       }
-      a0 += __shfl_xor(a0, 1);
-      a1 += __shfl_xor(a1, 1);
-      a2 += __shfl_xor(a2, 1);
-      a0 += __shfl_xor(a0, 2);
-      a1 += __shfl_xor(a1, 2);
-      a2 += __shfl_xor(a2, 2);
-      a0 += __shfl_xor(a0, 4);
-      a1 += __shfl_xor(a1, 4);
-      a2 += __shfl_xor(a2, 4);
-      if (own && sub == 0) {
-        sPart[l] = a0 - D.vecV1[i];
-        sPart[256 + l] = doTau ? a1 - D.rho[i] : 0.0;
-        sPart[512 + l] = doFlip ? a2 - D.flipRhs[i] : 0.0;
-      }
+      sPart[threadIdx.x] = a0 - D.vecV1[i];
+      sPart[256 + threadIdx.x] = doTau ? a1 - D.rho[i] : 0.0;
+      sPart[512 + threadIdx.x] = doFlip ? a2 - D.flipRhs[i] : 0.0;
     }
-    __syncthreads();
   } else {
     luPfApplyWg(D, t, blockIdx.x * ppb, ppb, sS, sS + LU_TCAP_MAX, sS + 2 * LU_TCAP_MAX, sPart, d1, d2, d3);
   }

@@ -107,8 +107,9 @@ def _assert_near_tie(gpu_cls, lp, status, stop_density, same, rec_engine, rec_or
       * leaving variables differ: infeasibility^2 / weight of the two rows agree to 1e-6 relative on BOTH sides (a tie of CHUZR);
       * entering variables differ: the breakpoints dj / alpha of the long-step ratio test come in the same order on both sides up to the
         first place where they do not, that place is not behind the earlier of the two choices, and the two breakpoints that swap there are
-        closer than 1e-5 relative on both sides (the sides' reduced costs agree to ~3e-6 after 147 pivots through bases of condition
-        1e10: closer breakpoints than that are ordered by rounding, and ClpSimplexDual::dualColumn's choice inside a lot follows the order)."""
+        closer on both sides than the dual tolerance allows telling apart: |ratio_x - ratio_y| <= 1e-7 (1 / |alpha_x| + 1 / |alpha_y|) (the
+        sides' reduced costs agree to ~2e-9 absolute after 147 pivots through bases of condition 1e10; ClpSimplexDual::dualColumn's choice
+        inside a lot follows the order of the breakpoints)."""
     from oracle.oracle import OracleSimplex
 
     g2 = gpu_cls().loadProblem(lp)
@@ -167,8 +168,15 @@ def _assert_near_tie(gpu_cls, lp, status, stop_density, same, rec_engine, rec_or
     print(f"  the breakpoint orders part at no. {first} (the earlier choice is no. {earlier}): engine has {x} there, the oracle {y}; "
           f"engine ratios {emap.get(x)} / {emap.get(y)}, oracle ratios {omap.get(x)} / {omap.get(y)}")
     assert first <= earlier, "the orders part only behind the earlier choice: the choices differ for another reason"
-    for m_ in (emap, omap):
-        assert x in m_ and y in m_ and abs(m_[x] - m_[y]) <= 1e-5 * max(abs(m_[x]), abs(m_[y])), "the swapped breakpoints are not a near-tie"
+    # a breakpoint dj / alpha is known to dj's accuracy over |alpha|; reduced costs closer than the dual tolerance (1e-7) are the same
+    # number to ClpSimplexDual (and the two sides' differ by ~2e-9 here): two breakpoints whose distance is below
+    # dualTolerance (1 / |alpha_x| + 1 / |alpha_y|) have no order that rounding does not decide
+    for name_, m_, al_ in (("engine", emap, ealpha), ("oracle", omap, oalpha)):
+        assert x in m_ and y in m_
+        gap, room = abs(m_[x] - m_[y]), 1.0e-7 * (1.0 / abs(al_[x]) + 1.0 / abs(al_[y]))
+        print(f"  {name_}: breakpoints {x} / {y}: |alpha| {abs(al_[x]):.6g} / {abs(al_[y]):.6g}, distance {gap:.3g} in ratio units against {room:.3g} "
+              "= the dual tolerance over the two |alpha|")
+        assert gap <= room, "the swapped breakpoints are not a near-tie"
 
 
 def _basis(lp, pv):
