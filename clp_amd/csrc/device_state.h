@@ -71,7 +71,7 @@ struct Ctrl {
   double statDensePi;                        // pricing launches whose pi was dense (12 nnz >= m): what the host picks the chain's pricing kernel by
   // CHUZR hand-over between its three kernels
   double chuzrTolerance;
-  int chuzrNumber, chuzrStart, chuzrLast, chuzrPad;
+  int chuzrNumber, chuzrStart, chuzrLast, chuzrOrdered;  // chuzrOrdered: partial scans that had to walk the whole list in order (a flagged candidate / the last pivot row in the scanned part)
   int classCount[4];
   int tCount, preDone;  // ratio-test candidates by breakpoint class (k_cand_scatter)
   long long dbg[16];    // development counters (CLPGPU_DEBUG_STATS)

@@ -6114,6 +6114,7 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
   stats->dc_wide_timeouts = ctx->numberDcWideTimeouts;
   stats->chuzr_partial_scans = ctx->hCtrl->chuzrPartialScans;
   stats->chuzr_recalls = ctx->hCtrl->chuzrRecalls;
+  stats->chuzr_ordered_walks = ctx->hCtrl->chuzrOrdered;
   stats->factor_elements = (long)ctx->hCtrl->factorElements;
   stats->nucleus_capacity = ctx->kcap;
   stats->refreshes = ctx->numberRefreshes;

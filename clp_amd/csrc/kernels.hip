@@ -2659,31 +2659,30 @@ __global__ void k_chuzr_pre(Dev D)
 
 #define CHZ_ITEMS 2
 // ---- the list scan of ClpDualRowSteepest::pivotRow in ITS order, by one workgroup (src/ClpDualRowSteepest.cpp:279-335) ----
-// Used where the order decides more than ties: the partial scan of modes 2 / 3 (the call stops after numberWanted entries above the
-// tolerance, counted from the random start) and the second call of :338-346.  The list is walked in rank order (rank 0 = the random
-// start) a chunk of CHZ_CHUNK entries at a time; the dependent loads of a chunk (list -> row -> basic variable -> value and bounds) are
-// requested level by level for all of it and the result staged in LDS.  A chunk without a flagged candidate and without the last pivot
-// row is finished in parallel: the entries above the tolerance are counted by ballots, the first `remaining` of them are eligible, the
-// best ratio among those (first of equals) is compared with what the earlier chunks left.  The two exceptions make the count depend on
-// the running maximum (a flagged candidate that would have been chosen hands its ticket back, the last pivot row put off by
-// `continue` never takes one), so a chunk that holds one is walked by one thread from the staged copy with the reference's own
-// statements.
+// Used where the order decides more than ties: the span of a partial scan (modes 2 / 3) in which the numberWanted-th entry above the
+// tolerance falls, the rest of such a scan from the first span that holds a flagged candidate or the last pivot row, and the second
+// call of :338-346.  The reference's loop carries two things from entry to entry -- `largest` (the ratio of the row chosen so far) and
+// numberWanted -- and both are scans over the list in rank order (rank 0 = the random start):
+//   largest before e   = max of value / weight over the earlier entries that could be chosen (above the tolerance, not flagged,
+//                        really infeasible), an exclusive prefix maximum;
+//   tickets used by e  = 1 for an entry above the tolerance, except 0 for a flagged one that passes `value > largest * weight` (it
+//                        hands its ticket back, :321-324) and 0 for the last pivot row when it is put off by `continue` (:303-305);
+//   e is looked at     iff the tickets used before it are fewer than numberWanted; the chosen row is the first largest ratio among
+//                        the entries looked at (`value > largest * weight` is strict).
+// A chunk of CHZ_CHUNK entries is loaded level by level (list -> row -> basic variable -> value and bounds) and scanned slab by slab
+// (256 consecutive ranks, one per thread): wave scans by shuffles, the four waves through LDS, the running values in registers.
 #define CHZ_CHUNK_ITEMS 4
 #define CHZ_CHUNK (256 * CHZ_CHUNK_ITEMS)
 struct ChzStage {
-  double value[CHZ_CHUNK], weight[CHZ_CHUNK];
-  int row[CHZ_CHUNK];
-  unsigned char flag[CHZ_CHUNK];  // 1 above the tolerance, 2 flagged, 4 really infeasible, 8 the last pivot row
-  int waveCount[CHZ_CHUNK_ITEMS * 4];
-  double shv[4];
-  int shk[4], shr[4];
   double best;  // ratio of the chosen row so far (the reference's `largest`)
-  int bestKey, bestRow, remaining, special;
+  int bestKey, bestRow, remaining, pad;
 };
 // ranks [rankBegin, rankEnd) of the list, continuing from a choice made on the ranks before them (carryKey < 0: none)
 __device__ inline void chuzrOrderedScan(const Dev &D, ChzStage *S, double tolerance, int number, int start, int last, int wanted,
                                         int rankBegin = 0, int rankEnd = 2147483647, double carryBest = 0.0, int carryKey = -1, int carryRow = -1)
 {
+  __shared__ double sMax[2][4], sLastC, sBv[4];
+  __shared__ int sSum[2][4], sLastRank, sBk[4], sBr[4];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   __syncthreads();
   if (t == 0) {
@@ -2713,8 +2712,7 @@ __device__ inline void chuzrOrderedScan(const Dev &D, ChzStage *S, double tolera
       weight[q] = D.weights[r];
       iSeq[q] = D.pivotVariable[r];
     }
-    unsigned char fl[CHZ_CHUNK_ITEMS];
-    int special = 0;
+    unsigned char fl[CHZ_CHUNK_ITEMS];  // 1 above the tolerance, 2 flagged, 4 really infeasible, 8 the last pivot row
 #pragma unroll
     for (int q = 0; q < CHZ_CHUNK_ITEMS; q++) {
       const unsigned char st = D.status[iSeq[q]];
@@ -2728,110 +2726,120 @@ __device__ inline void chuzrOrderedScan(const Dev &D, ChzStage *S, double tolera
           f |= 4;
         if (iRow[q] == last)
           f |= 8;
-        if (f & 10)
-          special = 1;
       }
       fl[q] = f;
       weight[q] = fmin(weight[q], 1.0e50);
-      const int slot = q * 256 + t;
-      S->value[slot] = value[q];
-      S->weight[slot] = weight[q];
-      S->row[slot] = iRow[q];
-      S->flag[slot] = f;
-      const unsigned long long above = __ballot(f & 1);
-      if (lane == 0)
-        S->waveCount[q * 4 + wv] = __popcll(above);
     }
-    special = __syncthreads_or(special);
+    const double carryL = S->best;
     const int remaining = S->remaining;
-    if (!special) {
-      double best = 0.0;
-      int bestKey = -1, bestRow = -1, seen = 0;
+    double runL = carryL;  // `largest` in front of the slab (the same in every thread)
+    int runUsed = 0;       // tickets used in front of the slab
+    double best = 0.0;
+    int bestKey = -1, bestRow = -1;
+    if (t == 0)
+      sLastRank = -1;
 #pragma unroll
-      for (int q = 0; q < CHZ_CHUNK_ITEMS; q++) {
-        int before = 0;
-        for (int w = 0; w < q * 4 + wv; w++)
-          before += S->waveCount[w];
-        const unsigned long long above = __ballot(fl[q] & 1);
-        before += __popcll(above & ((1ull << lane) - 1ull));
-        if ((fl[q] & 5) == 5 && before < remaining) {
-          const double ratio = value[q] / weight[q];
-          const int rank = base + q * 256 + t;
-          if (ratio > best || (ratio == best && bestKey >= 0 && rank < bestKey)) {
-            best = ratio;
-            bestKey = rank;
-            bestRow = iRow[q];
+    for (int q = 0; q < CHZ_CHUNK_ITEMS; q++) {
+      const int rank = base + q * 256 + t, par = q & 1;
+      const unsigned char f = fl[q];
+      // what this entry would make `largest` if it were chosen (the last pivot row joins below)
+      const double cand = ((f & 15) == 5) ? value[q] / weight[q] : -1.0;
+      double incl = cand;
+      for (int o = 1; o < 64; o <<= 1) {
+        const double up_ = __shfl_up(incl, o);
+        if (lane >= o)
+          incl = fmax(incl, up_);
+      }
+      double excl = __shfl_up(incl, 1);
+      if (lane == 0)
+        excl = -1.0;
+      if (lane == 63)
+        sMax[par][wv] = incl;
+      __syncthreads();
+      double Lb = fmax(runL, excl);
+      for (int w = 0; w < wv; w++)
+        Lb = fmax(Lb, sMax[par][w]);
+      // the last pivot row: put off (`continue`, no ticket) when its scaled value cannot win, otherwise it competes with value * 1e-10
+      int skipTicket = 0;
+      double mine = cand;
+      if (f & 8) {
+        if (value[q] > Lb * weight[q]) {
+          if (value[q] * 1.0e-10 < Lb * weight[q]) {
+            skipTicket = 1;
+          } else if ((f & 6) == 4) {
+            mine = (value[q] * 1.0e-10) / weight[q];
+            sLastC = mine;
+            sLastRank = rank;
           }
         }
-      }
-      for (int w = 0; w < CHZ_CHUNK_ITEMS * 4; w++)
-        seen += S->waveCount[w];
-      for (int o = 32; o > 0; o >>= 1) {
-        double ov = __shfl_down(best, o);
-        int ok = __shfl_down(bestKey, o);
-        int orow = __shfl_down(bestRow, o);
-        if (ok >= 0 && (bestKey < 0 || ov > best || (ov == best && ok < bestKey))) {
-          best = ov;
-          bestKey = ok;
-          bestRow = orow;
-        }
-      }
-      if (lane == 0) {
-        S->shv[wv] = best;
-        S->shk[wv] = bestKey;
-        S->shr[wv] = bestRow;
       }
       __syncthreads();
-      if (t == 0) {
-        for (int i = 1; i < 4; i++)
-          if (S->shk[i] >= 0 && (bestKey < 0 || S->shv[i] > best || (S->shv[i] == best && S->shk[i] < bestKey))) {
-            best = S->shv[i];
-            bestKey = S->shk[i];
-            bestRow = S->shr[i];
-          }
-        // value > largest * weight (:296): a later chunk only wins with a strictly larger ratio
-        if (bestKey >= 0 && best > S->best) {
-          S->best = best;
-          S->bestKey = bestKey;
-          S->bestRow = bestRow;
-        }
-        S->remaining = seen >= remaining ? 0 : remaining - seen;
+      if (sLastRank >= 0 && rank > sLastRank)
+        Lb = fmax(Lb, sLastC);
+      // tickets
+      int d = (f & 1) ? 1 : 0;
+      if ((f & 3) == 3 && !(f & 8) && value[q] > Lb * weight[q])
+        d = 0;  // flagged and it would have been chosen: numberWanted++ (:321-324)
+      if ((f & 11) == 11) {  // the last pivot row, flagged: the reference tests `continue` first, then flagged
+        if (value[q] > Lb * weight[q] && !skipTicket)
+          d = 0;
       }
-    } else if (t == 0) {
-      double largest = S->best;
-      int left = remaining, chosenKey = S->bestKey, chosenRow = S->bestRow;
-      const int count = min(CHZ_CHUNK, rankEnd - base);
-      for (int j = 0; j < count; j++) {
-        const unsigned char f = S->flag[j];
-        if (!(f & 1))
-          continue;
-        double v = S->value[j];
-        const double weight = S->weight[j];
-        if (v > largest * weight) {
-          if (f & 8) {
-            if (v * 1.0e-10 < largest * weight)
-              continue;
-            else
-              v *= 1.0e-10;
-          }
-          if (!(f & 2)) {
-            if (f & 4) {
-              chosenRow = S->row[j];
-              chosenKey = base + j;
-              largest = v / weight;
-            }
-          } else {
-            left++;
-          }
-        }
-        left--;
-        if (!left)
-          break;
+      if (skipTicket)
+        d = 0;
+      int sincl = d;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up_ = __shfl_up(sincl, o);
+        if (lane >= o)
+          sincl += up_;
       }
-      S->best = largest;
-      S->bestKey = chosenKey;
-      S->bestRow = chosenRow;
-      S->remaining = left;
+      if (lane == 63)
+        sSum[par][wv] = sincl;
+      __syncthreads();
+      int usedBefore = runUsed + sincl - d;
+      for (int w = 0; w < wv; w++)
+        usedBefore += sSum[par][w];
+      // looked at iff fewer than numberWanted tickets were used before it; chosen: first largest ratio, strictly above what came before
+      if (mine >= 0.0 && usedBefore < remaining && !skipTicket && (bestKey < 0 || mine > best)) {  // (this thread's ranks ascend)
+        best = mine;
+        bestKey = rank;
+        bestRow = iRow[q];
+      }
+      // running values for the next slab
+      runL = fmax(fmax(fmax(runL, sMax[par][0]), fmax(sMax[par][1], sMax[par][2])), sMax[par][3]);
+      if (sLastRank >= 0 && sLastRank >= base + q * 256 && sLastRank < base + (q + 1) * 256)
+        runL = fmax(runL, sLastC);
+      runUsed += sSum[par][0] + sSum[par][1] + sSum[par][2] + sSum[par][3];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      double ov = __shfl_down(best, o);
+      int ok = __shfl_down(bestKey, o);
+      int orow = __shfl_down(bestRow, o);
+      if (ok >= 0 && (bestKey < 0 || ov > best || (ov == best && ok < bestKey))) {
+        best = ov;
+        bestKey = ok;
+        bestRow = orow;
+      }
+    }
+    if (lane == 0) {
+      sBv[wv] = best;
+      sBk[wv] = bestKey;
+      sBr[wv] = bestRow;
+    }
+    __syncthreads();
+    if (t == 0) {
+      for (int i = 1; i < 4; i++)
+        if (sBk[i] >= 0 && (bestKey < 0 || sBv[i] > best || (sBv[i] == best && sBk[i] < bestKey))) {
+          best = sBv[i];
+          bestKey = sBk[i];
+          bestRow = sBr[i];
+        }
+      // value > largest * weight (:296): a later chunk only wins with a strictly larger ratio
+      if (bestKey >= 0 && best > S->best) {
+        S->best = best;
+        S->bestKey = bestKey;
+        S->bestRow = bestRow;
+      }
+      S->remaining = runUsed >= remaining ? 0 : remaining - runUsed;
     }
     __syncthreads();
     if (S->remaining <= 0)
@@ -4420,17 +4428,28 @@ template <bool COHERENT> __device__ inline void chuzrFinalBody(const Dev &D, int
       }
       __syncthreads();
       const int cut = s_cut;
-      const unsigned long long sp = __ballot(b < used && b <= cut && (v >> 30));
+      // the first span up to the cut that holds one of the two exceptions: the spans before it still count whole, the ordered walk
+      // starts there
+      const bool isSpec = b < used && b <= cut && (v >> 30);
+      const unsigned long long sp = __ballot(isSpec);
       if (lane_ == 0)
-        s_wspec[wv_] = sp != 0ull;
+        s_wspec[wv_] = sp ? wv_ * 64 + (__ffsll((unsigned long long)sp) - 1) : (1 << 30);
       __syncthreads();
-      if (threadIdx.x == 0)
-        s_special = s_wspec[0] | s_wspec[1] | s_wspec[2] | s_wspec[3];
+      const int first = min(min(s_wspec[0], s_wspec[1]), min(s_wspec[2], s_wspec[3]));
+      if (b == first) {
+        s_special = 1;
+        s_cut = first;  // "used" below: the spans before the first exception
+        s_before = incl - cnt;
+      }
     } else if (threadIdx.x == 0) {
       int before = 0, cut = used, special = 0;
       for (int b = 0; b < used; b++) {
         const int v = COHERENT ? ldc(&D.chzCnt[b]) : D.chzCnt[b];
-        special |= v >> 30;
+        if (v >> 30) {  // the ordered walk starts at this span
+          special = 1;
+          cut = b;
+          break;
+        }
         const int cnt = v & ((1 << 30) - 1);
         if (before + cnt >= c->chuzrWanted) {
           cut = b;
@@ -4487,8 +4506,12 @@ template <bool COHERENT> __device__ inline void chuzrFinalBody(const Dev &D, int
     // (all threads) the span of the cut in order, continuing from the best of the spans before it -- or, when a flagged candidate or
     // the last pivot row sits in the scanned part, the whole list in order with the reference's own statements
     const int cutBlocks = (c->chuzrNumber + 256 * CHZ_ITEMS - 1) / (256 * CHZ_ITEMS);
-    if (s_special)
-      chuzrOrderedScan(D, S, c->chuzrTolerance, c->chuzrNumber, c->chuzrStart, c->chuzrLast, c->chuzrWanted);
+    if (s_special) {
+      if (threadIdx.x == 0)
+        c->chuzrOrdered++;
+      chuzrOrderedScan(D, S, c->chuzrTolerance, c->chuzrNumber, c->chuzrStart, c->chuzrLast, c->chuzrWanted - s_before, s_cut * (256 * CHZ_ITEMS),
+                       2147483647, shv[0], shk[0], shr[0]);
+    }
     else if (s_cut < cutBlocks && s_cut < nblocks)
       chuzrOrderedScan(D, S, c->chuzrTolerance, c->chuzrNumber, c->chuzrStart, c->chuzrLast, c->chuzrWanted - s_before, s_cut * (256 * CHZ_ITEMS),
                        (s_cut + 1) * (256 * CHZ_ITEMS), shv[0], shk[0], shr[0]);

@@ -87,6 +87,7 @@ typedef struct {
   /* ClpDualRowSteepest::pivotRow (option steepest_mode, src/ClpDualRowSteepest.cpp:258-346) */
   long chuzr_partial_scans; /* calls that looked at numberWanted entries of the infeasibility list instead of all of them (:258-278, :329-335) */
   long chuzr_recalls;       /* second calls with largestDualError 0 after a changed tolerance found no row (:338-346) */
+  long chuzr_ordered_walks; /* partial scans that walked the list in order in one workgroup (a flagged candidate or the last pivot row in the scanned part) */
   long dc_wide_timeouts;    /* times k_dual_column_wide's grid barrier gave up (the context then keeps long lists in one workgroup, option dc_wide 0) */
   long factor_elements;     /* what stands for factorization()->numberElements() since the last factorization (option steepest_elements) */
 } clpgpu_stats;

@@ -33,5 +33,6 @@ for opts in sys.argv[1:] or ["lu_compact_eta=1", "lu_compact_eta=0"]:
     rows.sort(reverse=True)
     print(f"== {opts}: eta count {s0['eta_count']} -> {s1['eta_count']}, nucleus {s1['nucleus']}, tail {s1['lu_tail']}, refactorizations in the window {s1['refactorizations'] - s0['refactorizations']}; "
           f"sum {sum(r[0] for r in rows):.1f} us per pivot (eager launches, event after each)")
+    print("   partial scans", s1["chuzr_partial_scans"] - s0["chuzr_partial_scans"], "ordered walks", s1["chuzr_ordered_walks"] - s0["chuzr_ordered_walks"])
     for us, name, per in rows[:30]:
         print(f"   {name:28s} {us:8.2f} us per pivot ({per:.2f} launches)")
