@@ -163,6 +163,8 @@ struct LuDev {
   int ldc;             // slots allocated
   int *cslotOfPos;     // [m] slot of a position, -1 none
   int *posOfCslot;     // [ldc]
+  const int *sRowOf;   // [m] index of a row among the frozen slack rows (sRow*), -1 none
+  int ncs0;            // slots at the refactorization (the later ones are positions whose slack left since)
   int *posOfBasicCol;  // [n] basis position of a basic structural (kept per pivot by the housekeeping kernel)
 };
 

@@ -520,6 +520,9 @@ int clpgpu_context::factorizeLu(const std::vector<int> &kcol, const std::vector<
     rc |= luBuf[LB_POSOFBASICCOL].put(this, posOfBasicCol, ip);
     L.posOfBasicCol = ip;
     L.ldc = ldc;
+    L.ncs0 = count;
+    rc |= luBuf[LB_SROWOF].put(this, sRowOf, ip);
+    L.sRowOf = ip;
     L.Hc = nullptr;
     if (luCompactEta) {
       rc |= luBuf[LB_HC].need(this, sizeof(double) * (size_t)L.tcap * (size_t)ldc, vp);
@@ -647,7 +650,9 @@ void clpgpu_context::luLaunchFtran(int gm, int parity)
      D.rhoSlotF, D.flipSlot);
   KL("k_lu_gemv3", k_lu_gemv3, dim3(cdiv(kc, 16)), dim3(256), 0, stream, D);
   KL("k_lu_bwd", k_lu_bwd, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, (const double *)D.slotC, (const double *)D.slotD, (const double *)D.slotE, 1, 1, 1);
-  KL("k_lu_slack", k_lu_slack, dim3(cdiv(m, 32), 3), dim3(256), 0, stream, D, 1, (const double *)D.vecV1, (const double *)D.rho,
+  // (compact eta file: only the positions whose slack left since the refactorization still need their B0 value -- for s = G x0[P];
+  // the untouched slack positions get their final value from their own rows in k_ftran_scatter3_lu)
+  KL("k_lu_slack", k_lu_slack, dim3(hCtrl->luCompactOn ? cdiv(hLu.tcap, 32) : cdiv(m, 32), 3), dim3(256), 0, stream, D, 1, (const double *)D.vecV1, (const double *)D.rho,
        (const double *)D.flipRhs, 1, 1, 1);
   KL("k_lu_pf_s", k_lu_pf_s, dim3(128), dim3(256), 0, stream, D, 1, 1, 1, 1);
   {

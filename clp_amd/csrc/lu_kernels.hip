@@ -237,7 +237,15 @@ __global__ void __launch_bounds__(256) k_lu_slack(Dev D, int chain, const double
     return;
   // 8 lanes per row (fixed 8-way tree): rows are short on the uniform LPs, long on the power-law ones
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  const int s = g >> 3, sub = g & 7;
+  int s = g >> 3;
+  const int sub = g & 7;
+  if (chain && c->luCompactOn) {
+    // compact eta file: the rows of the positions that got a slot since the refactorization (their slack left), nothing else
+    const int q = LUD.ncs0 + s;
+    s = q < c->luCompactCount ? LUD.sRowOf[LUD.posOfCslot[q]] : LUD.ns;
+    if (s < 0)
+      s = LUD.ns;
+  }
   double acc = 0.0;
   if (s < LUD.ns) {
     const double *xc = LUD.xc + (size_t)r * LUD.kpad;
