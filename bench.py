@@ -584,7 +584,11 @@ def main():
                 "k_gemv3g": (8.0 * kd * kd, "hbm", "three FTRAN right-hand sides through the dense " + ("tail inverse" if lu else "nucleus inverse") + ": 8 k^2 B"),
                 "k_lu_gemvT": (8.0 * kd * kd, "hbm", "BTRAN through the transposed tail inverse: 8 k^2 B"),
                 "k_lu_gemv3": (8.0 * kd * kd, "hbm", "three FTRAN right-hand sides through the dense tail inverse in one sweep: 8 k^2 B"),
-                "k_ftran_scatter3_lu": (8.0 * lp.m * eta + 3 * 8.0 * lp.m, "hbm", "eta file: x = x0 - H s over the m positions, 8 m t B (t = etas since the factorization)"),
+                "k_ftran_scatter3_lu": ((8.0 * lp.m * eta + 3 * 8.0 * lp.m, "hbm", "eta file: x = x0 - H s over the m positions, 8 m t B (t = etas since the factorization)")
+                                        if not i1["eta_compact_slots"] else
+                                        (None, "latency", "compact eta file: the scatter, DSE weights and the slack positions from their own rows (gathers)")),
+                "k_lu_eta_apply": (8.0 * float(i1["eta_compact_slots"]) * eta, "hbm",
+                                   "compact eta file: x_K -= Hc s over the positions that hold or held a structural, 8 (k + conversions) t B instead of 8 m t"),
                 "k_primal_rank1": (16.0 * kd * kd, "hbm", "rank-1 update of the explicit nucleus inverse: 16 k^2 B"),
                 "k_price_sell": (None if "k_price_lds" in kern else price_b, "hbm", "row pricing by column: bytes the kernel streams (4 B per row index, 8 B per element fetched, lists)"),
                 "k_price_lds": (price_b, "hbm", "row pricing by column with pi tiles in LDS (jagged tile-by-tile streams of the SELL windows, fused first ratio pass): SURVEY 8d's B_col = 12 B per entry of the scanned columns + lists"),

@@ -6115,6 +6115,7 @@ int clpgpu_get_stats(clpgpu_context *ctx, clpgpu_stats *stats)
   stats->chuzr_partial_scans = ctx->hCtrl->chuzrPartialScans;
   stats->chuzr_recalls = ctx->hCtrl->chuzrRecalls;
   stats->chuzr_ordered_walks = ctx->hCtrl->chuzrOrdered;
+  stats->eta_compact_slots = (ctx->luActive && ctx->hCtrl->luCompactOn) ? ctx->hCtrl->luCompactCount : 0;
   stats->factor_elements = (long)ctx->hCtrl->factorElements;
   stats->nucleus_capacity = ctx->kcap;
   stats->refreshes = ctx->numberRefreshes;

@@ -39,7 +39,8 @@ class Stats(C.Structure):
                 ("exits_bad_update", C.c_long), ("comm_mode", C.c_long), ("shard_cand_cap", C.c_long),
                 ("free_first_rows", C.c_long), ("free_entered", C.c_long), ("try_primal_exits", C.c_long),
                 ("chuzr_partial_scans", C.c_long), ("chuzr_recalls", C.c_long),
-                ("chuzr_ordered_walks", C.c_long), ("dc_wide_timeouts", C.c_long), ("factor_elements", C.c_long)]
+                ("chuzr_ordered_walks", C.c_long), ("dc_wide_timeouts", C.c_long),
+                ("eta_compact_slots", C.c_long), ("factor_elements", C.c_long)]
 
 
 # every symbol include/clpgpu.h declares (tests/test_abi.py checks the library exports all of them)

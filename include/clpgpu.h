@@ -89,6 +89,7 @@ typedef struct {
   long chuzr_recalls;       /* second calls with largestDualError 0 after a changed tolerance found no row (:338-346) */
   long chuzr_ordered_walks; /* partial scans that walked the list in order in one workgroup (a flagged candidate or the last pivot row in the scanned part) */
   long dc_wide_timeouts;    /* times k_dual_column_wide's grid barrier gave up (the context then keeps long lists in one workgroup, option dc_wide 0) */
+  long eta_compact_slots;   /* LU mode, option lu_compact_eta: positions the chain's FTRAN reads the eta file over (structurals of the refactorization + positions whose slack left since); 0 when the full file is read */
   long factor_elements;     /* what stands for factorization()->numberElements() since the last factorization (option steepest_elements) */
 } clpgpu_stats;
 
