@@ -16,20 +16,25 @@ Legs (rank 0 prints ONE JSON line):
                 factorization of that basis is part of them), then EXACTLY K pivots as captured hipGraphs, bracketed by barrier +
                 synchronize; `value` = K / max-over-ranks time.  `slack_start` = the same count of pivots from the slack basis
                 (the near-identity regime earlier rounds quoted as the headline), a secondary field.  --start slack restores it.
-  roofline      a second context replays THE SAME pivots (the engine is deterministic) with eager
-                launches and HIP events on the engine's stream: pricing-kernel time per launch and the
-                algorithmic bytes the kernel counted (SURVEY.md 8d) -> achieved / peak = frac;
-                `per_kernel_us` = every kernel of the chain over the same window (kernel + launch gap).
-                `traffic` = HBM bytes per pricing launch from PMC counters: bench.py re-runs itself under
-                `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, --kernel-trace only)
-                and averages the launches of the timed window; falls back to the committed summary
-                under profiles/ (named in `traffic_source`) when rocprofv3 cannot run.
-                `moved_frac` = traffic / time / peak: what the memory system really delivered.
-  cpu_baseline  the CPU oracle (a C restatement of the reference loop -- the reference needs CoinUtils and
-                cannot be built here) on the same LP from the slack basis for >= 500 pivots and >= 5 s (at most 2000 pivots: ~17 s of CPU in all),
-                one core; `gpu_same_window` is the engine over exactly those pivots, so the ratio
-                compares like with like.  `clp_upstream` = real `clp` on the same LP written as MPS, when a
-                clp binary is on PATH; null otherwise.
+  roofline      the pricing kernel of the timed window.  `achieved` = algorithmic bytes (counted by the kernel) / the
+                kernel's OWN average duration over the timed pivots, taken from a `rocprofv3 --kernel-trace` child pass of this script
+                (`kernel_trace`, `duration_source`); the same bytes over the HIP-event time of an EAGER replay of the window (a second
+                context: the engine is deterministic; event pair + launch gap included) stays as `eager_events`, and is what `frac`
+                falls back to when rocprofv3 cannot run.  `per_kernel_us` = every kernel of the chain over the same replay.
+                `traffic` = HBM bytes per pricing launch from PMC counters: two more child passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`,
+                each with --kernel-trace only), mean of the launches of the timed window; falls back to the committed summary under
+                profiles/ (named in `traffic_source`).  `moved_frac` = traffic / time / peak.
+  cpu_baseline  the CPU oracle (a C restatement of the reference loop -- the reference needs CoinUtils and cannot be built here) LIVE
+                on this box IN THE HEADLINE'S REGIME: warm-started from the same committed mature basis for --cpu-mature-pivots
+                pivots (40: ~10 s of one core), its start-up factorization (a dense LU of order 10 514, ~15 s, threaded) clocked apart
+                and excluded on both sides; `gpu_same_window` = the engine over exactly those pivots after its own start-up
+                factorization, with the count of identical pivots (both sides under ClpDualRowSteepest's full scan in this leg: see
+                the comment at the leg).  `slack_start` = the pair of rounds 1-5 (oracle and engine over pivots 1..2000 from the
+                slack basis).  `clp_upstream` = real `clp` on the same LP written as MPS when a clp binary is on PATH; null otherwise.
+  sub_records   BASELINE configs[2] (dense 5000 x 5000) and the Netlib-shaped variant, each a child run of this script: window from
+                the slack basis, pricing roofline, time to optimal.
+  shard_pricing_proxy  the pricing kernel of a column shard [0, n / R) for R = 1, 2, 4, 8 timed on this one GPU (no 8-GPU node exists
+                for this repository): what a rank of an R-GPU run launches per pivot.
   time_to_optimal  the solve continued to optimality within --tto-budget seconds (or how far it got); compared with
                 the independent optimum under tests/golden/bench_optima.json when there is one.
   time_to_optimal_ladder  LPs of the same generator at sizes an independent solver finishes (tools/ladder.py, optima in

@@ -657,8 +657,8 @@ void clpgpu_context::luLaunchFtran(int gm, int parity)
   KL("k_lu_pf_s", k_lu_pf_s, dim3(128), dim3(256), 0, stream, D, 1, 1, 1, 1);
   {
     // positions per workgroup: one round of workgroups over the 256 CUs (m = 50 000: 250 workgroups of 200 positions, not 196 of 256)
-    const int ppb = std::min(256, std::max(64, (cdiv(m, 256) + 7) & ~7));
     const int compact = hCtrl->luCompactOn;
+    const int ppb = compact ? luScatterPpb : std::min(256, std::max(64, (cdiv(m, 256) + 7) & ~7));
     if (compact)  // x0 -= Hc s over the slots (the structural positions): 8 (k + conversions) t bytes instead of 8 m t
       KL("k_lu_eta_apply", k_lu_eta_apply, dim3(1024), dim3(256), 0, stream, D);
     KL("k_ftran_scatter3_lu", k_ftran_scatter3_lu, dim3(cdiv(m, ppb)), dim3(256), 0, stream, D, gm, parity, ppb, compact);

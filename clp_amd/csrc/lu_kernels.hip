@@ -880,12 +880,14 @@ __global__ void __launch_bounds__(256) k_ftran_scatter3_lu(Dev D, int nbNorm, in
   const int t = c->pivots;
   const bool doFlip = c->numberFlips != 0, doTau = c->pivotRule != 0;
   const double tolerance = c->primalTolerance;
-  for (int j = threadIdx.x; j < t; j += blockDim.x) {
-    sS[j] = LUD.s[j];
-    sS[LU_TCAP_MAX + j] = doTau ? LUD.s[LUD.tcap + j] : 0.0;
-    sS[2 * LU_TCAP_MAX + j] = doFlip ? LUD.s[2 * LUD.tcap + j] : 0.0;
+  if (!compact) {
+    for (int j = threadIdx.x; j < t; j += blockDim.x) {
+      sS[j] = LUD.s[j];
+      sS[LU_TCAP_MAX + j] = doTau ? LUD.s[LUD.tcap + j] : 0.0;
+      sS[2 * LU_TCAP_MAX + j] = doFlip ? LUD.s[2 * LUD.tcap + j] : 0.0;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   // ppb <= 256 positions per workgroup, chosen by the launch so that one round of workgroups covers the m positions on all CUs
   // (256 positions each left 60 of the 256 CUs without work at m = 50 000)
   const int tt = blockIdx.x * ppb + threadIdx.x;
@@ -894,35 +896,35 @@ __global__ void __launch_bounds__(256) k_ftran_scatter3_lu(Dev D, int nbNorm, in
   __shared__ double sPart[4 * 3 * 256];
   double d1 = 0.0, d2 = 0.0, d3 = 0.0;
   if (compact) {
-    // one thread per position of the workgroup's span; the entries of a row four at a time, every level of the chain
-    // entry -> column -> its position -> x requested for the four before anything is used
+    // one thread per position of the workgroup's span; the entries of a row eight at a time, every level of the chain
+    // entry -> column -> its position -> x requested for the eight before anything is used
     const size_t m = (size_t)D.m;
     const int i = blockIdx.x * ppb + threadIdx.x;
     if ((int)threadIdx.x < ppb && i < D.m && LUD.cslotOfPos[i] < 0) {
       const int s = D.rowStart[i], e = s + D.basicCount[i];
       const double *x0 = LUD.x0, *x1v = LUD.x0 + m, *x2v = LUD.x0 + 2 * m;
       double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-      for (int q = s; q < e; q += 4) {
-        double el[4];
-        int pos[4];
+      for (int q = s; q < e; q += 8) {
+        double el[8];
+        int pos[8];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < 8; u++) {
           const bool in = q + u < e;
           el[u] = in ? D.relem[q + u] : 0.0;
           pos[u] = in ? D.ccol[q + u] : -1;
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < 8; u++)
           pos[u] = pos[u] >= 0 ? LUD.posOfBasicCol[pos[u]] : 0;
-        double y0[4], y1[4], y2[4];
+        double y0[8], y1[8], y2[8];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < 8; u++) {
           y0[u] = x0[pos[u]];
           y1[u] = doTau ? x1v[pos[u]] : 0.0;
           y2[u] = doFlip ? x2v[pos[u]] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < 8; u++) {
           a0 += el[u] * y0[u];
           a1 += el[u] * y1[u];
           a2 += el[u] * y2[u];
