@@ -341,6 +341,7 @@ struct clpgpu_context {
   int shardGrow = 1;  // option "shard_grow": 0 = an overflow goes straight to the dense row exchange (tests)
   double *dCandSend = nullptr, *dCandRecv = nullptr, *dFlipSend = nullptr, *dFlipRecv = nullptr;
   int allocShardBuffers();
+  bool shardBuffersOwned = false;
   void *comm = nullptr;
   int (*ncclAllGatherFn)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
   clpgpu_virtual_group *virtualGroup = nullptr;  // loopback exchange instead of RCCL (clpgpu_virtual_attach)
@@ -988,6 +989,7 @@ void clpgpu_context::releaseProblem()
   logCapacity = 0;
   dKcol = dLocalOfRow = dInfo = nullptr;
   dCandSend = dCandRecv = dFlipSend = dFlipRecv = nullptr;
+  shardBuffersOwned = false;
   nLongBlocks = nSellBlocks = nChzBlocks = 0;
   weightsInitialized = false;
   haveStatus = false;
@@ -1028,19 +1030,57 @@ void clpgpu_context::applyShard()
 
 int clpgpu_context::allocShardBuffers()
 {
-  if (dalloc(D.classBlock, 3 * (size_t)(cdiv(m, PRICE_BLOCK) + cdiv(n, PRICE_BLOCK) + cdiv(nranks * shardCandCap, PRICE_BLOCK) + 4)))
-    return -99;
+  // (called again when the exchange buffers grow, EXIT_SHARD_OVERFLOW: the previous ones are freed once the new set is complete;
+  // a failure half-way leaves the old pointers and sizes in place for the dense-row fall-back -- ADVICE round 5)
+  int *newClass = nullptr;
+  double *newCandSend = nullptr, *newCandRecv = nullptr, *newFlipSend = nullptr, *newFlipRecv = nullptr;
   const size_t candRec = SHARD_HDR + 4 * (size_t)shardCandCap, flipRec = SHARD_HDR + 5 * (size_t)shardFlipCap;
   int rc = 0;
-  rc |= dalloc(dCandSend, candRec);
-  rc |= dalloc(dCandRecv, candRec * (size_t)nranks);
-  rc |= dalloc(dFlipSend, flipRec);
-  rc |= dalloc(dFlipRecv, flipRec * (size_t)nranks);
-  return rc;
+  rc |= dalloc(newClass, 3 * (size_t)(cdiv(m, PRICE_BLOCK) + cdiv(n, PRICE_BLOCK) + cdiv(nranks * shardCandCap, PRICE_BLOCK) + 4));
+  if (!rc)
+    rc |= dalloc(newCandSend, candRec);
+  if (!rc)
+    rc |= dalloc(newCandRecv, candRec * (size_t)nranks);
+  if (!rc)
+    rc |= dalloc(newFlipSend, flipRec);
+  if (!rc)
+    rc |= dalloc(newFlipRecv, flipRec * (size_t)nranks);
+  auto release = [&](void *q) {
+    if (!q)
+      return;
+    auto it = std::find(allocations.begin(), allocations.end(), q);
+    if (it != allocations.end()) {
+      allocations.erase(it);
+      (void)hipStreamSynchronize(stream);
+      (void)hipFree(q);
+    }
+  };
+  if (rc) {
+    release(newClass);
+    release(newCandSend);
+    release(newCandRecv);
+    release(newFlipSend);
+    release(newFlipRecv);
+    return -99;
+  }
+  if (shardBuffersOwned) {
+    release(D.classBlock);
+    release(dCandSend);
+    release(dCandRecv);
+    release(dFlipSend);
+    release(dFlipRecv);
+  } else {
+    release(D.classBlock);  // the load-time array is replaced by the wider one
+  }
+  D.classBlock = newClass;
+  dCandSend = newCandSend;
+  dCandRecv = newCandRecv;
+  dFlipSend = newFlipSend;
+  dFlipRecv = newFlipRecv;
+  shardBuffersOwned = true;
+  return 0;
 }
 
-// launch errors (bad extents, missing code object) are sticky until read: surface them where the
-// launches were issued instead of at the next blocking call
 int clpgpu_context::checkLaunches(const char *where)
 {
   hipError_t e = hipGetLastError();
