@@ -162,8 +162,12 @@ struct clpgpu_context {
   int tryPrimal = 0, numberTryPrimal = 0;
   // ClpDualRowSteepest::mode_ (src/ClpDualRowSteepest.hpp:118: the constructor's default is 3) and what stands for
   // factorization()->numberElements() in its mode 3 (src/ClpDualRowSteepest.cpp:262): 0 = entries of the basic structural columns (the
-  // count of an LU without fill; what the oracle computes too), 1 = this factorization's own stored entries
-  int steepestMode = 3, steepestElements = 0, chuzrFloor = 2000, debugLastBadIteration = -999999;
+  // count of an LU without fill; what the oracle computes too), 1 (default) = what the factorization on the device holds in
+  // CoinFactorization's terms: in LU mode front L + U + the dense tail + the frozen slack part; under the explicit inverse -- nuclei
+  // below lu_min_k, which triangularize or nearly so -- the entries an LU of that nucleus holds, i.e. the same count as 0 (k^2, the
+  // inverse's own storage, would send a 224-column nucleus of a 50 000-row LP past ratio 1 where CoinFactorization's LU of it holds
+  // 2 500 entries)
+  int steepestMode = 3, steepestElements = 1, chuzrFloor = 2000, debugLastBadIteration = -999999;
   long long pendingFactorElements = 0, luOwnElements = 0;
   double debugToleranceFactor = 0.0;
   double smallestPrimalInfeasibility = DBL_MAX, lastObjectiveValueGuts = -1.0e100;
@@ -1808,7 +1812,7 @@ int clpgpu_context::factorizeOnce()
   hCtrl->k = k;
   hCtrl->pivots = 0;
   hCtrl->kcap = kcap;
-  hCtrl->factorElements = steepestElements ? (long long)k * k : pendingFactorElements;
+  hCtrl->factorElements = pendingFactorElements;  // (both settings of steepest_elements: see the option)
   return rc;
 }
 
