@@ -34,6 +34,8 @@ namespace clpgpu {
 #define LUD (*D.lu)
 #define LU_TCAP_MAX 2048  // capacity of the eta file (rows of G, LDS staging of its vectors)
 #define LUG_ROWS 4        // rows of the dense tail (inverse or its transpose) one wave carries through a GEMV
+// (two strips of 128 columns per trip below: four strips -- 16 KB in flight per wave -- measured SLOWER in round 6 on all three streams of
+// this form, k_lu_gemv3 75 against 68 us, k_lu_gemvT 58 against 55, k_lu_eta_apply 32 against 30: they are not short of bytes in flight)
 
 // One sparse operator application in gather form: out[tgt] = (srcv[src] - sum val * vec[idx]) / div, every item
 // independent of the others.  The triangular factors of the front are applied through their EXPLICIT sparse
