@@ -639,7 +639,7 @@ void clpgpu_context::luLaunchBtran()
   KL("k_lu_cprime", k_lu_cprime, dim3(1), dim3(1024), 0, stream, D, 1, (const double *)nullptr);
   KL("k_lu_bt_gather", k_lu_bt_gather, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, (double *)nullptr);
   KL("k_lu_bt_front", k_lu_bt_front, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, D.slotA);
-  KL("k_lu_gemvT", k_lu_gemvT, dim3(cdiv(kc, 16)), dim3(256), 0, stream, D, 1, (const double *)D.slotA);
+  KL("k_lu_gemvT", k_lu_gemvT, dim3(cdiv(kc, LUG_ROWS * (luGemvThreads >> 6))), dim3(luGemvThreads), 0, stream, D, 1, (const double *)D.slotA);
   KL("k_lu_bt_back", k_lu_bt_back, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, (double *)nullptr);
 }
 // ... and the three FTRANs (entering column, rho, flip rhs) up to the scatter with the eta file applied
@@ -648,7 +648,7 @@ void clpgpu_context::luLaunchFtran(int gm, int parity)
   const int ns = hLu.ns, kc = kcap;
   KL("k_lu_fwd", k_lu_fwd, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, (const double *)D.vecV1, (const double *)D.rho, (const double *)D.flipRhs, D.slotV1,
      D.rhoSlotF, D.flipSlot);
-  KL("k_lu_gemv3", k_lu_gemv3, dim3(cdiv(kc, 16)), dim3(256), 0, stream, D);
+  KL("k_lu_gemv3", k_lu_gemv3, dim3(cdiv(kc, LUG_ROWS * (luGemvThreads >> 6))), dim3(luGemvThreads), 0, stream, D);
   KL("k_lu_bwd", k_lu_bwd, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, (const double *)D.slotC, (const double *)D.slotD, (const double *)D.slotE, 1, 1, 1);
   // (compact eta file: only the positions whose slack left since the refactorization still need their B0 value -- for s = G x0[P];
   // the untouched slack positions get their final value from their own rows in k_ftran_scatter3_lu)
@@ -660,7 +660,7 @@ void clpgpu_context::luLaunchFtran(int gm, int parity)
     const int compact = hCtrl->luCompactOn;
     const int ppb = compact ? luScatterPpb : std::min(256, std::max(64, (cdiv(m, 256) + 7) & ~7));
     if (compact)  // x0 -= Hc s over the slots (the structural positions): 8 (k + conversions) t bytes instead of 8 m t
-      KL("k_lu_eta_apply", k_lu_eta_apply, dim3(1024), dim3(256), 0, stream, D);
+      KL("k_lu_eta_apply", k_lu_eta_apply, dim3(4096 / (luGemvThreads >> 6)), dim3(luGemvThreads), 0, stream, D);
     KL("k_ftran_scatter3_lu", k_ftran_scatter3_lu, dim3(cdiv(m, ppb)), dim3(256), 0, stream, D, gm, parity, ppb, compact);
   }
 }

@@ -581,7 +581,7 @@ __global__ void __launch_bounds__(256) k_lu_bt_front(Dev D, int chain, double *z
 // y_T = S^-T z_T: the tail inverse is frozen between refactorizations, so its transpose is kept as well
 // (k_lu_transpose_tail, once per refactorization) and the BTRAN streams contiguous rows like the FTRAN does:
 // one wave per tail row slot, result straight into the work vector by local row
-__global__ void __launch_bounds__(256) k_lu_gemvT(Dev D, int chain, const double *zt)
+__global__ void __launch_bounds__(1024) k_lu_gemvT(Dev D, int chain, const double *zt)
 {
   if (chain && D.ctrl->state != RUN)
     return;
@@ -589,7 +589,9 @@ __global__ void __launch_bounds__(256) k_lu_gemvT(Dev D, int chain, const double
   const int lane = threadIdx.x & 63;
   // four rows per wave, 16-byte loads, two strips of 128 columns per trip: 8 x 1 KB in flight per wave (one row per wave with two
   // 8-byte loads in flight left the HBM stream at 0.52 of its peak, profiles/r03_bench_line_default.json)
-  for (int ts0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LUG_ROWS; ts0 < k2; ts0 += gridDim.x * 4 * LUG_ROWS) {
+  const int wpb = blockDim.x >> 6;  // (waves per workgroup: the launch decides -- 128-thread workgroups spread the ~1 400 waves of a tail of
+  // 5 600 evenly over the CUs; with 256 threads 353 workgroups land one or two to a CU and the stream runs 15 % slower, round 6)
+  for (int ts0 = (blockIdx.x * wpb + (threadIdx.x >> 6)) * LUG_ROWS; ts0 < k2; ts0 += gridDim.x * wpb * LUG_ROWS) {
     double acc[LUG_ROWS];
     const double *row[LUG_ROWS];
 #pragma unroll
@@ -632,7 +634,7 @@ __global__ void __launch_bounds__(256) k_lu_gemvT(Dev D, int chain, const double
 // x_T = S^-1 v_T for the three FTRAN right-hand sides in one sweep of the tail inverse.  One wave per FOUR rows:
 // the three vectors (slotV1 / rhoSlotF / flipSlot, from L2) are loaded once per column and used against four
 // matrix rows, so the kernel issues 7 loads per 12 multiply-adds instead of 4 per 3; skip rules as in k_gemv3g
-__global__ void __launch_bounds__(256) k_lu_gemv3(Dev D)
+__global__ void __launch_bounds__(1024) k_lu_gemv3(Dev D)
 {
   const Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -641,7 +643,8 @@ __global__ void __launch_bounds__(256) k_lu_gemv3(Dev D)
   const bool doTau = c->pivotRule != 0, doFlip = c->numberFlips != 0;
   const int lane = threadIdx.x & 63;
   const double *v1 = D.slotV1, *v2 = D.rhoSlotF, *v3 = D.flipSlot;
-  for (int sc0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LUG_ROWS; sc0 < k2; sc0 += gridDim.x * 4 * LUG_ROWS) {
+  const int wpb = blockDim.x >> 6;  // (waves per workgroup: the launch decides)
+  for (int sc0 = (blockIdx.x * wpb + (threadIdx.x >> 6)) * LUG_ROWS; sc0 < k2; sc0 += gridDim.x * wpb * LUG_ROWS) {
     double a1[LUG_ROWS], a2[LUG_ROWS], a3[LUG_ROWS];
     const double *row[LUG_ROWS];
 #pragma unroll
@@ -805,7 +808,7 @@ __global__ void __launch_bounds__(256) k_lu_pf_append(Dev D, int chain, int gm)
 // compact eta file: x0 -= Hc s over the slots in use, for the three right-hand sides, in place (x0 by position).  Hc is slot-major
 // (slot q holds its t eta entries contiguously): a (slots x t) matrix against the three s vectors -- the shape of k_lu_gemv3, and its
 // form: one wave per four slots, 16-byte loads, two strips of 128 etas per trip.
-__global__ void __launch_bounds__(256) k_lu_eta_apply(Dev D)
+__global__ void __launch_bounds__(1024) k_lu_eta_apply(Dev D)
 {
   const Ctrl *c = D.ctrl;
   if (c->state != RUN)
@@ -817,7 +820,8 @@ __global__ void __launch_bounds__(256) k_lu_eta_apply(Dev D)
   const int lane = threadIdx.x & 63;
   const size_t ld = (size_t)LUD.tcap, m = (size_t)D.m;
   const double *v1 = LUD.s, *v2 = LUD.s + LUD.tcap, *v3 = LUD.s + 2 * LUD.tcap;
-  for (int q0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LUG_ROWS; q0 < count; q0 += gridDim.x * 4 * LUG_ROWS) {
+  const int wpb = blockDim.x >> 6;
+  for (int q0 = (blockIdx.x * wpb + (threadIdx.x >> 6)) * LUG_ROWS; q0 < count; q0 += gridDim.x * wpb * LUG_ROWS) {
     double a1[LUG_ROWS], a2[LUG_ROWS], a3[LUG_ROWS];
     const double *row[LUG_ROWS];
 #pragma unroll
