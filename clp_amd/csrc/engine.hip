@@ -304,6 +304,7 @@ struct clpgpu_context {
   // them from the share of dense-pi pivots in the last batch (Ctrl::statDensePi) -- either form prices any pi correctly, so
   // the choice changes the speed of a pivot, never its result.
   int numberDcWideTimeouts = 0, debugDcTimeoutAt = -1;
+  int luPfsBlocks = 256;  // option "lu_pfs_blocks" (tuning): workgroups of k_lu_pf_s (each stages x0[P] once)
   int luGemvThreads = 128;  // option "lu_gemv_threads" (tuning): workgroup size of the row-dot streams k_lu_gemv3 / k_lu_gemvT / k_lu_eta_apply
   int luScatterPpb = 200;  // option "lu_scatter_ppb" (tuning): positions per workgroup of k_ftran_scatter3_lu with the compact eta file
   int luCompactEta = 1;  // option "lu_compact_eta": the chain's FTRAN reads the eta file over the structural positions only (device_state.h, LuDev::Hc)
@@ -5699,6 +5700,7 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "lu_inverse_fill_cap")) ctx->luInverseFillCap = v;
   else if (!strcmp(name, "lu_compact_eta")) { ctx->luCompactEta = v != 0.0; ctx->dropGraph(); }
   else if (!strcmp(name, "lu_gemv_threads")) { ctx->luGemvThreads = ((int)v >= 1024) ? 1024 : ((int)v >= 512 ? 512 : ((int)v >= 256 ? 256 : ((int)v >= 128 ? 128 : 64))); ctx->dropGraph(); }
+  else if (!strcmp(name, "lu_pfs_blocks")) { ctx->luPfsBlocks = std::max(1, std::min(1024, (int)v)); ctx->dropGraph(); }
   else if (!strcmp(name, "lu_scatter_ppb")) { ctx->luScatterPpb = std::max(64, std::min(256, ((int)v + 7) & ~7)); ctx->dropGraph(); }
   else if (!strcmp(name, "fake_bound_cleanup")) ctx->fakeBoundCleanup = v != 0.0;
   else if (!strcmp(name, "fork_update")) { ctx->forkUpdate = (int)v; ctx->dropGraph(); }

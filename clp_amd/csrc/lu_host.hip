@@ -654,7 +654,7 @@ void clpgpu_context::luLaunchFtran(int gm, int parity)
   // the untouched slack positions get their final value from their own rows in k_ftran_scatter3_lu)
   KL("k_lu_slack", k_lu_slack, dim3(hCtrl->luCompactOn ? cdiv(hLu.tcap, 32) : cdiv(m, 32), 3), dim3(256), 0, stream, D, 1, (const double *)D.vecV1, (const double *)D.rho,
        (const double *)D.flipRhs, 1, 1, 1);
-  KL("k_lu_pf_s", k_lu_pf_s, dim3(128), dim3(256), 0, stream, D, 1, 1, 1, 1);
+  KL("k_lu_pf_s", k_lu_pf_s, dim3(luPfsBlocks), dim3(256), 0, stream, D, 1, 1, 1, 1);
   {
     // positions per workgroup: one round of workgroups over the 256 CUs (m = 50 000: 250 workgroups of 200 positions, not 196 of 256)
     const int compact = hCtrl->luCompactOn;
