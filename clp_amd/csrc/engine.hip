@@ -304,6 +304,7 @@ struct clpgpu_context {
   // them from the share of dense-pi pivots in the last batch (Ctrl::statDensePi) -- either form prices any pi correctly, so
   // the choice changes the speed of a pivot, never its result.
   int numberDcWideTimeouts = 0, debugDcTimeoutAt = -1;
+  int panel68 = 1;  // option "panel_6x8" (tuning): tails of 4097 .. 6144 rows take inner panels of 8 columns (k_gj_panel_reg<6, 8, 1024>)
   int luPfsBlocks = 256;  // option "lu_pfs_blocks" (tuning): workgroups of k_lu_pf_s (each stages x0[P] once)
   int luGemvThreads = 128;  // option "lu_gemv_threads" (tuning): workgroup size of the row-dot streams k_lu_gemv3 / k_lu_gemvT / k_lu_eta_apply
   int luScatterPpb = 200;  // option "lu_scatter_ppb" (tuning): positions per workgroup of k_ftran_scatter3_lu with the compact eta file
@@ -1623,7 +1624,9 @@ int clpgpu_context::invertWork(int k, std::vector<int> &perm, int info[4])
       mode = 1;  // the register panels of the two-level form hold up to 16384 rows
     if (mode >= 2) {
       // two-level in-place form (see k_gj2_*): M = workW, identity side implicit
-      const int bIn = k <= 4096 ? 8 : (k <= 8192 ? 4 : 2);
+      // (inner panel width: rows per thread x width doubles live in registers -- 8 x 8 at 512 threads up to 4096 rows, 6 x 8 at 1024
+      // threads up to 6144 (96 of the 128 VGPRs a wave of a 16-wave workgroup may hold), 8 x 4 up to 8192, 16 x 2 beyond)
+      const int bIn = k <= (panel68 ? 6144 : 4096) ? 8 : (k <= 8192 ? 4 : 2);
       for (int I0 = 0; I0 < k; I0 += GJ_NB) {
         const int nb = std::min(GJ_NB, k - I0);
         for (int j0 = 0; j0 < nb; j0 += bIn) {
@@ -1635,6 +1638,8 @@ int clpgpu_context::invertWork(int k, std::vector<int> &perm, int info[4])
             hipLaunchKernelGGL((k_gj_panel_reg<4, 8, 512>), dim3(1), dim3(512), 0, stream, D, i0, b, k, dInfo, out);
           else if (k <= 4096)
             hipLaunchKernelGGL((k_gj_panel_reg<8, 8, 512>), dim3(1), dim3(512), 0, stream, D, i0, b, k, dInfo, out);
+          else if (k <= 6144 && panel68)
+            hipLaunchKernelGGL((k_gj_panel_reg<6, 8, 1024>), dim3(1), dim3(1024), 0, stream, D, i0, b, k, dInfo, out);
           else if (k <= 8192)
             hipLaunchKernelGGL((k_gj_panel_reg<8, 4, 1024>), dim3(1), dim3(1024), 0, stream, D, i0, b, k, dInfo, out);
           else
@@ -5700,6 +5705,7 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "lu_inverse_fill_cap")) ctx->luInverseFillCap = v;
   else if (!strcmp(name, "lu_compact_eta")) { ctx->luCompactEta = v != 0.0; ctx->dropGraph(); }
   else if (!strcmp(name, "lu_gemv_threads")) { ctx->luGemvThreads = ((int)v >= 1024) ? 1024 : ((int)v >= 512 ? 512 : ((int)v >= 256 ? 256 : ((int)v >= 128 ? 128 : 64))); ctx->dropGraph(); }
+  else if (!strcmp(name, "panel_6x8")) ctx->panel68 = v != 0.0;
   else if (!strcmp(name, "lu_pfs_blocks")) { ctx->luPfsBlocks = std::max(1, std::min(1024, (int)v)); ctx->dropGraph(); }
   else if (!strcmp(name, "lu_scatter_ppb")) { ctx->luScatterPpb = std::max(64, std::min(256, ((int)v + 7) & ~7)); ctx->dropGraph(); }
   else if (!strcmp(name, "fake_bound_cleanup")) ctx->fakeBoundCleanup = v != 0.0;
