@@ -14,9 +14,9 @@ python bench.py > $O/${T}_bench_line_default.json 2> $O/${T}_bench_line_default.
 python bench.py --steps 20 --warmup 5 --ladder-budget 0 --tto-budget 5 > $O/${T}_bench_line_driver_window.json 2> $O/${T}_bench_line_driver_window.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$T
-rocprofv3 --kernel-trace --stats -d /tmp/prof_$T -o p -- python $R/bench.py --cpu-iterations 0 --pmc off --tto-budget 0 --ladder-budget 0 > $O/${T}_bench_under_rocprof.json 2> $O/${T}_bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats -d /tmp/prof_$T -o p -- python $R/bench.py --cpu-iterations 0 --pmc off --tto-budget 0 --ladder-budget 0 --sub-records off --shard-proxy off > $O/${T}_bench_under_rocprof.json 2> $O/${T}_bench_under_rocprof.err
 f=$(find /tmp/prof_$T -name "*results.db" | head -1)
-python $R/tools/rocpd_summary.py "$f" "rocprofv3 --kernel-trace --stats -- python bench.py --cpu-iterations 0 --pmc off --tto-budget 0 --ladder-budget 0 (headline + slack-start leg + eager replay, config 4 from the mature basis)" | head -60 > $O/${T}_bench_kernel_stats.txt
+python $R/tools/rocpd_summary.py "$f" "rocprofv3 --kernel-trace --stats -- python bench.py --cpu-iterations 0 --pmc off --tto-budget 0 --ladder-budget 0 --sub-records off --shard-proxy off (headline + slack-start leg + eager replay, config 4 from the mature basis)" | head -60 > $O/${T}_bench_kernel_stats.txt
 head -30 $O/${T}_bench_kernel_stats.txt
 # the mature stretch alone (800 pre-roll + 100 + 600 eager pivots from the committed basis): per-kernel durations as CSV
 rm -rf /tmp/prof_${T}_m
