@@ -77,7 +77,7 @@ struct Ctrl {
   long long dbg[16];    // development counters (CLPGPU_DEBUG_STATS)
   long long dbg2[8];    // phase clocks of k_flip_apply2
   int ticket[8];        // "last workgroup done" counters (always 0 between launches)
-  int ticketGroup[4][64];  // first level of the same: one counter per 32 workgroups (<= 2048 workgroups)
+  int ticketGroup[8][64];  // first level of the same: one counter per 32 workgroups (<= 2048 workgroups)
   int flipAppend, numberAppend1;
   int flipHotCount;  // rows with more flip contributions than slots this pivot (k_dj_flags appends, CHUZR resets)
   int lastPriceByRow, shardRowCands;  // row candidates ahead of the column candidates in the local list (sharded runs)

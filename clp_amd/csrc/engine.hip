@@ -162,12 +162,14 @@ struct clpgpu_context {
   int tryPrimal = 0, numberTryPrimal = 0;
   // ClpDualRowSteepest::mode_ (src/ClpDualRowSteepest.hpp:118: the constructor's default is 3) and what stands for
   // factorization()->numberElements() in its mode 3 (src/ClpDualRowSteepest.cpp:262): 0 = entries of the basic structural columns (the
-  // count of an LU without fill; what the oracle computes too), 1 (default) = what the factorization on the device holds in
+  // count of an LU without fill; what the oracle computes too; the default), 1 (what the clpGpuDual adapter sets) = what the factorization on the device holds in
   // CoinFactorization's terms: in LU mode front L + U + the dense tail + the frozen slack part; under the explicit inverse -- nuclei
   // below lu_min_k, which triangularize or nearly so -- the entries an LU of that nucleus holds, i.e. the same count as 0 (k^2, the
   // inverse's own storage, would send a 224-column nucleus of a 50 000-row LP past ratio 1 where CoinFactorization's LU of it holds
-  // 2 500 entries)
-  int steepestMode = 3, steepestElements = 1, chuzrFloor = 2000, debugLastBadIteration = -999999;
+  // 2 500 entries).  Why 0 is the default although a real LU of a mature basis holds far more than the structural columns' entries:
+  // measured on the ladder (round 6), full scans in LU mode stall this LP family -- rung 7 000 x 28 000: 102 000 pivots / 35 s with the
+  // partial scans of 0 against > 2.7 M pivots / 900 s unfinished with 1; rung 5 000: 64-80 000 against 105 000 pivots
+  int steepestMode = 3, steepestElements = 0, chuzrFloor = 2000, debugLastBadIteration = -999999;
   long long pendingFactorElements = 0, luOwnElements = 0;
   double debugToleranceFactor = 0.0;
   double smallestPrimalInfeasibility = DBL_MAX, lastObjectiveValueGuts = -1.0e100;
@@ -304,6 +306,9 @@ struct clpgpu_context {
   // them from the share of dense-pi pivots in the last batch (Ctrl::statDensePi) -- either form prices any pi correctly, so
   // the choice changes the speed of a pivot, never its result.
   int numberDcWideTimeouts = 0, debugDcTimeoutAt = -1;
+  int luFold = 1;  // option "lu_fold", bits: 1 = the primal update made by k_lu_pf_append's position workgroups (one launch fewer per LU-mode pivot,
+                   // 28.5 -> 17.0 us for the pair between HIP events); 2 = c' built by the last workgroup of k_lu_pf_d (measured SLOWER: 29.3 against
+                   // 12.6 + 10.0 us -- the chain walk of one workgroup behind coherent loads; off)
   int panel68 = 1;  // option "panel_6x8" (tuning): tails of 4097 .. 6144 rows take inner panels of 8 columns (k_gj_panel_reg<6, 8, 1024>)
   int luPfsBlocks = 256;  // option "lu_pfs_blocks" (tuning): workgroups of k_lu_pf_s (each stages x0[P] once)
   int luGemvThreads = 128;  // option "lu_gemv_threads" (tuning): workgroup size of the row-dot streams k_lu_gemv3 / k_lu_gemvT / k_lu_eta_apply
@@ -3816,8 +3821,12 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
     const int gx = cdiv(kc, 256), gy = kc < 512 ? kc : 512;
     if (luActive) {
       // primal update as usual; the basis update is one more eta (column of H, row of G)
-      KL("k_primal_update", k_primal_update, dim3(gm), dim3(256), 0, stream, D, 0);
-      KL("k_lu_pf_append", k_lu_pf_append, dim3(gm + cdiv(hLu.tcap, 4)), dim3(256), 0, stream, D, 1, gm);
+      if (luFold & 1) {
+        KL("k_lu_pf_append", k_lu_pf_append, dim3(gm + cdiv(hLu.tcap, 4)), dim3(256), 0, stream, D, 2, gm);  // + the primal update
+      } else {
+        KL("k_primal_update", k_primal_update, dim3(gm), dim3(256), 0, stream, D, 0);
+        KL("k_lu_pf_append", k_lu_pf_append, dim3(gm + cdiv(hLu.tcap, 4)), dim3(256), 0, stream, D, 1, gm);
+      }
     } else if (forkUpdate && stream2) {
       (void)hipEventRecord(evFork, stream);
       (void)hipStreamWaitEvent(stream2, evFork, 0);
@@ -5705,6 +5714,7 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "lu_inverse_fill_cap")) ctx->luInverseFillCap = v;
   else if (!strcmp(name, "lu_compact_eta")) { ctx->luCompactEta = v != 0.0; ctx->dropGraph(); }
   else if (!strcmp(name, "lu_gemv_threads")) { ctx->luGemvThreads = ((int)v >= 1024) ? 1024 : ((int)v >= 512 ? 512 : ((int)v >= 256 ? 256 : ((int)v >= 128 ? 128 : 64))); ctx->dropGraph(); }
+  else if (!strcmp(name, "lu_fold")) { ctx->luFold = (int)v & 3; ctx->dropGraph(); }
   else if (!strcmp(name, "panel_6x8")) ctx->panel68 = v != 0.0;
   else if (!strcmp(name, "lu_pfs_blocks")) { ctx->luPfsBlocks = std::max(1, std::min(1024, (int)v)); ctx->dropGraph(); }
   else if (!strcmp(name, "lu_scatter_ppb")) { ctx->luScatterPpb = std::max(64, std::min(256, ((int)v + 7) & ~7)); ctx->dropGraph(); }

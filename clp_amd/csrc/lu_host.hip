@@ -635,8 +635,12 @@ int clpgpu_context::luBtran(const double *cPos, double *yRow)
 void clpgpu_context::luLaunchBtran()
 {
   const int k = hLu.k, ns = hLu.ns, tcap = hLu.tcap, kc = kcap;
-  KL("k_lu_pf_d", k_lu_pf_d, dim3(cdiv(tcap, 4)), dim3(256), 0, stream, D, 1);
-  KL("k_lu_cprime", k_lu_cprime, dim3(1), dim3(1024), 0, stream, D, 1, (const double *)nullptr);
+  if (luFold & 2) {
+    KL("k_lu_pf_d", k_lu_pf_d, dim3(cdiv(tcap, 4)), dim3(256), 0, stream, D, 2);  // + c' in the workgroup that finishes last
+  } else {
+    KL("k_lu_pf_d", k_lu_pf_d, dim3(cdiv(tcap, 4)), dim3(256), 0, stream, D, 1);
+    KL("k_lu_cprime", k_lu_cprime, dim3(1), dim3(1024), 0, stream, D, 1, (const double *)nullptr);
+  }
   KL("k_lu_bt_gather", k_lu_bt_gather, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, (double *)nullptr);
   KL("k_lu_bt_front", k_lu_bt_front, dim3(cdiv(m, 4)), dim3(256), 0, stream, D, 1, D.slotA);
   KL("k_lu_gemvT", k_lu_gemvT, dim3(cdiv(kc, LUG_ROWS * (luGemvThreads >> 6))), dim3(luGemvThreads), 0, stream, D, 1, (const double *)D.slotA);

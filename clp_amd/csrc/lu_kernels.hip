@@ -468,6 +468,7 @@ __global__ void __launch_bounds__(256) k_lu_pf_gdot(Dev D, const double *cvec)
 
 // d = G^T g: one wave per column i of G = row i of the transposed copy GT (contiguous), lanes over the etas j >= i;
 // chain form: g_j = dir * eta_j[r], a scattered load per eta that every wave issues alongside its GT loads
+// chain == 2: the workgroup that finishes last also builds c' (k_lu_cprime's chain form) -- one launch less per pivot
 __global__ void __launch_bounds__(256) k_lu_pf_d(Dev D, int chain)
 {
   const Ctrl *c = D.ctrl;
@@ -475,19 +476,48 @@ __global__ void __launch_bounds__(256) k_lu_pf_d(Dev D, int chain)
     return;
   const int t = c->pivots;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (i >= t)
-    return;
-  const double dir = (double)c->directionOut;
-  const int r = c->pivotRow;
-  const double *GTrow = LUD.GT + (size_t)i * LUD.tcap;
-  double acc = 0.0;
-  for (int j = i + lane; j < t; j += 64) {
-    const double gj = chain ? dir * LUD.H[(size_t)j * D.m + r] : LUD.g[j];
-    acc += GTrow[j] * gj;
+  if (i < t) {
+    const double dir = (double)c->directionOut;
+    const int r = c->pivotRow;
+    const double *GTrow = LUD.GT + (size_t)i * LUD.tcap;
+    double acc = 0.0;
+    for (int j = i + lane; j < t; j += 64) {
+      const double gj = chain ? dir * LUD.H[(size_t)j * D.m + r] : LUD.g[j];
+      acc += GTrow[j] * gj;
+    }
+    acc = waveSum(acc);
+    if (lane == 0) {
+      if (chain == 2)
+        stc(&LUD.d[i], acc);
+      else
+        LUD.d[i] = acc;
+    }
   }
-  acc = waveSum(acc);
-  if (lane == 0)
-    LUD.d[i] = acc;
+  if (chain != 2)
+    return;
+  if (!lastBlockDone(D.ctrl, 4))
+    return;
+  // c' = dir e_r - P d: every position of c' is written by one thread in eta order (the chains of etas on one position)
+  if (threadIdx.x == 0)
+    LUD.cp[c->pivotRow] = (double)c->directionOut;
+  __syncthreads();
+  for (int j = threadIdx.x; j < t; j += blockDim.x) {
+    if (LUD.nextSame[j] >= 0)
+      continue;
+    int head = j, len = 1;
+    while (LUD.prevSame[head] >= 0) {
+      head = LUD.prevSame[head];
+      len++;
+    }
+    double sum = 0.0;
+    int q = head;
+    for (int u = 0; u < len; u++) {
+      sum += ldc(&LUD.d[q]);
+      q = LUD.nextSame[q];
+    }
+    const int p = LUD.P[j];
+    LUD.cp[p] = LUD.cp[p] - sum;
+  }
 }
 
 // c' = c - P d as a dense vector by position (luCp).  Etas that replaced the same position form a chain
@@ -743,11 +773,14 @@ __global__ void __launch_bounds__(256) k_lu_bt_back(Dev D, int chain, double *y)
 // ---- the update: a new eta (column t of H), its position, and row t of G.
 // Workgroups [0, gm): eta = (w - e_r) / alpha over the m positions; the rest: a wave per column of the new row of G.
 // n_t[j] = eta_j[r] (j < t); G[t][i] = -sum_{j >= i} n_t[j] G[j][i]; G[t][t] = 1.
+// chain == 2: the first gm workgroups also make the pivot's primal update (primalUpdateBody: the same span of positions, the same w)
 __global__ void __launch_bounds__(256) k_lu_pf_append(Dev D, int chain, int gm)
 {
   const Ctrl *c = D.ctrl;
   if (chain && c->state != RUN)
     return;
+  if (chain == 2 && (int)blockIdx.x < gm)
+    primalUpdateBody(D, 0, blockIdx.x, gm);
   const int t = c->pivots;
   if (t >= LUD.tcap)
     return;

@@ -129,3 +129,28 @@ def test_full_size_first_500_pivots_in_the_default_mode(gpu_cls):
     assert g.dual_steps(500) == -1 and o.dual() == 3
     assert same_pivots(g.pivotLog(), o.pivot_log())
     assert g.stats()["chuzr_partial_scans"] == o.partial_scans == 500
+
+
+def test_mature_basis_scans_fully_with_the_factorization_s_own_count(gpu_cls):
+    """Mode 3 sizes the scan by factorization()->numberElements() / rows (:262-276).  From config 4's mature basis the engine is in LU mode
+    and its factorization holds front L + U + the dense tail + the frozen slack part: ~32 M entries, ratio ~640 > 80 -> every call scans the
+    whole list, as real Clp with an LU of that basis would (option steepest_elements 1, the engine's default and the adapter's).  With the
+    oracle's model (0: the 537 448 entries of the 10 514 basic structural columns, ratio 10.7) the same basis scans
+    number x ratio / 80 = 13 % of the rows per call."""
+    import os
+
+    lp = P.sparse_lp()
+    status = (np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "basis_sparse_30000.npy")) & 7).astype(np.uint8)
+    seen = {}
+    for model in (1, 0):
+        g = gpu_cls().loadProblem(lp)
+        g.setStatusArray(status)
+        g.set_option("pivot_rule", 1)
+        g.set_option("max_pivots", 0)
+        g.set_option("steepest_elements", model)
+        assert g.dual_steps(60) == -1
+        st = g.stats()
+        assert st["lu_active"] == 1
+        seen[model] = (int(st["factor_elements"]), int(st["chuzr_partial_scans"]))
+    assert seen[1][0] > 80 * lp.m and seen[1][1] == 0, seen
+    assert seen[0][0] < 12 * lp.m and seen[0][1] >= 55, seen
