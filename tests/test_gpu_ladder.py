@@ -56,7 +56,7 @@ def test_rung_beyond_highs_is_certified_optimal(gpu_cls, rung):
     g.set_option("max_pivots", 0)
     t0 = time.perf_counter()
     status = -1
-    while status == -1 and time.perf_counter() - t0 < 900.0:
+    while status == -1 and time.perf_counter() - t0 < 240.0:
         status = g.dual_steps(20000)
     assert status == 0, f"rung {rung}: status {status} after {g.numberIterations()} pivots in {time.perf_counter() - t0:.1f} s"
     cert = certify(lp, g.solution(), row_duals_from_engine(lp, g))
