@@ -5406,6 +5406,11 @@ clpgpu_context *clpgpu_clone(const clpgpu_context *src)
   ctx->luMinPivots = src->luMinPivots;
   ctx->luInverseFillCap = src->luInverseFillCap;
   ctx->luCompactEta = src->luCompactEta;
+  ctx->luFold = src->luFold;
+  ctx->panel68 = src->panel68;
+  ctx->luGemvThreads = src->luGemvThreads;
+  ctx->luPfsBlocks = src->luPfsBlocks;
+  ctx->luScatterPpb = src->luScatterPpb;
   ctx->fakeBoundCleanup = src->fakeBoundCleanup;
   ctx->checkBoth = src->checkBoth;
   ctx->freeNonbasic = src->freeNonbasic;
