@@ -225,7 +225,7 @@ def main():
     ap.add_argument("--check-every", type=int, default=16)
     ap.add_argument("--workload", default="sparse", choices=["sparse", "dense", "netlib"],
                     help="sparse = BASELINE configs[3] (default, the quoted metric); dense = configs[2]; netlib = power-law variant")
-    ap.add_argument("--tto-budget", type=float, default=20.0, help="seconds allowed for the time-to-optimal leg (0 skips it)")
+    ap.add_argument("--tto-budget", type=float, default=12.0, help="seconds allowed for the time-to-optimal leg (0 skips it)")
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"], help="live PMC traffic of the pricing kernel via rocprofv3 child runs")
     ap.add_argument("--pmc-timeout", type=float, default=150.0)
     ap.add_argument("--clp-timeout", type=float, default=600.0)
@@ -237,8 +237,9 @@ def main():
                          "so that the timed window sits in the middle of an eta-file cycle (its length runs 0 .. ~1600) and not right "
                          "behind a fresh factorization, where pivots are at their cheapest")
     ap.add_argument("--ladder-budget", type=float, default=60.0, help="seconds allowed for the time-to-optimal ladder (0 skips it)")
-    ap.add_argument("--ladder-rungs", default="1500,2000,3000,4000,5000,7000,10000")
-    ap.add_argument("--cpu-mature-pivots", type=int, default=40,
+    ap.add_argument("--ladder-rungs", default="1500,3000,5000,7000",
+                    help="rungs of tools/ladder.py's table to solve (also there: 2000, 4000, 10000 -- 10000 does not finish)")
+    ap.add_argument("--cpu-mature-pivots", type=int, default=30,
                     help="pivots of the CPU baseline in the headline's regime (oracle from the mature basis, ~0.4 s each after a ~15 s start-up; 0 skips it)")
     ap.add_argument("--sub-timeout", type=float, default=240.0)
     ap.add_argument("--sub-records", default="dense,netlib",
@@ -742,21 +743,20 @@ def main():
             try:
                 from clp_amd.engine import ClpGpuSimplex
 
-                for form, minwin in (("k_price_sell", None), ("k_price_lds", 1)):
-                    e = ClpGpuSimplex(local_rank)
-                    if minwin is not None:
-                        e.set_option("price_lds_min_windows", minwin)  # before the load: lays the shard out for the LDS form too
-                    e.loadProblem(lp)
-                    e.set_option("pivot_rule", args.pivot_rule)
-                    e.set_option("max_pivots", 0)
-                    if R > 1:
-                        e.setColumnRange(0, last)
-                    e.dual_steps(0)
-                    us = float(e.debugPriceBench([(1 << 20) if form == "k_price_lds" else 0], reps=30)[0])
+                e = ClpGpuSimplex(local_rank)
+                e.set_option("price_lds_min_windows", 1)  # before the load: lays the shard out for the LDS form too, however narrow
+                e.loadProblem(lp)
+                e.set_option("pivot_rule", args.pivot_rule)
+                e.set_option("max_pivots", 0)
+                if R > 1:
+                    e.setColumnRange(0, last)
+                e.dual_steps(0)
+                for form, us in zip(("k_price_sell", "k_price_lds"), e.debugPriceBench([0, 1 << 20], reps=30)):
+                    us = float(us)
                     if us > 0:
                         ent[form] = {"us": round(us, 2), "achieved": b_col / (us * 1e-6) / 1e9, "frac": b_col / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                      "aggregate_over_ranks": R * b_col / (us * 1e-6) / 1e9}
-                    del e
+                del e
             except Exception as ex:  # noqa: BLE001 -- a probe must not take the line down
                 ent["error"] = str(ex)[:200]
             shard_proxy["ranks"].append(ent)
