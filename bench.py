@@ -690,7 +690,9 @@ def main():
                 "law": f"pivots to optimality ~ rows^{slope:.2f} over the rungs finished in this run ({', '.join(str(d[0]) for d in done)} rows: "
                        f"{', '.join(str(d[1]) for d in done)} pivots)",
                 "pivots_at_this_size": round(need), "at_the_sustained_rate_s": round(need / max(rate, 1e-9)),
-                "note": "an extrapolation of the same generator's smaller instances, not a measurement: the solve above is "
+                "note": "an extrapolation of the same generator's smaller instances, not a measurement -- and too low: a 45-minute run of this LP from the "
+                        "slack basis made 3.74 M pivots (1 382 it/s sustained, dual objective 768 399) without reaching the optimum, "
+                        "profiles/r06_config4_long.jsonl; the solve above is "
                         f"{tto['iterations']} pivots in (counted from the committed basis at pivot 30 000 when started there)"}
 
     # ---- BASELINE configs[2] and the Netlib-shaped variant as sub-records (children of this script on the same GPU, one after the other)
