@@ -9,6 +9,8 @@ Three kinds of check, each through the C ABI:
     as any two LU codes do (ClpFactorization::factorize permutes pivotVariable_, src/ClpFactorization.cpp:1953);
   * whole solves in LU mode against the oracle and against the engine's explicit-inverse mode.
 Tolerances: 1e-9 relative on solve vectors, 1e-8 relative on objective / solutions (north_star)."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -357,3 +359,37 @@ def test_lds_pricing_with_long_columns(gpu_cls):
     a, b = runs[0].pivotLog(), runs[1].pivotLog()
     assert len(a) == len(b) and np.array_equal(a["sequenceIn"], b["sequenceIn"]) and np.array_equal(a["sequenceOut"], b["sequenceOut"])
     assert np.array_equal(runs[0].solution(), runs[1].solution())
+
+
+def test_compact_eta_file_against_the_full_file(gpu_cls):
+    """The chain's FTRAN through the compact copy of the eta file (option lu_compact_eta, default: the etas over the positions that hold or
+    held a structural, the other positions from their own rows of B x = v) against the full-file form on config 4
+    from the committed mature basis, 900 pivots each (the eta file grows to 900, ~60 positions convert): the two differ in rounding only
+    -- a long shared prefix of pivots, alpha / theta / objective to rounding over it, and no btran / ftran alpha check raised."""
+    lp = P.sparse_lp()
+    status = (np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "basis_sparse_30000.npy")) & 7).astype(np.uint8)
+    logs, stats = [], []
+    for compact in (1, 0):
+        g = gpu_cls().loadProblem(lp)
+        g.setStatusArray(status)
+        g.set_option("pivot_rule", 1)
+        g.set_option("max_pivots", 0)
+        g.set_option("steepest_mode", 1)
+        g.set_option("lu_compact_eta", compact)
+        assert g.dual_steps(900) == -1
+        logs.append(g.pivotLog())
+        stats.append(g.stats())
+    a, b = logs
+    assert stats[0]["eta_compact_slots"] > 10514 and stats[1]["eta_compact_slots"] == 0
+    assert stats[0]["exits_alpha_check"] == stats[1]["exits_alpha_check"] == 0
+    same = 0
+    while same < 900 and a[same]["sequenceIn"] == b[same]["sequenceIn"] and a[same]["sequenceOut"] == b[same]["sequenceOut"]:
+        same += 1
+    print(f"compact against full eta file from the mature basis: {same} of 900 pivots identical, slots at the end {stats[0]['eta_compact_slots']}")
+    assert same >= 200, same
+    pre = slice(0, same)
+    # (the bar of tests/test_gpu_mature_parity.py for two factorizations of these bases, condition 1e10: alpha to 1e-4; measured 4e-6)
+    worst = float(np.max(np.abs(a["alpha"][pre] - b["alpha"][pre]) / np.abs(b["alpha"][pre])))
+    print(f"  alpha: worst relative difference over the shared prefix {worst:.2e}")
+    assert worst < 1e-4
+    assert np.max(np.abs(a["objective"][pre] - b["objective"][pre]) / np.abs(b["objective"][pre])) < 1e-8
