@@ -111,7 +111,8 @@ def test_virtual_ranks_overflow_agrees(gpu, grow, lu):
         assert abs(e.objectiveValue() - base.objectiveValue()) <= 1e-9 * abs(base.objectiveValue())
 
 
-def test_virtual_ranks_full_size_from_the_mature_basis(gpu):
+@pytest.mark.parametrize("form", ["sell", "lds"])
+def test_virtual_ranks_full_size_from_the_mature_basis(gpu, form):
     """config 5 in miniature, in the regime a solve of this LP lives in: the 50 000 x 200 000 LP of config 4 warm-started from the
     committed mature basis (nucleus 10 514, LU mode, ~10^5 candidates per pivot = 12 500 per rank), columns sharded over 8
     loopback ranks, 200 pivots against the unsharded engine: identical pivots on every rank, identical solution bits, the
@@ -132,12 +133,22 @@ def test_virtual_ranks_full_size_from_the_mature_basis(gpu):
     conf(base)
     assert base.dual_steps(200) == -1
     assert base.stats()["lu_active"] == 1
-    # (the ranks' shards are 98 windows wide: below the width the LDS pricing form is laid out for -- not built at the full-width load either)
-    vr = gpu.VirtualRanks(lp, 8, configure=lambda e: conf(e, shard_cand_cap=32768, shard_flip_cap=8192), preconfigure=lambda e: e.set_option("price_lds", 0))
+    # the ranks' shards are 98 windows wide: below the width the LDS pricing form is laid out for by default ("sell": the L2-gather form,
+    # what a sharded run takes at this width); "lds": the shards laid out for the LDS form all the same (price_lds_min_windows 1) and
+    # priced with it on every pivot (price_lds 2) -- 25 workgroups of k_price_lds per rank, the same bits
+    def pre(e):
+        if form == "lds":
+            e.set_option("price_lds_min_windows", 1)
+            e.set_option("price_lds", 2)
+        else:
+            e.set_option("price_lds", 0)
+
+    vr = gpu.VirtualRanks(lp, 8, configure=lambda e: conf(e, shard_cand_cap=32768, shard_flip_cap=8192), preconfigure=pre)
     assert vr.dual_steps(200) == [-1] * 8
     ref = base.pivotLog()
     for r, e in enumerate(vr.engines):
         st = e.stats()
         assert st["lu_active"] == 1 and st["comm_mode"] == 2, f"rank {r}"
+        assert st["price_form"] == (1 if form == "lds" else 0), f"rank {r}"
         assert same_pivots(e.pivotLog(), ref, 200), f"rank {r}"
         assert np.array_equal(e.solution(), base.solution())
