@@ -55,3 +55,15 @@ def test_stub_accessors_exist_in_the_reference():
     assert len(decls) >= 30
     for d in decls:
         assert _norm(d) in reference, f"`{_norm(d)}` not found in ClpSimplex.hpp / ClpModel.hpp / ClpFactorization.hpp"
+
+
+def test_steepest_stub_is_the_reference_declaration():
+    """tests/stubs/ClpDualRowSteepest.hpp (what clpGpuDual reads to forward the pivot rule's mode): the constructor's default mode and
+    the accessor, looked up verbatim in src/ClpDualRowSteepest.hpp."""
+    ref_path = "/root/reference/src/ClpDualRowSteepest.hpp"
+    if not os.path.exists(ref_path):
+        pytest.skip("reference tree not mounted (GPU box)")
+    reference = _norm(open(ref_path).read())
+    for decl in ("ClpDualRowSteepest(int mode = 3);", "inline int mode() const", "public ClpDualRowPivot {"):
+        assert _norm(decl) in reference, decl
+        assert _norm(decl).rstrip(";") in _norm(open(os.path.join(ROOT, "tests", "stubs", "ClpDualRowSteepest.hpp")).read()), decl
