@@ -165,6 +165,7 @@ struct LuDev {
   int *posOfCslot;     // [ldc]
   const int *sRowOf;   // [m] index of a row among the frozen slack rows (sRow*), -1 none
   int ncs0;            // slots at the refactorization (the later ones are positions whose slack left since)
+  double *xK;          // [ldc * 4] the three FTRAN results at the slots, packed (x, tau, flip part, 0): what the slack rows gather
   int *posOfBasicCol;  // [n] basis position of a basic structural (kept per pivot by the housekeeping kernel)
 };
 

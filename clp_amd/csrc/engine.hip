@@ -100,7 +100,7 @@ struct DBuf {
 enum {
   LB_SROW, LB_SCOL, LB_SVAL, LB_ROWOFLOCAL, LB_POSOFCOL, LB_TAILROW, LB_TAILCOL, LB_SROWINDEX, LB_SROWSTART, LB_SROWCOL, LB_SROWVAL,
   LB_SCOLSTART, LB_SCOLROW, LB_SCOLVAL, LB_WR, LB_XC, LB_TCV, LB_X0, LB_CP, LB_Y, LB_H, LB_G, LB_GT, LB_P, LB_PREV, LB_NEXT, LB_S, LB_GV, LB_DV,
-  LB_LASTOFPOS, LB_HC, LB_SROWOF, LB_CSLOT, LB_POSOFCSLOT, LB_POSOFBASICCOL, LB_TRI, LB_COUNT = LB_TRI + 35
+  LB_LASTOFPOS, LB_HC, LB_XK, LB_SROWOF, LB_CSLOT, LB_POSOFCSLOT, LB_POSOFBASICCOL, LB_TRI, LB_COUNT = LB_TRI + 35
 };
 
 struct clpgpu_context {

@@ -2203,6 +2203,15 @@ __device__ inline void rowCopySwap(const Dev &D, int e, int b)
   D.cscToCsr[pe] = b;
   D.cslot[b] = se;
 }
+// LU mode with the compact eta file: the slot of the pivot's position -- the one it has, or the next free one, which the
+// housekeeping's bookkeeping (tid 0, behind the row-copy moves) is about to give it
+__device__ inline int luEnteringSlot(const Dev &D, const Ctrl *c)
+{
+  if (!c->luCompactOn)
+    return -1;
+  const int q = D.lu->cslotOfPos[c->pivotRow];
+  return q >= 0 ? q : c->luCompactCount;
+}
 // col-slot the entering structural is about to get (houseBody's bookkeeping: case 0 takes the leaving
 // column's slot, case 1 the new last slot)
 __device__ inline int enteringSlot(const Ctrl *c)
@@ -2231,7 +2240,7 @@ __global__ void __launch_bounds__(256) k_house_col(Dev D, int which)
   } else {
     const int b = D.rowStart[r] + D.basicCount[r];
     rowCopySwap(D, e, b);
-    D.cslot[b] = D.luMode ? -1 : enteringSlot(c);
+    D.cslot[b] = D.luMode ? luEnteringSlot(D, c) : enteringSlot(c);
     D.basicCount[r] += 1;
   }
 }
@@ -2306,7 +2315,7 @@ __device__ void houseBody(Dev D, int skipColumns = 0)
       int e = D.cscToCsr[p];
       int b = D.rowStart[r] + D.basicCount[r];
       rowCopySwap(D, e, b);
-      D.cslot[b] = D.luMode ? -1 : enteringSlot(c);
+      D.cslot[b] = D.luMode ? luEnteringSlot(D, c) : enteringSlot(c);
       D.basicCount[r] += 1;
     }
   }

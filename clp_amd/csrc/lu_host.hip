@@ -524,12 +524,15 @@ int clpgpu_context::factorizeLu(const std::vector<int> &kcol, const std::vector<
     rc |= luBuf[LB_SROWOF].put(this, sRowOf, ip);
     L.sRowOf = ip;
     L.Hc = nullptr;
+    L.xK = nullptr;
     if (luCompactEta) {
       rc |= luBuf[LB_HC].need(this, sizeof(double) * (size_t)L.tcap * (size_t)ldc, vp);
       L.Hc = (double *)vp;
+      rc |= luBuf[LB_XK].need(this, sizeof(double) * 4 * (size_t)ldc, vp);
+      L.xK = (double *)vp;
     }
     hCtrl->luCompactCount = count;
-    hCtrl->luCompactOn = (luCompactEta && L.Hc) ? 1 : 0;
+    hCtrl->luCompactOn = (luCompactEta && L.Hc && L.xK) ? 1 : 0;
   }
   if (rc)
     return rc;
@@ -556,6 +559,8 @@ int clpgpu_context::factorizeLu(const std::vector<int> &kcol, const std::vector<
   }
   rc |= h2d(D.pivotVariable, pivotVariable.data(), m);
   rc |= rebuildRowCopyIfNeeded();
+  if (hCtrl->luCompactOn)  // the basic entries of the row copy carry their column's compact slot (as they carry the col-slot under the explicit inverse)
+    hipLaunchKernelGGL(k_cslot_rebuild_lu, dim3(cdiv(m, 256)), dim3(256), 0, stream, D);
   luActive = true;
   kNucleus = k;
   pivots = 0;

@@ -838,6 +838,19 @@ __global__ void __launch_bounds__(256) k_lu_pf_append(Dev D, int chain, int gm)
   }
 }
 
+// LU mode with the compact eta file, at a refactorization: every basic entry of the row copy gets its column's slot
+__global__ void k_cslot_rebuild_lu(Dev D)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= D.m)
+    return;
+  const int s = D.rowStart[i], e = s + D.basicCount[i];
+  for (int q = s; q < e; q++) {
+    const int pos = LUD.posOfBasicCol[D.ccol[q]];
+    D.cslot[q] = pos >= 0 ? LUD.cslotOfPos[pos] : -1;
+  }
+}
+
 // compact eta file: x0 -= Hc s over the slots in use, for the three right-hand sides, in place (x0 by position).  Hc is slot-major
 // (slot q holds its t eta entries contiguously): a (slots x t) matrix against the three s vectors -- the shape of k_lu_gemv3, and its
 // form: one wave per four slots, 16-byte loads, two strips of 128 etas per trip.
@@ -847,8 +860,6 @@ __global__ void __launch_bounds__(1024) k_lu_eta_apply(Dev D)
   if (c->state != RUN)
     return;
   const int count = c->luCompactCount, t = c->pivots;
-  if (t == 0)
-    return;
   const bool doTau = c->pivotRule != 0, doFlip = c->numberFlips != 0;
   const int lane = threadIdx.x & 63;
   const size_t ld = (size_t)LUD.tcap, m = (size_t)D.m;
@@ -895,11 +906,14 @@ __global__ void __launch_bounds__(1024) k_lu_eta_apply(Dev D)
       const double r1 = waveSum(a1[r]), r2 = waveSum(a2[r]), r3 = waveSum(a3[r]);
       if (lane == 0 && q0 + r < count) {
         const int p = LUD.posOfCslot[q0 + r];
-        LUD.x0[p] -= r1;
+        const double y1 = LUD.x0[p] - r1, y2 = doTau ? LUD.x0[m + p] - r2 : 0.0, y3 = doFlip ? LUD.x0[2 * m + p] - r3 : 0.0;
+        LUD.x0[p] = y1;
         if (doTau)
-          LUD.x0[m + p] -= r2;
+          LUD.x0[m + p] = y2;
         if (doFlip)
-          LUD.x0[2 * m + p] -= r3;
+          LUD.x0[2 * m + p] = y3;
+        // the same three values packed by slot: one 32-byte gather per row entry for the slack rows (k_ftran_scatter3_lu)
+        *reinterpret_cast<double4 *>(LUD.xK + 4 * (size_t)(q0 + r)) = make_double4(y1, y2, y3, 0.0);
       }
     }
   }
@@ -935,38 +949,32 @@ __global__ void __launch_bounds__(256) k_ftran_scatter3_lu(Dev D, int nbNorm, in
   __shared__ double sPart[4 * 3 * 256];
   double d1 = 0.0, d2 = 0.0, d3 = 0.0;
   if (compact) {
-    // one thread per position of the workgroup's span; the entries of a row eight at a time, every level of the chain
-    // entry -> column -> its position -> x requested for the eight before anything is used
-    const size_t m = (size_t)D.m;
+    // one thread per position of the workgroup's span; the entries of a row eight at a time.  An entry carries its column's slot
+    // (D.cslot, kept with the row copy as under the explicit inverse), and the three results sit packed by slot: one 32-byte gather
+    // per entry instead of a column -> position lookup and three 8-byte gathers
     const int i = blockIdx.x * ppb + threadIdx.x;
     if ((int)threadIdx.x < ppb && i < D.m && LUD.cslotOfPos[i] < 0) {
       const int s = D.rowStart[i], e = s + D.basicCount[i];
-      const double *x0 = LUD.x0, *x1v = LUD.x0 + m, *x2v = LUD.x0 + 2 * m;
+      const double4 *xK = reinterpret_cast<const double4 *>(LUD.xK);
       double a0 = 0.0, a1 = 0.0, a2 = 0.0;
       for (int q = s; q < e; q += 8) {
         double el[8];
-        int pos[8];
+        int sl[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
           const bool in = q + u < e;
           el[u] = in ? D.relem[q + u] : 0.0;
-          pos[u] = in ? D.ccol[q + u] : -1;
+          sl[u] = in ? D.cslot[q + u] : 0;
         }
+        double4 y[8];
 #pragma unroll
         for (int u = 0; u < 8; u++)
-          pos[u] = pos[u] >= 0 ? LUD.posOfBasicCol[pos[u]] : 0;
-        double y0[8], y1[8], y2[8];
+          y[u] = xK[sl[u]];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-          y0[u] = x0[pos[u]];
-          y1[u] = doTau ? x1v[pos[u]] : 0.0;
-          y2[u] = doFlip ? x2v[pos[u]] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-          a0 += el[u] * y0[u];
-          a1 += el[u] * y1[u];
-          a2 += el[u] * y2[u];
+          a0 += el[u] * y[u].x;
+          a1 += el[u] * y[u].y;
+          a2 += el[u] * y[u].z;
         }
       }
       sPart[threadIdx.x] = a0 - D.vecV1[i];
