@@ -306,6 +306,7 @@ struct clpgpu_context {
   // them from the share of dense-pi pivots in the last batch (Ctrl::statDensePi) -- either form prices any pi correctly, so
   // the choice changes the speed of a pivot, never its result.
   int numberDcWideTimeouts = 0, debugDcTimeoutAt = -1;
+  int commGraph = 0;  // option "comm_graph": hipGraph batches in column-sharded runs over a real communicator (see clpgpu_comm_init)
   int luFold = 1;  // option "lu_fold", bits: 1 = the primal update made by k_lu_pf_append's position workgroups (one launch fewer per LU-mode pivot,
                    // 28.5 -> 17.0 us for the pair between HIP events); 2 = c' built by the last workgroup of k_lu_pf_d (measured SLOWER: 29.3 against
                    // 12.6 + 10.0 us -- the chain walk of one workgroup behind coherent loads; off)
@@ -3901,6 +3902,8 @@ int clpgpu_context::launchBatch(int count)
     if (captureBatch(checkEvery, graph, graphExec)) {
       dropGraph();
       useGraph = 0;  // fall back to eager launches of the same chain
+      if (logLevel > 0)
+        fprintf(stderr, "clpgpu: hipGraph capture of the pivot chain failed%s: eager launches from here on\n", commActive ? " (column-sharded run)" : "");
       sidePending = false;
       for (int b = 0; b < count; b++)
         launchIteration(b == 0, b & 1);
@@ -5537,7 +5540,11 @@ int clpgpu_comm_init(clpgpu_context *ctx, int rank, int nranks, const void *id12
   ctx->applyShard();
   if (ctx->allocShardBuffers())
     return -99;
-  ctx->useGraph = 0;  // collectives are enqueued between kernels; keep the eager chain
+  // collectives are enqueued between kernels: eager chain by default.  Option comm_graph 1 keeps the hipGraph batches -- the two
+  // ncclAllGather calls of a pivot are then captured with the kernels around them (RCCL supports stream capture); a failed capture
+  // falls back to eager launches as everywhere (launchBatch).  Measured with a one-rank communicator only: off by default.
+  if (!ctx->commGraph)
+    ctx->useGraph = 0;
   rc = ctx->buildSell();
   return rc;
 }
@@ -5719,6 +5726,7 @@ int clpgpu_set_option(clpgpu_context *ctx, const char *name, double v)
   else if (!strcmp(name, "lu_inverse_fill_cap")) ctx->luInverseFillCap = v;
   else if (!strcmp(name, "lu_compact_eta")) { ctx->luCompactEta = v != 0.0; ctx->dropGraph(); }
   else if (!strcmp(name, "lu_gemv_threads")) { ctx->luGemvThreads = ((int)v >= 1024) ? 1024 : ((int)v >= 512 ? 512 : ((int)v >= 256 ? 256 : ((int)v >= 128 ? 128 : 64))); ctx->dropGraph(); }
+  else if (!strcmp(name, "comm_graph")) ctx->commGraph = v != 0.0;
   else if (!strcmp(name, "lu_fold")) { ctx->luFold = (int)v & 3; ctx->dropGraph(); }
   else if (!strcmp(name, "panel_6x8")) ctx->panel68 = v != 0.0;
   else if (!strcmp(name, "lu_pfs_blocks")) { ctx->luPfsBlocks = std::max(1, std::min(1024, (int)v)); ctx->dropGraph(); }
