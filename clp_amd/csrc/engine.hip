@@ -3773,7 +3773,7 @@ int clpgpu_context::launchIteration(bool firstOfBatch, int parity)
   if (shardLists) {
     // the local list is [row candidates (replicated) | this rank's column candidates]: the column part
     // of every rank, gathered in rank order behind the rows, is the single-GPU list
-    KL("k_shard_pack_cands", k_shard_pack_cands, dim3(1), dim3(256), 0, stream, D, nbRows, dCandSend, shardCandCap);
+    KL("k_shard_pack_cands", k_shard_pack_cands, dim3(std::max(1, std::min(128, cdiv(shardCandCap, 1024)))), dim3(256), 0, stream, D, nbRows, dCandSend, shardCandCap);
     allGather(dCandSend, dCandRecv, SHARD_HDR + 4 * (size_t)shardCandCap, 8 /* ncclFloat64 */);
     KL("k_shard_merge_cands", k_shard_merge_cands, dim3(cdiv(shardCandCap, 256), nranks), dim3(256), 0, stream, D, (const double *)dCandRecv,
        nranks, shardCandCap);
