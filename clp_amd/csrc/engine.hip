@@ -162,7 +162,7 @@ struct clpgpu_context {
   int tryPrimal = 0, numberTryPrimal = 0;
   // ClpDualRowSteepest::mode_ (src/ClpDualRowSteepest.hpp:118: the constructor's default is 3) and what stands for
   // factorization()->numberElements() in its mode 3 (src/ClpDualRowSteepest.cpp:262): 0 = entries of the basic structural columns (the
-  // count of an LU without fill; what the oracle computes too; the default), 1 (what the clpGpuDual adapter sets) = what the factorization on the device holds in
+  // count of an LU without fill; what the oracle computes too; the default), 1 = what the factorization on the device holds in
   // CoinFactorization's terms: in LU mode front L + U + the dense tail + the frozen slack part; under the explicit inverse -- nuclei
   // below lu_min_k, which triangularize or nearly so -- the entries an LU of that nucleus holds, i.e. the same count as 0 (k^2, the
   // inverse's own storage, would send a 224-column nucleus of a 50 000-row LP past ratio 1 where CoinFactorization's LU of it holds

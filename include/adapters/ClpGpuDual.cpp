@@ -33,11 +33,14 @@ int clpGpuDual(ClpSimplex &model, int device, bool scaling)
     model.columnLower(), model.columnUpper(), cost.data(), model.rowLower(), model.rowUpper());
   clpgpu_set_option(ctx, "pivot_rule", model.dualRowPivot()->type() == 2 ? 1 : 0);
   // ClpDualRowSteepest::mode_ decides how much of the infeasibility list one pivotRow() call scans (src/ClpDualRowSteepest.cpp:258-278:
-  // 0 / 1 everything, 2 max(2000, number / 8), 3 -- the constructor's default -- sized by factorization()->numberElements() / rows);
-  // behind this entry point the factorization is the engine's own, so its own count is what that ratio is taken from
+  // 0 / 1 everything, 2 max(2000, number / 8), 3 -- the constructor's default -- sized by factorization()->numberElements() / rows).
+  // What stands for numberElements() in mode 3 is the engine's option steepest_elements: 0 (its default, left alone here) = the entries of
+  // the basic structural columns, 1 = the entries its own factorization holds (what CoinGpuFactorization::numberElements() answers at
+  // the plug-in level).  1 is the closer stand-in for CoinFactorization's count once the basis has a dense tail, but it means full scans
+  // there, and those were measured to stall LPs of the bench's family (102 000 pivots against 2.7 M unfinished on a
+  // 7 000-row instance); a caller who wants it sets clpgpu_set_option(ctx, "steepest_elements", 1) before clpgpu_dual.
   if (const ClpDualRowSteepest *steepest = dynamic_cast< const ClpDualRowSteepest * >(model.dualRowPivot()))
     clpgpu_set_option(ctx, "steepest_mode", steepest->mode());
-  clpgpu_set_option(ctx, "steepest_elements", 1);
   clpgpu_set_option(ctx, "max_iterations", model.maximumIterations());
   clpgpu_set_option(ctx, "max_pivots", model.factorization()->maximumPivots());
   clpgpu_set_option(ctx, "dual_bound", model.dualBound());

@@ -139,7 +139,7 @@ def test_full_size_first_500_pivots_in_the_default_mode(gpu_cls):
 def test_mature_basis_scans_fully_with_the_factorization_s_own_count(gpu_cls):
     """Mode 3 sizes the scan by factorization()->numberElements() / rows (:262-276).  From config 4's mature basis the engine is in LU mode
     and its factorization holds front L + U + the dense tail + the frozen slack part: ~32 M entries, ratio ~640 > 80 -> every call scans the
-    whole list, as real Clp with an LU of that basis would (option steepest_elements 1: what the clpGpuDual adapter sets).  With the
+    whole list, as real Clp with an LU of that basis would (option steepest_elements 1: what the plug-in's numberElements() answers).  With the
     shared model (0, the default on both sides -- DESIGN section 2 for why: the 537 448 entries of the 10 514 basic structural columns, ratio 10.7) the same basis scans
     number x ratio / 80 = 13 % of the rows per call."""
     import os
